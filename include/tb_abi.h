@@ -1,0 +1,221 @@
+/* tb_abi.h -- POD layouts shared by the C++ host, the CPU oracle and the HIP kernels.
+ *
+ * Every struct here is byte-compatible with the CPU/GPU-shared struct of the reference that it
+ * replaces (cited per struct); sizes are static_assert'ed the way the reference does it
+ * (/root/reference/D3D12RaytracingFallback/src/RayTracingHlslCompat.h:175,188,385,398 and
+ * /root/reference/TracerBoy/SharedHitGroup.h:13-23).
+ */
+#ifndef TB_ABI_H
+#define TB_ABI_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+#define TB_STATIC_ASSERT(c, m) static_assert(c, m)
+#else
+#define TB_STATIC_ASSERT(c, m) _Static_assert(c, m)
+#endif
+
+typedef struct TbFloat2 { float x, y; } TbFloat2;
+typedef struct TbFloat3 { float x, y, z; } TbFloat3;
+typedef struct TbFloat4 { float x, y, z, w; } TbFloat4;
+
+/* ---- per-dispatch constants: SharedShaderStructs.h:33-72 (37 dwords, root constants) -------- */
+typedef struct TbPerFrameConstants {
+    TbFloat3 CameraPosition;   float Time;
+    TbFloat3 CameraLookAt;     uint32_t InvalidateHistory;
+    TbFloat3 CameraUp;         uint32_t OutputMode;
+    TbFloat3 CameraRight;      float DOFFocusDistance;
+    float DOFApertureWidth;    uint32_t EnableNormalMaps;  float FocalDistance;  float FireflyClampValue;
+    uint32_t GlobalFrameCount; float MinConvergence;       uint32_t LightCount;  uint32_t UseBlueNoise;
+    uint32_t IsRealTime;       uint32_t EnableNextEventEstimation;
+    uint32_t EnableSamplingImportanceResampling;           float FilterWidth;
+    uint32_t FilterType;       uint32_t SelectedPixelX;    uint32_t SelectedPixelY;  float MaxZ;
+    TbFloat2 FixedPixelOffset; float DebugValue;           float DebugValue2;
+    uint32_t MaxBounces;
+} TbPerFrameConstants;
+TB_STATIC_ASSERT(sizeof(TbPerFrameConstants) == 148, "PerFrameConstants is 37 dwords");
+
+/* SharedShaderStructs.h:74-83 (C++ side: float4x3 = three float4) */
+typedef struct TbConfigConstants {
+    float CameraLensHeight;
+    uint32_t FlipTextureUVs;
+    TbFloat2 Padding;
+    TbFloat4 EnvMapTransformVx, EnvMapTransformVy, EnvMapTransformVz;
+    TbFloat3 EnvironmentMapColorScale;
+} TbConfigConstants;
+TB_STATIC_ASSERT(sizeof(TbConfigConstants) == 76, "ConfigConstants is 19 dwords");
+
+/* SharedShaderStructs.h:85-90; stride `VertexStride 8` floats (SharedHitGroup.h:11) */
+typedef struct TbVertex { TbFloat3 Normal; TbFloat2 UV; TbFloat3 Tangent; } TbVertex;
+TB_STATIC_ASSERT(sizeof(TbVertex) == 32, "Vertex is 8 floats");
+
+/* SharedShaderStructs.h:92-111 */
+typedef struct TbLight {
+    uint32_t LightType;
+    TbFloat3 LightColor;
+    float SurfaceArea;
+    TbFloat3 P0, P1, P2;
+    TbFloat3 N0, N1, N2;
+    TbFloat3 Direction;
+} TbLight;
+TB_STATIC_ASSERT(sizeof(TbLight) == 104, "Light is 26 dwords");
+#define TB_LIGHT_TYPE_AREA 0u
+#define TB_LIGHT_TYPE_DIRECTIONAL 1u
+
+/* SharedShaderStructs.h:116-124 */
+#define TB_MAT_DEFAULT 0x0
+#define TB_MAT_METALLIC 0x1
+#define TB_MAT_SUBSURFACE_SCATTER 0x2
+#define TB_MAT_NO_SPECULAR 0x4
+#define TB_MAT_MIX 0x8
+#define TB_MAT_LIGHT 0x10
+#define TB_MAT_NO_ALPHA 0x20
+#define TB_MAT_HAIR 0x40
+#define TB_MAT_SINGLE_SIDED 0x80
+
+/* SharedShaderStructs.h:126-139 */
+#define TB_OUTPUT_TYPE_LIT 0u
+#define TB_OUTPUT_TYPE_ALBEDO 1u
+#define TB_OUTPUT_TYPE_NORMAL 2u
+#define TB_OUTPUT_TYPE_DEPTH 3u
+#define TB_OUTPUT_TYPE_HEATMAP 9u
+#define TB_FILTER_TYPE_BOX 0u
+#define TB_FILTER_TYPE_TRIANGLE 1u
+#define TB_FILTER_TYPE_GAUSSIAN 2u
+
+/* SharedShaderStructs.h:141-161 */
+typedef struct TbMaterial {
+    TbFloat3 albedo;       uint32_t albedoIndex;
+    uint32_t alphaIndex;   uint32_t normalMapIndex;  uint32_t emissiveIndex;  uint32_t specularMapIndex;
+    float IOR;             TbFloat3 absorption;
+    float roughness;       TbFloat3 scattering;
+    TbFloat3 emissive;     int32_t Flags;
+    float SpecularCoef;
+} TbMaterial;
+TB_STATIC_ASSERT(sizeof(TbMaterial) == 84, "Material is 21 dwords");
+#define TB_INVALID_TEXTURE 0xffffffffu
+
+/* SharedShaderStructs.h:163-190 */
+#define TB_TEXTURE_TYPE_IMAGE 0u
+#define TB_TEXTURE_TYPE_CHECKER 1u
+#define TB_TEXTURE_TYPE_SCALE 2u
+#define TB_TEXTURE_FLAG_NEEDS_GAMMA 0x1u
+typedef struct TbTextureData {
+    uint32_t TextureType, DescriptorHeapIndex, TextureFlags, Padding;
+    TbFloat3 CheckerColor1; float UScale;
+    TbFloat3 CheckerColor2; float VScale;
+    uint32_t TextureIndex1; TbFloat3 ScaleColor1;
+    uint32_t TextureIndex2; TbFloat3 ScaleColor2;
+} TbTextureData;
+TB_STATIC_ASSERT(sizeof(TbTextureData) == 80, "TextureData is 20 dwords");
+
+/* SharedHitGroup.h:13-23 / TracerBoy.cpp:31-41.  ShaderIdentifier is dead weight in the software
+ * path but is kept so the record stride and field offsets match the reference's shader table.
+ * NOTE: the reference struct is 32 + 6*4 + 16 = 72 bytes (SURVEY.md says 64; the source wins). */
+typedef struct TbHitGroupRecord {
+    uint32_t ShaderIdentifier[8];
+    uint32_t MaterialIndex;
+    uint32_t VertexBufferIndex;
+    uint32_t VertexBufferOffset; /* bytes */
+    uint32_t IndexBufferIndex;
+    uint32_t IndexBufferOffset;  /* bytes */
+    uint32_t GeometryIndex;
+    uint32_t Padding[4];
+} TbHitGroupRecord;
+TB_STATIC_ASSERT(sizeof(TbHitGroupRecord) == 72, "HitGroupShaderRecord is 72 B");
+
+/* ---- BVH "layout A": the fallback layer's bottom-level memory image ----------------------------
+ * RayTracingHlslCompat.h:344-401, 122-191; readers RayTracingHelper.hlsli:152-227.
+ *   [0,16)  TbBvhHeader   [16, 16+32*(2N-1)) TbAabbNode (internal 0..N-2, leaf N-1+k)
+ *   then N x TbPrimitive (sorted order), then N x TbPrimitiveMeta. */
+typedef struct TbBvhHeader {
+    uint32_t offsetToBoxes, offsetToVertices, offsetToPrimitiveMetaData, totalSize;
+} TbBvhHeader;
+TB_STATIC_ASSERT(sizeof(TbBvhHeader) == 16, "BVHOffsets is 16 B");
+
+#define TB_BVH_LEAF_FLAG 0x80000000u
+#define TB_BVH_PROCEDURAL_FLAG 0x40000000u
+#define TB_BVH_INDEX_MASK 0x00ffffffu
+typedef struct TbAabbNode {
+    float center[3];
+    uint32_t flags;          /* leaf: LEAF_FLAG | leafIndex ; inner: left child index (24 bits) */
+    float halfDim[3];
+    uint32_t rightNodeIndex; /* leaf: number of triangles (always 1) */
+} TbAabbNode;
+TB_STATIC_ASSERT(sizeof(TbAabbNode) == 32, "AABBNode is 32 B");
+
+#pragma pack(push, 1)
+typedef struct TbPrimitive {
+    uint32_t PrimitiveType; /* 1 = triangle */
+    float v0[3], v1[3], v2[3];
+} TbPrimitive;
+#pragma pack(pop)
+TB_STATIC_ASSERT(sizeof(TbPrimitive) == 40, "Primitive is 40 B");
+TB_STATIC_ASSERT(offsetof(TbPrimitive, v0) == 4, "triangle data at +4");
+
+typedef struct TbPrimitiveMeta {
+    uint32_t GeometryContributionToHitGroupIndex, PrimitiveIndex, GeometryFlags;
+} TbPrimitiveMeta;
+TB_STATIC_ASSERT(sizeof(TbPrimitiveMeta) == 12, "PrimitiveMetaData is 12 B");
+
+/* ---- BVH "layout B": what the HIP kernels fetch -------------------------------------------------
+ * Same tree, same boxes (centre/half-extent, so the slab test arithmetic is bit-identical), but one
+ * 64-B node carries BOTH children's boxes and child references, so an inner-node visit is one
+ * aligned 64-B fetch instead of the reference's 32 B (parent flags) + 2 x 32 B (children), and a
+ * leaf reference goes straight to a 48-B triangle record (36 B vertices + 12 B metadata) without
+ * re-reading a node.  Child reference: bit 31 = leaf, low bits = inner-node index or sorted
+ * triangle index. */
+typedef struct TbNodeB {
+    float lc[3]; uint32_t left;   /* left child box centre, left child ref  */
+    float lh[3]; uint32_t right;  /* left child half-extent, right child ref */
+    float rc[3]; uint32_t pad0;
+    float rh[3]; uint32_t pad1;
+} TbNodeB;
+TB_STATIC_ASSERT(sizeof(TbNodeB) == 64, "layout-B node is 64 B");
+
+typedef struct TbTriB {
+    float v0[3]; uint32_t geometryIndex;
+    float v1[3]; uint32_t primitiveIndex;
+    float v2[3]; uint32_t geometryFlags;
+} TbTriB;
+TB_STATIC_ASSERT(sizeof(TbTriB) == 48, "layout-B triangle is 48 B");
+
+/* ---- image / environment textures ---------------------------------------------------------- */
+typedef struct TbImageDesc {
+    uint32_t width, height;
+    uint64_t texelOffset; /* in TbFloat4 texels from the start of the texel pool */
+} TbImageDesc;
+
+/* ---- the kernel seam: everything one path-tracing dispatch reads ------------------------------
+ * Replaces the shader binding contract SharedRaytracing.h:3-53 / root signature
+ * TracerBoy.cpp:568-664 (t1 raw BVH, t11 hit-group table, t21 materials, t22 texture data,
+ * t23 lights, t20 env map, t14/t15 blue noise, space2/3 index+vertex buffers).
+ * Pointers are host pointers for the oracle and device pointers for the HIP kernels. */
+typedef struct TbSceneView {
+    const uint8_t* bvh;                  /* layout A image */
+    uint32_t bvhBytes;
+    uint32_t numTriangles;
+    const TbHitGroupRecord* hitGroups;   uint32_t numHitGroups;
+    const uint32_t* indexBuffer;         uint32_t numIndices;
+    const float* vertexBuffer;           uint32_t numVertexFloats;
+    const TbMaterial* materials;         uint32_t numMaterials;
+    const TbTextureData* textureData;    uint32_t numTextureData;
+    const TbLight* lights;               uint32_t numLights;
+    const TbImageDesc* images;           uint32_t numImages;
+    const TbFloat4* texelPool;
+    const TbFloat4* envMap;              uint32_t envWidth, envHeight; /* null => black 1x1 */
+    const TbFloat4* blueNoise0;          /* 256x256, null unless UseBlueNoise */
+    const TbFloat4* blueNoise1;
+    TbConfigConstants config;
+} TbSceneView;
+
+/* Per-sample traversal counters with the reference's semantics
+ * (TraverseFunction.hlsli:46-47,662,751) plus the event counts DESIGN.md's byte model needs. */
+typedef struct TbRayStats {
+    uint64_t boxesTested, trianglesTested;
+    uint64_t hitsShaded, materialFetches, lightSamples, samples, rays;
+} TbRayStats;
+
+#endif /* TB_ABI_H */

@@ -1,0 +1,179 @@
+/* tracerboy_hip.h -- C ABI of libtracerboy_hip.so, the MI355X-native drop-in for TracerBoy's
+ * path-tracing hot path.
+ *
+ * The reference has no FFI; the path sits behind the host seam `class TracerBoy`
+ * (/root/reference/TracerBoy/TracerBoy.h:158-398, called from D3D12App.cpp:52,76,213,222,235,240).
+ * Each entry point below names the member it replaces.  Conventions: plain pointers and sizes,
+ * no C++/torch/D3D types; return 0 on success or a negative TB_E_* code (never abort -- the
+ * reference's VERIFY -> assert(false), pch.h:45-47, becomes an error code + tb_last_error());
+ * the caller owns every host buffer it passes; a context is not thread-safe and drives ONE GPU
+ * (one process per GPU; multi-GPU = one context per rank, see tb_set_tile_assignment).
+ * There is no CPU fallback: without a HIP device tb_create fails with TB_E_NO_DEVICE.
+ */
+#ifndef TRACERBOY_HIP_H
+#define TRACERBOY_HIP_H
+
+#include <stdint.h>
+#include "tb_abi.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TB_OK 0
+#define TB_E_INVALID -1      /* bad argument / call order */
+#define TB_E_NO_DEVICE -2    /* no usable HIP device */
+#define TB_E_IO -3           /* scene / texture file could not be read */
+#define TB_E_PARSE -4        /* scene parse error (std::runtime_error in the reference parser) */
+#define TB_E_DEVICE -5       /* HIP runtime error */
+#define TB_E_UNSUPPORTED -6  /* feature the reference also rejects (HANDLE_FAILURE paths) */
+#define TB_E_NO_SCENE -7
+
+typedef struct tb_context tb_context;
+
+/* TracerBoy::Camera, TracerBoy.h:59-67 */
+typedef struct tb_camera {
+    float Position[3], LookAt[3], Right[3], Up[3];
+    float LensHeight, FocalDistance;
+} tb_camera;
+
+/* TracerBoy::OutputSettings flattened (TracerBoy.h:212-288); only members that reach
+ * PerFrameConstants (TracerBoy.cpp:2808-2851) are carried.  Defaults: TracerBoy.h:290-360. */
+typedef struct tb_output_settings {
+    uint32_t OutputType;              /* m_OutputType -> OutputMode (TB_OUTPUT_TYPE_*)        */
+    uint32_t EnableNormalMaps;        /* m_EnableNormalMaps                                   */
+    uint32_t RenderModeRealTime;      /* m_renderMode == RealTime -> IsRealTime               */
+    float DebugValue, DebugValue2;    /* m_debugSettings                                      */
+    float DOFFocalDistance, ApertureWidth; uint32_t FilterType; float FilterWidth; /* m_cameraSettings */
+    float FireflyClampValue, MaxZ;    /* m_denoiserSettings                                   */
+    float ConvergencePercentage;      /* m_performanceSettings...                             */
+    uint32_t EnableNextEventEstimation, EnableSamplingImportanceResampling, EnableBlueNoise;
+    int32_t MaxBounces;
+    int32_t SampleTarget;
+} tb_output_settings;
+
+/* TracerBoy::ReadbackStats (TracerBoy.h:362-368) + the heatmap counters summed over the render */
+typedef struct tb_readback_stats {
+    uint32_t ActiveWaves, ActivePixels;
+    float SelectedPixelDistance;
+    int32_t SelectedMaterialID;
+    TbRayStats rays; /* zero unless tb_set_option("count_rays", 1) */
+} tb_readback_stats;
+
+typedef struct tb_scene_info {
+    uint32_t numTriangles, numVertices, numMaterials, numLights, numGeometries, numTextures;
+    uint32_t bvhBytesA, bvhNodesB, bvhMaxDepth;
+    uint32_t filmWidth, filmHeight;
+    float sceneMin[3], sceneMax[3];
+} tb_scene_info;
+
+/* AOV selectors for tb_read_aov (registers u2..u7 of SharedRaytracing.h:13-20) */
+#define TB_AOV_NORMALS 2
+#define TB_AOV_WORLD_POSITION0 3
+#define TB_AOV_WORLD_POSITION1 4
+#define TB_AOV_CUSTOM 5
+#define TB_AOV_DEPTH 6
+#define TB_AOV_EMISSIVE 7
+
+/* <-> TracerBoy::TracerBoy(ID3D12CommandQueue*)  (TracerBoy.cpp:507-960).  device_id = HIP ordinal. */
+int tb_create(tb_context** out, int device_id);
+void tb_destroy(tb_context* ctx);
+const char* tb_last_error(tb_context* ctx); /* ctx may be NULL: error of a failed tb_create */
+
+/* <-> TracerBoy::LoadScene (TracerBoy.cpp:1065-2161), blocking: parse, convert, build BVH, upload. */
+int tb_load_scene(tb_context* ctx, const char* pbrt_path);
+/* Deterministic procedural stand-ins for the scenes the reference tree lacks:
+ * kind 0 = "dragon-class" displaced closed surface + ground (all matte, white environment),
+ * kind 1 = "van-class" matte + mirror + glass + plastic mix, kind 2 = "bistro-class" (>=32 materials). */
+int tb_load_procedural(tb_context* ctx, int kind, uint32_t target_triangles, uint32_t seed);
+int tb_scene_info_get(tb_context* ctx, tb_scene_info* out);
+
+/* <-> TracerBoy::GetDefaultOutputSettings (TracerBoy.h:290-360) */
+void tb_default_output_settings(tb_output_settings* out);
+/* <-> m_camera / TracerBoy::Update (camera part, TracerBoy.cpp:3386-3500); set invalidates history */
+int tb_get_camera(tb_context* ctx, tb_camera* out);
+int tb_set_camera(tb_context* ctx, const tb_camera* cam);
+/* <-> TracerBoy::GetMaterial / SetMaterial / IsMaterialIDValid */
+int tb_get_material(tb_context* ctx, int id, TbMaterial* out);
+int tb_set_material(tb_context* ctx, int id, const TbMaterial* in);
+int tb_material_count(tb_context* ctx);
+
+/* <-> TracerBoy::Render x n_frames (TracerBoy.cpp:2677-2946): frames GlobalFrameCount =
+ * samples_rendered .. +n_frames-1 are traced and accumulated into the context's accumulation
+ * buffers.  time_seed <-> PerFrameConstants.Time (the reference uses wall-clock milliseconds,
+ * TracerBoy.cpp:2817; callers pass 0 for reproducible output).  A change of width/height or of a
+ * history-relevant setting restarts accumulation like UpdateOutputSettings (TracerBoy.cpp:2163-2185).
+ * Synchronous: returns after the GPU has finished. */
+int tb_render(tb_context* ctx, uint32_t width, uint32_t height, uint32_t n_frames,
+              const tb_output_settings* settings, float time_seed);
+/* Same, but returns after enqueueing on the context's stream; pair with tb_sync. */
+int tb_render_async(tb_context* ctx, uint32_t width, uint32_t height, uint32_t n_frames,
+                    const tb_output_settings* settings, float time_seed);
+int tb_sync(tb_context* ctx);
+
+/* <-> OutputTexture u0 / JitteredOutputTexture u1 (sum rgb*w, sum w), W*H*4 floats each, row 0 = top */
+int tb_read_accum(tb_context* ctx, float* rgba_sum, float* jittered_or_null);
+int tb_read_aov(tb_context* ctx, int which, void* dst);
+/* device pointers of the accumulation buffers (for zero-copy consumers, e.g. an RCCL gather) */
+int tb_accum_device_ptr(tb_context* ctx, void** output, void** jittered);
+/* <-> ReadbackStats copy (TracerBoy.cpp:2946, D3D12App.cpp:195-201) */
+int tb_read_stats(tb_context* ctx, tb_readback_stats* out);
+/* <-> InvalidateHistory (TracerBoy.cpp:3569-3575) / GetNumberOfSamplesSinceLastInvalidate */
+void tb_invalidate_history(tb_context* ctx);
+uint32_t tb_samples_rendered(tb_context* ctx);
+/* <-> TracerBoy::SelectPixel */
+int tb_select_pixel(tb_context* ctx, uint32_t x, uint32_t y);
+
+/* Multi-GPU tile split: the frame is cut into tile_w x tile_h tiles numbered row-major;
+ * this context renders tile t iff t % world == rank.  Pixels of other tiles are left untouched.
+ * With world == 1 (default) the whole frame is rendered. */
+int tb_set_tile_assignment(tb_context* ctx, uint32_t rank, uint32_t world, uint32_t tile_w, uint32_t tile_h);
+/* Compact per-rank buffer: the owned tiles' pixels in tile order (tile-major, then row-major inside
+ * the tile), RGBA32F.  count = number of pixels written; buffer must hold tb_owned_pixels(). */
+uint64_t tb_owned_pixels(tb_context* ctx, uint32_t width, uint32_t height);
+int tb_pack_owned_device(tb_context* ctx, void* device_dst);   /* device-to-device pack on the context stream */
+int tb_unpack_gathered_host(uint32_t width, uint32_t height, uint32_t world, uint32_t tile_w, uint32_t tile_h,
+                            const float* const* per_rank_packed, float* full_rgba);
+
+/* Tunables / instrumentation: "pipeline" (0 = per-pixel megakernel, 1 = wavefront queues),
+ * "count_rays" (0/1), "bvh_builder" (0 = LBVH as the reference, 1 = binned SAH), "flatten_instances". */
+int tb_set_option(tb_context* ctx, const char* name, int64_t value);
+int64_t tb_get_option(tb_context* ctx, const char* name);
+
+/* The kernel seam, exported so the checker can run on exactly the arrays the kernels read:
+ * fills `view` with HOST pointers owned by the context (valid until the next load/destroy). */
+int tb_host_scene_view(tb_context* ctx, TbSceneView* view);
+/* PerFrameConstants the next tb_render would push for frame `frame` (TracerBoy.cpp:2808-2851). */
+int tb_make_frame_constants(tb_context* ctx, uint32_t width, uint32_t height, uint32_t frame,
+                            const tb_output_settings* settings, float time_seed, TbPerFrameConstants* out);
+/* Last timed render: GPU milliseconds measured with HIP events on the context's stream. */
+float tb_last_render_ms(tb_context* ctx);
+/* Closest-hit query through the device BVH (IntersectWithMaxDistance, RayGenCommon.h:365-414): n rays,
+ * host arrays; out_t = -1 on miss. Used by the parity tests of the traversal kernel. */
+int tb_trace_closest(tb_context* ctx, uint32_t n, const float* origins, const float* dirs, float* out_t,
+                     int32_t* out_material, float* out_bary, uint32_t* out_prim, uint32_t* out_geom,
+                     float* out_normal, float* out_uv, uint32_t* out_boxes, uint32_t* out_tris);
+/* Device-side evaluation of tb_math.h (fn codes as oracle tbo_math) for host/device bit-equality tests. */
+int tb_device_math(tb_context* ctx, int fn, uint32_t n, const float* a, const float* b, float* out);
+
+/* ---- host-only half of LoadScene (no device needed) ------------------------------------------------
+ * The same parse / convert / BVH-build code tb_load_scene runs, exposed separately so that the
+ * scene conversion and the BVH can be inspected and checked on machines without a GPU.  Nothing here
+ * renders. */
+typedef struct tb_host_scene tb_host_scene;
+int tb_host_scene_load(const char* pbrt_path, int bvh_builder, int flatten_instances, tb_host_scene** out, char* err, uint32_t err_len);
+int tb_host_scene_procedural(int kind, uint32_t target_triangles, uint32_t seed, int bvh_builder, tb_host_scene** out, char* err, uint32_t err_len);
+void tb_host_scene_free(tb_host_scene* s);
+int tb_host_scene_view_get(tb_host_scene* s, TbSceneView* view);          /* pointers owned by s */
+int tb_host_scene_camera(tb_host_scene* s, tb_camera* cam);
+int tb_host_scene_info(tb_host_scene* s, tb_scene_info* info);
+int tb_host_scene_frame_constants(tb_host_scene* s, const tb_output_settings* settings, uint32_t frame, float time_seed, TbPerFrameConstants* out);
+/* layout-B arrays (what the kernels fetch) and the per-triangle builder inputs */
+int tb_host_scene_layout_b(tb_host_scene* s, const TbNodeB** nodes, uint32_t* num_nodes, const TbTriB** tris, uint32_t* num_tris, uint32_t* root_ref);
+int tb_host_scene_triangles(tb_host_scene* s, const float** positions, uint32_t* num_vertices, const uint32_t** tri_vertex_index,
+                            const uint32_t** tri_geometry, const uint32_t** tri_primitive, const uint32_t** tri_flags, uint32_t* num_triangles);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRACERBOY_HIP_H */

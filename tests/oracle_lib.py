@@ -1,0 +1,123 @@
+"""ctypes access to oracle/liboracle.so -- the CPU checker.  Imported by tests/, smoke() and
+bench.py's cpu_baseline leg only (see oracle/tb_oracle.h)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from tracerboy_amd import _ctypes_abi as abi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB = os.path.join(ORACLE_DIR, "liboracle.so")
+_lib = None
+
+
+class TboAovs(C.Structure):
+    _fields_ = [("normals", C.c_void_p), ("worldPosition0", C.c_void_p), ("worldPosition1", C.c_void_p), ("customOutput", C.c_void_p),
+                ("depth", C.c_void_p), ("emissive", C.c_void_p)]
+
+
+def build():
+    subprocess.run(["make", "-s", "-C", ORACLE_DIR], check=True)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB):
+            build()
+        L = C.CDLL(LIB)
+        vp = C.c_void_p
+        L.tbo_render.restype = C.c_int
+        L.tbo_render.argtypes = [C.POINTER(abi.TbSceneView), C.POINTER(abi.TbPerFrameConstants), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                 C.c_uint32, C.c_uint32, vp, vp, C.POINTER(TboAovs), C.POINTER(abi.TbRayStats), C.c_int]
+        L.tbo_sample_pixel.restype = None
+        L.tbo_sample_pixel.argtypes = [C.POINTER(abi.TbSceneView), C.POINTER(abi.TbPerFrameConstants), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                       C.POINTER(C.c_float * 4), C.POINTER(C.c_float), C.POINTER(abi.TbRayStats)]
+        L.tbo_trace_closest.restype = None
+        L.tbo_trace_closest.argtypes = [C.POINTER(abi.TbSceneView), C.c_uint32] + [vp] * 11
+        L.tbo_hash13.restype = C.c_float
+        L.tbo_hash13.argtypes = [C.c_float] * 3
+        L.tbo_rand_stream.restype = None
+        L.tbo_rand_stream.argtypes = [C.c_float, C.c_float, C.c_uint32, vp]
+        L.tbo_math.restype = C.c_float
+        L.tbo_math.argtypes = [C.c_int, C.c_float, C.c_float]
+        L.tbo_camera_ray.restype = None
+        L.tbo_camera_ray.argtypes = [C.POINTER(abi.TbPerFrameConstants), C.c_float, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_float, C.c_float,
+                                     C.POINTER(C.c_float * 3), C.POINTER(C.c_float * 3)]
+        L.tbo_build_lbvh.restype = C.c_int64
+        L.tbo_build_lbvh.argtypes = [vp, vp, vp, vp, vp, C.c_uint32, vp, C.c_uint64]
+        L.tbo_validate_bvh.restype = C.c_int
+        L.tbo_validate_bvh.argtypes = [vp, C.c_uint32, vp, vp, C.c_uint32, C.POINTER(C.c_uint32)]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def render(view, pf, width, height, frames, first_frame=0, y0=0, y1=None, threads=1, jittered=False, aovs=False, stats=False, out=None, jit=None):
+    """Oracle render of rows [y0,y1): returns dict(output[,jittered][,aovs][,stats])."""
+    y1 = height if y1 is None else y1
+    if out is None:
+        out = np.zeros((height, width, 4), np.float32)
+    if jittered and jit is None:
+        jit = np.zeros((height, width, 4), np.float32)
+    av = None
+    res = {}
+    if aovs:
+        res["normals"] = np.zeros((height, width, 4), np.float32); res["worldpos0"] = np.zeros((height, width, 4), np.float32)
+        res["worldpos1"] = np.zeros((height, width, 4), np.float32); res["custom"] = np.zeros((height, width, 4), np.float32)
+        res["depth"] = np.zeros((height, width), np.float32); res["emissive"] = np.zeros((height, width, 4), np.float32)
+        av = TboAovs(res["normals"].ctypes.data, res["worldpos0"].ctypes.data, res["worldpos1"].ctypes.data, res["custom"].ctypes.data,
+                     res["depth"].ctypes.data, res["emissive"].ctypes.data)
+    st = abi.TbRayStats() if stats else None
+    rc = lib().tbo_render(C.byref(view), C.byref(pf), width, height, y0, y1, first_frame, frames, _p(out), _p(jit) if jittered else None,
+                          C.byref(av) if av is not None else None, C.byref(st) if st is not None else None, threads)
+    assert rc == 0, rc
+    res["output"] = out
+    if jittered:
+        res["jittered"] = jit
+    if stats:
+        res["stats"] = st
+    return res
+
+
+def trace_closest(view, origins, dirs):
+    o = np.ascontiguousarray(origins, np.float32); d = np.ascontiguousarray(dirs, np.float32)
+    n = o.shape[0]
+    r = dict(t=np.empty(n, np.float32), material=np.empty(n, np.int32), bary=np.empty((n, 2), np.float32), prim=np.empty(n, np.uint32),
+             geom=np.empty(n, np.uint32), normal=np.empty((n, 3), np.float32), uv=np.empty((n, 2), np.float32),
+             boxes=np.empty(n, np.uint32), tris=np.empty(n, np.uint32))
+    lib().tbo_trace_closest(C.byref(view), n, _p(o), _p(d), _p(r["t"]), _p(r["material"]), _p(r["bary"]), _p(r["prim"]), _p(r["geom"]),
+                            _p(r["normal"]), _p(r["uv"]), _p(r["boxes"]), _p(r["tris"]))
+    return r
+
+
+def build_lbvh(tri):
+    n = tri["tri_geometry"].shape[0]
+    cap = 16 + 32 * (2 * n - 1) + 52 * n
+    out = np.zeros(cap, np.uint8)
+    pos = np.ascontiguousarray(tri["positions"], np.float32); tvi = np.ascontiguousarray(tri["tri_vertex_index"], np.uint32)
+    g = np.ascontiguousarray(tri["tri_geometry"], np.uint32); p = np.ascontiguousarray(tri["tri_primitive"], np.uint32); f = np.ascontiguousarray(tri["tri_flags"], np.uint32)
+    got = lib().tbo_build_lbvh(_p(pos), _p(tvi), _p(g), _p(p), _p(f), n, _p(out), cap)
+    assert got == cap, got
+    return out
+
+
+def validate_bvh(bvh, tri):
+    pos = np.ascontiguousarray(tri["positions"], np.float32); tvi = np.ascontiguousarray(tri["tri_vertex_index"], np.uint32)
+    depth = C.c_uint32()
+    b = np.ascontiguousarray(bvh, np.uint8)
+    rc = lib().tbo_validate_bvh(_p(b), b.size, _p(pos), _p(tvi), tvi.shape[0], C.byref(depth))
+    return rc, depth.value
+
+
+def math_fn(fn, a, b=None):
+    a = np.asarray(a, np.float32).ravel()
+    b = np.zeros_like(a) if b is None else np.asarray(b, np.float32).ravel()
+    L = lib()
+    return np.array([L.tbo_math(fn, float(x), float(y)) for x, y in zip(a, b)], np.float32)

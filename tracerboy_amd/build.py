@@ -1,0 +1,81 @@
+"""Build libtracerboy_hip.so (hipcc, gfx950) in-tree.
+
+    python -m tracerboy_amd.build [--force]
+
+Every translation unit is compiled with -ffp-contract=off: the fp32 arithmetic contract of
+include/tb_math.h (bit-identical results on host and device) depends on it.  Kernel variants are
+separate TUs so they compile in parallel.
+"""
+import concurrent.futures as cf
+import hashlib
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(ROOT)
+CSRC = os.path.join(ROOT, "csrc")
+OBJ = os.path.join(ROOT, "_build")
+LIB = os.path.join(ROOT, "libtracerboy_hip.so")
+CLI = os.path.join(ROOT, "tracerboy-hip")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = "gfx950"
+
+COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function",
+          "-Wno-unused-variable", "-Wno-unused-but-set-variable", "-I" + os.path.join(REPO, "include")]
+DEVICE = ["--offload-arch=" + ARCH, "-fgpu-flush-denormals-to-zero=false"] if False else ["--offload-arch=" + ARCH]
+
+HOST_SRCS = ["host/pbrt_loader.cpp", "host/host_scene.cpp", "host/images.cpp", "host/bvh_build.cpp", "host/procedural.cpp", "host/context.cpp"]
+KERNEL_SRCS = ["kernels/pt_kernels.hip", "kernels/pt_variant_matte.hip", "kernels/pt_variant_env.hip", "kernels/pt_variant_surf.hip",
+               "kernels/pt_variant_vol.hip", "kernels/pt_variant_full.hip"]
+
+
+def _deps_digest():
+    h = hashlib.sha1()
+    for base in (CSRC, os.path.join(REPO, "include")):
+        for dp, _, fs in sorted(os.walk(base)):
+            for f in sorted(fs):
+                if f.endswith((".h", ".hpp", ".inc", ".cpp", ".hip")):
+                    with open(os.path.join(dp, f), "rb") as fh:
+                        h.update(f.encode()); h.update(fh.read())
+    h.update(" ".join(COMMON + DEVICE).encode())
+    return h.hexdigest()
+
+
+def _compile(src):
+    obj = os.path.join(OBJ, src.replace("/", "_") + ".o")
+    cmd = [HIPCC] + COMMON + (DEVICE if src.endswith(".hip") else ["-x", "hip", "--offload-arch=" + ARCH]) + ["-c", os.path.join(CSRC, src), "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("compile failed: %s\n%s\n%s" % (" ".join(cmd), r.stdout, r.stderr))
+    return obj
+
+
+def build(force=False, verbose=True):
+    os.makedirs(OBJ, exist_ok=True)
+    stamp = os.path.join(OBJ, "stamp")
+    digest = _deps_digest()
+    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == digest:
+        return LIB
+    srcs = HOST_SRCS + KERNEL_SRCS
+    with cf.ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(_compile, srcs))
+    cmd = [HIPCC, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB] + objs
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+    cli_src = os.path.join(CSRC, "host", "cli.cpp")
+    if os.path.exists(cli_src):
+        cmd = [HIPCC] + COMMON + ["-x", "hip", "--offload-arch=" + ARCH, cli_src, "-o", CLI, "-L" + ROOT, "-ltracerboy_hip", "-Wl,-rpath,$ORIGIN"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("cli build failed:\n%s\n%s" % (r.stdout, r.stderr))
+    with open(stamp, "w") as f:
+        f.write(digest)
+    if verbose:
+        print("built", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,250 @@
+/* bvh_build.cpp -- host BVH2 construction for the HIP traversal kernels.
+ *
+ * builder 0 (default, "LBVH"): the tree the reference's fallback layer would hand to
+ *   SoftwareRayTraceCS minus its treelet pass -- 30-bit Morton codes (y,x,z interleave,
+ *   /root/reference/D3D12RaytracingFallback/src/CalculateMortonCodesBindings.h:116-149), sort,
+ *   Karras-2012 hierarchy (BuildBVHSplits.hlsli:33-131), bottom-up fit with one triangle per leaf,
+ *   the 0.001 thin-box padding (RayTracingHelper.hlsli:251-263) and "smaller subtree on the left"
+ *   (ComputeAABBs.hlsli:152-156).  Checked bit-for-bit against oracle/bvh_ref.cpp.
+ * builder 1 ("SAH"): top-down 32-bin surface-area-heuristic build in the spirit of the reference's
+ *   unused CpuBVH2Builder.cpp:249-516; same node numbering (inner 0..N-2, leaf N-1+k), same box
+ *   arithmetic, so both layouts and the traversal code are shared.
+ * Both emit layout A (the fallback layer's memory image, used by the CPU checker and exported through
+ * tb_host_scene_view) and layout B (what the kernels fetch, tb_abi.h).
+ */
+#include "host_scene.h"
+#include "../../../include/tb_vec.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cstring>
+#include <stdexcept>
+#include <thread>
+
+namespace tbhost {
+
+namespace {
+
+struct Tree {
+    uint32_t N = 0;
+    std::vector<uint32_t> order;       /* sorted position k -> input triangle */
+    std::vector<uint32_t> left, right; /* children of inner node i (node ids; leaf k = N-1+k) */
+};
+
+inline tb3 P(const HostScene& s, uint32_t tri, int k) { const float* p = &s.positions[3ull * s.triVertexIndex[3ull * tri + k]]; return tb3_make(p[0], p[1], p[2]); }
+
+template <class F> void parallelFor(size_t n, F f)
+{
+    unsigned hw = std::thread::hardware_concurrency(); if (hw == 0) hw = 1;
+    size_t nt = n < 65536 ? 1 : std::min<size_t>(hw, 16);
+    if (nt == 1) { f((size_t)0, n); return; }
+    std::vector<std::thread> th; size_t chunk = (n + nt - 1) / nt;
+    for (size_t t = 0; t < nt; t++) { size_t a = t * chunk, b = std::min(n, a + chunk); if (a < b) th.emplace_back([=]() { f(a, b); }); }
+    for (auto& t : th) t.join();
+}
+
+inline uint32_t expand10(uint32_t v) { v &= 0x3ff; v = (v | (v << 16)) & 0x030000FF; v = (v | (v << 8)) & 0x0300F00F; v = (v | (v << 4)) & 0x030C30C3; v = (v | (v << 2)) & 0x09249249; return v; }
+
+void buildLbvh(const HostScene& s, Tree& t)
+{
+    const uint32_t N = t.N;
+    tb3 smin = tb3_splat(3.402823466e+38f), smax = tb3_splat(-3.402823466e+38f);
+    for (uint32_t i = 0; i < N; i++) for (int k = 0; k < 3; k++) { tb3 v = P(s, i, k); smin = tb3_min(v, smin); smax = tb3_max(v, smax); }
+    tb3 dim = tb3_max(smax - smin, tb3_splat(0.00001f));
+    std::vector<uint64_t> keys(N);
+    parallelFor(N, [&](size_t a, size_t b) {
+        for (size_t i = a; i < b; i++) {
+            tb3 c = (P(s, (uint32_t)i, 0) + P(s, (uint32_t)i, 1) + P(s, (uint32_t)i, 2)) / 3.0f;
+            tb3 u = (c - smin) / dim;
+            float ax = tb_min(tb_max(u.x * 1024.0f, 0.0f), 1023.0f), ay = tb_min(tb_max(u.y * 1024.0f, 0.0f), 1023.0f), az = tb_min(tb_max(u.z * 1024.0f, 0.0f), 1023.0f);
+            /* axis 0 <- y, axis 1 <- x, axis 2 <- z: bit (3*b + axis) */
+            uint32_t code = expand10((uint32_t)ay) | (expand10((uint32_t)ax) << 1) | (expand10((uint32_t)az) << 2);
+            keys[i] = ((uint64_t)code << 32) | (uint64_t)i;
+        }
+    });
+    std::sort(keys.begin(), keys.end()); /* ties broken by triangle index: the build's definition */
+    t.order.resize(N);
+    std::vector<uint32_t> codes(N);
+    for (uint32_t i = 0; i < N; i++) { t.order[i] = (uint32_t)keys[i]; codes[i] = (uint32_t)(keys[i] >> 32); }
+    if (N < 2) return;
+    t.left.resize(N - 1); t.right.resize(N - 1);
+    auto delta = [&](int64_t a, int64_t b) -> int {
+        if (b < 0 || b >= (int64_t)N) return -1;
+        uint32_t x = codes[(size_t)a] ^ codes[(size_t)b];
+        if (x) return __builtin_clz(x);
+        uint32_t y = (uint32_t)a ^ (uint32_t)b;
+        return (y ? __builtin_clz(y) : 32) + 31;
+    };
+    parallelFor(N - 1, [&](size_t a, size_t b) {
+        for (int64_t i = (int64_t)a; i < (int64_t)b; i++) {
+            int d = delta(i, i + 1) - delta(i, i - 1); d = (d > 0) - (d < 0);
+            int dmin = delta(i, i - d);
+            int64_t lmax = 2; while (delta(i, i + lmax * d) > dmin) lmax *= 4;
+            int64_t l = 0; for (int64_t st = lmax / 2; st > 0; st /= 2) if (delta(i, i + (l + st) * d) > dmin) l += st;
+            int64_t j = i + l * d, first = std::min(i, j), last = std::max(i, j);
+            int dn = delta(first, last);
+            int64_t split = first, step = last - first;
+            do { step = (step + 1) >> 1; int64_t ns = split + step; if (ns < last && delta(first, ns) > dn) split = ns; } while (step > 1);
+            t.left[(size_t)i] = (split == first) ? (N - 1) + (uint32_t)split : (uint32_t)split;
+            t.right[(size_t)i] = (split + 1 == last) ? (N - 1) + (uint32_t)split + 1 : (uint32_t)split + 1;
+        }
+    });
+}
+
+/* ---- binned SAH ---------------------------------------------------------------------------- */
+struct Bounds { tb3 mn, mx; };
+inline Bounds emptyB() { Bounds b; b.mn = tb3_splat(3.402823466e+38f); b.mx = tb3_splat(-3.402823466e+38f); return b; }
+inline void grow(Bounds& b, tb3 p) { b.mn = tb3_min(b.mn, p); b.mx = tb3_max(b.mx, p); }
+inline void grow(Bounds& b, const Bounds& o) { b.mn = tb3_min(b.mn, o.mn); b.mx = tb3_max(b.mx, o.mx); }
+inline float area(const Bounds& b) { tb3 d = b.mx - b.mn; if (d.x < 0 || d.y < 0 || d.z < 0) return 0.0f; return 2.0f * (d.x * d.y + d.y * d.z + d.z * d.x); }
+
+void buildSah(const HostScene& s, Tree& t)
+{
+    const uint32_t N = t.N;
+    std::vector<Bounds> tb(N); std::vector<tb3> cen(N);
+    for (uint32_t i = 0; i < N; i++) { Bounds b = emptyB(); for (int k = 0; k < 3; k++) grow(b, P(s, i, k)); tb[i] = b; cen[i] = (b.mn + b.mx) * 0.5f; }
+    std::vector<uint32_t> ids(N); for (uint32_t i = 0; i < N; i++) ids[i] = i;
+    t.order.clear(); t.order.reserve(N);
+    if (N >= 2) { t.left.assign(N - 1, 0); t.right.assign(N - 1, 0); }
+    struct Job { uint32_t begin, end, node; };
+    std::vector<Job> stack;
+    /* inner nodes are numbered in the order they are created; leaves take their number from the
+     * position of their triangle in the final left-to-right order, which a depth-first emission gives */
+    uint32_t nextInner = 0;
+    struct Pending { uint32_t begin, end; uint32_t parent; int side; };
+    std::vector<Pending> todo; todo.push_back({0, N, 0xffffffffu, 0});
+    std::vector<uint32_t> leafOfRange; /* unused */
+    /* depth-first, left before right, so that leaf numbers increase left to right */
+    while (!todo.empty()) {
+        Pending p = todo.back(); todo.pop_back();
+        uint32_t count = p.end - p.begin, me;
+        if (count == 1) {
+            me = (N - 1) + (uint32_t)t.order.size();
+            t.order.push_back(ids[p.begin]);
+        } else {
+            me = nextInner++;
+            Bounds cb = emptyB(); for (uint32_t i = p.begin; i < p.end; i++) grow(cb, cen[ids[i]]);
+            tb3 ext = cb.mx - cb.mn;
+            int axis = (ext.x >= ext.y && ext.x >= ext.z) ? 0 : (ext.y >= ext.z ? 1 : 2);
+            uint32_t mid = p.begin + count / 2;
+            float e = tb3_get(ext, axis);
+            bool split = false;
+            if (e > 0.0f && count > 2) {
+                const int B = 32; Bounds bb[B]; uint32_t bc[B];
+                float bestCost = 3.402823466e+38f; int bestAxis = -1, bestBin = -1;
+                for (int ax = 0; ax < 3; ax++) {
+                    float ea = tb3_get(ext, ax); if (!(ea > 0.0f)) continue;
+                    for (int i = 0; i < B; i++) { bb[i] = emptyB(); bc[i] = 0; }
+                    float k0 = tb3_get(cb.mn, ax), k1 = (float)B * (1.0f - 1e-6f) / ea;
+                    for (uint32_t i = p.begin; i < p.end; i++) { int b = (int)((tb3_get(cen[ids[i]], ax) - k0) * k1); b = b < 0 ? 0 : (b >= B ? B - 1 : b); grow(bb[b], tb[ids[i]]); bc[b]++; }
+                    float ra[B]; Bounds acc = emptyB(); uint32_t rc[B]; uint32_t c = 0;
+                    for (int i = B - 1; i > 0; i--) { grow(acc, bb[i]); c += bc[i]; ra[i] = area(acc); rc[i] = c; }
+                    acc = emptyB(); c = 0;
+                    for (int i = 0; i < B - 1; i++) { grow(acc, bb[i]); c += bc[i]; if (c == 0 || rc[i + 1] == 0) continue; float cost = area(acc) * (float)c + ra[i + 1] * (float)rc[i + 1]; if (cost < bestCost) { bestCost = cost; bestAxis = ax; bestBin = i; } }
+                }
+                if (bestAxis >= 0) {
+                    float ea = tb3_get(ext, bestAxis), k0 = tb3_get(cb.mn, bestAxis), k1 = (float)B * (1.0f - 1e-6f) / ea;
+                    auto it = std::stable_partition(ids.begin() + p.begin, ids.begin() + p.end, [&](uint32_t id) { int b = (int)((tb3_get(cen[id], bestAxis) - k0) * k1); b = b < 0 ? 0 : (b >= B ? B - 1 : b); return b <= bestBin; });
+                    mid = (uint32_t)(it - ids.begin());
+                    split = mid > p.begin && mid < p.end;
+                }
+            }
+            if (!split) { /* median along the widest axis (also the fallback for coincident centroids) */
+                mid = p.begin + count / 2;
+                std::stable_sort(ids.begin() + p.begin, ids.begin() + p.end, [&](uint32_t a, uint32_t b) { return tb3_get(cen[a], axis) < tb3_get(cen[b], axis); });
+            }
+            /* push right first so the left subtree is emitted first */
+            todo.push_back({mid, p.end, me, 1});
+            todo.push_back({p.begin, mid, me, 0});
+        }
+        if (p.parent != 0xffffffffu) { if (p.side == 0) t.left[p.parent] = me; else t.right[p.parent] = me; }
+    }
+    (void)stack; (void)leafOfRange;
+}
+
+} // namespace
+
+void BuildBvh(HostScene& s, int builder)
+{
+    const uint64_t N64 = s.triGeometry.size();
+    if (N64 == 0) throw std::runtime_error("BuildBvh: no triangles");
+    if (N64 > 0x00ffffffull) throw std::runtime_error("BuildBvh: more than 2^24-1 triangles does not fit the 24-bit node indices of the reference layout");
+    Tree t; t.N = (uint32_t)N64;
+    const uint32_t N = t.N;
+    if (builder == 1) buildSah(s, t); else buildLbvh(s, t);
+
+    const uint64_t numNodes = 2ull * N - 1;
+    const uint64_t offBoxes = 16, offPrims = offBoxes + 32 * numNodes, offMeta = offPrims + 40ull * N, total = offMeta + 12ull * N;
+    if (total > 0xffffffffull) throw std::runtime_error("BuildBvh: BVH image exceeds 4 GiB");
+    s.bvhA.assign((size_t)total, 0);
+    TbBvhHeader hdr = {(uint32_t)offBoxes, (uint32_t)offPrims, (uint32_t)offMeta, (uint32_t)total};
+    memcpy(s.bvhA.data(), &hdr, 16);
+    TbAabbNode* nodes = (TbAabbNode*)(s.bvhA.data() + offBoxes);
+    uint8_t* prims = s.bvhA.data() + offPrims;
+    TbPrimitiveMeta* meta = (TbPrimitiveMeta*)(s.bvhA.data() + offMeta);
+    s.trisB.resize(N);
+    for (uint32_t k = 0; k < N; k++) {
+        uint32_t tri = t.order[k];
+        TbPrimitive p; p.PrimitiveType = 1;
+        TbTriB tbv;
+        for (int v = 0; v < 3; v++) {
+            tb3 q = P(s, tri, v);
+            float* d = v == 0 ? p.v0 : (v == 1 ? p.v1 : p.v2); d[0] = q.x; d[1] = q.y; d[2] = q.z;
+            float* e = v == 0 ? tbv.v0 : (v == 1 ? tbv.v1 : tbv.v2); e[0] = q.x; e[1] = q.y; e[2] = q.z;
+        }
+        memcpy(prims + 40ull * k, &p, 40);
+        meta[k].GeometryContributionToHitGroupIndex = s.triGeometry[tri];
+        meta[k].PrimitiveIndex = s.triPrimitive[tri];
+        meta[k].GeometryFlags = s.triFlags[tri];
+        tbv.geometryIndex = s.triGeometry[tri]; tbv.primitiveIndex = s.triPrimitive[tri]; tbv.geometryFlags = s.triFlags[tri];
+        s.trisB[k] = tbv;
+    }
+    /* fit boxes bottom-up: visit order = reverse of a pre-order walk */
+    std::vector<uint32_t> walk; walk.reserve((size_t)numNodes);
+    std::vector<uint32_t> depth((size_t)numNodes, 0);
+    { std::vector<uint32_t> st; st.push_back(0); depth[0] = 1; uint32_t maxD = 1;
+      while (!st.empty()) { uint32_t x = st.back(); st.pop_back(); walk.push_back(x);
+          if (N > 1 && x < N - 1) { uint32_t l = t.left[x], r = t.right[x]; depth[l] = depth[r] = depth[x] + 1; if (depth[l] > maxD) maxD = depth[l]; st.push_back(l); st.push_back(r); } }
+      s.bvhMaxDepth = maxD; }
+    std::vector<uint32_t> count((size_t)numNodes, 0);
+    auto center = [&](uint32_t i) { return tb3_make(nodes[i].center[0], nodes[i].center[1], nodes[i].center[2]); };
+    auto half = [&](uint32_t i) { return tb3_make(nodes[i].halfDim[0], nodes[i].halfDim[1], nodes[i].halfDim[2]); };
+    auto put = [&](uint32_t i, tb3 mn, tb3 mx, uint32_t fx, uint32_t fy) {
+        tb3 c = (mn + mx) * 0.5f, h = mx - c;
+        nodes[i].center[0] = c.x; nodes[i].center[1] = c.y; nodes[i].center[2] = c.z; nodes[i].flags = fx;
+        nodes[i].halfDim[0] = h.x; nodes[i].halfDim[1] = h.y; nodes[i].halfDim[2] = h.z; nodes[i].rightNodeIndex = fy;
+    };
+    for (size_t w = walk.size(); w-- > 0;) {
+        uint32_t x = walk[w];
+        if (x >= N - 1) {
+            uint32_t k = x - (N - 1);
+            const TbTriB& q = s.trisB[k];
+            tb3 v0 = tb3_make(q.v0[0], q.v0[1], q.v0[2]), v1 = tb3_make(q.v1[0], q.v1[1], q.v1[2]), v2 = tb3_make(q.v2[0], q.v2[1], q.v2[2]);
+            tb3 mn = tb3_min(tb3_min(v0, v1), v2), mx = tb3_max(tb3_max(v0, v1), v2);
+            mn = tb3_min(mn, mx - tb3_splat(0.001f));
+            put(x, mn, mx, k | TB_BVH_LEAF_FLAG, 1);
+            count[x] = 1;
+        } else {
+            uint32_t l = t.left[x], r = t.right[x];
+            if (count[l] > count[r]) std::swap(l, r);
+            tb3 mn = tb3_min(center(l) - half(l), center(r) - half(r));
+            tb3 mx = tb3_max(center(l) + half(l), center(r) + half(r));
+            put(x, mn, mx, l & TB_BVH_INDEX_MASK, r);
+            count[x] = count[l] + count[r];
+        }
+    }
+    /* layout B */
+    auto ref = [&](uint32_t node) -> uint32_t { return node >= N - 1 ? (TB_BVH_LEAF_FLAG | (node - (N - 1))) : node; };
+    s.nodesB.assign(N > 1 ? N - 1 : 1, TbNodeB{});
+    for (uint32_t i = 0; i + 1 < N; i++) {
+        uint32_t l = nodes[i].flags & TB_BVH_INDEX_MASK, r = nodes[i].rightNodeIndex;
+        TbNodeB nb; memset(&nb, 0, sizeof nb);
+        memcpy(nb.lc, nodes[l].center, 12); memcpy(nb.lh, nodes[l].halfDim, 12);
+        memcpy(nb.rc, nodes[r].center, 12); memcpy(nb.rh, nodes[r].halfDim, 12);
+        nb.left = ref(l); nb.right = ref(r);
+        s.nodesB[i] = nb;
+    }
+    s.rootRefB = ref(0);
+}
+
+} // namespace tbhost

@@ -1,0 +1,645 @@
+/* context.cpp -- implementation of the C ABI (include/tracerboy_hip.h) on top of the host scene
+ * code and the HIP kernels.  tb_context plays the role of `class TracerBoy`
+ * (/root/reference/TracerBoy/TracerBoy.h:158-398): it owns every device resource, the accumulation
+ * surfaces (OutputTexture / JitteredOutputTexture) and the sample counter (m_SamplesRendered).
+ * There is no CPU rendering path in this library: every entry point that produces pixels or hits
+ * launches a HIP kernel, and tb_create fails when no HIP device is usable.
+ */
+#include "host_scene.h"
+#include "../kernels/pt_launch.h"
+#include "../kernels/pt_device_features.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+using namespace tbhost;
+
+extern "C" {
+typedef hipError_t (*pt_variant_fn)(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, uint32_t, uint32_t, uint32_t, uint32_t,
+                                    const TbTileMap*, int, int);
+hipError_t pt_launch_persistent_matte(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, uint32_t, uint32_t, uint32_t, uint32_t, const TbTileMap*, int, int);
+hipError_t pt_launch_persistent_env(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, uint32_t, uint32_t, uint32_t, uint32_t, const TbTileMap*, int, int);
+hipError_t pt_launch_persistent_surf(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, uint32_t, uint32_t, uint32_t, uint32_t, const TbTileMap*, int, int);
+hipError_t pt_launch_persistent_vol(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, uint32_t, uint32_t, uint32_t, uint32_t, const TbTileMap*, int, int);
+hipError_t pt_launch_persistent_full(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, uint32_t, uint32_t, uint32_t, uint32_t, const TbTileMap*, int, int);
+}
+
+namespace {
+
+std::string g_createError;
+
+struct Variant { uint32_t features; pt_variant_fn fn; const char* name; };
+const Variant kVariants[] = {
+    {0u, pt_launch_persistent_matte, "matte"},
+    {PT_FEAT_ENV, pt_launch_persistent_env, "env"},
+    {PT_FEAT_ENV | PT_FEAT_SPECULAR | PT_FEAT_TEXTURES, pt_launch_persistent_surf, "surf"},
+    {PT_FEAT_ENV | PT_FEAT_SPECULAR | PT_FEAT_TEXTURES | PT_FEAT_SSS | PT_FEAT_MIX, pt_launch_persistent_vol, "vol"},
+    {PT_FEAT_ALL, pt_launch_persistent_full, "full"},
+};
+
+struct DevBuf {
+    void* p = nullptr; size_t bytes = 0;
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+};
+
+} // namespace
+
+struct tb_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::string err;
+    HostScene scene; bool hasScene = false;
+    tb_camera camera{};
+    std::vector<DevBuf> sceneBufs;
+    TbDeviceScene ds{};
+    uint32_t sceneFeatures = 0; bool sceneInLds = false;
+    /* surfaces */
+    uint32_t width = 0, height = 0;
+    DevBuf output, jittered, aov[8], stats, rayStats, packed;
+    uint32_t samplesRendered = 0;
+    tb_output_settings lastSettings{}; bool haveLastSettings = false;
+    float lastTime = 0.0f;
+    uint32_t selX = 0xffffffffu, selY = 0xffffffffu;
+    TbTileMap tiles{0, 1, 64, 64};
+    std::map<std::string, int64_t> options;
+    float lastMs = 0.0f;
+    std::string lastVariant;
+};
+
+namespace {
+
+#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
+
+int fail(tb_context* c, int code, const std::string& msg) { if (c) c->err = msg; else g_createError = msg; return code; }
+
+template <class F> int guarded(tb_context* c, F f)
+{
+    if (!c) return TB_E_INVALID;
+    try { (void)hipSetDevice(c->device); return f(); }
+    catch (const std::bad_alloc&) { return fail(c, TB_E_DEVICE, "out of host memory"); }
+    catch (const std::exception& e) {
+        std::string m = e.what();
+        int code = TB_E_PARSE;
+        if (m.find("hip") == 0 || m.find("HIP") != std::string::npos) code = TB_E_DEVICE;
+        else if (m.find("open") != std::string::npos || m.find("Couldn't") != std::string::npos) code = TB_E_IO;
+        else if (m.find("not supported") != std::string::npos || m.find("unsupported") != std::string::npos) code = TB_E_UNSUPPORTED;
+        return fail(c, code, m);
+    }
+}
+
+template <class T> const T* upload(tb_context* c, const std::vector<T>& v)
+{
+    DevBuf b;
+    b.bytes = v.size() * sizeof(T);
+    if (b.bytes == 0) return nullptr;
+    HIP_TRY(hipMalloc(&b.p, b.bytes));
+    c->sceneBufs.push_back(b);
+    HIP_TRY(hipMemcpyAsync(b.p, v.data(), b.bytes, hipMemcpyHostToDevice, c->stream));
+    return (const T*)b.p;
+}
+
+void ensure(DevBuf& b, size_t bytes)
+{
+    if (b.bytes == bytes && b.p) return;
+    b.release();
+    if (bytes == 0) return;
+    HIP_TRY(hipMalloc(&b.p, bytes));
+    b.bytes = bytes;
+}
+
+void releaseScene(tb_context* c)
+{
+    for (DevBuf& b : c->sceneBufs) b.release();
+    c->sceneBufs.clear();
+    memset(&c->ds, 0, sizeof c->ds);
+}
+
+uint32_t sceneFeatureMask(const HostScene& s)
+{
+    uint32_t f = 0;
+    if (!s.envMap.empty()) f |= PT_FEAT_ENV;
+    for (const TbMaterial& m : s.materials) {
+        if ((m.Flags & TB_MAT_NO_SPECULAR) == 0 && (m.Flags & TB_MAT_MIX) == 0) f |= PT_FEAT_SPECULAR;
+        if (m.albedoIndex != TB_INVALID_TEXTURE || m.emissiveIndex != TB_INVALID_TEXTURE || m.specularMapIndex != TB_INVALID_TEXTURE || m.normalMapIndex != TB_INVALID_TEXTURE) f |= PT_FEAT_TEXTURES | PT_FEAT_SPECULAR;
+        if (m.Flags & TB_MAT_SUBSURFACE_SCATTER) f |= PT_FEAT_SSS;
+        if (m.Flags & TB_MAT_MIX) f |= PT_FEAT_MIX;
+    }
+    for (const TbLight& l : s.lights) if (l.LightType != TB_LIGHT_TYPE_AREA) f |= PT_FEAT_EXT;
+    return f;
+}
+
+uint32_t settingsFeatureMask(const tb_context* c, const tb_output_settings& s, bool aov)
+{
+    bool ext = s.EnableBlueNoise || s.EnableSamplingImportanceResampling || s.DOFFocalDistance > 0.0f || s.FilterType != TB_FILTER_TYPE_BOX ||
+               s.FireflyClampValue != 0.0f || s.RenderModeRealTime || s.OutputType == TB_OUTPUT_TYPE_HEATMAP || aov ||
+               (c->selX != 0xffffffffu);
+    return ext ? PT_FEAT_EXT : 0u;
+}
+
+/* nodes in breadth-first order so the top of the tree is one contiguous prefix */
+void reorderNodesBfs(HostScene& s)
+{
+    const uint32_t n = (uint32_t)s.nodesB.size();
+    if (s.rootRefB & TB_BVH_LEAF_FLAG) return;
+    std::vector<uint32_t> order; order.reserve(n);
+    std::vector<uint32_t> newIndex(n, 0);
+    order.push_back(s.rootRefB);
+    for (size_t i = 0; i < order.size(); i++) {
+        const TbNodeB& nd = s.nodesB[order[i]];
+        if (!(nd.left & TB_BVH_LEAF_FLAG)) order.push_back(nd.left);
+        if (!(nd.right & TB_BVH_LEAF_FLAG)) order.push_back(nd.right);
+    }
+    for (uint32_t i = 0; i < (uint32_t)order.size(); i++) newIndex[order[i]] = i;
+    std::vector<TbNodeB> out(order.size());
+    for (uint32_t i = 0; i < (uint32_t)order.size(); i++) {
+        TbNodeB nd = s.nodesB[order[i]];
+        if (!(nd.left & TB_BVH_LEAF_FLAG)) nd.left = newIndex[nd.left];
+        if (!(nd.right & TB_BVH_LEAF_FLAG)) nd.right = newIndex[nd.right];
+        out[i] = nd;
+    }
+    s.nodesB.swap(out);
+    s.rootRefB = 0;
+}
+
+void finalizeScene(tb_context* c)
+{
+    HostScene& s = c->scene;
+    auto opt = [&](const char* k, int64_t d) { auto it = c->options.find(k); return it == c->options.end() ? d : it->second; };
+    BuildBvh(s, (int)opt("bvh_builder", 0));
+    reorderNodesBfs(s);
+    c->camera = s.camera;
+    releaseScene(c);
+    TbDeviceScene& d = c->ds;
+    d.nodes = upload(c, s.nodesB); d.tris = upload(c, s.trisB);
+    d.rootRef = s.rootRefB; d.numNodes = (uint32_t)s.nodesB.size(); d.numTris = (uint32_t)s.trisB.size();
+    { const TbAabbNode* root = (const TbAabbNode*)(s.bvhA.data() + 16); memcpy(d.rootCenter, root->center, 12); memcpy(d.rootHalf, root->halfDim, 12); }
+    d.hitGroups = upload(c, s.hitGroups); d.numHitGroups = (uint32_t)s.hitGroups.size();
+    d.indexBuffer = upload(c, s.indexBuffer); d.numIndices = (uint32_t)s.indexBuffer.size();
+    d.vertexBuffer = upload(c, s.vertexBuffer); d.numVertexFloats = (uint32_t)s.vertexBuffer.size();
+    d.materials = upload(c, s.materials); d.numMaterials = (uint32_t)s.materials.size();
+    d.textureData = upload(c, s.textureData); d.numTextureData = (uint32_t)s.textureData.size();
+    d.lights = upload(c, s.lights); d.numLights = (uint32_t)s.lights.size();
+    d.images = upload(c, s.images); d.numImages = (uint32_t)s.images.size();
+    d.texelPool = upload(c, s.texelPool);
+    d.envMap = upload(c, s.envMap); d.envWidth = s.envWidth; d.envHeight = s.envHeight;
+    d.blueNoise0 = upload(c, s.blueNoise0); d.blueNoise1 = upload(c, s.blueNoise1);
+    d.config = s.config;
+    d.stackDepth = s.bvhMaxDepth + 2;
+    /* whole-scene LDS image */
+    {
+        std::vector<uint8_t> blob;
+        auto put = [&](const void* p, size_t bytes) { while (blob.size() % 16) blob.push_back(0); uint32_t off = (uint32_t)blob.size(); const uint8_t* b = (const uint8_t*)p; blob.insert(blob.end(), b, b + bytes); return off; };
+        d.offNodes = put(s.nodesB.data(), s.nodesB.size() * sizeof(TbNodeB));
+        d.offTris = put(s.trisB.data(), s.trisB.size() * sizeof(TbTriB));
+        d.offHitGroups = put(s.hitGroups.data(), s.hitGroups.size() * sizeof(TbHitGroupRecord));
+        d.offIndices = put(s.indexBuffer.data(), s.indexBuffer.size() * 4);
+        d.offVertices = put(s.vertexBuffer.data(), s.vertexBuffer.size() * 4);
+        d.offMaterials = put(s.materials.data(), s.materials.size() * sizeof(TbMaterial));
+        d.offLights = put(s.lights.data(), s.lights.size() * sizeof(TbLight));
+        while (blob.size() % 16) blob.push_back(0);
+        size_t budget = (size_t)opt("lds_scene_budget", 40 * 1024);
+        c->sceneInLds = blob.size() + (size_t)d.stackDepth * 256 * 4 <= budget && opt("scene_in_lds", 1) != 0;
+        if (c->sceneInLds) { d.ldsBlob = upload(c, blob); d.ldsBlobBytes = (uint32_t)blob.size(); }
+        else { d.ldsBlob = nullptr; d.ldsBlobBytes = 0; }
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->sceneFeatures = sceneFeatureMask(s);
+    c->hasScene = true;
+    c->samplesRendered = 0;
+}
+
+bool historyRelevantChange(const tb_output_settings& a, const tb_output_settings& b) /* TracerBoy.cpp:2163-2185 */
+{
+    return a.OutputType != b.OutputType || a.EnableNormalMaps != b.EnableNormalMaps || a.RenderModeRealTime != b.RenderModeRealTime ||
+           a.DOFFocalDistance != b.DOFFocalDistance || a.ApertureWidth != b.ApertureWidth || a.FilterType != b.FilterType || a.FilterWidth != b.FilterWidth ||
+           a.FireflyClampValue != b.FireflyClampValue || a.EnableNextEventEstimation != b.EnableNextEventEstimation ||
+           a.EnableSamplingImportanceResampling != b.EnableSamplingImportanceResampling || a.EnableBlueNoise != b.EnableBlueNoise || a.MaxBounces != b.MaxBounces ||
+           a.DebugValue != b.DebugValue || a.DebugValue2 != b.DebugValue2;
+}
+
+int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_output_settings* settings, float timeSeed, bool sync)
+{
+    if (!c->hasScene) return fail(c, TB_E_NO_SCENE, "tb_render: no scene loaded");
+    if (W == 0 || H == 0) return fail(c, TB_E_INVALID, "tb_render: zero-sized target");
+    tb_output_settings s; if (settings) s = *settings; else DefaultOutputSettings(s);
+    if (W != c->width || H != c->height) {
+        size_t bytes = (size_t)W * H * sizeof(TbFloat4);
+        ensure(c->output, bytes); ensure(c->jittered, bytes);
+        HIP_TRY(hipMemsetAsync(c->output.p, 0, bytes, c->stream)); HIP_TRY(hipMemsetAsync(c->jittered.p, 0, bytes, c->stream));
+        for (DevBuf& b : c->aov) b.release();
+        c->width = W; c->height = H; c->samplesRendered = 0;
+    }
+    if (c->haveLastSettings && (historyRelevantChange(s, c->lastSettings) || timeSeed != c->lastTime)) c->samplesRendered = 0;
+    c->lastSettings = s; c->haveLastSettings = true; c->lastTime = timeSeed;
+    if (n == 0) return TB_OK;
+    auto opt = [&](const char* k, int64_t d) { auto it = c->options.find(k); return it == c->options.end() ? d : it->second; };
+    const bool aov = opt("aov", 0) != 0, count = opt("count_rays", 0) != 0;
+    ensure(c->stats, 16);
+    if (c->samplesRendered == 0) HIP_TRY(hipMemsetAsync(c->stats.p, 0, 16, c->stream));
+    TbDeviceTargets tg; memset(&tg, 0, sizeof tg);
+    tg.output = (TbFloat4*)c->output.p; tg.jittered = (TbFloat4*)c->jittered.p; tg.stats = (uint32_t*)c->stats.p;
+    if (aov) {
+        size_t px = (size_t)W * H;
+        for (int i = 2; i <= 7; i++) { size_t bytes = px * (i == TB_AOV_DEPTH ? 4 : 16); if (c->aov[i].bytes != bytes) { ensure(c->aov[i], bytes); HIP_TRY(hipMemsetAsync(c->aov[i].p, 0, bytes, c->stream)); } }
+        tg.aovNormals = (TbFloat4*)c->aov[2].p; tg.aovWorldPos0 = (TbFloat4*)c->aov[3].p; tg.aovWorldPos1 = (TbFloat4*)c->aov[4].p;
+        tg.aovCustom = (TbFloat4*)c->aov[5].p; tg.aovDepth = (float*)c->aov[6].p; tg.aovEmissive = (TbFloat4*)c->aov[7].p;
+    }
+    if (count) { ensure(c->rayStats, 7 * 8); if (c->samplesRendered == 0) HIP_TRY(hipMemsetAsync(c->rayStats.p, 0, 56, c->stream)); tg.rayStats = (unsigned long long*)c->rayStats.p; }
+    TbPerFrameConstants pf;
+    MakeFrameConstants(c->scene, c->camera, s, c->samplesRendered, timeSeed, c->selX, c->selY, pf);
+    uint32_t need = c->sceneFeatures | settingsFeatureMask(c, s, aov);
+    if (count || opt("force_full_variant", 0)) need = PT_FEAT_ALL;
+    const Variant* v = nullptr;
+    for (const Variant& k : kVariants) if ((need & ~k.features) == 0) { v = &k; break; }
+    if (!v) v = &kVariants[4];
+    c->lastVariant = v->name;
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    HIP_TRY(v->fn(c->stream, &c->ds, &pf, &tg, W, H, c->samplesRendered, n, &c->tiles, c->sceneInLds ? 1 : 0, count ? 1 : 0));
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    c->samplesRendered += n;
+    if (sync) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipEventElapsedTime(&c->lastMs, c->ev0, c->ev1)); }
+    return TB_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int tb_create(tb_context** out, int device_id)
+{
+    if (!out) return TB_E_INVALID;
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return fail(nullptr, TB_E_NO_DEVICE, std::string("no HIP device available: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count is 0") + " (libtracerboy_hip has no CPU fallback)");
+    if (device_id < 0 || device_id >= n) return fail(nullptr, TB_E_INVALID, "tb_create: device id out of range");
+    tb_context* c = new tb_context();
+    c->device = device_id;
+    try {
+        HIP_TRY(hipSetDevice(device_id));
+        HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreate(&c->ev0)); HIP_TRY(hipEventCreate(&c->ev1));
+    } catch (const std::exception& ex) { g_createError = ex.what(); delete c; return TB_E_DEVICE; }
+    *out = c;
+    return TB_OK;
+}
+
+void tb_destroy(tb_context* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    releaseScene(c);
+    c->output.release(); c->jittered.release(); c->stats.release(); c->rayStats.release(); c->packed.release();
+    for (DevBuf& b : c->aov) b.release();
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* tb_last_error(tb_context* c) { return c ? c->err.c_str() : g_createError.c_str(); }
+
+int tb_load_scene(tb_context* c, const char* path)
+{
+    return guarded(c, [&]() {
+        if (!path) return fail(c, TB_E_INVALID, "tb_load_scene: null path");
+        std::shared_ptr<PbrtScene> ps = importPBRT(path);
+        ConvertOptions co; auto it = c->options.find("flatten_instances"); if (it != c->options.end()) co.flattenInstances = it->second != 0;
+        c->hasScene = false;
+        ConvertScene(*ps, c->scene, co);
+        finalizeScene(c);
+        return TB_OK;
+    });
+}
+
+int tb_load_procedural(tb_context* c, int kind, uint32_t targetTriangles, uint32_t seed)
+{
+    return guarded(c, [&]() {
+        c->hasScene = false;
+        MakeProceduralScene(c->scene, kind, targetTriangles, seed);
+        finalizeScene(c);
+        return TB_OK;
+    });
+}
+
+int tb_scene_info_get(tb_context* c, tb_scene_info* o)
+{
+    if (!c || !o) return TB_E_INVALID;
+    if (!c->hasScene) return fail(c, TB_E_NO_SCENE, "no scene loaded");
+    const HostScene& s = c->scene;
+    memset(o, 0, sizeof *o);
+    o->numTriangles = (uint32_t)s.triGeometry.size(); o->numVertices = (uint32_t)(s.positions.size() / 3); o->numMaterials = (uint32_t)s.materials.size();
+    o->numLights = (uint32_t)s.lights.size(); o->numGeometries = (uint32_t)s.hitGroups.size(); o->numTextures = (uint32_t)s.textureData.size();
+    o->bvhBytesA = (uint32_t)s.bvhA.size(); o->bvhNodesB = (uint32_t)s.nodesB.size(); o->bvhMaxDepth = s.bvhMaxDepth;
+    o->filmWidth = (uint32_t)s.filmWidth; o->filmHeight = (uint32_t)s.filmHeight;
+    memcpy(o->sceneMin, s.sceneMin, 12); memcpy(o->sceneMax, s.sceneMax, 12);
+    return TB_OK;
+}
+
+void tb_default_output_settings(tb_output_settings* o) { if (o) DefaultOutputSettings(*o); }
+
+int tb_get_camera(tb_context* c, tb_camera* o) { if (!c || !o) return TB_E_INVALID; if (!c->hasScene) return fail(c, TB_E_NO_SCENE, "no scene loaded"); *o = c->camera; return TB_OK; }
+int tb_set_camera(tb_context* c, const tb_camera* cam)
+{
+    if (!c || !cam) return TB_E_INVALID;
+    if (!c->hasScene) return fail(c, TB_E_NO_SCENE, "no scene loaded");
+    c->camera = *cam; c->ds.config.CameraLensHeight = cam->LensHeight; c->scene.config.CameraLensHeight = cam->LensHeight; c->samplesRendered = 0;
+    return TB_OK;
+}
+
+int tb_material_count(tb_context* c) { return (c && c->hasScene) ? (int)c->scene.materials.size() : 0; }
+int tb_get_material(tb_context* c, int id, TbMaterial* o)
+{
+    if (!c || !o) return TB_E_INVALID;
+    if (!c->hasScene || id < 0 || id >= (int)c->scene.materials.size()) return fail(c, TB_E_INVALID, "material id out of range");
+    *o = c->scene.materials[(size_t)id]; return TB_OK;
+}
+int tb_set_material(tb_context* c, int id, const TbMaterial* in)
+{
+    return guarded(c, [&]() {
+        if (!in || !c->hasScene || id < 0 || id >= (int)c->scene.materials.size()) return fail(c, TB_E_INVALID, "material id out of range");
+        c->scene.materials[(size_t)id] = *in;
+        HIP_TRY(hipMemcpy((void*)(c->ds.materials + id), in, sizeof *in, hipMemcpyHostToDevice));
+        if (c->sceneInLds) HIP_TRY(hipMemcpy((void*)(c->ds.ldsBlob + c->ds.offMaterials + sizeof(TbMaterial) * (size_t)id), in, sizeof *in, hipMemcpyHostToDevice));
+        c->sceneFeatures = sceneFeatureMask(c->scene);
+        c->samplesRendered = 0;
+        return TB_OK;
+    });
+}
+
+int tb_render(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_output_settings* s, float t) { return guarded(c, [&]() { return renderImpl(c, W, H, n, s, t, true); }); }
+int tb_render_async(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_output_settings* s, float t) { return guarded(c, [&]() { return renderImpl(c, W, H, n, s, t, false); }); }
+int tb_sync(tb_context* c)
+{
+    return guarded(c, [&]() { HIP_TRY(hipStreamSynchronize(c->stream)); (void)hipEventElapsedTime(&c->lastMs, c->ev0, c->ev1); return TB_OK; });
+}
+
+int tb_read_accum(tb_context* c, float* rgba, float* jit)
+{
+    return guarded(c, [&]() {
+        if (!c->output.p) return fail(c, TB_E_INVALID, "tb_read_accum: nothing rendered yet");
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (rgba) HIP_TRY(hipMemcpy(rgba, c->output.p, c->output.bytes, hipMemcpyDeviceToHost));
+        if (jit) HIP_TRY(hipMemcpy(jit, c->jittered.p, c->jittered.bytes, hipMemcpyDeviceToHost));
+        return TB_OK;
+    });
+}
+
+int tb_read_aov(tb_context* c, int which, void* dst)
+{
+    return guarded(c, [&]() {
+        if (which < 2 || which > 7 || !dst || !c->aov[which].p) return fail(c, TB_E_INVALID, "tb_read_aov: AOV not available (set option \"aov\" before rendering)");
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipMemcpy(dst, c->aov[which].p, c->aov[which].bytes, hipMemcpyDeviceToHost));
+        return TB_OK;
+    });
+}
+
+int tb_accum_device_ptr(tb_context* c, void** o, void** j) { if (!c) return TB_E_INVALID; if (o) *o = c->output.p; if (j) *j = c->jittered.p; return c->output.p ? TB_OK : TB_E_INVALID; }
+
+int tb_read_stats(tb_context* c, tb_readback_stats* o)
+{
+    return guarded(c, [&]() {
+        if (!o) return TB_E_INVALID;
+        memset(o, 0, sizeof *o);
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->stats.p) { uint32_t raw[4]; HIP_TRY(hipMemcpy(raw, c->stats.p, 16, hipMemcpyDeviceToHost)); o->ActiveWaves = raw[0]; o->ActivePixels = raw[1]; memcpy(&o->SelectedPixelDistance, &raw[2], 4); o->SelectedMaterialID = (int32_t)raw[3]; }
+        if (c->rayStats.p) { uint64_t r[7]; HIP_TRY(hipMemcpy(r, c->rayStats.p, 56, hipMemcpyDeviceToHost)); o->rays.boxesTested = r[0]; o->rays.trianglesTested = r[1]; o->rays.hitsShaded = r[2]; o->rays.materialFetches = r[3]; o->rays.lightSamples = r[4]; o->rays.samples = r[5]; o->rays.rays = r[6]; }
+        return TB_OK;
+    });
+}
+
+void tb_invalidate_history(tb_context* c) { if (c) c->samplesRendered = 0; }
+uint32_t tb_samples_rendered(tb_context* c) { return c ? c->samplesRendered : 0; }
+int tb_select_pixel(tb_context* c, uint32_t x, uint32_t y) { if (!c) return TB_E_INVALID; c->selX = x; c->selY = y; return TB_OK; }
+
+int tb_set_tile_assignment(tb_context* c, uint32_t rank, uint32_t world, uint32_t tw, uint32_t th)
+{
+    if (!c || world == 0 || rank >= world || tw == 0 || th == 0) return c ? fail(c, TB_E_INVALID, "tb_set_tile_assignment: bad arguments") : TB_E_INVALID;
+    c->tiles = TbTileMap{rank, world, tw, th}; c->samplesRendered = 0;
+    return TB_OK;
+}
+
+static uint32_t ownedTiles(uint32_t W, uint32_t H, const TbTileMap& t)
+{
+    uint32_t total = ((W + t.tileW - 1) / t.tileW) * ((H + t.tileH - 1) / t.tileH);
+    return total > t.rank ? (total - t.rank + t.world - 1) / t.world : 0;
+}
+
+uint64_t tb_owned_pixels(tb_context* c, uint32_t W, uint32_t H) { return c ? (uint64_t)ownedTiles(W, H, c->tiles) * c->tiles.tileW * c->tiles.tileH : 0; }
+
+int tb_pack_owned_device(tb_context* c, void* dst)
+{
+    return guarded(c, [&]() {
+        if (!dst || !c->output.p) return fail(c, TB_E_INVALID, "tb_pack_owned_device: nothing rendered / null destination");
+        HIP_TRY(pt_launch_pack_owned(c->stream, (const TbFloat4*)c->output.p, (TbFloat4*)dst, c->width, c->height, &c->tiles, ownedTiles(c->width, c->height, c->tiles)));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        return TB_OK;
+    });
+}
+
+int tb_unpack_gathered_host(uint32_t W, uint32_t H, uint32_t world, uint32_t tw, uint32_t th, const float* const* perRank, float* full)
+{
+    if (!perRank || !full || world == 0 || tw == 0 || th == 0) return TB_E_INVALID;
+    uint32_t tilesX = (W + tw - 1) / tw, tilesY = (H + th - 1) / th;
+    for (uint32_t t = 0; t < tilesX * tilesY; t++) {
+        uint32_t rank = t % world, local = t / world;
+        const float* src = perRank[rank] + (size_t)local * tw * th * 4;
+        uint32_t x0 = (t % tilesX) * tw, y0 = (t / tilesX) * th;
+        uint32_t w = (W - x0 < tw) ? W - x0 : tw, h = (H - y0 < th) ? H - y0 : th;
+        for (uint32_t y = 0; y < h; y++) memcpy(full + ((size_t)(y0 + y) * W + x0) * 4, src + (size_t)y * w * 4, (size_t)w * 16);
+    }
+    return TB_OK;
+}
+
+int tb_set_option(tb_context* c, const char* name, int64_t v)
+{
+    if (!c || !name) return TB_E_INVALID;
+    static const char* known[] = {"pipeline", "count_rays", "bvh_builder", "flatten_instances", "aov", "scene_in_lds", "lds_scene_budget", "force_full_variant"};
+    for (const char* k : known) if (!strcmp(k, name)) { c->options[name] = v; if (!strcmp(name, "count_rays") || !strcmp(name, "aov")) c->samplesRendered = 0; return TB_OK; }
+    return fail(c, TB_E_INVALID, std::string("unknown option '") + name + "'");
+}
+int64_t tb_get_option(tb_context* c, const char* name)
+{
+    if (!c || !name) return 0;
+    if (!strcmp(name, "scene_in_lds_active")) return c->sceneInLds ? 1 : 0;
+    if (!strcmp(name, "scene_features")) return c->sceneFeatures;
+    if (!strcmp(name, "last_variant")) { for (int i = 0; i < 5; i++) if (c->lastVariant == kVariants[i].name) return i; return -1; }
+    auto it = c->options.find(name); return it == c->options.end() ? 0 : it->second;
+}
+
+int tb_host_scene_view(tb_context* c, TbSceneView* v)
+{
+    if (!c || !v) return TB_E_INVALID;
+    if (!c->hasScene) return fail(c, TB_E_NO_SCENE, "no scene loaded");
+    const HostScene& s = c->scene;
+    memset(v, 0, sizeof *v);
+    v->bvh = s.bvhA.data(); v->bvhBytes = (uint32_t)s.bvhA.size(); v->numTriangles = (uint32_t)s.triGeometry.size();
+    v->hitGroups = s.hitGroups.data(); v->numHitGroups = (uint32_t)s.hitGroups.size();
+    v->indexBuffer = s.indexBuffer.data(); v->numIndices = (uint32_t)s.indexBuffer.size();
+    v->vertexBuffer = s.vertexBuffer.data(); v->numVertexFloats = (uint32_t)s.vertexBuffer.size();
+    v->materials = s.materials.data(); v->numMaterials = (uint32_t)s.materials.size();
+    v->textureData = s.textureData.empty() ? nullptr : s.textureData.data(); v->numTextureData = (uint32_t)s.textureData.size();
+    v->lights = s.lights.empty() ? nullptr : s.lights.data(); v->numLights = (uint32_t)s.lights.size();
+    v->images = s.images.empty() ? nullptr : s.images.data(); v->numImages = (uint32_t)s.images.size();
+    v->texelPool = s.texelPool.empty() ? nullptr : s.texelPool.data();
+    v->envMap = s.envMap.empty() ? nullptr : s.envMap.data(); v->envWidth = s.envWidth; v->envHeight = s.envHeight;
+    v->blueNoise0 = s.blueNoise0.empty() ? nullptr : s.blueNoise0.data(); v->blueNoise1 = s.blueNoise1.empty() ? nullptr : s.blueNoise1.data();
+    v->config = s.config;
+    return TB_OK;
+}
+
+int tb_make_frame_constants(tb_context* c, uint32_t, uint32_t, uint32_t frame, const tb_output_settings* settings, float t, TbPerFrameConstants* out)
+{
+    if (!c || !out) return TB_E_INVALID;
+    if (!c->hasScene) return fail(c, TB_E_NO_SCENE, "no scene loaded");
+    tb_output_settings s; if (settings) s = *settings; else DefaultOutputSettings(s);
+    MakeFrameConstants(c->scene, c->camera, s, frame, t, c->selX, c->selY, *out);
+    return TB_OK;
+}
+
+float tb_last_render_ms(tb_context* c) { return c ? c->lastMs : 0.0f; }
+
+int tb_trace_closest(tb_context* c, uint32_t n, const float* origins, const float* dirs, float* outT, int32_t* outMat, float* outBary, uint32_t* outPrim,
+                     uint32_t* outGeom, float* outNormal, float* outUV, uint32_t* outBoxes, uint32_t* outTris)
+{
+    return guarded(c, [&]() {
+        if (!c->hasScene) return fail(c, TB_E_NO_SCENE, "no scene loaded");
+        if (n == 0) return TB_OK;
+        if (!origins || !dirs || !outT) return fail(c, TB_E_INVALID, "tb_trace_closest: null array");
+        struct Tmp { DevBuf b; ~Tmp() { b.release(); } };
+        Tmp dO, dD, dT, dM, dB, dP, dG, dN, dU, dBx, dTr;
+        auto in = [&](Tmp& t, const void* h, size_t bytes) { ensure(t.b, bytes); HIP_TRY(hipMemcpy(t.b.p, h, bytes, hipMemcpyHostToDevice)); };
+        in(dO, origins, (size_t)n * 12); in(dD, dirs, (size_t)n * 12);
+        ensure(dT.b, (size_t)n * 4); ensure(dM.b, (size_t)n * 4); ensure(dB.b, (size_t)n * 8); ensure(dP.b, (size_t)n * 4); ensure(dG.b, (size_t)n * 4);
+        ensure(dN.b, (size_t)n * 12); ensure(dU.b, (size_t)n * 8); ensure(dBx.b, (size_t)n * 4); ensure(dTr.b, (size_t)n * 4);
+        HIP_TRY(pt_launch_trace_closest(c->stream, &c->ds, n, (const float*)dO.b.p, (const float*)dD.b.p, (float*)dT.b.p, (int*)dM.b.p, (float*)dB.b.p, (uint32_t*)dP.b.p,
+                                        (uint32_t*)dG.b.p, (float*)dN.b.p, (float*)dU.b.p, (uint32_t*)dBx.b.p, (uint32_t*)dTr.b.p));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        auto outc = [&](void* h, Tmp& t, size_t bytes) { if (h) HIP_TRY(hipMemcpy(h, t.b.p, bytes, hipMemcpyDeviceToHost)); };
+        outc(outT, dT, (size_t)n * 4); outc(outMat, dM, (size_t)n * 4); outc(outBary, dB, (size_t)n * 8); outc(outPrim, dP, (size_t)n * 4); outc(outGeom, dG, (size_t)n * 4);
+        outc(outNormal, dN, (size_t)n * 12); outc(outUV, dU, (size_t)n * 8); outc(outBoxes, dBx, (size_t)n * 4); outc(outTris, dTr, (size_t)n * 4);
+        return TB_OK;
+    });
+}
+
+int tb_device_math(tb_context* c, int fn, uint32_t n, const float* a, const float* b, float* out)
+{
+    return guarded(c, [&]() {
+        if (!a || !out) return fail(c, TB_E_INVALID, "tb_device_math: null array");
+        if (n == 0) return TB_OK;
+        DevBuf dA, dB, dO;
+        try {
+            ensure(dA, (size_t)n * 4); ensure(dO, (size_t)n * 4);
+            HIP_TRY(hipMemcpy(dA.p, a, (size_t)n * 4, hipMemcpyHostToDevice));
+            if (b) { ensure(dB, (size_t)n * 4); HIP_TRY(hipMemcpy(dB.p, b, (size_t)n * 4, hipMemcpyHostToDevice)); }
+            HIP_TRY(pt_launch_device_math(c->stream, fn, n, (const float*)dA.p, (const float*)dB.p, (float*)dO.p));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            HIP_TRY(hipMemcpy(out, dO.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+        } catch (...) { dA.release(); dB.release(); dO.release(); throw; }
+        dA.release(); dB.release(); dO.release();
+        return TB_OK;
+    });
+}
+
+
+/* ---- host-only scene API ---------------------------------------------------------------------- */
+struct tb_host_scene { HostScene scene; };
+
+static int hostFail(char* err, uint32_t n, int code, const std::string& m) { if (err && n) { strncpy(err, m.c_str(), n - 1); err[n - 1] = 0; } return code; }
+
+int tb_host_scene_load(const char* path, int builder, int flatten, tb_host_scene** out, char* err, uint32_t errLen)
+{
+    if (!path || !out) return TB_E_INVALID;
+    *out = nullptr;
+    try {
+        std::shared_ptr<PbrtScene> ps = importPBRT(path);
+        tb_host_scene* h = new tb_host_scene();
+        ConvertOptions co; co.flattenInstances = flatten != 0;
+        try { ConvertScene(*ps, h->scene, co); BuildBvh(h->scene, builder); } catch (...) { delete h; throw; }
+        *out = h; return TB_OK;
+    } catch (const std::exception& e) {
+        std::string m = e.what();
+        int code = (m.find("open") != std::string::npos || m.find("Couldn't") != std::string::npos) ? TB_E_IO : TB_E_PARSE;
+        if (m.find("not supported") != std::string::npos || m.find("unsupported") != std::string::npos) code = TB_E_UNSUPPORTED;
+        return hostFail(err, errLen, code, m);
+    }
+}
+
+int tb_host_scene_procedural(int kind, uint32_t tris, uint32_t seed, int builder, tb_host_scene** out, char* err, uint32_t errLen)
+{
+    if (!out) return TB_E_INVALID;
+    *out = nullptr;
+    try {
+        tb_host_scene* h = new tb_host_scene();
+        try { MakeProceduralScene(h->scene, kind, tris, seed); BuildBvh(h->scene, builder); } catch (...) { delete h; throw; }
+        *out = h; return TB_OK;
+    } catch (const std::exception& e) { return hostFail(err, errLen, TB_E_INVALID, e.what()); }
+}
+
+void tb_host_scene_free(tb_host_scene* s) { delete s; }
+
+static void fillView(const HostScene& s, TbSceneView* v)
+{
+    memset(v, 0, sizeof *v);
+    v->bvh = s.bvhA.data(); v->bvhBytes = (uint32_t)s.bvhA.size(); v->numTriangles = (uint32_t)s.triGeometry.size();
+    v->hitGroups = s.hitGroups.data(); v->numHitGroups = (uint32_t)s.hitGroups.size();
+    v->indexBuffer = s.indexBuffer.data(); v->numIndices = (uint32_t)s.indexBuffer.size();
+    v->vertexBuffer = s.vertexBuffer.data(); v->numVertexFloats = (uint32_t)s.vertexBuffer.size();
+    v->materials = s.materials.data(); v->numMaterials = (uint32_t)s.materials.size();
+    v->textureData = s.textureData.empty() ? nullptr : s.textureData.data(); v->numTextureData = (uint32_t)s.textureData.size();
+    v->lights = s.lights.empty() ? nullptr : s.lights.data(); v->numLights = (uint32_t)s.lights.size();
+    v->images = s.images.empty() ? nullptr : s.images.data(); v->numImages = (uint32_t)s.images.size();
+    v->texelPool = s.texelPool.empty() ? nullptr : s.texelPool.data();
+    v->envMap = s.envMap.empty() ? nullptr : s.envMap.data(); v->envWidth = s.envWidth; v->envHeight = s.envHeight;
+    v->blueNoise0 = s.blueNoise0.empty() ? nullptr : s.blueNoise0.data(); v->blueNoise1 = s.blueNoise1.empty() ? nullptr : s.blueNoise1.data();
+    v->config = s.config;
+}
+
+int tb_host_scene_view_get(tb_host_scene* s, TbSceneView* v) { if (!s || !v) return TB_E_INVALID; fillView(s->scene, v); return TB_OK; }
+int tb_host_scene_camera(tb_host_scene* s, tb_camera* cam) { if (!s || !cam) return TB_E_INVALID; *cam = s->scene.camera; return TB_OK; }
+int tb_host_scene_info(tb_host_scene* h, tb_scene_info* o)
+{
+    if (!h || !o) return TB_E_INVALID;
+    const HostScene& s = h->scene;
+    memset(o, 0, sizeof *o);
+    o->numTriangles = (uint32_t)s.triGeometry.size(); o->numVertices = (uint32_t)(s.positions.size() / 3); o->numMaterials = (uint32_t)s.materials.size();
+    o->numLights = (uint32_t)s.lights.size(); o->numGeometries = (uint32_t)s.hitGroups.size(); o->numTextures = (uint32_t)s.textureData.size();
+    o->bvhBytesA = (uint32_t)s.bvhA.size(); o->bvhNodesB = (uint32_t)s.nodesB.size(); o->bvhMaxDepth = s.bvhMaxDepth;
+    o->filmWidth = (uint32_t)s.filmWidth; o->filmHeight = (uint32_t)s.filmHeight;
+    memcpy(o->sceneMin, s.sceneMin, 12); memcpy(o->sceneMax, s.sceneMax, 12);
+    return TB_OK;
+}
+int tb_host_scene_frame_constants(tb_host_scene* h, const tb_output_settings* settings, uint32_t frame, float t, TbPerFrameConstants* out)
+{
+    if (!h || !out) return TB_E_INVALID;
+    tb_output_settings s; if (settings) s = *settings; else DefaultOutputSettings(s);
+    MakeFrameConstants(h->scene, h->scene.camera, s, frame, t, 0xffffffffu, 0xffffffffu, *out);
+    return TB_OK;
+}
+int tb_host_scene_layout_b(tb_host_scene* h, const TbNodeB** nodes, uint32_t* nn, const TbTriB** tris, uint32_t* nt, uint32_t* root)
+{
+    if (!h) return TB_E_INVALID;
+    if (nodes) *nodes = h->scene.nodesB.data(); if (nn) *nn = (uint32_t)h->scene.nodesB.size();
+    if (tris) *tris = h->scene.trisB.data(); if (nt) *nt = (uint32_t)h->scene.trisB.size();
+    if (root) *root = h->scene.rootRefB;
+    return TB_OK;
+}
+int tb_host_scene_triangles(tb_host_scene* h, const float** pos, uint32_t* nv, const uint32_t** tvi, const uint32_t** tg, const uint32_t** tp, const uint32_t** tf, uint32_t* nt)
+{
+    if (!h) return TB_E_INVALID;
+    const HostScene& s = h->scene;
+    if (pos) *pos = s.positions.data(); if (nv) *nv = (uint32_t)(s.positions.size() / 3);
+    if (tvi) *tvi = s.triVertexIndex.data(); if (tg) *tg = s.triGeometry.data(); if (tp) *tp = s.triPrimitive.data(); if (tf) *tf = s.triFlags.data();
+    if (nt) *nt = (uint32_t)s.triGeometry.size();
+    return TB_OK;
+}
+
+} // extern "C"

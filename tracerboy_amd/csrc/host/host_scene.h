@@ -1,0 +1,61 @@
+/* host_scene.h -- host-side image of everything the kernels read: the output of the build's
+ * restatement of TracerBoy::LoadScene (/root/reference/TracerBoy/TracerBoy.cpp:1065-2161). */
+#pragma once
+#include "../../../include/tb_abi.h"
+#include "../../../include/tracerboy_hip.h"
+#include "pbrt_scene.h"
+
+#include <string>
+#include <vector>
+
+namespace tbhost {
+
+struct HostScene {
+    tb_camera camera{};
+    std::vector<TbMaterial> materials;
+    std::vector<TbTextureData> textureData;
+    std::vector<TbLight> lights;
+    std::vector<TbHitGroupRecord> hitGroups;
+    std::vector<float> vertexBuffer;   /* TbVertex, 8 floats per vertex, all meshes back to back */
+    std::vector<float> positions;      /* 3 floats per vertex, same vertex numbering             */
+    std::vector<uint32_t> indexBuffer; /* mesh-local indices, as the reference uploads them      */
+    /* one entry per triangle, in geometry order: what the BVH builder consumes */
+    std::vector<uint32_t> triVertexIndex /*3 per tri, absolute into positions*/, triGeometry, triPrimitive, triFlags;
+    std::vector<TbImageDesc> images;
+    std::vector<TbFloat4> texelPool;
+    std::vector<TbFloat4> envMap; uint32_t envWidth = 0, envHeight = 0;
+    std::vector<TbFloat4> blueNoise0, blueNoise1;
+    TbConfigConstants config{};
+    int filmWidth = 0, filmHeight = 0;
+    float sceneMin[3] = {0, 0, 0}, sceneMax[3] = {0, 0, 0};
+    /* acceleration structure */
+    std::vector<uint8_t> bvhA;
+    std::vector<TbNodeB> nodesB;
+    std::vector<TbTriB> trisB;
+    uint32_t rootRefB = 0;   /* child-ref encoding of the root (leaf bit set when N == 1) */
+    uint32_t bvhMaxDepth = 0;
+};
+
+struct ConvertOptions {
+    bool flattenInstances = true; /* reference SW path traces BLAS[0] only and uses shapes[0] of an instance
+                                     (TracerBoy.cpp:1370-1375, 2861-2866); the build flattens all of them */
+};
+
+/* TracerBoy::LoadScene steps 2-4 (camera :1243-1272, shape loop :1356-1835, lights :1896-1917) */
+void ConvertScene(const PbrtScene& in, HostScene& out, const ConvertOptions& opt);
+
+/* BVH build (bvh_build.cpp).  builder 0 = LBVH with the fallback layer's semantics, 1 = binned SAH. */
+void BuildBvh(HostScene& scene, int builder);
+
+/* Procedural stand-ins (procedural.cpp) */
+void MakeProceduralScene(HostScene& out, int kind, uint32_t targetTriangles, uint32_t seed);
+
+/* images (images.cpp): Radiance RGBE .hdr and .pfm -> RGBA32F, top row first */
+bool LoadImageRGBA32F(const std::string& file, std::vector<TbFloat4>& texels, uint32_t& w, uint32_t& h, bool& normalizedFormat, std::string& err);
+
+void DefaultOutputSettings(tb_output_settings& s);
+/* TracerBoy.cpp:2808-2851 */
+void MakeFrameConstants(const HostScene& scene, const tb_camera& cam, const tb_output_settings& s, uint32_t frame, float timeSeed,
+                        uint32_t selX, uint32_t selY, TbPerFrameConstants& out);
+
+} // namespace tbhost

@@ -1,0 +1,112 @@
+/* images.cpp -- image decode for environment maps and image textures: Radiance RGBE (.hdr, flat
+ * and new-style RLE scanlines) and PFM.  Replaces DirectXTex's LoadFromHDRFile as used by
+ * TracerBoy::InitializeTexture (/root/reference/TracerBoy/TracerBoy.cpp:2188-2255) for the formats
+ * the reference scenes ship; output is RGBA32F, top row first, alpha 1.
+ * RGBE decode: value = mantissa * 2^(e - 136)  (Ward's format; e == 0 -> 0).
+ */
+#include "host_scene.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+
+namespace tbhost {
+
+namespace {
+
+bool endsWith(const std::string& s, const char* suf)
+{
+    size_t n = strlen(suf);
+    if (s.size() < n) return false;
+    for (size_t i = 0; i < n; i++) if (tolower((unsigned char)s[s.size() - n + i]) != suf[i]) return false;
+    return true;
+}
+
+bool loadHdr(const std::string& file, std::vector<TbFloat4>& texels, uint32_t& W, uint32_t& H, std::string& err)
+{
+    std::ifstream in(file, std::ios::binary);
+    if (!in) { err = "could not open image '" + file + "'"; return false; }
+    std::string line;
+    std::getline(in, line);
+    if (line.substr(0, 2) != "#?") { err = file + ": not a Radiance HDR file"; return false; }
+    bool rgbe = false;
+    while (std::getline(in, line)) {
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        if (line.empty()) break;
+        if (line.find("FORMAT=32-bit_rle_rgbe") != std::string::npos) rgbe = true;
+    }
+    (void)rgbe;
+    std::getline(in, line);
+    int h = 0, w = 0; char sy = 0, sx = 0, ay = 0, ax = 0;
+    if (sscanf(line.c_str(), "%c%c %d %c%c %d", &sy, &ay, &h, &sx, &ax, &w) != 6 || ay != 'Y' || ax != 'X' || w <= 0 || h <= 0) { err = file + ": unsupported HDR resolution line '" + line + "'"; return false; }
+    W = (uint32_t)w; H = (uint32_t)h;
+    texels.assign((size_t)W * H, TbFloat4{0, 0, 0, 1});
+    std::vector<unsigned char> scan((size_t)W * 4);
+    for (uint32_t y = 0; y < H; y++) {
+        unsigned char hd[4];
+        in.read((char*)hd, 4);
+        if (!in) { err = file + ": truncated HDR data"; return false; }
+        if (hd[0] == 2 && hd[1] == 2 && !(hd[2] & 0x80) && W >= 8 && W < 32768 && (uint32_t)((hd[2] << 8) | hd[3]) == W) {
+            for (int c = 0; c < 4; c++) {
+                uint32_t x = 0;
+                while (x < W) {
+                    unsigned char cnt; in.read((char*)&cnt, 1);
+                    if (!in) { err = file + ": truncated HDR data"; return false; }
+                    if (cnt > 128) { unsigned char v; in.read((char*)&v, 1); uint32_t n = cnt - 128u; if (x + n > W) { err = file + ": bad HDR run"; return false; } for (uint32_t k = 0; k < n; k++) scan[(size_t)(x++) * 4 + c] = v; }
+                    else { uint32_t n = cnt; if (n == 0 || x + n > W) { err = file + ": bad HDR run"; return false; } for (uint32_t k = 0; k < n; k++) { unsigned char v; in.read((char*)&v, 1); scan[(size_t)(x++) * 4 + c] = v; } }
+                }
+            }
+        } else {
+            memcpy(scan.data(), hd, 4);
+            in.read((char*)scan.data() + 4, (std::streamsize)((size_t)W * 4 - 4));
+            if (!in) { err = file + ": truncated HDR data"; return false; }
+        }
+        uint32_t row = (sy == '-') ? y : (H - 1 - y);
+        for (uint32_t x = 0; x < W; x++) {
+            const unsigned char* p = &scan[(size_t)x * 4];
+            TbFloat4 t = {0, 0, 0, 1};
+            if (p[3]) { float f = ldexpf(1.0f, (int)p[3] - 136); t.x = p[0] * f; t.y = p[1] * f; t.z = p[2] * f; }
+            uint32_t col = (sx == '+') ? x : (W - 1 - x);
+            texels[(size_t)row * W + col] = t;
+        }
+    }
+    return true;
+}
+
+bool loadPfm(const std::string& file, std::vector<TbFloat4>& texels, uint32_t& W, uint32_t& H, std::string& err)
+{
+    std::ifstream in(file, std::ios::binary);
+    if (!in) { err = "could not open image '" + file + "'"; return false; }
+    std::string magic; int w = 0, h = 0; float scale = 0;
+    in >> magic >> w >> h >> scale;
+    in.get();
+    int ch = magic == "PF" ? 3 : (magic == "Pf" ? 1 : 0);
+    if (!ch || w <= 0 || h <= 0) { err = file + ": not a PFM file"; return false; }
+    W = (uint32_t)w; H = (uint32_t)h;
+    std::vector<float> raw((size_t)W * H * ch);
+    in.read((char*)raw.data(), (std::streamsize)(raw.size() * 4));
+    if (!in) { err = file + ": truncated PFM data"; return false; }
+    if (scale > 0) { err = file + ": big-endian PFM not supported"; return false; }
+    texels.resize((size_t)W * H);
+    for (uint32_t y = 0; y < H; y++) for (uint32_t x = 0; x < W; x++) {
+        const float* p = &raw[((size_t)(H - 1 - y) * W + x) * ch]; /* PFM stores bottom row first */
+        TbFloat4 t = {p[0], ch == 3 ? p[1] : p[0], ch == 3 ? p[2] : p[0], 1.0f};
+        texels[(size_t)y * W + x] = t;
+    }
+    return true;
+}
+
+} // namespace
+
+bool LoadImageRGBA32F(const std::string& file, std::vector<TbFloat4>& texels, uint32_t& w, uint32_t& h, bool& normalizedFormat, std::string& err)
+{
+    normalizedFormat = false;
+    if (endsWith(file, ".hdr")) return loadHdr(file, texels, w, h, err);
+    if (endsWith(file, ".pfm")) return loadPfm(file, texels, w, h, err);
+    err = "unsupported image format for '" + file + "' (this build decodes .hdr and .pfm; see DESIGN.md row f1)";
+    return false;
+}
+
+} // namespace tbhost

@@ -1,0 +1,454 @@
+/* pbrt_loader.cpp -- PBRT-v3 subset loader (text scenes + binary/ascii PLY).
+ *
+ * Written from the format, not from the reference's parser sources; what it must reproduce is the
+ * OUTPUT of pbrt::importPBRT for the reference's scenes, including two
+ * behaviours of that parser that differ from pbrt itself:
+ *   - `Transform [16]` CONCATENATES onto the CTM (it does not replace it) and reads the matrix as
+ *     rows (m0..2),(m4..6),(m8..10),(m12..14)  (impl/syntactic/Parser.inl:366-375, Parser.h:130-133);
+ *   - mesh vertices/normals are baked to world space with xfmPoint / xfmNormal at load
+ *     (impl/semantic/Geometry.cpp:227-231,250-254); the camera frame is inverse(CTM at Camera)
+ *     (impl/semantic/Camera.cpp:102).
+ */
+#include "pbrt_scene.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <stdexcept>
+
+namespace tbhost {
+
+namespace {
+
+struct Token { std::string text; bool quoted = false; bool eof = false; };
+
+class Lexer {
+public:
+    explicit Lexer(const std::string& file) : fileName(file)
+    {
+        std::ifstream in(file, std::ios::binary);
+        if (!in) throw std::runtime_error("could not open pbrt file '" + file + "'");
+        std::stringstream ss; ss << in.rdbuf(); buf = ss.str();
+    }
+    Token next()
+    {
+        Token t;
+        for (;;) {
+            while (pos < buf.size() && isspace((unsigned char)buf[pos])) pos++;
+            if (pos < buf.size() && buf[pos] == '#') { while (pos < buf.size() && buf[pos] != '\n') pos++; continue; }
+            break;
+        }
+        if (pos >= buf.size()) { t.eof = true; return t; }
+        char c = buf[pos];
+        if (c == '"') {
+            size_t e = buf.find('"', pos + 1);
+            if (e == std::string::npos) throw std::runtime_error(fileName + ": unterminated string");
+            t.text = buf.substr(pos + 1, e - pos - 1); t.quoted = true; pos = e + 1; return t;
+        }
+        if (c == '[' || c == ']') { t.text = std::string(1, c); pos++; return t; }
+        size_t s = pos;
+        while (pos < buf.size() && !isspace((unsigned char)buf[pos]) && buf[pos] != '[' && buf[pos] != ']' && buf[pos] != '"' && buf[pos] != '#') pos++;
+        t.text = buf.substr(s, pos - s);
+        return t;
+    }
+    std::string fileName;
+private:
+    std::string buf;
+    size_t pos = 0;
+};
+
+struct Param {
+    std::string type;
+    std::vector<double> num;       /* numeric payload; floats go through (float)stod like the reference */
+    std::vector<std::string> str;  /* string / texture / bool / spectrum-file payload */
+};
+typedef std::map<std::string, Param> ParamSet;
+
+struct GraphicsState {
+    PbrtMaterialSP material;
+    bool hasAreaLight = false;
+    Vec3 areaL{1, 1, 1};
+    bool reverseOrientation = false;
+    std::map<std::string, PbrtMaterialSP> namedMaterials;
+    std::map<std::string, PbrtTextureSP> namedTextures;
+};
+
+class Parser {
+public:
+    std::shared_ptr<PbrtScene> scene = std::make_shared<PbrtScene>();
+
+    void parseFile(const std::string& file)
+    {
+        if (scene->basePath.empty()) {
+            size_t slash = file.find_last_of("/\\");
+            scene->basePath = slash == std::string::npos ? std::string("") : file.substr(0, slash + 1);
+        }
+        lexers.push_back(std::make_shared<Lexer>(file));
+        run();
+    }
+
+private:
+    std::vector<std::shared_ptr<Lexer>> lexers;
+    bool havePeek = false; Token peeked;
+    Affine ctm;
+    std::vector<Affine> transformStack;
+    std::vector<GraphicsState> attributeStack;
+    GraphicsState gs;
+    std::map<std::string, Affine> namedCoordSys;
+    std::map<std::string, std::shared_ptr<PbrtObject>> objects;
+    std::vector<std::shared_ptr<PbrtObject>> objectStack;
+
+    Token next()
+    {
+        if (havePeek) { havePeek = false; return peeked; }
+        while (!lexers.empty()) {
+            Token t = lexers.back()->next();
+            if (!t.eof) return t;
+            lexers.pop_back();
+        }
+        Token e; e.eof = true; return e;
+    }
+    Token peek() { if (!havePeek) { peeked = next(); havePeek = true; } return peeked; }
+
+    float parseFloat() { Token t = next(); return (float)std::stod(t.text); }
+    Vec3 parseVec3() { Vec3 v; v.x = parseFloat(); v.y = parseFloat(); v.z = parseFloat(); return v; }
+    std::string global(const std::string& f) const { return (!f.empty() && f[0] == '/') ? f : scene->basePath + f; }
+
+    ParamSet parseParams()
+    {
+        ParamSet ps;
+        for (;;) {
+            Token t = peek();
+            if (t.eof || !t.quoted) break;
+            next();
+            std::string decl = t.text;
+            std::istringstream is(decl);
+            std::string type, name; is >> type >> name;
+            if (name.empty()) throw std::runtime_error("malformed parameter declaration '" + decl + "'");
+            Param p; p.type = type;
+            auto addValue = [&](const Token& v) {
+                if (v.quoted || type == "string" || type == "texture" || type == "bool") p.str.push_back(v.text);
+                else p.num.push_back(std::stod(v.text));
+            };
+            Token v = next();
+            if (v.text == "[" && !v.quoted) {
+                for (;;) { Token e = next(); if (e.eof) throw std::runtime_error("unterminated parameter list"); if (e.text == "]" && !e.quoted) break; addValue(e); }
+            } else addValue(v);
+            ps[name] = p;
+        }
+        return ps;
+    }
+
+    static bool has(const ParamSet& ps, const std::string& n) { return ps.find(n) != ps.end(); }
+    static bool isTexture(const ParamSet& ps, const std::string& n) { auto it = ps.find(n); return it != ps.end() && it->second.type == "texture"; }
+    static float get1f(const ParamSet& ps, const std::string& n, float def) { auto it = ps.find(n); if (it == ps.end() || it->second.num.empty()) return def; return (float)it->second.num[0]; }
+    static bool has3f(const ParamSet& ps, const std::string& n) { auto it = ps.find(n); return it != ps.end() && it->second.num.size() == 3 && it->second.type != "spectrum"; }
+    static void get3f(const ParamSet& ps, const std::string& n, Vec3& v) { auto it = ps.find(n); if (it == ps.end() || it->second.num.size() < 3) return; v = Vec3((float)it->second.num[0], (float)it->second.num[1], (float)it->second.num[2]); }
+    static std::string getStr(const ParamSet& ps, const std::string& n) { auto it = ps.find(n); if (it == ps.end() || it->second.str.empty()) return ""; return it->second.str[0]; }
+
+    PbrtTextureSP findTexture(const std::string& name) const
+    {
+        auto it = gs.namedTextures.find(name);
+        return it == gs.namedTextures.end() ? PbrtTextureSP() : it->second;
+    }
+    PbrtTextureSP paramTexture(const ParamSet& ps, const std::string& n) const { return findTexture(getStr(ps, n)); }
+
+    PbrtMaterialSP makeMaterial(const std::string& type, const std::string& name, const ParamSet& ps)
+    {
+        PbrtMaterialSP m = std::make_shared<PbrtMaterial>();
+        m->type = type; m->name = name;
+        auto kdLike = [&](const char* key, Vec3& dst, PbrtTextureSP* map) {
+            if (!has(ps, key)) return;
+            if (isTexture(ps, key)) { dst = Vec3(1.f); if (map) *map = paramTexture(ps, key); }
+            else get3f(ps, key, dst);
+        };
+        if (type == "matte") { /* Scene.h:650-669 */
+            m->kd = Vec3(.5f); m->sigma = 0.f;
+            kdLike("Kd", m->kd, &m->map_kd);
+            if (has(ps, "sigma") && !isTexture(ps, "sigma")) m->sigma = get1f(ps, "sigma", 0.f);
+        } else if (type == "plastic") { /* :540-562 */
+            m->kd = Vec3(.25f); m->ks = Vec3(.25f); m->roughness = 0.1f;
+            kdLike("Kd", m->kd, &m->map_kd); kdLike("Ks", m->ks, nullptr);
+            if (has(ps, "roughness") && !isTexture(ps, "roughness")) m->roughness = get1f(ps, "roughness", 0.1f);
+        } else if (type == "substrate") { /* :564-589 */
+            m->kd = Vec3(.5f); m->ks = Vec3(.5f); m->uRoughness = .1f; m->vRoughness = .1f;
+            kdLike("Kd", m->kd, &m->map_kd); kdLike("Ks", m->ks, nullptr);
+            if (has(ps, "uroughness")) m->uRoughness = isTexture(ps, "uroughness") ? 1.f : get1f(ps, "uroughness", .1f);
+            if (has(ps, "vroughness")) m->vRoughness = isTexture(ps, "vroughness") ? 1.f : get1f(ps, "vroughness", .1f);
+        } else if (type == "uber") { /* :690-738 */
+            m->kd = Vec3(.25f); m->ks = Vec3(.25f); m->kr = Vec3(0.f); m->kt = Vec3(0.f); m->opacity = Vec3(1.f);
+            m->index = 1.5f; m->roughness = 0.1f; m->uRoughness = 0.f; m->vRoughness = 0.f;
+            kdLike("Kd", m->kd, &m->map_kd); kdLike("Ks", m->ks, nullptr); kdLike("Kr", m->kr, nullptr); kdLike("Kt", m->kt, nullptr);
+            kdLike("opacity", m->opacity, nullptr);
+            m->index = get1f(ps, "index", m->index);
+            if (has(ps, "roughness") && !isTexture(ps, "roughness")) m->roughness = get1f(ps, "roughness", 0.1f);
+            m->uRoughness = get1f(ps, "uroughness", 0.f); m->vRoughness = get1f(ps, "vroughness", 0.f);
+        } else if (type == "mirror") { /* :614-631 */
+            m->kr = Vec3(.9f); get3f(ps, "Kr", m->kr);
+        } else if (type == "metal") { /* :473-499 */
+            m->roughness = 0.01f; m->uRoughness = 0.f; m->vRoughness = 0.f;
+            m->eta3 = Vec3(0.21221054f, 0.91804785f, 1.1000715f);
+            if (has(ps, "roughness") && !isTexture(ps, "roughness")) m->roughness = get1f(ps, "roughness", 0.01f);
+            if (has(ps, "uroughness") && !isTexture(ps, "uroughness")) m->uRoughness = get1f(ps, "uroughness", 0.f);
+            if (has(ps, "vroughness") && !isTexture(ps, "vroughness")) m->vRoughness = get1f(ps, "vroughness", 0.f);
+            if (has3f(ps, "eta")) get3f(ps, "eta", m->eta3);
+        } else if (type == "glass") { /* :671-688 */
+            m->kr = Vec3(1.f); m->kt = Vec3(1.f); m->index = get1f(ps, "index", 1.5f);
+            get3f(ps, "Kr", m->kr); get3f(ps, "Kt", m->kt);
+        } else if (type == "disney") { /* :425-452 + createMaterial_disney defaults */
+            m->color = Vec3(.5f); get3f(ps, "color", m->color);
+            m->eta = get1f(ps, "eta", 1.2f); m->metallic = get1f(ps, "metallic", 0.f);
+            m->roughness = get1f(ps, "roughness", 0.9f); m->specTrans = get1f(ps, "spectrans", 0.f);
+        } else if (type == "mix") { /* :454-471 */
+            m->amount = Vec3(.5f);
+            if (!isTexture(ps, "amount")) { if (has3f(ps, "amount")) get3f(ps, "amount", m->amount); else if (has(ps, "amount")) m->amount = Vec3(get1f(ps, "amount", .5f)); }
+            std::string n0 = getStr(ps, "namedmaterial1"), n1 = getStr(ps, "namedmaterial2");
+            if (n0.empty() || n1.empty()) throw std::runtime_error("mix material w/o 'namedmaterial1/2' parameter");
+            auto i0 = gs.namedMaterials.find(n0), i1 = gs.namedMaterials.find(n1);
+            if (i0 == gs.namedMaterials.end() || i1 == gs.namedMaterials.end()) throw std::runtime_error("mix material refers to unknown named material");
+            m->material0 = i0->second; m->material1 = i1->second;
+        } else if (type == "translucent") { /* :520-538 */
+            m->kd = Vec3(.25f);
+            if (isTexture(ps, "Kd")) m->map_kd = paramTexture(ps, "Kd"); else get3f(ps, "Kd", m->kd);
+        } else if (type == "fourier" || type == "subsurface" || type == "hair" || type == "none" || type == "") {
+            /* carried by name only */
+        }
+        return m;
+    }
+
+    PbrtTextureSP makeTexture(const std::string& name, const std::string& kind, const ParamSet& ps)
+    {
+        PbrtTextureSP t = std::make_shared<PbrtTexture>();
+        t->name = name; t->kind = kind;
+        if (kind == "imagemap") t->fileName = global(getStr(ps, "filename"));
+        else if (kind == "checkerboard") {
+            t->uscale = get1f(ps, "uscale", 1.f); t->vscale = get1f(ps, "vscale", 1.f);
+            get3f(ps, "tex1", t->tex1); get3f(ps, "tex2", t->tex2);
+        } else if (kind == "scale") {
+            auto side = [&](const char* key, PbrtTextureSP& tex, Vec3& sc) {
+                if (isTexture(ps, key)) tex = paramTexture(ps, key);
+                else if (has3f(ps, key)) get3f(ps, key, sc);
+                else sc = Vec3(get1f(ps, key, 1.f));
+            };
+            side("tex1", t->scaleTex1, t->scale1); side("tex2", t->scaleTex2, t->scale2);
+        } else if (kind == "constant") {
+            if (has3f(ps, "value")) get3f(ps, "value", t->value); else t->value = Vec3(get1f(ps, "value", 1.f));
+        }
+        return t;
+    }
+
+    PbrtObject& currentObject() { return objectStack.empty() ? scene->world : *objectStack.back(); }
+
+    void emitShape(const std::string& type, const ParamSet& ps)
+    {
+        if (type != "trianglemesh" && type != "plymesh") { scene->numSkippedShapes++; return; }
+        PbrtMeshSP mesh = std::make_shared<PbrtMesh>();
+        mesh->material = gs.material;
+        mesh->reverseOrientation = gs.reverseOrientation;
+        if (type == "plymesh") {
+            readPly(global(getStr(ps, "filename")), mesh->vertex, mesh->normal, mesh->texcoord, mesh->index);
+        } else {
+            auto v3 = [&](const char* key, std::vector<Vec3>& out) {
+                auto it = ps.find(key); if (it == ps.end()) return;
+                const std::vector<double>& n = it->second.num;
+                for (size_t i = 0; i + 2 < n.size(); i += 3) out.push_back(Vec3((float)n[i], (float)n[i + 1], (float)n[i + 2]));
+            };
+            v3("P", mesh->vertex); v3("N", mesh->normal);
+            auto uvIt = ps.find("uv"); if (uvIt == ps.end()) uvIt = ps.find("st");
+            if (uvIt != ps.end()) for (size_t i = 0; i + 1 < uvIt->second.num.size(); i += 2) { Vec2 t; t.x = (float)uvIt->second.num[i]; t.y = (float)uvIt->second.num[i + 1]; mesh->texcoord.push_back(t); }
+            auto ix = ps.find("indices");
+            if (ix != ps.end()) { size_t n = ix->second.num.size() / 3 * 3; for (size_t i = 0; i < n; i++) mesh->index.push_back((uint32_t)(int64_t)ix->second.num[i]); }
+        }
+        for (Vec3& v : mesh->vertex) v = xfmPoint(ctm, v);
+        for (Vec3& v : mesh->normal) v = xfmNormal(ctm, v);
+        for (auto& kv : ps) if (kv.second.type == "texture") mesh->textures[kv.first] = findTexture(kv.second.str.empty() ? std::string() : kv.second.str[0]);
+        if (gs.hasAreaLight) { mesh->hasAreaLight = true; mesh->areaLightL = gs.areaL; }
+        currentObject().shapes.push_back(mesh);
+    }
+
+    void run()
+    {
+        for (;;) {
+            Token t = next();
+            if (t.eof) break;
+            const std::string& d = t.text;
+            if (d == "Include") { Token f = next(); lexers.push_back(std::make_shared<Lexer>(global(f.text))); }
+            else if (d == "WorldBegin") { ctm = Affine(); namedCoordSys["world"] = ctm; }
+            else if (d == "WorldEnd") { }
+            else if (d == "AttributeBegin") { attributeStack.push_back(gs); transformStack.push_back(ctm); }
+            else if (d == "AttributeEnd") {
+                if (attributeStack.empty()) throw std::runtime_error("unmatched AttributeEnd");
+                gs = attributeStack.back(); attributeStack.pop_back(); ctm = transformStack.back(); transformStack.pop_back();
+            }
+            else if (d == "TransformBegin") transformStack.push_back(ctm);
+            else if (d == "TransformEnd") { if (transformStack.empty()) throw std::runtime_error("unmatched TransformEnd"); ctm = transformStack.back(); transformStack.pop_back(); }
+            else if (d == "Identity") ctm = Affine();
+            else if (d == "Scale") { Vec3 s = parseVec3(); Affine a; a.l.vx = Vec3(s.x, 0, 0); a.l.vy = Vec3(0, s.y, 0); a.l.vz = Vec3(0, 0, s.z); ctm = ctm * a; }
+            else if (d == "Translate") { Vec3 s = parseVec3(); Affine a; a.p = s; ctm = ctm * a; }
+            else if (d == "Rotate") { /* math.h:183-191 */
+                float angle = parseFloat(); Vec3 axis = parseVec3();
+                float r = angle * (float)M_PI / 180.f;
+                Vec3 u = normalize(axis);
+                float s = sinf(r), c = cosf(r);
+                Affine a;
+                a.l.vx = Vec3(u.x * u.x + (1 - u.x * u.x) * c, u.x * u.y * (1 - c) + u.z * s, u.x * u.z * (1 - c) - u.y * s);
+                a.l.vy = Vec3(u.x * u.y * (1 - c) - u.z * s, u.y * u.y + (1 - u.y * u.y) * c, u.y * u.z * (1 - c) + u.x * s);
+                a.l.vz = Vec3(u.x * u.z * (1 - c) + u.y * s, u.y * u.z * (1 - c) - u.x * s, u.z * u.z + (1 - u.z * u.z) * c);
+                ctm = ctm * a;
+            }
+            else if (d == "Transform" || d == "ConcatTransform") {
+                Token open = next(); if (open.text != "[") throw std::runtime_error(d + ": expected '['");
+                float m[16]; for (int i = 0; i < 16; i++) m[i] = parseFloat();
+                Token close = next(); if (close.text != "]") throw std::runtime_error(d + ": expected ']'");
+                Affine a; a.l.vx = Vec3(m[0], m[1], m[2]); a.l.vy = Vec3(m[4], m[5], m[6]); a.l.vz = Vec3(m[8], m[9], m[10]); a.p = Vec3(m[12], m[13], m[14]);
+                ctm = ctm * a;
+            }
+            else if (d == "LookAt") { /* Parser.inl:728-741 */
+                Vec3 v0 = parseVec3(), v1 = parseVec3(), v2 = parseVec3();
+                Affine a; a.l.vz = normalize(v1 - v0); a.l.vx = normalize(cross(v2, a.l.vz)); a.l.vy = cross(a.l.vz, a.l.vx); a.p = v0;
+                ctm = ctm * inverse(a);
+            }
+            else if (d == "CoordinateSystem") { Token n = next(); namedCoordSys[n.text] = ctm; }
+            else if (d == "CoordSysTransform") { next(); /* the reference parser ignores it */ }
+            else if (d == "ReverseOrientation") gs.reverseOrientation = !gs.reverseOrientation;
+            else if (d == "Camera") {
+                Token ty = next(); ParamSet ps = parseParams();
+                scene->hasCamera = true; scene->fov = get1f(ps, "fov", 30.f);
+                scene->cameraFrame = inverse(ctm);
+                namedCoordSys["camera"] = scene->cameraFrame;
+            }
+            else if (d == "Film") { next(); ParamSet ps = parseParams(); scene->filmWidth = (int)get1f(ps, "xresolution", 0); scene->filmHeight = (int)get1f(ps, "yresolution", 0); }
+            else if (d == "Integrator" || d == "Sampler" || d == "PixelFilter" || d == "Accelerator" || d == "SurfaceIntegrator" || d == "VolumeIntegrator" || d == "Renderer") { next(); parseParams(); }
+            else if (d == "MakeNamedMedium" || d == "MediumInterface") { next(); if (d == "MediumInterface") { Token p2 = peek(); if (p2.quoted) next(); } else parseParams(); }
+            else if (d == "MakeNamedMaterial") {
+                Token n = next(); ParamSet ps = parseParams();
+                gs.namedMaterials[n.text] = makeMaterial(getStr(ps, "type"), n.text, ps);
+            }
+            else if (d == "NamedMaterial") {
+                Token n = next(); auto it = gs.namedMaterials.find(n.text);
+                if (it == gs.namedMaterials.end()) throw std::runtime_error("NamedMaterial '" + n.text + "' not defined");
+                gs.material = it->second;
+            }
+            else if (d == "Material") { Token ty = next(); ParamSet ps = parseParams(); gs.material = makeMaterial(ty.text, "", ps); }
+            else if (d == "Texture") {
+                Token n = next(); next(); /* "spectrum" | "float" */ Token kind = next(); ParamSet ps = parseParams();
+                gs.namedTextures[n.text] = makeTexture(n.text, kind.text, ps);
+            }
+            else if (d == "AreaLightSource") { Token ty = next(); ParamSet ps = parseParams(); gs.hasAreaLight = true; gs.areaL = Vec3(1.f); get3f(ps, "L", gs.areaL); }
+            else if (d == "LightSource") {
+                Token ty = next(); ParamSet ps = parseParams();
+                PbrtLight l; l.transform = ctm;
+                if (ty.text == "infinite") { l.kind = PbrtLight::Infinite; std::string mn = getStr(ps, "mapname"); l.mapName = mn.empty() ? mn : global(mn); get3f(ps, "L", l.L); get3f(ps, "scale", l.scale); scene->lights.push_back(l); }
+                else if (ty.text == "distant") { l.kind = PbrtLight::Distant; get3f(ps, "L", l.L); get3f(ps, "scale", l.scale); get3f(ps, "from", l.from); get3f(ps, "to", l.to); scene->lights.push_back(l); }
+                /* point / spot / others: TracerBoy.cpp:1896-1917 ignores them */
+            }
+            else if (d == "Shape") { Token ty = next(); ParamSet ps = parseParams(); emitShape(ty.text, ps); }
+            else if (d == "ObjectBegin") {
+                Token n = next(); auto o = std::make_shared<PbrtObject>(); o->name = n.text; objects[n.text] = o; objectStack.push_back(o);
+                attributeStack.push_back(gs); transformStack.push_back(ctm);
+            }
+            else if (d == "ObjectEnd") {
+                if (objectStack.empty()) throw std::runtime_error("unmatched ObjectEnd");
+                objectStack.pop_back(); gs = attributeStack.back(); attributeStack.pop_back(); ctm = transformStack.back(); transformStack.pop_back();
+            }
+            else if (d == "ObjectInstance") {
+                Token n = next(); auto it = objects.find(n.text);
+                if (it == objects.end()) throw std::runtime_error("ObjectInstance of unknown object '" + n.text + "'");
+                PbrtInstance inst; inst.xfm = ctm; inst.object = it->second; currentObject().instances.push_back(inst);
+            }
+            else if (d == "ActiveTransform" || d == "TransformTimes") { next(); if (d == "TransformTimes") next(); }
+            else throw std::runtime_error(lexers.empty() ? "unexpected token '" + d + "'" : lexers.back()->fileName + ": unexpected token '" + d + "'");
+        }
+    }
+};
+
+} // namespace
+
+std::shared_ptr<PbrtScene> importPBRT(const std::string& fileName)
+{
+    Parser p;
+    p.parseFile(fileName);
+    return p.scene;
+}
+
+/* ---- PLY ------------------------------------------------------------------------------------ */
+void readPly(const std::string& fileName, std::vector<Vec3>& pos, std::vector<Vec3>& nor, std::vector<Vec2>& uv, std::vector<uint32_t>& idx)
+{
+    std::ifstream in(fileName, std::ios::binary);
+    if (!in) throw std::runtime_error("Couldn't open PLY file " + fileName);
+    std::string line;
+    std::getline(in, line);
+    if (line.substr(0, 3) != "ply") throw std::runtime_error(fileName + ": not a PLY file");
+    enum Fmt { Ascii, LE, BE } fmt = Ascii;
+    struct Prop { std::string name, type, listCount, listItem; bool isList = false; };
+    struct Elem { std::string name; size_t count = 0; std::vector<Prop> props; };
+    std::vector<Elem> elems;
+    while (std::getline(in, line)) {
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        std::istringstream is(line); std::string w; is >> w;
+        if (w == "format") { std::string f; is >> f; fmt = f == "ascii" ? Ascii : (f == "binary_little_endian" ? LE : BE); }
+        else if (w == "element") { Elem e; is >> e.name >> e.count; elems.push_back(e); }
+        else if (w == "property") {
+            Prop p; std::string t; is >> t;
+            if (t == "list") { p.isList = true; is >> p.listCount >> p.listItem >> p.name; } else { p.type = t; is >> p.name; }
+            if (elems.empty()) throw std::runtime_error(fileName + ": property before element");
+            elems.back().props.push_back(p);
+        } else if (w == "end_header") break;
+    }
+    if (fmt == BE) throw std::runtime_error(fileName + ": big-endian PLY not supported");
+    auto sizeOf = [](const std::string& t) -> int {
+        if (t == "char" || t == "uchar" || t == "int8" || t == "uint8") return 1;
+        if (t == "short" || t == "ushort" || t == "int16" || t == "uint16") return 2;
+        if (t == "int" || t == "uint" || t == "float" || t == "int32" || t == "uint32" || t == "float32") return 4;
+        if (t == "double" || t == "float64") return 8;
+        return 0;
+    };
+    auto readNum = [&](const std::string& t) -> double {
+        if (fmt == Ascii) { double d; in >> d; return d; }
+        char b[8]; int n = sizeOf(t); if (n == 0) throw std::runtime_error(fileName + ": unknown PLY type " + t);
+        in.read(b, n); if (!in) throw std::runtime_error(fileName + ": unable to read the contents of PLY file");
+        if (t == "float" || t == "float32") { float f; memcpy(&f, b, 4); return f; }
+        if (t == "double" || t == "float64") { double f; memcpy(&f, b, 8); return f; }
+        if (t == "uchar" || t == "uint8") return (unsigned char)b[0];
+        if (t == "char" || t == "int8") return (signed char)b[0];
+        if (t == "ushort" || t == "uint16") { uint16_t v; memcpy(&v, b, 2); return v; }
+        if (t == "short" || t == "int16") { int16_t v; memcpy(&v, b, 2); return v; }
+        if (t == "uint" || t == "uint32") { uint32_t v; memcpy(&v, b, 4); return v; }
+        int32_t v; memcpy(&v, b, 4); return v;
+    };
+    for (const Elem& e : elems) {
+        if (e.name == "vertex") {
+            bool hasN = false, hasUV = false;
+            for (const Prop& p : e.props) { if (p.name == "nx") hasN = true; if (p.name == "u" || p.name == "s") hasUV = true; }
+            pos.resize(e.count); if (hasN) nor.resize(e.count); if (hasUV) uv.resize(e.count);
+            for (size_t i = 0; i < e.count; i++)
+                for (const Prop& p : e.props) {
+                    if (p.isList) { size_t n = (size_t)readNum(p.listCount); for (size_t k = 0; k < n; k++) readNum(p.listItem); continue; }
+                    float v = (float)readNum(p.type);
+                    if (p.name == "x") pos[i].x = v; else if (p.name == "y") pos[i].y = v; else if (p.name == "z") pos[i].z = v;
+                    else if (p.name == "nx") nor[i].x = v; else if (p.name == "ny") nor[i].y = v; else if (p.name == "nz") nor[i].z = v;
+                    else if (p.name == "u" || p.name == "s") uv[i].x = v; else if (p.name == "v" || p.name == "t") uv[i].y = v;
+                }
+        } else if (e.name == "face") {
+            idx.reserve(e.count * 3);
+            for (size_t i = 0; i < e.count; i++)
+                for (const Prop& p : e.props) {
+                    if (!p.isList) { readNum(p.type); continue; }
+                    size_t n = (size_t)readNum(p.listCount);
+                    bool isIdx = p.name == "vertex_indices" || p.name == "vertex_index";
+                    if (isIdx && n != 3) throw std::runtime_error(fileName + ": PLY face with " + std::to_string(n) + " vertices (only triangles are supported)");
+                    for (size_t k = 0; k < n; k++) { double v = readNum(p.listItem); if (isIdx) idx.push_back((uint32_t)(int64_t)v); }
+                }
+        } else {
+            for (size_t i = 0; i < e.count; i++)
+                for (const Prop& p : e.props) {
+                    if (p.isList) { size_t n = (size_t)readNum(p.listCount); for (size_t k = 0; k < n; k++) readNum(p.listItem); }
+                    else readNum(p.type);
+                }
+        }
+    }
+}
+
+} // namespace tbhost

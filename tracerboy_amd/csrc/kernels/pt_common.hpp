@@ -1,0 +1,34 @@
+/* pt_common.hpp -- helpers shared by the kernel translation units. */
+#pragma once
+#include <hip/hip_runtime.h>
+#include "pt_device.hpp"
+
+namespace {
+using namespace pt;
+
+constexpr int BLOCK = 256;
+
+template <bool SCENE_LDS>
+__device__ __forceinline__ void make_refs(SceneRefs& sc, const TbDeviceScene& ds, const uint8_t* blob)
+{
+    if (SCENE_LDS) {
+        sc.nodes = (const TbNodeB*)(blob + ds.offNodes); sc.tris = (const TbTriB*)(blob + ds.offTris);
+        sc.hitGroups = (const TbHitGroupRecord*)(blob + ds.offHitGroups); sc.indices = (const uint32_t*)(blob + ds.offIndices);
+        sc.vertices = (const float*)(blob + ds.offVertices); sc.materials = (const TbMaterial*)(blob + ds.offMaterials);
+        sc.lights = (const TbLight*)(blob + ds.offLights);
+    } else {
+        sc.nodes = ds.nodes; sc.tris = ds.tris; sc.hitGroups = ds.hitGroups; sc.indices = ds.indexBuffer; sc.vertices = ds.vertexBuffer;
+        sc.materials = ds.materials; sc.lights = ds.lights;
+    }
+    sc.numHitGroups = ds.numHitGroups; sc.numIndices = ds.numIndices; sc.numVertexFloats = ds.numVertexFloats;
+    sc.numMaterials = ds.numMaterials; sc.numLights = ds.numLights;
+}
+
+__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+
+} // namespace

@@ -1,0 +1,830 @@
+/* pt_device.hpp -- device functions of the MI355X path tracer.
+ *
+ * The reference runs one thread per pixel through one monolithic shader
+ * (/root/reference/TracerBoy/SoftwareRayTraceCS.hlsl -> RayGenCommon.h:690 RayTraceCommon ->
+ * kernel.glsl:1805 PathTrace -> :1278 Trace).  Here the same per-path arithmetic is cut at every
+ * ray cast into a small state machine, so that a lane (persistent megakernel) or a queue entry
+ * (wavefront pipeline) always has exactly one pending ray:
+ *
+ *     path_begin()           camera ray                         kernel.glsl:1805-1906 + :1283
+ *     path_pre_extend()      Russian roulette                   kernel.glsl:1288-1302
+ *     -- traverse --                                           TraverseFunction.hlsli:537-779
+ *     path_on_closest()      miss / material / emissive / NEE sample -> shadow ray   :1312-1455
+ *     -- traverse --
+ *     path_on_shadow()       visibility + NEE add               kernel.glsl:1460-1516
+ *     path_scatter()         BSDF sample, throughput, (enter SSS walk)              :1519-1772
+ *     -- traverse --  (SSS walk only)
+ *     path_on_sss()          one interior random-walk step      kernel.glsl:1601-1687
+ *
+ * All arithmetic goes through include/tb_math.h / tb_vec.h with -ffp-contract=off, in the same
+ * order as the CPU checker, which is what makes the images bit-identical.  "R" = one rnd() call.
+ */
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../../include/tb_vec.h"
+#include "pt_scene.h"
+#include "pt_device_features.h"
+
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+
+#define TBD __device__ __forceinline__
+
+namespace pt {
+
+constexpr float EPSILON = 0.000001f;      /* kernel.glsl:1 */
+constexpr float PI = 3.1415926535f;       /* kernel.glsl:2 */
+constexpr float LARGE_NUMBER = 1e20f;
+constexpr float AIR_IOR = 1.0f;
+constexpr float MIN_ROUGHNESS = 0.04f;
+constexpr float MIN_ROUGHNESS_SQUARED = (float)(0.04 * 0.04);
+constexpr float MIN_T = 0.001f;           /* RayGenCommon.h:364 */
+constexpr float MAX_T = 999999.0f;        /* kernel.glsl:1160 */
+constexpr int MAX_SSS_BOUNCES = 100;      /* kernel.glsl:1565 */
+
+/* Scene/setting features a kernel variant is compiled for.  The host picks the smallest compiled
+ * superset of what the loaded scene and the output settings can ever exercise, so a stripped
+ * branch is one that could never be taken: results are identical across variants. */
+enum : uint32_t {
+    FEAT_ENV = PT_FEAT_ENV, FEAT_SPECULAR = PT_FEAT_SPECULAR, FEAT_TEXTURES = PT_FEAT_TEXTURES, FEAT_SSS = PT_FEAT_SSS,
+    FEAT_MIX = PT_FEAT_MIX, FEAT_EXT = PT_FEAT_EXT, FEAT_ALL = PT_FEAT_ALL,
+};
+
+/* Pointers the step functions read through; filled from global memory or from the LDS copy. */
+struct SceneRefs {
+    const TbNodeB* nodes; const TbTriB* tris;
+    const TbHitGroupRecord* hitGroups; const uint32_t* indices; const float* vertices;
+    const TbMaterial* materials; const TbLight* lights;
+    uint32_t numHitGroups, numIndices, numVertexFloats, numMaterials, numLights;
+};
+
+TBD tb3 ld3(const float* p) { return tb3_make(p[0], p[1], p[2]); }
+TBD tb3 ld3(const TbFloat3& f) { return tb3_make(f.x, f.y, f.z); }
+
+/* ---- RNG: kernel.glsl:39-40, RayGenCommon.h:662-667 ------------------------------------------ */
+TBD float rnd(float& seed, float time)
+{
+    float s = seed;
+    seed = seed + 1.0f;
+    return tb_frac(tb_sin(s + time) * 43758.5453123f);
+}
+
+TBD float hash13(float x, float y, float z)
+{
+    tb3 p = tb3_make(tb_frac(x * .1031f), tb_frac(y * .1031f), tb_frac(z * .1031f));
+    float d = tb3_dot(p, tb3_make(p.y + 33.33f, p.z + 33.33f, p.x + 33.33f));
+    p = tb3_make(p.x + d, p.y + d, p.z + d);
+    return tb_frac((p.x + p.y) * p.z);
+}
+
+/* ---- traversal ------------------------------------------------------------------------------- */
+struct RayPre { tb3 inv, oinv, shear; int kx, ky, kz; };
+
+TBD RayPre ray_prepare(tb3 o, tb3 d) /* GetRayData, TraverseFunction.hlsli:473-495 */
+{
+    RayPre r;
+    r.inv = tb3_make(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    r.oinv = o * r.inv;
+    tb3 a = tb3_abs(d);
+    int z = (a.x > a.y && a.x > a.z) ? 0 : (a.y > a.z ? 1 : 2);
+    int kx = z == 2 ? 0 : z + 1, ky = kx == 2 ? 0 : kx + 1;
+    float dz = tb3_get(d, z);
+    if (dz < 0.0f) { int t = kx; kx = ky; ky = t; }
+    r.kx = kx; r.ky = ky; r.kz = z;
+    r.shear = tb3_make(tb3_get(d, kx) / dz, tb3_get(d, ky) / dz, 1.0f / dz);
+    return r;
+}
+
+TBD bool box_test(float& tEntry, float closest, const RayPre& r, tb3 c, tb3 h) /* RayBoxTest :204-221 */
+{
+    tb3 mid = c * r.inv - r.oinv;
+    tb3 ai = tb3_abs(r.inv);
+    tb3 hi = mid + h * ai;
+    tb3 lo = mid - h * ai;
+    float tmin = tb_max(tb_max(lo.x, lo.y), lo.z);
+    float tmax = tb_min(tb_min(hi.x, hi.y), hi.z);
+    tEntry = tb_max(tmin, 0.0f);
+    return tb_max(tmin, 0.0f) < tb_min(tmax, closest);
+}
+
+struct Hit { float t, u, v; uint32_t prim, geom; };
+
+/* Woop/Benthin/Wald watertight test, two-sided branch: RayTriangleIntersect :232-313 + :420-426 */
+TBD void tri_test(Hit& best, float tMin, tb3 o, const RayPre& r, const TbTriB& tri)
+{
+    tb3 a = ld3(tri.v0) - o, b = ld3(tri.v1) - o, c = ld3(tri.v2) - o;
+    float Az = tb3_get(a, r.kz), Bz = tb3_get(b, r.kz), Cz = tb3_get(c, r.kz);
+    float Ax = tb3_get(a, r.kx) - r.shear.x * Az, Ay = tb3_get(a, r.ky) - r.shear.y * Az;
+    float Bx = tb3_get(b, r.kx) - r.shear.x * Bz, By = tb3_get(b, r.ky) - r.shear.y * Bz;
+    float Cx = tb3_get(c, r.kx) - r.shear.x * Cz, Cy = tb3_get(c, r.ky) - r.shear.y * Cz;
+    float U = Cx * By - Cy * Bx;
+    float V = Ax * Cy - Ay * Cx;
+    float W = Bx * Ay - By * Ax;
+    float det = U + V + W;
+    if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) return;
+    if (det == 0.0f) return;
+    Az = r.shear.z * Az; Bz = r.shear.z * Bz; Cz = r.shear.z * Cz;
+    float T = U * Az + V * Bz + W * Cz;
+    float sT = tb_abs(T);
+    if ((T > 0.0f) != (det > 0.0f)) sT = -sT;
+    if (sT < 0.0f || sT > best.t * tb_abs(det)) return;
+    float rcpDet = 1.0f / det;
+    float t0 = T * rcpDet;
+    if (t0 < best.t && t0 > tMin) {
+        best.t = t0; best.u = V * rcpDet; best.v = W * rcpDet;
+        best.prim = tri.primitiveIndex; best.geom = tri.geometryIndex;
+    }
+}
+
+/* Stack-based near-first BVH2 walk over layout B (tb_abi.h).  Visit order, box arithmetic and the
+ * `closest` used by each box test are exactly Traverse()'s (TraverseFunction.hlsli:584-768): both
+ * children are tested when their parent is popped, the far child is pushed and the near child is
+ * visited next (the reference pushes both and pops the near one straight back, :163-180), ties go
+ * left.  stack: LDS, entry e of this lane at stack[e * stride]. */
+template <bool COUNT>
+TBD bool traverse(const SceneRefs& sc, const TbDeviceScene& ds, tb3 o, tb3 d, Hit& best, uint32_t* stack, uint32_t stride,
+                  uint32_t& boxes, uint32_t& tris)
+{
+    best.t = MAX_T; best.u = best.v = 0.0f; best.prim = best.geom = 0u;
+    RayPre r = ray_prepare(o, d);
+    float unusedT;
+    if (!box_test(unusedT, best.t, r, ld3(ds.rootCenter), ld3(ds.rootHalf))) return false; /* :566-580 */
+    uint32_t top = 0;
+    uint32_t ref = ds.rootRef;
+    for (;;) {
+        if (ref & TB_BVH_LEAF_FLAG) {
+            const TbTriB tri = sc.tris[ref & TB_BVH_INDEX_MASK];
+            if (COUNT) tris++;
+            tri_test(best, MIN_T, o, r, tri);
+            if (top == 0) break;
+            ref = stack[(--top) * stride];
+        } else {
+            const TbNodeB n = sc.nodes[ref];
+            float lt, rt;
+            bool lh = box_test(lt, best.t, r, ld3(n.lc), ld3(n.lh));
+            bool rh = box_test(rt, best.t, r, ld3(n.rc), ld3(n.rh));
+            if (COUNT) boxes += 2;
+            if (lh && rh) {
+                bool rightFirst = rt < lt;
+                stack[(top++) * stride] = rightFirst ? n.left : n.right;
+                ref = rightFirst ? n.right : n.left;
+            } else if (lh || rh) {
+                ref = rh ? n.right : n.left;
+            } else {
+                if (top == 0) break;
+                ref = stack[(--top) * stride];
+            }
+        }
+    }
+    return best.t < MAX_T;
+}
+
+/* ---- hit attributes: SharedHitGroup.h:48-151 --------------------------------------------------- */
+struct Surface { tb3 normal, tangent; float u, v; int material; };
+
+TBD float vbf(const SceneRefs& sc, uint32_t i) { return i < sc.numVertexFloats ? sc.vertices[i] : 0.0f; }
+TBD uint32_t ibu(const SceneRefs& sc, uint32_t i) { return i < sc.numIndices ? sc.indices[i] : 0u; }
+
+TBD void fetch_surface(const SceneRefs& sc, const Hit& h, Surface& s, bool needTangent)
+{
+    TbHitGroupRecord rec;
+    if (h.geom < sc.numHitGroups) rec = sc.hitGroups[h.geom];
+    else { rec.MaterialIndex = 0; rec.VertexBufferOffset = 0; rec.IndexBufferOffset = 0; }
+    const uint32_t vFirst = rec.VertexBufferOffset / 4, iFirst = rec.IndexBufferOffset / 4;
+    const uint32_t i0 = ibu(sc, iFirst + h.prim * 3), i1 = ibu(sc, iFirst + h.prim * 3 + 1), i2 = ibu(sc, iFirst + h.prim * 3 + 2);
+    const float bx = 1 - h.u - h.v, by = h.u, bz = h.v; /* GetBarycentrics3 :135-138 */
+    const uint32_t b0 = 8 * i0 + vFirst, b1 = 8 * i1 + vFirst, b2 = 8 * i2 + vFirst;
+    s.u = bx * vbf(sc, b0 + 3) + by * vbf(sc, b1 + 3) + bz * vbf(sc, b2 + 3);
+    s.v = bx * vbf(sc, b0 + 4) + by * vbf(sc, b1 + 4) + bz * vbf(sc, b2 + 4);
+    tb3 n0 = tb3_make(vbf(sc, b0), vbf(sc, b0 + 1), vbf(sc, b0 + 2)), n1 = tb3_make(vbf(sc, b1), vbf(sc, b1 + 1), vbf(sc, b1 + 2)), n2 = tb3_make(vbf(sc, b2), vbf(sc, b2 + 1), vbf(sc, b2 + 2));
+    s.normal = tb3_normalize(bx * n0 + by * n1 + bz * n2);
+    if (needTangent) {
+        tb3 t0 = tb3_make(vbf(sc, b0 + 5), vbf(sc, b0 + 6), vbf(sc, b0 + 7)), t1 = tb3_make(vbf(sc, b1 + 5), vbf(sc, b1 + 6), vbf(sc, b1 + 7)), t2 = tb3_make(vbf(sc, b2 + 5), vbf(sc, b2 + 6), vbf(sc, b2 + 7));
+        s.tangent = tb3_normalize(bx * t0 + by * t1 + bz * t2);
+    } else s.tangent = tb3_splat(0.0f);
+    s.material = (int)rec.MaterialIndex;
+}
+
+/* ---- textures: SharedRaytracing.h:55-137 -------------------------------------------------------- */
+struct F4 { float x, y, z, w; };
+TBD F4 f4(float x, float y, float z, float w) { F4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
+
+TBD uint32_t wrap_texel(float f, uint32_t n)
+{
+    float m = f - tb_floor(f / (float)n) * (float)n;
+    int i = (int)m; if (i < 0) i = 0; if (i >= (int)n) i = (int)n - 1;
+    return (uint32_t)i;
+}
+
+TBD F4 sample_bilinear_wrap(const TbFloat4* tex, uint32_t w, uint32_t h, float u, float v)
+{
+    if (!tex || w == 0 || h == 0) return f4(0, 0, 0, 0);
+    float fx = u * (float)w - 0.5f, fy = v * (float)h - 0.5f;
+    float x0f = tb_floor(fx), y0f = tb_floor(fy);
+    float tx = fx - x0f, ty = fy - y0f;
+    uint32_t x0 = wrap_texel(x0f, w), x1 = wrap_texel(x0f + 1.0f, w), y0 = wrap_texel(y0f, h), y1 = wrap_texel(y0f + 1.0f, h);
+    const TbFloat4 a = tex[y0 * w + x0], b = tex[y0 * w + x1], c = tex[y1 * w + x0], d = tex[y1 * w + x1];
+    F4 r;
+    r.x = tb_lerp(tb_lerp(a.x, b.x, tx), tb_lerp(c.x, d.x, tx), ty);
+    r.y = tb_lerp(tb_lerp(a.y, b.y, tx), tb_lerp(c.y, d.y, tx), ty);
+    r.z = tb_lerp(tb_lerp(a.z, b.z, tx), tb_lerp(c.z, d.z, tx), ty);
+    r.w = tb_lerp(tb_lerp(a.w, b.w, tx), tb_lerp(c.w, d.w, tx), ty);
+    return r;
+}
+
+TBD F4 texture_nonrecursive(const TbDeviceScene& ds, const TbTextureData& td, float u, float v)
+{
+    F4 data = f4(0, 0, 0, 0);
+    if (td.TextureType == TB_TEXTURE_TYPE_IMAGE) {
+        if (td.DescriptorHeapIndex < ds.numImages) {
+            const TbImageDesc im = ds.images[td.DescriptorHeapIndex];
+            data = sample_bilinear_wrap(ds.texelPool + im.texelOffset, im.width, im.height, u, v);
+        }
+    } else if (td.TextureType == TB_TEXTURE_TYPE_CHECKER) {
+        float su = u * td.UScale, sv = v * td.VScale;
+        data = f4(td.CheckerColor1.x, td.CheckerColor1.y, td.CheckerColor1.z, 1);
+        if ((((int)su + (int)sv) % 2) == 0) data = f4(td.CheckerColor2.x, td.CheckerColor2.y, td.CheckerColor2.z, 1);
+    }
+    if (td.TextureFlags & TB_TEXTURE_FLAG_NEEDS_GAMMA) { data.x = tb_pow(data.x, 2.2f); data.y = tb_pow(data.y, 2.2f); data.z = tb_pow(data.z, 2.2f); }
+    return data;
+}
+
+__device__ __noinline__ F4 texture_fetch(const TbDeviceScene& ds, uint32_t textureIndex, float u, float v)
+{
+    if (textureIndex == TB_INVALID_TEXTURE) return f4(0, 0, 0, 0);
+    if (ds.config.FlipTextureUVs) { u = 0.0f + u * 1.0f; v = 1.0f + v * -1.0f; }
+    if (textureIndex >= ds.numTextureData) return f4(0, 0, 0, 0);
+    const TbTextureData td = ds.textureData[textureIndex];
+    if (td.TextureType == TB_TEXTURE_TYPE_SCALE) {
+        TbTextureData z; memset(&z, 0, sizeof z);
+        const TbTextureData t1 = td.TextureIndex1 < ds.numTextureData ? ds.textureData[td.TextureIndex1] : z;
+        const TbTextureData t2 = td.TextureIndex2 < ds.numTextureData ? ds.textureData[td.TextureIndex2] : z;
+        F4 c1 = texture_nonrecursive(ds, t1, u, v), c2 = texture_nonrecursive(ds, t2, u, v);
+        return f4(c1.x * td.ScaleColor1.x + c2.x * td.ScaleColor2.x, c1.y * td.ScaleColor1.y + c2.y * td.ScaleColor2.y,
+                  c1.z * td.ScaleColor1.z + c2.z * td.ScaleColor2.z, c1.w * 1.0f + c2.w * 1.0f);
+    }
+    return texture_nonrecursive(ds, td, u, v);
+}
+
+__device__ __noinline__ tb3 sample_environment(const TbDeviceScene& ds, tb3 v) /* RayGenCommon.h:21-44 */
+{
+    const TbConfigConstants& cc = ds.config;
+    tb3 vx = tb3_make(cc.EnvMapTransformVx.x, cc.EnvMapTransformVx.y, cc.EnvMapTransformVx.z);
+    tb3 vy = tb3_make(cc.EnvMapTransformVy.x, cc.EnvMapTransformVy.y, cc.EnvMapTransformVy.z);
+    tb3 vz = tb3_make(cc.EnvMapTransformVz.x, cc.EnvMapTransformVz.y, cc.EnvMapTransformVz.z);
+    v = tb3_make(tb3_dot(v, vx), tb3_dot(v, vy), tb3_dot(v, vz));
+    tb3 dir = tb3_normalize(v);
+    float p = tb_atan2(dir.y, dir.x);
+    p = p > 0 ? p : p + 6.28f;
+    float u = p / 6.28f;
+    float w = tb_acos(dir.z) / 3.14f;
+    if (!ds.envMap) return tb3_splat(0.0f);
+    F4 s = sample_bilinear_wrap(ds.envMap, ds.envWidth, ds.envHeight, u, w);
+    return tb3_make(s.x, s.y, s.z) * ld3(cc.EnvironmentMapColorScale);
+}
+
+/* ---- materials: RayGenCommon.h:298-341, kernel.glsl:1224-1246 ---------------------------------- */
+TBD TbMaterial fetch_material(const SceneRefs& sc, uint32_t id)
+{
+    TbMaterial m;
+    if (id < sc.numMaterials) m = sc.materials[id]; else memset(&m, 0, sizeof m);
+    return m;
+}
+
+template <uint32_t F>
+TBD TbMaterial get_material(const SceneRefs& sc, const TbDeviceScene& ds, float& seed, float time, int id, float u, float v, bool back)
+{
+    TbMaterial mat = fetch_material(sc, (uint32_t)id);
+    if (back) { mat.emissive.x = mat.emissive.y = mat.emissive.z = 0.0f; }
+    if ((F & FEAT_MIX) && (mat.Flags & TB_MAT_MIX) != 0) { /* 1 R */
+        if (rnd(seed, time) < mat.albedo.z) mat = fetch_material(sc, (uint32_t)mat.albedo.x);
+        else mat = fetch_material(sc, (uint32_t)mat.albedo.y);
+    } else if (F & FEAT_TEXTURES) {
+        if (mat.albedoIndex != TB_INVALID_TEXTURE) { F4 t = texture_fetch(ds, mat.albedoIndex, u, v); mat.albedo.x = t.x; mat.albedo.y = t.y; mat.albedo.z = t.z; }
+        if (mat.emissiveIndex != TB_INVALID_TEXTURE && !back) { F4 t = texture_fetch(ds, mat.emissiveIndex, u, v); mat.emissive.x = t.x; mat.emissive.y = t.y; mat.emissive.z = t.z; }
+        if (mat.specularMapIndex != TB_INVALID_TEXTURE) { F4 t = texture_fetch(ds, mat.specularMapIndex, u, v); mat.roughness = t.y; if (t.z > 0.5f) mat.Flags |= TB_MAT_METALLIC; }
+    }
+    bool anyAlbedo = mat.albedo.x != 0.0f || mat.albedo.y != 0.0f || mat.albedo.z != 0.0f;
+    if ((F & FEAT_SSS) && (mat.Flags & TB_MAT_SUBSURFACE_SCATTER) != 0 && anyAlbedo) { /* ArtistFriendlyAlbdeoToAbsorption :1224-1233 */
+        tb3 color = ld3(mat.albedo), mfp = tb3_splat(1.0f) / ld3(mat.scattering);
+        tb3 e = (-5.09406f * color + 2.61188f * color * color) - 4.31805f * color * color * color;
+        tb3 alpha = tb3_splat(1.0f) - tb3_make(tb_exp(e.x), tb_exp(e.y), tb_exp(e.z));
+        tb3 cm = color - tb3_splat(0.8f);
+        tb3 s = (tb3_splat(1.9f) - color) + 3.5f * cm * cm;
+        tb3 transmission = tb3_splat(1.0f) / (s * mfp);
+        tb3 scattering = transmission * alpha, absorption = transmission - scattering;
+        mat.absorption.x = absorption.x; mat.absorption.y = absorption.y; mat.absorption.z = absorption.z;
+        mat.scattering.x = scattering.x; mat.scattering.y = scattering.y; mat.scattering.z = scattering.z;
+        mat.albedo.x = mat.albedo.y = mat.albedo.z = 0.0f;
+    }
+    return mat;
+}
+
+/* ---- BSDF helpers: kernel.glsl:466-478, 991-1099, 1258-1269 ------------------------------------ */
+TBD float ggx_ndf(tb3 N, tb3 H, float r2)
+{
+    r2 = tb_max(r2, MIN_ROUGHNESS_SQUARED);
+    float a2 = r2 * r2;
+    float nDotH = tb3_dot(N, H);
+    float den = PI * tb_pow(nDotH * nDotH * (a2 - 1.0f) + 1.0f, 2.0f);
+    return a2 / den;
+}
+TBD float diffuse_brdf(tb3 L, tb3 N) { return tb_max(tb3_dot(L, N), 0.0f) / PI; }
+
+TBD tb3 reorient(tb3 v, tb3 n) /* ReorientVectorAroundNormal :1001-1015 */
+{
+    tb3 t;
+    if (tb_abs(n.x) > tb_abs(n.y)) t = tb3_make(-n.z, 0, n.x) / tb_sqrt(n.x * n.x + n.z * n.z);
+    else t = tb3_make(0, n.z, -n.y) / tb_sqrt(n.y * n.y + n.z * n.z);
+    tb3 b = tb3_cross(n, t);
+    return tb3_normalize(v.x * t + v.y * n + v.z * b);
+}
+
+TBD tb3 cosine_direction(tb3 n, float r0, float r1) /* :1025-1041 */
+{
+    float r = tb_sqrt(r0);
+    float theta = (2.0f * PI) * r1;
+    float x = r * tb_cos(theta);
+    float y = tb_sqrt(tb_max(EPSILON, 1.0f - r0));
+    float z = r * tb_sin(theta);
+    return reorient(tb3_make(x, y, z), n);
+}
+
+TBD tb3 lobe_direction(tb3 n, float roughness, float r0, float r1, float& pdf) /* GenerateImportanceSampledDirection :1048-1064 */
+{
+    float lobe = tb_pow(1.0f - roughness, 5.0f) * 1000.0f;
+    float theta = (2.0f * PI) * r1;
+    float phi = tb_acos(tb_sqrt(tb_pow(r0, 1.0f / (lobe + 1.0f))));
+    tb3 d = tb3_make(tb_sin(phi) * tb_cos(theta), tb_cos(phi), tb_sin(phi) * tb_sin(theta));
+    pdf = (lobe + 1.0f) * tb_pow(tb_cos(phi), lobe) / (2.0f * PI);
+    return reorient(d, n);
+}
+
+TBD tb3 ggx_reflect(float& seed, float time, tb3 incoming, tb3 n, float roughness) /* ImportanceSampleGGX :1066-1082, 2 R */
+{
+    roughness = tb_max(MIN_ROUGHNESS, roughness);
+    float a = roughness * roughness, a2 = a * a;
+    float u1 = rnd(seed, time); float u2 = rnd(seed, time);
+    float theta = (2.0f * PI) * u2;
+    float phi = tb_acos(tb_sqrt((1.0f - u1) / ((a2 - 1.0f) * u1 + 1.0f)));
+    tb3 d = tb3_make(tb_sin(phi) * tb_cos(theta), tb_cos(phi), tb_sin(phi) * tb_sin(theta));
+    return tb3_reflect(incoming, reorient(d, n));
+}
+
+TBD float ggx_pdf(tb3 n, tb3 outgoing, tb3 h, float roughness) /* ImportanceSampleGGXPDF :1084-1094 */
+{
+    roughness = tb_max(MIN_ROUGHNESS, roughness);
+    float a = roughness * roughness, a2 = a * a;
+    float c = tb_abs(tb3_dot(n, h));
+    float e = (a2 - 1.0f) * c * c + 1.0f;
+    if (e <= 0.0f) return LARGE_NUMBER;
+    float d = a2 / (PI * e * e);
+    return d * tb_abs(tb3_dot(h, n)) / (4.0f * tb_abs(tb3_dot(outgoing, h)));
+}
+
+TBD tb3 half_vector_safe(tb3 a, tb3 b, tb3 n) { return tb3_dot(a, b) > (-1.0f + EPSILON) ? tb3_normalize(a + b) : n; }
+
+/* ---- per-path state ------------------------------------------------------------------------------ */
+enum : uint32_t {
+    ST_DONE = 0,      /* sample finished: L/weight are final, needs accumulate */
+    ST_EXTEND = 1,    /* pending ray is the bounce ray */
+    ST_SHADOW = 2,    /* pending ray is the NEE shadow feeler */
+    ST_SSS = 3,       /* pending ray is a step of the interior random walk */
+    ST_SCATTER = 4,   /* no pending ray: path_scatter() must run next */
+};
+enum : uint32_t {
+    F_SPECULAR = 1u << 0, F_PERFECT = 1u << 1, F_PREV_PERFECT = 1u << 2, F_EXITING = 1u << 3, F_NOSCATTER = 1u << 4,
+    F_AOV_DEPTH = 1u << 5, F_AOV_EMISSIVE = 1u << 6, F_HEATMAP = 1u << 7,
+};
+
+/* Fields that a feature set never touches are dead after inlining and cost no registers. */
+struct Path {
+    tb3 ro, rd;            /* pending ray */
+    tb3 T, L;              /* accumulatedIndirectLightMultiplier, accumulatedColor */
+    float seed, weight;
+    uint32_t state, flags;
+    int bounce;
+    /* live from path_on_closest to path_scatter */
+    tb3 N, Nd, prevDir, nextOrigin;
+    tb3 albedo; float roughness, specCoef, curIOR, newIOR, nDotD; int matFlags;
+    tb3 absorption, scattering;
+    tb3 contrib;           /* NEE contribution waiting for visibility: ((T*albedo)*lm)*lightColor */
+    /* SSS walk */
+    int sssStep; float maxTravel;
+    /* AOV side channel (first hit; FEAT_EXT only) */
+    tb3 aovNormal, aovAlbedo, aovEmissive, aovWorldPos; float aovNeighbor, aovDepth;
+    tb3 neighborDir;
+    uint32_t lastBoxes, lastTris;
+    uint32_t nMat, nLight; /* GetMaterial / GetOneLightSample calls of the current sample (byte model) */
+};
+
+/* kernel.glsl:1786-1798 with the identity view matrix (GetRotationFactor() == 0.5) */
+TBD tb3 lens_position(const TbPerFrameConstants& pf, float lensHeight, float u, float v, float aspect)
+{
+    tb3 p = ld3(pf.CameraPosition);
+    float lensWidth = lensHeight * aspect;
+    p = p + ld3(pf.CameraRight) * (u * 2.0f - 1.0f) * lensWidth / 2.0f;
+    p = p + ld3(pf.CameraUp) * (v * 2.0f - 1.0f) * lensHeight / 2.0f;
+    return p;
+}
+
+TBD float gaussian(float x, float mu, float sigma)
+{
+    float d = x - mu;
+    return 1.0f / tb_sqrt(2.0f * PI * sigma * sigma) * tb_exp(-tb_pow(d, 2.0f) / (2.0f * sigma * sigma));
+}
+
+TBD float halton(int b, int i) /* RayGenCommon.h:49-59 */
+{
+    float r = 0.0f, f = 1.0f;
+    while (i > 0) { f = f / (float)b; r = r + f * (float)(i % b); i = (int)tb_floor((float)i / (float)b); }
+    return r;
+}
+
+/* GetBlueNoise, RayGenCommon.h:104-122: 8 R, or 2 texel fetches + Halton23 */
+template <uint32_t F>
+TBD void blue_noise(const TbDeviceScene& ds, const TbPerFrameConstants& pf, uint32_t frame, float& seed, uint32_t x, uint32_t y, float out[8])
+{
+    if (!(F & FEAT_EXT) || !pf.UseBlueNoise) {
+        for (int i = 0; i < 8; i++) out[i] = rnd(seed, pf.Time);
+    } else {
+        uint32_t idx = (y % 256u) * 256u + (x % 256u);
+        TbFloat4 z = {0, 0, 0, 0};
+        TbFloat4 n0 = ds.blueNoise0 ? ds.blueNoise0[idx] : z, n1 = ds.blueNoise1 ? ds.blueNoise1[idx] : z;
+        float h2 = halton(2, (int)frame), h3 = halton(3, (int)frame);
+        out[0] = tb_frac(n0.x + h2); out[1] = tb_frac(n0.y + h3); out[2] = tb_frac(n0.z + h2); out[3] = tb_frac(n0.w + h3);
+        out[4] = tb_frac(n1.x + h2); out[5] = tb_frac(n1.y + h3); out[6] = tb_frac(n1.z + h2); out[7] = tb_frac(n1.w + h3);
+    }
+}
+
+/* SoftwareRayTraceCS.hlsl:38-39 + RayGenCommon.h:693-703 + kernel.glsl:1805-1906,1280-1284.
+ * `frame` is PerFrameConstants.GlobalFrameCount of this sample (a lane may be on a different frame
+ * than its neighbours in the persistent kernel, so it is not read from pf). */
+template <uint32_t F>
+TBD void path_begin(Path& p, const TbDeviceScene& ds, const TbPerFrameConstants& pf, uint32_t frame, uint32_t W, uint32_t H, uint32_t x, uint32_t y)
+{
+    p.flags = 0; p.bounce = 0; p.lastBoxes = p.lastTris = 0; p.nMat = p.nLight = 0;
+    p.aovNormal = p.aovAlbedo = p.aovEmissive = p.aovWorldPos = tb3_splat(0.0f); p.aovNeighbor = 0.0f; p.aovDepth = 0.0f;
+    p.seed = hash13((float)x, (float)y, (float)frame);
+    float resX = (float)W, resY = (float)H;
+    float dux = ((float)x + 0.5f) / resX, duy = ((float)y + 0.5f) / resY;
+    float uvx = 0.0f + dux * 1.0f, uvy = 1.0f + duy * -1.0f;
+    float pcx = uvx * resX, pcy = uvy * resY;
+    float bn[8];
+    blue_noise<F>(ds, pf, frame, p.seed, x, y, bn); /* kernel.glsl:1830 */
+    float psx = 1.0f / resX, psy = 1.0f / resY;
+    float u = pcx * psx, v = pcy * psy;
+    float jx = bn[0], jy = bn[1];
+    if ((F & FEAT_EXT) && pf.FixedPixelOffset.x >= 0.0f) { jx = pf.FixedPixelOffset.x; jy = pf.FixedPixelOffset.y; }
+    float offX = jx - 0.5f, offY = jy - 0.5f;
+    float pixelRadius = pf.FilterWidth / 2.0f;
+    float w = 1.0f;
+    if (F & FEAT_EXT) {
+        if (pf.FilterType == TB_FILTER_TYPE_TRIANGLE) w = tb_max(0.5f - tb_abs(offX), 0.5f - tb_abs(offY));
+        else if (pf.FilterType == TB_FILTER_TYPE_GAUSSIAN) {
+            float sigma = 0.8f;
+            float eX = gaussian(1.0f, 0.0f, sigma), eY = gaussian(1.0f, 0.0f, sigma);
+            w = tb_max(0.0f, gaussian(offX * 2.0f, 0.0f, sigma) - eX) * tb_max(0.0f, gaussian(offY * 2.0f, 0.0f, sigma) - eY);
+        }
+    }
+    p.weight = w;
+    u += offX * psx * (pixelRadius * 2.0f);
+    v += offY * psy * (pixelRadius * 2.0f);
+    float aspect = resX / resY;
+    tb3 camPos = ld3(pf.CameraPosition);
+    tb3 focal = camPos - pf.FocalDistance * tb3_normalize(ld3(pf.CameraLookAt) - camPos);
+    float lensHeight = ds.config.CameraLensHeight;
+    tb3 lens = lens_position(pf, lensHeight, u, v, aspect);
+    p.ro = focal; p.rd = tb3_normalize(lens - focal);
+    if (F & FEAT_EXT) {
+        tb3 nlens = lens_position(pf, lensHeight, u + psx, v + psy, aspect);
+        p.neighborDir = tb3_normalize(nlens - focal);
+        if (pf.DOFFocusDistance > 0.0f) { /* :1890-1901 */
+            tb3 focus = p.ro + p.rd * pf.DOFFocusDistance;
+            float radius = tb_sqrt(bn[6]) * pf.DOFApertureWidth;
+            float theta = bn[7] * 2.0f * PI;
+            float fx = tb_cos(theta) * radius, fy = tb_sin(theta) * radius;
+            p.ro = p.ro + (fx * ld3(pf.CameraRight) + fy * ld3(pf.CameraUp));
+            p.rd = tb3_normalize(focus - p.ro);
+        }
+    }
+    /* Trace() prologue :1280-1284 (second GetBlueNoise: 8 R whose values are unused) */
+    p.L = tb3_splat(0.0f); p.T = tb3_splat(1.0f);
+    float unused[8];
+    blue_noise<F>(ds, pf, frame, p.seed, x, y, unused);
+    p.state = pf.MaxBounces > 0 ? ST_EXTEND : ST_DONE;
+}
+
+/* Russian roulette at the top of bounce i >= 2 (kernel.glsl:1288-1302); also the loop bound */
+TBD void path_pre_extend(Path& p, const TbPerFrameConstants& pf)
+{
+    if (p.bounce >= (int)pf.MaxBounces) { p.state = ST_DONE; return; }
+    if (p.bounce >= 2) {
+        float q = tb_max(tb_max(p.T.x, p.T.y), p.T.z);
+        q = tb_max(q, EPSILON);
+        if (q < rnd(p.seed, pf.Time)) { p.state = ST_DONE; return; }
+        p.T = p.T * (1.0f / q);
+    }
+    p.state = ST_EXTEND;
+}
+
+/* GetOneLightSample, RayGenCommon.h:170-261 */
+TBD TbLight fetch_light(const SceneRefs& sc, uint32_t i)
+{
+    TbLight l;
+    if (i < sc.numLights) l = sc.lights[i]; else memset(&l, 0, sizeof l);
+    return l;
+}
+TBD tb3 random_barycentric(float& seed, float time)
+{
+    float u = rnd(seed, time);
+    float v = rnd(seed, time);
+    if (u + v > 1.0f) { u = 1.0f - u; v = 1.0f - v; }
+    return tb3_make(u, v, 1.0f - u - v);
+}
+TBD float light_target_pdf(const TbLight& l, tb3 b, tb3 P)
+{
+    tb3 lp = ld3(l.P0) * b.x + ld3(l.P1) * b.y + ld3(l.P2) * b.z;
+    float d = tb3_length(lp - P);
+    float luma = tb3_dot(ld3(l.LightColor), tb3_make(0.212671f, 0.715160f, 0.072169f));
+    return (l.SurfaceArea * luma) / d * d;
+}
+
+template <uint32_t F>
+TBD void one_light_sample(const SceneRefs& sc, const TbPerFrameConstants& pf, float& seed, tb3 P, tb3& dir, tb3& color, float& pdf, tb3& nrm, float& atten)
+{
+    dir = color = nrm = tb3_splat(0.0f); atten = 0.0f; pdf = 0.0f;
+    const uint32_t lightCount = pf.LightCount;
+    if (!(lightCount > 0 && pf.EnableNextEventEstimation)) return;
+    if ((F & FEAT_EXT) && pf.EnableSamplingImportanceResampling) { /* :180-211 */
+        uint32_t sel = 0; tb3 selB = tb3_splat(0.0f); float wsum = 0.0f;
+        for (uint32_t i = 0; i < 16; i++) {
+            uint32_t li = (uint32_t)(rnd(seed, pf.Time) * (float)lightCount);
+            TbLight l = fetch_light(sc, li);
+            tb3 b = random_barycentric(seed, pf.Time);
+            float target = light_target_pdf(l, b, P);
+            float proposal = 1.0f / (float)lightCount;
+            float w = target / (proposal * 16.0f);
+            wsum += w;
+            if (rnd(seed, pf.Time) < w / wsum) { sel = li; selB = b; }
+        }
+        TbLight l = fetch_light(sc, sel);
+        float sir = light_target_pdf(l, selB, P) / wsum;
+        pdf = sir / l.SurfaceArea;
+        tb3 lp = ld3(l.P0) * selB.x + ld3(l.P1) * selB.y + ld3(l.P2) * selB.z;
+        dir = lp - P;
+        nrm = ld3(l.N0) * selB.x + ld3(l.N1) * selB.y + ld3(l.N2) * selB.z;
+        color = ld3(l.LightColor);
+        return;
+    }
+    uint32_t li = (uint32_t)(rnd(seed, pf.Time) * (float)lightCount);
+    TbLight l = fetch_light(sc, li);
+    tb3 b = random_barycentric(seed, pf.Time);
+    if (l.LightType == TB_LIGHT_TYPE_AREA) {
+        tb3 lp = ld3(l.P0) * b.x + ld3(l.P1) * b.y + ld3(l.P2) * b.z;
+        dir = lp - P;
+        nrm = ld3(l.N0) * b.x + ld3(l.N1) * b.y + ld3(l.N2) * b.z;
+        float d = tb3_length(dir);
+        atten = 1.0f / (d * d);
+        dir = dir / d;
+    } else if ((F & FEAT_EXT) && l.LightType == TB_LIGHT_TYPE_DIRECTIONAL) {
+        dir = -ld3(l.Direction);
+        if (pf.DebugValue > 0.0f) { dir.x = tb_sin(pf.DebugValue); dir.y = tb_sin(pf.DebugValue2); dir = tb3_normalize(dir); }
+        nrm = -dir;
+        atten = 1.0f;
+    }
+    color = ld3(l.LightColor);
+    pdf = 1.0f / (float)lightCount;
+    if (l.LightType == TB_LIGHT_TYPE_AREA) pdf /= l.SurfaceArea;
+}
+
+TBD tb3 detail_normal(const TbDeviceScene& ds, const TbPerFrameConstants& pf, const TbMaterial& m, tb3 n, tb3 t, float u, float v) /* RayGenCommon.h:273-295 */
+{
+    if (m.normalMapIndex != TB_INVALID_TEXTURE && pf.EnableNormalMaps) {
+        tb3 bt = tb3_cross(t, n);
+        F4 nm = texture_fetch(ds, m.normalMapIndex, u, v);
+        float tx = (0.5f - nm.x) * 2.0f, ty = (0.5f - nm.y) * 2.0f;
+        float tz = tb_sqrt(1.0f - (tx * tx + ty * ty));
+        return tb3_normalize(t * tx + bt * ty + n * tb_max(tz, 0.02f));
+    }
+    return n;
+}
+
+/* After the closest-hit traversal of bounce p.bounce: kernel.glsl:1314-1455.
+ * Leaves the path in ST_SHADOW (shadow feeler pending), ST_SCATTER or ST_DONE. */
+template <uint32_t F>
+TBD void path_on_closest(Path& p, const SceneRefs& sc, const TbDeviceScene& ds, const TbPerFrameConstants& pf, bool isHit, const Hit& h)
+{
+    const bool first = p.bounce == 0;
+    if (p.T.x < EPSILON && p.T.y < EPSILON && p.T.z < EPSILON) { p.state = ST_DONE; return; } /* :1319-1326 */
+    if (!isHit) { /* :1328-1343 */
+        tb3 env = (F & FEAT_ENV) ? sample_environment(ds, p.rd) : tb3_splat(0.0f); /* black 1x1 texture when no map is bound */
+        p.L = p.L + p.T * env;
+        if ((F & FEAT_EXT) && first) { p.aovEmissive = p.L; p.flags |= F_AOV_EMISSIVE; }
+        p.state = ST_DONE; return;
+    }
+    Surface s;
+    fetch_surface(sc, h, s, (F & FEAT_TEXTURES) && pf.EnableNormalMaps != 0);
+    tb3 RayPoint = p.ro + p.rd * h.t;
+    p.nextOrigin = RayPoint + s.normal * EPSILON; /* :1353, unflipped normal */
+    float nDotD = tb3_dot(s.normal, p.rd);
+    const bool back = nDotD > 0.0f;
+    TbMaterial m = get_material<F>(sc, ds, p.seed, pf.Time, s.material, s.u, s.v, back);
+    p.nMat++;
+    tb3 Nd = (F & FEAT_TEXTURES) ? detail_normal(ds, pf, m, s.normal, s.tangent, s.u, s.v) : s.normal;
+    if ((F & FEAT_EXT) && first) { /* :1365-1376 */
+        tb3 camPos = ld3(pf.CameraPosition);
+        tb3 focal = camPos - pf.FocalDistance * tb3_normalize(ld3(pf.CameraLookAt) - camPos); /* neighbour ray origin, kernel.glsl:1887 */
+        tb3 npt = focal + p.neighborDir * h.t;
+        p.aovWorldPos = p.aovWorldPos + RayPoint;
+        p.aovNeighbor += tb3_length(npt - RayPoint);
+        p.aovNormal = Nd;
+        p.aovDepth = tb_saturate(h.t / pf.MaxZ); p.flags |= F_AOV_DEPTH;
+        if (pf.OutputMode == TB_OUTPUT_TYPE_HEATMAP) { p.flags |= F_HEATMAP; p.state = ST_DONE; return; }
+    }
+    tb3 N = s.normal;
+    if (F & FEAT_SSS) { p.curIOR = back ? m.IOR : AIR_IOR; p.newIOR = back ? AIR_IOR : m.IOR; }
+    if (back) { N = -N; nDotD = -nDotD; Nd = -Nd; }
+    bool spec = false;
+    if ((F & FEAT_SPECULAR) && (m.Flags & TB_MAT_NO_SPECULAR) == 0) { /* :1400-1417 */
+        if ((m.Flags & TB_MAT_METALLIC) != 0 || (m.Flags & TB_MAT_HAIR) != 0) spec = true;
+        else spec = rnd(p.seed, pf.Time) < 0.5f;
+    }
+    const bool perfect = spec && m.roughness < 0.05f;
+    const bool isLight = (m.Flags & TB_MAT_LIGHT) != 0;
+    if ((p.flags & F_PREV_PERFECT) || first || !isLight || !pf.EnableNextEventEstimation) p.L = p.L + p.T * ld3(m.emissive); /* :1425-1428 */
+    if (isLight) { p.state = ST_DONE; return; } /* :1430-1433 */
+
+    p.N = N; p.Nd = Nd; p.nDotD = nDotD; p.prevDir = p.rd;
+    p.albedo = ld3(m.albedo); p.roughness = m.roughness; p.specCoef = m.SpecularCoef; p.matFlags = m.Flags;
+    if (F & FEAT_SSS) { p.absorption = ld3(m.absorption); p.scattering = ld3(m.scattering); }
+    if ((F & FEAT_EXT) && first) p.aovEmissive = ld3(m.emissive); /* value written at :1722 if the bounce completes */
+    p.flags = (p.flags & ~(F_SPECULAR | F_PERFECT)) | (spec ? F_SPECULAR : 0u) | (perfect ? F_PERFECT : 0u);
+
+    float lpdf, latten; tb3 ldir, lcol, lnrm;
+    one_light_sample<F>(sc, pf, p.seed, RayPoint, ldir, lcol, lpdf, lnrm, latten); /* :1437 */
+    if (pf.LightCount > 0 && pf.EnableNextEventEstimation) p.nLight++;
+    if (!perfect && lpdf > EPSILON && tb3_dot(ldir, lnrm) < 0.0f) { /* :1440-1455 */
+        float lm = latten * diffuse_brdf(ldir, Nd) * tb_abs(tb3_dot(lnrm, ldir)) / lpdf;
+        /* :1514-1515 is (((T*albedo)*lm)*Shadow)*lightColor with Shadow in {0,1}: x*1 == x, so the lit
+         * value is pend*lightColor; the shadowed value is taken as contrib*0 (see path_on_shadow) */
+        p.contrib = (p.T * p.albedo * lm) * lcol;
+        p.ro = RayPoint + N * EPSILON; p.rd = ldir;
+        p.state = ST_SHADOW;
+        return;
+    }
+    p.state = ST_SCATTER;
+}
+
+/* After the shadow feeler: kernel.glsl:1460-1516.  p.rd is still the light direction. */
+template <uint32_t F>
+TBD void path_on_shadow(Path& p, const SceneRefs& sc, const TbDeviceScene& ds, const TbPerFrameConstants& pf, bool isHit, const Hit& h)
+{
+    bool lit = true;
+    if (isHit) {
+        Surface s;
+        fetch_surface(sc, h, s, false);
+        bool back = tb3_dot(s.normal, p.rd) > 0.0f;
+        TbMaterial m = get_material<F>(sc, ds, p.seed, pf.Time, s.material, s.u, s.v, back);
+        p.nMat++;
+        if ((m.Flags & TB_MAT_LIGHT) == 0) lit = false;
+    }
+    /* shadowed: (pend*0)*lightColor == +-0 for finite operands and NaN otherwise; contrib*0 has the same
+     * value except when pend*lightColor overflows fp32, which needs radiance ~1e38 (parity notes) */
+    p.L = p.L + (lit ? p.contrib : p.contrib * 0.0f);
+    p.state = ST_SCATTER;
+}
+
+TBD void finish_bounce(Path& p, const TbPerFrameConstants& pf)
+{
+    p.bounce++;
+    path_pre_extend(p, pf);
+}
+
+/* Refraction / reflection at an SSS boundary; shared by entry (:1531-1563) and exit (:1645-1678).
+ * Returns false when the path must stop the enclosing loop (`break`). */
+TBD bool refract_or_reflect(Path& p, const TbPerFrameConstants& pf, tb3 normal, float nDotD, float nr, bool perfect, bool& reflected)
+{
+    reflected = false;
+    float disc = 1.0f - nr * nr * (1.0f - nDotD * nDotD);
+    if (disc > EPSILON) {
+        tb3 refr = tb3_normalize(nr * (p.rd - normal * nDotD) - normal * tb_sqrt(disc));
+        if (perfect) { p.rd = refr; p.flags |= F_PREV_PERFECT; }
+        else {
+            float pdf;
+            float r0 = rnd(p.seed, pf.Time); float r1 = rnd(p.seed, pf.Time);
+            p.rd = lobe_direction(refr, p.roughness, r0, r1, pdf);
+            if (pdf < EPSILON) {
+                r0 = rnd(p.seed, pf.Time); r1 = rnd(p.seed, pf.Time);
+                p.rd = lobe_direction(refr, p.roughness, r0, r1, pdf);
+                if (pdf < EPSILON) return false;
+            }
+        }
+    } else {
+        p.rd = tb3_reflect(p.rd, normal);
+        reflected = true;
+    }
+    return true;
+}
+
+/* kernel.glsl:1519-1772: next direction + throughput.  Sets up the next pending ray. */
+template <uint32_t F>
+TBD void path_scatter(Path& p, const TbPerFrameConstants& pf)
+{
+    const bool first = p.bounce == 0;
+    const bool spec = (F & FEAT_SPECULAR) && (p.flags & F_SPECULAR) != 0, perfect = (F & FEAT_SPECULAR) && (p.flags & F_PERFECT) != 0;
+    const bool allowsSpec = (F & FEAT_SPECULAR) && (p.matFlags & TB_MAT_NO_SPECULAR) == 0, metallic = (F & FEAT_SPECULAR) && (p.matFlags & TB_MAT_METALLIC) != 0;
+    p.rd = p.prevDir; p.ro = p.nextOrigin;
+    p.flags = (p.flags & ~F_PREV_PERFECT) | (perfect ? F_PREV_PERFECT : 0u); /* :1520 */
+    if (spec) {
+        p.rd = ggx_reflect(p.seed, pf.Time, p.prevDir, p.N, p.roughness); /* :1521-1526 */
+    } else if ((F & FEAT_SSS) && (p.matFlags & TB_MAT_SUBSURFACE_SCATTER) != 0) { /* :1529-1600 */
+        bool reflected;
+        if (!refract_or_reflect(p, pf, p.N, p.nDotD, p.curIOR / p.newIOR, perfect, reflected)) { p.state = ST_DONE; return; } /* :1552 */
+        bool noScatter = p.scattering.x < EPSILON;
+        float perScatter = 1.0f / ((p.scattering.x + p.scattering.y + p.scattering.z) / 3.0f);
+        p.maxTravel = noScatter ? LARGE_NUMBER : perScatter;
+        bool exiting = (p.matFlags & TB_MAT_SINGLE_SIDED) != 0;
+        p.flags = (p.flags & ~(F_EXITING | F_NOSCATTER)) | (exiting ? F_EXITING : 0u) | (noScatter ? F_NOSCATTER : 0u);
+        p.sssStep = 0;
+        if (exiting) { finish_bounce(p, pf); return; } /* loop body never runs, then `continue` :1690 */
+        p.state = ST_SSS; /* first walk step's ray is (p.ro, p.rd) */
+        return;
+    } else {
+        float r0 = rnd(p.seed, pf.Time); float r1 = rnd(p.seed, pf.Time);
+        p.rd = cosine_direction(p.N, r0, r1); /* :1695 */
+    }
+    float diffusePdf = tb3_dot(p.rd, p.N) / PI; /* :1699 */
+    if (allowsSpec) {
+        tb3 hv = half_vector_safe(-p.prevDir, p.rd, p.N);
+        float specPdf = ggx_pdf(p.N, p.rd, hv, p.roughness);
+        float pdf = metallic ? specPdf : tb_lerp(specPdf, diffusePdf, 0.5f);
+        p.T = p.T / pdf;
+    } else {
+        p.T = p.T / diffusePdf;
+    }
+    if ((F & FEAT_EXT) && first) p.flags |= F_AOV_EMISSIVE; /* :1720-1723 (value stored in path_on_closest) */
+    tb3 albedo = ((F & FEAT_EXT) && pf.IsRealTime && first) ? tb3_splat(1.0f) : p.albedo;
+    if (metallic) { /* :1734-1741 */
+        tb3 hv = tb3_normalize(-p.prevDir + p.rd);
+        float r2 = tb_max(p.roughness * p.roughness, MIN_ROUGHNESS_SQUARED);
+        float specular = ggx_ndf(p.Nd, hv, r2) / (4.0f * tb_abs(tb3_dot(-p.prevDir, hv)) * tb_max(tb_abs(tb3_dot(-p.prevDir, p.N)), tb_abs(tb3_dot(p.rd, p.N))));
+        p.T = p.T * (specular * albedo * tb_saturate(tb3_dot(p.rd, p.N)));
+    } else if (allowsSpec) { /* :1744-1765 */
+        tb3 hv = half_vector_safe(-p.prevDir, p.rd, p.N);
+        float fresnel = p.specCoef + (1.0f - p.specCoef) * tb_pow(tb_abs(1.0f - tb3_dot(-p.prevDir, hv)), 5.0f);
+        float dm = (float)(28.0 / (23.0 * 3.1415926535)) * (1.0f - p.specCoef)
+            * (1.0f - tb_pow(1.0f - 0.5f * tb3_dot(-p.prevDir, p.N), 5.0f))
+            * (1.0f - tb_pow(1.0f - 0.5f * tb3_dot(p.rd, p.N), 5.0f));
+        tb3 diffuse = albedo * dm;
+        float r2 = tb_max(p.roughness * p.roughness, MIN_ROUGHNESS_SQUARED);
+        float specular = ggx_ndf(p.Nd, hv, r2) / (4.0f * tb_abs(tb3_dot(-p.prevDir, hv)) * tb_max(tb_abs(tb3_dot(-p.prevDir, p.N)), tb_abs(tb3_dot(p.rd, p.N))));
+        tb3 mult = (diffuse + tb3_splat(fresnel * specular)) * tb_saturate(tb3_dot(p.rd, p.N));
+        p.T = p.T * mult;
+    } else { /* :1766-1769 */
+        p.T = p.T * (albedo * diffuse_brdf(p.rd, p.Nd));
+    }
+    if ((F & FEAT_EXT) && first) p.aovAlbedo = p.albedo; /* :1771 */
+    finish_bounce(p, pf);
+}
+
+/* One step of the interior random walk after its traversal: kernel.glsl:1601-1687.
+ * The step's travelDistance R is drawn BEFORE the traversal in the reference (:1603); callers
+ * draw it with sss_travel() when they issue the ray. */
+TBD float sss_travel(Path& p, const TbPerFrameConstants& pf) { return tb_max(-tb_log(rnd(p.seed, pf.Time)), 0.1f) * p.maxTravel; }
+
+TBD void path_on_sss(Path& p, const SceneRefs& sc, const TbPerFrameConstants& pf, bool isHit, const Hit& h, float travel)
+{
+    const bool perfect = (p.flags & F_PERFECT) != 0, noScatter = (p.flags & F_NOSCATTER) != 0;
+    if (!isHit) { p.T = tb3_splat(0.0f); finish_bounce(p, pf); return; } /* :1610-1615 then :1690 */
+    Surface s;
+    fetch_surface(sc, h, s, false);
+    tb3 normal = s.normal;
+    float t = tb_min(travel, h.t);
+    bool exiting = t < travel || noScatter;
+    bool lastRay = p.sssStep == MAX_SSS_BOUNCES - 1;
+    if (lastRay && !exiting) p.T = tb3_splat(0.0f);
+    tb3 RayPoint = p.ro + p.rd * t;
+    p.ro = RayPoint + normal * EPSILON;
+    p.T = p.T * tb3_make(tb_exp(-t * p.absorption.x), tb_exp(-t * p.absorption.y), tb_exp(-t * p.absorption.z));
+    bool stop = false;
+    if (exiting) {
+        float nDotD = tb3_dot(normal, p.rd);
+        if (nDotD >= 0.0f) { normal = -normal; nDotD = -nDotD; }
+        bool reflected;
+        if (!refract_or_reflect(p, pf, normal, nDotD, p.newIOR / p.curIOR, perfect, reflected)) stop = true; /* :1666 leaves the walk */
+        else if (reflected) exiting = false;
+    } else {
+        float u1 = rnd(p.seed, pf.Time); float u2 = rnd(p.seed, pf.Time); /* GenerateRandomDirection :991-999 */
+        float r = tb_sqrt(1.0f - u1 * u1);
+        float phi = 6.28f * u2;
+        p.rd = tb3_make(tb_cos(phi) * r, tb_sin(phi) * r, u1);
+        p.T = p.T / 1.0f;
+    }
+    p.sssStep++;
+    if (stop || exiting || p.sssStep >= MAX_SSS_BOUNCES) { finish_bounce(p, pf); return; } /* `continue` :1690 */
+    p.state = ST_SSS;
+}
+
+} // namespace pt

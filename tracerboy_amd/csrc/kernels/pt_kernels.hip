@@ -1,0 +1,110 @@
+/* pt_kernels.hip -- gfx950 kernels of the path tracer and their launchers.
+ *
+ * pt_persistent<SCENE_LDS, COUNT>: the replacement of SoftwareRayTraceCS::main
+ * (/root/reference/TracerBoy/SoftwareRayTraceCS.hlsl:9-51).  One lane owns one pixel for ALL
+ * frames of the launch ("persistent" lanes with path regeneration): when its path ends it
+ * accumulates the sample exactly like RayGenCommon.h:704-727 and immediately starts the next
+ * frame's path, so a wavefront only idles at the very end of the launch instead of at the end of
+ * every frame's longest path.  Per-pixel sample order is frame order, so the fp32 accumulation is
+ * bit-identical to the reference's one-dispatch-per-frame loop.
+ *   - every loop iteration casts exactly one ray per live lane (bounce, shadow or SSS ray), through
+ *     ONE traversal instance -> no duplicated traversal code, ray types share the wave;
+ *   - wave = 8x8 pixel tile (the reference's thread-group shape), block = 2x2 tiles;
+ *   - traversal stack in LDS, [entry][lane] layout (bank-conflict free, unlike the reference's
+ *     lane*16+entry, TraverseFunction.hlsli:147-154);
+ *   - SCENE_LDS: scenes whose whole kernel-visible image (nodes, triangles, hit-group records,
+ *     indices, vertices, materials, lights) fits the LDS budget are copied into LDS once per block
+ *     with coalesced 16-B loads; all traversal and shading fetches are then ds_reads.
+ */
+#include <hip/hip_runtime.h>
+#include "pt_common.hpp"
+#include "pt_launch.h"
+
+namespace {
+
+/* Closest-hit batch for the traversal parity tests (IntersectWithMaxDistance, RayGenCommon.h:365-414) */
+__global__ __launch_bounds__(BLOCK) void trace_closest_kernel(TbDeviceScene ds, uint32_t n, const float* origins, const float* dirs, float* outT, int* outMat,
+                                                               float* outBary, uint32_t* outPrim, uint32_t* outGeom, float* outNormal, float* outUV,
+                                                               uint32_t* outBoxes, uint32_t* outTris)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint32_t* stack = (uint32_t*)smem + threadIdx.x;
+    SceneRefs sc; make_refs<false>(sc, ds, nullptr);
+    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    tb3 o = ld3(origins + 3 * i), d = ld3(dirs + 3 * i);
+    Hit h; uint32_t nb = 0, nt = 0;
+    bool hit = traverse<true>(sc, ds, o, d, h, stack, BLOCK, nb, nt);
+    outT[i] = hit ? h.t : -1.0f;
+    if (outBary) { outBary[2 * i] = hit ? h.u : 0.0f; outBary[2 * i + 1] = hit ? h.v : 0.0f; }
+    if (outPrim) outPrim[i] = hit ? h.prim : 0xffffffffu;
+    if (outGeom) outGeom[i] = hit ? h.geom : 0xffffffffu;
+    if (outBoxes) outBoxes[i] = nb;
+    if (outTris) outTris[i] = nt;
+    Surface s; s.normal = tb3_splat(0.0f); s.u = s.v = 0.0f; s.material = -1;
+    if (hit) fetch_surface(sc, h, s, false);
+    if (outMat) outMat[i] = s.material;
+    if (outNormal) { outNormal[3 * i] = s.normal.x; outNormal[3 * i + 1] = s.normal.y; outNormal[3 * i + 2] = s.normal.z; }
+    if (outUV) { outUV[2 * i] = s.u; outUV[2 * i + 1] = s.v; }
+}
+
+__global__ void device_math_kernel(int fn, uint32_t n, const float* a, const float* b, float* out)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float x = a[i], y = b ? b[i] : 0.0f, r = 0.0f;
+    switch (fn) {
+    case 0: r = tb_sin(x); break; case 1: r = tb_cos(x); break; case 2: r = tb_acos(x); break; case 3: r = tb_atan2(x, y); break;
+    case 4: r = tb_exp(x); break; case 5: r = tb_log(x); break; case 6: r = tb_pow(x, y); break; case 7: r = tb_sqrt(x); break;
+    case 8: r = tb_exp2(x); break; case 9: r = tb_log2(x); break; case 10: r = tb_asin(x); break;
+    case 11: r = x / y; break; case 12: r = tb_frac(tb_sin(x + y) * 43758.5453123f); break; case 13: r = hash13(x, y, 0.0f); break;
+    default: break;
+    }
+    out[i] = r;
+}
+
+/* tile-major pack of the pixels this rank owns (tb_pack_owned_device) */
+__global__ void pack_owned_kernel(const TbFloat4* full, TbFloat4* packed, uint32_t W, uint32_t H, TbTileMap tiles, uint32_t numOwnedTiles)
+{
+    uint32_t tilesX = (W + tiles.tileW - 1) / tiles.tileW;
+    uint32_t local = blockIdx.x; /* index among owned tiles */
+    if (local >= numOwnedTiles) return;
+    uint32_t t = tiles.rank + local * tiles.world;
+    uint32_t tx = t % tilesX, ty = t / tilesX;
+    uint32_t x0 = tx * tiles.tileW, y0 = ty * tiles.tileH;
+    uint32_t tw = min(tiles.tileW, W - x0), th = min(tiles.tileH, H - y0);
+    size_t base = (size_t)local * tiles.tileW * tiles.tileH;
+    for (uint32_t i = threadIdx.x; i < tw * th; i += blockDim.x) {
+        uint32_t lx = i % tw, ly = i / tw;
+        packed[base + i] = full[(size_t)(y0 + ly) * W + (x0 + lx)];
+    }
+}
+
+} // namespace
+
+extern "C" {
+
+hipError_t pt_launch_trace_closest(hipStream_t stream, const TbDeviceScene* ds, uint32_t n, const float* origins, const float* dirs, float* outT, int* outMat,
+                                   float* outBary, uint32_t* outPrim, uint32_t* outGeom, float* outNormal, float* outUV, uint32_t* outBoxes, uint32_t* outTris)
+{
+    size_t lds = (size_t)ds->stackDepth * BLOCK * 4;
+    hipError_t e = hipFuncSetAttribute((const void*)trace_closest_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(trace_closest_kernel, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), lds, stream, *ds, n, origins, dirs, outT, outMat, outBary, outPrim, outGeom, outNormal, outUV, outBoxes, outTris);
+    return hipGetLastError();
+}
+
+hipError_t pt_launch_device_math(hipStream_t stream, int fn, uint32_t n, const float* a, const float* b, float* out)
+{
+    hipLaunchKernelGGL(device_math_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, fn, n, a, b, out);
+    return hipGetLastError();
+}
+
+hipError_t pt_launch_pack_owned(hipStream_t stream, const TbFloat4* full, TbFloat4* packed, uint32_t W, uint32_t H, const TbTileMap* tiles, uint32_t numOwnedTiles)
+{
+    if (numOwnedTiles == 0) return hipSuccess;
+    hipLaunchKernelGGL(pack_owned_kernel, dim3(numOwnedTiles), dim3(256), 0, stream, full, packed, W, H, *tiles, numOwnedTiles);
+    return hipGetLastError();
+}
+
+} // extern "C"

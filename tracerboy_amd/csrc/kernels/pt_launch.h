@@ -1,0 +1,17 @@
+/* pt_launch.h -- C launch interface between the host context and the kernel translation units. */
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include "pt_scene.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+hipError_t pt_launch_persistent(hipStream_t stream, const TbDeviceScene* ds, const TbPerFrameConstants* pf, const TbDeviceTargets* tg, uint32_t W, uint32_t H,
+                                uint32_t firstFrame, uint32_t numFrames, const TbTileMap* tiles, int sceneInLds, int countRays);
+hipError_t pt_launch_trace_closest(hipStream_t stream, const TbDeviceScene* ds, uint32_t n, const float* origins, const float* dirs, float* outT, int* outMat,
+                                   float* outBary, uint32_t* outPrim, uint32_t* outGeom, float* outNormal, float* outUV, uint32_t* outBoxes, uint32_t* outTris);
+hipError_t pt_launch_device_math(hipStream_t stream, int fn, uint32_t n, const float* a, const float* b, float* out);
+hipError_t pt_launch_pack_owned(hipStream_t stream, const TbFloat4* full, TbFloat4* packed, uint32_t W, uint32_t H, const TbTileMap* tiles, uint32_t numOwnedTiles);
+#ifdef __cplusplus
+}
+#endif

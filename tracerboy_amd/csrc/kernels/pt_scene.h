@@ -1,0 +1,47 @@
+/* pt_scene.h -- device-side view of the scene and launch parameters shared by every kernel. */
+#pragma once
+#include "../../../include/tb_abi.h"
+#include <stdint.h>
+
+/* What the kernels read, as device pointers (the HIP replacement of the root signature at
+ * /root/reference/TracerBoy/TracerBoy.cpp:568-664 / SharedRaytracing.h:3-53). */
+struct TbDeviceScene {
+    const TbNodeB* nodes;        /* layout B, breadth-first order: the first `ldsNodes` are the top of the tree */
+    const TbTriB* tris;
+    uint32_t rootRef;            /* child-ref of the root */
+    uint32_t numNodes, numTris;
+    float rootCenter[3], rootHalf[3];
+    const TbHitGroupRecord* hitGroups;   uint32_t numHitGroups;
+    const uint32_t* indexBuffer;         uint32_t numIndices;
+    const float* vertexBuffer;           uint32_t numVertexFloats;
+    const TbMaterial* materials;         uint32_t numMaterials;
+    const TbTextureData* textureData;    uint32_t numTextureData;
+    const TbLight* lights;               uint32_t numLights;
+    const TbImageDesc* images;           uint32_t numImages;
+    const TbFloat4* texelPool;
+    const TbFloat4* envMap;              uint32_t envWidth, envHeight;
+    const TbFloat4* blueNoise0;
+    const TbFloat4* blueNoise1;
+    TbConfigConstants config;
+    uint32_t stackDepth;         /* entries per lane of the traversal stack (bvh max depth + 2) */
+    /* whole-scene-in-LDS image (small scenes): byte offsets inside one contiguous device blob */
+    const uint8_t* ldsBlob;      uint32_t ldsBlobBytes;
+    uint32_t offNodes, offTris, offHitGroups, offIndices, offVertices, offMaterials, offLights;
+};
+
+/* Output surfaces of one dispatch (u0..u7, u10 of SharedRaytracing.h:13-23) */
+struct TbDeviceTargets {
+    TbFloat4* output;      /* u0 */
+    TbFloat4* jittered;    /* u1 */
+    TbFloat4* aovNormals;  /* u2, nullable */
+    TbFloat4* aovWorldPos0, *aovWorldPos1; /* u3,u4 */
+    TbFloat4* aovCustom;   /* u5 */
+    float* aovDepth;       /* u6 */
+    TbFloat4* aovEmissive; /* u7 */
+    uint32_t* stats;       /* u10: [0]=ActiveWaves(groups) [1]=ActivePixels [2]=SelectedPixelDistance [3]=SelectedMaterialID */
+    unsigned long long* rayStats; /* 7 x u64 (TbRayStats), nullable */
+};
+
+struct TbTileMap { /* multi-GPU tile ownership: tile t is rendered iff t % world == rank */
+    uint32_t rank, world, tileW, tileH;
+};

@@ -1,0 +1,6 @@
+/* pt_variant_surf.hip -- persistent path-tracing kernel compiled for feature set "surf" (pt_device_features.h). */
+#include "pt_device_features.h"
+#define PT_FEATURES (PT_FEAT_ENV | PT_FEAT_SPECULAR | PT_FEAT_TEXTURES)
+#define PT_NAME surf
+#define PT_COUNT 0
+#include "pt_variant.inc"
