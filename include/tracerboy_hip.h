@@ -170,6 +170,8 @@ int tb_host_scene_info(tb_host_scene* s, tb_scene_info* info);
 int tb_host_scene_frame_constants(tb_host_scene* s, const tb_output_settings* settings, uint32_t frame, float time_seed, TbPerFrameConstants* out);
 /* layout-B arrays (what the kernels fetch) and the per-triangle builder inputs */
 int tb_host_scene_layout_b(tb_host_scene* s, const TbNodeB** nodes, uint32_t* num_nodes, const TbTriB** tris, uint32_t* num_tris, uint32_t* root_ref);
+/* Diagnostic: the build's own parse of a PBRT file in the record format of oracle/ref_dump.cpp. */
+int tb_host_pbrt_dump(const char* pbrt_path, const char* out_path, char* err, uint32_t err_len);
 int tb_host_scene_triangles(tb_host_scene* s, const float** positions, uint32_t* num_vertices, const uint32_t** tri_vertex_index,
                             const uint32_t** tri_geometry, const uint32_t** tri_primitive, const uint32_t** tri_flags, uint32_t* num_triangles);
 

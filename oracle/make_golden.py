@@ -1,0 +1,114 @@
+#!/usr/bin/env python3
+"""Generates the fixtures under tests/golden/ (run in the build container only; needs /root/reference
+and `make -C oracle ref`).  TEST INFRASTRUCTURE ONLY.
+
+  cornell-box.parser.txt      the REFERENCE parser's view of Scenes/cornell-box (oracle/_ref/pbrt_dump),
+                              bit patterns in hex; pins tracerboy_amd's own PBRT loader
+  teapot.parser.digest.json   per-record sha256 digest of the same dump for Scenes/Teapot (126 050 tris)
+  scenes/cornell-box/         the scene file itself (input data)
+  scenes/Teapot/              geometry (CC0) + scene file with the infinite light pointed at a synthetic
+                              sky (the original env map is non-commercial and is NOT copied)
+  bluenoise{0,1}.rgba8        the two 256x256 RGBA8 blue-noise tiles TracerBoy binds at t14/t15, as raw bytes
+  cornell_oracle_64x48x3.npy  oracle radiance (frames 0..2, depth 4) for regression of the oracle itself
+"""
+import hashlib
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+GOLD = os.path.join(ROOT, "tests", "golden")
+DUMP = os.path.join(ROOT, "oracle", "_ref", "pbrt_dump")
+
+
+def digest_records(path):
+    out = []
+    with open(path) as f:
+        for line in f:
+            parts = line.rstrip("\n").split(" ")
+            name, count, vals = parts[0], parts[1], parts[2:]
+            if name == "material_ptr":
+                continue
+            if len(vals) <= 16:
+                out.append([name, count, " ".join(vals)])
+            else:
+                out.append([name, count, "sha256:" + hashlib.sha256(" ".join(vals).encode()).hexdigest(), " ".join(vals[:6])])
+    return out
+
+
+def write_rgbe(path, img):
+    """Radiance .hdr, flat (non-RLE) scanlines, -Y H +X W."""
+    h, w, _ = img.shape
+    m = img.max(axis=2)
+    e = np.where(m > 1e-32, np.floor(np.log2(np.maximum(m, 1e-38))) + 1, 0)
+    scale = np.where(m > 1e-32, 256.0 / np.exp2(e), 0.0)
+    rgb = np.clip(img * scale[..., None], 0, 255).astype(np.uint8)
+    ee = np.where(m > 1e-32, e + 128, 0).astype(np.uint8)
+    data = np.concatenate([rgb, ee[..., None]], axis=2)
+    with open(path, "wb") as f:
+        f.write(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n")
+        f.write(("-Y %d +X %d\n" % (h, w)).encode())
+        f.write(data.tobytes())
+
+
+def synthetic_sky(w=256, h=128):
+    v, u = np.meshgrid((np.arange(h) + 0.5) / h, (np.arange(w) + 0.5) / w, indexing="ij")
+    theta, phi = v * np.pi, u * 2 * np.pi
+    d = np.stack([np.sin(theta) * np.cos(phi), np.sin(theta) * np.sin(phi), np.cos(theta)], axis=-1)
+    up = np.clip(d[..., 2], -1, 1)
+    sky = np.stack([0.35 + 0.25 * (1 - up), 0.45 + 0.25 * (1 - up), 0.8 + 0.1 * up], axis=-1) * (0.6 + 0.4 * np.clip(up, 0, 1))[..., None]
+    ground = np.array([0.18, 0.16, 0.14])[None, None, :] * np.ones_like(sky)
+    img = np.where((up > 0)[..., None], sky, ground)
+    sun = np.array([0.4, 0.5, 0.768]); sun /= np.linalg.norm(sun)
+    c = (d * sun).sum(-1)
+    img = img + np.exp((c - 1) * 400.0)[..., None] * np.array([60.0, 52.0, 40.0])
+    return img.astype(np.float32)
+
+
+def main():
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "all", "ref"], check=True)
+    os.makedirs(GOLD, exist_ok=True)
+    # 1. scenes
+    os.makedirs(os.path.join(GOLD, "scenes", "cornell-box"), exist_ok=True)
+    shutil.copyfile(os.path.join(REF, "Scenes/cornell-box/scene.pbrt"), os.path.join(GOLD, "scenes/cornell-box/scene.pbrt"))
+    tp = os.path.join(GOLD, "scenes", "Teapot")
+    os.makedirs(os.path.join(tp, "models"), exist_ok=True); os.makedirs(os.path.join(tp, "textures"), exist_ok=True)
+    for f in ("models/Mesh000.ply", "models/Mesh001.ply", "LICENSE.txt"):
+        shutil.copyfile(os.path.join(REF, "Scenes/Teapot", f), os.path.join(tp, f))
+    text = open(os.path.join(REF, "Scenes/Teapot/scene.pbrt")).read()
+    assert "textures/envmap.hdr" in text
+    open(os.path.join(tp, "scene.pbrt"), "w").write(text.replace("textures/envmap.hdr", "textures/sky.hdr"))
+    write_rgbe(os.path.join(tp, "textures", "sky.hdr"), synthetic_sky())
+    # 2. reference-parser dumps
+    tmp = "/tmp/_tb_dump.txt"
+    subprocess.run([DUMP, os.path.join(REF, "Scenes/cornell-box/scene.pbrt"), tmp], check=True, stdout=subprocess.DEVNULL)
+    with open(tmp) as f, open(os.path.join(GOLD, "cornell-box.parser.txt"), "w") as g:
+        for line in f:
+            if not line.startswith("material_ptr"):
+                g.write(line)
+    subprocess.run([DUMP, os.path.join(REF, "Scenes/Teapot/scene.pbrt"), tmp], check=True, stdout=subprocess.DEVNULL)
+    json.dump(digest_records(tmp), open(os.path.join(GOLD, "teapot.parser.digest.json"), "w"), indent=0)
+    # 3. blue-noise tiles (data files of the reference: TracerBoy/Textures/LDR_RGBA_{0,1}.png, TracerBoy.cpp:2129-2130)
+    from PIL import Image
+    for i in (0, 1):
+        im = np.asarray(Image.open(os.path.join(REF, "TracerBoy/Textures/LDR_RGBA_%d.png" % i)).convert("RGBA"), np.uint8)
+        assert im.shape == (256, 256, 4)
+        im.tofile(os.path.join(GOLD, "bluenoise%d.rgba8" % i))
+    # 4. oracle regression image
+    import oracle_lib as ol
+    from tracerboy_amd import api
+    hs = api.HostScene(os.path.join(GOLD, "scenes/cornell-box/scene.pbrt"))
+    s = api.GetDefaultOutputSettings(); s.EnableBlueNoise = 0; s.MaxBounces = 4
+    img = ol.render(hs.view(), hs.frame_constants(s, 0, 0.0), 64, 48, 3, threads=4)["output"]
+    np.save(os.path.join(GOLD, "cornell_oracle_64x48x3.npy"), img)
+    print("fixtures written under", GOLD)
+
+
+if __name__ == "__main__":
+    main()

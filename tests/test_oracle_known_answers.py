@@ -1,0 +1,135 @@
+"""Pins the CPU oracle against the known-answer material inside the reference."""
+import ctypes as C
+import math
+
+import numpy as np
+
+import oracle_lib as ol
+
+
+def test_hash13_seed_values(built):
+    # RayGenCommon.h:662-667 evaluated in fp32
+    L = ol.lib()
+    assert L.tbo_hash13(0, 0, 0) == 0.0
+    assert abs(L.tbo_hash13(1, 0, 0) - 0.970919) < 2e-6
+    assert abs(L.tbo_hash13(960, 540, 0) - 0.172363) < 2e-6
+    # numpy fp32 re-derivation with the pinned association order
+    def h(x, y, z):
+        f = np.float32
+        p = [f(v) * f(.1031) for v in (x, y, z)]
+        p = [v - np.floor(v) for v in p]
+        q = [p[1] + f(33.33), p[2] + f(33.33), p[0] + f(33.33)]
+        d = (p[0] * q[0] + p[1] * q[1]) + p[2] * q[2]
+        p = [v + d for v in p]
+        r = (p[0] + p[1]) * p[2]
+        return r - np.floor(r)
+    for x, y, z in [(1, 0, 0), (960, 540, 0), (17, 333, 5), (1919, 1079, 63)]:
+        assert L.tbo_hash13(x, y, z) == float(h(x, y, z))
+
+
+def test_rand_stream_is_frac_sin(built):
+    # kernel.glsl:39-40: fract(sin(seed++ + Time) * 43758.5453123), every value in [0,1)
+    out = np.zeros(256, np.float32)
+    ol.lib().tbo_rand_stream(0.25, 0.0, 256, out.ctypes.data_as(C.c_void_p))
+    assert (out >= 0).all() and (out < 1).all()
+    ref = np.array([math.sin(0.25 + i) * 43758.5453123 for i in range(256)])
+    ref = ref - np.floor(ref)
+    # fp32 sin + fp32 multiply: agree with the double evaluation to ~43758 * 1e-7
+    d = np.abs(out - ref); d = np.minimum(d, 1 - d)
+    assert d.max() < 2e-2
+    assert 0.4 < out.mean() < 0.6
+
+
+def test_camera_matches_shadertoy_cornell_constants(cornell_host):
+    # kernel.glsl:720-744 hard-codes the camera the host derives from cornell-box/scene.pbrt
+    c = cornell_host.camera()
+    assert list(c.Right) == [1.0, 0.0, 0.0] or list(c.Right) == [1.0, 0.0, -0.0]
+    assert abs(c.Position[0]) < 1e-7 and abs(c.Position[1] - 1.0) < 1e-7 and abs(c.Position[2] - 0.97) < 1e-3
+    assert abs(c.LookAt[2] - (c.Position[2] - 1.0)) < 1e-6
+    assert c.LensHeight == 2.0
+    assert abs(c.FocalDistance - 5.819) < 1e-3
+    assert abs(c.FocalDistance - 5.819657) < 2e-6 and abs(c.Position[2] - 0.970343) < 2e-6
+
+
+def test_cornell_albedos_and_light_match_shadertoy_scene(cornell_host):
+    # kernel.glsl:933-936,983 and scene.pbrt:8-15,31
+    v = cornell_host.view()
+    mats = [v.materials[i] for i in range(v.numMaterials)]
+    alb = sorted((round(m.albedo.x, 3), round(m.albedo.y, 3), round(m.albedo.z, 3)) for m in mats)
+    assert (0.725, 0.71, 0.68) in alb and (0.63, 0.065, 0.05) in alb and (0.14, 0.45, 0.091) in alb
+    lights = [v.lights[i] for i in range(v.numLights)]
+    assert len(lights) == 2
+    for l in lights:
+        assert (l.LightColor.x, l.LightColor.y, l.LightColor.z) == (17.0, 12.0, 4.0)
+        assert abs(l.SurfaceArea - 0.0893) < 1e-4  # 0.47 * 0.38 / 2
+    flags = [m.Flags for m in mats]
+    assert all(f & 0x4 and f & 0x20 for f in flags)  # NO_SPECULAR | NO_ALPHA
+    assert sum(1 for f in flags if f & 0x10) == 1   # one LIGHT material
+
+
+def test_primary_ray_through_image_centre(cornell_host, settings):
+    pf = cornell_host.frame_constants(settings, 0, 0.0)
+    o = (C.c_float * 3)(); d = (C.c_float * 3)()
+    ol.lib().tbo_camera_ray(C.byref(pf), 2.0, 512, 512, 256.0, 256.0, 0.5, 0.5, C.byref(o), C.byref(d))
+    assert abs(d[0]) < 1e-6 and abs(d[1]) < 1e-6 and abs(d[2] + 1.0) < 1e-6
+    # the eye (focal point) sits FocalDistance behind the lens plane: z = 0.970343 + 5.819657 = 6.79 = 6.8 - 0.01
+    assert abs(o[2] - 6.79) < 1e-5 and abs(o[1] - 1.0) < 1e-6
+
+
+def test_direct_light_on_floor_centre_is_analytic(cornell_host, settings):
+    """Energy check of NEE: radiance leaving the floor centre towards the camera after ONE bounce equals
+    albedo/pi * integral of L cos cos / r^2 over the light, which the estimator must reproduce in the mean."""
+    import copy
+    s = copy.copy(settings); s.MaxBounces = 1  # primary hit + NEE only: pure direct lighting
+    view = cornell_host.view()
+    W = H = 64
+    pf = cornell_host.frame_constants(s, 0, 0.0)
+    img = ol.render(view, pf, W, H, 64, threads=8)["output"]
+    rgb = img[..., :3] / img[..., 3:]
+    # unshadowed floor patch in front of the boxes, left of the short box (x ~ -0.4, z ~ 0.7..0.9)
+    rows, cols = range(62, 64), range(18, 22)
+    n = 64
+    xs = np.linspace(-0.24, 0.23, n, endpoint=False) + 0.47 / n / 2   # light quad, scene.pbrt:33
+    zs = np.linspace(-0.22, 0.16, n, endpoint=False) + 0.38 / n / 2
+    X, Z = np.meshgrid(xs, zs)
+    got, expect = [], []
+    for y in rows:
+        for x in cols:
+            o = (C.c_float * 3)(); d = (C.c_float * 3)()
+            ol.lib().tbo_camera_ray(C.byref(pf), 2.0, W, H, x + 0.5, H - (y + 0.5), 0.5, 0.5, C.byref(o), C.byref(d))
+            t = -o[1] / d[1]
+            P = np.array([o[0] + t * d[0], 0.0, o[2] + t * d[2]])
+            dx, dy, dz = X - P[0], 1.98 - P[1], Z - P[2]
+            r2 = dx * dx + dy * dy + dz * dz
+            cos = dy / np.sqrt(r2)
+            E = (cos * cos / r2).sum() * (0.47 / n) * (0.38 / n)
+            expect.append(np.array([0.725, 0.71, 0.68]) / math.pi * np.array([17.0, 12.0, 4.0]) * E)
+            got.append(rgb[y, x])
+    got, expect = np.mean(got, axis=0), np.mean(expect, axis=0)
+    assert np.all(np.abs(got - expect) / expect < 0.08), (got, expect)
+
+
+def test_render_threads_and_strips_are_bit_identical(cornell_host, settings):
+    view = cornell_host.view()
+    pf = cornell_host.frame_constants(settings, 0, 0.0)
+    a = ol.render(view, pf, 40, 24, 3, threads=1, jittered=True)
+    b = ol.render(view, pf, 40, 24, 3, threads=5, jittered=True)
+    assert np.array_equal(a["output"].view(np.uint32), b["output"].view(np.uint32))
+    assert np.array_equal(a["jittered"].view(np.uint32), b["jittered"].view(np.uint32))
+    # frames rendered in two calls accumulate to the same bits as one call (RayGenCommon.h:721-722)
+    c = ol.render(view, pf, 40, 24, 2, threads=2, jittered=True)
+    d = ol.render(view, pf, 40, 24, 1, first_frame=2, threads=2, jittered=True, out=c["output"], jit=c["jittered"])
+    assert np.array_equal(a["output"].view(np.uint32), d["output"].view(np.uint32))
+    assert np.array_equal(a["jittered"].view(np.uint32), d["jittered"].view(np.uint32))
+
+
+def test_no_nan_and_weights_count_frames(cornell_host, settings):
+    view = cornell_host.view()
+    pf = cornell_host.frame_constants(settings, 0, 0.0)
+    r = ol.render(view, pf, 48, 32, 5, threads=4, stats=True)
+    out = r["output"]
+    assert not np.isnan(out).any()
+    assert np.all(out[..., 3] == 5.0)  # box filter: weight 1 per sample
+    st = r["stats"]
+    assert st.samples == 48 * 32 * 5
+    assert st.rays >= st.samples and st.boxesTested > st.trianglesTested > 0

@@ -72,6 +72,7 @@ def lib():
         "tb_host_scene_load": (C.c_int, [C.c_char_p, C.c_int, C.c_int, P(vp), C.c_char_p, C.c_uint32]),
         "tb_host_scene_procedural": (C.c_int, [C.c_int, C.c_uint32, C.c_uint32, C.c_int, P(vp), C.c_char_p, C.c_uint32]),
         "tb_host_scene_free": (None, [vp]),
+        "tb_host_pbrt_dump": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint32]),
         "tb_host_scene_view_get": (C.c_int, [vp, P(abi.TbSceneView)]),
         "tb_host_scene_camera": (C.c_int, [vp, P(abi.tb_camera)]),
         "tb_host_scene_info": (C.c_int, [vp, P(abi.tb_scene_info)]),

@@ -169,6 +169,7 @@ void BuildBvh(HostScene& s, int builder)
     const uint64_t N64 = s.triGeometry.size();
     if (N64 == 0) throw std::runtime_error("BuildBvh: no triangles");
     if (N64 > 0x00ffffffull) throw std::runtime_error("BuildBvh: more than 2^24-1 triangles does not fit the 24-bit node indices of the reference layout");
+    if (s.blueNoise0.empty()) LoadBlueNoiseTiles(s); /* system textures are bound with the scene (TracerBoy.cpp:2126-2134) */
     Tree t; t.N = (uint32_t)N64;
     const uint32_t N = t.N;
     if (builder == 1) buildSah(s, t); else buildLbvh(s, t);

@@ -289,9 +289,9 @@ void ConvertScene(const PbrtScene& in, HostScene& out, const ConvertOptions& opt
     Mat3 envL; Vec3 envScale(1, 1, 1);
     for (const PbrtLight& l : in.lights) {
         if (l.kind == PbrtLight::Infinite) {
-            if (!l.mapName.empty()) {
+            if (!l.mapFile.empty()) {
                 bool normalized; std::string err;
-                if (!LoadImageRGBA32F(l.mapName, out.envMap, out.envWidth, out.envHeight, normalized, err)) throw std::runtime_error(err);
+                if (!LoadImageRGBA32F(l.mapFile, out.envMap, out.envWidth, out.envHeight, normalized, err)) throw std::runtime_error(err);
             }
             envL = l.transform.l; envScale = l.scale;
         } else {

@@ -53,6 +53,9 @@ void MakeProceduralScene(HostScene& out, int kind, uint32_t targetTriangles, uin
 /* images (images.cpp): Radiance RGBE .hdr and .pfm -> RGBA32F, top row first */
 bool LoadImageRGBA32F(const std::string& file, std::vector<TbFloat4>& texels, uint32_t& w, uint32_t& h, bool& normalizedFormat, std::string& err);
 
+/* the two 256x256 RGBA8 blue-noise tiles (t14/t15) from tracerboy_amd/data; false when absent */
+bool LoadBlueNoiseTiles(HostScene& scene);
+
 void DefaultOutputSettings(tb_output_settings& s);
 /* TracerBoy.cpp:2808-2851 */
 void MakeFrameConstants(const HostScene& scene, const tb_camera& cam, const tb_output_settings& s, uint32_t frame, float timeSeed,

@@ -110,3 +110,38 @@ bool LoadImageRGBA32F(const std::string& file, std::vector<TbFloat4>& texels, ui
 }
 
 } // namespace tbhost
+
+/* ---- blue-noise tiles ---------------------------------------------------------------------------
+ * TracerBoy binds two 256x256 RGBA8 tiles at t14/t15 (TracerBoy.cpp:2126-2134, files
+ * TracerBoy/Textures/LDR_RGBA_{0,1}.png).  The build ships them as raw bytes in
+ * tracerboy_amd/data/ next to the library; TB_DATA_DIR overrides the location. */
+#include <dlfcn.h>
+
+namespace tbhost {
+
+static std::string dataDir()
+{
+    if (const char* e = getenv("TB_DATA_DIR")) return std::string(e);
+    Dl_info info;
+    if (dladdr((const void*)&dataDir, &info) && info.dli_fname) {
+        std::string p = info.dli_fname;
+        size_t s = p.find_last_of('/');
+        return (s == std::string::npos ? std::string(".") : p.substr(0, s)) + "/data";
+    }
+    return "data";
+}
+
+bool LoadBlueNoiseTiles(HostScene& scene)
+{
+    std::vector<TbFloat4>* dst[2] = {&scene.blueNoise0, &scene.blueNoise1};
+    for (int i = 0; i < 2; i++) {
+        std::ifstream in(dataDir() + "/bluenoise" + std::to_string(i) + ".rgba8", std::ios::binary);
+        std::vector<unsigned char> raw(256 * 256 * 4);
+        if (!in || !in.read((char*)raw.data(), (std::streamsize)raw.size())) { scene.blueNoise0.clear(); scene.blueNoise1.clear(); return false; }
+        dst[i]->resize(256 * 256);
+        for (size_t p = 0; p < 256 * 256; p++) (*dst[i])[p] = TbFloat4{raw[4 * p] / 255.0f, raw[4 * p + 1] / 255.0f, raw[4 * p + 2] / 255.0f, raw[4 * p + 3] / 255.0f};
+    }
+    return true;
+}
+
+} // namespace tbhost

@@ -340,7 +340,7 @@ private:
             else if (d == "LightSource") {
                 Token ty = next(); ParamSet ps = parseParams();
                 PbrtLight l; l.transform = ctm;
-                if (ty.text == "infinite") { l.kind = PbrtLight::Infinite; std::string mn = getStr(ps, "mapname"); l.mapName = mn.empty() ? mn : global(mn); get3f(ps, "L", l.L); get3f(ps, "scale", l.scale); scene->lights.push_back(l); }
+                if (ty.text == "infinite") { l.kind = PbrtLight::Infinite; std::string mn = getStr(ps, "mapname"); l.mapName = mn; l.mapFile = mn.empty() ? mn : global(mn); get3f(ps, "L", l.L); get3f(ps, "scale", l.scale); scene->lights.push_back(l); }
                 else if (ty.text == "distant") { l.kind = PbrtLight::Distant; get3f(ps, "L", l.L); get3f(ps, "scale", l.scale); get3f(ps, "from", l.from); get3f(ps, "to", l.to); scene->lights.push_back(l); }
                 /* point / spot / others: TracerBoy.cpp:1896-1917 ignores them */
             }

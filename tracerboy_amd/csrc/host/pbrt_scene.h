@@ -94,7 +94,8 @@ struct PbrtObject {
 struct PbrtLight {
     enum Kind { Infinite, Distant } kind = Infinite;
     Affine transform;
-    std::string mapName;
+    std::string mapName;  /* as written in the scene file (what the reference parser records) */
+    std::string mapFile;  /* resolved against the scene directory */
     Vec3 L{1, 1, 1}, scale{1, 1, 1}, from{0, 0, 0}, to{0, 0, 1};
 };
 
