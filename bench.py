@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the hot path: Msamples/s (W x H x spp / s) on BASELINE.json
+configs[1]: Scenes/cornell-box, 1920x1080, 64 spp, depth 8, wavefront HIP on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one full render of the workload (W*H*spp samples).  With N > 1 the frame is cut into
+64x64 tiles dealt round-robin to the ranks (tile t -> rank t % N); each rank renders its
+tiles, packs them and the packed HDR buffers are gathered to rank 0 over RCCL inside the timed region.
+The total work is fixed, so scaling is "strong".  Scene + BVH are resident in HBM before the timed
+region starts; nothing is read from the host inside it.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+CORNELL = os.path.join(ROOT, "tests", "golden", "scenes", "cornell-box", "scene.pbrt")
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def byte_model(st):
+    """Algorithmic bytes of DESIGN.md section 'Byte model' (layout-A accounting of SURVEY.md 8d, with the
+    reference's real 72-B hit-group record): traversal + attribute + material + light + accumulation."""
+    return (32 * st.boxesTested + 48 * st.trianglesTested + 180 * st.hitsShaded + 84 * st.materialFetches
+            + 104 * st.lightSamples + 32 * st.samples)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=64)
+    ap.add_argument("--depth", type=int, default=8)
+    ap.add_argument("--scene", default="cornell-box")  # or proc0:<tris> / proc1:<tris> / proc2:<tris> / path.pbrt
+    ap.add_argument("--builder", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from tracerboy_amd import api
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs the torch.distributed launcher (WORLD_SIZE is 1)" % args.gpus)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path is HIP-only (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    W, H, SPP = args.width, args.height, args.spp
+    s = api.GetDefaultOutputSettings()
+    s.EnableBlueNoise = 0       # SURVEY.md 8d "Common": pure rand() path, Time = 0, NEE on, RIS off, box filter
+    s.MaxBounces = args.depth
+    tb = api.TracerBoy(local_rank)
+    tb.SetOption("bvh_builder", args.builder)
+    t0 = time.time()
+    if args.scene == "cornell-box":
+        tb.LoadScene(CORNELL)
+    elif args.scene.startswith("proc"):
+        kind, tris = args.scene[4:].split(":")
+        tb.LoadProcedural(int(kind), int(tris), 1234)
+    else:
+        tb.LoadScene(args.scene)
+    load_s = time.time() - t0
+    info = tb.SceneInfo()
+    TILE = 64
+    tb.SetTileAssignment(rank, world, TILE, TILE)
+    owned = tb.OwnedPixels(W, H)
+    packed = torch.zeros((max(owned, 1), 4), dtype=torch.float32, device="cuda")
+    gather_list = None
+    if world > 1:
+        # equal-sized slices: every rank pads to the largest owner so one all_gather-shaped collective suffices
+        mx = torch.tensor([owned], device="cuda"); dist.all_reduce(mx, op=dist.ReduceOp.MAX); cap = int(mx.item())
+        packed = torch.zeros((cap, 4), dtype=torch.float32, device="cuda")
+        if rank == 0:
+            gather_list = [torch.zeros_like(packed) for _ in range(world)]
+    torch.cuda.synchronize()
+
+    kernel_ms = []
+
+    def step():
+        tb.InvalidateHistory()
+        tb.Render(W, H, SPP, s, 0.0)          # synchronous; GPU time measured with HIP events on the library's stream
+        kernel_ms.append(tb.LastRenderMs())
+        if world > 1:
+            tb.PackOwnedTo(packed.data_ptr())
+            dist.gather(packed, gather_list, dst=0)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    kernel_ms.clear()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX); elapsed = float(t.item())
+
+    samples_per_step = W * H * SPP
+    value = samples_per_step * args.steps / elapsed / 1e6
+    result = {
+        "metric": "Msamples/s (WxHxspp/s)", "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%s %dx%d %dspp depth%d" % (args.scene, W, H, SPP, args.depth), "triangles": int(info.numTriangles),
+                   "bvh_builder": "lbvh" if args.builder == 0 else "sah", "tile": TILE if world > 1 else None,
+                   "parallelism": "tiles%d" % world, "scene_in_lds": bool(tb.GetOption("scene_in_lds_active")),
+                   "kernel_variant": ["matte", "env", "surf", "vol", "full"][tb.GetOption("last_variant")], "scene_load_s": round(load_s, 3)},
+    }
+
+    if rank == 0:
+        # ---- roofline of the dominant (only) kernel: pt_persistent ------------------------------------
+        avg_ms = float(np.mean(kernel_ms))
+        tb.SetOption("count_rays", 1)
+        tb.Render(W, H, 1, s, 0.0)           # counters-on launch of the same kernels, 1 spp, outside the timed region
+        st = tb.ReadbackStats().rays
+        tb.SetOption("count_rays", 0)
+        bytes_per_sample = byte_model(st) / max(st.samples, 1)
+        samples_per_launch = owned_samples = (W * H if world == 1 else owned) * SPP
+        achieved = bytes_per_sample * samples_per_launch / (avg_ms * 1e-3) / 1e9
+        result["roofline"] = {
+            "bound": "hbm", "kernel": "pt_persistent", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "avg_launch_ms": round(avg_ms, 3), "algorithmic_bytes_per_sample": round(bytes_per_sample, 1),
+            "boxes_per_sample": round(st.boxesTested / max(st.samples, 1), 2), "tris_per_sample": round(st.trianglesTested / max(st.samples, 1), 2),
+            "rays_per_sample": round(st.rays / max(st.samples, 1), 3),
+            "note": ("scene image is LDS-resident: algorithmic bytes are served by LDS, HBM only sees the accumulation surfaces"
+                     if tb.GetOption("scene_in_lds_active") else "BVH fetched from L2/MALL/HBM"),
+        }
+        # ---- CPU baseline: the scalar oracle on a bounded sample of the same workload ------------------
+        if not args.no_cpu_baseline:
+            import oracle_lib as ol
+            cores = os.cpu_count() or 1
+            view = tb.HostSceneView(); pf = tb.FrameConstants(W, H, 0, s, 0.0)
+            # probe the rate on one full 1-spp frame, then size the sample (whole frames) to ~cpu_baseline_seconds
+            t1 = time.perf_counter(); ol.render(view, pf, W, H, 1, threads=cores); dt = time.perf_counter() - t1
+            frames = int(max(1, min(SPP, args.cpu_baseline_seconds / max(dt, 1e-3))))
+            t1 = time.perf_counter(); ol.render(view, pf, W, H, frames, threads=cores); dt = time.perf_counter() - t1
+            rows1 = 8 * max(1, H // 8 // 32)
+            t2 = time.perf_counter(); ol.render(view, pf, W, H, 1, y0=(H - rows1) // 2, y1=(H - rows1) // 2 + rows1, threads=1); dt1 = time.perf_counter() - t2
+            result["cpu_baseline"] = {"value": round(W * H * frames / dt / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
+                                      "sample": "scalar C++ oracle (oracle/tb_oracle.cpp, g++ -O2), the %dx%d frame x %d spp of %d, depth %d, %d threads over 8-row strips (%.1f s)"
+                                                % (W, H, frames, SPP, args.depth, cores, dt),
+                                      "single_thread": round(W * rows1 / dt1 / 1e6, 4)}
+        print(json.dumps(result))
+    tb.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -266,13 +266,16 @@ def test_tile_split_reproduces_the_single_gpu_image(gpu_tb, settings):
     gpu_tb.Render(W, H, F, settings, 0.0)
     full = gpu_tb.ReadAccumulation()
     packed = []
-    for r in range(world):
-        gpu_tb.SetTileAssignment(r, world, tw, th)
-        gpu_tb.Render(W, H, F, settings, 0.0)
-        buf = torch.zeros((gpu_tb.OwnedPixels(W, H), 4), dtype=torch.float32, device="cuda:0")
-        gpu_tb.PackOwnedTo(buf.data_ptr())
-        packed.append(buf.cpu().numpy())
-    gpu_tb.SetTileAssignment(0, 1)
+    try:
+        for r in range(world):
+            gpu_tb.SetTileAssignment(r, world, tw, th)
+            gpu_tb.Render(W, H, F, settings, 0.0)
+            buf = torch.zeros((gpu_tb.OwnedPixels(W, H), 4), dtype=torch.float32, device="cuda:0")
+            torch.cuda.synchronize()  # the library packs on its own stream; order it after torch's fill
+            gpu_tb.PackOwnedTo(buf.data_ptr())
+            packed.append(buf.cpu().numpy())
+    finally:
+        gpu_tb.SetTileAssignment(0, 1)
     assert np.array_equal(bits(api.unpack_gathered(W, H, world, tw, th, packed)), bits(full))
 
 

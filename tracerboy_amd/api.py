@@ -32,6 +32,12 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise ImportError("libtracerboy_hip.so is not built: run `python -m tracerboy_amd.build` "
                           "(or __graft_entry__.build()); there is no non-HIP fallback")
+    try:
+        # PyTorch-ROCm bundles its own libamdhip64; importing it first makes this library bind to the SAME
+        # HIP runtime instance, so torch tensors (device memory, RCCL buffers) and tb_* calls can share a process.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     P = C.POINTER
     vp = C.c_void_p
