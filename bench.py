@@ -43,7 +43,7 @@ def main():
     ap.add_argument("--spp", type=int, default=64)
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--scene", default="cornell-box")  # or proc0:<tris> / proc1:<tris> / proc2:<tris> / path.pbrt
-    ap.add_argument("--builder", type=int, default=0)
+    ap.add_argument("--builder", type=int, default=1)  # 0 = LBVH (fallback-layer semantics), 1 = binned SAH
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
     args = ap.parse_args()

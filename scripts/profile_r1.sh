@@ -16,13 +16,14 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o write -- pyt
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/pmc_sq -o sq -- python3 bench.py $ARGS > $OUT/bench_sq.json 2> $OUT/sq.err
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_lds -o lds -- python3 bench.py $ARGS > $OUT/bench_lds.json 2> $OUT/lds.err
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum --output-format csv -d $OUT/pmc_tcc -o tcc -- python3 bench.py $ARGS > $OUT/bench_tcc.json 2> $OUT/tcc.err
+rocprofv3 --pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_SCA --output-format csv -d $OUT/pmc_util -o util -- python3 bench.py $ARGS > $OUT/bench_util.json 2> $OUT/util.err
 find $OUT -name "*.csv" -size +0 | head -40
 for f in $(find $OUT -name "*kernel_stats.csv"); do echo "== $f"; head -6 "$f"; done
 python3 - "$OUT" <<'PY'
 import csv, glob, collections, sys, json
 out = sys.argv[1]
 summary = {}
-for tag in ("fetch", "write", "sq", "lds", "tcc"):
+for tag in ("fetch", "write", "sq", "lds", "tcc", "util"):
     for f in glob.glob("%s/pmc_%s/**/*counter_collection.csv" % (out, tag), recursive=True):
         agg = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
         seen = set()

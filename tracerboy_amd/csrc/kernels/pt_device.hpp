@@ -150,16 +150,16 @@ TBD bool traverse(const SceneRefs& sc, const TbDeviceScene& ds, tb3 o, tb3 d, Hi
     RayPre r = ray_prepare(o, d);
     float unusedT;
     if (!box_test(unusedT, best.t, r, ld3(ds.rootCenter), ld3(ds.rootHalf))) return false; /* :566-580 */
+    /* "while-while" scheduling: a lane that reaches a leaf parks on it until the other lanes of the
+     * wave have reached theirs (or fewer than PARK_MIN are still descending), then the wave runs the
+     * triangle test once for everybody.  Only the interleaving ACROSS lanes changes; each lane's own
+     * sequence of box and triangle tests is unchanged. */
+    constexpr uint32_t DONE = 0xffffffffu; /* has the leaf bit set, so it also leaves the inner loop */
+    constexpr int PARK_MIN = 8;
     uint32_t top = 0;
     uint32_t ref = ds.rootRef;
-    for (;;) {
-        if (ref & TB_BVH_LEAF_FLAG) {
-            const TbTriB tri = sc.tris[ref & TB_BVH_INDEX_MASK];
-            if (COUNT) tris++;
-            tri_test(best, MIN_T, o, r, tri);
-            if (top == 0) break;
-            ref = stack[(--top) * stride];
-        } else {
+    while (ref != DONE) {
+        while (!(ref & TB_BVH_LEAF_FLAG)) {
             const TbNodeB n = sc.nodes[ref];
             float lt, rt;
             bool lh = box_test(lt, best.t, r, ld3(n.lc), ld3(n.lh));
@@ -172,9 +172,15 @@ TBD bool traverse(const SceneRefs& sc, const TbDeviceScene& ds, tb3 o, tb3 d, Hi
             } else if (lh || rh) {
                 ref = rh ? n.right : n.left;
             } else {
-                if (top == 0) break;
-                ref = stack[(--top) * stride];
+                ref = top ? stack[(--top) * stride] : DONE;
             }
+            if (__popcll(__ballot(!(ref & TB_BVH_LEAF_FLAG))) < PARK_MIN) break;
+        }
+        if ((ref & TB_BVH_LEAF_FLAG) && ref != DONE) {
+            const TbTriB tri = sc.tris[ref & TB_BVH_INDEX_MASK];
+            if (COUNT) tris++;
+            tri_test(best, MIN_T, o, r, tri);
+            ref = top ? stack[(--top) * stride] : DONE;
         }
     }
     return best.t < MAX_T;
