@@ -118,6 +118,10 @@ int tb_read_aov(tb_context* ctx, int which, void* dst);
 int tb_accum_device_ptr(tb_context* ctx, void** output, void** jittered);
 /* <-> ReadbackStats copy (TracerBoy.cpp:2946, D3D12App.cpp:195-201) */
 int tb_read_stats(tb_context* ctx, tb_readback_stats* out);
+/* Wave-occupancy profile of the last counting render (option "count_rays"): 7 pairs (active lane-executions,
+ * wave trips) for: BVH inner-node step, leaf step, closest-hit shading, shadow-ray slot, scatter, regeneration,
+ * main-loop iteration.  occupancy of a phase = active / (64 * trips). */
+int tb_read_wave_profile(tb_context* ctx, uint64_t* out14);
 /* <-> InvalidateHistory (TracerBoy.cpp:3569-3575) / GetNumberOfSamplesSinceLastInvalidate */
 void tb_invalidate_history(tb_context* ctx);
 uint32_t tb_samples_rendered(tb_context* ctx);

@@ -61,6 +61,7 @@ def lib():
         "tb_read_aov": (C.c_int, [vp, C.c_int, vp]),
         "tb_accum_device_ptr": (C.c_int, [vp, P(vp), P(vp)]),
         "tb_read_stats": (C.c_int, [vp, P(abi.tb_readback_stats)]),
+        "tb_read_wave_profile": (C.c_int, [vp, P(C.c_uint64)]),
         "tb_invalidate_history": (None, [vp]),
         "tb_samples_rendered": (C.c_uint32, [vp]),
         "tb_select_pixel": (C.c_int, [vp, C.c_uint32, C.c_uint32]),
@@ -254,6 +255,13 @@ class TracerBoy:
         s = abi.tb_readback_stats()
         self._check(self._L.tb_read_stats(self._ctx, C.byref(s)))
         return s
+
+    def WaveProfile(self):
+        """Per-phase wave occupancy of the last counting render: {phase: (active_lanes, trips, occupancy)}."""
+        raw = (C.c_uint64 * 14)()
+        self._check(self._L.tb_read_wave_profile(self._ctx, raw))
+        names = ["bvh_inner", "bvh_leaf", "closest_shade", "shadow_slot", "scatter", "regenerate", "iteration"]
+        return {n: (int(raw[2 * i]), int(raw[2 * i + 1]), (raw[2 * i] / (64.0 * raw[2 * i + 1])) if raw[2 * i + 1] else 0.0) for i, n in enumerate(names)}
 
     # -- surfaces -------------------------------------------------------------------------------
     def ReadAccumulation(self, jittered=False):

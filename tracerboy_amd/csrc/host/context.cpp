@@ -250,7 +250,7 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
         tg.aovNormals = (TbFloat4*)c->aov[2].p; tg.aovWorldPos0 = (TbFloat4*)c->aov[3].p; tg.aovWorldPos1 = (TbFloat4*)c->aov[4].p;
         tg.aovCustom = (TbFloat4*)c->aov[5].p; tg.aovDepth = (float*)c->aov[6].p; tg.aovEmissive = (TbFloat4*)c->aov[7].p;
     }
-    if (count) { ensure(c->rayStats, 7 * 8); if (c->samplesRendered == 0) HIP_TRY(hipMemsetAsync(c->rayStats.p, 0, 56, c->stream)); tg.rayStats = (unsigned long long*)c->rayStats.p; }
+    if (count) { ensure(c->rayStats, 21 * 8); if (c->samplesRendered == 0) HIP_TRY(hipMemsetAsync(c->rayStats.p, 0, 21 * 8, c->stream)); tg.rayStats = (unsigned long long*)c->rayStats.p; }
     TbPerFrameConstants pf;
     MakeFrameConstants(c->scene, c->camera, s, c->samplesRendered, timeSeed, c->selX, c->selY, pf);
     uint32_t need = c->sceneFeatures | settingsFeatureMask(c, s, aov);
@@ -412,6 +412,16 @@ int tb_read_stats(tb_context* c, tb_readback_stats* o)
         HIP_TRY(hipStreamSynchronize(c->stream));
         if (c->stats.p) { uint32_t raw[4]; HIP_TRY(hipMemcpy(raw, c->stats.p, 16, hipMemcpyDeviceToHost)); o->ActiveWaves = raw[0]; o->ActivePixels = raw[1]; memcpy(&o->SelectedPixelDistance, &raw[2], 4); o->SelectedMaterialID = (int32_t)raw[3]; }
         if (c->rayStats.p) { uint64_t r[7]; HIP_TRY(hipMemcpy(r, c->rayStats.p, 56, hipMemcpyDeviceToHost)); o->rays.boxesTested = r[0]; o->rays.trianglesTested = r[1]; o->rays.hitsShaded = r[2]; o->rays.materialFetches = r[3]; o->rays.lightSamples = r[4]; o->rays.samples = r[5]; o->rays.rays = r[6]; }
+        return TB_OK;
+    });
+}
+
+int tb_read_wave_profile(tb_context* c, uint64_t* out14)
+{
+    return guarded(c, [&]() {
+        if (!out14 || !c->rayStats.p) return fail(c, TB_E_INVALID, "tb_read_wave_profile: render with option \"count_rays\" first");
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipMemcpy(out14, (const char*)c->rayStats.p + 56, 14 * 8, hipMemcpyDeviceToHost));
         return TB_OK;
     });
 }

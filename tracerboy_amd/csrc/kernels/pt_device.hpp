@@ -142,9 +142,21 @@ TBD void tri_test(Hit& best, float tMin, tb3 o, const RayPre& r, const TbTriB& t
  * children are tested when their parent is popped, the far child is pushed and the near child is
  * visited next (the reference pushes both and pops the near one straight back, :163-180), ties go
  * left.  stack: LDS, entry e of this lane at stack[e * stride]. */
+/* Wave-occupancy profile (counting kernel only): for each phase, the number of times a wave executed it
+ * ("trips", counted by the first active lane) and the number of lanes that were active in it. */
+enum { PROF_INNER = 0, PROF_LEAF = 2, PROF_CLOSEST = 4, PROF_SHADOW = 6, PROF_SCATTER = 8, PROF_REGEN = 10, PROF_ITER = 12, PROF_SLOTS = 14 };
+struct WaveProf { unsigned long long v[PROF_SLOTS]; };
+TBD void prof_hit(WaveProf* p, int slot)
+{
+    if (!p) return;
+    p->v[slot] += 1; /* active lane-executions */
+    unsigned long long m = __ballot(1);
+    if ((int)(threadIdx.x & 63u) == __ffsll((long long)m) - 1) p->v[slot + 1] += 1; /* wave trips */
+}
+
 template <bool COUNT>
 TBD bool traverse(const SceneRefs& sc, const TbDeviceScene& ds, tb3 o, tb3 d, Hit& best, uint32_t* stack, uint32_t stride,
-                  uint32_t& boxes, uint32_t& tris)
+                  uint32_t& boxes, uint32_t& tris, WaveProf* prof = nullptr)
 {
     best.t = MAX_T; best.u = best.v = 0.0f; best.prim = best.geom = 0u;
     RayPre r = ray_prepare(o, d);
@@ -160,6 +172,7 @@ TBD bool traverse(const SceneRefs& sc, const TbDeviceScene& ds, tb3 o, tb3 d, Hi
     uint32_t ref = ds.rootRef;
     while (ref != DONE) {
         while (!(ref & TB_BVH_LEAF_FLAG)) {
+            if (COUNT) prof_hit(prof, PROF_INNER);
             const TbNodeB n = sc.nodes[ref];
             float lt, rt;
             bool lh = box_test(lt, best.t, r, ld3(n.lc), ld3(n.lh));
@@ -177,6 +190,7 @@ TBD bool traverse(const SceneRefs& sc, const TbDeviceScene& ds, tb3 o, tb3 d, Hi
             if (__popcll(__ballot(!(ref & TB_BVH_LEAF_FLAG))) < PARK_MIN) break;
         }
         if ((ref & TB_BVH_LEAF_FLAG) && ref != DONE) {
+            if (COUNT) prof_hit(prof, PROF_LEAF);
             const TbTriB tri = sc.tris[ref & TB_BVH_INDEX_MASK];
             if (COUNT) tris++;
             tri_test(best, MIN_T, o, r, tri);
