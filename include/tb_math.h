@@ -51,8 +51,33 @@ TB_HD float tb_sqrt(float x) { return __builtin_sqrtf(x); }
 TB_HD float tb_rcp(float x) { return 1.0f / x; }
 TB_HD float tb_floor(float x) { return __builtin_floorf(x); }
 TB_HD float tb_abs(float x) { return tb_u2f(tb_f2u(x) & 0x7fffffffu); }
-TB_HD float tb_min(float a, float b) { return (b < a || a != a) ? b : a; }
-TB_HD float tb_max(float a, float b) { return (b > a || a != a) ? b : a; }
+/* min/max with the semantics of gfx950's v_min_f32 / v_max_f32 (IEEE minNum/maxNum as HLSL's min/max:
+ * the non-NaN operand wins; -0 orders below +0).  The device uses the native instruction (and lets the
+ * compiler form v_min3/v_max3); the host spells the same function out. */
+TB_HD float tb_min(float a, float b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_fminf(a, b);
+#else
+    if (a < b) return a;
+    if (b < a) return b;
+    if (a != a) return b;
+    if (b != b) return a;
+    return tb_u2f(tb_f2u(a) | tb_f2u(b)); /* equal: -0 if either is -0 */
+#endif
+}
+TB_HD float tb_max(float a, float b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_fmaxf(a, b);
+#else
+    if (a > b) return a;
+    if (b > a) return b;
+    if (a != a) return b;
+    if (b != b) return a;
+    return tb_u2f(tb_f2u(a) & tb_f2u(b)); /* equal: +0 if either is +0 */
+#endif
+}
 TB_HD float tb_clamp(float x, float lo, float hi) { return tb_min(tb_max(x, lo), hi); }
 TB_HD float tb_saturate(float x) { return tb_clamp(x, 0.0f, 1.0f); }
 TB_HD float tb_frac(float x) { return x - tb_floor(x); }

@@ -21,7 +21,19 @@ TB_HD tb3 operator*(tb3 a, float s) { return tb3_make(a.x * s, a.y * s, a.z * s)
 TB_HD tb3 operator*(float s, tb3 a) { return tb3_make(s * a.x, s * a.y, s * a.z); }
 TB_HD tb3 operator/(tb3 a, float s) { return tb3_make(a.x / s, a.y / s, a.z / s); }
 TB_HD tb3 operator-(tb3 a) { return tb3_make(-a.x, -a.y, -a.z); }
-TB_HD float tb3_dot(tb3 a, tb3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+/* HLSL leaves contraction to the driver compiler except where `precise` is written; the build pins it:
+ * dot products, a*s+b and the barycentric blend are fused-multiply-add chains (one rounding per step,
+ * identical on host and device), everything else is unfused. */
+TB_HD float tb3_dot(tb3 a, tb3 b) { return tb_fma(a.z, b.z, tb_fma(a.y, b.y, a.x * b.x)); }
+TB_HD tb3 tb3_madd(tb3 a, float s, tb3 b) { tb3 r; r.x = tb_fma(a.x, s, b.x); r.y = tb_fma(a.y, s, b.y); r.z = tb_fma(a.z, s, b.z); return r; } /* a*s + b */
+TB_HD tb3 tb3_bary(float b0, float b1, float b2, tb3 v0, tb3 v1, tb3 v2)
+{
+    tb3 r;
+    r.x = tb_fma(b2, v2.x, tb_fma(b1, v1.x, b0 * v0.x));
+    r.y = tb_fma(b2, v2.y, tb_fma(b1, v1.y, b0 * v0.y));
+    r.z = tb_fma(b2, v2.z, tb_fma(b1, v1.z, b0 * v0.z));
+    return r;
+}
 TB_HD tb3 tb3_cross(tb3 a, tb3 b)
 {
     return tb3_make(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);

@@ -61,7 +61,8 @@ inline float rnd(Ctx& c)
 inline float hash13(tb3 p3)
 {
     p3 = tb3_make(tb_frac(p3.x * .1031f), tb_frac(p3.y * .1031f), tb_frac(p3.z * .1031f));
-    float d = tb3_dot(p3, tb3_make(p3.y + 33.33f, p3.z + 33.33f, p3.x + 33.33f));
+    /* dot() written out unfused: the known-answer seeds of SURVEY.md 8c are for this association */
+    float d = (p3.x * (p3.y + 33.33f) + p3.y * (p3.z + 33.33f)) + p3.z * (p3.x + 33.33f);
     p3 = tb3_make(p3.x + d, p3.y + d, p3.z + d);
     return tb_frac((p3.x + p3.y) * p3.z);
 }
@@ -103,10 +104,13 @@ inline RayData GetRayData(tb3 o, tb3 d)
 /* TraverseFunction.hlsli:204-221 */
 inline bool RayBoxTest(float& resultT, float closestT, const RayData& rd, tb3 c, tb3 h)
 {
-    tb3 relativeMiddle = c * rd.InverseDirection - rd.OriginTimesRayInverseDirection;
-    tb3 ai = tb3_abs(rd.InverseDirection);
-    tb3 maxL = relativeMiddle + h * ai;
-    tb3 minL = relativeMiddle - h * ai;
+    /* not `precise` in the reference, so the shader compiler may contract; the build pins the contraction
+     * (one fma per component per line), see include/tb_vec.h */
+    const tb3 inv = rd.InverseDirection, oi = rd.OriginTimesRayInverseDirection;
+    tb3 ai = tb3_abs(inv);
+    tb3 relativeMiddle = tb3_make(tb_fma(c.x, inv.x, -oi.x), tb_fma(c.y, inv.y, -oi.y), tb_fma(c.z, inv.z, -oi.z));
+    tb3 maxL = tb3_make(tb_fma(h.x, ai.x, relativeMiddle.x), tb_fma(h.y, ai.y, relativeMiddle.y), tb_fma(h.z, ai.z, relativeMiddle.z));
+    tb3 minL = tb3_make(tb_fma(-h.x, ai.x, relativeMiddle.x), tb_fma(-h.y, ai.y, relativeMiddle.y), tb_fma(-h.z, ai.z, relativeMiddle.z));
     float minT = tb_max(tb_max(minL.x, minL.y), minL.z);
     float maxT = tb_min(tb_min(maxL.x, maxL.y), maxL.z);
     resultT = tb_max(minT, 0.0f);
@@ -121,9 +125,10 @@ inline void RayTriangleIntersect(float& hitT, float bary[2], tb3 o, const RayDat
     float Ax = tb3_get(a0, rd.kx), Ay = tb3_get(a0, rd.ky), Az = tb3_get(a0, rd.kz);
     float Bx = tb3_get(b0, rd.kx), By = tb3_get(b0, rd.ky), Bz = tb3_get(b0, rd.kz);
     float Cx = tb3_get(c0, rd.kx), Cy = tb3_get(c0, rd.ky), Cz = tb3_get(c0, rd.kz);
-    Ax = Ax - rd.Shear.x * Az; Ay = Ay - rd.Shear.y * Az;
-    Bx = Bx - rd.Shear.x * Bz; By = By - rd.Shear.y * Bz;
-    Cx = Cx - rd.Shear.x * Cz; Cy = Cy - rd.Shear.y * Cz;
+    Ax = tb_fma(-rd.Shear.x, Az, Ax); Ay = tb_fma(-rd.Shear.y, Az, Ay);
+    Bx = tb_fma(-rd.Shear.x, Bz, Bx); By = tb_fma(-rd.Shear.y, Bz, By);
+    Cx = tb_fma(-rd.Shear.x, Cz, Cx); Cy = tb_fma(-rd.Shear.y, Cz, Cy);
+    /* `precise` (:260-262): U, V, W are never contracted */
     float U = Cx * By - Cy * Bx;
     float V = Ax * Cy - Ay * Cx;
     float W = Bx * Ay - By * Ax;
@@ -131,7 +136,7 @@ inline void RayTriangleIntersect(float& hitT, float bary[2], tb3 o, const RayDat
     if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) return;
     if (det == 0.0f) return;
     Az = rd.Shear.z * Az; Bz = rd.Shear.z * Bz; Cz = rd.Shear.z * Cz;
-    const float T = U * Az + V * Bz + W * Cz;
+    const float T = tb_fma(W, Cz, tb_fma(V, Bz, U * Az));
     float signCorrectedT = tb_abs(T);
     if ((T > 0.0f) != (det > 0.0f)) signCorrectedT = -signCorrectedT;
     if (signCorrectedT < 0.0f || signCorrectedT > hitT * tb_abs(det)) return;
@@ -225,11 +230,11 @@ inline void GetHitInfo(const TbSceneView* sc, const TbHitGroupRecord& rec, uint3
     /* uv :97-108 (offset 3) */
     {
         uint32_t b0 = s * i0 + vFirst + 3, b1 = s * i1 + vFirst + 3, b2 = s * i2 + vFirst + 3;
-        info.uvx = bx * vbf(sc, b0) + by * vbf(sc, b1) + bz * vbf(sc, b2);
-        info.uvy = bx * vbf(sc, b0 + 1) + by * vbf(sc, b1 + 1) + bz * vbf(sc, b2 + 1);
+        info.uvx = tb_fma(bz, vbf(sc, b2), tb_fma(by, vbf(sc, b1), bx * vbf(sc, b0)));
+        info.uvy = tb_fma(bz, vbf(sc, b2 + 1), tb_fma(by, vbf(sc, b1 + 1), bx * vbf(sc, b0 + 1)));
     }
-    info.normal = tb3_normalize(bx * f3(i0, 0) + by * f3(i1, 0) + bz * f3(i2, 0));   /* :110-121 */
-    info.tangent = tb3_normalize(bx * f3(i0, 5) + by * f3(i1, 5) + bz * f3(i2, 5));  /* :123-133 */
+    info.normal = tb3_normalize(tb3_bary(bx, by, bz, f3(i0, 0), f3(i1, 0), f3(i2, 0)));   /* :110-121 */
+    info.tangent = tb3_normalize(tb3_bary(bx, by, bz, f3(i0, 5), f3(i1, 5), f3(i2, 5)));  /* :123-133 */
 }
 
 /* RayGenCommon.h:365-414,482-487: returns (t, materialIndex) or (-1,-1) */
@@ -600,7 +605,7 @@ inline tb3 GetHalfVectorSafe(tb3 a, tb3 b, tb3 normal) /* :1258-1269 */
     else return normal;
 }
 
-inline tb3 GetRayPoint(const Ray& r, float t) { return r.origin + r.direction * t; }
+inline tb3 GetRayPoint(const Ray& r, float t) { return tb3_madd(r.direction, t, r.origin); }
 
 /* ------------------------------------------------------------------------------------------
  * Trace: kernel.glsl:1278-1776

@@ -14,12 +14,20 @@ def test_hash13_seed_values(built):
     assert abs(L.tbo_hash13(1, 0, 0) - 0.970919) < 2e-6
     assert abs(L.tbo_hash13(960, 540, 0) - 0.172363) < 2e-6
     # numpy fp32 re-derivation with the pinned association order
+    from fractions import Fraction
+
+    def fma32(a, b, c):  # correctly rounded float32 fma, evaluated exactly with rationals
+        exact = Fraction(float(a)) * Fraction(float(b)) + Fraction(float(c))
+        g = np.float32(float(exact))
+        cands = [g, np.nextafter(g, np.float32(np.inf)), np.nextafter(g, np.float32(-np.inf))]
+        return min(cands, key=lambda v: (abs(Fraction(float(v)) - exact), int(v.view(np.uint32)) & 1))
+
     def h(x, y, z):
         f = np.float32
         p = [f(v) * f(.1031) for v in (x, y, z)]
         p = [v - np.floor(v) for v in p]
         q = [p[1] + f(33.33), p[2] + f(33.33), p[0] + f(33.33)]
-        d = (p[0] * q[0] + p[1] * q[1]) + p[2] * q[2]
+        d = (p[0] * q[0] + p[1] * q[1]) + p[2] * q[2]  # hash13 keeps the unfused association
         p = [v + d for v in p]
         r = (p[0] + p[1]) * p[2]
         return r - np.floor(r)

@@ -73,7 +73,7 @@ TBD float rnd(float& seed, float time)
 TBD float hash13(float x, float y, float z)
 {
     tb3 p = tb3_make(tb_frac(x * .1031f), tb_frac(y * .1031f), tb_frac(z * .1031f));
-    float d = tb3_dot(p, tb3_make(p.y + 33.33f, p.z + 33.33f, p.x + 33.33f));
+    float d = (p.x * (p.y + 33.33f) + p.y * (p.z + 33.33f)) + p.z * (p.x + 33.33f); /* unfused, like the checker */
     p = tb3_make(p.x + d, p.y + d, p.z + d);
     return tb_frac((p.x + p.y) * p.z);
 }
@@ -98,10 +98,11 @@ TBD RayPre ray_prepare(tb3 o, tb3 d) /* GetRayData, TraverseFunction.hlsli:473-4
 
 TBD bool box_test(float& tEntry, float closest, const RayPre& r, tb3 c, tb3 h) /* RayBoxTest :204-221 */
 {
-    tb3 mid = c * r.inv - r.oinv;
+    /* (not `precise` in the reference: contraction allowed, pinned here as explicit fmas) */
     tb3 ai = tb3_abs(r.inv);
-    tb3 hi = mid + h * ai;
-    tb3 lo = mid - h * ai;
+    tb3 mid = tb3_make(tb_fma(c.x, r.inv.x, -r.oinv.x), tb_fma(c.y, r.inv.y, -r.oinv.y), tb_fma(c.z, r.inv.z, -r.oinv.z));
+    tb3 hi = tb3_make(tb_fma(h.x, ai.x, mid.x), tb_fma(h.y, ai.y, mid.y), tb_fma(h.z, ai.z, mid.z));
+    tb3 lo = tb3_make(tb_fma(-h.x, ai.x, mid.x), tb_fma(-h.y, ai.y, mid.y), tb_fma(-h.z, ai.z, mid.z));
     float tmin = tb_max(tb_max(lo.x, lo.y), lo.z);
     float tmax = tb_min(tb_min(hi.x, hi.y), hi.z);
     tEntry = tb_max(tmin, 0.0f);
@@ -115,9 +116,10 @@ TBD void tri_test(Hit& best, float tMin, tb3 o, const RayPre& r, const TbTriB& t
 {
     tb3 a = ld3(tri.v0) - o, b = ld3(tri.v1) - o, c = ld3(tri.v2) - o;
     float Az = tb3_get(a, r.kz), Bz = tb3_get(b, r.kz), Cz = tb3_get(c, r.kz);
-    float Ax = tb3_get(a, r.kx) - r.shear.x * Az, Ay = tb3_get(a, r.ky) - r.shear.y * Az;
-    float Bx = tb3_get(b, r.kx) - r.shear.x * Bz, By = tb3_get(b, r.ky) - r.shear.y * Bz;
-    float Cx = tb3_get(c, r.kx) - r.shear.x * Cz, Cy = tb3_get(c, r.ky) - r.shear.y * Cz;
+    float Ax = tb_fma(-r.shear.x, Az, tb3_get(a, r.kx)), Ay = tb_fma(-r.shear.y, Az, tb3_get(a, r.ky));
+    float Bx = tb_fma(-r.shear.x, Bz, tb3_get(b, r.kx)), By = tb_fma(-r.shear.y, Bz, tb3_get(b, r.ky));
+    float Cx = tb_fma(-r.shear.x, Cz, tb3_get(c, r.kx)), Cy = tb_fma(-r.shear.y, Cz, tb3_get(c, r.ky));
+    /* `precise` in the reference (TraverseFunction.hlsli:260-262): never contracted */
     float U = Cx * By - Cy * Bx;
     float V = Ax * Cy - Ay * Cx;
     float W = Bx * Ay - By * Ax;
@@ -125,7 +127,7 @@ TBD void tri_test(Hit& best, float tMin, tb3 o, const RayPre& r, const TbTriB& t
     if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) return;
     if (det == 0.0f) return;
     Az = r.shear.z * Az; Bz = r.shear.z * Bz; Cz = r.shear.z * Cz;
-    float T = U * Az + V * Bz + W * Cz;
+    float T = tb_fma(W, Cz, tb_fma(V, Bz, U * Az));
     float sT = tb_abs(T);
     if ((T > 0.0f) != (det > 0.0f)) sT = -sT;
     if (sT < 0.0f || sT > best.t * tb_abs(det)) return;
@@ -215,13 +217,13 @@ TBD void fetch_surface(const SceneRefs& sc, const Hit& h, Surface& s, bool needT
     const uint32_t i0 = ibu(sc, iFirst + h.prim * 3), i1 = ibu(sc, iFirst + h.prim * 3 + 1), i2 = ibu(sc, iFirst + h.prim * 3 + 2);
     const float bx = 1 - h.u - h.v, by = h.u, bz = h.v; /* GetBarycentrics3 :135-138 */
     const uint32_t b0 = 8 * i0 + vFirst, b1 = 8 * i1 + vFirst, b2 = 8 * i2 + vFirst;
-    s.u = bx * vbf(sc, b0 + 3) + by * vbf(sc, b1 + 3) + bz * vbf(sc, b2 + 3);
-    s.v = bx * vbf(sc, b0 + 4) + by * vbf(sc, b1 + 4) + bz * vbf(sc, b2 + 4);
+    s.u = tb_fma(bz, vbf(sc, b2 + 3), tb_fma(by, vbf(sc, b1 + 3), bx * vbf(sc, b0 + 3)));
+    s.v = tb_fma(bz, vbf(sc, b2 + 4), tb_fma(by, vbf(sc, b1 + 4), bx * vbf(sc, b0 + 4)));
     tb3 n0 = tb3_make(vbf(sc, b0), vbf(sc, b0 + 1), vbf(sc, b0 + 2)), n1 = tb3_make(vbf(sc, b1), vbf(sc, b1 + 1), vbf(sc, b1 + 2)), n2 = tb3_make(vbf(sc, b2), vbf(sc, b2 + 1), vbf(sc, b2 + 2));
-    s.normal = tb3_normalize(bx * n0 + by * n1 + bz * n2);
+    s.normal = tb3_normalize(tb3_bary(bx, by, bz, n0, n1, n2));
     if (needTangent) {
         tb3 t0 = tb3_make(vbf(sc, b0 + 5), vbf(sc, b0 + 6), vbf(sc, b0 + 7)), t1 = tb3_make(vbf(sc, b1 + 5), vbf(sc, b1 + 6), vbf(sc, b1 + 7)), t2 = tb3_make(vbf(sc, b2 + 5), vbf(sc, b2 + 6), vbf(sc, b2 + 7));
-        s.tangent = tb3_normalize(bx * t0 + by * t1 + bz * t2);
+        s.tangent = tb3_normalize(tb3_bary(bx, by, bz, t0, t1, t2));
     } else s.tangent = tb3_splat(0.0f);
     s.material = (int)rec.MaterialIndex;
 }
@@ -521,7 +523,7 @@ TBD void path_begin(Path& p, const TbDeviceScene& ds, const TbPerFrameConstants&
         tb3 nlens = lens_position(pf, lensHeight, u + psx, v + psy, aspect);
         p.neighborDir = tb3_normalize(nlens - focal);
         if (pf.DOFFocusDistance > 0.0f) { /* :1890-1901 */
-            tb3 focus = p.ro + p.rd * pf.DOFFocusDistance;
+            tb3 focus = tb3_madd(p.rd, pf.DOFFocusDistance, p.ro);
             float radius = tb_sqrt(bn[6]) * pf.DOFApertureWidth;
             float theta = bn[7] * 2.0f * PI;
             float fx = tb_cos(theta) * radius, fy = tb_sin(theta) * radius;
@@ -646,7 +648,7 @@ TBD void path_on_closest(Path& p, const SceneRefs& sc, const TbDeviceScene& ds, 
     }
     Surface s;
     fetch_surface(sc, h, s, (F & FEAT_TEXTURES) && pf.EnableNormalMaps != 0);
-    tb3 RayPoint = p.ro + p.rd * h.t;
+    tb3 RayPoint = tb3_madd(p.rd, h.t, p.ro);
     p.nextOrigin = RayPoint + s.normal * EPSILON; /* :1353, unflipped normal */
     float nDotD = tb3_dot(s.normal, p.rd);
     const bool back = nDotD > 0.0f;
@@ -656,7 +658,7 @@ TBD void path_on_closest(Path& p, const SceneRefs& sc, const TbDeviceScene& ds, 
     if ((F & FEAT_EXT) && first) { /* :1365-1376 */
         tb3 camPos = ld3(pf.CameraPosition);
         tb3 focal = camPos - pf.FocalDistance * tb3_normalize(ld3(pf.CameraLookAt) - camPos); /* neighbour ray origin, kernel.glsl:1887 */
-        tb3 npt = focal + p.neighborDir * h.t;
+        tb3 npt = tb3_madd(p.neighborDir, h.t, focal);
         p.aovWorldPos = p.aovWorldPos + RayPoint;
         p.aovNeighbor += tb3_length(npt - RayPoint);
         p.aovNormal = Nd;
@@ -825,7 +827,7 @@ TBD void path_on_sss(Path& p, const SceneRefs& sc, const TbPerFrameConstants& pf
     bool exiting = t < travel || noScatter;
     bool lastRay = p.sssStep == MAX_SSS_BOUNCES - 1;
     if (lastRay && !exiting) p.T = tb3_splat(0.0f);
-    tb3 RayPoint = p.ro + p.rd * t;
+    tb3 RayPoint = tb3_madd(p.rd, t, p.ro);
     p.ro = RayPoint + normal * EPSILON;
     p.T = p.T * tb3_make(tb_exp(-t * p.absorption.x), tb_exp(-t * p.absorption.y), tb_exp(-t * p.absorption.z));
     bool stop = false;
