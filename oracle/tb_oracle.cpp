@@ -15,6 +15,7 @@
 #include "../include/tb_vec.h"
 
 #include <atomic>
+#include <cstdlib>
 #include <thread>
 #include <vector>
 
@@ -75,7 +76,24 @@ inline float hash13(tb3 p3)
 struct RayData { /* TraverseFunction.hlsli:464-471 */
     tb3 InverseDirection, OriginTimesRayInverseDirection, Shear;
     int kx, ky, kz;
+    tb3 o; uint32_t degen; /* bit k: direction component k is exactly 0 */
 };
+
+/* The one place where the checker does not follow the reference's box test to the letter: for a ray with
+ * d.k == 0 the reference's c*inv - o*inv is inf - inf = NaN on axis k and that axis never rejects a box
+ * (TraverseFunction.hlsli:212-214).  Hits are unaffected, but the ray visits every node in its slab.
+ * TB_LITERAL_BOX_TEST=1 restores the literal behaviour (tests/test_host_scene.py shows the images are
+ * bit-identical either way); by default the origin must lie inside the box on a degenerate axis. */
+static const bool g_literalBoxTest = getenv("TB_LITERAL_BOX_TEST") && atoi(getenv("TB_LITERAL_BOX_TEST")) != 0;
+
+inline bool DegenerateAxesInside(const RayData& r, tb3 c, tb3 h)
+{
+    bool in = true;
+    if ((r.degen & 1u) && !(tb_abs(r.o.x - c.x) <= h.x + 4e-6f * (tb_abs(r.o.x) + tb_abs(c.x) + h.x))) in = false;
+    if ((r.degen & 2u) && !(tb_abs(r.o.y - c.y) <= h.y + 4e-6f * (tb_abs(r.o.y) + tb_abs(c.y) + h.y))) in = false;
+    if ((r.degen & 4u) && !(tb_abs(r.o.z - c.z) <= h.z + 4e-6f * (tb_abs(r.o.z) + tb_abs(c.z) + h.z))) in = false;
+    return in;
+}
 
 /* TraverseFunction.hlsli:431-445 */
 inline int GetIndexOfBiggestChannel(tb3 v)
@@ -95,6 +113,7 @@ inline RayData GetRayData(tb3 o, tb3 d)
     r.kx = (z + 1) % 3;
     r.ky = (z + 2) % 3;
     r.kz = z;
+    r.o = o; r.degen = (d.x == 0.0f ? 1u : 0u) | (d.y == 0.0f ? 2u : 0u) | (d.z == 0.0f ? 4u : 0u);
     if (tb3_get(d, r.kz) < 0.0f) { int t = r.kx; r.kx = r.ky; r.ky = t; }
     r.Shear = tb3_make(tb3_get(d, r.kx) / tb3_get(d, r.kz), tb3_get(d, r.ky) / tb3_get(d, r.kz),
                        1.0f / tb3_get(d, r.kz));
@@ -114,7 +133,9 @@ inline bool RayBoxTest(float& resultT, float closestT, const RayData& rd, tb3 c,
     float minT = tb_max(tb_max(minL.x, minL.y), minL.z);
     float maxT = tb_min(tb_min(maxL.x, maxL.y), maxL.z);
     resultT = tb_max(minT, 0.0f);
-    return tb_max(minT, 0.0f) < tb_min(maxT, closestT);
+    bool pass = tb_max(minT, 0.0f) < tb_min(maxT, closestT);
+    if (rd.degen && pass && !g_literalBoxTest) pass = DegenerateAxesInside(rd, c, h);
+    return pass;
 }
 
 /* TraverseFunction.hlsli:232-313, two-sided branch (:273-277, :295-307).  `precise` U,V,W: no

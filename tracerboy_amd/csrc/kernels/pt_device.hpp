@@ -79,7 +79,22 @@ TBD float hash13(float x, float y, float z)
 }
 
 /* ---- traversal ------------------------------------------------------------------------------- */
-struct RayPre { tb3 inv, oinv, shear; int kx, ky, kz; };
+struct RayPre { tb3 inv, oinv, shear; int kx, ky, kz; tb3 o; uint32_t degen; /* bit k: direction component k is exactly 0 */ };
+
+/* Axis-parallel rays.  With d.k == 0 the reference's slab arithmetic (c*inv - o*inv, TraverseFunction.hlsli:212-214)
+ * yields inf - inf = NaN on axis k, which min/max ignore: the axis never rejects a box, so such a ray visits every
+ * node inside its slab on the other axes (hundreds of thousands on a large scene) -- and the reference RNG produces
+ * them routinely (rand() returns exactly 0 about once in 300 calls, giving a bounce direction equal to the normal).
+ * The build adds the missing test: the origin must lie inside the box on a degenerate axis, with a tolerance of a few
+ * ulps so that no box the reference would have needed is lost.  Hits are unchanged; only fewer boxes are visited. */
+TBD bool degenerate_axes_inside(const RayPre& r, tb3 c, tb3 h)
+{
+    bool in = true;
+    if ((r.degen & 1u) && !(tb_abs(r.o.x - c.x) <= h.x + 4e-6f * (tb_abs(r.o.x) + tb_abs(c.x) + h.x))) in = false;
+    if ((r.degen & 2u) && !(tb_abs(r.o.y - c.y) <= h.y + 4e-6f * (tb_abs(r.o.y) + tb_abs(c.y) + h.y))) in = false;
+    if ((r.degen & 4u) && !(tb_abs(r.o.z - c.z) <= h.z + 4e-6f * (tb_abs(r.o.z) + tb_abs(c.z) + h.z))) in = false;
+    return in;
+}
 
 TBD RayPre ray_prepare(tb3 o, tb3 d) /* GetRayData, TraverseFunction.hlsli:473-495 */
 {
@@ -92,6 +107,7 @@ TBD RayPre ray_prepare(tb3 o, tb3 d) /* GetRayData, TraverseFunction.hlsli:473-4
     float dz = tb3_get(d, z);
     if (dz < 0.0f) { int t = kx; kx = ky; ky = t; }
     r.kx = kx; r.ky = ky; r.kz = z;
+    r.o = o; r.degen = (d.x == 0.0f ? 1u : 0u) | (d.y == 0.0f ? 2u : 0u) | (d.z == 0.0f ? 4u : 0u);
     r.shear = tb3_make(tb3_get(d, kx) / dz, tb3_get(d, ky) / dz, 1.0f / dz);
     return r;
 }
@@ -106,7 +122,9 @@ TBD bool box_test(float& tEntry, float closest, const RayPre& r, tb3 c, tb3 h) /
     float tmin = tb_max(tb_max(lo.x, lo.y), lo.z);
     float tmax = tb_min(tb_min(hi.x, hi.y), hi.z);
     tEntry = tb_max(tmin, 0.0f);
-    return tb_max(tmin, 0.0f) < tb_min(tmax, closest);
+    bool pass = tb_max(tmin, 0.0f) < tb_min(tmax, closest);
+    if (r.degen && pass) pass = degenerate_axes_inside(r, c, h);
+    return pass;
 }
 
 struct Hit { float t, u, v; uint32_t prim, geom; };
