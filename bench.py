@@ -84,15 +84,11 @@ def main():
     info = tb.SceneInfo()
     TILE = 64
     tb.SetTileAssignment(rank, world, TILE, TILE)
+    from tracerboy_amd import tiles
     owned = tb.OwnedPixels(W, H)
-    packed = torch.zeros((max(owned, 1), 4), dtype=torch.float32, device="cuda")
-    gather_list = None
-    if world > 1:
-        # equal-sized slices: every rank pads to the largest owner so one all_gather-shaped collective suffices
-        mx = torch.tensor([owned], device="cuda"); dist.all_reduce(mx, op=dist.ReduceOp.MAX); cap = int(mx.item())
-        packed = torch.zeros((cap, 4), dtype=torch.float32, device="cuda")
-        if rank == 0:
-            gather_list = [torch.zeros_like(packed) for _ in range(world)]
+    # equal-sized slices: every rank pads to the largest owner (rank 0) so ONE gather per render suffices
+    packed = torch.zeros((max(tiles.packed_capacity(W, H, world, TILE, TILE), 1), 4), dtype=torch.float32, device="cuda")
+    gather_list = [torch.zeros_like(packed) for _ in range(world)] if (world > 1 and rank == 0) else None
     torch.cuda.synchronize()
 
     kernel_ms = []
@@ -102,8 +98,8 @@ def main():
         tb.Render(W, H, SPP, s, 0.0)          # synchronous; GPU time measured with HIP events on the library's stream
         kernel_ms.append(tb.LastRenderMs())
         if world > 1:
-            tb.PackOwnedTo(packed.data_ptr())
-            dist.gather(packed, gather_list, dst=0)
+            tb.PackOwnedTo(packed.data_ptr())     # device-to-device, synchronous on the library's stream
+            tiles.gather_to_rank0(packed, rank, world, gather_list)
 
     def barrier():
         if world > 1:
