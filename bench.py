@@ -33,6 +33,27 @@ def byte_model(st):
             + 104 * st.lightSamples + 32 * st.samples)
 
 
+def pmc_traffic_bytes(args, world):
+    """HBM bytes per launch of the timed kernel from the committed rocprofv3 PMC passes of this exact command
+    (profiles/<round>/<key>_pmc_summary.json, separate --pmc FETCH_SIZE / WRITE_SIZE runs, scripts/profile_r1.sh):
+    (2 * FETCH_SIZE + WRITE_SIZE) * 1024 -- the counters are in KiB and gfx950's FETCH_SIZE reads half the bytes of
+    16-B/lane loads (MI355X_MICROARCH.md, HBM).  None when no profile of this workload is committed."""
+    key = {("cornell-box", 1920, 1080, 64, 8): "c2", ("proc0:870000", 1920, 1080, 16, 6): "c3"}.get(
+        (args.scene, args.width, args.height, args.spp, args.depth))
+    if key is None or world != 1:
+        return None
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", key + "_pmc_summary.json")))
+    if not files:
+        return None
+    for name, passes in json.load(open(files[-1])).items():
+        if ", true>(" in name:   # pt_persistent<F, LDS, COUNT = true>: the counters-on launch, not the timed kernel
+            continue
+        if "fetch" in passes and "write" in passes:
+            return int((2.0 * passes["fetch"]["FETCH_SIZE"] + passes["write"]["WRITE_SIZE"]) * 1024)
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -142,7 +163,7 @@ def main():
         achieved = bytes_per_sample * samples_per_launch / (avg_ms * 1e-3) / 1e9
         result["roofline"] = {
             "bound": "hbm", "kernel": "pt_persistent", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic_bytes(args, world),
             "avg_launch_ms": round(avg_ms, 3), "algorithmic_bytes_per_sample": round(bytes_per_sample, 1),
             "boxes_per_sample": round(st.boxesTested / max(st.samples, 1), 2), "tris_per_sample": round(st.trianglesTested / max(st.samples, 1), 2),
             "rays_per_sample": round(st.rays / max(st.samples, 1), 3),
