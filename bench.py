@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--scene", default="cornell-box")  # or proc0:<tris> / proc1:<tris> / proc2:<tris> / path.pbrt
     ap.add_argument("--builder", type=int, default=1)  # 0 = LBVH (fallback-layer semantics), 1 = binned SAH
+    ap.add_argument("--pipeline", type=int, default=0)  # 0 = lock-step bounce (fastest measured), 1 = streaming (resumable BVH walk)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
     args = ap.parse_args()
@@ -93,6 +94,7 @@ def main():
     s.MaxBounces = args.depth
     tb = api.TracerBoy(local_rank)
     tb.SetOption("bvh_builder", args.builder)
+    tb.SetOption("pipeline", args.pipeline)
     t0 = time.time()
     if args.scene == "cornell-box":
         tb.LoadScene(CORNELL)
@@ -146,7 +148,7 @@ def main():
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s %dx%d %dspp depth%d" % (args.scene, W, H, SPP, args.depth), "triangles": int(info.numTriangles),
-                   "bvh_builder": "lbvh" if args.builder == 0 else "sah", "tile": TILE if world > 1 else None,
+                   "bvh_builder": "lbvh" if args.builder == 0 else "sah", "pipeline": "stream" if args.pipeline == 1 else "lockstep", "tile": TILE if world > 1 else None,
                    "parallelism": "tiles%d" % world, "scene_in_lds": bool(tb.GetOption("scene_in_lds_active")),
                    "kernel_variant": ["matte", "env", "surf", "vol", "full"][tb.GetOption("last_variant")], "scene_load_s": round(load_s, 3)},
     }

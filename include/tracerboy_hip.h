@@ -139,7 +139,8 @@ int tb_pack_owned_device(tb_context* ctx, void* device_dst);   /* device-to-devi
 int tb_unpack_gathered_host(uint32_t width, uint32_t height, uint32_t world, uint32_t tile_w, uint32_t tile_h,
                             const float* const* per_rank_packed, float* full_rgba);
 
-/* Tunables / instrumentation: "pipeline" (0 = per-pixel megakernel, 1 = wavefront queues),
+/* Tunables / instrumentation: "pipeline" (0 = lock-step-bounce persistent kernel [default, fastest measured],
+ * 1 = streaming persistent kernel with a resumable BVH walk),
  * "count_rays" (0/1), "bvh_builder" (0 = LBVH as the reference, 1 = binned SAH), "flatten_instances". */
 int tb_set_option(tb_context* ctx, const char* name, int64_t value);
 int64_t tb_get_option(tb_context* ctx, const char* name);

@@ -17,10 +17,12 @@ ap.add_argument("--height", type=int, default=1080)
 ap.add_argument("--spp", type=int, default=4)
 ap.add_argument("--depth", type=int, default=8)
 ap.add_argument("--builder", type=int, default=1)
+ap.add_argument("--pipeline", type=int, default=0)
 a = ap.parse_args()
 s = api.GetDefaultOutputSettings(); s.EnableBlueNoise = 0; s.MaxBounces = a.depth
 tb = api.TracerBoy(0)
 tb.SetOption("bvh_builder", a.builder)
+tb.SetOption("pipeline", a.pipeline)
 if a.scene == "cornell-box":
     tb.LoadScene(os.path.join(ROOT, "tests/golden/scenes/cornell-box/scene.pbrt"))
 elif a.scene.startswith("proc"):

@@ -254,6 +254,36 @@ def test_all_kernel_variants_agree(gpu_tb, settings):
         assert np.array_equal(bits(a), bits(gpu_tb.ReadAccumulation()))
     finally:
         gpu_tb.SetOption("force_full_variant", 0)
+    # the two schedulings of the same step functions (streaming vs lock-step bounce) agree as well
+    for pipeline in (0, 1, 2):
+        gpu_tb.SetOption("pipeline", pipeline); gpu_tb.InvalidateHistory()
+        gpu_tb.Render(W, H, F, settings, 0.0)
+        assert np.array_equal(bits(a), bits(gpu_tb.ReadAccumulation())), pipeline
+    gpu_tb.SetOption("pipeline", 0)
+
+
+@pytest.mark.parametrize("scene", ["cornell", "teapot", "proc0"])
+def test_wavefront_pipeline_bit_exact(gpu_tb, settings, scene):
+    """SoA-queue wavefront pipeline (generate/extend/shade/connect kernels, ballot-prefix compaction, frames of a
+    batch in flight together, ordered accumulation from the sample buffer) against the oracle; the path budget is
+    forced small so that several batches and partially filled queues occur."""
+    if scene == "cornell":
+        gpu_tb.LoadScene(CORNELL); W, H, F, depth = 200, 120, 7, 8
+    elif scene == "teapot":
+        gpu_tb.LoadScene(TEAPOT); W, H, F, depth = 96, 54, 3, 5
+    else:
+        gpu_tb.LoadProcedural(0, 30000, 11); W, H, F, depth = 120, 72, 4, 6
+    s = copy.copy(settings); s.MaxBounces = depth
+    gpu_tb.SetOption("pipeline", 2); gpu_tb.SetOption("wavefront_paths", W * H * 3)
+    try:
+        gpu_tb.Render(W, H, F - 2, s, 0.0)
+        gpu_tb.Render(W, H, 2, s, 0.0)   # progressive: second call continues the accumulation
+        out, jit = gpu_tb.ReadAccumulation(jittered=True)
+    finally:
+        gpu_tb.SetOption("pipeline", 0); gpu_tb.SetOption("wavefront_paths", 16 << 20)
+    ref = _oracle(gpu_tb, W, H, F, s, jittered=True)
+    assert np.array_equal(bits(out), bits(ref["output"]))
+    assert np.array_equal(bits(jit), bits(ref["jittered"]))
 
 
 def test_tile_split_reproduces_the_single_gpu_image(gpu_tb, settings):

@@ -11,6 +11,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstring>
 #include <map>
 #include <stdexcept>
@@ -21,17 +22,27 @@ using namespace tbhost;
 
 extern "C" {
 typedef hipError_t (*pt_variant_fn)(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, uint32_t, uint32_t, uint32_t, uint32_t,
-                                    const TbTileMap*, int, int);
-hipError_t pt_launch_persistent_matte(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, uint32_t, uint32_t, uint32_t, uint32_t, const TbTileMap*, int, int);
-hipError_t pt_launch_persistent_env(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, uint32_t, uint32_t, uint32_t, uint32_t, const TbTileMap*, int, int);
-hipError_t pt_launch_persistent_surf(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, uint32_t, uint32_t, uint32_t, uint32_t, const TbTileMap*, int, int);
-hipError_t pt_launch_persistent_vol(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, uint32_t, uint32_t, uint32_t, uint32_t, const TbTileMap*, int, int);
-hipError_t pt_launch_persistent_full(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, uint32_t, uint32_t, uint32_t, uint32_t, const TbTileMap*, int, int);
+                                    const TbTileMap*, int, int, int);
+hipError_t pt_launch_persistent_matte(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, uint32_t, uint32_t, uint32_t, uint32_t, const TbTileMap*, int, int, int);
+hipError_t pt_launch_persistent_env(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, uint32_t, uint32_t, uint32_t, uint32_t, const TbTileMap*, int, int, int);
+hipError_t pt_launch_persistent_surf(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, uint32_t, uint32_t, uint32_t, uint32_t, const TbTileMap*, int, int, int);
+hipError_t pt_launch_persistent_vol(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, uint32_t, uint32_t, uint32_t, uint32_t, const TbTileMap*, int, int, int);
+hipError_t pt_launch_persistent_full(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, uint32_t, uint32_t, uint32_t, uint32_t, const TbTileMap*, int, int, int);
+}
+
+#include "../kernels/wf_types.h"
+extern "C" {
+typedef hipError_t (*wf_variant_fn)(hipStream_t, int, const TbDeviceScene*, const TbPerFrameConstants*, const WfParams*, const WfQueue*, const WfQueue*, const WfQueue*,
+                                    const WfHits*, uint32_t, uint32_t, uint32_t, int, TbFloat4*, TbFloat4*, uint32_t);
+hipError_t wf_launch_matte(hipStream_t, int, const TbDeviceScene*, const TbPerFrameConstants*, const WfParams*, const WfQueue*, const WfQueue*, const WfQueue*, const WfHits*, uint32_t, uint32_t, uint32_t, int, TbFloat4*, TbFloat4*, uint32_t);
+hipError_t wf_launch_env(hipStream_t, int, const TbDeviceScene*, const TbPerFrameConstants*, const WfParams*, const WfQueue*, const WfQueue*, const WfQueue*, const WfHits*, uint32_t, uint32_t, uint32_t, int, TbFloat4*, TbFloat4*, uint32_t);
+hipError_t wf_launch_surf(hipStream_t, int, const TbDeviceScene*, const TbPerFrameConstants*, const WfParams*, const WfQueue*, const WfQueue*, const WfQueue*, const WfHits*, uint32_t, uint32_t, uint32_t, int, TbFloat4*, TbFloat4*, uint32_t);
 }
 
 namespace {
 
 std::string g_createError;
+const wf_variant_fn kWfVariants[3] = {wf_launch_matte, wf_launch_env, wf_launch_surf}; /* same order as kVariants[0..2] */
 
 struct Variant { uint32_t features; pt_variant_fn fn; const char* name; };
 const Variant kVariants[] = {
@@ -62,6 +73,9 @@ struct tb_context {
     /* surfaces */
     uint32_t width = 0, height = 0;
     DevBuf output, jittered, aov[8], stats, rayStats, packed;
+    /* wavefront pipeline: two ping-pong extend queues (4 columns), one shadow queue (11 columns), hits, samples, counters */
+    DevBuf wfCols[2][4], wfShadowCols[11], wfHitA, wfHitG, wfSamples, wfCounts;
+    uint64_t wfCapacity = 0, wfSampleCapacity = 0;
     uint32_t samplesRendered = 0;
     tb_output_settings lastSettings{}; bool haveLastSettings = false;
     float lastTime = 0.0f;
@@ -223,6 +237,53 @@ bool historyRelevantChange(const tb_output_settings& a, const tb_output_settings
            a.DebugValue != b.DebugValue || a.DebugValue2 != b.DebugValue2;
 }
 
+/* Wavefront pipeline (option "pipeline" = 2): frames are processed in batches of as many frames as fit the path
+ * budget; per batch: generate+extend, then MaxBounces x (shade, connect, extend), then the ordered accumulation.
+ * Every launch is a fixed-size grid-stride kernel reading its queue length from device memory: no host sync inside. */
+void renderWavefront(tb_context* c, int variant, uint32_t W, uint32_t H, uint32_t firstFrame, uint32_t n, TbPerFrameConstants pf)
+{
+    auto opt = [&](const char* k, int64_t d) { auto it = c->options.find(k); return it == c->options.end() ? d : it->second; };
+    const uint64_t pixels = (uint64_t)W * H;
+    const uint64_t budget = (uint64_t)opt("wavefront_paths", 16ll << 20);
+    uint32_t batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n, budget / pixels));
+    const uint64_t capacity = pixels * batch;
+    if (capacity > 0xffffff00ull) throw std::runtime_error("wavefront batch exceeds 2^32 paths");
+    if (c->wfCapacity != capacity) {
+        for (int q = 0; q < 2; q++) for (int k = 0; k < 4; k++) ensure(c->wfCols[q][k], capacity * 16);
+        for (int k = 0; k < 11; k++) ensure(c->wfShadowCols[k], capacity * 16);
+        ensure(c->wfHitA, capacity * 16); ensure(c->wfHitG, capacity * 4);
+        ensure(c->wfSamples, capacity * 16);
+        ensure(c->wfCounts, 256 * 4);
+        c->wfCapacity = capacity;
+    }
+    WfQueue E[2], S; memset(E, 0, sizeof E); memset(&S, 0, sizeof S);
+    for (int q = 0; q < 2; q++) { E[q].a = (float4*)c->wfCols[q][0].p; E[q].b = (float4*)c->wfCols[q][1].p; E[q].c = (float4*)c->wfCols[q][2].p; E[q].d = (float4*)c->wfCols[q][3].p; }
+    float4** sc[11] = {&S.a, &S.b, &S.c, &S.d, &S.e, &S.f, &S.g, &S.h, &S.i, &S.j, &S.k};
+    for (int k = 0; k < 11; k++) *sc[k] = (float4*)c->wfShadowCols[k].p;
+    WfHits hits; hits.tuv_prim = (float4*)c->wfHitA.p; hits.geom = (uint32_t*)c->wfHitG.p;
+    const wf_variant_fn fn = kWfVariants[variant];
+    const uint32_t grid = (uint32_t)opt("wavefront_grid", 256 * 8);
+    const uint32_t depth = pf.MaxBounces;
+    if (depth > 100) throw std::runtime_error("wavefront pipeline supports MaxBounces <= 100");
+    for (uint32_t f0 = 0; f0 < n; f0 += batch) {
+        const uint32_t nf = std::min(batch, n - f0);
+        WfParams wp; memset(&wp, 0, sizeof wp);
+        wp.W = W; wp.H = H; wp.firstFrame = firstFrame + f0; wp.numFrames = nf; wp.tiles = c->tiles;
+        wp.samples = (float4*)c->wfSamples.p; wp.counts = (uint32_t*)c->wfCounts.p;
+        HIP_TRY(hipMemsetAsync(c->wfCounts.p, 0, 256 * 4, c->stream));
+        const int lds = c->sceneInLds ? 1 : 0;
+        /* counters: E[b] -> b, S[b] -> 128 + b */
+        HIP_TRY(fn(c->stream, WF_STAGE_GENERATE_EXTEND, &c->ds, &pf, &wp, nullptr, nullptr, &E[0], &hits, 0, 0, 0, lds, nullptr, nullptr, grid));
+        for (uint32_t b = 0; b < depth; b++) {
+            const WfQueue& in = E[b & 1]; const WfQueue& next = E[(b + 1) & 1];
+            HIP_TRY(fn(c->stream, WF_STAGE_SHADE, &c->ds, &pf, &wp, &in, &S, &next, &hits, b, 128 + b, b + 1, lds, nullptr, nullptr, grid));
+            HIP_TRY(fn(c->stream, WF_STAGE_CONNECT, &c->ds, &pf, &wp, nullptr, &S, &next, &hits, 0, 128 + b, b + 1, lds, nullptr, nullptr, grid));
+            if (b + 1 < depth) HIP_TRY(fn(c->stream, WF_STAGE_EXTEND, &c->ds, &pf, &wp, nullptr, nullptr, &next, &hits, 0, 0, b + 1, lds, nullptr, nullptr, grid));
+        }
+        HIP_TRY(fn(c->stream, WF_STAGE_ACCUMULATE, &c->ds, &pf, &wp, nullptr, nullptr, nullptr, &hits, 0, 0, 0, lds, (TbFloat4*)c->output.p, (TbFloat4*)c->jittered.p, grid));
+    }
+}
+
 int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_output_settings* settings, float timeSeed, bool sync)
 {
     if (!c->hasScene) return fail(c, TB_E_NO_SCENE, "tb_render: no scene loaded");
@@ -259,8 +320,11 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
     for (const Variant& k : kVariants) if ((need & ~k.features) == 0) { v = &k; break; }
     if (!v) v = &kVariants[4];
     c->lastVariant = v->name;
+    const int variantIndex = (int)(v - kVariants);
+    const bool wavefront = opt("pipeline", 0) == 2 && variantIndex <= 2 && !count && !aov;
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
-    HIP_TRY(v->fn(c->stream, &c->ds, &pf, &tg, W, H, c->samplesRendered, n, &c->tiles, c->sceneInLds ? 1 : 0, count ? 1 : 0));
+    if (wavefront) { c->lastVariant = std::string(v->name); renderWavefront(c, variantIndex, W, H, c->samplesRendered, n, pf); }
+    else HIP_TRY(v->fn(c->stream, &c->ds, &pf, &tg, W, H, c->samplesRendered, n, &c->tiles, c->sceneInLds ? 1 : 0, count ? 1 : 0, (int)opt("pipeline", 0)));
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
     c->samplesRendered += n;
     if (sync) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipEventElapsedTime(&c->lastMs, c->ev0, c->ev1)); }
@@ -297,6 +361,9 @@ void tb_destroy(tb_context* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     releaseScene(c);
     c->output.release(); c->jittered.release(); c->stats.release(); c->rayStats.release(); c->packed.release();
+    for (int q = 0; q < 2; q++) for (DevBuf& b : c->wfCols[q]) b.release();
+    for (DevBuf& b : c->wfShadowCols) b.release();
+    c->wfHitA.release(); c->wfHitG.release(); c->wfSamples.release(); c->wfCounts.release();
     for (DevBuf& b : c->aov) b.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -472,7 +539,7 @@ int tb_unpack_gathered_host(uint32_t W, uint32_t H, uint32_t world, uint32_t tw,
 int tb_set_option(tb_context* c, const char* name, int64_t v)
 {
     if (!c || !name) return TB_E_INVALID;
-    static const char* known[] = {"pipeline", "count_rays", "bvh_builder", "flatten_instances", "aov", "scene_in_lds", "lds_scene_budget", "force_full_variant"};
+    static const char* known[] = {"pipeline", "count_rays", "bvh_builder", "flatten_instances", "aov", "scene_in_lds", "lds_scene_budget", "force_full_variant", "wavefront_paths", "wavefront_grid"};
     for (const char* k : known) if (!strcmp(k, name)) { c->options[name] = v; if (!strcmp(name, "count_rays") || !strcmp(name, "aov")) c->samplesRendered = 0; return TB_OK; }
     return fail(c, TB_E_INVALID, std::string("unknown option '") + name + "'");
 }

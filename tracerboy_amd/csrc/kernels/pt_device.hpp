@@ -220,6 +220,56 @@ TBD bool traverse(const SceneRefs& sc, const TbDeviceScene& ds, tb3 o, tb3 d, Hi
     return best.t < MAX_T;
 }
 
+/* Resumable form of the same walk for the streaming kernel: the traversal state lives in registers
+ * across calls, so a lane whose ray has finished can wait for shading while the others keep walking. */
+struct Trav { RayPre r; Hit best; uint32_t ref, top; uint32_t boxes, tris; };
+constexpr uint32_t TRAV_DONE = 0xffffffffu;
+
+TBD bool trav_begin(Trav& t, const TbDeviceScene& ds, tb3 o, tb3 d) /* returns false when the root box is missed */
+{
+    t.best.t = MAX_T; t.best.u = t.best.v = 0.0f; t.best.prim = t.best.geom = 0u;
+    t.boxes = t.tris = 0; t.top = 0;
+    t.r = ray_prepare(o, d);
+    float unusedT;
+    bool in = box_test(unusedT, t.best.t, t.r, ld3(ds.rootCenter), ld3(ds.rootHalf));
+    t.ref = in ? ds.rootRef : TRAV_DONE;
+    return in;
+}
+
+/* One while-while round for the lanes with `busy` set; clears `busy` when a lane's walk is complete. */
+template <bool COUNT, int PARK_MIN>
+TBD void trav_round(Trav& t, bool& busy, const SceneRefs& sc, uint32_t* stack, uint32_t stride, WaveProf* prof)
+{
+    while (busy && !(t.ref & TB_BVH_LEAF_FLAG)) {
+        if (COUNT) prof_hit(prof, PROF_INNER);
+        const TbNodeB n = sc.nodes[t.ref];
+        float lt, rt;
+        bool lh = box_test(lt, t.best.t, t.r, ld3(n.lc), ld3(n.lh));
+        bool rh = box_test(rt, t.best.t, t.r, ld3(n.rc), ld3(n.rh));
+        if (COUNT) t.boxes += 2;
+        if (lh && rh) {
+            bool rightFirst = rt < lt;
+            stack[(t.top++) * stride] = rightFirst ? n.left : n.right;
+            t.ref = rightFirst ? n.right : n.left;
+        } else if (lh || rh) {
+            t.ref = rh ? n.right : n.left;
+        } else {
+            t.ref = t.top ? stack[(--t.top) * stride] : TRAV_DONE;
+        }
+        if (__popcll(__ballot(!(t.ref & TB_BVH_LEAF_FLAG))) < PARK_MIN) break;
+    }
+    if (busy && (t.ref & TB_BVH_LEAF_FLAG)) {
+        if (t.ref != TRAV_DONE) {
+            if (COUNT) prof_hit(prof, PROF_LEAF);
+            const TbTriB tri = sc.tris[t.ref & TB_BVH_INDEX_MASK];
+            if (COUNT) t.tris++;
+            tri_test(t.best, MIN_T, t.r.o, t.r, tri);
+            t.ref = t.top ? stack[(--t.top) * stride] : TRAV_DONE;
+        }
+        if (t.ref == TRAV_DONE) busy = false;
+    }
+}
+
 /* ---- hit attributes: SharedHitGroup.h:48-151 --------------------------------------------------- */
 struct Surface { tb3 normal, tangent; float u, v; int material; };
 

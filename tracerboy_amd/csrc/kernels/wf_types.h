@@ -1,0 +1,24 @@
+/* wf_types.h -- host/device-shared descriptors of the wavefront pipeline's queues (see wf_kernels.inc). */
+#pragma once
+#include <hip/hip_runtime.h>
+#include "pt_scene.h"
+
+struct WfQueue {      /* columns of one queue; unused columns may be null for a feature set */
+    float4 *a, *b, *c, *d;             /* a = (ro, seed)  b = (rd, weight)  c = (T, bits sampleId)  d = (L, bits flags|bounce<<16) */
+    float4 *e, *f, *g, *h, *i, *j, *k; /* shadow queue only: e = (shadow origin, nDotD) f = (shadow dir, roughness) g = (N, specCoef)
+                                          h = (Nd, bits matFlags) i = (nextOrigin, 0) j = (albedo, 0) k = (contrib, 0) */
+};
+struct WfHits { float4* tuv_prim; uint32_t* geom; }; /* (t, u, v, bits prim); t = MAX_T on a miss */
+
+struct WfParams {
+    uint32_t W, H, firstFrame, numFrames;   /* frames of this batch */
+    TbTileMap tiles;
+    float4* samples;                         /* [numFrames][W*H]: (o0, o1, o2, +-o3) sign of .w = jitter coin < 0.5 */
+    uint32_t* counts;                        /* device counters, one per queue instance */
+};
+
+#define WF_STAGE_GENERATE_EXTEND 0
+#define WF_STAGE_SHADE 1
+#define WF_STAGE_CONNECT 2
+#define WF_STAGE_EXTEND 3
+#define WF_STAGE_ACCUMULATE 4
