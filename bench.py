@@ -40,7 +40,7 @@ def pmc_traffic_bytes(args, world):
     16-B/lane loads (MI355X_MICROARCH.md, HBM).  None when no profile of this workload is committed."""
     key = {("cornell-box", 1920, 1080, 64, 8): "c2", ("proc0:870000", 1920, 1080, 16, 6): "c3"}.get(
         (args.scene, args.width, args.height, args.spp, args.depth))
-    if key is None or world != 1:
+    if key is None or world != 1 or args.pipeline != 0:
         return None
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", key + "_pmc_summary.json")))
@@ -148,7 +148,7 @@ def main():
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s %dx%d %dspp depth%d" % (args.scene, W, H, SPP, args.depth), "triangles": int(info.numTriangles),
-                   "bvh_builder": "lbvh" if args.builder == 0 else "sah", "pipeline": "stream" if args.pipeline == 1 else "lockstep", "tile": TILE if world > 1 else None,
+                   "bvh_builder": "lbvh" if args.builder == 0 else "sah", "pipeline": ("lockstep", "stream", "wavefront")[args.pipeline], "tile": TILE if world > 1 else None,
                    "parallelism": "tiles%d" % world, "scene_in_lds": bool(tb.GetOption("scene_in_lds_active")),
                    "kernel_variant": ["matte", "env", "surf", "vol", "full"][tb.GetOption("last_variant")], "scene_load_s": round(load_s, 3)},
     }
@@ -164,7 +164,7 @@ def main():
         samples_per_launch = owned_samples = (W * H if world == 1 else owned) * SPP
         achieved = bytes_per_sample * samples_per_launch / (avg_ms * 1e-3) / 1e9
         result["roofline"] = {
-            "bound": "hbm", "kernel": "pt_persistent", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "bound": "hbm", "kernel": ("pt_persistent", "pt_stream", "wf_* (all stages)")[args.pipeline], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic_bytes(args, world),
             "avg_launch_ms": round(avg_ms, 3), "algorithmic_bytes_per_sample": round(bytes_per_sample, 1),
             "boxes_per_sample": round(st.boxesTested / max(st.samples, 1), 2), "tris_per_sample": round(st.trianglesTested / max(st.samples, 1), 2),

@@ -33,10 +33,10 @@ hipError_t pt_launch_persistent_full(hipStream_t, const TbDeviceScene*, const Tb
 #include "../kernels/wf_types.h"
 extern "C" {
 typedef hipError_t (*wf_variant_fn)(hipStream_t, int, const TbDeviceScene*, const TbPerFrameConstants*, const WfParams*, const WfQueue*, const WfQueue*, const WfQueue*,
-                                    const WfHits*, uint32_t, uint32_t, uint32_t, int, TbFloat4*, TbFloat4*, uint32_t);
-hipError_t wf_launch_matte(hipStream_t, int, const TbDeviceScene*, const TbPerFrameConstants*, const WfParams*, const WfQueue*, const WfQueue*, const WfQueue*, const WfHits*, uint32_t, uint32_t, uint32_t, int, TbFloat4*, TbFloat4*, uint32_t);
-hipError_t wf_launch_env(hipStream_t, int, const TbDeviceScene*, const TbPerFrameConstants*, const WfParams*, const WfQueue*, const WfQueue*, const WfQueue*, const WfHits*, uint32_t, uint32_t, uint32_t, int, TbFloat4*, TbFloat4*, uint32_t);
-hipError_t wf_launch_surf(hipStream_t, int, const TbDeviceScene*, const TbPerFrameConstants*, const WfParams*, const WfQueue*, const WfQueue*, const WfQueue*, const WfHits*, uint32_t, uint32_t, uint32_t, int, TbFloat4*, TbFloat4*, uint32_t);
+                                    const WfHits*, int, TbFloat4*, TbFloat4*, uint32_t);
+hipError_t wf_launch_matte(hipStream_t, int, const TbDeviceScene*, const TbPerFrameConstants*, const WfParams*, const WfQueue*, const WfQueue*, const WfQueue*, const WfHits*, int, TbFloat4*, TbFloat4*, uint32_t);
+hipError_t wf_launch_env(hipStream_t, int, const TbDeviceScene*, const TbPerFrameConstants*, const WfParams*, const WfQueue*, const WfQueue*, const WfQueue*, const WfHits*, int, TbFloat4*, TbFloat4*, uint32_t);
+hipError_t wf_launch_surf(hipStream_t, int, const TbDeviceScene*, const TbPerFrameConstants*, const WfParams*, const WfQueue*, const WfQueue*, const WfQueue*, const WfHits*, int, TbFloat4*, TbFloat4*, uint32_t);
 }
 
 namespace {
@@ -244,43 +244,47 @@ void renderWavefront(tb_context* c, int variant, uint32_t W, uint32_t H, uint32_
 {
     auto opt = [&](const char* k, int64_t d) { auto it = c->options.find(k); return it == c->options.end() ? d : it->second; };
     const uint64_t pixels = (uint64_t)W * H;
+    const uint64_t perFrame = (uint64_t)((W + 7) / 8) * ((H + 7) / 8) * 64; /* sample ids walk whole 8x8 tiles (wf_sample_pixel) */
     const uint64_t budget = (uint64_t)opt("wavefront_paths", 16ll << 20);
-    uint32_t batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n, budget / pixels));
-    const uint64_t capacity = pixels * batch;
+    const uint32_t segCap = (uint32_t)std::max<int64_t>(256, opt("wavefront_segment", 4096));
+    uint32_t batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n, budget / perFrame));
+    const uint64_t maxSegments = (perFrame * batch + segCap - 1) / segCap;
+    const uint64_t capacity = maxSegments * segCap;
     if (capacity > 0xffffff00ull) throw std::runtime_error("wavefront batch exceeds 2^32 paths");
-    if (c->wfCapacity != capacity) {
+    {
         for (int q = 0; q < 2; q++) for (int k = 0; k < 4; k++) ensure(c->wfCols[q][k], capacity * 16);
         for (int k = 0; k < 11; k++) ensure(c->wfShadowCols[k], capacity * 16);
         ensure(c->wfHitA, capacity * 16); ensure(c->wfHitG, capacity * 4);
-        ensure(c->wfSamples, capacity * 16);
-        ensure(c->wfCounts, 256 * 4);
+        ensure(c->wfSamples, pixels * batch * 16);
+        ensure(c->wfCounts, maxSegments * 3 * 4);
         c->wfCapacity = capacity;
     }
     WfQueue E[2], S; memset(E, 0, sizeof E); memset(&S, 0, sizeof S);
     for (int q = 0; q < 2; q++) { E[q].a = (float4*)c->wfCols[q][0].p; E[q].b = (float4*)c->wfCols[q][1].p; E[q].c = (float4*)c->wfCols[q][2].p; E[q].d = (float4*)c->wfCols[q][3].p; }
     float4** sc[11] = {&S.a, &S.b, &S.c, &S.d, &S.e, &S.f, &S.g, &S.h, &S.i, &S.j, &S.k};
     for (int k = 0; k < 11; k++) *sc[k] = (float4*)c->wfShadowCols[k].p;
+    /* per-segment fill counts; every stage writes the counts of all segments of its output queues, so no clearing */
+    E[0].segCount = (uint32_t*)c->wfCounts.p; E[1].segCount = E[0].segCount + maxSegments; S.segCount = E[1].segCount + maxSegments;
     WfHits hits; hits.tuv_prim = (float4*)c->wfHitA.p; hits.geom = (uint32_t*)c->wfHitG.p;
     const wf_variant_fn fn = kWfVariants[variant];
-    const uint32_t grid = (uint32_t)opt("wavefront_grid", 256 * 8);
+    const uint32_t gridOpt = (uint32_t)opt("wavefront_grid", 256 * 8);
     const uint32_t depth = pf.MaxBounces;
-    if (depth > 100) throw std::runtime_error("wavefront pipeline supports MaxBounces <= 100");
     for (uint32_t f0 = 0; f0 < n; f0 += batch) {
         const uint32_t nf = std::min(batch, n - f0);
         WfParams wp; memset(&wp, 0, sizeof wp);
         wp.W = W; wp.H = H; wp.firstFrame = firstFrame + f0; wp.numFrames = nf; wp.tiles = c->tiles;
-        wp.samples = (float4*)c->wfSamples.p; wp.counts = (uint32_t*)c->wfCounts.p;
-        HIP_TRY(hipMemsetAsync(c->wfCounts.p, 0, 256 * 4, c->stream));
+        wp.samples = (float4*)c->wfSamples.p;
+        wp.segCapacity = segCap; wp.numSegments = (uint32_t)((perFrame * nf + segCap - 1) / segCap);
+        const uint32_t grid = std::min(gridOpt, wp.numSegments);
         const int lds = c->sceneInLds ? 1 : 0;
-        /* counters: E[b] -> b, S[b] -> 128 + b */
-        HIP_TRY(fn(c->stream, WF_STAGE_GENERATE_EXTEND, &c->ds, &pf, &wp, nullptr, nullptr, &E[0], &hits, 0, 0, 0, lds, nullptr, nullptr, grid));
+        HIP_TRY(fn(c->stream, WF_STAGE_GENERATE_EXTEND, &c->ds, &pf, &wp, nullptr, nullptr, &E[0], &hits, lds, nullptr, nullptr, grid));
         for (uint32_t b = 0; b < depth; b++) {
             const WfQueue& in = E[b & 1]; const WfQueue& next = E[(b + 1) & 1];
-            HIP_TRY(fn(c->stream, WF_STAGE_SHADE, &c->ds, &pf, &wp, &in, &S, &next, &hits, b, 128 + b, b + 1, lds, nullptr, nullptr, grid));
-            HIP_TRY(fn(c->stream, WF_STAGE_CONNECT, &c->ds, &pf, &wp, nullptr, &S, &next, &hits, 0, 128 + b, b + 1, lds, nullptr, nullptr, grid));
-            if (b + 1 < depth) HIP_TRY(fn(c->stream, WF_STAGE_EXTEND, &c->ds, &pf, &wp, nullptr, nullptr, &next, &hits, 0, 0, b + 1, lds, nullptr, nullptr, grid));
+            HIP_TRY(fn(c->stream, WF_STAGE_SHADE, &c->ds, &pf, &wp, &in, &S, &next, &hits, lds, nullptr, nullptr, grid));
+            HIP_TRY(fn(c->stream, WF_STAGE_CONNECT, &c->ds, &pf, &wp, nullptr, &S, &next, &hits, lds, nullptr, nullptr, grid));
+            if (b + 1 < depth) HIP_TRY(fn(c->stream, WF_STAGE_EXTEND, &c->ds, &pf, &wp, nullptr, nullptr, &next, &hits, lds, nullptr, nullptr, grid));
         }
-        HIP_TRY(fn(c->stream, WF_STAGE_ACCUMULATE, &c->ds, &pf, &wp, nullptr, nullptr, nullptr, &hits, 0, 0, 0, lds, (TbFloat4*)c->output.p, (TbFloat4*)c->jittered.p, grid));
+        HIP_TRY(fn(c->stream, WF_STAGE_ACCUMULATE, &c->ds, &pf, &wp, nullptr, nullptr, nullptr, &hits, lds, (TbFloat4*)c->output.p, (TbFloat4*)c->jittered.p, gridOpt));
     }
 }
 
@@ -539,7 +543,7 @@ int tb_unpack_gathered_host(uint32_t W, uint32_t H, uint32_t world, uint32_t tw,
 int tb_set_option(tb_context* c, const char* name, int64_t v)
 {
     if (!c || !name) return TB_E_INVALID;
-    static const char* known[] = {"pipeline", "count_rays", "bvh_builder", "flatten_instances", "aov", "scene_in_lds", "lds_scene_budget", "force_full_variant", "wavefront_paths", "wavefront_grid"};
+    static const char* known[] = {"pipeline", "count_rays", "bvh_builder", "flatten_instances", "aov", "scene_in_lds", "lds_scene_budget", "force_full_variant", "wavefront_paths", "wavefront_grid", "wavefront_segment"};
     for (const char* k : known) if (!strcmp(k, name)) { c->options[name] = v; if (!strcmp(name, "count_rays") || !strcmp(name, "aov")) c->samplesRendered = 0; return TB_OK; }
     return fail(c, TB_E_INVALID, std::string("unknown option '") + name + "'");
 }

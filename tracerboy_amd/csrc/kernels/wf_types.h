@@ -5,16 +5,20 @@
 
 struct WfQueue {      /* columns of one queue; unused columns may be null for a feature set */
     float4 *a, *b, *c, *d;             /* a = (ro, seed)  b = (rd, weight)  c = (T, bits sampleId)  d = (L, bits flags|bounce<<16) */
-    float4 *e, *f, *g, *h, *i, *j, *k; /* shadow queue only: e = (shadow origin, nDotD) f = (shadow dir, roughness) g = (N, specCoef)
-                                          h = (Nd, bits matFlags) i = (nextOrigin, 0) j = (albedo, 0) k = (contrib, 0) */
+    float4 *e, *f, *g, *h, *i, *j, *k; /* shadow queue only: a = (nextOrigin, seed) b = (prevDir, weight); e = (shadow origin, nDotD)
+                                          f = (shadow dir, roughness) g = (N, specCoef) h = (Nd, bits matFlags) j = (albedo, 0) k = (contrib, 0) */
+    uint32_t* segCount;                /* [numSegments]: live entries of each segment */
 };
 struct WfHits { float4* tuv_prim; uint32_t* geom; }; /* (t, u, v, bits prim); t = MAX_T on a miss */
 
+/* A queue is cut into numSegments segments of segCapacity slots.  One workgroup processes one segment at a time and
+ * appends the survivors to the SAME segment of the output queue (paths never multiply, so it cannot overflow),
+ * compacting with wave ballots + one LDS atomic per wave: no global atomics anywhere in the pipeline. */
 struct WfParams {
     uint32_t W, H, firstFrame, numFrames;   /* frames of this batch */
     TbTileMap tiles;
-    float4* samples;                         /* [numFrames][W*H]: (o0, o1, o2, +-o3) sign of .w = jitter coin < 0.5 */
-    uint32_t* counts;                        /* device counters, one per queue instance */
+    float4* samples;                         /* [numFrames][W*H]: (o0, o1, o2, +-o3), sign of .w = jitter coin < 0.5 */
+    uint32_t segCapacity, numSegments;
 };
 
 #define WF_STAGE_GENERATE_EXTEND 0
