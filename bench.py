@@ -66,6 +66,7 @@ def main():
     ap.add_argument("--scene", default="cornell-box")  # or proc0:<tris> / proc1:<tris> / proc2:<tris> / path.pbrt
     ap.add_argument("--builder", type=int, default=1)  # 0 = LBVH (fallback-layer semantics), 1 = binned SAH
     ap.add_argument("--pipeline", type=int, default=0)  # 0 = lock-step bounce (fastest measured), 1 = streaming (resumable BVH walk)
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=INT")  # extra tb_set_option()s, applied before the scene is loaded
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
     args = ap.parse_args()
@@ -95,6 +96,8 @@ def main():
     tb = api.TracerBoy(local_rank)
     tb.SetOption("bvh_builder", args.builder)
     tb.SetOption("pipeline", args.pipeline)
+    for kv in args.opt:
+        k, v = kv.split("="); tb.SetOption(k, int(v))
     t0 = time.time()
     if args.scene == "cornell-box":
         tb.LoadScene(CORNELL)
@@ -148,7 +151,7 @@ def main():
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s %dx%d %dspp depth%d" % (args.scene, W, H, SPP, args.depth), "triangles": int(info.numTriangles),
-                   "bvh_builder": "lbvh" if args.builder == 0 else "sah", "pipeline": ("lockstep", "stream", "wavefront")[args.pipeline], "tile": TILE if world > 1 else None,
+                   "bvh_builder": "lbvh" if args.builder == 0 else "sah", "pipeline": ("lockstep", "stream", "wavefront", "pooled")[args.pipeline], "tile": TILE if world > 1 else None,
                    "parallelism": "tiles%d" % world, "scene_in_lds": bool(tb.GetOption("scene_in_lds_active")),
                    "kernel_variant": ["matte", "env", "surf", "vol", "full"][tb.GetOption("last_variant")], "scene_load_s": round(load_s, 3)},
     }
@@ -164,7 +167,7 @@ def main():
         samples_per_launch = owned_samples = (W * H if world == 1 else owned) * SPP
         achieved = bytes_per_sample * samples_per_launch / (avg_ms * 1e-3) / 1e9
         result["roofline"] = {
-            "bound": "hbm", "kernel": ("pt_persistent", "pt_stream", "wf_* (all stages)")[args.pipeline], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "bound": "hbm", "kernel": ("pt_persistent", "pt_stream", "wf_* (all stages)", "pt_pooled")[args.pipeline], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic_bytes(args, world),
             "avg_launch_ms": round(avg_ms, 3), "algorithmic_bytes_per_sample": round(bytes_per_sample, 1),
             "boxes_per_sample": round(st.boxesTested / max(st.samples, 1), 2), "tris_per_sample": round(st.trianglesTested / max(st.samples, 1), 2),

@@ -168,10 +168,14 @@ TB_STATIC_ASSERT(sizeof(TbPrimitiveMeta) == 12, "PrimitiveMetaData is 12 B");
  * re-reading a node.  Child reference: bit 31 = leaf, low bits = inner-node index or sorted
  * triangle index. */
 typedef struct TbNodeB {
-    float lc[3]; uint32_t left;   /* left child box centre, left child ref  */
-    float lh[3]; uint32_t right;  /* left child half-extent, right child ref */
-    float rc[3]; uint32_t pad0;
-    float rh[3]; uint32_t pad1;
+    /* [0] = left child, [1] = right child.  The two boxes are interleaved per component so that a lane tests both
+     * children with packed fp32 fmas (v_pk_fma_f32: one instruction per component pair) straight out of four aligned
+     * 16-B loads. */
+    float cx[2], cy[2];           /* box centre */
+    float cz[2], hx[2];           /* half-extent */
+    float hy[2], hz[2];
+    uint32_t left, right;         /* child refs */
+    uint32_t pad[2];
 } TbNodeB;
 TB_STATIC_ASSERT(sizeof(TbNodeB) == 64, "layout-B node is 64 B");
 

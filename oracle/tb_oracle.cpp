@@ -15,6 +15,9 @@
 #include "../include/tb_vec.h"
 
 #include <atomic>
+#include <cstdio>
+#include <mutex>
+#include <string>
 #include <cstdlib>
 #include <thread>
 #include <vector>
@@ -48,6 +51,7 @@ struct Ctx {
     bool aovDepthWritten, aovEmissiveWritten;
     uint32_t lastTris, lastBoxes;
     bool heatmapWritten;
+    char rayKind; /* ray-step log only: E bounce ray, S shadow feeler, W interior walk */
 };
 
 /* kernel.glsl:39-40  float rand() { return fract(sin(seed++ + GetTime())*43758.5453123); } */
@@ -174,6 +178,13 @@ inline float ldf(const uint8_t* p) { float v; memcpy(&v, p, 4); return v; }
 
 const int ORACLE_STACK = 256; /* reference: 16 with no overflow check (RayTracingHlslCompat.h:15) */
 
+/* Optional ray-step log for scheduling studies (scripts/simd_sim.py): with TB_ORACLE_RAY_LOG=<file> every traversal
+ * appends "x y frame steps" where steps is the sequence of I (inner node: both children tested) and L (leaf: one
+ * triangle tested) events in visit order.  Off by default; not used by any test. */
+static FILE* g_rayLog = nullptr;
+static std::mutex g_rayLogMutex;
+static thread_local std::string* g_raySteps = nullptr;
+
 /* TraverseFunction.hlsli:537-779 */
 bool Traverse(const TbSceneView* sc, tb3 origin, tb3 direction, float TMin, float TMax, Committed& hit,
               uint32_t& trianglesTested, uint32_t& boxesTested)
@@ -202,6 +213,7 @@ bool Traverse(const TbSceneView* sc, tb3 origin, tb3 direction, float TMin, floa
             const uint8_t* m = bvh + offMeta + 12u * leafIndex;
             uint32_t geomContribution = ld32(m), primIdx = ld32(m + 4);
             trianglesTested++; /* :662 */
+            if (g_raySteps) g_raySteps->push_back('L');
             uint32_t triId = flagsX & TB_BVH_INDEX_MASK; /* :331 */
             const uint8_t* p = bvh + offPrims + 40u * triId + 4; /* RayTracingHelper.hlsli:210-227 */
             tb3 v0 = tb3_make(ldf(p), ldf(p + 4), ldf(p + 8));
@@ -221,6 +233,7 @@ bool Traverse(const TbSceneView* sc, tb3 origin, tb3 direction, float TMin, floa
             bool lh = RayBoxTest(lt, hit.t, rd, to3((const float*)ln), to3((const float*)(ln + 16)));
             bool rh = RayBoxTest(rt, hit.t, rd, to3((const float*)rn), to3((const float*)(rn + 16)));
             boxesTested += 2; /* :751 */
+            if (g_raySteps) g_raySteps->push_back('I');
             if (top + 2 > ORACLE_STACK) return false; /* would have been UB in the reference */
             if (lh && rh) { /* :754-760, StackPush2 :163-173: far first, near on top; ties -> left first */
                 bool rightFirst = rt < lt;
@@ -263,7 +276,14 @@ inline void IntersectWithMaxDistance(Ctx& c, const Ray& ray, float maxT, float& 
 {
     Committed h;
     uint32_t tris, boxes;
+    std::string steps;
+    if (g_rayLog) g_raySteps = &steps;
     bool isHit = Traverse(c.scene, ray.origin, ray.direction, MIN_T, maxT, h, tris, boxes);
+    if (g_rayLog) {
+        g_raySteps = nullptr;
+        std::lock_guard<std::mutex> lock(g_rayLogMutex);
+        fprintf(g_rayLog, "%u %u %u %c %s\n", c.x, c.y, c.pf->GlobalFrameCount, c.rayKind ? c.rayKind : 'E', steps.empty() ? "-" : steps.c_str());
+    }
     c.lastTris = tris; c.lastBoxes = boxes;
     if (c.stats) { c.stats->boxesTested += boxes; c.stats->trianglesTested += tris; c.stats->rays++; }
     normal = tb3_splat(0); tangent = tb3_splat(0); uvx = uvy = 0; /* payload init :386 */
@@ -686,6 +706,7 @@ tb3 Trace(Ctx& c, Ray ray, Ray neighborRay)
         bool bFirstRay = (i == 0);
         tb3 normal, tangent; float uvx, uvy;
         float resT; int resMat;
+        c.rayKind = 'E';
         IntersectWithMaxDistance(c, ray, 999999.0f, resT, resMat, normal, tangent, uvx, uvy); /* :1312 */
 
         if (accumulatedIndirectLightMultiplier.x < EPSILON && accumulatedIndirectLightMultiplier.y < EPSILON && accumulatedIndirectLightMultiplier.z < EPSILON) break; /* :1319-1326 */
@@ -733,6 +754,7 @@ tb3 Trace(Ctx& c, Ray ray, Ray neighborRay)
                 tb3 ShadowMultiplier = tb3_splat(1.0f);
                 Ray shadowFeeler; shadowFeeler.origin = RayPoint + normal * EPSILON; shadowFeeler.direction = lightDirection;
                 tb3 sN, sT; float su, sv; float sResT; int sMat;
+                c.rayKind = 'S';
                 IntersectWithMaxDistance(c, shadowFeeler, 999999.0f, sResT, sMat, sN, sT, su, sv); /* :1455 */
                 if (sMat != INVALID_MATERIAL_ID) {
                     float LightDirectionDotN = tb3_dot(sN, lightDirection);
@@ -775,6 +797,7 @@ tb3 Trace(Ctx& c, Ray ray, Ray neighborRay)
                 bool brokeOut = false;
                 for (int j = 0; j < MAX_SSS_BOUNCES && !exittingPrimitive; j++) {
                     float travelDistance = tb_max(-tb_log(rnd(c)), 0.1f) * maxTravelDistance;
+                    c.rayKind = 'W';
                     IntersectWithMaxDistance(c, ray, 999999.0f, resT, resMat, normal, tangent, uvx, uvy); /* :1607 */
                     bool bHitFound = resMat != INVALID_MATERIAL_ID;
                     if (!bHitFound) { accumulatedIndirectLightMultiplier = tb3_splat(0.0f); break; }
@@ -1002,6 +1025,8 @@ int tbo_render(const TbSceneView* scene, const TbPerFrameConstants* constants, u
 {
     if (!scene || !constants || !output || y1 > H || y0 > y1) return -1;
     if (stats) memset(stats, 0, sizeof *stats);
+    struct LogGuard { LogGuard() { const char* e = getenv("TB_ORACLE_RAY_LOG"); if (e && *e && !g_rayLog) g_rayLog = fopen(e, "a"); }
+                      ~LogGuard() { if (g_rayLog) { fclose(g_rayLog); g_rayLog = nullptr; } } } logGuard;
     if (numThreads <= 1) { render_rows(scene, constants, W, H, y0, y1, firstFrame, numFrames, output, jittered, aovs, stats); return 0; }
     /* 8-row strips handed out dynamically; each pixel is touched by exactly one thread per frame and
      * frames stay in order inside a strip, so the image is identical to the serial one. */

@@ -18,6 +18,7 @@ ap.add_argument("--spp", type=int, default=4)
 ap.add_argument("--depth", type=int, default=8)
 ap.add_argument("--builder", type=int, default=1)
 ap.add_argument("--pipeline", type=int, default=0)
+ap.add_argument("--paths", type=int, default=2)
 a = ap.parse_args()
 s = api.GetDefaultOutputSettings(); s.EnableBlueNoise = 0; s.MaxBounces = a.depth
 tb = api.TracerBoy(0)
@@ -29,6 +30,14 @@ elif a.scene.startswith("proc"):
     k, n = a.scene[4:].split(":"); tb.LoadProcedural(int(k), int(n), 1234)
 else:
     tb.LoadScene(a.scene)
+ap2 = None
+if a.pipeline == 3:
+    tb.SetOption("pooled_profile", 1); tb.SetOption("pooled_paths", a.paths)
+    tb.Render(a.width, a.height, a.spp, s, 0.0)
+    prof = tb.WaveProfile()
+    n = a.width * a.height * a.spp
+    print(json.dumps({"samples": n, "ms": tb.LastRenderMs(), "phases": {k: {"active": v[0], "trips": v[1], "occupancy": round(v[2], 4), "trips_per_64_samples": round(v[1] * 64 / n, 2)} for k, v in prof.items()}}, indent=1))
+    sys.exit(0)
 tb.SetOption("count_rays", 1)
 tb.Render(a.width, a.height, a.spp, s, 0.0)
 st = tb.ReadbackStats().rays

@@ -255,7 +255,7 @@ def test_all_kernel_variants_agree(gpu_tb, settings):
     finally:
         gpu_tb.SetOption("force_full_variant", 0)
     # the two schedulings of the same step functions (streaming vs lock-step bounce) agree as well
-    for pipeline in (0, 1, 2):
+    for pipeline in (0, 1, 2, 3):
         gpu_tb.SetOption("pipeline", pipeline); gpu_tb.InvalidateHistory()
         gpu_tb.Render(W, H, F, settings, 0.0)
         assert np.array_equal(bits(a), bits(gpu_tb.ReadAccumulation())), pipeline
@@ -281,6 +281,31 @@ def test_wavefront_pipeline_bit_exact(gpu_tb, settings, scene):
         out, jit = gpu_tb.ReadAccumulation(jittered=True)
     finally:
         gpu_tb.SetOption("pipeline", 0); gpu_tb.SetOption("wavefront_paths", 16 << 20)
+    ref = _oracle(gpu_tb, W, H, F, s, jittered=True)
+    assert np.array_equal(bits(out), bits(ref["output"]))
+    assert np.array_equal(bits(jit), bits(ref["jittered"]))
+
+
+@pytest.mark.parametrize("paths", [1, 2])
+@pytest.mark.parametrize("scene", ["cornell", "teapot", "proc0"])
+def test_pooled_pipeline_bit_exact(gpu_tb, settings, scene, paths):
+    """Pipeline 3 (pt_pooled.inc): LDS ray pool with dynamic ray fetch, the bounce ray issued together with the shadow
+    feeler, 1 or 2 samples per lane in flight, ordered accumulation from the sample buffer -- against the oracle.
+    The sample budget is forced small so that several batches occur; odd sizes leave lanes without a pixel."""
+    if scene == "cornell":
+        gpu_tb.LoadScene(CORNELL); W, H, F, depth = 200, 120, 7, 8
+    elif scene == "teapot":
+        gpu_tb.LoadScene(TEAPOT); W, H, F, depth = 97, 55, 3, 5
+    else:
+        gpu_tb.LoadProcedural(0, 30000, 11); W, H, F, depth = 120, 72, 4, 6
+    s = copy.copy(settings); s.MaxBounces = depth
+    gpu_tb.SetOption("pipeline", 3); gpu_tb.SetOption("pooled_paths", paths); gpu_tb.SetOption("pooled_samples", W * H * 3)
+    try:
+        gpu_tb.Render(W, H, F - 2, s, 0.0)
+        gpu_tb.Render(W, H, 2, s, 0.0)   # progressive: second call continues the accumulation
+        out, jit = gpu_tb.ReadAccumulation(jittered=True)
+    finally:
+        gpu_tb.SetOption("pipeline", 0); gpu_tb.SetOption("pooled_samples", 256 << 20); gpu_tb.SetOption("pooled_paths", 2)
     ref = _oracle(gpu_tb, W, H, F, s, jittered=True)
     assert np.array_equal(bits(out), bits(ref["output"]))
     assert np.array_equal(bits(jit), bits(ref["jittered"]))

@@ -135,9 +135,11 @@ def test_layout_b_is_the_same_tree_as_layout_a(cornell_host):
     assert root == 0 and nodes.shape[0] == n - 1 and tris.shape[0] == n
     for i in range(n - 1):
         l, r = a_nodes[i, 3] & 0xffffff, a_nodes[i, 7]
-        assert np.array_equal(nodes[i, 0:3], a_nodes[l, 0:3]) and np.array_equal(nodes[i, 4:7], a_nodes[l, 4:7])
-        assert np.array_equal(nodes[i, 8:11], a_nodes[r, 0:3]) and np.array_equal(nodes[i, 12:15], a_nodes[r, 4:7])
-        for ref, child in ((nodes[i, 3], l), (nodes[i, 7], r)):
+        # layout B interleaves the two child boxes per component: cx[2] cy[2] cz[2] hx[2] hy[2] hz[2] left right
+        for k, child in enumerate((l, r)):
+            assert np.array_equal(nodes[i, [0 + k, 2 + k, 4 + k]], a_nodes[child, 0:3])     # centre
+            assert np.array_equal(nodes[i, [6 + k, 8 + k, 10 + k]], a_nodes[child, 4:7])    # half-extent
+        for ref, child in ((nodes[i, 12], l), (nodes[i, 13], r)):
             if child >= n - 1:
                 assert ref == (0x80000000 | (child - (n - 1)))
             else:

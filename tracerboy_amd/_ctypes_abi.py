@@ -63,8 +63,8 @@ class TbHitGroupRecord(C.Structure):
 
 
 class TbNodeB(C.Structure):
-    _fields_ = [("lc", C.c_float * 3), ("left", C.c_uint32), ("lh", C.c_float * 3), ("right", C.c_uint32),
-                ("rc", C.c_float * 3), ("pad0", C.c_uint32), ("rh", C.c_float * 3), ("pad1", C.c_uint32)]
+    _fields_ = [("cx", C.c_float * 2), ("cy", C.c_float * 2), ("cz", C.c_float * 2), ("hx", C.c_float * 2), ("hy", C.c_float * 2), ("hz", C.c_float * 2),
+                ("left", C.c_uint32), ("right", C.c_uint32), ("pad", C.c_uint32 * 2)]
 
 
 class TbTriB(C.Structure):

@@ -240,8 +240,11 @@ void BuildBvh(HostScene& s, int builder)
     for (uint32_t i = 0; i + 1 < N; i++) {
         uint32_t l = nodes[i].flags & TB_BVH_INDEX_MASK, r = nodes[i].rightNodeIndex;
         TbNodeB nb; memset(&nb, 0, sizeof nb);
-        memcpy(nb.lc, nodes[l].center, 12); memcpy(nb.lh, nodes[l].halfDim, 12);
-        memcpy(nb.rc, nodes[r].center, 12); memcpy(nb.rh, nodes[r].halfDim, 12);
+        const uint32_t child[2] = {l, r};
+        for (int k = 0; k < 2; k++) {
+            nb.cx[k] = nodes[child[k]].center[0]; nb.cy[k] = nodes[child[k]].center[1]; nb.cz[k] = nodes[child[k]].center[2];
+            nb.hx[k] = nodes[child[k]].halfDim[0]; nb.hy[k] = nodes[child[k]].halfDim[1]; nb.hz[k] = nodes[child[k]].halfDim[2];
+        }
         nb.left = ref(l); nb.right = ref(r);
         s.nodesB[i] = nb;
     }

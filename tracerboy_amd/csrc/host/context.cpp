@@ -209,7 +209,11 @@ void finalizeScene(tb_context* c)
     {
         std::vector<uint8_t> blob;
         auto put = [&](const void* p, size_t bytes) { while (blob.size() % 16) blob.push_back(0); uint32_t off = (uint32_t)blob.size(); const uint8_t* b = (const uint8_t*)p; blob.insert(blob.end(), b, b + bytes); return off; };
-        d.offNodes = put(s.nodesB.data(), s.nodesB.size() * sizeof(TbNodeB));
+        {   /* nodes TB_LDS_NODE_STRIDE apart (pt_scene.h) */
+            std::vector<uint8_t> padded(s.nodesB.size() * TB_LDS_NODE_STRIDE, 0);
+            for (size_t i = 0; i < s.nodesB.size(); i++) memcpy(padded.data() + i * TB_LDS_NODE_STRIDE, &s.nodesB[i], sizeof(TbNodeB));
+            d.offNodes = put(padded.data(), padded.size());
+        }
         d.offTris = put(s.trisB.data(), s.trisB.size() * sizeof(TbTriB));
         d.offHitGroups = put(s.hitGroups.data(), s.hitGroups.size() * sizeof(TbHitGroupRecord));
         d.offIndices = put(s.indexBuffer.data(), s.indexBuffer.size() * 4);
@@ -288,6 +292,34 @@ void renderWavefront(tb_context* c, int variant, uint32_t W, uint32_t H, uint32_
     }
 }
 
+/* Pooled pipeline (option "pipeline" = 3, pt_pooled.inc): one persistent launch per batch of frames, then the ordered
+ * accumulation of the batch's sample buffer. */
+void renderPooled(tb_context* c, int variant, uint32_t W, uint32_t H, uint32_t firstFrame, uint32_t n, TbPerFrameConstants pf)
+{
+    auto opt = [&](const char* k, int64_t d) { auto it = c->options.find(k); return it == c->options.end() ? d : it->second; };
+    const uint64_t pixels = (uint64_t)W * H;
+    const uint64_t budget = (uint64_t)opt("pooled_samples", 256ll << 20); /* sample buffer entries (16 B each) */
+    const uint32_t batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n, budget / pixels));
+    if (pixels * batch > 0xffffff00ull) throw std::runtime_error("pooled batch exceeds 2^32 samples");
+    ensure(c->wfSamples, pixels * batch * 16);
+    const wf_variant_fn fn = kWfVariants[variant];
+    const uint32_t blocks = ((W + 15u) / 16u) * ((H + 15u) / 16u);
+    for (uint32_t f0 = 0; f0 < n; f0 += batch) {
+        WfParams wp; memset(&wp, 0, sizeof wp);
+        wp.W = W; wp.H = H; wp.firstFrame = firstFrame + f0; wp.numFrames = std::min(batch, n - f0); wp.tiles = c->tiles;
+        wp.samples = (float4*)c->wfSamples.p;
+        wp.pathsPerLane = (uint32_t)opt("pooled_paths", 2);
+        if (opt("pooled_profile", 0)) { /* counting variant: wave-occupancy slots, read back with tb_read_wave_profile */
+            ensure(c->rayStats, 21 * 8);
+            if (firstFrame + f0 == 0) HIP_TRY(hipMemsetAsync(c->rayStats.p, 0, 21 * 8, c->stream));
+            wp.prof = (unsigned long long*)c->rayStats.p + 7;
+        }
+        const int lds = c->sceneInLds ? 1 : 0;
+        HIP_TRY(fn(c->stream, WF_STAGE_POOLED, &c->ds, &pf, &wp, nullptr, nullptr, nullptr, nullptr, lds, nullptr, nullptr, blocks));
+        HIP_TRY(fn(c->stream, WF_STAGE_ACCUMULATE, &c->ds, &pf, &wp, nullptr, nullptr, nullptr, nullptr, lds, (TbFloat4*)c->output.p, (TbFloat4*)c->jittered.p, 2048));
+    }
+}
+
 int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_output_settings* settings, float timeSeed, bool sync)
 {
     if (!c->hasScene) return fail(c, TB_E_NO_SCENE, "tb_render: no scene loaded");
@@ -326,8 +358,10 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
     c->lastVariant = v->name;
     const int variantIndex = (int)(v - kVariants);
     const bool wavefront = opt("pipeline", 0) == 2 && variantIndex <= 2 && !count && !aov;
+    const bool pooled = opt("pipeline", 0) == 3 && variantIndex <= 2 && !count && !aov;
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
-    if (wavefront) { c->lastVariant = std::string(v->name); renderWavefront(c, variantIndex, W, H, c->samplesRendered, n, pf); }
+    if (wavefront) renderWavefront(c, variantIndex, W, H, c->samplesRendered, n, pf);
+    else if (pooled) renderPooled(c, variantIndex, W, H, c->samplesRendered, n, pf);
     else HIP_TRY(v->fn(c->stream, &c->ds, &pf, &tg, W, H, c->samplesRendered, n, &c->tiles, c->sceneInLds ? 1 : 0, count ? 1 : 0, (int)opt("pipeline", 0)));
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
     c->samplesRendered += n;
@@ -543,7 +577,7 @@ int tb_unpack_gathered_host(uint32_t W, uint32_t H, uint32_t world, uint32_t tw,
 int tb_set_option(tb_context* c, const char* name, int64_t v)
 {
     if (!c || !name) return TB_E_INVALID;
-    static const char* known[] = {"pipeline", "count_rays", "bvh_builder", "flatten_instances", "aov", "scene_in_lds", "lds_scene_budget", "force_full_variant", "wavefront_paths", "wavefront_grid", "wavefront_segment"};
+    static const char* known[] = {"pipeline", "count_rays", "bvh_builder", "flatten_instances", "aov", "scene_in_lds", "lds_scene_budget", "force_full_variant", "wavefront_paths", "wavefront_grid", "wavefront_segment", "pooled_paths", "pooled_samples", "pooled_profile"};
     for (const char* k : known) if (!strcmp(k, name)) { c->options[name] = v; if (!strcmp(name, "count_rays") || !strcmp(name, "aov")) c->samplesRendered = 0; return TB_OK; }
     return fail(c, TB_E_INVALID, std::string("unknown option '") + name + "'");
 }

@@ -53,7 +53,8 @@ enum : uint32_t {
 
 /* Pointers the step functions read through; filled from global memory or from the LDS copy. */
 struct SceneRefs {
-    const TbNodeB* nodes; const TbTriB* tris;
+    const uint8_t* nodes; uint32_t nodeStride; /* layout-B nodes: 64 B apart in global memory, 80 B apart in the LDS copy (bank spread) */
+    const TbTriB* tris;
     const TbHitGroupRecord* hitGroups; const uint32_t* indices; const float* vertices;
     const TbMaterial* materials; const TbLight* lights;
     uint32_t numHitGroups, numIndices, numVertexFloats, numMaterials, numLights;
@@ -79,7 +80,7 @@ TBD float hash13(float x, float y, float z)
 }
 
 /* ---- traversal ------------------------------------------------------------------------------- */
-struct RayPre { tb3 inv, oinv, shear; int kx, ky, kz; tb3 o; uint32_t degen; /* bit k: direction component k is exactly 0 */ };
+struct RayPre { tb3 inv, ainv, oinv, shear; int kx, ky, kz; tb3 o; uint32_t degen; /* bit k: direction component k is exactly 0 */ };
 
 /* Axis-parallel rays.  With d.k == 0 the reference's slab arithmetic (c*inv - o*inv, TraverseFunction.hlsli:212-214)
  * yields inf - inf = NaN on axis k, which min/max ignore: the axis never rejects a box, so such a ray visits every
@@ -100,7 +101,7 @@ TBD RayPre ray_prepare(tb3 o, tb3 d) /* GetRayData, TraverseFunction.hlsli:473-4
 {
     RayPre r;
     r.inv = tb3_make(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    r.oinv = o * r.inv;
+    r.oinv = o * r.inv; r.ainv = tb3_abs(r.inv);
     tb3 a = tb3_abs(d);
     int z = (a.x > a.y && a.x > a.z) ? 0 : (a.y > a.z ? 1 : 2);
     int kx = z == 2 ? 0 : z + 1, ky = kx == 2 ? 0 : kx + 1;
@@ -125,6 +126,41 @@ TBD bool box_test(float& tEntry, float closest, const RayPre& r, tb3 c, tb3 h) /
     bool pass = tb_max(tmin, 0.0f) < tb_min(tmax, closest);
     if (r.degen && pass) pass = degenerate_axes_inside(r, c, h);
     return pass;
+}
+
+/* Both children of a layout-B node at once: the same arithmetic as two box_test() calls, with the nine fmas of the
+ * two boxes issued as packed fp32 (v_pk_fma_f32, IEEE fma per half, so the bits are those of the scalar form). */
+typedef float tbf2 __attribute__((ext_vector_type(2)));
+TBD tbf2 f2_splat(float x) { tbf2 r; r.x = x; r.y = x; return r; }
+TBD tbf2 f2_ld(const float* p) { tbf2 r; r.x = p[0]; r.y = p[1]; return r; }
+
+TBD TbNodeB load_node(const SceneRefs& sc, uint32_t ref)
+{
+    return *(const TbNodeB*)__builtin_assume_aligned(sc.nodes + (size_t)ref * sc.nodeStride, 16);
+}
+
+TBD TbTriB load_tri(const SceneRefs& sc, uint32_t index) /* 48-B records from a 16-B aligned base: three aligned 16-B loads */
+{
+    return *(const TbTriB*)__builtin_assume_aligned((const uint8_t*)sc.tris + (size_t)index * sizeof(TbTriB), 16);
+}
+
+TBD void box_test2(bool& lh, bool& rh, float& lt, float& rt, float closest, const RayPre& r, const TbNodeB& n)
+{
+    const tbf2 cx = f2_ld(n.cx), cy = f2_ld(n.cy), cz = f2_ld(n.cz), hx = f2_ld(n.hx), hy = f2_ld(n.hy), hz = f2_ld(n.hz);
+    const tbf2 mx = __builtin_elementwise_fma(cx, f2_splat(r.inv.x), f2_splat(-r.oinv.x));
+    const tbf2 my = __builtin_elementwise_fma(cy, f2_splat(r.inv.y), f2_splat(-r.oinv.y));
+    const tbf2 mz = __builtin_elementwise_fma(cz, f2_splat(r.inv.z), f2_splat(-r.oinv.z));
+    const tbf2 hix = __builtin_elementwise_fma(hx, f2_splat(r.ainv.x), mx), lox = __builtin_elementwise_fma(-hx, f2_splat(r.ainv.x), mx);
+    const tbf2 hiy = __builtin_elementwise_fma(hy, f2_splat(r.ainv.y), my), loy = __builtin_elementwise_fma(-hy, f2_splat(r.ainv.y), my);
+    const tbf2 hiz = __builtin_elementwise_fma(hz, f2_splat(r.ainv.z), mz), loz = __builtin_elementwise_fma(-hz, f2_splat(r.ainv.z), mz);
+    const float tminL = tb_max(tb_max(lox.x, loy.x), loz.x), tmaxL = tb_min(tb_min(hix.x, hiy.x), hiz.x);
+    const float tminR = tb_max(tb_max(lox.y, loy.y), loz.y), tmaxR = tb_min(tb_min(hix.y, hiy.y), hiz.y);
+    lt = tb_max(tminL, 0.0f); rt = tb_max(tminR, 0.0f);
+    lh = lt < tb_min(tmaxL, closest); rh = rt < tb_min(tmaxR, closest);
+    if (r.degen) {
+        if (lh) lh = degenerate_axes_inside(r, tb3_make(n.cx[0], n.cy[0], n.cz[0]), tb3_make(n.hx[0], n.hy[0], n.hz[0]));
+        if (rh) rh = degenerate_axes_inside(r, tb3_make(n.cx[1], n.cy[1], n.cz[1]), tb3_make(n.hx[1], n.hy[1], n.hz[1]));
+    }
 }
 
 struct Hit { float t, u, v; uint32_t prim, geom; };
@@ -193,10 +229,9 @@ TBD bool traverse(const SceneRefs& sc, const TbDeviceScene& ds, tb3 o, tb3 d, Hi
     while (ref != DONE) {
         while (!(ref & TB_BVH_LEAF_FLAG)) {
             if (COUNT) prof_hit(prof, PROF_INNER);
-            const TbNodeB n = sc.nodes[ref];
-            float lt, rt;
-            bool lh = box_test(lt, best.t, r, ld3(n.lc), ld3(n.lh));
-            bool rh = box_test(rt, best.t, r, ld3(n.rc), ld3(n.rh));
+            const TbNodeB n = load_node(sc, ref);
+            float lt, rt; bool lh, rh;
+            box_test2(lh, rh, lt, rt, best.t, r, n);
             if (COUNT) boxes += 2;
             if (lh && rh) {
                 bool rightFirst = rt < lt;
@@ -211,7 +246,7 @@ TBD bool traverse(const SceneRefs& sc, const TbDeviceScene& ds, tb3 o, tb3 d, Hi
         }
         if ((ref & TB_BVH_LEAF_FLAG) && ref != DONE) {
             if (COUNT) prof_hit(prof, PROF_LEAF);
-            const TbTriB tri = sc.tris[ref & TB_BVH_INDEX_MASK];
+            const TbTriB tri = load_tri(sc, ref & TB_BVH_INDEX_MASK);
             if (COUNT) tris++;
             tri_test(best, MIN_T, o, r, tri);
             ref = top ? stack[(--top) * stride] : DONE;
@@ -242,10 +277,9 @@ TBD void trav_round(Trav& t, bool& busy, const SceneRefs& sc, uint32_t* stack, u
 {
     while (busy && !(t.ref & TB_BVH_LEAF_FLAG)) {
         if (COUNT) prof_hit(prof, PROF_INNER);
-        const TbNodeB n = sc.nodes[t.ref];
-        float lt, rt;
-        bool lh = box_test(lt, t.best.t, t.r, ld3(n.lc), ld3(n.lh));
-        bool rh = box_test(rt, t.best.t, t.r, ld3(n.rc), ld3(n.rh));
+        const TbNodeB n = load_node(sc, t.ref);
+        float lt, rt; bool lh, rh;
+        box_test2(lh, rh, lt, rt, t.best.t, t.r, n);
         if (COUNT) t.boxes += 2;
         if (lh && rh) {
             bool rightFirst = rt < lt;
@@ -261,7 +295,7 @@ TBD void trav_round(Trav& t, bool& busy, const SceneRefs& sc, uint32_t* stack, u
     if (busy && (t.ref & TB_BVH_LEAF_FLAG)) {
         if (t.ref != TRAV_DONE) {
             if (COUNT) prof_hit(prof, PROF_LEAF);
-            const TbTriB tri = sc.tris[t.ref & TB_BVH_INDEX_MASK];
+            const TbTriB tri = load_tri(sc, t.ref & TB_BVH_INDEX_MASK);
             if (COUNT) t.tris++;
             tri_test(t.best, MIN_T, t.r.o, t.r, tri);
             t.ref = t.top ? stack[(--t.top) * stride] : TRAV_DONE;
@@ -380,6 +414,15 @@ TBD TbMaterial fetch_material(const SceneRefs& sc, uint32_t id)
     TbMaterial m;
     if (id < sc.numMaterials) m = sc.materials[id]; else memset(&m, 0, sizeof m);
     return m;
+}
+
+/* Outcome of a shadow feeler's first hit when GetMaterial draws no random number (no mix materials): only the LIGHT
+ * flag of the base material matters (kernel.glsl:1460-1516; texture overrides never touch that flag). */
+TBD bool shadow_hit_is_light(const SceneRefs& sc, uint32_t geom)
+{
+    const uint32_t mi = geom < sc.numHitGroups ? sc.hitGroups[geom].MaterialIndex : 0u;
+    const int flags = mi < sc.numMaterials ? sc.materials[mi].Flags : 0;
+    return (flags & TB_MAT_LIGHT) != 0;
 }
 
 template <uint32_t F>

@@ -5,6 +5,10 @@
 
 /* What the kernels read, as device pointers (the HIP replacement of the root signature at
  * /root/reference/TracerBoy/TracerBoy.cpp:568-664 / SharedRaytracing.h:3-53). */
+/* Layout-B nodes are 64 B; in the LDS image they are stored 80 B apart: with a 64-B stride the 16-B pieces of different
+ * nodes fall on only 4 distinct bank groups (ds_read_b128 serves 16 lanes per cycle), with 80 B on 16. */
+#define TB_LDS_NODE_STRIDE 80u
+
 struct TbDeviceScene {
     const TbNodeB* nodes;        /* layout B, breadth-first order: the first `ldsNodes` are the top of the tree */
     const TbTriB* tris;

@@ -19,6 +19,8 @@ struct WfParams {
     TbTileMap tiles;
     float4* samples;                         /* [numFrames][W*H]: (o0, o1, o2, +-o3), sign of .w = jitter coin < 0.5 */
     uint32_t segCapacity, numSegments;
+    unsigned long long* prof;                /* pipeline 3, counting launch: WaveProf slots (pt_device.hpp), else null */
+    uint32_t pathsPerLane;                   /* pipeline 3 (pt_pooled.inc): samples of its pixel a lane keeps in flight, 1 or 2 */
 };
 
 #define WF_STAGE_GENERATE_EXTEND 0
@@ -26,3 +28,4 @@ struct WfParams {
 #define WF_STAGE_CONNECT 2
 #define WF_STAGE_EXTEND 3
 #define WF_STAGE_ACCUMULATE 4
+#define WF_STAGE_POOLED 5          /* pipeline 3: the whole batch in one persistent launch with an LDS ray pool */
