@@ -88,6 +88,48 @@ def lockstep(samples, park_min=8):
     return total
 
 
+def lockstep_hoisted(samples, park_min=8, share_wave=False, refill_below=48):
+    """lock-step per wave, but the bounce ray is issued together with the shadow feeler (pt_pooled's hoisting) and a
+    lane walks its two rays back to back inside one traversal loop; share_wave: the wave's rays go through a wave-local
+    pool with dynamic fetch instead of staying on their own lane"""
+    total = Wave(park_min)
+    for tile, lanes in tiles(samples).items():
+        seq = {l: [r for f in sorted(fr) for r in fr[f] + [("X", "")]] for l, fr in lanes.items()}   # X = sample boundary
+        pos = {l: 0 for l in seq}
+        while any(pos[l] < len(seq[l]) for l in seq):
+            mine = {}
+            for l in seq:
+                if pos[l] >= len(seq[l]): continue
+                q = seq[l]; i = pos[l]
+                if q[i][0] == "X": pos[l] += 1; continue   # regenerate: costs this lane one round (like the kernel's state machine)
+                take = [q[i][1]]; i += 1
+                if q[i - 1][0] == "S" and q[i][0] != "X": take.append(q[i][1]); i += 1
+                mine[l] = take; pos[l] = i
+            if not mine: continue
+            w = Wave(park_min)
+            if share_wave:
+                pool = [r for l in mine for r in mine[l]]; qi = 0
+                while True:
+                    if qi < len(pool) and w.nbusy() < refill_below:
+                        for l in range(64):
+                            if not w.busy(l) and qi < len(pool): w.give(l, pool[qi]); qi += 1
+                    if not w.nbusy():
+                        if qi >= len(pool): break
+                        continue
+                    w.round()
+            else:
+                left = {l: list(v) for l, v in mine.items()}
+                while True:
+                    for l in left:
+                        if not w.busy(l) and left[l]: w.give(l, left[l].pop(0))
+                    if not w.nbusy():
+                        if not any(left.values()): break
+                        continue
+                    w.round()
+            total.merge(w)
+    return total
+
+
 def pooled(samples, R=1, waves_per_block=4, refill_below=48, park_min=8, hoist=True, block_tiles=None):
     """pt_pooled: a block of 4 waves (2x2 tiles), each lane R samples in flight; per round every path contributes its
     shadow feeler and (hoisted) the next bounce ray; the waves drain the round's pool with dynamic fetch."""
@@ -162,7 +204,11 @@ def main():
     print("%d samples, %.2f rays/sample, %.2f inner + %.2f leaf steps per ray" % (
         n, nr / n, sum(r[1].count("I") for v in samples.values() for r in v) / nr, sum(r[1].count("L") for v in samples.values() for r in v) / nr))
     report("lock-step (pt_persistent) PARK_MIN=8", lockstep(samples, 8), n)
-    for rb in (32, 48, 56, 64):
+    report("lock-step + hoisted bounce ray, own lane", lockstep_hoisted(samples), n)
+    report("lock-step + hoisted, wave-local pool", lockstep_hoisted(samples, share_wave=True), n)
+    for R in (1, 2, 4):
+        report("pooled block R=%d" % R, pooled(samples, R), n)
+    for rb in (48,):
         for pm in (8, 16):
             report("infinite pool refill<%d PARK_MIN=%d" % (rb, pm), infinite_pool(samples, rb, pm), n)
 

@@ -190,8 +190,16 @@ void finalizeScene(tb_context* c)
     c->camera = s.camera;
     releaseScene(c);
     TbDeviceScene& d = c->ds;
-    d.nodes = upload(c, s.nodesB); d.tris = upload(c, s.trisB);
-    d.rootRef = s.rootRefB; d.numNodes = (uint32_t)s.nodesB.size(); d.numTris = (uint32_t)s.trisB.size();
+    if (s.nodesB.size() > 0x7fffffffull / 5 || s.trisB.size() > 0x7fffffffull / 3) throw std::runtime_error("scene too large for 31-bit device child refs");
+    /* device child refs: offsets in 16-B units (pt_scene.h) */
+    auto deviceRef = [](uint32_t ref, uint32_t nodeUnits) { return (ref & TB_BVH_LEAF_FLAG) ? (TB_BVH_LEAF_FLAG | ((ref & ~TB_BVH_LEAF_FLAG) * 3u)) : ref * nodeUnits; };
+    {
+        std::vector<TbNodeB> dev(s.nodesB);
+        for (TbNodeB& nd : dev) { nd.left = deviceRef(nd.left, 4); nd.right = deviceRef(nd.right, 4); }
+        d.nodes = upload(c, dev);
+    }
+    d.tris = upload(c, s.trisB);
+    d.rootRef = deviceRef(s.rootRefB, 4); /* 0 or LEAF|0: the same in both images */ d.numNodes = (uint32_t)s.nodesB.size(); d.numTris = (uint32_t)s.trisB.size();
     { const TbAabbNode* root = (const TbAabbNode*)(s.bvhA.data() + 16); memcpy(d.rootCenter, root->center, 12); memcpy(d.rootHalf, root->halfDim, 12); }
     d.hitGroups = upload(c, s.hitGroups); d.numHitGroups = (uint32_t)s.hitGroups.size();
     d.indexBuffer = upload(c, s.indexBuffer); d.numIndices = (uint32_t)s.indexBuffer.size();
@@ -211,7 +219,10 @@ void finalizeScene(tb_context* c)
         auto put = [&](const void* p, size_t bytes) { while (blob.size() % 16) blob.push_back(0); uint32_t off = (uint32_t)blob.size(); const uint8_t* b = (const uint8_t*)p; blob.insert(blob.end(), b, b + bytes); return off; };
         {   /* nodes TB_LDS_NODE_STRIDE apart (pt_scene.h) */
             std::vector<uint8_t> padded(s.nodesB.size() * TB_LDS_NODE_STRIDE, 0);
-            for (size_t i = 0; i < s.nodesB.size(); i++) memcpy(padded.data() + i * TB_LDS_NODE_STRIDE, &s.nodesB[i], sizeof(TbNodeB));
+            for (size_t i = 0; i < s.nodesB.size(); i++) {
+                TbNodeB nd = s.nodesB[i]; nd.left = deviceRef(nd.left, TB_LDS_NODE_STRIDE / 16); nd.right = deviceRef(nd.right, TB_LDS_NODE_STRIDE / 16);
+                memcpy(padded.data() + i * TB_LDS_NODE_STRIDE, &nd, sizeof nd);
+            }
             d.offNodes = put(padded.data(), padded.size());
         }
         d.offTris = put(s.trisB.data(), s.trisB.size() * sizeof(TbTriB));

@@ -53,7 +53,7 @@ enum : uint32_t {
 
 /* Pointers the step functions read through; filled from global memory or from the LDS copy. */
 struct SceneRefs {
-    const uint8_t* nodes; uint32_t nodeStride; /* layout-B nodes: 64 B apart in global memory, 80 B apart in the LDS copy (bank spread) */
+    const uint8_t* nodes; /* layout-B nodes: 64 B apart in global memory, 80 B apart in the LDS copy (bank spread) */
     const TbTriB* tris;
     const TbHitGroupRecord* hitGroups; const uint32_t* indices; const float* vertices;
     const TbMaterial* materials; const TbLight* lights;
@@ -134,14 +134,19 @@ typedef float tbf2 __attribute__((ext_vector_type(2)));
 TBD tbf2 f2_splat(float x) { tbf2 r; r.x = x; r.y = x; return r; }
 TBD tbf2 f2_ld(const float* p) { tbf2 r; r.x = p[0]; r.y = p[1]; return r; }
 
+/* the records are 16-B aligned in global memory and in the LDS image; say so in the type so that they are fetched
+ * with 16-B loads (global_load_dwordx4 / ds_read_b128) */
+struct __attribute__((aligned(16))) NodeB16 { TbNodeB n; };
+struct __attribute__((aligned(16))) TriB16 { TbTriB t; };
+
 TBD TbNodeB load_node(const SceneRefs& sc, uint32_t ref)
 {
-    return *(const TbNodeB*)__builtin_assume_aligned(sc.nodes + (size_t)ref * sc.nodeStride, 16);
+    return ((const NodeB16*)(sc.nodes + ((size_t)ref << 4)))->n; /* device child refs are offsets in 16-B units (pt_scene.h) */
 }
 
-TBD TbTriB load_tri(const SceneRefs& sc, uint32_t index) /* 48-B records from a 16-B aligned base: three aligned 16-B loads */
+TBD TbTriB load_tri(const SceneRefs& sc, uint32_t leafRef) /* 48-B records from a 16-B aligned base: three aligned 16-B loads */
 {
-    return *(const TbTriB*)__builtin_assume_aligned((const uint8_t*)sc.tris + (size_t)index * sizeof(TbTriB), 16);
+    return ((const TriB16*)((const uint8_t*)sc.tris + ((size_t)(leafRef & TB_DEVICE_REF_MASK) << 4)))->t;
 }
 
 TBD void box_test2(bool& lh, bool& rh, float& lt, float& rt, float closest, const RayPre& r, const TbNodeB& n)
@@ -246,7 +251,7 @@ TBD bool traverse(const SceneRefs& sc, const TbDeviceScene& ds, tb3 o, tb3 d, Hi
         }
         if ((ref & TB_BVH_LEAF_FLAG) && ref != DONE) {
             if (COUNT) prof_hit(prof, PROF_LEAF);
-            const TbTriB tri = load_tri(sc, ref & TB_BVH_INDEX_MASK);
+            const TbTriB tri = load_tri(sc, ref);
             if (COUNT) tris++;
             tri_test(best, MIN_T, o, r, tri);
             ref = top ? stack[(--top) * stride] : DONE;
@@ -295,7 +300,7 @@ TBD void trav_round(Trav& t, bool& busy, const SceneRefs& sc, uint32_t* stack, u
     if (busy && (t.ref & TB_BVH_LEAF_FLAG)) {
         if (t.ref != TRAV_DONE) {
             if (COUNT) prof_hit(prof, PROF_LEAF);
-            const TbTriB tri = load_tri(sc, t.ref & TB_BVH_INDEX_MASK);
+            const TbTriB tri = load_tri(sc, t.ref);
             if (COUNT) t.tris++;
             tri_test(t.best, MIN_T, t.r.o, t.r, tri);
             t.ref = t.top ? stack[(--t.top) * stride] : TRAV_DONE;

@@ -8,6 +8,9 @@
 /* Layout-B nodes are 64 B; in the LDS image they are stored 80 B apart: with a 64-B stride the 16-B pieces of different
  * nodes fall on only 4 distinct bank groups (ds_read_b128 serves 16 lanes per cycle), with 80 B on 16. */
 #define TB_LDS_NODE_STRIDE 80u
+/* Child refs in the DEVICE images are byte offsets / 16 instead of indices, so that an address is one shift-add: an
+ * inner ref is node index * 4 (global image) or * 5 (LDS image), a leaf ref is TB_BVH_LEAF_FLAG | triangle index * 3. */
+#define TB_DEVICE_REF_MASK 0x7fffffffu
 
 struct TbDeviceScene {
     const TbNodeB* nodes;        /* layout B, breadth-first order: the first `ldsNodes` are the top of the tree */
