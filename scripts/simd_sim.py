@@ -88,6 +88,45 @@ def lockstep(samples, park_min=8):
     return total
 
 
+def lockstep_regen(samples, regen_thresh=1, park_min=8, costs=(450.0, 300.0, 150.0, 100.0, 80.0)):
+    """pt_persistent with its non-traversal phases priced too (wave-instructions per trip: regenerate, closest-hit
+    shading, scatter, shadow slot, ray setup) and a regeneration threshold: finished lanes start their next sample only
+    when at least regen_thresh lanes of the wave are waiting (or nobody is alive)."""
+    c_regen, c_shade, c_scatter, c_shadow, c_setup = costs
+    total = Wave(park_min); other = 0.0; regen_trips = iters = 0
+    for tile, lanes in tiles(samples).items():
+        todo = {l: [fr[f] for f in sorted(fr)] for l, fr in lanes.items()}   # lane -> list of samples (ray lists)
+        cur = {l: None for l in todo}; pos = {l: 0 for l in todo}
+        waiting = set(todo)                                                    # lanes that need a new sample
+        while True:
+            alive = [l for l in cur if cur[l] is not None]
+            can = [l for l in waiting if todo[l]]
+            if can and (len(can) >= regen_thresh or not alive):
+                for l in can: cur[l] = todo[l].pop(0); pos[l] = 0; waiting.discard(l)
+                regen_trips += 1; other += c_regen
+                alive = [l for l in cur if cur[l] is not None]
+            if not alive:
+                if not any(todo[l] for l in waiting): break
+                continue
+            iters += 1
+            for kind in ("E", "S"):
+                w = Wave(park_min); n = 0
+                for l in alive:
+                    q = cur[l]
+                    if pos[l] < len(q) and (q[pos[l]][0] == kind or (kind == "E" and q[pos[l]][0] == "W")):
+                        w.give(l, q[pos[l]][1]); pos[l] += 1; n += 1
+                if n:
+                    other += c_setup + (c_shade if kind == "E" else c_shadow)
+                    while w.nbusy(): w.round()
+                    total.merge(w)
+            other += c_scatter
+            for l in alive:
+                if pos[l] >= len(cur[l]): cur[l] = None; waiting.add(l)
+    n = len(samples)
+    print("%-44s traversal %7.1f  other %7.1f  total %7.1f per sample   (regen trips/64 samples %.2f, iterations %.2f)" % (
+        "lock-step regen_thresh=%d" % regen_thresh, total.cost() / n, other / n, (total.cost() + other) / n, regen_trips * 64.0 / n, iters * 64.0 / n))
+
+
 def lockstep_hoisted(samples, park_min=8, share_wave=False, refill_below=48):
     """lock-step per wave, but the bounce ray is issued together with the shadow feeler (pt_pooled's hoisting) and a
     lane walks its two rays back to back inside one traversal loop; share_wave: the wave's rays go through a wave-local
@@ -204,6 +243,9 @@ def main():
     print("%d samples, %.2f rays/sample, %.2f inner + %.2f leaf steps per ray" % (
         n, nr / n, sum(r[1].count("I") for v in samples.values() for r in v) / nr, sum(r[1].count("L") for v in samples.values() for r in v) / nr))
     report("lock-step (pt_persistent) PARK_MIN=8", lockstep(samples, 8), n)
+    for th in (1, 4, 8, 16, 24, 32):
+        lockstep_regen(samples, th)
+    return
     report("lock-step + hoisted bounce ray, own lane", lockstep_hoisted(samples), n)
     report("lock-step + hoisted, wave-local pool", lockstep_hoisted(samples, share_wave=True), n)
     for R in (1, 2, 4):

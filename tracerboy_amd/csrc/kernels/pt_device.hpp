@@ -362,7 +362,18 @@ TBD F4 sample_bilinear_wrap(const TbFloat4* tex, uint32_t w, uint32_t h, float u
     return r;
 }
 
-TBD F4 texture_nonrecursive(const TbDeviceScene& ds, const TbTextureData& td, float u, float v)
+/* The out-of-line helpers take what they read BY VALUE: handing them `ds` (a by-value kernel argument) by reference
+ * makes the compiler copy the whole 336-B struct to scratch and turns every scene pointer loaded back from there into a
+ * generic one (flat_load instead of global_load for all BVH / geometry fetches of the kernel). */
+struct TexArgs { const TbTextureData* textureData; const TbImageDesc* images; const TbFloat4* texelPool; uint32_t numTextureData, numImages; int flip; };
+TBD TexArgs tex_args(const TbDeviceScene& ds)
+{
+    TexArgs a; a.textureData = ds.textureData; a.images = ds.images; a.texelPool = ds.texelPool;
+    a.numTextureData = ds.numTextureData; a.numImages = ds.numImages; a.flip = (int)ds.config.FlipTextureUVs;
+    return a;
+}
+
+TBD F4 texture_nonrecursive(const TexArgs& ds, const TbTextureData& td, float u, float v)
 {
     F4 data = f4(0, 0, 0, 0);
     if (td.TextureType == TB_TEXTURE_TYPE_IMAGE) {
@@ -379,10 +390,10 @@ TBD F4 texture_nonrecursive(const TbDeviceScene& ds, const TbTextureData& td, fl
     return data;
 }
 
-__device__ __noinline__ F4 texture_fetch(const TbDeviceScene& ds, uint32_t textureIndex, float u, float v)
+__device__ __noinline__ F4 texture_fetch_impl(TexArgs ds, uint32_t textureIndex, float u, float v)
 {
     if (textureIndex == TB_INVALID_TEXTURE) return f4(0, 0, 0, 0);
-    if (ds.config.FlipTextureUVs) { u = 0.0f + u * 1.0f; v = 1.0f + v * -1.0f; }
+    if (ds.flip) { u = 0.0f + u * 1.0f; v = 1.0f + v * -1.0f; }
     if (textureIndex >= ds.numTextureData) return f4(0, 0, 0, 0);
     const TbTextureData td = ds.textureData[textureIndex];
     if (td.TextureType == TB_TEXTURE_TYPE_SCALE) {
@@ -396,21 +407,30 @@ __device__ __noinline__ F4 texture_fetch(const TbDeviceScene& ds, uint32_t textu
     return texture_nonrecursive(ds, td, u, v);
 }
 
-__device__ __noinline__ tb3 sample_environment(const TbDeviceScene& ds, tb3 v) /* RayGenCommon.h:21-44 */
+TBD F4 texture_fetch(const TbDeviceScene& ds, uint32_t textureIndex, float u, float v) { return texture_fetch_impl(tex_args(ds), textureIndex, u, v); }
+
+struct EnvArgs { const TbFloat4* map; uint32_t w, h; tb3 vx, vy, vz, scale; };
+__device__ __noinline__ tb3 sample_environment_impl(EnvArgs e, tb3 v) /* RayGenCommon.h:21-44 */
 {
-    const TbConfigConstants& cc = ds.config;
-    tb3 vx = tb3_make(cc.EnvMapTransformVx.x, cc.EnvMapTransformVx.y, cc.EnvMapTransformVx.z);
-    tb3 vy = tb3_make(cc.EnvMapTransformVy.x, cc.EnvMapTransformVy.y, cc.EnvMapTransformVy.z);
-    tb3 vz = tb3_make(cc.EnvMapTransformVz.x, cc.EnvMapTransformVz.y, cc.EnvMapTransformVz.z);
-    v = tb3_make(tb3_dot(v, vx), tb3_dot(v, vy), tb3_dot(v, vz));
+    v = tb3_make(tb3_dot(v, e.vx), tb3_dot(v, e.vy), tb3_dot(v, e.vz));
     tb3 dir = tb3_normalize(v);
     float p = tb_atan2(dir.y, dir.x);
     p = p > 0 ? p : p + 6.28f;
     float u = p / 6.28f;
     float w = tb_acos(dir.z) / 3.14f;
-    if (!ds.envMap) return tb3_splat(0.0f);
-    F4 s = sample_bilinear_wrap(ds.envMap, ds.envWidth, ds.envHeight, u, w);
-    return tb3_make(s.x, s.y, s.z) * ld3(cc.EnvironmentMapColorScale);
+    if (!e.map) return tb3_splat(0.0f);
+    F4 s = sample_bilinear_wrap(e.map, e.w, e.h, u, w);
+    return tb3_make(s.x, s.y, s.z) * e.scale;
+}
+TBD tb3 sample_environment(const TbDeviceScene& ds, tb3 v)
+{
+    const TbConfigConstants& cc = ds.config;
+    EnvArgs e; e.map = ds.envMap; e.w = ds.envWidth; e.h = ds.envHeight;
+    e.vx = tb3_make(cc.EnvMapTransformVx.x, cc.EnvMapTransformVx.y, cc.EnvMapTransformVx.z);
+    e.vy = tb3_make(cc.EnvMapTransformVy.x, cc.EnvMapTransformVy.y, cc.EnvMapTransformVy.z);
+    e.vz = tb3_make(cc.EnvMapTransformVz.x, cc.EnvMapTransformVz.y, cc.EnvMapTransformVz.z);
+    e.scale = ld3(cc.EnvironmentMapColorScale);
+    return sample_environment_impl(e, v);
 }
 
 /* ---- materials: RayGenCommon.h:298-341, kernel.glsl:1224-1246 ---------------------------------- */
