@@ -201,12 +201,22 @@ void finalizeScene(tb_context* c)
     d.tris = upload(c, s.trisB);
     d.rootRef = deviceRef(s.rootRefB, 4); /* 0 or LEAF|0: the same in both images */ d.numNodes = (uint32_t)s.nodesB.size(); d.numTris = (uint32_t)s.trisB.size();
     { const TbAabbNode* root = (const TbAabbNode*)(s.bvhA.data() + 16); memcpy(d.rootCenter, root->center, 12); memcpy(d.rootHalf, root->halfDim, 12); }
-    d.hitGroups = upload(c, s.hitGroups); d.numHitGroups = (uint32_t)s.hitGroups.size();
+    /* shading records in their 16-B aligned device form (pt_scene.h) */
+    std::vector<TbDevHitGroup> devHit(s.hitGroups.size());
+    for (size_t i = 0; i < devHit.size(); i++) {
+        if (s.hitGroups[i].VertexBufferOffset % 32 || s.hitGroups[i].IndexBufferOffset % 4) throw std::runtime_error("hit group buffer offsets must be vertex-/index-aligned");
+        devHit[i] = TbDevHitGroup{s.hitGroups[i].MaterialIndex, s.hitGroups[i].VertexBufferOffset / 4, s.hitGroups[i].IndexBufferOffset / 4, 0};
+    }
+    std::vector<TbDevMaterial> devMat(s.materials.size());
+    for (size_t i = 0; i < devMat.size(); i++) { memset(&devMat[i], 0, sizeof(TbDevMaterial)); devMat[i].m = s.materials[i]; }
+    std::vector<TbDevLight> devLight(s.lights.size());
+    for (size_t i = 0; i < devLight.size(); i++) { memset(&devLight[i], 0, sizeof(TbDevLight)); devLight[i].l = s.lights[i]; }
+    d.hitGroups = upload(c, devHit); d.numHitGroups = (uint32_t)s.hitGroups.size();
     d.indexBuffer = upload(c, s.indexBuffer); d.numIndices = (uint32_t)s.indexBuffer.size();
     d.vertexBuffer = upload(c, s.vertexBuffer); d.numVertexFloats = (uint32_t)s.vertexBuffer.size();
-    d.materials = upload(c, s.materials); d.numMaterials = (uint32_t)s.materials.size();
+    d.materials = upload(c, devMat); d.numMaterials = (uint32_t)s.materials.size();
     d.textureData = upload(c, s.textureData); d.numTextureData = (uint32_t)s.textureData.size();
-    d.lights = upload(c, s.lights); d.numLights = (uint32_t)s.lights.size();
+    d.lights = upload(c, devLight); d.numLights = (uint32_t)s.lights.size();
     d.images = upload(c, s.images); d.numImages = (uint32_t)s.images.size();
     d.texelPool = upload(c, s.texelPool);
     d.envMap = upload(c, s.envMap); d.envWidth = s.envWidth; d.envHeight = s.envHeight;
@@ -226,11 +236,11 @@ void finalizeScene(tb_context* c)
             d.offNodes = put(padded.data(), padded.size());
         }
         d.offTris = put(s.trisB.data(), s.trisB.size() * sizeof(TbTriB));
-        d.offHitGroups = put(s.hitGroups.data(), s.hitGroups.size() * sizeof(TbHitGroupRecord));
+        d.offHitGroups = put(devHit.data(), devHit.size() * sizeof(TbDevHitGroup));
         d.offIndices = put(s.indexBuffer.data(), s.indexBuffer.size() * 4);
         d.offVertices = put(s.vertexBuffer.data(), s.vertexBuffer.size() * 4);
-        d.offMaterials = put(s.materials.data(), s.materials.size() * sizeof(TbMaterial));
-        d.offLights = put(s.lights.data(), s.lights.size() * sizeof(TbLight));
+        d.offMaterials = put(devMat.data(), devMat.size() * sizeof(TbDevMaterial));
+        d.offLights = put(devLight.data(), devLight.size() * sizeof(TbDevLight));
         while (blob.size() % 16) blob.push_back(0);
         size_t budget = (size_t)opt("lds_scene_budget", 40 * 1024);
         c->sceneInLds = blob.size() + (size_t)d.stackDepth * 256 * 4 <= budget && opt("scene_in_lds", 1) != 0;
@@ -482,8 +492,8 @@ int tb_set_material(tb_context* c, int id, const TbMaterial* in)
     return guarded(c, [&]() {
         if (!in || !c->hasScene || id < 0 || id >= (int)c->scene.materials.size()) return fail(c, TB_E_INVALID, "material id out of range");
         c->scene.materials[(size_t)id] = *in;
-        HIP_TRY(hipMemcpy((void*)(c->ds.materials + id), in, sizeof *in, hipMemcpyHostToDevice));
-        if (c->sceneInLds) HIP_TRY(hipMemcpy((void*)(c->ds.ldsBlob + c->ds.offMaterials + sizeof(TbMaterial) * (size_t)id), in, sizeof *in, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy((void*)&c->ds.materials[id].m, in, sizeof *in, hipMemcpyHostToDevice));
+        if (c->sceneInLds) HIP_TRY(hipMemcpy((void*)(c->ds.ldsBlob + c->ds.offMaterials + sizeof(TbDevMaterial) * (size_t)id), in, sizeof *in, hipMemcpyHostToDevice));
         c->sceneFeatures = sceneFeatureMask(c->scene);
         c->samplesRendered = 0;
         return TB_OK;

@@ -13,9 +13,9 @@ __device__ __forceinline__ void make_refs(SceneRefs& sc, const TbDeviceScene& ds
 {
     if (SCENE_LDS) {
         sc.nodes = blob + ds.offNodes; sc.tris = (const TbTriB*)__builtin_assume_aligned(blob + ds.offTris, 16);
-        sc.hitGroups = (const TbHitGroupRecord*)(blob + ds.offHitGroups); sc.indices = (const uint32_t*)(blob + ds.offIndices);
-        sc.vertices = (const float*)(blob + ds.offVertices); sc.materials = (const TbMaterial*)(blob + ds.offMaterials);
-        sc.lights = (const TbLight*)(blob + ds.offLights);
+        sc.hitGroups = (const TbDevHitGroup*)(blob + ds.offHitGroups); sc.indices = (const uint32_t*)(blob + ds.offIndices);
+        sc.vertices = (const float*)(blob + ds.offVertices); sc.materials = (const TbDevMaterial*)(blob + ds.offMaterials);
+        sc.lights = (const TbDevLight*)(blob + ds.offLights);
     } else {
         sc.nodes = (const uint8_t*)ds.nodes; sc.tris = ds.tris; sc.hitGroups = ds.hitGroups; sc.indices = ds.indexBuffer; sc.vertices = ds.vertexBuffer;
         sc.materials = ds.materials; sc.lights = ds.lights;

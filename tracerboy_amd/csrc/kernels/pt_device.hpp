@@ -55,8 +55,8 @@ enum : uint32_t {
 struct SceneRefs {
     const uint8_t* nodes; /* layout-B nodes: 64 B apart in global memory, 80 B apart in the LDS copy (bank spread) */
     const TbTriB* tris;
-    const TbHitGroupRecord* hitGroups; const uint32_t* indices; const float* vertices;
-    const TbMaterial* materials; const TbLight* lights;
+    const TbDevHitGroup* hitGroups; const uint32_t* indices; const float* vertices;
+    const TbDevMaterial* materials; const TbDevLight* lights;
     uint32_t numHitGroups, numIndices, numVertexFloats, numMaterials, numLights;
 };
 
@@ -312,24 +312,34 @@ TBD void trav_round(Trav& t, bool& busy, const SceneRefs& sc, uint32_t* stack, u
 /* ---- hit attributes: SharedHitGroup.h:48-151 --------------------------------------------------- */
 struct Surface { tb3 normal, tangent; float u, v; int material; };
 
-TBD float vbf(const SceneRefs& sc, uint32_t i) { return i < sc.numVertexFloats ? sc.vertices[i] : 0.0f; }
-TBD uint32_t ibu(const SceneRefs& sc, uint32_t i) { return i < sc.numIndices ? sc.indices[i] : 0u; }
+struct __attribute__((aligned(16))) Vertex8 { float f[8]; };   /* N.xyz, UV.xy, T.xyz (SharedHitGroup.h:11 VertexStride 8) */
+struct Index3 { uint32_t a, b, c; };
+
+/* out-of-range reads return 0 like the reference's raw buffer loads; a record is either wholly inside or treated as absent */
+TBD Vertex8 load_vertex(const SceneRefs& sc, uint32_t firstFloat)
+{
+    Vertex8 v;
+    if (firstFloat + 8u <= sc.numVertexFloats) v = *(const Vertex8*)(sc.vertices + firstFloat);
+    else for (int k = 0; k < 8; k++) v.f[k] = 0.0f;
+    return v;
+}
 
 TBD void fetch_surface(const SceneRefs& sc, const Hit& h, Surface& s, bool needTangent)
 {
-    TbHitGroupRecord rec;
+    TbDevHitGroup rec;
     if (h.geom < sc.numHitGroups) rec = sc.hitGroups[h.geom];
-    else { rec.MaterialIndex = 0; rec.VertexBufferOffset = 0; rec.IndexBufferOffset = 0; }
-    const uint32_t vFirst = rec.VertexBufferOffset / 4, iFirst = rec.IndexBufferOffset / 4;
-    const uint32_t i0 = ibu(sc, iFirst + h.prim * 3), i1 = ibu(sc, iFirst + h.prim * 3 + 1), i2 = ibu(sc, iFirst + h.prim * 3 + 2);
+    else { rec.MaterialIndex = 0; rec.vFirst = 0; rec.iFirst = 0; rec.pad = 0; }
+    const uint32_t iAt = rec.iFirst + h.prim * 3;
+    Index3 ix; ix.a = ix.b = ix.c = 0u;
+    if (iAt + 3u <= sc.numIndices) ix = *(const Index3*)(sc.indices + iAt);
     const float bx = 1 - h.u - h.v, by = h.u, bz = h.v; /* GetBarycentrics3 :135-138 */
-    const uint32_t b0 = 8 * i0 + vFirst, b1 = 8 * i1 + vFirst, b2 = 8 * i2 + vFirst;
-    s.u = tb_fma(bz, vbf(sc, b2 + 3), tb_fma(by, vbf(sc, b1 + 3), bx * vbf(sc, b0 + 3)));
-    s.v = tb_fma(bz, vbf(sc, b2 + 4), tb_fma(by, vbf(sc, b1 + 4), bx * vbf(sc, b0 + 4)));
-    tb3 n0 = tb3_make(vbf(sc, b0), vbf(sc, b0 + 1), vbf(sc, b0 + 2)), n1 = tb3_make(vbf(sc, b1), vbf(sc, b1 + 1), vbf(sc, b1 + 2)), n2 = tb3_make(vbf(sc, b2), vbf(sc, b2 + 1), vbf(sc, b2 + 2));
+    const Vertex8 v0 = load_vertex(sc, 8 * ix.a + rec.vFirst), v1 = load_vertex(sc, 8 * ix.b + rec.vFirst), v2 = load_vertex(sc, 8 * ix.c + rec.vFirst);
+    s.u = tb_fma(bz, v2.f[3], tb_fma(by, v1.f[3], bx * v0.f[3]));
+    s.v = tb_fma(bz, v2.f[4], tb_fma(by, v1.f[4], bx * v0.f[4]));
+    tb3 n0 = tb3_make(v0.f[0], v0.f[1], v0.f[2]), n1 = tb3_make(v1.f[0], v1.f[1], v1.f[2]), n2 = tb3_make(v2.f[0], v2.f[1], v2.f[2]);
     s.normal = tb3_normalize(tb3_bary(bx, by, bz, n0, n1, n2));
     if (needTangent) {
-        tb3 t0 = tb3_make(vbf(sc, b0 + 5), vbf(sc, b0 + 6), vbf(sc, b0 + 7)), t1 = tb3_make(vbf(sc, b1 + 5), vbf(sc, b1 + 6), vbf(sc, b1 + 7)), t2 = tb3_make(vbf(sc, b2 + 5), vbf(sc, b2 + 6), vbf(sc, b2 + 7));
+        tb3 t0 = tb3_make(v0.f[5], v0.f[6], v0.f[7]), t1 = tb3_make(v1.f[5], v1.f[6], v1.f[7]), t2 = tb3_make(v2.f[5], v2.f[6], v2.f[7]);
         s.tangent = tb3_normalize(tb3_bary(bx, by, bz, t0, t1, t2));
     } else s.tangent = tb3_splat(0.0f);
     s.material = (int)rec.MaterialIndex;
@@ -437,7 +447,7 @@ TBD tb3 sample_environment(const TbDeviceScene& ds, tb3 v)
 TBD TbMaterial fetch_material(const SceneRefs& sc, uint32_t id)
 {
     TbMaterial m;
-    if (id < sc.numMaterials) m = sc.materials[id]; else memset(&m, 0, sizeof m);
+    if (id < sc.numMaterials) m = sc.materials[id].m; else memset(&m, 0, sizeof m);
     return m;
 }
 
@@ -446,7 +456,7 @@ TBD TbMaterial fetch_material(const SceneRefs& sc, uint32_t id)
 TBD bool shadow_hit_is_light(const SceneRefs& sc, uint32_t geom)
 {
     const uint32_t mi = geom < sc.numHitGroups ? sc.hitGroups[geom].MaterialIndex : 0u;
-    const int flags = mi < sc.numMaterials ? sc.materials[mi].Flags : 0;
+    const int flags = mi < sc.numMaterials ? sc.materials[mi].m.Flags : 0;
     return (flags & TB_MAT_LIGHT) != 0;
 }
 
@@ -691,7 +701,7 @@ TBD void path_pre_extend(Path& p, const TbPerFrameConstants& pf)
 TBD TbLight fetch_light(const SceneRefs& sc, uint32_t i)
 {
     TbLight l;
-    if (i < sc.numLights) l = sc.lights[i]; else memset(&l, 0, sizeof l);
+    if (i < sc.numLights) l = sc.lights[i].l; else memset(&l, 0, sizeof l);
     return l;
 }
 TBD tb3 random_barycentric(float& seed, float time)

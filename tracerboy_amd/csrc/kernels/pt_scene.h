@@ -12,18 +12,25 @@
  * inner ref is node index * 4 (global image) or * 5 (LDS image), a leaf ref is TB_BVH_LEAF_FLAG | triangle index * 3. */
 #define TB_DEVICE_REF_MASK 0x7fffffffu
 
+/* Device copies of the shading records, padded / trimmed to 16-B multiples so that each is fetched with 16-B loads
+ * (a scattered 4-B load costs the vector memory pipe as much as a 16-B one).  The byte model of DESIGN.md keeps the
+ * reference's record sizes. */
+struct __attribute__((aligned(16))) TbDevHitGroup { uint32_t MaterialIndex, vFirst, iFirst, pad; }; /* the fields of HitGroupShaderRecord the path reads; offsets in elements */
+struct __attribute__((aligned(16))) TbDevMaterial { TbMaterial m; uint32_t pad[3]; };               /* 84 -> 96 B */
+struct __attribute__((aligned(16))) TbDevLight { TbLight l; uint32_t pad[2]; };                     /* 104 -> 112 B */
+
 struct TbDeviceScene {
     const TbNodeB* nodes;        /* layout B, breadth-first order: the first `ldsNodes` are the top of the tree */
     const TbTriB* tris;
     uint32_t rootRef;            /* child-ref of the root */
     uint32_t numNodes, numTris;
     float rootCenter[3], rootHalf[3];
-    const TbHitGroupRecord* hitGroups;   uint32_t numHitGroups;
+    const TbDevHitGroup* hitGroups;      uint32_t numHitGroups;
     const uint32_t* indexBuffer;         uint32_t numIndices;
     const float* vertexBuffer;           uint32_t numVertexFloats;
-    const TbMaterial* materials;         uint32_t numMaterials;
+    const TbDevMaterial* materials;      uint32_t numMaterials;
     const TbTextureData* textureData;    uint32_t numTextureData;
-    const TbLight* lights;               uint32_t numLights;
+    const TbDevLight* lights;            uint32_t numLights;
     const TbImageDesc* images;           uint32_t numImages;
     const TbFloat4* texelPool;
     const TbFloat4* envMap;              uint32_t envWidth, envHeight;
