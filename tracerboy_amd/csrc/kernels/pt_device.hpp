@@ -228,7 +228,7 @@ TBD bool traverse(const SceneRefs& sc, const TbDeviceScene& ds, tb3 o, tb3 d, Hi
      * triangle test once for everybody.  Only the interleaving ACROSS lanes changes; each lane's own
      * sequence of box and triangle tests is unchanged. */
     constexpr uint32_t DONE = 0xffffffffu; /* has the leaf bit set, so it also leaves the inner loop */
-    constexpr int PARK_MIN = 8;
+    const int PARK_MIN = (int)ds.parkMin; /* option "park_min", default 8 */
     uint32_t top = 0;
     uint32_t ref = ds.rootRef;
     while (ref != DONE) {
