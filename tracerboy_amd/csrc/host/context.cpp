@@ -227,15 +227,29 @@ void finalizeScene(tb_context* c)
     {
         std::vector<uint8_t> blob;
         auto put = [&](const void* p, size_t bytes) { while (blob.size() % 16) blob.push_back(0); uint32_t off = (uint32_t)blob.size(); const uint8_t* b = (const uint8_t*)p; blob.insert(blob.end(), b, b + bytes); return off; };
+        auto ldsRef = [](uint32_t ref) { return (ref & TB_BVH_LEAF_FLAG) ? (TB_BVH_LEAF_FLAG | ((ref & ~TB_BVH_LEAF_FLAG) * 3u * TB_LDS_TRI_COPIES)) : ref * (TB_LDS_NODE_STRIDE / 16); };
         {   /* nodes TB_LDS_NODE_STRIDE apart (pt_scene.h) */
             std::vector<uint8_t> padded(s.nodesB.size() * TB_LDS_NODE_STRIDE, 0);
             for (size_t i = 0; i < s.nodesB.size(); i++) {
-                TbNodeB nd = s.nodesB[i]; nd.left = deviceRef(nd.left, TB_LDS_NODE_STRIDE / 16); nd.right = deviceRef(nd.right, TB_LDS_NODE_STRIDE / 16);
+                TbNodeB nd = s.nodesB[i]; nd.left = ldsRef(nd.left); nd.right = ldsRef(nd.right);
                 memcpy(padded.data() + i * TB_LDS_NODE_STRIDE, &nd, sizeof nd);
             }
             d.offNodes = put(padded.data(), padded.size());
         }
-        d.offTris = put(s.trisB.data(), s.trisB.size() * sizeof(TbTriB));
+        {   /* six axis-permuted copies per triangle (pt_scene.h): copy = kz * 2 + swapped, (kx, ky) = the two axes after kz, swapped when d[kz] < 0 */
+            std::vector<TbTriB> perm(s.trisB.size() * TB_LDS_TRI_COPIES);
+            for (size_t i = 0; i < s.trisB.size(); i++)
+                for (int kz = 0; kz < 3; kz++)
+                    for (int sw = 0; sw < 2; sw++) {
+                        int kx = kz == 2 ? 0 : kz + 1, ky = kx == 2 ? 0 : kx + 1;
+                        if (sw) std::swap(kx, ky);
+                        const TbTriB& t = s.trisB[i]; TbTriB q = t;
+                        const float* src[3] = {t.v0, t.v1, t.v2}; float* dst[3] = {q.v0, q.v1, q.v2};
+                        for (int v = 0; v < 3; v++) { dst[v][0] = src[v][kx]; dst[v][1] = src[v][ky]; dst[v][2] = src[v][kz]; }
+                        perm[i * TB_LDS_TRI_COPIES + (size_t)(kz * 2 + sw)] = q;
+                    }
+            d.offTris = put(perm.data(), perm.size() * sizeof(TbTriB));
+        }
         d.offHitGroups = put(devHit.data(), devHit.size() * sizeof(TbDevHitGroup));
         d.offIndices = put(s.indexBuffer.data(), s.indexBuffer.size() * 4);
         d.offVertices = put(s.vertexBuffer.data(), s.vertexBuffer.size() * 4);

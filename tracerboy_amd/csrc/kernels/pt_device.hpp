@@ -54,7 +54,7 @@ enum : uint32_t {
 /* Pointers the step functions read through; filled from global memory or from the LDS copy. */
 struct SceneRefs {
     const uint8_t* nodes; /* layout-B nodes: 64 B apart in global memory, 80 B apart in the LDS copy (bank spread) */
-    const TbTriB* tris;
+    const TbTriB* tris; uint32_t trisPermuted; /* LDS image: six axis-permuted copies per triangle (pt_scene.h) */
     const TbDevHitGroup* hitGroups; const uint32_t* indices; const float* vertices;
     const TbDevMaterial* materials; const TbDevLight* lights;
     uint32_t numHitGroups, numIndices, numVertexFloats, numMaterials, numLights;
@@ -80,7 +80,7 @@ TBD float hash13(float x, float y, float z)
 }
 
 /* ---- traversal ------------------------------------------------------------------------------- */
-struct RayPre { tb3 inv, ainv, oinv, shear; int kx, ky, kz; tb3 o; uint32_t degen; /* bit k: direction component k is exactly 0 */ };
+struct RayPre { tb3 inv, ainv, oinv, shear; int kx, ky, kz; tb3 o, operm; uint32_t permUnits; uint32_t degen; /* bit k: direction component k is exactly 0 */ };
 
 /* Axis-parallel rays.  With d.k == 0 the reference's slab arithmetic (c*inv - o*inv, TraverseFunction.hlsli:212-214)
  * yields inf - inf = NaN on axis k, which min/max ignore: the axis never rejects a box, so such a ray visits every
@@ -108,6 +108,8 @@ TBD RayPre ray_prepare(tb3 o, tb3 d) /* GetRayData, TraverseFunction.hlsli:473-4
     float dz = tb3_get(d, z);
     if (dz < 0.0f) { int t = kx; kx = ky; ky = t; }
     r.kx = kx; r.ky = ky; r.kz = z;
+    r.operm = tb3_make(tb3_get(o, kx), tb3_get(o, ky), tb3_get(o, z)); /* for the axis-permuted triangle copies */
+    r.permUnits = (uint32_t)(z * 2 + (dz < 0.0f ? 1 : 0)) * 3u;        /* copy index * 48 B / 16 */
     r.o = o; r.degen = (d.x == 0.0f ? 1u : 0u) | (d.y == 0.0f ? 2u : 0u) | (d.z == 0.0f ? 4u : 0u);
     r.shear = tb3_make(tb3_get(d, kx) / dz, tb3_get(d, ky) / dz, 1.0f / dz);
     return r;
@@ -171,13 +173,23 @@ TBD void box_test2(bool& lh, bool& rh, float& lt, float& rt, float closest, cons
 struct Hit { float t, u, v; uint32_t prim, geom; };
 
 /* Woop/Benthin/Wald watertight test, two-sided branch: RayTriangleIntersect :232-313 + :420-426 */
-TBD void tri_test(Hit& best, float tMin, tb3 o, const RayPre& r, const TbTriB& tri)
+TBD void tri_test(Hit& best, float tMin, tb3 o, const RayPre& r, const TbTriB& tri, bool permuted = false)
 {
-    tb3 a = ld3(tri.v0) - o, b = ld3(tri.v1) - o, c = ld3(tri.v2) - o;
-    float Az = tb3_get(a, r.kz), Bz = tb3_get(b, r.kz), Cz = tb3_get(c, r.kz);
-    float Ax = tb_fma(-r.shear.x, Az, tb3_get(a, r.kx)), Ay = tb_fma(-r.shear.y, Az, tb3_get(a, r.ky));
-    float Bx = tb_fma(-r.shear.x, Bz, tb3_get(b, r.kx)), By = tb_fma(-r.shear.y, Bz, tb3_get(b, r.ky));
-    float Cx = tb_fma(-r.shear.x, Cz, tb3_get(c, r.kx)), Cy = tb_fma(-r.shear.y, Cz, tb3_get(c, r.ky));
+    float Ax, Ay, Az, Bx, By, Bz, Cx, Cy, Cz;
+    if (permuted) {
+        /* the record already holds (v[kx], v[ky], v[kz]) for this ray's axis order: no per-lane component selects */
+        const tb3 a = ld3(tri.v0) - r.operm, b = ld3(tri.v1) - r.operm, c = ld3(tri.v2) - r.operm;
+        Az = a.z; Bz = b.z; Cz = c.z;
+        Ax = tb_fma(-r.shear.x, Az, a.x); Ay = tb_fma(-r.shear.y, Az, a.y);
+        Bx = tb_fma(-r.shear.x, Bz, b.x); By = tb_fma(-r.shear.y, Bz, b.y);
+        Cx = tb_fma(-r.shear.x, Cz, c.x); Cy = tb_fma(-r.shear.y, Cz, c.y);
+    } else {
+        const tb3 a = ld3(tri.v0) - o, b = ld3(tri.v1) - o, c = ld3(tri.v2) - o;
+        Az = tb3_get(a, r.kz); Bz = tb3_get(b, r.kz); Cz = tb3_get(c, r.kz);
+        Ax = tb_fma(-r.shear.x, Az, tb3_get(a, r.kx)); Ay = tb_fma(-r.shear.y, Az, tb3_get(a, r.ky));
+        Bx = tb_fma(-r.shear.x, Bz, tb3_get(b, r.kx)); By = tb_fma(-r.shear.y, Bz, tb3_get(b, r.ky));
+        Cx = tb_fma(-r.shear.x, Cz, tb3_get(c, r.kx)); Cy = tb_fma(-r.shear.y, Cz, tb3_get(c, r.ky));
+    }
     /* `precise` in the reference (TraverseFunction.hlsli:260-262): never contracted */
     float U = Cx * By - Cy * Bx;
     float V = Ax * Cy - Ay * Cx;
@@ -251,9 +263,9 @@ TBD bool traverse(const SceneRefs& sc, const TbDeviceScene& ds, tb3 o, tb3 d, Hi
         }
         if ((ref & TB_BVH_LEAF_FLAG) && ref != DONE) {
             if (COUNT) prof_hit(prof, PROF_LEAF);
-            const TbTriB tri = load_tri(sc, ref);
+            const TbTriB tri = load_tri(sc, sc.trisPermuted ? ref + r.permUnits : ref);
             if (COUNT) tris++;
-            tri_test(best, MIN_T, o, r, tri);
+            tri_test(best, MIN_T, o, r, tri, sc.trisPermuted != 0);
             ref = top ? stack[(--top) * stride] : DONE;
         }
     }
@@ -300,9 +312,9 @@ TBD void trav_round(Trav& t, bool& busy, const SceneRefs& sc, uint32_t* stack, u
     if (busy && (t.ref & TB_BVH_LEAF_FLAG)) {
         if (t.ref != TRAV_DONE) {
             if (COUNT) prof_hit(prof, PROF_LEAF);
-            const TbTriB tri = load_tri(sc, t.ref);
+            const TbTriB tri = load_tri(sc, sc.trisPermuted ? t.ref + t.r.permUnits : t.ref);
             if (COUNT) t.tris++;
-            tri_test(t.best, MIN_T, t.r.o, t.r, tri);
+            tri_test(t.best, MIN_T, t.r.o, t.r, tri, sc.trisPermuted != 0);
             t.ref = t.top ? stack[(--t.top) * stride] : TRAV_DONE;
         }
         if (t.ref == TRAV_DONE) busy = false;

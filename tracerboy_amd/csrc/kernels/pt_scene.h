@@ -11,6 +11,10 @@
 /* Child refs in the DEVICE images are byte offsets / 16 instead of indices, so that an address is one shift-add: an
  * inner ref is node index * 4 (global image) or * 5 (LDS image), a leaf ref is TB_BVH_LEAF_FLAG | triangle index * 3. */
 #define TB_DEVICE_REF_MASK 0x7fffffffu
+/* The LDS image stores every triangle six times, once per axis order (kx, ky, kz) the watertight test can ask for
+ * (copy kz*2 + (d[kz] < 0)): the per-lane component selects of RayTriangleIntersect (18 v_cndmask per test) disappear.
+ * A leaf ref of the LDS image is TB_BVH_LEAF_FLAG | triangle index * 18; the lane adds copy * 3. */
+#define TB_LDS_TRI_COPIES 6u
 
 /* Device copies of the shading records, padded / trimmed to 16-B multiples so that each is fetched with 16-B loads
  * (a scattered 4-B load costs the vector memory pipe as much as a 16-B one).  The byte model of DESIGN.md keeps the

@@ -3,4 +3,5 @@
 #define PT_FEATURES (PT_FEAT_ENV)
 #define PT_NAME env
 #define PT_COUNT 0
+#define PT_PERSISTENT_ATTR __attribute__((amdgpu_waves_per_eu(4))) /* 129 -> 127 VGPRs, 2 spilled: 4 waves per SIMD */
 #include "pt_variant.inc"
