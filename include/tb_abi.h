@@ -80,10 +80,34 @@ TB_STATIC_ASSERT(sizeof(TbLight) == 104, "Light is 26 dwords");
 #define TB_OUTPUT_TYPE_ALBEDO 1u
 #define TB_OUTPUT_TYPE_NORMAL 2u
 #define TB_OUTPUT_TYPE_DEPTH 3u
+#define TB_OUTPUT_TYPE_MOTION_VECTORS 4u
+#define TB_OUTPUT_TYPE_LUMINANCE 5u
+#define TB_OUTPUT_TYPE_VARIANCE 6u
+#define TB_OUTPUT_TYPE_LIVE_PIXELS 7u
+#define TB_OUTPUT_TYPE_LIVE_WAVES 8u
 #define TB_OUTPUT_TYPE_HEATMAP 9u
+/* Tonemap.h:3-10 */
+#define TB_TONEMAP_REINHARD 0u
+#define TB_TONEMAP_ACES 1u
+#define TB_TONEMAP_CLAMP 2u
+#define TB_TONEMAP_UNCHARTED 3u
+#define TB_TONEMAP_KHRONOS_PBR_NEUTRAL 4u
+#define TB_TONEMAP_AGX 5u
+#define TB_TONEMAP_AGX_PUNCHY 6u
+#define TB_TONEMAP_GT 7u
 #define TB_FILTER_TYPE_BOX 0u
 #define TB_FILTER_TYPE_TRIANGLE 1u
 #define TB_FILTER_TYPE_GAUSSIAN 2u
+
+/* PostProcessConstants, SharedPostProcessStructs.h:3-13 (W, H = Resolution) */
+typedef struct TbPostConstants {
+    uint32_t W, H;
+    uint32_t FramesRendered;
+    float ExposureMultiplier;
+    uint32_t TonemapType, UseGammaCorrection, UseAutoExposure, OutputType;
+    float VarianceMultiplier;
+} TbPostConstants;
+TB_STATIC_ASSERT(sizeof(TbPostConstants) == 36, "PostProcessConstants is 9 dwords");
 
 /* SharedShaderStructs.h:141-161 */
 typedef struct TbMaterial {

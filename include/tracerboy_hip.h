@@ -52,6 +52,15 @@ typedef struct tb_output_settings {
     int32_t SampleTarget;
 } tb_output_settings;
 
+/* TracerBoy::PostProcessSettings (TracerBoy.h:222-245) + DebugSettings::m_VarianceMultiplier; defaults TracerBoy.h:298,309-313 */
+typedef struct tb_post_settings {
+    float ExposureMultiplier;         /* m_ExposureMultiplier, default 1                         */
+    uint32_t EnableGammaCorrection;   /* m_bEnableGammaCorrection, default on                     */
+    uint32_t EnableAutoExposure;      /* m_bEnableAutoExposure, default on                        */
+    uint32_t TonemapType;             /* m_TonemapType (TB_TONEMAP_*), default AGX punchy          */
+    float VarianceMultiplier;         /* m_debugSettings.m_VarianceMultiplier, default 1          */
+} tb_post_settings;
+
 /* TracerBoy::ReadbackStats (TracerBoy.h:362-368) + the heatmap counters summed over the render */
 typedef struct tb_readback_stats {
     uint32_t ActiveWaves, ActivePixels;
@@ -116,6 +125,23 @@ int tb_read_accum(tb_context* ctx, float* rgba_sum, float* jittered_or_null);
 int tb_read_aov(tb_context* ctx, int which, void* dst);
 /* device pointers of the accumulation buffers (for zero-copy consumers, e.g. an RCCL gather) */
 int tb_accum_device_ptr(tb_context* ctx, void** output, void** jittered);
+/* ---- output stage ---------------------------------------------------------------
+ * <-> the tail of TracerBoy::Render (TracerBoy.cpp:2948-3030, 3165-3200): luminance histogram + averaged luminance when
+ * auto exposure is on (GenerateHistogramCS.hlsl, CalculateAveragedLuminanceCS.hlsl), then PostProcessCS.hlsl on the
+ * surface GetOutputSRV(output_type) selects (TracerBoy.cpp:2354-2383): the accumulated output for LIT / LUMINANCE, the
+ * AOVs for ALBEDO / HEATMAP / LIVE_PIXELS / NORMAL / DEPTH (render with option "aov").  Writes the post-processed RGBA32F
+ * image and/or the R8G8B8A8_UNORM back-buffer value (either pointer may be NULL), W*H pixels, row 0 = top.
+ * Output types that need surfaces of the real-time chain (motion vectors, variance, live waves) return
+ * TB_E_UNSUPPORTED. */
+void tb_default_post_settings(tb_post_settings* out);
+int tb_post_process(tb_context* ctx, const tb_post_settings* post, uint32_t output_type, float* rgba_f32_or_null, uint8_t* rgba8_or_null);
+/* averaged luminance of the last auto-exposed tb_post_process (AveragedLuminance buffer) */
+int tb_read_averaged_luminance(tb_context* ctx, float* out);
+/* Image files for the headless CLI (the reference presents to a swap chain): ".png" (8-bit RGBA, stored deflate blocks) or
+ * ".pfm" (RGB float, bottom-up per the format) chosen by extension; host-only, no context needed. */
+int tb_write_image_rgba8(const char* path, uint32_t width, uint32_t height, const uint8_t* rgba8);
+int tb_write_image_f32(const char* path, uint32_t width, uint32_t height, const float* rgba);
+
 /* <-> ReadbackStats copy (TracerBoy.cpp:2946, D3D12App.cpp:195-201) */
 int tb_read_stats(tb_context* ctx, tb_readback_stats* out);
 /* Wave-occupancy profile of the last counting render (option "count_rays"): 7 pairs (active lane-executions,

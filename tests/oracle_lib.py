@@ -36,6 +36,8 @@ def lib():
         L.tbo_sample_pixel.restype = None
         L.tbo_sample_pixel.argtypes = [C.POINTER(abi.TbSceneView), C.POINTER(abi.TbPerFrameConstants), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                        C.POINTER(C.c_float * 4), C.POINTER(C.c_float), C.POINTER(abi.TbRayStats)]
+        L.tbo_post_process.restype = None
+        L.tbo_post_process.argtypes = [C.POINTER(abi.TbPostConstants), vp, C.c_int, vp, vp, C.POINTER(C.c_float), vp]
         L.tbo_trace_closest.restype = None
         L.tbo_trace_closest.argtypes = [C.POINTER(abi.TbSceneView), C.c_uint32] + [vp] * 11
         L.tbo_hash13.restype = C.c_float
@@ -84,6 +86,18 @@ def render(view, pf, width, height, frames, first_frame=0, y0=0, y1=None, thread
     if stats:
         res["stats"] = st
     return res
+
+
+def post_process(accum, post, output_type=0, frames_rendered=0, r32=False):
+    """Oracle output stage on an accumulation / AOV surface (H, W, 4) float32 (or (H, W) when r32).
+    post: abi.tb_post_settings.  Returns dict(rgba, rgba8, averaged, histogram)."""
+    a = np.ascontiguousarray(accum, np.float32)
+    h, w = a.shape[:2]
+    pc = abi.TbPostConstants(w, h, frames_rendered, post.ExposureMultiplier, post.TonemapType, post.EnableGammaCorrection, post.EnableAutoExposure,
+                             output_type, post.VarianceMultiplier)
+    rgba = np.empty((h, w, 4), np.float32); rgba8 = np.empty((h, w, 4), np.uint8); hist = np.zeros(256, np.uint32); avg = C.c_float(0)
+    lib().tbo_post_process(C.byref(pc), _p(a), 1 if r32 else 0, _p(rgba), _p(rgba8), C.byref(avg), _p(hist))
+    return {"rgba": rgba, "rgba8": rgba8, "averaged": avg.value, "histogram": hist}
 
 
 def trace_closest(view, origins, dirs):

@@ -1,0 +1,212 @@
+"""Output stage: luminance histogram -> averaged luminance -> PostProcessCS tonemappers -> 8-bit image.
+
+CPU part: the oracle's restatement (oracle/post_ref.cpp) against closed-form float64 evaluations of the reference's
+formulas (Tonemap.h:12-211, GenerateHistogramCS.hlsl:19-31, CalculateAveragedLuminanceCS.hlsl:24-33), and the image
+writers.  GPU part: post_kernels.hip against the oracle, bit for bit, through the C ABI (tb_post_process)."""
+import copy
+import os
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from tracerboy_amd import _ctypes_abi as abi
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CORNELL = os.path.join(GOLDEN, "scenes", "cornell-box", "scene.pbrt")
+TONEMAPS = {"reinhard": 0, "aces": 1, "clamp": 2, "uncharted": 3, "khronos": 4, "agx": 5, "agx_punchy": 6, "gt": 7}
+
+
+def post(tonemap, exposure=1.0, auto=0, gamma=1):
+    return abi.tb_post_settings(exposure, gamma, auto, tonemap, 1.0)
+
+
+def accum_image(rgb, weight=1.0):
+    rgb = np.asarray(rgb, np.float32)
+    a = np.empty(rgb.shape[:-1] + (4,), np.float32)
+    a[..., :3] = rgb * np.float32(weight); a[..., 3] = np.float32(weight)
+    return a
+
+
+# ---- float64 restatements of Tonemap.h, written from the formulas (independent of oracle/post_ref.cpp) ----------------
+def gamma(c): return np.power(np.maximum(c, 0.0), 1.0 / 2.2)
+
+
+def ref_aces(c):
+    m_in = np.array([[0.59719, 0.35458, 0.04823], [0.07600, 0.90834, 0.01566], [0.02840, 0.13383, 0.83777]])
+    m_out = np.array([[1.60475, -0.53108, -0.07367], [-0.10208, 1.10813, -0.00605], [-0.00327, -0.07276, 1.07602]])
+    v = c @ m_in.T
+    v = (v * (v + 0.0245786) - 0.000090537) / (v * (0.983729 * v + 0.4329510) + 0.238081)
+    return gamma(np.clip(v @ m_out.T, 0, 1))
+
+
+def ref_uncharted(c):
+    def part(x):
+        A, B, C, D, E, F = 0.15, 0.50, 0.10, 0.20, 0.02, 0.30
+        return ((x * (A * x + C * B) + D * E) / (x * (A * x + B) + D * F)) - E / F
+    return gamma(part(c * 2.0) / part(11.2))
+
+
+def ref_khronos(c):
+    out = np.empty_like(c)
+    for i, col in enumerate(c):
+        col = col.copy()
+        sc, des = 0.8 - 0.04, 0.15
+        x = col.min()
+        col -= (x - 6.25 * x * x) if x < 0.08 else 0.04
+        peak = col.max()
+        if peak >= sc:
+            d = 1 - sc
+            new_peak = 1 - d * d / (peak + d - sc)
+            col *= new_peak / peak
+            g = 1 - 1 / (des * (peak - new_peak) + 1)
+            col = col + g * (new_peak - col)
+        out[i] = col
+    return gamma(out)
+
+
+def ref_agx(c, punchy):
+    m = np.array([[0.842479062253094, 0.0423282422610123, 0.0423756549057051], [0.0784335999999992, 0.878468636469772, 0.0784336],
+                  [0.0792237451477643, 0.0791661274605434, 0.879142973793104]])
+    lo, hi = -12.47393, 4.026069
+    v = c @ m
+    v = (np.clip(np.log2(np.maximum(v, 1e-300)), lo, hi) - lo) / (hi - lo)
+    v2 = v * v; v4 = v2 * v2
+    v = 15.5 * v4 * v2 - 40.14 * v4 * v + 31.96 * v4 - 6.868 * v2 * v + 0.4298 * v2 + 0.1191 * v - 0.00232
+    luma = v @ np.array([0.2126, 0.7152, 0.0722])
+    power, sat = (1.35, 1.4) if punchy else (1.0, 1.0)
+    v = np.power(np.maximum(v, 0.0), power)
+    return luma[:, None] + sat * (v - luma[:, None])
+
+
+def ref_gt(c):
+    m, a, cc, P, l = 0.22, 1.0, 1.33, 1.0, 0.4
+    l0 = (P - m) * l / a; S0 = m + l0; S1 = m + a * l0; C2 = a * P / (P - S1)
+    L = m + a * (c - m); T = m * np.power(c / m, cc); S = P - (P - S1) * np.exp(-C2 * (c - S0) / P)
+    t = np.clip(c / m, 0, 1); w0 = 1 - t * t * (3 - 2 * t); w2 = (c >= m + l).astype(np.float64); w1 = 1 - w0 - w2
+    return gamma(T * w0 + L * w1 + S * w2)
+
+
+REFERENCE = {
+    "reinhard": lambda c: gamma(c / (1 + c)), "clamp": lambda c: gamma(np.clip(c, 0, 1)), "aces": ref_aces, "uncharted": ref_uncharted,
+    "khronos": ref_khronos, "agx": lambda c: ref_agx(c, False), "agx_punchy": lambda c: ref_agx(c, True), "gt": ref_gt,
+}
+
+
+@pytest.mark.parametrize("name", sorted(TONEMAPS))
+def test_oracle_tonemappers_match_closed_forms(built, name):
+    rng = np.random.default_rng(7)
+    c = np.concatenate([rng.uniform(0.001, 1.2, (200, 3)), rng.uniform(1.0, 12.0, (56, 3))]).astype(np.float32)
+    out = ol.post_process(accum_image(c.reshape(16, 16, 3), weight=3.0), post(TONEMAPS[name], exposure=1.0))["rgba"].reshape(-1, 4)
+    want = REFERENCE[name](c.astype(np.float64))
+    assert np.all(out[:, 3] == 1.0)
+    np.testing.assert_allclose(out[:, :3], want, rtol=3e-5, atol=3e-6)
+
+
+def test_oracle_exposure_and_known_points(built):
+    one = accum_image(np.full((2, 2, 3), 1.0), weight=5.0)
+    r = ol.post_process(one, post(TONEMAPS["reinhard"]))["rgba"]
+    np.testing.assert_allclose(r[..., :3], 0.5 ** (1 / 2.2), rtol=2e-6)          # Reinhard(1) = 1/2, then gamma
+    r = ol.post_process(one, post(TONEMAPS["clamp"], exposure=0.25))
+    np.testing.assert_allclose(r["rgba"][..., :3], 0.25 ** (1 / 2.2), rtol=2e-6)
+    assert np.all(r["rgba8"][..., :3] == int(0.25 ** (1 / 2.2) * 255 + 0.5)) and np.all(r["rgba8"][..., 3] == 255)
+    over = ol.post_process(accum_image(np.full((1, 1, 3), 9.0)), post(TONEMAPS["clamp"]))
+    assert np.all(over["rgba8"] == 255)
+
+
+def test_oracle_auto_exposure_histogram(built):
+    """A frame of constant luminance L falls into one bin; the integer mean of the bin indices gives that bin back and
+    the averaged luminance is the bin's lower edge (GenerateHistogramCS.hlsl:19-31, CalculateAveragedLuminanceCS.hlsl:24-33)."""
+    for L in (0.02, 0.18, 1.0, 7.5):
+        img = accum_image(np.full((24, 40, 3), L), weight=2.0)
+        r = ol.post_process(img, post(TONEMAPS["clamp"], auto=1))
+        lum = np.float32(L) * np.float32(0.212671) + np.float32(L) * np.float32(0.715160) + np.float32(L) * np.float32(0.072169)
+        idx = int(np.clip((np.log2(float(lum)) + 10.0) / 16.0, 0, 1) * 254.0 + 1.0)
+        assert r["histogram"][idx] == 24 * 40 and r["histogram"].sum() == 24 * 40
+        avg = 2.0 ** ((idx - 1.0) / 254.0 * 16.0 - 10.0)
+        assert abs(r["averaged"] - avg) <= 2e-6 * avg
+        expect = np.clip(L * (0.5 ** 2.2) / avg, 0, 1) ** (1 / 2.2)
+        np.testing.assert_allclose(r["rgba"][..., :3], expect, rtol=2e-5)
+    # black pixels go to bin 0 and are left out of the mean's denominator
+    img = accum_image(np.zeros((8, 8, 3)), weight=1.0); img[0, 0, :3] = 1.0
+    r = ol.post_process(img, post(TONEMAPS["clamp"], auto=1))
+    assert r["histogram"][0] == 63
+
+
+def _png_decode(data):
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    at, chunks = 8, []
+    while at < len(data):
+        n, = struct.unpack(">I", data[at:at + 4]); typ = data[at + 4:at + 8]; body = data[at + 8:at + 8 + n]
+        crc, = struct.unpack(">I", data[at + 8 + n:at + 12 + n])
+        assert zlib.crc32(typ + body) == crc
+        chunks.append((typ, body)); at += 12 + n
+    assert [c[0] for c in chunks] == [b"IHDR", b"IDAT", b"IEND"]
+    w, h, depth, ctype, comp, flt, inter = struct.unpack(">IIBBBBB", chunks[0][1])
+    assert (depth, ctype, comp, flt, inter) == (8, 6, 0, 0, 0)
+    raw = np.frombuffer(zlib.decompress(chunks[1][1]), np.uint8).reshape(h, 1 + w * 4)
+    assert np.all(raw[:, 0] == 0)
+    return raw[:, 1:].reshape(h, w, 4)
+
+
+def test_image_writers_round_trip(built, tmp_path):
+    from tracerboy_amd import api
+    rng = np.random.default_rng(3)
+    for (h, w) in ((1, 1), (37, 53), (130, 129)):     # the last one needs more than one 65535-byte stored block
+        img = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+        p = str(tmp_path / ("i%dx%d.png" % (w, h)))
+        api.WriteImage(p, img)
+        assert np.array_equal(_png_decode(open(p, "rb").read()), img)
+    f = rng.standard_normal((19, 23, 4)).astype(np.float32)
+    p = str(tmp_path / "f.pfm")
+    api.WriteImage(p, f)
+    blob = open(p, "rb").read()
+    head = b"PF\n23 19\n-1.0\n"
+    assert blob.startswith(head)
+    rows = np.frombuffer(blob[len(head):], "<f4").reshape(19, 23, 3)
+    assert np.array_equal(rows[::-1], f[..., :3])
+
+
+# ---- GPU: post_kernels.hip against the oracle -----------------------------------------------------------------------
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("auto", [0, 1])
+@pytest.mark.parametrize("name", sorted(TONEMAPS))
+def test_gpu_post_process_bit_exact(gpu_tb, settings, name, auto):
+    gpu_tb.LoadScene(CORNELL)
+    W, H, F = 200, 120, 4
+    gpu_tb.Render(W, H, F, settings, 0.0)
+    ps = post(TONEMAPS[name], exposure=1.7, auto=auto)
+    f, b = gpu_tb.PostProcess(ps)
+    ref = ol.post_process(gpu_tb.ReadAccumulation(), ps, frames_rendered=F)
+    assert np.array_equal(bits(f), bits(ref["rgba"]))
+    assert np.array_equal(b, ref["rgba8"])
+    if auto:
+        assert np.float32(gpu_tb.AveragedLuminance()).view(np.uint32) == np.float32(ref["averaged"]).view(np.uint32)
+
+
+@pytest.mark.gpu
+def test_gpu_post_process_aov_output_types(gpu_tb, settings):
+    """ALBEDO / NORMAL / DEPTH / LUMINANCE go through their own PostProcessCS branch on the surface GetOutputSRV selects."""
+    from tracerboy_amd import api
+    gpu_tb.LoadScene(CORNELL)
+    gpu_tb.SetOption("aov", 1)
+    try:
+        W, H, F = 96, 64, 3
+        gpu_tb.Render(W, H, F, settings, 0.0)
+        ps = post(TONEMAPS["aces"], exposure=1.0, auto=0)
+        for out_type, which, r32 in ((1, 5, False), (2, 2, False), (3, 6, True), (5, None, False)):
+            f, b = gpu_tb.PostProcess(ps, outputType=out_type)
+            src = gpu_tb.ReadAccumulation() if which is None else gpu_tb.ReadAOV(which)
+            ref = ol.post_process(src, ps, output_type=out_type, frames_rendered=F, r32=r32)
+            assert np.array_equal(bits(f), bits(ref["rgba"])), out_type
+            assert np.array_equal(b, ref["rgba8"]), out_type
+        with pytest.raises(api.TracerBoyError):
+            gpu_tb.PostProcess(ps, outputType=4)   # motion vectors: surface of the real-time chain, not built
+    finally:
+        gpu_tb.SetOption("aov", 0)

@@ -112,6 +112,17 @@ class tb_output_settings(C.Structure):
                 ("MaxBounces", C.c_int32), ("SampleTarget", C.c_int32)]
 
 
+class tb_post_settings(C.Structure):
+    _fields_ = [("ExposureMultiplier", C.c_float), ("EnableGammaCorrection", C.c_uint32), ("EnableAutoExposure", C.c_uint32),
+                ("TonemapType", C.c_uint32), ("VarianceMultiplier", C.c_float)]
+
+
+class TbPostConstants(C.Structure):
+    _fields_ = [("W", C.c_uint32), ("H", C.c_uint32), ("FramesRendered", C.c_uint32), ("ExposureMultiplier", C.c_float),
+                ("TonemapType", C.c_uint32), ("UseGammaCorrection", C.c_uint32), ("UseAutoExposure", C.c_uint32), ("OutputType", C.c_uint32),
+                ("VarianceMultiplier", C.c_float)]
+
+
 class tb_readback_stats(C.Structure):
     _fields_ = [("ActiveWaves", C.c_uint32), ("ActivePixels", C.c_uint32), ("SelectedPixelDistance", C.c_float), ("SelectedMaterialID", C.c_int32),
                 ("rays", TbRayStats)]
@@ -124,6 +135,7 @@ class tb_scene_info(C.Structure):
                 ("sceneMin", C.c_float * 3), ("sceneMax", C.c_float * 3)]
 
 
+assert C.sizeof(TbPostConstants) == 36
 assert C.sizeof(TbPerFrameConstants) == 148
 assert C.sizeof(TbConfigConstants) == 76
 assert C.sizeof(TbLight) == 104

@@ -58,6 +58,11 @@ def lib():
         "tb_render_async": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_uint32, P(abi.tb_output_settings), C.c_float]),
         "tb_sync": (C.c_int, [vp]),
         "tb_read_accum": (C.c_int, [vp, vp, vp]),
+        "tb_default_post_settings": (None, [P(abi.tb_post_settings)]),
+        "tb_post_process": (C.c_int, [vp, P(abi.tb_post_settings), C.c_uint32, vp, vp]),
+        "tb_read_averaged_luminance": (C.c_int, [vp, P(C.c_float)]),
+        "tb_write_image_rgba8": (C.c_int, [C.c_char_p, C.c_uint32, C.c_uint32, vp]),
+        "tb_write_image_f32": (C.c_int, [C.c_char_p, C.c_uint32, C.c_uint32, vp]),
         "tb_read_aov": (C.c_int, [vp, C.c_int, vp]),
         "tb_accum_device_ptr": (C.c_int, [vp, P(vp), P(vp)]),
         "tb_read_stats": (C.c_int, [vp, P(abi.tb_readback_stats)]),
@@ -101,6 +106,26 @@ def GetDefaultOutputSettings():
     s = abi.tb_output_settings()
     lib().tb_default_output_settings(C.byref(s))
     return s
+
+
+def GetDefaultPostProcessSettings():
+    """GetDefaultOutputSettings().m_postProcessSettings (TracerBoy.h:309-313): exposure 1, AGX punchy, gamma and auto exposure on."""
+    s = abi.tb_post_settings()
+    lib().tb_default_post_settings(C.byref(s))
+    return s
+
+
+def WriteImage(path, image):
+    """uint8 HxWx4 -> .png, float32 HxWx4 -> .pfm (tb_write_image_*)."""
+    a = np.ascontiguousarray(image)
+    h, w = a.shape[:2]
+    if a.dtype == np.uint8:
+        rc = lib().tb_write_image_rgba8(os.fsencode(path), w, h, _np_ptr(a))
+    else:
+        a = np.ascontiguousarray(a, np.float32)
+        rc = lib().tb_write_image_f32(os.fsencode(path), w, h, _np_ptr(a))
+    if rc != 0:
+        raise TracerBoyError(rc, "could not write %s" % path)
 
 
 def _np_ptr(a):
@@ -270,6 +295,20 @@ class TracerBoy:
         jit = np.empty_like(out) if jittered else None
         self._check(self._L.tb_read_accum(self._ctx, _np_ptr(out), _np_ptr(jit) if jittered else None))
         return (out, jit) if jittered else out
+
+    def PostProcess(self, postSettings=None, outputType=0, rgba8=True):
+        """The tail of TracerBoy::Render (TracerBoy.cpp:2948-3200): auto exposure + PostProcessCS on the surface the output
+        type selects.  Returns (float32 HxWx4 image, uint8 HxWx4 back-buffer image or None)."""
+        ps = postSettings if postSettings is not None else GetDefaultPostProcessSettings()
+        f = np.empty((self.height, self.width, 4), np.float32)
+        b = np.empty((self.height, self.width, 4), np.uint8) if rgba8 else None
+        self._check(self._L.tb_post_process(self._ctx, C.byref(ps), outputType, _np_ptr(f), _np_ptr(b) if rgba8 else None))
+        return f, b
+
+    def AveragedLuminance(self):
+        v = C.c_float()
+        self._check(self._L.tb_read_averaged_luminance(self._ctx, C.byref(v)))
+        return v.value
 
     def ReadAOV(self, which):
         shape = (self.height, self.width) if which == 6 else (self.height, self.width, 4)

@@ -1,9 +1,10 @@
 /* cli.cpp -- headless replacement of the reference's Win32 shell (WinMain/WinMain.cpp, D3D12App.cpp):
  *   tracerboy-hip scene.pbrt [--width W] [--height H] [--spp N] [--depth D] [--seed-time T] [--device I]
- *                 [--builder lbvh|sah] [--blue-noise 0|1] [--out frame.pfm]
+ *                 [--builder lbvh|sah] [--blue-noise 0|1] [--tonemap 0..7] [--exposure E|auto] [--out frame.png|frame.pfm]
  * Uses only the C ABI (include/tracerboy_hip.h), the way an embedding application would.
- * Output: PFM (RGB float32, bottom row first) of sum(rgb*w)/sum(w), i.e. the value PostProcessCS divides
- * out before tonemapping (PostProcessCS.hlsl:23-47). */
+ * Output by extension: .png = what the reference presents (auto exposure + PostProcessCS tonemap, 8-bit back buffer,
+ * tb_post_process); .pfm = linear radiance sum(rgb*w)/sum(w), the value PostProcessCS divides out before tonemapping
+ * (PostProcessCS.hlsl:23-47), RGB float32, bottom row first. */
 #include "../../../include/tracerboy_hip.h"
 
 #include <chrono>
@@ -23,13 +24,16 @@ static int fail(tb_context* c, const char* what, int rc)
 int main(int argc, char** argv)
 {
     if (argc < 2) { fprintf(stderr, "usage: tracerboy-hip scene.pbrt [--width W --height H --spp N --depth D --seed-time T --device I --builder lbvh|sah --blue-noise 0|1 --out f.pfm]\n"); return 2; }
-    std::string scene = argv[1], out = "frame.pfm";
+    std::string scene = argv[1], out = "frame.png";
+    tb_post_settings post; tb_default_post_settings(&post);
     uint32_t W = 0, H = 0, spp = 64; int depth = -1, device = 0, builder = 0, blue = -1; float t = 0.0f;
     for (int i = 2; i + 1 < argc; i += 2) {
         std::string k = argv[i]; const char* v = argv[i + 1];
         if (k == "--width") W = (uint32_t)atoi(v); else if (k == "--height") H = (uint32_t)atoi(v); else if (k == "--spp") spp = (uint32_t)atoi(v);
         else if (k == "--depth") depth = atoi(v); else if (k == "--seed-time") t = (float)atof(v); else if (k == "--device") device = atoi(v);
         else if (k == "--builder") builder = !strcmp(v, "sah") ? 1 : 0; else if (k == "--blue-noise") blue = atoi(v); else if (k == "--out") out = v;
+        else if (k == "--tonemap") post.TonemapType = (uint32_t)atoi(v);
+        else if (k == "--exposure") { if (!strcmp(v, "auto")) post.EnableAutoExposure = 1; else { post.EnableAutoExposure = 0; post.ExposureMultiplier = (float)atof(v); } }
         else { fprintf(stderr, "unknown option %s\n", k.c_str()); return 2; }
     }
     tb_context* ctx = nullptr;
@@ -47,18 +51,17 @@ int main(int argc, char** argv)
     if (blue >= 0) s.EnableBlueNoise = (uint32_t)blue;
     if ((rc = tb_render(ctx, W, H, spp, &s, t))) return fail(ctx, "tb_render", rc);
     float ms = tb_last_render_ms(ctx);
-    std::vector<float> acc((size_t)W * H * 4);
-    if ((rc = tb_read_accum(ctx, acc.data(), nullptr))) return fail(ctx, "tb_read_accum", rc);
-    FILE* f = fopen(out.c_str(), "wb");
-    if (!f) { fprintf(stderr, "cannot write %s\n", out.c_str()); tb_destroy(ctx); return 1; }
-    fprintf(f, "PF\n%u %u\n-1.0\n", W, H);
-    std::vector<float> row((size_t)W * 3);
-    for (uint32_t y = 0; y < H; y++) {
-        const float* src = &acc[(size_t)(H - 1 - y) * W * 4];
-        for (uint32_t x = 0; x < W; x++) { float w = src[4 * x + 3]; float inv = w > 0 ? 1.0f / w : 0.0f; row[3 * x] = src[4 * x] * inv; row[3 * x + 1] = src[4 * x + 1] * inv; row[3 * x + 2] = src[4 * x + 2] * inv; }
-        fwrite(row.data(), 4, row.size(), f);
+    const bool png = out.size() >= 4 && out.compare(out.size() - 4, 4, ".png") == 0;
+    if (png) {
+        std::vector<uint8_t> img((size_t)W * H * 4);
+        if ((rc = tb_post_process(ctx, &post, TB_OUTPUT_TYPE_LIT, nullptr, img.data()))) return fail(ctx, "tb_post_process", rc);
+        if ((rc = tb_write_image_rgba8(out.c_str(), W, H, img.data()))) return fail(ctx, "tb_write_image_rgba8", rc);
+    } else {
+        std::vector<float> acc((size_t)W * H * 4);
+        if ((rc = tb_read_accum(ctx, acc.data(), nullptr))) return fail(ctx, "tb_read_accum", rc);
+        for (size_t i = 0; i < (size_t)W * H; i++) { float w = acc[4 * i + 3], inv = w > 0 ? 1.0f / w : 0.0f; acc[4 * i] *= inv; acc[4 * i + 1] *= inv; acc[4 * i + 2] *= inv; }
+        if ((rc = tb_write_image_f32(out.c_str(), W, H, acc.data()))) return fail(ctx, "tb_write_image_f32 (use .png or .pfm)", rc);
     }
-    fclose(f);
     printf("%s: %u triangles, %ux%u x %u spp, depth %d: %.2f ms on the GPU (%.1f Msamples/s), scene load + BVH %.2f s -> %s\n",
            scene.c_str(), info.numTriangles, W, H, spp, s.MaxBounces, ms, (double)W * H * spp / (ms * 1e3), loadS, out.c_str());
     tb_destroy(ctx);

@@ -73,6 +73,7 @@ struct tb_context {
     /* surfaces */
     uint32_t width = 0, height = 0;
     DevBuf output, jittered, aov[8], stats, rayStats, packed;
+    DevBuf postOut, postRgba8, postHistogram, postAverage; /* output stage (post_kernels.hip) */
     /* wavefront pipeline: two ping-pong extend queues (4 columns), one shadow queue (11 columns), hits, samples, counters */
     DevBuf wfCols[2][4], wfShadowCols[11], wfHitA, wfHitG, wfSamples, wfCounts;
     uint64_t wfCapacity = 0, wfSampleCapacity = 0;
@@ -440,6 +441,7 @@ void tb_destroy(tb_context* c)
     for (int q = 0; q < 2; q++) for (DevBuf& b : c->wfCols[q]) b.release();
     for (DevBuf& b : c->wfShadowCols) b.release();
     c->wfHitA.release(); c->wfHitG.release(); c->wfSamples.release(); c->wfCounts.release();
+    c->postOut.release(); c->postRgba8.release(); c->postHistogram.release(); c->postAverage.release();
     for (DevBuf& b : c->aov) b.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -546,6 +548,66 @@ int tb_read_aov(tb_context* c, int which, void* dst)
 }
 
 int tb_accum_device_ptr(tb_context* c, void** o, void** j) { if (!c) return TB_E_INVALID; if (o) *o = c->output.p; if (j) *j = c->jittered.p; return c->output.p ? TB_OK : TB_E_INVALID; }
+
+void tb_default_post_settings(tb_post_settings* o) /* TracerBoy.h:298,309-313 */
+{
+    if (!o) return;
+    o->ExposureMultiplier = 1.0f; o->EnableGammaCorrection = 1; o->EnableAutoExposure = 1; o->TonemapType = TB_TONEMAP_AGX_PUNCHY; o->VarianceMultiplier = 1.0f;
+}
+
+int tb_post_process(tb_context* c, const tb_post_settings* post, uint32_t outputType, float* rgbaF32, uint8_t* rgba8)
+{
+    return guarded(c, [&]() {
+        if (!c->output.p || c->width == 0) return fail(c, TB_E_INVALID, "tb_post_process: nothing rendered yet");
+        tb_post_settings ps; if (post) ps = *post; else tb_default_post_settings(&ps);
+        const TbFloat4* in = nullptr; const float* inR32 = nullptr;
+        switch (outputType) { /* GetOutputSRV, TracerBoy.cpp:2354-2383 */
+        case TB_OUTPUT_TYPE_LIT: case TB_OUTPUT_TYPE_LUMINANCE: in = (const TbFloat4*)c->output.p; break;
+        case TB_OUTPUT_TYPE_ALBEDO: case TB_OUTPUT_TYPE_LIVE_PIXELS: case TB_OUTPUT_TYPE_HEATMAP: in = (const TbFloat4*)c->aov[TB_AOV_CUSTOM].p; break;
+        case TB_OUTPUT_TYPE_NORMAL: in = (const TbFloat4*)c->aov[TB_AOV_NORMALS].p; break;
+        case TB_OUTPUT_TYPE_DEPTH: inR32 = (const float*)c->aov[TB_AOV_DEPTH].p; break;
+        default: return fail(c, TB_E_UNSUPPORTED, "tb_post_process: this output type needs surfaces of the real-time chain (not built)");
+        }
+        if (!in && !inR32) return fail(c, TB_E_INVALID, "tb_post_process: the AOV for this output type was not rendered (set option \"aov\" before tb_render)");
+        const size_t px = (size_t)c->width * c->height;
+        ensure(c->postOut, px * 16); ensure(c->postRgba8, px * 4); ensure(c->postHistogram, 256 * 4); ensure(c->postAverage, 4);
+        TbPostConstants pc; memset(&pc, 0, sizeof pc);
+        pc.W = c->width; pc.H = c->height; pc.FramesRendered = c->samplesRendered; pc.ExposureMultiplier = ps.ExposureMultiplier;
+        pc.TonemapType = ps.TonemapType; pc.UseGammaCorrection = ps.EnableGammaCorrection; pc.UseAutoExposure = ps.EnableAutoExposure;
+        pc.OutputType = outputType; pc.VarianceMultiplier = ps.VarianceMultiplier;
+        HIP_TRY(post_launch(c->stream, &pc, in, inR32, (const TbFloat4*)c->aov[TB_AOV_CUSTOM].p, (uint32_t*)c->postHistogram.p, (float*)c->postAverage.p,
+                            (TbFloat4*)c->postOut.p, (uint32_t*)c->postRgba8.p));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (rgbaF32) HIP_TRY(hipMemcpy(rgbaF32, c->postOut.p, px * 16, hipMemcpyDeviceToHost));
+        if (rgba8) HIP_TRY(hipMemcpy(rgba8, c->postRgba8.p, px * 4, hipMemcpyDeviceToHost));
+        return TB_OK;
+    });
+}
+
+int tb_read_averaged_luminance(tb_context* c, float* out)
+{
+    return guarded(c, [&]() {
+        if (!out || !c->postAverage.p) return fail(c, TB_E_INVALID, "tb_read_averaged_luminance: run tb_post_process with auto exposure first");
+        HIP_TRY(hipMemcpy(out, c->postAverage.p, 4, hipMemcpyDeviceToHost));
+        return TB_OK;
+    });
+}
+
+static bool hasSuffix(const char* path, const char* suf) { size_t n = strlen(path), m = strlen(suf); return n >= m && strcmp(path + n - m, suf) == 0; }
+int tb_write_image_rgba8(const char* path, uint32_t W, uint32_t H, const uint8_t* rgba8)
+{
+    if (!path || !rgba8 || !W || !H) return TB_E_INVALID;
+    if (!hasSuffix(path, ".png")) return TB_E_UNSUPPORTED;
+    std::string err;
+    return tbhost::WritePngRGBA8(path, W, H, rgba8, err) ? TB_OK : TB_E_IO;
+}
+int tb_write_image_f32(const char* path, uint32_t W, uint32_t H, const float* rgba)
+{
+    if (!path || !rgba || !W || !H) return TB_E_INVALID;
+    if (!hasSuffix(path, ".pfm")) return TB_E_UNSUPPORTED;
+    std::string err;
+    return tbhost::WritePfmRGB(path, W, H, rgba, err) ? TB_OK : TB_E_IO;
+}
 
 int tb_read_stats(tb_context* c, tb_readback_stats* o)
 {

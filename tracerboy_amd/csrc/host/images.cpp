@@ -6,6 +6,7 @@
  */
 #include "host_scene.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -142,6 +143,71 @@ bool LoadBlueNoiseTiles(HostScene& scene)
         for (size_t p = 0; p < 256 * 256; p++) (*dst[i])[p] = TbFloat4{raw[4 * p] / 255.0f, raw[4 * p + 1] / 255.0f, raw[4 * p + 2] / 255.0f, raw[4 * p + 3] / 255.0f};
     }
     return true;
+}
+
+
+/* ---- image writers for the headless output stage (tb_write_image_*) ------------------------------------------------ */
+namespace {
+uint32_t crc32_update(uint32_t crc, const uint8_t* p, size_t n)
+{
+    static uint32_t table[256]; static bool init = false;
+    if (!init) { for (uint32_t i = 0; i < 256; i++) { uint32_t c = i; for (int k = 0; k < 8; k++) c = (c & 1) ? 0xedb88320u ^ (c >> 1) : c >> 1; table[i] = c; } init = true; }
+    for (size_t i = 0; i < n; i++) crc = table[(crc ^ p[i]) & 0xff] ^ (crc >> 8);
+    return crc;
+}
+void put32be(std::vector<uint8_t>& v, uint32_t x) { v.push_back((uint8_t)(x >> 24)); v.push_back((uint8_t)(x >> 16)); v.push_back((uint8_t)(x >> 8)); v.push_back((uint8_t)x); }
+void pngChunk(std::vector<uint8_t>& out, const char type[4], const std::vector<uint8_t>& data)
+{
+    put32be(out, (uint32_t)data.size());
+    size_t at = out.size();
+    out.insert(out.end(), type, type + 4); out.insert(out.end(), data.begin(), data.end());
+    put32be(out, crc32_update(0xffffffffu, out.data() + at, out.size() - at) ^ 0xffffffffu);
+}
+} // namespace
+
+/* 8-bit RGBA PNG; the zlib stream uses stored (uncompressed) deflate blocks -- a valid PNG every decoder reads */
+bool WritePngRGBA8(const std::string& file, uint32_t W, uint32_t H, const uint8_t* rgba, std::string& err)
+{
+    std::vector<uint8_t> raw; raw.reserve((size_t)H * (W * 4 + 1));
+    for (uint32_t y = 0; y < H; y++) { raw.push_back(0); raw.insert(raw.end(), rgba + (size_t)y * W * 4, rgba + (size_t)(y + 1) * W * 4); } /* filter 0 */
+    std::vector<uint8_t> z; z.push_back(0x78); z.push_back(0x01);
+    uint32_t a = 1, b = 0;
+    for (size_t i = 0; i < raw.size(); i++) { a = (a + raw[i]) % 65521u; b = (b + a) % 65521u; }
+    for (size_t at = 0; at < raw.size() || at == 0; at += 65535) {
+        size_t n = std::min<size_t>(65535, raw.size() - at);
+        z.push_back(at + n >= raw.size() ? 1 : 0);
+        z.push_back((uint8_t)n); z.push_back((uint8_t)(n >> 8)); z.push_back((uint8_t)~n); z.push_back((uint8_t)(~n >> 8));
+        z.insert(z.end(), raw.begin() + (long)at, raw.begin() + (long)(at + n));
+        if (raw.empty()) break;
+    }
+    put32be(z, (b << 16) | a);
+    std::vector<uint8_t> out = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    std::vector<uint8_t> ihdr; put32be(ihdr, W); put32be(ihdr, H); ihdr.push_back(8); ihdr.push_back(6); ihdr.push_back(0); ihdr.push_back(0); ihdr.push_back(0);
+    pngChunk(out, "IHDR", ihdr); pngChunk(out, "IDAT", z); pngChunk(out, "IEND", {});
+    FILE* f = fopen(file.c_str(), "wb");
+    if (!f) { err = "cannot open " + file + " for writing"; return false; }
+    bool ok = fwrite(out.data(), 1, out.size(), f) == out.size();
+    fclose(f);
+    if (!ok) err = "short write to " + file;
+    return ok;
+}
+
+/* PFM: "PF", little-endian RGB floats, rows bottom-up */
+bool WritePfmRGB(const std::string& file, uint32_t W, uint32_t H, const float* rgba, std::string& err)
+{
+    FILE* f = fopen(file.c_str(), "wb");
+    if (!f) { err = "cannot open " + file + " for writing"; return false; }
+    fprintf(f, "PF\n%u %u\n-1.0\n", W, H);
+    std::vector<float> row((size_t)W * 3);
+    bool ok = true;
+    for (uint32_t y = 0; y < H && ok; y++) {
+        const float* src = rgba + (size_t)(H - 1 - y) * W * 4;
+        for (uint32_t x = 0; x < W; x++) { row[x * 3] = src[x * 4]; row[x * 3 + 1] = src[x * 4 + 1]; row[x * 3 + 2] = src[x * 4 + 2]; }
+        ok = fwrite(row.data(), 4, row.size(), f) == row.size();
+    }
+    fclose(f);
+    if (!ok) err = "short write to " + file;
+    return ok;
 }
 
 } // namespace tbhost
