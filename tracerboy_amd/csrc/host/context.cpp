@@ -182,11 +182,45 @@ void reorderNodesBfs(HostScene& s)
     s.rootRefB = 0;
 }
 
+/* option "bvh_builder" = 2: the LBVH of builder 0 constructed on the GPU (bvh_kernels.hip); the host copies are filled
+ * from the device result so that every host-side consumer (oracle view, layout queries) sees the same tree */
+void BuildBvhGpu(tb_context* c, HostScene& s)
+{
+    const uint64_t N64 = s.triGeometry.size();
+    if (N64 == 0) throw std::runtime_error("BuildBvh: no triangles");
+    if (N64 > 0x00ffffffull) throw std::runtime_error("BuildBvh: more than 2^24-1 triangles does not fit the 24-bit node indices of the reference layout");
+    if (s.blueNoise0.empty()) LoadBlueNoiseTiles(s);
+    const uint32_t N = (uint32_t)N64;
+    const uint64_t nodes = 2ull * N - 1, total = 16 + 32 * nodes + 52ull * N;
+    if (total > 0xffffffffull) throw std::runtime_error("BuildBvh: BVH image exceeds 4 GiB");
+    DevBuf dPos, dIdx, dGeo, dPrim, dFlag, dA, dNodes, dTris, dScratch, dHeight;
+    auto up = [&](DevBuf& b, const void* p, size_t bytes) { ensure(b, bytes); HIP_TRY(hipMemcpyAsync(b.p, p, bytes, hipMemcpyHostToDevice, c->stream)); };
+    try {
+        up(dPos, s.positions.data(), s.positions.size() * 4); up(dIdx, s.triVertexIndex.data(), s.triVertexIndex.size() * 4);
+        up(dGeo, s.triGeometry.data(), 4ull * N); up(dPrim, s.triPrimitive.data(), 4ull * N); up(dFlag, s.triFlags.data(), 4ull * N);
+        const size_t nB = N > 1 ? N - 1 : 1, scratchBytes = bvh_gpu_scratch_bytes(N);
+        ensure(dA, total); ensure(dNodes, nB * sizeof(TbNodeB)); ensure(dTris, (size_t)N * sizeof(TbTriB)); ensure(dScratch, scratchBytes); ensure(dHeight, 4);
+        HIP_TRY(hipMemsetAsync(dNodes.p, 0, nB * sizeof(TbNodeB), c->stream));
+        HIP_TRY(bvh_gpu_build(c->stream, (const float*)dPos.p, (const uint32_t*)dIdx.p, (const uint32_t*)dGeo.p, (const uint32_t*)dPrim.p, (const uint32_t*)dFlag.p, N,
+                              (uint8_t*)dScratch.p, scratchBytes, (uint8_t*)dA.p, (TbNodeB*)dNodes.p, (TbTriB*)dTris.p, (uint32_t*)dHeight.p));
+        s.bvhA.resize((size_t)total); s.nodesB.resize(nB); s.trisB.resize(N);
+        HIP_TRY(hipMemcpy(s.bvhA.data(), dA.p, total, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(s.nodesB.data(), dNodes.p, nB * sizeof(TbNodeB), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(s.trisB.data(), dTris.p, (size_t)N * sizeof(TbTriB), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(&s.bvhMaxDepth, dHeight.p, 4, hipMemcpyDeviceToHost));
+        s.rootRefB = N == 1 ? TB_BVH_LEAF_FLAG : 0u;
+    } catch (...) {
+        for (DevBuf* b : {&dPos, &dIdx, &dGeo, &dPrim, &dFlag, &dA, &dNodes, &dTris, &dScratch, &dHeight}) b->release();
+        throw;
+    }
+    for (DevBuf* b : {&dPos, &dIdx, &dGeo, &dPrim, &dFlag, &dA, &dNodes, &dTris, &dScratch, &dHeight}) b->release();
+}
+
 void finalizeScene(tb_context* c)
 {
     HostScene& s = c->scene;
     auto opt = [&](const char* k, int64_t d) { auto it = c->options.find(k); return it == c->options.end() ? d : it->second; };
-    BuildBvh(s, (int)opt("bvh_builder", 0));
+    if (opt("bvh_builder", 0) == 2) BuildBvhGpu(c, s); else BuildBvh(s, (int)opt("bvh_builder", 0));
     reorderNodesBfs(s);
     c->camera = s.camera;
     releaseScene(c);

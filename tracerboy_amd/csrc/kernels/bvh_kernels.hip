@@ -1,0 +1,224 @@
+/* bvh_kernels.hip -- LBVH construction on the GPU (option "bvh_builder" = 2).
+ *
+ * The same tree, bit for bit, as the host builder 0 (bvh_build.cpp) and the oracle's restatement (oracle/bvh_ref.cpp):
+ *   bvh_bounds      scene box over all triangle vertices                          SceneAABBCalculator / CalculateSceneAABB
+ *   bvh_morton      30-bit Morton code of the centroid (y,x,z interleave)         CalculateMortonCodesBindings.h:116-149
+ *   rocprim sort    64-bit key = code << 32 | triangle index (ties by index)      BitonicSort in the reference
+ *   bvh_hierarchy   Karras-2012 split search, one lane per inner node             BuildBVHSplits.hlsli:33-131
+ *   bvh_fit         leaves (1 triangle, 0.001 thin-box padding), then bottom-up:  RayTracingHelper.hlsli:251-263,
+ *                   the second lane to reach a node fits it, smaller subtree left ComputeAABBs.hlsli:152-156
+ * Output: the reference's bottom-level memory image (layout A: header, 32-B nodes, 40-B primitives, 12-B metadata) plus
+ * the layout-B arrays the kernels fetch.  Boxes are min/max of exact inputs, so the fit order cannot change a bit.
+ * Integer / bit work apart from the box arithmetic: one pass over the triangles per stage, HBM-bound; the sort is
+ * rocPRIM's radix sort (the library primitive for a plain key sort). */
+#include <hip/hip_runtime.h>
+#include <cstring>
+#include <rocprim/rocprim.hpp>
+#include "tb_math.h"
+#include "tb_vec.h"
+#include "tb_abi.h"
+#include "pt_launch.h"
+
+namespace {
+
+constexpr int BLOCK = 256;
+
+__device__ __forceinline__ tb3 vertex(const float* positions, const uint32_t* triVertexIndex, uint32_t tri, int k)
+{
+    const float* p = positions + 3ull * triVertexIndex[3ull * tri + k];
+    return tb3_make(p[0], p[1], p[2]);
+}
+
+/* float min/max through order-preserving integer keys (no NaNs in vertex data) */
+__device__ __forceinline__ uint32_t f2ord(float f) { uint32_t u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__device__ __forceinline__ float ord2f(uint32_t o) { return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o); }
+
+__global__ __launch_bounds__(BLOCK) void bvh_bounds(const float* positions, const uint32_t* triVertexIndex, uint32_t N, uint32_t* ordMin, uint32_t* ordMax)
+{
+    tb3 mn = tb3_splat(3.402823466e+38f), mx = tb3_splat(-3.402823466e+38f);
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < N; i += gridDim.x * BLOCK)
+        for (int k = 0; k < 3; k++) { tb3 v = vertex(positions, triVertexIndex, i, k); mn = tb3_min(v, mn); mx = tb3_max(v, mx); }
+    float lo[3] = {mn.x, mn.y, mn.z}, hi[3] = {mx.x, mx.y, mx.z};
+    for (int a = 0; a < 3; a++) {
+        for (int o = 32; o > 0; o >>= 1) { lo[a] = tb_min(lo[a], __shfl_down(lo[a], o, 64)); hi[a] = tb_max(hi[a], __shfl_down(hi[a], o, 64)); }
+        if ((threadIdx.x & 63) == 0) { atomicMin(&ordMin[a], f2ord(lo[a])); atomicMax(&ordMax[a], f2ord(hi[a])); }
+    }
+}
+
+__device__ __forceinline__ uint32_t expand10(uint32_t v)
+{
+    v &= 0x3ff; v = (v | (v << 16)) & 0x030000FF; v = (v | (v << 8)) & 0x0300F00F; v = (v | (v << 4)) & 0x030C30C3; v = (v | (v << 2)) & 0x09249249;
+    return v;
+}
+
+__global__ __launch_bounds__(BLOCK) void bvh_morton(const float* positions, const uint32_t* triVertexIndex, uint32_t N, const uint32_t* ordMin, const uint32_t* ordMax,
+                                                    unsigned long long* keys)
+{
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= N) return;
+    const tb3 smin = tb3_make(ord2f(ordMin[0]), ord2f(ordMin[1]), ord2f(ordMin[2])), smax = tb3_make(ord2f(ordMax[0]), ord2f(ordMax[1]), ord2f(ordMax[2]));
+    const tb3 dim = tb3_max(smax - smin, tb3_splat(0.00001f));
+    const tb3 c = (vertex(positions, triVertexIndex, i, 0) + vertex(positions, triVertexIndex, i, 1) + vertex(positions, triVertexIndex, i, 2)) / 3.0f;
+    const tb3 u = (c - smin) / dim;
+    const float ax = tb_min(tb_max(u.x * 1024.0f, 0.0f), 1023.0f), ay = tb_min(tb_max(u.y * 1024.0f, 0.0f), 1023.0f), az = tb_min(tb_max(u.z * 1024.0f, 0.0f), 1023.0f);
+    const uint32_t code = expand10((uint32_t)ay) | (expand10((uint32_t)ax) << 1) | (expand10((uint32_t)az) << 2); /* axis 0 <- y, 1 <- x, 2 <- z */
+    keys[i] = ((unsigned long long)code << 32) | (unsigned long long)i;
+}
+
+__device__ __forceinline__ int delta(const unsigned long long* keys, uint32_t N, long long a, long long b)
+{
+    if (b < 0 || b >= (long long)N) return -1;
+    const uint32_t x = (uint32_t)(keys[a] >> 32) ^ (uint32_t)(keys[b] >> 32);
+    if (x) return __clz((int)x);
+    const uint32_t y = (uint32_t)a ^ (uint32_t)b;
+    return (y ? __clz((int)y) : 32) + 31;
+}
+
+__global__ __launch_bounds__(BLOCK) void bvh_hierarchy(const unsigned long long* keys, uint32_t N, uint32_t* left, uint32_t* right, uint32_t* parent)
+{
+    const long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= (long long)N - 1) return;
+    int d = delta(keys, N, i, i + 1) - delta(keys, N, i, i - 1); d = (d > 0) - (d < 0);
+    const int dmin = delta(keys, N, i, i - d);
+    long long lmax = 2; while (delta(keys, N, i, i + lmax * d) > dmin) lmax *= 4;
+    long long l = 0; for (long long st = lmax / 2; st > 0; st /= 2) if (delta(keys, N, i, i + (l + st) * d) > dmin) l += st;
+    const long long j = i + l * d, first = i < j ? i : j, last = i < j ? j : i;
+    const int dn = delta(keys, N, first, last);
+    long long split = first, step = last - first;
+    do { step = (step + 1) >> 1; const long long ns = split + step; if (ns < last && delta(keys, N, first, ns) > dn) split = ns; } while (step > 1);
+    const uint32_t lc = (split == first) ? (N - 1) + (uint32_t)split : (uint32_t)split;
+    const uint32_t rc = (split + 1 == last) ? (N - 1) + (uint32_t)split + 1 : (uint32_t)split + 1;
+    left[i] = lc; right[i] = rc; parent[lc] = (uint32_t)i; parent[rc] = (uint32_t)i;
+}
+
+struct FitOut {
+    TbAabbNode* nodesA; uint8_t* primsA; TbPrimitiveMeta* metaA; /* layout A */
+    TbNodeB* nodesB; TbTriB* trisB;                               /* layout B */
+    uint32_t* count; uint32_t* height; uint32_t* arrived;         /* per node scratch */
+};
+
+__device__ __forceinline__ void put_node(TbAabbNode* nodes, uint32_t i, tb3 mn, tb3 mx, uint32_t fx, uint32_t fy)
+{
+    const tb3 c = (mn + mx) * 0.5f, h = mx - c;
+    TbAabbNode n;
+    n.center[0] = c.x; n.center[1] = c.y; n.center[2] = c.z; n.flags = fx;
+    n.halfDim[0] = h.x; n.halfDim[1] = h.y; n.halfDim[2] = h.z; n.rightNodeIndex = fy;
+    nodes[i] = n;
+}
+
+__global__ __launch_bounds__(BLOCK) void bvh_fit(const float* positions, const uint32_t* triVertexIndex, const uint32_t* triGeometry, const uint32_t* triPrimitive,
+                                                 const uint32_t* triFlags, const unsigned long long* keys, uint32_t N, const uint32_t* left, const uint32_t* right,
+                                                 const uint32_t* parent, FitOut o)
+{
+    const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
+    if (k >= N) return;
+    const uint32_t tri = (uint32_t)keys[k]; /* sorted position k -> input triangle */
+    const tb3 v0 = vertex(positions, triVertexIndex, tri, 0), v1 = vertex(positions, triVertexIndex, tri, 1), v2 = vertex(positions, triVertexIndex, tri, 2);
+    {
+        float* p = (float*)(o.primsA + 40ull * k); /* 40-B packed primitive: type + 9 floats */
+        ((uint32_t*)p)[0] = 1u;
+        p[1] = v0.x; p[2] = v0.y; p[3] = v0.z; p[4] = v1.x; p[5] = v1.y; p[6] = v1.z; p[7] = v2.x; p[8] = v2.y; p[9] = v2.z;
+        TbPrimitiveMeta m; m.GeometryContributionToHitGroupIndex = triGeometry[tri]; m.PrimitiveIndex = triPrimitive[tri]; m.GeometryFlags = triFlags[tri];
+        o.metaA[k] = m;
+        TbTriB t;
+        t.v0[0] = v0.x; t.v0[1] = v0.y; t.v0[2] = v0.z; t.geometryIndex = m.GeometryContributionToHitGroupIndex;
+        t.v1[0] = v1.x; t.v1[1] = v1.y; t.v1[2] = v1.z; t.primitiveIndex = m.PrimitiveIndex;
+        t.v2[0] = v2.x; t.v2[1] = v2.y; t.v2[2] = v2.z; t.geometryFlags = m.GeometryFlags;
+        o.trisB[k] = t;
+    }
+    uint32_t x = (N - 1) + k;
+    {
+        tb3 mn = tb3_min(tb3_min(v0, v1), v2), mx = tb3_max(tb3_max(v0, v1), v2);
+        mn = tb3_min(mn, mx - tb3_splat(0.001f));
+        put_node(o.nodesA, x, mn, mx, k | TB_BVH_LEAF_FLAG, 1);
+        o.count[x] = 1; o.height[x] = 1;
+    }
+    /* climb: the first lane to reach an inner node stops, the second one (which sees both children) fits it */
+    if (N == 1) return;
+    while (x != 0) {
+        const uint32_t up = parent[x];
+        __threadfence();
+        if (atomicAdd(&o.arrived[up], 1u) == 0u) return;
+        __threadfence();
+        uint32_t l = left[up], r = right[up];
+        const uint32_t cl = ((volatile uint32_t*)o.count)[l], cr = ((volatile uint32_t*)o.count)[r];
+        if (cl > cr) { const uint32_t t = l; l = r; r = t; }
+        const volatile TbAabbNode* nl = o.nodesA + l; const volatile TbAabbNode* nr = o.nodesA + r;
+        const tb3 lcen = tb3_make(nl->center[0], nl->center[1], nl->center[2]), lhal = tb3_make(nl->halfDim[0], nl->halfDim[1], nl->halfDim[2]);
+        const tb3 rcen = tb3_make(nr->center[0], nr->center[1], nr->center[2]), rhal = tb3_make(nr->halfDim[0], nr->halfDim[1], nr->halfDim[2]);
+        const tb3 mn = tb3_min(lcen - lhal, rcen - rhal), mx = tb3_max(lcen + lhal, rcen + rhal);
+        put_node(o.nodesA, up, mn, mx, l & TB_BVH_INDEX_MASK, r);
+        o.count[up] = cl + cr;
+        const uint32_t hl = ((volatile uint32_t*)o.height)[l], hr = ((volatile uint32_t*)o.height)[r];
+        o.height[up] = 1u + (hl > hr ? hl : hr);
+        TbNodeB nb;
+        nb.cx[0] = lcen.x; nb.cy[0] = lcen.y; nb.cz[0] = lcen.z; nb.hx[0] = lhal.x; nb.hy[0] = lhal.y; nb.hz[0] = lhal.z;
+        nb.cx[1] = rcen.x; nb.cy[1] = rcen.y; nb.cz[1] = rcen.z; nb.hx[1] = rhal.x; nb.hy[1] = rhal.y; nb.hz[1] = rhal.z;
+        nb.left = l >= N - 1 ? (TB_BVH_LEAF_FLAG | (l - (N - 1))) : l;
+        nb.right = r >= N - 1 ? (TB_BVH_LEAF_FLAG | (r - (N - 1))) : r;
+        nb.pad[0] = nb.pad[1] = 0;
+        o.nodesB[up] = nb;
+        x = up;
+    }
+}
+
+} // namespace
+
+#define BVH_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return e_; } while (0)
+
+/* All pointers are device pointers.  bvhA receives the 16-B header + nodes + primitives + metadata (layout A image,
+ * 16 + 32(2N-1) + 52N bytes), nodesB N-1 (at least 1) layout-B nodes, trisB N records; rootHeight the tree depth in
+ * nodes (= HostScene::bvhMaxDepth).  scratch: bvh_gpu_scratch_bytes(N) bytes. */
+static size_t round256(size_t b) { return (b + 255) / 256 * 256; }
+extern "C" size_t bvh_gpu_scratch_bytes(uint32_t N)
+{
+    size_t sortTmp = 0;
+    unsigned long long* nullKeys = nullptr;
+    (void)rocprim::radix_sort_keys(nullptr, sortTmp, nullKeys, nullKeys, (size_t)N, 0, 62, (hipStream_t)0);
+    const size_t nodes = 2ull * N - 1;
+    return 2 * round256(8ull * N) /* keys in/out */ + 3 * round256(4 * nodes) /* parent, count, height */ + 3 * round256(4ull * N) /* left, right, arrived */
+           + round256(64) /* bounds */ + round256(sortTmp);
+}
+
+extern "C" hipError_t bvh_gpu_build(hipStream_t stream, const float* positions, const uint32_t* triVertexIndex, const uint32_t* triGeometry, const uint32_t* triPrimitive,
+                                    const uint32_t* triFlags, uint32_t N, uint8_t* scratch, size_t scratchBytes, uint8_t* bvhA, TbNodeB* nodesB, TbTriB* trisB,
+                                    uint32_t* rootHeight)
+{
+    if (N == 0) return hipErrorInvalidValue;
+    const size_t nodes = 2ull * N - 1;
+    uint8_t* at = scratch;
+    auto take = [&](size_t bytes) { uint8_t* p = at; at += (bytes + 255) / 256 * 256; return p; };
+    unsigned long long* keysIn = (unsigned long long*)take(8ull * N);
+    unsigned long long* keysOut = (unsigned long long*)take(8ull * N);
+    uint32_t* parent = (uint32_t*)take(4 * nodes);
+    uint32_t* count = (uint32_t*)take(4 * nodes);
+    uint32_t* height = (uint32_t*)take(4 * nodes);
+    uint32_t* left = (uint32_t*)take(4ull * N);
+    uint32_t* right = (uint32_t*)take(4ull * N);
+    uint32_t* arrived = (uint32_t*)take(4ull * N);
+    uint32_t* bounds = (uint32_t*)take(64);
+    size_t sortTmp = 0;
+    BVH_TRY(rocprim::radix_sort_keys(nullptr, sortTmp, keysIn, keysOut, (size_t)N, 0, 62, stream));
+    uint8_t* sortScratch = take(sortTmp);
+    if ((size_t)(at - scratch) > scratchBytes) return hipErrorInvalidValue;
+
+    BVH_TRY(hipMemsetAsync(bounds, 0xff, 12, stream));      /* ordMin = 0xffffffff */
+    BVH_TRY(hipMemsetAsync(bounds + 4, 0x00, 12, stream));  /* ordMax = 0 */
+    BVH_TRY(hipMemsetAsync(arrived, 0, 4ull * N, stream));
+    const uint32_t blocksN = (N + BLOCK - 1) / BLOCK;
+    hipLaunchKernelGGL(bvh_bounds, dim3(blocksN < 2048u ? blocksN : 2048u), dim3(BLOCK), 0, stream, positions, triVertexIndex, N, bounds, bounds + 4);
+    hipLaunchKernelGGL(bvh_morton, dim3(blocksN), dim3(BLOCK), 0, stream, positions, triVertexIndex, N, (const uint32_t*)bounds, (const uint32_t*)(bounds + 4), keysIn);
+    BVH_TRY(rocprim::radix_sort_keys(sortScratch, sortTmp, keysIn, keysOut, (size_t)N, 0, 62, stream));
+    if (N > 1) hipLaunchKernelGGL(bvh_hierarchy, dim3((N - 1 + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, stream, (const unsigned long long*)keysOut, N, left, right, parent);
+    const uint64_t offBoxes = 16, offPrims = offBoxes + 32 * nodes, offMeta = offPrims + 40ull * N, total = offMeta + 12ull * N;
+    const TbBvhHeader hdr = {(uint32_t)offBoxes, (uint32_t)offPrims, (uint32_t)offMeta, (uint32_t)total};
+    BVH_TRY(hipMemcpyAsync(bvhA, &hdr, 16, hipMemcpyHostToDevice, stream));
+    FitOut o;
+    o.nodesA = (TbAabbNode*)(bvhA + offBoxes); o.primsA = bvhA + offPrims; o.metaA = (TbPrimitiveMeta*)(bvhA + offMeta);
+    o.nodesB = nodesB; o.trisB = trisB; o.count = count; o.height = height; o.arrived = arrived;
+    hipLaunchKernelGGL(bvh_fit, dim3(blocksN), dim3(BLOCK), 0, stream, positions, triVertexIndex, triGeometry, triPrimitive, triFlags, (const unsigned long long*)keysOut, N,
+                       (const uint32_t*)left, (const uint32_t*)right, (const uint32_t*)parent, o);
+    BVH_TRY(hipMemcpyAsync(rootHeight, height, 4, hipMemcpyDeviceToDevice, stream)); /* node 0 is the root (the only leaf when N == 1) */
+    BVH_TRY(hipStreamSynchronize(stream)); /* hdr lives on this stack frame */
+    return hipGetLastError();
+}

@@ -12,6 +12,10 @@ hipError_t pt_launch_trace_closest(hipStream_t stream, const TbDeviceScene* ds, 
                                    float* outBary, uint32_t* outPrim, uint32_t* outGeom, float* outNormal, float* outUV, uint32_t* outBoxes, uint32_t* outTris);
 hipError_t pt_launch_device_math(hipStream_t stream, int fn, uint32_t n, const float* a, const float* b, float* out);
 hipError_t pt_launch_pack_owned(hipStream_t stream, const TbFloat4* full, TbFloat4* packed, uint32_t W, uint32_t H, const TbTileMap* tiles, uint32_t numOwnedTiles);
+/* GPU LBVH build (bvh_kernels.hip); every pointer is a device pointer */
+size_t bvh_gpu_scratch_bytes(uint32_t N);
+hipError_t bvh_gpu_build(hipStream_t stream, const float* positions, const uint32_t* triVertexIndex, const uint32_t* triGeometry, const uint32_t* triPrimitive,
+                         const uint32_t* triFlags, uint32_t N, uint8_t* scratch, size_t scratchBytes, uint8_t* bvhA, TbNodeB* nodesB, TbTriB* trisB, uint32_t* rootHeight);
 /* output stage (post_kernels.hip): optional histogram + average (auto exposure), then PostProcessCS */
 hipError_t post_launch(hipStream_t stream, const TbPostConstants* pc, const TbFloat4* in, const float* inR32, const TbFloat4* aux,
                        uint32_t* histogram, float* averaged, TbFloat4* out, uint32_t* outRgba8);
