@@ -141,6 +141,10 @@ int tb_read_averaged_luminance(tb_context* ctx, float* out);
  * ".pfm" (RGB float, bottom-up per the format) chosen by extension; host-only, no context needed. */
 int tb_write_image_rgba8(const char* path, uint32_t width, uint32_t height, const uint8_t* rgba8);
 int tb_write_image_f32(const char* path, uint32_t width, uint32_t height, const float* rgba);
+/* The texture decoders of tb_load_scene on their own (<-> DirectX::LoadFromHDRFile / LoadFromTGAFile / LoadFromWICFile +
+ * the typed load of the resulting DXGI format, TracerBoy.cpp:2188-2232): .hdr .pfm .png .tga -> RGBA32F, row 0 = top.
+ * rgba may be NULL to query the size; normalized <-> IsNormalizedFormat, has_alpha <-> !IsAlphaAllOpaque. */
+int tb_decode_image(const char* path, uint32_t* width, uint32_t* height, int* normalized, int* has_alpha, float* rgba_or_null);
 
 /* <-> ReadbackStats copy (TracerBoy.cpp:2946, D3D12App.cpp:195-201) */
 int tb_read_stats(tb_context* ctx, tb_readback_stats* out);

@@ -63,6 +63,7 @@ def lib():
         "tb_read_averaged_luminance": (C.c_int, [vp, P(C.c_float)]),
         "tb_write_image_rgba8": (C.c_int, [C.c_char_p, C.c_uint32, C.c_uint32, vp]),
         "tb_write_image_f32": (C.c_int, [C.c_char_p, C.c_uint32, C.c_uint32, vp]),
+        "tb_decode_image": (C.c_int, [C.c_char_p, P(C.c_uint32), P(C.c_uint32), P(C.c_int), P(C.c_int), vp]),
         "tb_read_aov": (C.c_int, [vp, C.c_int, vp]),
         "tb_accum_device_ptr": (C.c_int, [vp, P(vp), P(vp)]),
         "tb_read_stats": (C.c_int, [vp, P(abi.tb_readback_stats)]),
@@ -126,6 +127,19 @@ def WriteImage(path, image):
         rc = lib().tb_write_image_f32(os.fsencode(path), w, h, _np_ptr(a))
     if rc != 0:
         raise TracerBoyError(rc, "could not write %s" % path)
+
+
+def DecodeImage(path):
+    """The scene loader's texture decoder on its own: (float32 HxWx4, normalized, has_alpha) for .hdr/.pfm/.png/.tga."""
+    w, h, n, a = C.c_uint32(), C.c_uint32(), C.c_int(), C.c_int()
+    rc = lib().tb_decode_image(os.fsencode(path), C.byref(w), C.byref(h), C.byref(n), C.byref(a), None)
+    if rc != 0:
+        raise TracerBoyError(rc, (lib().tb_last_error(None) or b"").decode())
+    img = np.empty((h.value, w.value, 4), np.float32)
+    rc = lib().tb_decode_image(os.fsencode(path), C.byref(w), C.byref(h), C.byref(n), C.byref(a), _np_ptr(img))
+    if rc != 0:
+        raise TracerBoyError(rc, (lib().tb_last_error(None) or b"").decode())
+    return img, bool(n.value), bool(a.value)
 
 
 def _np_ptr(a):

@@ -643,6 +643,18 @@ int tb_write_image_f32(const char* path, uint32_t W, uint32_t H, const float* rg
     return tbhost::WritePfmRGB(path, W, H, rgba, err) ? TB_OK : TB_E_IO;
 }
 
+int tb_decode_image(const char* path, uint32_t* W, uint32_t* H, int* normalized, int* hasAlpha, float* rgba)
+{
+    if (!path || !W || !H) return TB_E_INVALID;
+    try {
+        std::vector<TbFloat4> texels; bool norm = false, alpha = false; std::string err;
+        if (!tbhost::LoadImageRGBA32F(path, texels, *W, *H, norm, err, &alpha)) { g_createError = err; return TB_E_IO; }
+        if (normalized) *normalized = norm; if (hasAlpha) *hasAlpha = alpha;
+        if (rgba) memcpy(rgba, texels.data(), texels.size() * sizeof(TbFloat4));
+        return TB_OK;
+    } catch (const std::exception& e) { g_createError = e.what(); return TB_E_IO; }
+}
+
 int tb_read_stats(tb_context* c, tb_readback_stats* o)
 {
     return guarded(c, [&]() {

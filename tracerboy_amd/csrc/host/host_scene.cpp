@@ -22,7 +22,8 @@ inline float ConvertSpecularToIOR(float s) { return (float)((sqrt((double)s) + 1
 
 struct TextureAllocator { /* TracerBoy.cpp:177-251 */
     HostScene& scene;
-    std::unordered_map<std::string, uint32_t> imageCache;
+    struct CachedImage { uint32_t index; bool normalized, hasAlpha; };
+    std::unordered_map<std::string, CachedImage> imageCache;
     explicit TextureAllocator(HostScene& s) : scene(s) {}
 
     uint32_t CreateTexture(const PbrtTextureSP& tex, bool gammaCorrect, bool* hasAlpha)
@@ -31,21 +32,21 @@ struct TextureAllocator { /* TracerBoy.cpp:177-251 */
         TbTextureData td; memset(&td, 0, sizeof td);
         if (tex->kind == "imagemap") {
             td.TextureType = TB_TEXTURE_TYPE_IMAGE;
-            bool normalized = false;
+            bool normalized = false, alpha = false;
             auto it = imageCache.find(tex->fileName);
-            if (it != imageCache.end()) td.DescriptorHeapIndex = it->second;
+            if (it != imageCache.end()) { td.DescriptorHeapIndex = it->second.index; normalized = it->second.normalized; alpha = it->second.hasAlpha; }
             else {
                 std::vector<TbFloat4> texels; uint32_t w = 0, h = 0; std::string err;
-                if (!LoadImageRGBA32F(tex->fileName, texels, w, h, normalized, err)) throw std::runtime_error(err);
+                if (!LoadImageRGBA32F(tex->fileName, texels, w, h, normalized, err, &alpha)) throw std::runtime_error(err);
                 TbImageDesc d; d.width = w; d.height = h; d.texelOffset = scene.texelPool.size();
                 scene.texelPool.insert(scene.texelPool.end(), texels.begin(), texels.end());
                 td.DescriptorHeapIndex = (uint32_t)scene.images.size();
                 scene.images.push_back(d);
-                imageCache[tex->fileName] = td.DescriptorHeapIndex;
+                imageCache[tex->fileName] = CachedImage{td.DescriptorHeapIndex, normalized, alpha};
             }
             td.TextureFlags = 0;
             if (gammaCorrect && normalized) td.TextureFlags |= TB_TEXTURE_FLAG_NEEDS_GAMMA;
-            if (hasAlpha) *hasAlpha = false;
+            if (hasAlpha) *hasAlpha = alpha; /* !scratchImage.IsAlphaAllOpaque(), TracerBoy.cpp:2229-2232 */
         } else if (tex->kind == "checkerboard") {
             td.TextureType = TB_TEXTURE_TYPE_CHECKER;
             td.UScale = tex->uscale; td.VScale = tex->vscale;

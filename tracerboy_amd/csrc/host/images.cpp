@@ -101,13 +101,17 @@ bool loadPfm(const std::string& file, std::vector<TbFloat4>& texels, uint32_t& W
 
 } // namespace
 
-bool LoadImageRGBA32F(const std::string& file, std::vector<TbFloat4>& texels, uint32_t& w, uint32_t& h, bool& normalizedFormat, std::string& err)
+bool LoadImageRGBA32F(const std::string& file, std::vector<TbFloat4>& texels, uint32_t& w, uint32_t& h, bool& normalizedFormat, std::string& err, bool* hasAlpha)
 {
     normalizedFormat = false;
+    if (hasAlpha) *hasAlpha = false;
     if (endsWith(file, ".hdr")) return loadHdr(file, texels, w, h, err);
     if (endsWith(file, ".pfm")) return loadPfm(file, texels, w, h, err);
-    err = "unsupported image format for '" + file + "' (this build decodes .hdr and .pfm; see DESIGN.md row f1)";
-    return false;
+    DecodedImage img; /* .png / .tga (TracerBoy.cpp:2216-2227) */
+    if (!DecodeImageFile(file, img, err)) return false;
+    texels.swap(img.texels); w = img.width; h = img.height; normalizedFormat = img.normalized;
+    if (hasAlpha) *hasAlpha = img.hasAlpha;
+    return true;
 }
 
 } // namespace tbhost
