@@ -185,6 +185,12 @@ static FILE* g_rayLog = nullptr;
 static std::mutex g_rayLogMutex;
 static thread_local std::string* g_raySteps = nullptr;
 
+/* The any-hit alpha test of the reference's hardware path (IsValidHit, SharedHitGroup.h:157-179, applied to candidate
+ * hits of non-opaque geometry by the RayQuery loop RayGenCommon.h:423-434).  The software path this file restates compiles
+ * it out (DISABLE_ANYHIT, RayGenCommon.h:357); tbo_set_alpha_test(1) turns it on. */
+static int g_alphaTest = 0;
+bool IsValidHit(const TbSceneView* sc, uint32_t geometryIndex, uint32_t primitiveIndex, float b0, float b1);
+
 /* TraverseFunction.hlsli:537-779 */
 bool Traverse(const TbSceneView* sc, tb3 origin, tb3 direction, float TMin, float TMax, Committed& hit,
               uint32_t& trianglesTested, uint32_t& boxesTested)
@@ -221,7 +227,9 @@ bool Traverse(const TbSceneView* sc, tb3 origin, tb3 direction, float TMin, floa
             tb3 v2 = tb3_make(ldf(p + 24), ldf(p + 28), ldf(p + 32));
             float t0 = hit.t, b[2] = {0, 0};
             RayTriangleIntersect(t0, b, origin, rd, v0, v1, v2);
-            if (t0 < hit.t && t0 > TMin) { /* :420-426, commit :685-697 */
+            bool valid = true;
+            if (g_alphaTest && t0 < hit.t && t0 > TMin && !(ld32(m + 8) & 1u)) valid = IsValidHit(sc, geomContribution, primIdx, b[0], b[1]);
+            if (valid && t0 < hit.t && t0 > TMin) { /* :420-426, commit :685-697 */
                 hit.t = t0; hit.bary[0] = b[0]; hit.bary[1] = b[1];
                 hit.primitiveIndex = primIdx; hit.geometryIndex = geomContribution;
             }
@@ -456,6 +464,18 @@ inline tb3 GetDetailNormal(Ctx& c, const TbMaterial& mat, tb3 normal, tb3 tangen
         return tb3_normalize(tangent * tx + bitangent * ty + normal * tb_max(tz, normalYClamp));
     }
     return normal;
+}
+
+bool IsValidHit(const TbSceneView* sc, uint32_t geometryIndex, uint32_t primitiveIndex, float b0, float b1) /* SharedHitGroup.h:157-179 */
+{
+    TbHitGroupRecord rec;
+    if (geometryIndex < sc->numHitGroups) rec = sc->hitGroups[geometryIndex]; else memset(&rec, 0, sizeof rec);
+    HitInfo hit;
+    GetHitInfo(sc, rec, primitiveIndex, 1 - b0 - b1, b0, b1, hit);
+    TbMaterial mat = FetchMaterial(sc, rec.MaterialIndex); /* GetMaterial_NonRecursive */
+    if (IsValidTexture(mat.alphaIndex)) { float alpha = GetTextureData(sc, mat.alphaIndex, hit.uvx, hit.uvy).x; if (alpha < 0.9f) return false; }
+    else if (IsValidTexture(mat.albedoIndex)) { float alpha = GetTextureData(sc, mat.albedoIndex, hit.uvx, hit.uvy).w; if (alpha < 0.9f) return false; }
+    return true;
 }
 
 inline bool AllowsSpecular(const TbMaterial& m) { return (m.Flags & TB_MAT_NO_SPECULAR) == 0; }
@@ -1091,6 +1111,8 @@ void tbo_trace_closest(const TbSceneView* scene, uint32_t n, const float* origin
         if (uv) { uv[2 * i] = u; uv[2 * i + 1] = v; }
     }
 }
+
+void tbo_set_alpha_test(int enabled) { g_alphaTest = enabled ? 1 : 0; }
 
 float tbo_hash13(float x, float y, float z) { return hash13(tb3_make(x, y, z)); }
 

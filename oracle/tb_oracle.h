@@ -59,6 +59,9 @@ void tbo_rand_stream(float seed, float time, uint32_t n, float* out);
  * output type is LIT) then PostProcessCS on `in` (W*H float4, or W*H floats when inIsR32).  All outputs nullable. */
 void tbo_post_process(const TbPostConstants* pc, const float* in, int inIsR32, float* outRgba, uint8_t* outRgba8, float* averagedOut, uint32_t* histogramOut);
 
+/* IsValidHit alpha test on candidate hits of non-opaque geometry (off by default, like the reference's software path) */
+void tbo_set_alpha_test(int enabled);
+
 float tbo_math(int fn, float a, float b); /* 0 sin 1 cos 2 acos 3 atan2 4 exp 5 log 6 pow 7 sqrt 8 exp2 9 log2 10 asin */
 void tbo_camera_ray(const TbPerFrameConstants* constants, float lensHeight, uint32_t width, uint32_t height,
                     float pixelX, float pixelY, float jitterX, float jitterY, float origin[3], float dir[3]);

@@ -36,6 +36,8 @@ def lib():
         L.tbo_sample_pixel.restype = None
         L.tbo_sample_pixel.argtypes = [C.POINTER(abi.TbSceneView), C.POINTER(abi.TbPerFrameConstants), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                        C.POINTER(C.c_float * 4), C.POINTER(C.c_float), C.POINTER(abi.TbRayStats)]
+        L.tbo_set_alpha_test.restype = None
+        L.tbo_set_alpha_test.argtypes = [C.c_int]
         L.tbo_post_process.restype = None
         L.tbo_post_process.argtypes = [C.POINTER(abi.TbPostConstants), vp, C.c_int, vp, vp, C.POINTER(C.c_float), vp]
         L.tbo_trace_closest.restype = None
@@ -86,6 +88,10 @@ def render(view, pf, width, height, frames, first_frame=0, y0=0, y1=None, thread
     if stats:
         res["stats"] = st
     return res
+
+
+def set_alpha_test(enabled):
+    lib().tbo_set_alpha_test(1 if enabled else 0)
 
 
 def post_process(accum, post, output_type=0, frames_rendered=0, r32=False):

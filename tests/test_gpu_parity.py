@@ -344,6 +344,30 @@ def test_gpu_lbvh_build_equals_host_build(gpu_tb, settings, scene):
         gpu_tb.SetOption("bvh_builder", 0)
 
 
+def test_alpha_tested_geometry_bit_exact(gpu_tb, settings):
+    """Rows a12 / f1: the IsValidHit alpha test (SharedHitGroup.h:157-179) as a filter on candidate hits of non-opaque
+    geometry, on a card textured with a PNG that has transparent texels.  Off (the reference's software path compiles
+    it out) and on, both against the oracle; the two pictures differ."""
+    import oracle_lib as ol
+    scene = os.path.join(GOLDEN, "scenes", "alpha-card", "scene.pbrt")
+    gpu_tb.LoadScene(scene)
+    W, H, F = 96, 64, 3
+    s = copy.copy(settings); s.MaxBounces = 3
+    pictures = []
+    try:
+        for on in (0, 1):
+            gpu_tb.SetOption("alpha_test", on); ol.set_alpha_test(on)
+            gpu_tb.InvalidateHistory()
+            gpu_tb.Render(W, H, F, s, 0.0)
+            out = gpu_tb.ReadAccumulation()
+            ref = _oracle(gpu_tb, W, H, F, s)
+            assert np.array_equal(bits(out), bits(ref["output"])), on
+            pictures.append(out)
+    finally:
+        gpu_tb.SetOption("alpha_test", 0); ol.set_alpha_test(0)
+    assert np.any(pictures[0] != pictures[1])
+
+
 def test_tile_split_reproduces_the_single_gpu_image(gpu_tb, settings):
     """Multi-GPU partition on one device: every rank's tiles, packed and un-permuted, give the same bits."""
     from tracerboy_amd import api

@@ -153,7 +153,7 @@ uint32_t settingsFeatureMask(const tb_context* c, const tb_output_settings& s, b
 {
     bool ext = s.EnableBlueNoise || s.EnableSamplingImportanceResampling || s.DOFFocalDistance > 0.0f || s.FilterType != TB_FILTER_TYPE_BOX ||
                s.FireflyClampValue != 0.0f || s.RenderModeRealTime || s.OutputType == TB_OUTPUT_TYPE_HEATMAP || aov ||
-               (c->selX != 0xffffffffu);
+               (c->selX != 0xffffffffu) || c->ds.alphaTest != 0;
     return ext ? PT_FEAT_EXT : 0u;
 }
 
@@ -258,6 +258,7 @@ void finalizeScene(tb_context* c)
     d.blueNoise0 = upload(c, s.blueNoise0); d.blueNoise1 = upload(c, s.blueNoise1);
     d.config = s.config;
     d.stackDepth = s.bvhMaxDepth + 2;
+    d.alphaTest = opt("alpha_test", 0) ? 1u : 0u;
     /* whole-scene LDS image */
     {
         std::vector<uint8_t> blob;
@@ -410,6 +411,7 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
     if (n == 0) return TB_OK;
     auto opt = [&](const char* k, int64_t d) { auto it = c->options.find(k); return it == c->options.end() ? d : it->second; };
     const bool aov = opt("aov", 0) != 0, count = opt("count_rays", 0) != 0;
+    c->ds.alphaTest = opt("alpha_test", 0) ? 1u : 0u;
     ensure(c->stats, 16);
     if (c->samplesRendered == 0) HIP_TRY(hipMemsetAsync(c->stats.p, 0, 16, c->stream));
     TbDeviceTargets tg; memset(&tg, 0, sizeof tg);
@@ -723,7 +725,7 @@ int tb_unpack_gathered_host(uint32_t W, uint32_t H, uint32_t world, uint32_t tw,
 int tb_set_option(tb_context* c, const char* name, int64_t v)
 {
     if (!c || !name) return TB_E_INVALID;
-    static const char* known[] = {"pipeline", "count_rays", "bvh_builder", "flatten_instances", "aov", "scene_in_lds", "lds_scene_budget", "force_full_variant", "wavefront_paths", "wavefront_grid", "wavefront_segment", "pooled_paths", "pooled_samples", "pooled_profile", "park_min"};
+    static const char* known[] = {"pipeline", "count_rays", "bvh_builder", "flatten_instances", "aov", "scene_in_lds", "lds_scene_budget", "force_full_variant", "wavefront_paths", "wavefront_grid", "wavefront_segment", "pooled_paths", "pooled_samples", "pooled_profile", "park_min", "alpha_test"};
     for (const char* k : known) if (!strcmp(k, name)) { c->options[name] = v; if (!strcmp(name, "count_rays") || !strcmp(name, "aov")) c->samplesRendered = 0; return TB_OK; }
     return fail(c, TB_E_INVALID, std::string("unknown option '") + name + "'");
 }

@@ -173,7 +173,13 @@ TBD void box_test2(bool& lh, bool& rh, float& lt, float& rt, float closest, cons
 struct Hit { float t, u, v; uint32_t prim, geom; };
 
 /* Woop/Benthin/Wald watertight test, two-sided branch: RayTriangleIntersect :232-313 + :420-426 */
-TBD void tri_test(Hit& best, float tMin, tb3 o, const RayPre& r, const TbTriB& tri, bool permuted = false)
+/* IsValidHit (SharedHitGroup.h:157-179), the any-hit alpha test of the reference's hardware path; defined after the
+ * texture functions.  The software path the build mirrors compiles it out (DISABLE_ANYHIT, RayGenCommon.h:357); option
+ * "alpha_test" turns it on as a filter on candidate hits of non-opaque geometry. */
+TBD bool is_valid_hit(const SceneRefs& sc, const TbDeviceScene& ds, uint32_t geom, uint32_t prim, float u, float v);
+
+template <bool ALPHA>
+TBD void tri_test(Hit& best, float tMin, tb3 o, const RayPre& r, const TbTriB& tri, bool permuted, const SceneRefs& sc, const TbDeviceScene& ds)
 {
     float Ax, Ay, Az, Bx, By, Bz, Cx, Cy, Cz;
     if (permuted) {
@@ -205,7 +211,10 @@ TBD void tri_test(Hit& best, float tMin, tb3 o, const RayPre& r, const TbTriB& t
     float rcpDet = 1.0f / det;
     float t0 = T * rcpDet;
     if (t0 < best.t && t0 > tMin) {
-        best.t = t0; best.u = V * rcpDet; best.v = W * rcpDet;
+        const float bu = V * rcpDet, bv = W * rcpDet;
+        /* non-opaque candidate (D3D12_RAYTRACING_GEOMETRY_FLAG_OPAQUE clear): RayGenCommon.h:423-434 */
+        if (ALPHA && ds.alphaTest && !(tri.geometryFlags & 1u) && !is_valid_hit(sc, ds, tri.geometryIndex, tri.primitiveIndex, bu, bv)) return;
+        best.t = t0; best.u = bu; best.v = bv;
         best.prim = tri.primitiveIndex; best.geom = tri.geometryIndex;
     }
 }
@@ -265,7 +274,7 @@ TBD bool traverse(const SceneRefs& sc, const TbDeviceScene& ds, tb3 o, tb3 d, Hi
             if (COUNT) prof_hit(prof, PROF_LEAF);
             const TbTriB tri = load_tri(sc, sc.trisPermuted ? ref + r.permUnits : ref);
             if (COUNT) tris++;
-            tri_test(best, MIN_T, o, r, tri, sc.trisPermuted != 0);
+            tri_test<COUNT>(best, MIN_T, o, r, tri, sc.trisPermuted != 0, sc, ds);
             ref = top ? stack[(--top) * stride] : DONE;
         }
     }
@@ -290,7 +299,7 @@ TBD bool trav_begin(Trav& t, const TbDeviceScene& ds, tb3 o, tb3 d) /* returns f
 
 /* One while-while round for the lanes with `busy` set; clears `busy` when a lane's walk is complete. */
 template <bool COUNT, int PARK_MIN>
-TBD void trav_round(Trav& t, bool& busy, const SceneRefs& sc, uint32_t* stack, uint32_t stride, WaveProf* prof)
+TBD void trav_round(Trav& t, bool& busy, const SceneRefs& sc, const TbDeviceScene& ds, uint32_t* stack, uint32_t stride, WaveProf* prof)
 {
     while (busy && !(t.ref & TB_BVH_LEAF_FLAG)) {
         if (COUNT) prof_hit(prof, PROF_INNER);
@@ -314,7 +323,7 @@ TBD void trav_round(Trav& t, bool& busy, const SceneRefs& sc, uint32_t* stack, u
             if (COUNT) prof_hit(prof, PROF_LEAF);
             const TbTriB tri = load_tri(sc, sc.trisPermuted ? t.ref + t.r.permUnits : t.ref);
             if (COUNT) t.tris++;
-            tri_test(t.best, MIN_T, t.r.o, t.r, tri, sc.trisPermuted != 0);
+            tri_test<COUNT>(t.best, MIN_T, t.r.o, t.r, tri, sc.trisPermuted != 0, sc, ds);
             t.ref = t.top ? stack[(--t.top) * stride] : TRAV_DONE;
         }
         if (t.ref == TRAV_DONE) busy = false;
@@ -470,6 +479,17 @@ TBD bool shadow_hit_is_light(const SceneRefs& sc, uint32_t geom)
     const uint32_t mi = geom < sc.numHitGroups ? sc.hitGroups[geom].MaterialIndex : 0u;
     const int flags = mi < sc.numMaterials ? sc.materials[mi].m.Flags : 0;
     return (flags & TB_MAT_LIGHT) != 0;
+}
+
+TBD bool is_valid_hit(const SceneRefs& sc, const TbDeviceScene& ds, uint32_t geom, uint32_t prim, float u, float v)
+{
+    Hit h; h.t = 0.0f; h.u = u; h.v = v; h.prim = prim; h.geom = geom;
+    Surface s;
+    fetch_surface(sc, h, s, false);                              /* GetHitInfo: the interpolated uv is what matters */
+    const TbMaterial m = fetch_material(sc, (uint32_t)s.material); /* GetMaterial_NonRecursive */
+    if (m.alphaIndex != TB_INVALID_TEXTURE) return !(texture_fetch(ds, m.alphaIndex, s.u, s.v).x < 0.9f);
+    if (m.albedoIndex != TB_INVALID_TEXTURE) return !(texture_fetch(ds, m.albedoIndex, s.u, s.v).w < 0.9f);
+    return true;
 }
 
 template <uint32_t F>

@@ -41,6 +41,7 @@ struct TbDeviceScene {
     const TbFloat4* blueNoise0;
     const TbFloat4* blueNoise1;
     TbConfigConstants config;
+    uint32_t alphaTest;          /* option "alpha_test": IsValidHit filter on candidate hits of non-opaque geometry (full variant only) */
     uint32_t parkMin;            /* while-while scheduling of traverse(): leave the inner-node loop when fewer lanes than this still descend */
     uint32_t stackDepth;         /* entries per lane of the traversal stack (bvh max depth + 2) */
     /* whole-scene-in-LDS image (small scenes): byte offsets inside one contiguous device blob */
