@@ -109,6 +109,28 @@ typedef struct TbPostConstants {
 } TbPostConstants;
 TB_STATIC_ASSERT(sizeof(TbPostConstants) == 36, "PostProcessConstants is 9 dwords");
 
+/* TemporalAccumulationConstants, TemporalAccumulationSharedShaderStructs.h:6-34 (36 dwords, float3 + scalar rows) */
+typedef struct TbTemporalConstants {
+    uint32_t ResolutionX, ResolutionY; float CameraFocalDistance; uint32_t IgnoreHistory;
+    float CameraPosition[3]; float CameraLensHeight;
+    float CameraLookAt[3]; float HistoryWeight;
+    float CameraUp[3]; uint32_t OutputMomentInformation;
+    float CameraRight[3]; uint32_t padding3;
+    float PrevFrameCameraPosition[3]; uint32_t padding4;
+    float PrevFrameCameraUp[3]; uint32_t padding5;
+    float PrevFrameCameraRight[3]; uint32_t padding6;
+    float PrevFrameCameraLookAt[3]; uint32_t padding7;
+} TbTemporalConstants;
+TB_STATIC_ASSERT(sizeof(TbTemporalConstants) == 144, "TemporalAccumulationConstants is 36 dwords");
+
+/* DenoiserConstants, DenoiserSharedShaderStructs.h:6-14 */
+typedef struct TbDenoiserConstants {
+    uint32_t ResolutionX, ResolutionY, OffsetMultiplier;
+    float NormalWeightingExponential, IntersectionPositionWeightingMultiplier, LumaWeightingMultiplier;
+    uint32_t GlobalFrameCount;
+} TbDenoiserConstants;
+TB_STATIC_ASSERT(sizeof(TbDenoiserConstants) == 28, "DenoiserConstants is 7 dwords");
+
 /* SharedShaderStructs.h:141-161 */
 typedef struct TbMaterial {
     TbFloat3 albedo;       uint32_t albedoIndex;

@@ -61,6 +61,15 @@ typedef struct tb_post_settings {
     float VarianceMultiplier;         /* m_debugSettings.m_VarianceMultiplier, default 1          */
 } tb_post_settings;
 
+/* TracerBoy::DenoiserSettings (TracerBoy.h:252-262), defaults TracerBoy.h:338-344 */
+typedef struct tb_denoiser_settings {
+    uint32_t Enabled;                               /* m_bEnabled, default on                         */
+    float IntersectPositionWeightingMultiplier;     /* m_intersectPositionWeightingMultiplier, 1     */
+    float NormalWeightingExponential;               /* m_normalWeightingExponential, 128             */
+    float LuminanceWeightingMultiplier;             /* m_luminanceWeightingMultiplier, 4             */
+    uint32_t WaveletIterations;                     /* m_waveletIterations, 5                        */
+} tb_denoiser_settings;
+
 /* TracerBoy::ReadbackStats (TracerBoy.h:362-368) + the heatmap counters summed over the render */
 typedef struct tb_readback_stats {
     uint32_t ActiveWaves, ActivePixels;
@@ -145,6 +154,16 @@ int tb_write_image_f32(const char* path, uint32_t width, uint32_t height, const 
  * the typed load of the resulting DXGI format, TracerBoy.cpp:2188-2232): .hdr .pfm .png .tga -> RGBA32F, row 0 = top.
  * rgba may be NULL to query the size; normalized <-> IsNormalizedFormat, has_alpha <-> !IsAlphaAllOpaque. */
 int tb_decode_image(const char* path, uint32_t* width, uint32_t* height, int* normalized, int* has_alpha, float* rgba_or_null);
+
+/* ---- real-time chain ------------------------------------------------------------
+ * <-> TracerBoy::Render with RenderMode::RealTime (TracerBoy.cpp:2677-3160), one displayed frame per call: one sample per
+ * pixel with IsRealTime (per-frame output, albedo demodulated into the custom AOV), TemporalAccumulationCS on the indirect
+ * lighting with luminance moments, DenoiserCS x WaveletIterations, CompositeAlbedoCS, TemporalAccumulationCS again.  History
+ * buffers and the previous camera live in the context.  tb_post_process(LIT) afterwards tonemaps the chain's output.
+ * tb_read_realtime stages: 0 first TAA output (rgb, variance), 1 moments, 2 denoised, 3 composited, 4 final TAA output. */
+void tb_default_denoiser_settings(tb_denoiser_settings* out);
+int tb_render_realtime(tb_context* ctx, uint32_t width, uint32_t height, const tb_output_settings* settings, const tb_denoiser_settings* denoiser, float time_seed);
+int tb_read_realtime(tb_context* ctx, int stage, float* rgba);
 
 /* <-> ReadbackStats copy (TracerBoy.cpp:2946, D3D12App.cpp:195-201) */
 int tb_read_stats(tb_context* ctx, tb_readback_stats* out);

@@ -59,6 +59,13 @@ void tbo_rand_stream(float seed, float time, uint32_t n, float* out);
  * output type is LIT) then PostProcessCS on `in` (W*H float4, or W*H floats when inIsR32).  All outputs nullable. */
 void tbo_post_process(const TbPostConstants* pc, const float* in, int inIsR32, float* outRgba, uint8_t* outRgba8, float* averagedOut, uint32_t* histogramOut);
 
+/* Real-time chain (rt_ref.cpp); surfaces are W*H float4, row 0 = top; momentHistory / outMoment may be NULL when
+ * OutputMomentInformation is 0 */
+void tbo_temporal(const TbTemporalConstants* constants, const float* history, const float* current, const float* worldPos, const float* prevWorldPos,
+                  const float* momentHistory, const float* normals, float* out, float* outMoment);
+void tbo_denoise(const TbDenoiserConstants* constants, const float* input, const float* normals, const float* positions, const float* undenoised, float* out);
+void tbo_composite(uint32_t W, uint32_t H, const float* albedo, const float* lighting, const float* emissive, float* out);
+
 /* IsValidHit alpha test on candidate hits of non-opaque geometry (off by default, like the reference's software path) */
 void tbo_set_alpha_test(int enabled);
 

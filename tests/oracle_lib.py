@@ -36,6 +36,12 @@ def lib():
         L.tbo_sample_pixel.restype = None
         L.tbo_sample_pixel.argtypes = [C.POINTER(abi.TbSceneView), C.POINTER(abi.TbPerFrameConstants), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                        C.POINTER(C.c_float * 4), C.POINTER(C.c_float), C.POINTER(abi.TbRayStats)]
+        L.tbo_temporal.restype = None
+        L.tbo_temporal.argtypes = [C.POINTER(abi.TbTemporalConstants)] + [vp] * 8
+        L.tbo_denoise.restype = None
+        L.tbo_denoise.argtypes = [C.POINTER(abi.TbDenoiserConstants)] + [vp] * 5
+        L.tbo_composite.restype = None
+        L.tbo_composite.argtypes = [C.c_uint32, C.c_uint32] + [vp] * 4
         L.tbo_set_alpha_test.restype = None
         L.tbo_set_alpha_test.argtypes = [C.c_int]
         L.tbo_post_process.restype = None
@@ -88,6 +94,33 @@ def render(view, pf, width, height, frames, first_frame=0, y0=0, y1=None, thread
     if stats:
         res["stats"] = st
     return res
+
+
+def _f4(a):
+    return np.ascontiguousarray(a, np.float32)
+
+
+def temporal(constants, history, current, world_pos, prev_world_pos, moment_history, normals):
+    """TemporalAccumulationCS on (H, W, 4) surfaces; returns (out, moments or None)."""
+    h, w = current.shape[:2]
+    out = np.empty((h, w, 4), np.float32)
+    mom = np.empty((h, w, 4), np.float32) if constants.OutputMomentInformation else None
+    lib().tbo_temporal(C.byref(constants), _p(_f4(history)), _p(_f4(current)), _p(_f4(world_pos)), _p(_f4(prev_world_pos)),
+                       _p(_f4(moment_history)) if moment_history is not None else None, _p(_f4(normals)), _p(out), _p(mom))
+    return out, mom
+
+
+def denoise(constants, inp, normals, positions, undenoised):
+    out = np.empty(inp.shape, np.float32)
+    lib().tbo_denoise(C.byref(constants), _p(_f4(inp)), _p(_f4(normals)), _p(_f4(positions)), _p(_f4(undenoised)), _p(out))
+    return out
+
+
+def composite(albedo, lighting, emissive):
+    h, w = albedo.shape[:2]
+    out = np.empty((h, w, 4), np.float32)
+    lib().tbo_composite(w, h, _p(_f4(albedo)), _p(_f4(lighting)), _p(_f4(emissive)), _p(out))
+    return out
 
 
 def set_alpha_test(enabled):

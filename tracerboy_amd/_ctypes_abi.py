@@ -123,6 +123,24 @@ class TbPostConstants(C.Structure):
                 ("VarianceMultiplier", C.c_float)]
 
 
+class tb_denoiser_settings(C.Structure):
+    _fields_ = [("Enabled", C.c_uint32), ("IntersectPositionWeightingMultiplier", C.c_float), ("NormalWeightingExponential", C.c_float),
+                ("LuminanceWeightingMultiplier", C.c_float), ("WaveletIterations", C.c_uint32)]
+
+
+class TbTemporalConstants(C.Structure):
+    _fields_ = [("ResolutionX", C.c_uint32), ("ResolutionY", C.c_uint32), ("CameraFocalDistance", C.c_float), ("IgnoreHistory", C.c_uint32),
+                ("CameraPosition", C.c_float * 3), ("CameraLensHeight", C.c_float), ("CameraLookAt", C.c_float * 3), ("HistoryWeight", C.c_float),
+                ("CameraUp", C.c_float * 3), ("OutputMomentInformation", C.c_uint32), ("CameraRight", C.c_float * 3), ("padding3", C.c_uint32),
+                ("PrevFrameCameraPosition", C.c_float * 3), ("padding4", C.c_uint32), ("PrevFrameCameraUp", C.c_float * 3), ("padding5", C.c_uint32),
+                ("PrevFrameCameraRight", C.c_float * 3), ("padding6", C.c_uint32), ("PrevFrameCameraLookAt", C.c_float * 3), ("padding7", C.c_uint32)]
+
+
+class TbDenoiserConstants(C.Structure):
+    _fields_ = [("ResolutionX", C.c_uint32), ("ResolutionY", C.c_uint32), ("OffsetMultiplier", C.c_uint32), ("NormalWeightingExponential", C.c_float),
+                ("IntersectionPositionWeightingMultiplier", C.c_float), ("LumaWeightingMultiplier", C.c_float), ("GlobalFrameCount", C.c_uint32)]
+
+
 class tb_readback_stats(C.Structure):
     _fields_ = [("ActiveWaves", C.c_uint32), ("ActivePixels", C.c_uint32), ("SelectedPixelDistance", C.c_float), ("SelectedMaterialID", C.c_int32),
                 ("rays", TbRayStats)]
@@ -136,6 +154,8 @@ class tb_scene_info(C.Structure):
 
 
 assert C.sizeof(TbPostConstants) == 36
+assert C.sizeof(TbTemporalConstants) == 144
+assert C.sizeof(TbDenoiserConstants) == 28
 assert C.sizeof(TbPerFrameConstants) == 148
 assert C.sizeof(TbConfigConstants) == 76
 assert C.sizeof(TbLight) == 104

@@ -59,6 +59,9 @@ def lib():
         "tb_sync": (C.c_int, [vp]),
         "tb_read_accum": (C.c_int, [vp, vp, vp]),
         "tb_default_post_settings": (None, [P(abi.tb_post_settings)]),
+        "tb_default_denoiser_settings": (None, [P(abi.tb_denoiser_settings)]),
+        "tb_render_realtime": (C.c_int, [vp, C.c_uint32, C.c_uint32, P(abi.tb_output_settings), P(abi.tb_denoiser_settings), C.c_float]),
+        "tb_read_realtime": (C.c_int, [vp, C.c_int, vp]),
         "tb_post_process": (C.c_int, [vp, P(abi.tb_post_settings), C.c_uint32, vp, vp]),
         "tb_read_averaged_luminance": (C.c_int, [vp, P(C.c_float)]),
         "tb_write_image_rgba8": (C.c_int, [C.c_char_p, C.c_uint32, C.c_uint32, vp]),
@@ -106,6 +109,13 @@ def GetDefaultOutputSettings():
     """TracerBoy::GetDefaultOutputSettings (TracerBoy.h:290-360)."""
     s = abi.tb_output_settings()
     lib().tb_default_output_settings(C.byref(s))
+    return s
+
+
+def GetDefaultDenoiserSettings():
+    """GetDefaultOutputSettings().m_denoiserSettings (TracerBoy.h:338-344)."""
+    s = abi.tb_denoiser_settings()
+    lib().tb_default_denoiser_settings(C.byref(s))
     return s
 
 
@@ -309,6 +319,18 @@ class TracerBoy:
         jit = np.empty_like(out) if jittered else None
         self._check(self._L.tb_read_accum(self._ctx, _np_ptr(out), _np_ptr(jit) if jittered else None))
         return (out, jit) if jittered else out
+
+    def RenderRealTime(self, width, height, outputSettings=None, denoiserSettings=None, time_seed=0.0):
+        """One displayed frame of RenderMode::RealTime: 1 spp + TAA + a-trous denoiser + albedo composite + TAA (TracerBoy.cpp:2677-3160)."""
+        self._check(self._L.tb_render_realtime(self._ctx, width, height, C.byref(outputSettings) if outputSettings is not None else None,
+                                               C.byref(denoiserSettings) if denoiserSettings is not None else None, time_seed))
+        self.width, self.height = width, height
+
+    def ReadRealTimeStage(self, stage):
+        """0 first TAA output (rgb, variance), 1 moments, 2 denoised, 3 composited, 4 final TAA output."""
+        out = np.empty((self.height, self.width, 4), np.float32)
+        self._check(self._L.tb_read_realtime(self._ctx, stage, _np_ptr(out)))
+        return out
 
     def PostProcess(self, postSettings=None, outputType=0, rgba8=True):
         """The tail of TracerBoy::Render (TracerBoy.cpp:2948-3200): auto exposure + PostProcessCS on the surface the output

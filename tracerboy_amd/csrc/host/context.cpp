@@ -74,6 +74,10 @@ struct tb_context {
     uint32_t width = 0, height = 0;
     DevBuf output, jittered, aov[8], stats, rayStats, packed;
     DevBuf postOut, postRgba8, postHistogram, postAverage; /* output stage (post_kernels.hip) */
+    /* real-time chain (rt_kernels.hip): ping-pong histories like TracerBoy.h:513-518,747-749 */
+    DevBuf rtIndirect[2], rtMoment[2], rtFinal[2], rtDenoise[2], rtComposited;
+    uint32_t rtActive = 0, rtWidth = 0, rtHeight = 0; int rtLast[5] = {-1, -1, -1, -1, -1}; /* which buffer holds each stage's last output */
+    bool lastRenderRealtime = false; tb_camera prevCamera{};
     /* wavefront pipeline: two ping-pong extend queues (4 columns), one shadow queue (11 columns), hits, samples, counters */
     DevBuf wfCols[2][4], wfShadowCols[11], wfHitA, wfHitG, wfSamples, wfCounts;
     uint64_t wfCapacity = 0, wfSampleCapacity = 0;
@@ -478,6 +482,8 @@ void tb_destroy(tb_context* c)
     for (DevBuf& b : c->wfShadowCols) b.release();
     c->wfHitA.release(); c->wfHitG.release(); c->wfSamples.release(); c->wfCounts.release();
     c->postOut.release(); c->postRgba8.release(); c->postHistogram.release(); c->postAverage.release();
+    for (int i = 0; i < 2; i++) { c->rtIndirect[i].release(); c->rtMoment[i].release(); c->rtFinal[i].release(); c->rtDenoise[i].release(); }
+    c->rtComposited.release();
     for (DevBuf& b : c->aov) b.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -555,8 +561,8 @@ int tb_set_material(tb_context* c, int id, const TbMaterial* in)
     });
 }
 
-int tb_render(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_output_settings* s, float t) { return guarded(c, [&]() { return renderImpl(c, W, H, n, s, t, true); }); }
-int tb_render_async(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_output_settings* s, float t) { return guarded(c, [&]() { return renderImpl(c, W, H, n, s, t, false); }); }
+int tb_render(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_output_settings* s, float t) { return guarded(c, [&]() { c->lastRenderRealtime = false; return renderImpl(c, W, H, n, s, t, true); }); }
+int tb_render_async(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_output_settings* s, float t) { return guarded(c, [&]() { c->lastRenderRealtime = false; return renderImpl(c, W, H, n, s, t, false); }); }
 int tb_sync(tb_context* c)
 {
     return guarded(c, [&]() { HIP_TRY(hipStreamSynchronize(c->stream)); (void)hipEventElapsedTime(&c->lastMs, c->ev0, c->ev1); return TB_OK; });
@@ -585,6 +591,85 @@ int tb_read_aov(tb_context* c, int which, void* dst)
 
 int tb_accum_device_ptr(tb_context* c, void** o, void** j) { if (!c) return TB_E_INVALID; if (o) *o = c->output.p; if (j) *j = c->jittered.p; return c->output.p ? TB_OK : TB_E_INVALID; }
 
+void tb_default_denoiser_settings(tb_denoiser_settings* o) /* TracerBoy.h:338-344 */
+{
+    if (!o) return;
+    o->Enabled = 1; o->IntersectPositionWeightingMultiplier = 1.0f; o->NormalWeightingExponential = 128.0f; o->LuminanceWeightingMultiplier = 4.0f; o->WaveletIterations = 5;
+}
+
+/* One frame of RenderMode::RealTime: path trace 1 spp (IsRealTime: per-frame output, demodulated albedo, AOVs), then
+ * TracerBoy.cpp:3060-3160: TAA on the indirect lighting (with luminance moments), a-trous denoiser, albedo composite, TAA. */
+int tb_render_realtime(tb_context* c, uint32_t W, uint32_t H, const tb_output_settings* settings, const tb_denoiser_settings* denoiser, float timeSeed)
+{
+    return guarded(c, [&]() {
+        if (!c->hasScene) return fail(c, TB_E_NO_SCENE, "tb_render_realtime: no scene loaded");
+        tb_output_settings s; if (settings) s = *settings; else DefaultOutputSettings(s);
+        s.RenderModeRealTime = 1;
+        tb_denoiser_settings dn; if (denoiser) dn = *denoiser; else tb_default_denoiser_settings(&dn);
+        const auto savedAov = c->options.find("aov") != c->options.end() ? c->options["aov"] : 0;
+        c->options["aov"] = 1;
+        const size_t bytes = (size_t)W * H * sizeof(TbFloat4);
+        if (c->rtWidth != W || c->rtHeight != H) {
+            for (DevBuf* b : {&c->rtIndirect[0], &c->rtIndirect[1], &c->rtMoment[0], &c->rtMoment[1], &c->rtFinal[0], &c->rtFinal[1], &c->rtDenoise[0], &c->rtDenoise[1], &c->rtComposited}) {
+                ensure(*b, bytes); HIP_TRY(hipMemsetAsync(b->p, 0, bytes, c->stream));
+            }
+            c->rtWidth = W; c->rtHeight = H; c->rtActive = 0; c->prevCamera = c->camera;
+        }
+        int rc = renderImpl(c, W, H, 1, &s, timeSeed, false);
+        c->options["aov"] = savedAov;
+        if (rc != TB_OK) return rc;
+        const uint32_t cur = c->rtActive, prev = cur ^ 1u;
+        const TbFloat4* wpCur = (const TbFloat4*)c->aov[TB_AOV_WORLD_POSITION0 + cur].p;   /* AOVWorldPosition0SRV + GetPathTracerOutputIndex(), TracerBoy.cpp:3614-3622 */
+        const TbFloat4* wpPrev = (const TbFloat4*)c->aov[TB_AOV_WORLD_POSITION0 + prev].p;
+        const TbFloat4* normals = (const TbFloat4*)c->aov[TB_AOV_NORMALS].p;
+        auto temporal = [&](const TbFloat4* current, DevBuf* outBuf, DevBuf* histBuf, DevBuf* momentOut, DevBuf* momentHist) {
+            TbTemporalConstants k; memset(&k, 0, sizeof k); /* TemporalAccumulationPass.cpp:95-110 */
+            k.ResolutionX = W; k.ResolutionY = H; k.OutputMomentInformation = momentOut ? 1u : 0u;
+            k.IgnoreHistory = c->samplesRendered == 0 ? 1u : 0u; /* evaluated after m_SamplesRendered++ (TracerBoy.cpp:2930,3083), i.e. never set while rendering */
+            k.HistoryWeight = 0.95f; k.CameraLensHeight = c->camera.LensHeight; k.CameraFocalDistance = c->camera.FocalDistance;
+            memcpy(k.CameraPosition, c->camera.Position, 12); memcpy(k.CameraLookAt, c->camera.LookAt, 12); memcpy(k.CameraRight, c->camera.Right, 12); memcpy(k.CameraUp, c->camera.Up, 12);
+            memcpy(k.PrevFrameCameraPosition, c->prevCamera.Position, 12); memcpy(k.PrevFrameCameraLookAt, c->prevCamera.LookAt, 12);
+            memcpy(k.PrevFrameCameraRight, c->prevCamera.Right, 12); memcpy(k.PrevFrameCameraUp, c->prevCamera.Up, 12);
+            HIP_TRY(rt_launch_temporal(c->stream, &k, (const TbFloat4*)histBuf->p, current, wpCur, wpPrev, momentHist ? (const TbFloat4*)momentHist->p : nullptr, normals,
+                                       (TbFloat4*)outBuf->p, momentOut ? (TbFloat4*)momentOut->p : nullptr));
+        };
+        temporal((const TbFloat4*)c->output.p, &c->rtIndirect[cur], &c->rtIndirect[prev], &c->rtMoment[cur], &c->rtMoment[prev]);
+        c->rtLast[0] = (int)cur; c->rtLast[1] = (int)cur;
+        const TbFloat4* lighting = (const TbFloat4*)c->rtIndirect[cur].p;
+        c->rtLast[2] = -1;
+        if (dn.Enabled && s.OutputType == TB_OUTPUT_TYPE_LIT) { /* DenoiserPass.cpp:61-93 */
+            uint32_t outIdx = 0, inIdx = 1;
+            for (uint32_t i = 0; i < dn.WaveletIterations; i++) {
+                TbDenoiserConstants k; k.ResolutionX = W; k.ResolutionY = H; k.OffsetMultiplier = 1u << i;
+                k.NormalWeightingExponential = dn.NormalWeightingExponential; k.IntersectionPositionWeightingMultiplier = dn.IntersectPositionWeightingMultiplier;
+                k.LumaWeightingMultiplier = dn.LuminanceWeightingMultiplier; k.GlobalFrameCount = c->samplesRendered;
+                const TbFloat4* in = i == 0 ? (const TbFloat4*)c->rtIndirect[cur].p : (const TbFloat4*)c->rtDenoise[inIdx].p;
+                HIP_TRY(rt_launch_denoise(c->stream, &k, in, normals, wpCur, (const TbFloat4*)c->rtIndirect[cur].p, (TbFloat4*)c->rtDenoise[outIdx].p));
+                inIdx = outIdx; outIdx = (outIdx + 1) % 2;
+            }
+            if (dn.WaveletIterations > 0) { lighting = (const TbFloat4*)c->rtDenoise[inIdx].p; c->rtLast[2] = (int)inIdx; }
+        }
+        HIP_TRY(rt_launch_composite(c->stream, W, H, (const TbFloat4*)c->aov[TB_AOV_CUSTOM].p, lighting, (const TbFloat4*)c->aov[TB_AOV_EMISSIVE].p, (TbFloat4*)c->rtComposited.p));
+        c->rtLast[3] = 0;
+        temporal((const TbFloat4*)c->rtComposited.p, &c->rtFinal[cur], &c->rtFinal[prev], nullptr, nullptr);
+        c->rtLast[4] = (int)cur;
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->rtActive = prev; c->prevCamera = c->camera; c->lastRenderRealtime = true; /* TracerBoy.cpp:3363-3367 */
+        return TB_OK;
+    });
+}
+
+int tb_read_realtime(tb_context* c, int stage, float* dst)
+{
+    return guarded(c, [&]() {
+        if (!dst || stage < 0 || stage > 4 || !c->lastRenderRealtime || c->rtLast[stage] < 0) return fail(c, TB_E_INVALID, "tb_read_realtime: stage not available (render a real-time frame first)");
+        const DevBuf* b = stage == 0 ? &c->rtIndirect[c->rtLast[0]] : stage == 1 ? &c->rtMoment[c->rtLast[1]] : stage == 2 ? &c->rtDenoise[c->rtLast[2]] : stage == 3 ? &c->rtComposited : &c->rtFinal[c->rtLast[4]];
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipMemcpy(dst, b->p, (size_t)c->rtWidth * c->rtHeight * sizeof(TbFloat4), hipMemcpyDeviceToHost));
+        return TB_OK;
+    });
+}
+
 void tb_default_post_settings(tb_post_settings* o) /* TracerBoy.h:298,309-313 */
 {
     if (!o) return;
@@ -598,7 +683,8 @@ int tb_post_process(tb_context* c, const tb_post_settings* post, uint32_t output
         tb_post_settings ps; if (post) ps = *post; else tb_default_post_settings(&ps);
         const TbFloat4* in = nullptr; const float* inR32 = nullptr;
         switch (outputType) { /* GetOutputSRV, TracerBoy.cpp:2354-2383 */
-        case TB_OUTPUT_TYPE_LIT: case TB_OUTPUT_TYPE_LUMINANCE: in = (const TbFloat4*)c->output.p; break;
+        case TB_OUTPUT_TYPE_LIT: in = (const TbFloat4*)(c->lastRenderRealtime ? c->rtFinal[c->rtLast[4]].p : c->output.p); break; /* PostProcessInput after the real-time chain, TracerBoy.cpp:3144-3160 */
+        case TB_OUTPUT_TYPE_LUMINANCE: in = (const TbFloat4*)c->output.p; break;
         case TB_OUTPUT_TYPE_ALBEDO: case TB_OUTPUT_TYPE_LIVE_PIXELS: case TB_OUTPUT_TYPE_HEATMAP: in = (const TbFloat4*)c->aov[TB_AOV_CUSTOM].p; break;
         case TB_OUTPUT_TYPE_NORMAL: in = (const TbFloat4*)c->aov[TB_AOV_NORMALS].p; break;
         case TB_OUTPUT_TYPE_DEPTH: inR32 = (const float*)c->aov[TB_AOV_DEPTH].p; break;

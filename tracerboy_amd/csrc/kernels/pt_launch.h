@@ -16,6 +16,12 @@ hipError_t pt_launch_pack_owned(hipStream_t stream, const TbFloat4* full, TbFloa
 size_t bvh_gpu_scratch_bytes(uint32_t N);
 hipError_t bvh_gpu_build(hipStream_t stream, const float* positions, const uint32_t* triVertexIndex, const uint32_t* triGeometry, const uint32_t* triPrimitive,
                          const uint32_t* triFlags, uint32_t N, uint8_t* scratch, size_t scratchBytes, uint8_t* bvhA, TbNodeB* nodesB, TbTriB* trisB, uint32_t* rootHeight);
+/* real-time chain (rt_kernels.hip): temporal accumulation, one a-trous denoiser iteration, albedo composite */
+hipError_t rt_launch_temporal(hipStream_t stream, const TbTemporalConstants* k, const TbFloat4* history, const TbFloat4* current, const TbFloat4* worldPos,
+                              const TbFloat4* prevWorldPos, const TbFloat4* momentHistory, const TbFloat4* normals, TbFloat4* out, TbFloat4* outMoment);
+hipError_t rt_launch_denoise(hipStream_t stream, const TbDenoiserConstants* k, const TbFloat4* input, const TbFloat4* normals, const TbFloat4* positions,
+                             const TbFloat4* undenoised, TbFloat4* out);
+hipError_t rt_launch_composite(hipStream_t stream, uint32_t W, uint32_t H, const TbFloat4* albedo, const TbFloat4* lighting, const TbFloat4* emissive, TbFloat4* out);
 /* output stage (post_kernels.hip): optional histogram + average (auto exposure), then PostProcessCS */
 hipError_t post_launch(hipStream_t stream, const TbPostConstants* pc, const TbFloat4* in, const float* inR32, const TbFloat4* aux,
                        uint32_t* histogram, float* averaged, TbFloat4* out, uint32_t* outRgba8);
