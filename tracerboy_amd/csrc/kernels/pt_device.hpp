@@ -181,25 +181,29 @@ TBD bool is_valid_hit(const SceneRefs& sc, const TbDeviceScene& ds, uint32_t geo
 template <bool ALPHA>
 TBD void tri_test(Hit& best, float tMin, tb3 o, const RayPre& r, const TbTriB& tri, bool permuted, const SceneRefs& sc, const TbDeviceScene& ds)
 {
-    float Ax, Ay, Az, Bx, By, Bz, Cx, Cy, Cz;
+    float Az, Bz, Cz, U, V, W;
     if (permuted) {
-        /* the record already holds (v[kx], v[ky], v[kz]) for this ray's axis order: no per-lane component selects */
-        const tb3 a = ld3(tri.v0) - r.operm, b = ld3(tri.v1) - r.operm, c = ld3(tri.v2) - r.operm;
-        Az = a.z; Bz = b.z; Cz = c.z;
-        Ax = tb_fma(-r.shear.x, Az, a.x); Ay = tb_fma(-r.shear.y, Az, a.y);
-        Bx = tb_fma(-r.shear.x, Bz, b.x); By = tb_fma(-r.shear.y, Bz, b.y);
-        Cx = tb_fma(-r.shear.x, Cz, c.x); Cy = tb_fma(-r.shear.y, Cz, c.y);
+        /* the record already holds (v[kx], v[ky], v[kz]) for this ray's axis order: no per-lane component selects, and
+         * the x/y halves go through packed fp32 ops (each product / fma rounded on its own, like the scalar form) */
+        const tbf2 oxy = {r.operm.x, r.operm.y}, shear = {r.shear.x, r.shear.y};
+        Az = tri.v0[2] - r.operm.z; Bz = tri.v1[2] - r.operm.z; Cz = tri.v2[2] - r.operm.z;
+        const tbf2 A = __builtin_elementwise_fma(-shear, f2_splat(Az), f2_ld(tri.v0) - oxy);
+        const tbf2 B = __builtin_elementwise_fma(-shear, f2_splat(Bz), f2_ld(tri.v1) - oxy);
+        const tbf2 C = __builtin_elementwise_fma(-shear, f2_splat(Cz), f2_ld(tri.v2) - oxy);
+        /* `precise` in the reference (TraverseFunction.hlsli:260-262): never contracted */
+        const tbf2 pu = C * B.yx, pv = A * C.yx, pw = B * A.yx;
+        U = pu.x - pu.y; V = pv.x - pv.y; W = pw.x - pw.y;
     } else {
         const tb3 a = ld3(tri.v0) - o, b = ld3(tri.v1) - o, c = ld3(tri.v2) - o;
         Az = tb3_get(a, r.kz); Bz = tb3_get(b, r.kz); Cz = tb3_get(c, r.kz);
-        Ax = tb_fma(-r.shear.x, Az, tb3_get(a, r.kx)); Ay = tb_fma(-r.shear.y, Az, tb3_get(a, r.ky));
-        Bx = tb_fma(-r.shear.x, Bz, tb3_get(b, r.kx)); By = tb_fma(-r.shear.y, Bz, tb3_get(b, r.ky));
-        Cx = tb_fma(-r.shear.x, Cz, tb3_get(c, r.kx)); Cy = tb_fma(-r.shear.y, Cz, tb3_get(c, r.ky));
+        const float Ax = tb_fma(-r.shear.x, Az, tb3_get(a, r.kx)), Ay = tb_fma(-r.shear.y, Az, tb3_get(a, r.ky));
+        const float Bx = tb_fma(-r.shear.x, Bz, tb3_get(b, r.kx)), By = tb_fma(-r.shear.y, Bz, tb3_get(b, r.ky));
+        const float Cx = tb_fma(-r.shear.x, Cz, tb3_get(c, r.kx)), Cy = tb_fma(-r.shear.y, Cz, tb3_get(c, r.ky));
+        /* `precise` in the reference (TraverseFunction.hlsli:260-262): never contracted */
+        U = Cx * By - Cy * Bx;
+        V = Ax * Cy - Ay * Cx;
+        W = Bx * Ay - By * Ax;
     }
-    /* `precise` in the reference (TraverseFunction.hlsli:260-262): never contracted */
-    float U = Cx * By - Cy * Bx;
-    float V = Ax * Cy - Ay * Cx;
-    float W = Bx * Ay - By * Ax;
     float det = U + V + W;
     if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) return;
     if (det == 0.0f) return;
