@@ -368,6 +368,47 @@ def test_alpha_tested_geometry_bit_exact(gpu_tb, settings):
     assert np.any(pictures[0] != pictures[1])
 
 
+@pytest.mark.parametrize("triangles", [1, 2, 3])
+def test_tiny_scenes_every_builder_and_pipeline(gpu_tb, settings, triangles, tmp_path):
+    """Edge cases of the tree: a single triangle (the root reference is a leaf, no inner node exists), two (one inner node)
+    and three triangles, one of them degenerate (zero area) -- every BVH builder (host LBVH, SAH, GPU LBVH) and every
+    pipeline against the oracle."""
+    shapes = [
+        'Shape "trianglemesh" "integer indices" [0 1 2] "point P" [-1 0 -1  1 0 -1  0 2 -1]',
+        'Shape "trianglemesh" "integer indices" [0 1 2] "point P" [-3 0 2  3 0 2  0 0 -4]',
+        'Shape "trianglemesh" "integer indices" [0 1 2] "point P" [0.5 0.5 0  0.5 0.5 0  0.5 0.5 0]',
+    ][:triangles]
+    scene = """LookAt 0 1 5  0 1 0  0 1 0
+Camera "perspective" "float fov" [45]
+Film "image" "integer xresolution" [48] "integer yresolution" [32]
+WorldBegin
+MakeNamedMaterial "M" "string type" ["matte"] "rgb Kd" [0.6 0.5 0.4]
+AttributeBegin
+  AreaLightSource "diffuse" "rgb L" [9 9 9]
+  %s
+AttributeEnd
+NamedMaterial "M"
+%s
+WorldEnd
+""" % (shapes[0], "\n".join(shapes[1:]))
+    p = tmp_path / "tiny.pbrt"; p.write_text(scene)
+    W, H, F = 48, 32, 2
+    try:
+        for builder in (0, 1, 2):
+            gpu_tb.SetOption("bvh_builder", builder)
+            gpu_tb.LoadScene(str(p))
+            assert gpu_tb.SceneInfo().numTriangles == triangles
+            ref = None
+            for pipeline in (0, 1, 2, 3):
+                gpu_tb.SetOption("pipeline", pipeline); gpu_tb.InvalidateHistory()
+                gpu_tb.Render(W, H, F, settings, 0.0)
+                out = gpu_tb.ReadAccumulation()
+                if ref is None: ref = _oracle(gpu_tb, W, H, F, settings)["output"]
+                assert np.array_equal(bits(out), bits(ref)), (builder, pipeline)
+    finally:
+        gpu_tb.SetOption("pipeline", 0); gpu_tb.SetOption("bvh_builder", 0)
+
+
 def test_tile_split_reproduces_the_single_gpu_image(gpu_tb, settings):
     """Multi-GPU partition on one device: every rank's tiles, packed and un-permuted, give the same bits."""
     from tracerboy_amd import api
