@@ -68,9 +68,18 @@ static void dumpMaterial(FILE* f, const Material::SP& m)
 
 int main(int argc, char** argv)
 {
-    if (argc < 3) { fprintf(stderr, "usage: pbrt_dump scene.pbrt out.txt\n"); return 2; }
+    if (argc < 3) { fprintf(stderr, "usage: pbrt_dump scene.pbrt out.txt | pbrt_dump --save-pbf scene.pbrt out.pbf | pbrt_dump scene.pbf out.txt\n"); return 2; }
+    if (!strcmp(argv[1], "--save-pbf")) { /* the reference parser's own binary writer (pbrt::Scene::saveTo), for the .pbf reader's fixture */
+        if (argc < 4) return 2;
+        try { Scene::SP s = importPBRT(argv[2]); s->saveTo(argv[3]); }
+        catch (const std::exception& e) { fprintf(stderr, "save-pbf threw: %s\n", e.what()); return 1; }
+        return 0;
+    }
     Scene::SP scene;
-    try { scene = importPBRT(argv[1]); }
+    try {
+        const std::string in = argv[1];
+        scene = (in.size() > 4 && in.compare(in.size() - 4, 4, ".pbf") == 0) ? Scene::loadFrom(in) : importPBRT(in);
+    }
     catch (const std::exception& e) { fprintf(stderr, "importPBRT threw: %s\n", e.what()); return 1; }
     FILE* f = fopen(argv[2], "w");
     if (!f) return 3;

@@ -514,7 +514,7 @@ int tb_load_scene(tb_context* c, const char* path)
 {
     return guarded(c, [&]() {
         if (!path) return fail(c, TB_E_INVALID, "tb_load_scene: null path");
-        std::shared_ptr<PbrtScene> ps = importPBRT(path);
+        std::shared_ptr<PbrtScene> ps = importScene(path);
         ConvertOptions co; auto it = c->options.find("flatten_instances"); if (it != c->options.end()) co.flattenInstances = it->second != 0;
         c->hasScene = false;
         ConvertScene(*ps, c->scene, co);
@@ -926,7 +926,7 @@ int tb_host_scene_load(const char* path, int builder, int flatten, tb_host_scene
     if (!path || !out) return TB_E_INVALID;
     *out = nullptr;
     try {
-        std::shared_ptr<PbrtScene> ps = importPBRT(path);
+        std::shared_ptr<PbrtScene> ps = importScene(path);
         tb_host_scene* h = new tb_host_scene();
         ConvertOptions co; co.flattenInstances = flatten != 0;
         try { ConvertScene(*ps, h->scene, co); BuildBvh(h->scene, builder); } catch (...) { delete h; throw; }

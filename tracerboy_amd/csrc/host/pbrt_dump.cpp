@@ -38,7 +38,7 @@ void dumpMaterial(FILE* f, const PbrtMaterialSP& m)
 extern "C" int tb_host_pbrt_dump(const char* pbrt_path, const char* out_path, char* err, uint32_t errLen)
 {
     try {
-        std::shared_ptr<PbrtScene> s = importPBRT(pbrt_path);
+        std::shared_ptr<PbrtScene> s = importScene(pbrt_path);
         FILE* f = fopen(out_path, "w");
         if (!f) throw std::runtime_error(std::string("could not open '") + out_path + "' for writing");
         fprintf(f, "num_cameras 1 %d\n", s->hasCamera ? 1 : 0);

@@ -112,6 +112,14 @@ struct PbrtScene {
 
 /* Throws std::runtime_error (like pbrt::importPBRT, impl/semantic/importPBRT.cpp:26-42). */
 std::shared_ptr<PbrtScene> importPBRT(const std::string& fileName);
+/* `.pbf`, the reference parser's binary scene format (pbf_loader.cpp; <-> pbrt::Scene::loadFrom, TracerBoy.cpp:1210-1223) */
+std::shared_ptr<PbrtScene> importPBF(const std::string& fileName);
+/* by extension: ".pbf" -> importPBF, anything else -> importPBRT (TracerBoy.cpp:1189-1224) */
+inline std::shared_ptr<PbrtScene> importScene(const std::string& fileName)
+{
+    const size_t n = fileName.size();
+    return (n >= 4 && fileName.compare(n - 4, 4, ".pbf") == 0) ? importPBF(fileName) : importPBRT(fileName);
+}
 
 /* Binary PLY reader (triangles only; any other face arity throws, Geometry.cpp:46-66). */
 void readPly(const std::string& fileName, std::vector<Vec3>& pos, std::vector<Vec3>& nor, std::vector<Vec2>& uv, std::vector<uint32_t>& idx);
