@@ -671,6 +671,7 @@ int tb_render_realtime(tb_context* c, uint32_t W, uint32_t H, const tb_output_se
         temporal((const TbFloat4*)c->rtComposited.p, &c->rtFinal[cur], &c->rtFinal[prev], nullptr, nullptr);
         c->rtLast[4] = (int)cur;
         HIP_TRY(hipStreamSynchronize(c->stream));
+        (void)hipEventElapsedTime(&c->lastMs, c->ev0, c->ev1); /* the path-tracing launch of this frame */
         c->rtActive = prev; c->prevCamera = c->camera; c->lastRenderRealtime = true; /* TracerBoy.cpp:3363-3367 */
         return TB_OK;
     });
