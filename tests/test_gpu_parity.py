@@ -182,6 +182,14 @@ def test_settings_variants_bit_exact(gpu_tb, settings, variant):
     ref = _oracle(gpu_tb, W, H, F, s, jittered=True)
     assert np.array_equal(bits(out), bits(ref["output"])), variant
     assert np.array_equal(bits(jit), bits(ref["jittered"])), variant
+    if variant in ("blue_noise", "no_nee", "depth1", "depth0"):   # settings every pipeline's kernels carry (no FEAT_EXT needed)
+        try:
+            for pipeline in (1, 2, 3):
+                gpu_tb.SetOption("pipeline", pipeline); gpu_tb.InvalidateHistory()
+                gpu_tb.Render(W, H, F, s, 0.0)
+                assert np.array_equal(bits(gpu_tb.ReadAccumulation()), bits(ref["output"])), (variant, pipeline)
+        finally:
+            gpu_tb.SetOption("pipeline", 0)
 
 
 def test_aovs_and_heatmap_match(gpu_tb, settings):

@@ -155,7 +155,7 @@ uint32_t sceneFeatureMask(const HostScene& s)
 
 uint32_t settingsFeatureMask(const tb_context* c, const tb_output_settings& s, bool aov)
 {
-    bool ext = s.EnableBlueNoise || s.EnableSamplingImportanceResampling || s.DOFFocalDistance > 0.0f || s.FilterType != TB_FILTER_TYPE_BOX ||
+    bool ext = s.EnableSamplingImportanceResampling || s.DOFFocalDistance > 0.0f || s.FilterType != TB_FILTER_TYPE_BOX ||
                s.FireflyClampValue != 0.0f || s.RenderModeRealTime || s.OutputType == TB_OUTPUT_TYPE_HEATMAP || aov ||
                (c->selX != 0xffffffffu) || c->ds.alphaTest != 0;
     return ext ? PT_FEAT_EXT : 0u;

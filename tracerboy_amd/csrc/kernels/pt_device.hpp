@@ -650,7 +650,7 @@ TBD float halton(int b, int i) /* RayGenCommon.h:49-59 */
 template <uint32_t F>
 TBD void blue_noise(const TbDeviceScene& ds, const TbPerFrameConstants& pf, uint32_t frame, float& seed, uint32_t x, uint32_t y, float out[8])
 {
-    if (!(F & FEAT_EXT) || !pf.UseBlueNoise) {
+    if (!pf.UseBlueNoise) { /* a uniform branch in every variant: blue noise is the reference's default (TracerBoy.h:354) */
         for (int i = 0; i < 8; i++) out[i] = rnd(seed, pf.Time);
     } else {
         uint32_t idx = (y % 256u) * 256u + (x % 256u);
