@@ -157,10 +157,19 @@ __global__ __launch_bounds__(256) void post_histogram_kernel(const TbFloat4* in,
     __syncthreads();
     const uint32_t groupsX = (W + 15u) / 16u;
     const uint32_t x = (blockIdx.x % groupsX) * 16u + (threadIdx.x & 15u), y = (blockIdx.x / groupsX) * 16u + (threadIdx.x >> 4);
+    uint32_t bin = 0xffffffffu; /* no pixel */
     if (x < W && y < H) {
         const TbFloat4 a = in[(size_t)y * W + x];
         P3 c = p3(a.x / a.w, a.y / a.w, a.z / a.w);
-        atomicAdd(&bins[luminance_bin(luma709(c), minLog, oneOverRange)], 1u);
+        bin = luminance_bin(luma709(c), minLog, oneOverRange);
+    }
+    /* neighbouring pixels mostly share a bin: one LDS atomic per distinct bin of the wave instead of one per pixel */
+    unsigned long long todo = __ballot(bin != 0xffffffffu);
+    while (todo) {
+        const uint32_t leaderBin = (uint32_t)__shfl((int)bin, __ffsll((long long)todo) - 1, 64);
+        const unsigned long long same = __ballot(bin == leaderBin);
+        if ((threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)todo) - 1)) atomicAdd(&bins[leaderBin], (uint32_t)__popcll(same));
+        todo &= ~same;
     }
     __syncthreads();
     if (bins[threadIdx.x]) atomicAdd(&histogram[threadIdx.x], bins[threadIdx.x]);
