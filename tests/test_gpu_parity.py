@@ -417,6 +417,25 @@ WorldEnd
         gpu_tb.SetOption("pipeline", 0); gpu_tb.SetOption("bvh_builder", 0)
 
 
+@pytest.mark.parametrize("group", [1, 3, 8])
+def test_frame_group_mode_bit_exact(gpu_tb, settings, group):
+    """Frame-group mode of the persistent kernel (TbDeviceTargets::samples): workgroups render `group` frames each into a
+    (frame, pixel) sample buffer that is summed in frame order afterwards -- the image and the jittered image must be the
+    oracle's bits, also across two progressive calls and several sample-buffer batches."""
+    gpu_tb.LoadScene(CORNELL)
+    W, H, F = 200, 120, 7
+    gpu_tb.SetOption("frame_group", group); gpu_tb.SetOption("pooled_samples", W * H * 3)
+    try:
+        gpu_tb.Render(W, H, F - 2, settings, 0.0)
+        gpu_tb.Render(W, H, 2, settings, 0.0)
+        out, jit = gpu_tb.ReadAccumulation(jittered=True)
+    finally:
+        gpu_tb.SetOption("frame_group", 0); gpu_tb.SetOption("pooled_samples", 256 << 20)
+    ref = _oracle(gpu_tb, W, H, F, settings, jittered=True)
+    assert np.array_equal(bits(out), bits(ref["output"]))
+    assert np.array_equal(bits(jit), bits(ref["jittered"]))
+
+
 def test_tile_split_reproduces_the_single_gpu_image(gpu_tb, settings):
     """Multi-GPU partition on one device: every rank's tiles, packed and un-permuted, give the same bits."""
     from tracerboy_amd import api

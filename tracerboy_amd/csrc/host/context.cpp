@@ -398,7 +398,8 @@ void renderPooled(tb_context* c, int variant, uint32_t W, uint32_t H, uint32_t f
     if (pixels * batch > 0xffffff00ull) throw std::runtime_error("pooled batch exceeds 2^32 samples");
     ensure(c->wfSamples, pixels * batch * 16);
     const wf_variant_fn fn = kWfVariants[variant];
-    const uint32_t blocks = ((W + 15u) / 16u) * ((H + 15u) / 16u);
+    const uint32_t blocks = tb_persistent_grid(W, H, c->tiles);
+    if (blocks == 0) return; /* this rank owns no tile */
     for (uint32_t f0 = 0; f0 < n; f0 += batch) {
         WfParams wp; memset(&wp, 0, sizeof wp);
         wp.W = W; wp.H = H; wp.firstFrame = firstFrame + f0; wp.numFrames = std::min(batch, n - f0); wp.tiles = c->tiles;
@@ -458,7 +459,27 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
     if (wavefront) renderWavefront(c, variantIndex, W, H, c->samplesRendered, n, pf);
     else if (pooled) renderPooled(c, variantIndex, W, H, c->samplesRendered, n, pf);
-    else HIP_TRY(v->fn(c->stream, &c->ds, &pf, &tg, W, H, c->samplesRendered, n, &c->tiles, c->sceneInLds ? 1 : 0, count ? 1 : 0, (int)opt("pipeline", 0)));
+    else {
+        /* frame-group mode (TbDeviceTargets::samples, pt_scene.h): on by default under the tile split, where a rank owns too
+         * few 16x16 regions to balance whole-launch workgroups; option "frame_group" = G > 0 forces it, < 0 forbids it */
+        const int64_t fg = opt("frame_group", 0);
+        const bool groups = opt("pipeline", 0) == 0 && !count && !aov && !s.RenderModeRealTime && fg >= 0 && (fg > 0 || c->tiles.world > 1);
+        if (!groups) HIP_TRY(v->fn(c->stream, &c->ds, &pf, &tg, W, H, c->samplesRendered, n, &c->tiles, c->sceneInLds ? 1 : 0, count ? 1 : 0, (int)opt("pipeline", 0)));
+        else {
+            const uint64_t pixels = (uint64_t)W * H, budget = (uint64_t)opt("pooled_samples", 256ll << 20);
+            const uint32_t batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n, budget / pixels));
+            ensure(c->wfSamples, pixels * batch * 16);
+            /* automatic group size: about 8192 workgroups per launch (measured best at 2 / 4 / 8 ranks on 1080p x 64: G = 32 / 16 / 8) */
+            const uint64_t regions = tb_persistent_grid(W, H, c->tiles);
+            const uint32_t autoG = (uint32_t)std::min<uint64_t>(batch, std::max<uint64_t>(1, ((uint64_t)std::min(batch, n) * regions + 4096) / 8192));
+            tg.samples = (TbFloat4*)c->wfSamples.p; tg.frameGroup = fg > 0 ? (uint32_t)fg : autoG;
+            for (uint32_t f0 = 0; f0 < n; f0 += batch) {
+                const uint32_t nf = std::min(batch, n - f0);
+                HIP_TRY(v->fn(c->stream, &c->ds, &pf, &tg, W, H, c->samplesRendered + f0, nf, &c->tiles, c->sceneInLds ? 1 : 0, 0, 0));
+                HIP_TRY(pt_launch_accumulate_samples(c->stream, tg.samples, W, H, c->samplesRendered + f0, nf, &c->tiles, tg.output, tg.jittered));
+            }
+        }
+    }
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
     c->samplesRendered += n;
     if (sync) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipEventElapsedTime(&c->lastMs, c->ev0, c->ev1)); }
@@ -790,6 +811,7 @@ int tb_select_pixel(tb_context* c, uint32_t x, uint32_t y) { if (!c) return TB_E
 int tb_set_tile_assignment(tb_context* c, uint32_t rank, uint32_t world, uint32_t tw, uint32_t th)
 {
     if (!c || world == 0 || rank >= world || tw == 0 || th == 0) return c ? fail(c, TB_E_INVALID, "tb_set_tile_assignment: bad arguments") : TB_E_INVALID;
+    if (world > 1 && (tw % 16 || th % 16)) return fail(c, TB_E_INVALID, "tb_set_tile_assignment: tile width and height must be multiples of 16 (a workgroup renders 16x16 pixels)");
     c->tiles = TbTileMap{rank, world, tw, th}; c->samplesRendered = 0;
     return TB_OK;
 }
@@ -829,7 +851,7 @@ int tb_unpack_gathered_host(uint32_t W, uint32_t H, uint32_t world, uint32_t tw,
 int tb_set_option(tb_context* c, const char* name, int64_t v)
 {
     if (!c || !name) return TB_E_INVALID;
-    static const char* known[] = {"pipeline", "count_rays", "bvh_builder", "flatten_instances", "aov", "scene_in_lds", "lds_scene_budget", "force_full_variant", "wavefront_paths", "wavefront_grid", "wavefront_segment", "pooled_paths", "pooled_samples", "pooled_profile", "park_min", "alpha_test", "node_order", "node_order_top_levels"};
+    static const char* known[] = {"pipeline", "count_rays", "bvh_builder", "flatten_instances", "aov", "scene_in_lds", "lds_scene_budget", "force_full_variant", "wavefront_paths", "wavefront_grid", "wavefront_segment", "pooled_paths", "pooled_samples", "pooled_profile", "park_min", "alpha_test", "node_order", "node_order_top_levels", "frame_group"};
     for (const char* k : known) if (!strcmp(k, name)) { c->options[name] = v; if (!strcmp(name, "count_rays") || !strcmp(name, "aov")) c->samplesRendered = 0; return TB_OK; }
     return fail(c, TB_E_INVALID, std::string("unknown option '") + name + "'");
 }

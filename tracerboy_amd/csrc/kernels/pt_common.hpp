@@ -24,6 +24,17 @@ __device__ __forceinline__ void make_refs(SceneRefs& sc, const TbDeviceScene& ds
     sc.numMaterials = ds.numMaterials; sc.numLights = ds.numLights;
 }
 
+/* the 16x16 region of this workgroup (tb_persistent_grid, pt_scene.h); false when it lies outside the frame */
+__device__ __forceinline__ bool block_region(const TbTileMap& tiles, uint32_t W, uint32_t H, uint32_t region, uint32_t& bx, uint32_t& by)
+{
+    if (tiles.world <= 1) { const uint32_t blocksX = (W + 15u) / 16u; bx = region % blocksX; by = region / blocksX; return true; }
+    const uint32_t subX = tiles.tileW / 16u, perTile = subX * (tiles.tileH / 16u);
+    const uint32_t k = region / perTile, sub = region % perTile;
+    const uint32_t tilesX = (W + tiles.tileW - 1) / tiles.tileW, t = tiles.rank + k * tiles.world;
+    bx = (t % tilesX) * subX + sub % subX; by = (t / tilesX) * (tiles.tileH / 16u) + sub / subX;
+    return true;
+}
+
 __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v)
 {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);

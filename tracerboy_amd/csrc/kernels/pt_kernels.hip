@@ -80,9 +80,46 @@ __global__ void pack_owned_kernel(const TbFloat4* full, TbFloat4* packed, uint32
     }
 }
 
+/* Ordered sum of the frame-group mode's sample buffer (TbDeviceTargets::samples): RayGenCommon.h:721-727 per pixel,
+ * frames in order.  One lane per owned pixel; reads numFrames x 16 B, HBM-bound. */
+__global__ __launch_bounds__(256) void accumulate_samples_kernel(const TbFloat4* samples, uint32_t W, uint32_t H, uint32_t firstFrame, uint32_t numFrames, TbTileMap tiles,
+                                                                 TbFloat4* output, TbFloat4* jittered)
+{
+    const uint32_t n = W * H;
+    for (uint32_t pix = blockIdx.x * 256u + threadIdx.x; pix < n; pix += gridDim.x * 256u) {
+        if (tiles.world > 1) {
+            const uint32_t x = pix % W, y = pix / W, tx = (W + tiles.tileW - 1) / tiles.tileW;
+            if ((((y / tiles.tileH) * tx + (x / tiles.tileW)) % tiles.world) != tiles.rank) continue;
+        }
+        TbFloat4 acc = {0, 0, 0, 0}, jacc = {0, 0, 0, 0};
+        if (firstFrame > 0) { acc = output[pix]; jacc = jittered[pix]; }
+        for (uint32_t f = 0; f < numFrames; f++) {
+            const TbFloat4 s = samples[(size_t)f * n + pix];
+            const uint32_t frame = firstFrame + f;
+            const float o3 = tb_abs(s.w);
+            const bool coinLow = (__float_as_uint(s.w) >> 31) != 0;
+            if (frame == 0) acc = TbFloat4{0, 0, 0, 0};
+            acc = TbFloat4{s.x + acc.x, s.y + acc.y, s.z + acc.z, o3 + acc.w};
+            if (frame == 0 || coinLow) {
+                if (frame == 0) jacc = TbFloat4{0, 0, 0, 0};
+                jacc = TbFloat4{s.x + jacc.x, s.y + jacc.y, s.z + jacc.z, o3 + jacc.w};
+            }
+        }
+        output[pix] = acc; jittered[pix] = jacc;
+    }
+}
+
 } // namespace
 
 extern "C" {
+
+hipError_t pt_launch_accumulate_samples(hipStream_t stream, const TbFloat4* samples, uint32_t W, uint32_t H, uint32_t firstFrame, uint32_t numFrames, const TbTileMap* tiles,
+                                        TbFloat4* output, TbFloat4* jittered)
+{
+    hipLaunchKernelGGL(accumulate_samples_kernel, dim3(2048), dim3(256), 0, stream, samples, W, H, firstFrame, numFrames, *tiles, output, jittered);
+    return hipGetLastError();
+}
+
 
 hipError_t pt_launch_trace_closest(hipStream_t stream, const TbDeviceScene* ds, uint32_t n, const float* origins, const float* dirs, float* outT, int* outMat,
                                    float* outBary, uint32_t* outPrim, uint32_t* outGeom, float* outNormal, float* outUV, uint32_t* outBoxes, uint32_t* outTris)

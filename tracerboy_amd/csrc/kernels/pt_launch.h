@@ -10,6 +10,8 @@ hipError_t pt_launch_persistent(hipStream_t stream, const TbDeviceScene* ds, con
                                 uint32_t firstFrame, uint32_t numFrames, const TbTileMap* tiles, int sceneInLds, int countRays);
 hipError_t pt_launch_trace_closest(hipStream_t stream, const TbDeviceScene* ds, uint32_t n, const float* origins, const float* dirs, float* outT, int* outMat,
                                    float* outBary, uint32_t* outPrim, uint32_t* outGeom, float* outNormal, float* outUV, uint32_t* outBoxes, uint32_t* outTris);
+hipError_t pt_launch_accumulate_samples(hipStream_t stream, const TbFloat4* samples, uint32_t W, uint32_t H, uint32_t firstFrame, uint32_t numFrames, const TbTileMap* tiles,
+                                        TbFloat4* output, TbFloat4* jittered);
 hipError_t pt_launch_device_math(hipStream_t stream, int fn, uint32_t n, const float* a, const float* b, float* out);
 hipError_t pt_launch_pack_owned(hipStream_t stream, const TbFloat4* full, TbFloat4* packed, uint32_t W, uint32_t H, const TbTileMap* tiles, uint32_t numOwnedTiles);
 /* GPU LBVH build (bvh_kernels.hip); every pointer is a device pointer */

@@ -60,8 +60,34 @@ struct TbDeviceTargets {
     TbFloat4* aovEmissive; /* u7 */
     uint32_t* stats;       /* u10: [0]=ActiveWaves(groups) [1]=ActivePixels [2]=SelectedPixelDistance [3]=SelectedMaterialID */
     unsigned long long* rayStats; /* 7 x u64 (TbRayStats), nullable */
+    /* Frame-group mode (nullable): with `samples` set a workgroup renders its 16x16 region for frameGroup consecutive
+     * frames only and writes every finished sample to samples[(frame - firstFrame) * W * H + pixel] as
+     * (rgb*w, +-w; sign bit = jitter coin < 0.5); accumulate_samples_kernel then sums them in frame order, which keeps
+     * the fp32 accumulation of RayGenCommon.h:704-727 bit for bit while the launch has numFrames/frameGroup times more
+     * workgroups to balance (needed when a rank of the tile split owns only ~1000 regions). */
+    TbFloat4* samples; uint32_t frameGroup;
 };
 
-struct TbTileMap { /* multi-GPU tile ownership: tile t is rendered iff t % world == rank */
+struct TbTileMap { /* multi-GPU tile ownership: tile t is rendered iff t % world == rank; tileW, tileH multiples of 16 */
     uint32_t rank, world, tileW, tileH;
 };
+
+/* Workgroup -> 16x16 pixel region of the persistent kernels.  One GPU: row-major over the frame.  Tile split
+ * (world > 1): ONLY the rank's own tiles are launched, tile-major -- the k-th owned tile is rank + k * world and a
+ * tile is tileW/16 x tileH/16 consecutive workgroups.  The hardware deals consecutive workgroups round-robin to the 8
+ * XCDs, so every XCD gets real work; launching the whole frame and letting foreign workgroups exit left half of the
+ * XCDs idle for every even world size (a rank's tiles then all sit in columns of one parity: measured 51 / 42 / 32 %
+ * efficiency at 2 / 4 / 8 ranks, scripts/tile_split_timing.py). */
+#if defined(__HIPCC__) || defined(__cplusplus)
+static inline
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+uint32_t tb_persistent_grid(uint32_t W, uint32_t H, const TbTileMap& t)
+{
+    if (t.world <= 1) return ((W + 15u) / 16u) * ((H + 15u) / 16u);
+    const uint32_t tiles = ((W + t.tileW - 1) / t.tileW) * ((H + t.tileH - 1) / t.tileH);
+    const uint32_t owned = t.rank < tiles ? (tiles - t.rank + t.world - 1) / t.world : 0u;
+    return owned * (t.tileW / 16u) * (t.tileH / 16u);
+}
+#endif
