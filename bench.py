@@ -122,7 +122,7 @@ def main():
     def step():
         tb.InvalidateHistory()
         tb.Render(W, H, SPP, s, 0.0)          # synchronous; GPU time measured with HIP events on the library's stream
-        kernel_ms.append(tb.LastRenderMs())
+        kernel_ms.append(tb.GetOption("last_kernel_us") / 1e3)  # the render's (first) path-tracing launch, without the sample fold
         if world > 1:
             tb.PackOwnedTo(packed.data_ptr())     # device-to-device, synchronous on the library's stream
             tiles.gather_to_rank0(packed, rank, world, gather_list)
@@ -158,13 +158,13 @@ def main():
 
     if rank == 0:
         # ---- roofline of the dominant (only) kernel: pt_persistent ------------------------------------
-        avg_ms = float(np.mean(kernel_ms))
+        avg_ms = float(np.mean(kernel_ms)); launch_frames = tb.GetOption("last_kernel_frames")
         tb.SetOption("count_rays", 1)
         tb.Render(W, H, 1, s, 0.0)           # counters-on launch of the same kernels, 1 spp, outside the timed region
         st = tb.ReadbackStats().rays
         tb.SetOption("count_rays", 0)
         bytes_per_sample = byte_model(st) / max(st.samples, 1)
-        samples_per_launch = owned_samples = (W * H if world == 1 else owned) * SPP
+        samples_per_launch = owned_samples = (W * H if world == 1 else owned) * launch_frames
         achieved = bytes_per_sample * samples_per_launch / (avg_ms * 1e-3) / 1e9
         result["roofline"] = {
             "bound": "hbm", "kernel": ("pt_persistent", "pt_stream", "wf_* (all stages)", "pt_pooled")[args.pipeline], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -436,6 +436,26 @@ def test_frame_group_mode_bit_exact(gpu_tb, settings, group):
     assert np.array_equal(bits(jit), bits(ref["jittered"]))
 
 
+def test_frame_group_default_and_classic_agree(gpu_tb, settings):
+    """A call of 8 or more frames takes the frame-group mode by itself (lanes draw (pixel, frame) pairs of their region from an
+    LDS counter); frame_group = -1 keeps the one-pixel-per-lane kernel.  Both are the oracle's bits, on a frame whose last
+    region row is half outside the image."""
+    gpu_tb.LoadScene(CORNELL)
+    W, H, F = 200, 120, 12
+    gpu_tb.InvalidateHistory(); gpu_tb.Render(W, H, F, settings, 0.0)
+    auto_out, auto_jit = gpu_tb.ReadAccumulation(jittered=True)
+    gpu_tb.SetOption("frame_group", -1)
+    try:
+        gpu_tb.InvalidateHistory(); gpu_tb.Render(W, H, F, settings, 0.0)
+        classic_out, classic_jit = gpu_tb.ReadAccumulation(jittered=True)
+    finally:
+        gpu_tb.SetOption("frame_group", 0)
+    ref = _oracle(gpu_tb, W, H, F, settings, jittered=True)
+    for out, jit in ((auto_out, auto_jit), (classic_out, classic_jit)):
+        assert np.array_equal(bits(out), bits(ref["output"]))
+        assert np.array_equal(bits(jit), bits(ref["jittered"]))
+
+
 def test_tile_split_reproduces_the_single_gpu_image(gpu_tb, settings):
     """Multi-GPU partition on one device: every rank's tiles, packed and un-permuted, give the same bits."""
     from tracerboy_amd import api

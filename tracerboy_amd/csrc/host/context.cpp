@@ -63,7 +63,8 @@ struct DevBuf {
 struct tb_context {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, evKernel = nullptr; /* evKernel: end of the render's first path-tracing launch */
+    uint32_t lastKernelFrames = 0; float lastKernelMs = 0.0f;
     std::string err;
     HostScene scene; bool hasScene = false;
     tb_camera camera{};
@@ -457,32 +458,42 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
     const bool wavefront = opt("pipeline", 0) == 2 && variantIndex <= 2 && !count && !aov;
     const bool pooled = opt("pipeline", 0) == 3 && variantIndex <= 2 && !count && !aov;
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    c->lastKernelFrames = 0;
     if (wavefront) renderWavefront(c, variantIndex, W, H, c->samplesRendered, n, pf);
     else if (pooled) renderPooled(c, variantIndex, W, H, c->samplesRendered, n, pf);
     else {
-        /* frame-group mode (TbDeviceTargets::samples, pt_scene.h): on by default under the tile split, where a rank owns too
-         * few 16x16 regions to balance whole-launch workgroups; option "frame_group" = G > 0 forces it, < 0 forbids it */
+        /* frame-group mode (TbDeviceTargets::samples, pt_scene.h): the frames of a batch are cut into groups, workgroup
+         * (group, region) renders its 256 pixels x G frames drawing (pixel, frame) pairs from a counter in LDS, every sample goes
+         * to an ordered sample buffer and accumulate_samples_kernel folds them in frame order (bit-identical sums).  Keeps all
+         * lanes of a workgroup busy to its end and gives a rank of a tile split enough workgroups; on whenever a call renders
+         * enough frames to form groups.  Option "frame_group" = G > 0 forces the group size, < 0 forbids the mode. */
         const int64_t fg = opt("frame_group", 0);
-        const bool groups = opt("pipeline", 0) == 0 && !count && !aov && !s.RenderModeRealTime && fg >= 0 && (fg > 0 || c->tiles.world > 1);
+        const bool groups = opt("pipeline", 0) == 0 && !count && !aov && !s.RenderModeRealTime && fg >= 0 && (fg > 0 || n >= 8);
         if (!groups) HIP_TRY(v->fn(c->stream, &c->ds, &pf, &tg, W, H, c->samplesRendered, n, &c->tiles, c->sceneInLds ? 1 : 0, count ? 1 : 0, (int)opt("pipeline", 0)));
         else {
             const uint64_t pixels = (uint64_t)W * H, budget = (uint64_t)opt("pooled_samples", 256ll << 20);
             const uint32_t batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n, budget / pixels));
             ensure(c->wfSamples, pixels * batch * 16);
-            /* automatic group size: about 8192 workgroups per launch (measured best at 2 / 4 / 8 ranks on 1080p x 64: G = 32 / 16 / 8) */
-            const uint64_t regions = tb_persistent_grid(W, H, c->tiles);
-            const uint32_t autoG = (uint32_t)std::min<uint64_t>(batch, std::max<uint64_t>(1, ((uint64_t)std::min(batch, n) * regions + 4096) / 8192));
+            /* automatic group size: at least 8192 workgroups per launch, groups of at least 4 frames (measured on 1080p x 64,
+             * 1 / 2 / 4 / 8 ranks: best G = 32 / 16 / 8-16 / 8, scripts/frame_group_sweep.py) */
+            const uint64_t regions = std::max<uint64_t>(1, tb_persistent_grid(W, H, c->tiles));
+            const uint32_t frames = std::min(batch, n), wantGroups = (uint32_t)std::min<uint64_t>((8192 + regions - 1) / regions, std::max(1u, frames / 4));
+            const uint32_t autoG = (frames + wantGroups - 1) / wantGroups;
             tg.samples = (TbFloat4*)c->wfSamples.p; tg.frameGroup = fg > 0 ? (uint32_t)fg : autoG;
             for (uint32_t f0 = 0; f0 < n; f0 += batch) {
                 const uint32_t nf = std::min(batch, n - f0);
                 HIP_TRY(v->fn(c->stream, &c->ds, &pf, &tg, W, H, c->samplesRendered + f0, nf, &c->tiles, c->sceneInLds ? 1 : 0, 0, 0));
+                if (f0 == 0) { HIP_TRY(hipEventRecord(c->evKernel, c->stream)); c->lastKernelFrames = nf; }
                 HIP_TRY(pt_launch_accumulate_samples(c->stream, tg.samples, W, H, c->samplesRendered + f0, nf, &c->tiles, tg.output, tg.jittered));
             }
         }
     }
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
     c->samplesRendered += n;
-    if (sync) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipEventElapsedTime(&c->lastMs, c->ev0, c->ev1)); }
+    if (sync) {
+        HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipEventElapsedTime(&c->lastMs, c->ev0, c->ev1));
+        if (c->lastKernelFrames) HIP_TRY(hipEventElapsedTime(&c->lastKernelMs, c->ev0, c->evKernel)); else { c->lastKernelMs = c->lastMs; c->lastKernelFrames = n; }
+    }
     return TB_OK;
 }
 
@@ -503,7 +514,7 @@ int tb_create(tb_context** out, int device_id)
     try {
         HIP_TRY(hipSetDevice(device_id));
         HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-        HIP_TRY(hipEventCreate(&c->ev0)); HIP_TRY(hipEventCreate(&c->ev1));
+        HIP_TRY(hipEventCreate(&c->ev0)); HIP_TRY(hipEventCreate(&c->ev1)); HIP_TRY(hipEventCreate(&c->evKernel));
     } catch (const std::exception& ex) { g_createError = ex.what(); delete c; return TB_E_DEVICE; }
     *out = c;
     return TB_OK;
@@ -525,6 +536,7 @@ void tb_destroy(tb_context* c)
     for (DevBuf& b : c->aov) b.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->evKernel) (void)hipEventDestroy(c->evKernel);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -860,6 +872,8 @@ int64_t tb_get_option(tb_context* c, const char* name)
     if (!c || !name) return 0;
     if (!strcmp(name, "scene_in_lds_active")) return c->sceneInLds ? 1 : 0;
     if (!strcmp(name, "scene_features")) return c->sceneFeatures;
+    if (!strcmp(name, "last_kernel_us")) return (int64_t)(c->lastKernelMs * 1000.0f + 0.5f); /* first path-tracing launch of the last synchronous render */
+    if (!strcmp(name, "last_kernel_frames")) return c->lastKernelFrames;
     if (!strcmp(name, "last_variant")) { for (int i = 0; i < 5; i++) if (c->lastVariant == kVariants[i].name) return i; return -1; }
     auto it = c->options.find(name); return it == c->options.end() ? 0 : it->second;
 }
