@@ -80,7 +80,7 @@ struct tb_context {
     uint32_t rtActive = 0, rtWidth = 0, rtHeight = 0; int rtLast[5] = {-1, -1, -1, -1, -1}; /* which buffer holds each stage's last output */
     bool lastRenderRealtime = false; tb_camera prevCamera{};
     /* wavefront pipeline: two ping-pong extend queues (4 columns), one shadow queue (11 columns), hits, samples, counters */
-    DevBuf wfCols[2][4], wfShadowCols[11], wfHitA, wfHitG, wfSamples, wfCounts;
+    DevBuf wfCols[2][4], wfShadowCols[11], wfHitA, wfHitG, wfSamples, wfCounts, workCounter;
     uint64_t wfCapacity = 0, wfSampleCapacity = 0;
     uint32_t samplesRendered = 0;
     tb_output_settings lastSettings{}; bool haveLastSettings = false;
@@ -474,12 +474,14 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
             const uint64_t pixels = (uint64_t)W * H, budget = (uint64_t)opt("pooled_samples", 256ll << 20);
             const uint32_t batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n, budget / pixels));
             ensure(c->wfSamples, pixels * batch * 16);
-            /* automatic group size: at least 8192 workgroups per launch, groups of at least 4 frames (measured on 1080p x 64,
-             * 1 / 2 / 4 / 8 ranks: best G = 32 / 16 / 8-16 / 8, scripts/frame_group_sweep.py) */
+            /* automatic group size: about 49 152 work items per launch -- fine enough that the last items end together, coarse
+             * enough that claiming them does not show (measured on 1080p, scripts/frame_group_sweep.py: Cornell x 64 frames best
+             * at G = 8-16 on the whole frame and 2-4 on an eighth of it; 870 k triangles x 16 frames best at G = 2-4) */
             const uint64_t regions = std::max<uint64_t>(1, tb_persistent_grid(W, H, c->tiles));
-            const uint32_t frames = std::min(batch, n), wantGroups = (uint32_t)std::min<uint64_t>((8192 + regions - 1) / regions, std::max(1u, frames / 4));
-            const uint32_t autoG = (frames + wantGroups - 1) / wantGroups;
-            tg.samples = (TbFloat4*)c->wfSamples.p; tg.frameGroup = fg > 0 ? (uint32_t)fg : autoG;
+            const uint32_t frames = std::min(batch, n);
+            const uint32_t autoG = (uint32_t)std::min<uint64_t>(frames, std::max<uint64_t>(1, ((uint64_t)frames * regions + 49151) / 49152));
+            ensure(c->workCounter, 512);
+            tg.samples = (TbFloat4*)c->wfSamples.p; tg.frameGroup = fg > 0 ? (uint32_t)fg : autoG; tg.workCounter = (uint32_t*)c->workCounter.p;
             for (uint32_t f0 = 0; f0 < n; f0 += batch) {
                 const uint32_t nf = std::min(batch, n - f0);
                 HIP_TRY(v->fn(c->stream, &c->ds, &pf, &tg, W, H, c->samplesRendered + f0, nf, &c->tiles, c->sceneInLds ? 1 : 0, 0, 0));

@@ -35,6 +35,18 @@ __device__ __forceinline__ bool block_region(const TbTileMap& tiles, uint32_t W,
     return true;
 }
 
+/* Frame-group mode of pt_persistent: work items come from 8 interleaved lists (item = 8 * count + list), a workgroup starting
+ * at list blockIdx % 8 and moving on when a list is empty -- one counter for the whole device would serialise every claim on a
+ * single address.  Out of line: it runs once per few thousand samples and must not cost the path loop any registers. */
+__device__ __noinline__ uint32_t claim_work_item(uint32_t* counters, uint32_t totalItems)
+{
+    for (uint32_t t = 0; t < 8; t++) {
+        const uint32_t q = (blockIdx.x + t) & 7u, item = atomicAdd(counters + q * 16u, 1u) * 8u + q;
+        if (item < totalItems) return item;
+    }
+    return 0xffffffffu;
+}
+
 __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v)
 {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);

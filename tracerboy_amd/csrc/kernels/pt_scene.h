@@ -60,12 +60,13 @@ struct TbDeviceTargets {
     TbFloat4* aovEmissive; /* u7 */
     uint32_t* stats;       /* u10: [0]=ActiveWaves(groups) [1]=ActivePixels [2]=SelectedPixelDistance [3]=SelectedMaterialID */
     unsigned long long* rayStats; /* 7 x u64 (TbRayStats), nullable */
-    /* Frame-group mode (nullable): with `samples` set a workgroup renders its 16x16 region for frameGroup consecutive
-     * frames only and writes every finished sample to samples[(frame - firstFrame) * W * H + pixel] as
-     * (rgb*w, +-w; sign bit = jitter coin < 0.5); accumulate_samples_kernel then sums them in frame order, which keeps
-     * the fp32 accumulation of RayGenCommon.h:704-727 bit for bit while the launch has numFrames/frameGroup times more
-     * workgroups to balance (needed when a rank of the tile split owns only ~1000 regions). */
-    TbFloat4* samples; uint32_t frameGroup;
+    /* Frame-group mode (nullable): with `samples` set the launch is a resident grid whose workgroups draw work items
+     * (16x16 region x frameGroup consecutive frames) from *workCounter and whose lanes draw (pixel, frame) pairs of the
+     * workgroup's items from a counter in LDS (pt_persistent.inc); every finished sample is written to
+     * samples[(frame - firstFrame) * W * H + pixel] as (rgb*w, +-w; sign bit = jitter coin < 0.5) and
+     * accumulate_samples_kernel then sums them in frame order, which keeps the fp32 accumulation of RayGenCommon.h:704-727
+     * bit for bit while no lane waits for its neighbours' longer paths. */
+    TbFloat4* samples; uint32_t frameGroup; uint32_t* workCounter;
 };
 
 struct TbTileMap { /* multi-GPU tile ownership: tile t is rendered iff t % world == rank; tileW, tileH multiples of 16 */
