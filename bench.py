@@ -46,8 +46,10 @@ def pmc_traffic_bytes(args, world):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", key + "_pmc_summary.json")))
     if not files:
         return None
+    import re
     for name, passes in json.load(open(files[-1])).items():
-        if ", true>(" in name:   # pt_persistent<F, LDS, COUNT = true>: the counters-on launch, not the timed kernel
+        # pt_persistent<F, LDS, COUNT, GROUPS>: not the counters-on launch (COUNT = true), not the sample fold
+        if "pt_persistent" not in name or re.search(r"pt_persistent<\d+u, (true|false), true", name):
             continue
         if "fetch" in passes and "write" in passes:
             return int((2.0 * passes["fetch"]["FETCH_SIZE"] + passes["write"]["WRITE_SIZE"]) * 1024)
@@ -113,8 +115,12 @@ def main():
     from tracerboy_amd import tiles
     owned = tb.OwnedPixels(W, H)
     # equal-sized slices: every rank pads to the largest owner (rank 0) so ONE gather per render suffices
-    packed = torch.zeros((max(tiles.packed_capacity(W, H, world, TILE, TILE), 1), 4), dtype=torch.float32, device="cuda")
-    gather_list = [torch.zeros_like(packed) for _ in range(world)] if (world > 1 and rank == 0) else None
+    # two packed buffers: the gather of one render runs on RCCL's stream while the next render traces, and a buffer is packed
+    # again only after the gather that read it (two renders ago) has finished
+    packed = [torch.zeros((max(tiles.packed_capacity(W, H, world, TILE, TILE), 1), 4), dtype=torch.float32, device="cuda") for _ in range(2)]
+    gather_list = [torch.zeros_like(packed[0]) for _ in range(world)] if (world > 1 and rank == 0) else None
+    in_flight = [None, None]
+    renders = [0]
     torch.cuda.synchronize()
 
     kernel_ms = []
@@ -124,8 +130,11 @@ def main():
         tb.Render(W, H, SPP, s, 0.0)          # synchronous; GPU time measured with HIP events on the library's stream
         kernel_ms.append(tb.GetOption("last_kernel_us") / 1e3)  # the render's (first) path-tracing launch, without the sample fold
         if world > 1:
-            tb.PackOwnedTo(packed.data_ptr())     # device-to-device, synchronous on the library's stream
-            tiles.gather_to_rank0(packed, rank, world, gather_list)
+            b = renders[0] & 1; renders[0] += 1
+            if in_flight[b] is not None:
+                in_flight[b].wait(); torch.cuda.current_stream().synchronize()
+            tb.PackOwnedTo(packed[b].data_ptr())     # device-to-device, synchronous on the library's stream
+            in_flight[b] = dist.gather(packed[b], gather_list if rank == 0 else None, dst=0, async_op=True)
 
     def barrier():
         if world > 1:
@@ -172,7 +181,7 @@ def main():
             "avg_launch_ms": round(avg_ms, 3), "algorithmic_bytes_per_sample": round(bytes_per_sample, 1),
             "boxes_per_sample": round(st.boxesTested / max(st.samples, 1), 2), "tris_per_sample": round(st.trianglesTested / max(st.samples, 1), 2),
             "rays_per_sample": round(st.rays / max(st.samples, 1), 3),
-            "note": ("scene image is LDS-resident: algorithmic bytes are served by LDS, HBM only sees the accumulation surfaces"
+            "note": ("scene image is LDS-resident: algorithmic bytes are served by LDS, HBM only sees the sample buffer / accumulation surfaces"
                      if tb.GetOption("scene_in_lds_active") else "BVH fetched from L2/MALL/HBM"),
         }
         # ---- CPU baseline: the scalar oracle on a bounded sample of the same workload ------------------
