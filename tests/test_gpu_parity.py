@@ -494,6 +494,31 @@ def test_full_size_properties_c2(gpu_tb, settings):
     assert 0.05 < mean[0] < 1.0 and mean[0] > mean[1] > mean[2]  # warm light: R > G > B
 
 
+@pytest.mark.parametrize("scene", ["cornell", "proc"])
+def test_full_size_frame_groups_equal_one_pixel_per_lane(gpu_tb, settings, scene):
+    """The bench workloads in full (1920x1080; cornell 64 spp depth 8 from LDS, 200 k triangles 16 spp depth 6 from global
+    memory): the frame-group launch (resident grid, work items claimed through the device counters, sample buffer + ordered
+    fold) gives the bits of the one-pixel-per-lane launch over the whole frame, and an 8-row strip of it is the oracle's."""
+    W, H = 1920, 1080
+    s = copy.copy(settings)
+    if scene == "cornell":
+        gpu_tb.LoadScene(CORNELL); s.MaxBounces = 8; F = 64
+    else:
+        gpu_tb.LoadProcedural(0, 200000, 1234); s.MaxBounces = 6; F = 16
+    gpu_tb.InvalidateHistory(); gpu_tb.Render(W, H, F, s, 0.0)
+    groups, groups_jit = gpu_tb.ReadAccumulation(jittered=True)
+    gpu_tb.SetOption("frame_group", -1)
+    try:
+        gpu_tb.InvalidateHistory(); gpu_tb.Render(W, H, F, s, 0.0)
+        classic, classic_jit = gpu_tb.ReadAccumulation(jittered=True)
+    finally:
+        gpu_tb.SetOption("frame_group", 0)
+    assert np.all(groups[..., 3] == float(F))
+    assert np.array_equal(bits(groups), bits(classic)) and np.array_equal(bits(groups_jit), bits(classic_jit))
+    ref = ol.render(gpu_tb.HostSceneView(), gpu_tb.FrameConstants(W, H, 0, s, 0.0), W, H, F, y0=536, y1=544, threads=8)["output"]
+    assert np.array_equal(bits(groups[536:544]), bits(ref[536:544]))
+
+
 def test_material_edit_and_errors(gpu_tb, settings):
     from tracerboy_amd import api
     gpu_tb.LoadScene(CORNELL)
