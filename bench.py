@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--pipeline", type=int, default=0)  # 0 = lock-step bounce (fastest measured), 1 = streaming (resumable BVH walk)
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=INT")  # extra tb_set_option()s, applied before the scene is loaded
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--async-steps", action="store_true")  # run the N > 1 step pipeline (async render + pack + stream-ordered consumer) on one GPU
     ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
     args = ap.parse_args()
 
@@ -119,22 +120,38 @@ def main():
     # again only after the gather that read it (two renders ago) has finished
     packed = [torch.zeros((max(tiles.packed_capacity(W, H, world, TILE, TILE), 1), 4), dtype=torch.float32, device="cuda") for _ in range(2)]
     gather_list = [torch.zeros_like(packed[0]) for _ in range(world)] if (world > 1 and rank == 0) else None
+    scratch = torch.zeros_like(packed[0]) if (world == 1 and args.async_steps) else None
     in_flight = [None, None]
     renders = [0]
     torch.cuda.synchronize()
 
     kernel_ms = []
 
+    # N > 1 (and --async-steps): nothing in a step blocks the host -- the render and the pack are enqueued on the library's
+    # stream, the gather on RCCL's, ordered by stream waits -- so host-side launch gaps do not idle the GPU between renders
+    pipelined = world > 1 or args.async_steps
+    lib_stream = torch.cuda.ExternalStream(tb.Stream()) if pipelined else None
+
+    def exchange(buf):
+        if world > 1:
+            return dist.gather(buf, gather_list if rank == 0 else None, dst=0, async_op=True)
+        scratch.copy_(buf, non_blocking=True)   # --async-steps on one GPU: a stand-in consumer on torch's stream
+        return None
+
     def step():
         tb.InvalidateHistory()
-        tb.Render(W, H, SPP, s, 0.0)          # synchronous; GPU time measured with HIP events on the library's stream
-        kernel_ms.append(tb.GetOption("last_kernel_us") / 1e3)  # the render's (first) path-tracing launch, without the sample fold
-        if world > 1:
-            b = renders[0] & 1; renders[0] += 1
-            if in_flight[b] is not None:
-                in_flight[b].wait(); torch.cuda.current_stream().synchronize()
-            tb.PackOwnedTo(packed[b].data_ptr())     # device-to-device, synchronous on the library's stream
-            in_flight[b] = dist.gather(packed[b], gather_list if rank == 0 else None, dst=0, async_op=True)
+        if not pipelined:
+            tb.Render(W, H, SPP, s, 0.0)          # synchronous; GPU time measured with HIP events on the library's stream
+            kernel_ms.append(tb.GetOption("last_kernel_us") / 1e3)  # the render's (first) path-tracing launch, without the sample fold
+            return
+        b = renders[0] & 1; renders[0] += 1
+        tb.Render(W, H, SPP, s, 0.0, sync=False)
+        if in_flight[b] is not None:
+            in_flight[b].wait()                                   # torch's stream waits for the gather that last read packed[b] ...
+        lib_stream.wait_stream(torch.cuda.current_stream())     # ... and the library's stream waits for torch's
+        tb.PackOwnedTo(packed[b].data_ptr(), sync=False)
+        torch.cuda.current_stream().wait_stream(lib_stream)     # the gather reads what the library's stream packed
+        in_flight[b] = exchange(packed[b])
 
     def barrier():
         if world > 1:
@@ -150,6 +167,8 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
+    if pipelined:
+        tb.Sync(); kernel_ms.append(tb.GetOption("last_kernel_us") / 1e3)   # HIP events of the last render of the timed region
     if world > 1:
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX); elapsed = float(t.item())
 

@@ -185,6 +185,11 @@ int tb_set_tile_assignment(tb_context* ctx, uint32_t rank, uint32_t world, uint3
  * the tile), RGBA32F.  count = number of pixels written; buffer must hold tb_owned_pixels(). */
 uint64_t tb_owned_pixels(tb_context* ctx, uint32_t width, uint32_t height);
 int tb_pack_owned_device(tb_context* ctx, void* device_dst);   /* device-to-device pack on the context stream */
+int tb_pack_owned_device_async(tb_context* ctx, void* device_dst);   /* same, returns after enqueueing (pair with tb_sync or order through tb_stream) */
+/* The context's HIP stream (a hipStream_t), for callers that order their own device work against the library's without
+ * blocking the host -- e.g. an RCCL gather of the packed tiles after tb_render_async + tb_pack_owned_device_async
+ * (torch.cuda.ExternalStream(tb_stream(ctx)) on the Python side).  Owned by the context. */
+void* tb_stream(tb_context* ctx);
 int tb_unpack_gathered_host(uint32_t width, uint32_t height, uint32_t world, uint32_t tile_w, uint32_t tile_h,
                             const float* const* per_rank_packed, float* full_rgba);
 

@@ -77,6 +77,8 @@ def lib():
         "tb_set_tile_assignment": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
         "tb_owned_pixels": (C.c_uint64, [vp, C.c_uint32, C.c_uint32]),
         "tb_pack_owned_device": (C.c_int, [vp, vp]),
+        "tb_pack_owned_device_async": (C.c_int, [vp, vp]),
+        "tb_stream": (vp, [vp]),
         "tb_unpack_gathered_host": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, P(vp), vp]),
         "tb_set_option": (C.c_int, [vp, C.c_char_p, C.c_int64]),
         "tb_get_option": (C.c_int64, [vp, C.c_char_p]),
@@ -364,8 +366,13 @@ class TracerBoy:
     def OwnedPixels(self, width, height):
         return int(self._L.tb_owned_pixels(self._ctx, width, height))
 
-    def PackOwnedTo(self, device_ptr):
-        self._check(self._L.tb_pack_owned_device(self._ctx, C.c_void_p(device_ptr)))
+    def PackOwnedTo(self, device_ptr, sync=True):
+        fn = self._L.tb_pack_owned_device if sync else self._L.tb_pack_owned_device_async
+        self._check(fn(self._ctx, C.c_void_p(device_ptr)))
+
+    def Stream(self):
+        """the context's hipStream_t as an integer (torch.cuda.ExternalStream(tb.Stream()))"""
+        return int(self._L.tb_stream(self._ctx) or 0)
 
     # -- misc -----------------------------------------------------------------------------------
     def SetOption(self, name, value):

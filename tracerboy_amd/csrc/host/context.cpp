@@ -490,11 +490,12 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
             }
         }
     }
+    if (!c->lastKernelFrames) { HIP_TRY(hipEventRecord(c->evKernel, c->stream)); c->lastKernelFrames = n; } /* one launch (or one pipeline) for the whole call */
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
     c->samplesRendered += n;
     if (sync) {
         HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipEventElapsedTime(&c->lastMs, c->ev0, c->ev1));
-        if (c->lastKernelFrames) HIP_TRY(hipEventElapsedTime(&c->lastKernelMs, c->ev0, c->evKernel)); else { c->lastKernelMs = c->lastMs; c->lastKernelFrames = n; }
+        HIP_TRY(hipEventElapsedTime(&c->lastKernelMs, c->ev0, c->evKernel));
     }
     return TB_OK;
 }
@@ -617,7 +618,11 @@ int tb_render(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_output
 int tb_render_async(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_output_settings* s, float t) { return guarded(c, [&]() { c->lastRenderRealtime = false; return renderImpl(c, W, H, n, s, t, false); }); }
 int tb_sync(tb_context* c)
 {
-    return guarded(c, [&]() { HIP_TRY(hipStreamSynchronize(c->stream)); (void)hipEventElapsedTime(&c->lastMs, c->ev0, c->ev1); return TB_OK; });
+    return guarded(c, [&]() {
+        HIP_TRY(hipStreamSynchronize(c->stream)); (void)hipEventElapsedTime(&c->lastMs, c->ev0, c->ev1);
+        if (hipEventElapsedTime(&c->lastKernelMs, c->ev0, c->evKernel) != hipSuccess) c->lastKernelMs = c->lastMs;
+        return TB_OK;
+    });
 }
 
 int tb_read_accum(tb_context* c, float* rgba, float* jit)
@@ -847,6 +852,17 @@ int tb_pack_owned_device(tb_context* c, void* dst)
         return TB_OK;
     });
 }
+
+int tb_pack_owned_device_async(tb_context* c, void* dst)
+{
+    return guarded(c, [&]() {
+        if (!dst || !c->output.p) return fail(c, TB_E_INVALID, "tb_pack_owned_device_async: nothing rendered / null destination");
+        HIP_TRY(pt_launch_pack_owned(c->stream, (const TbFloat4*)c->output.p, (TbFloat4*)dst, c->width, c->height, &c->tiles, ownedTiles(c->width, c->height, c->tiles)));
+        return TB_OK;
+    });
+}
+
+void* tb_stream(tb_context* c) { return c ? (void*)c->stream : nullptr; }
 
 int tb_unpack_gathered_host(uint32_t W, uint32_t H, uint32_t world, uint32_t tw, uint32_t th, const float* const* perRank, float* full)
 {
