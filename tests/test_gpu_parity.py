@@ -456,6 +456,26 @@ def test_frame_group_default_and_classic_agree(gpu_tb, settings):
         assert np.array_equal(bits(jit), bits(ref["jittered"]))
 
 
+def test_async_calls_overlap_and_stay_ordered(gpu_tb, settings):
+    """Back-to-back tb_render_async calls: the path-tracing launches alternate between the context's two side streams (each
+    may start while the one before drains) but the folds stay in order on the main stream -- progressive accumulation over
+    three calls, several sample-buffer batches each, is the oracle's image; with overlap_launches = 0 as well."""
+    gpu_tb.LoadScene(CORNELL)
+    W, H = 200, 120
+    ref = _oracle(gpu_tb, W, H, 8 + 9 + 10, settings, jittered=True)
+    for overlap in (1, 0):
+        gpu_tb.SetOption("overlap_launches", overlap); gpu_tb.SetOption("pooled_samples", W * H * 4)
+        try:
+            gpu_tb.InvalidateHistory()
+            for n in (8, 9, 10):
+                gpu_tb.Render(W, H, n, settings, 0.0, sync=False)
+            gpu_tb.Sync()
+            out, jit = gpu_tb.ReadAccumulation(jittered=True)
+        finally:
+            gpu_tb.SetOption("overlap_launches", 1); gpu_tb.SetOption("pooled_samples", 256 << 20)
+        assert np.array_equal(bits(out), bits(ref["output"])) and np.array_equal(bits(jit), bits(ref["jittered"]))
+
+
 def test_tile_split_reproduces_the_single_gpu_image(gpu_tb, settings):
     """Multi-GPU partition on one device: every rank's tiles, packed and un-permuted, give the same bits."""
     from tracerboy_amd import api

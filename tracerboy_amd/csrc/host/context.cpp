@@ -63,7 +63,13 @@ struct DevBuf {
 struct tb_context {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, evKernel = nullptr; /* evKernel: end of the render's first path-tracing launch */
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, evKernelStart = nullptr, evKernel = nullptr; /* evKernelStart..evKernel: the render's first path-tracing launch */
+    /* frame-group launches alternate between two side streams and two sample buffers: launch k+1 starts while the last paths
+     * of launch k drain; the folds stay on `stream`, in order (renderImpl) */
+    hipStream_t side[2] = {nullptr, nullptr};
+    hipEvent_t evPt[2] = {nullptr, nullptr}, evFold[2] = {nullptr, nullptr}, evMain = nullptr;
+    DevBuf fgSamples[2];
+    uint32_t fgLaunch = 0; bool sideOrdered = false; /* sideOrdered: the side streams have been ordered after everything else on `stream` */
     uint32_t lastKernelFrames = 0; float lastKernelMs = 0.0f;
     std::string err;
     HostScene scene; bool hasScene = false;
@@ -436,7 +442,7 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
     const bool aov = opt("aov", 0) != 0, count = opt("count_rays", 0) != 0;
     c->ds.alphaTest = opt("alpha_test", 0) ? 1u : 0u;
     ensure(c->stats, 16);
-    if (c->samplesRendered == 0) HIP_TRY(hipMemsetAsync(c->stats.p, 0, 16, c->stream));
+    const bool clearStats = c->samplesRendered == 0; /* enqueued below, on the stream of the first path-tracing launch */
     TbDeviceTargets tg; memset(&tg, 0, sizeof tg);
     tg.output = (TbFloat4*)c->output.p; tg.jittered = (TbFloat4*)c->jittered.p; tg.stats = (uint32_t*)c->stats.p;
     if (aov) {
@@ -457,7 +463,15 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
     const int variantIndex = (int)(v - kVariants);
     const bool wavefront = opt("pipeline", 0) == 2 && variantIndex <= 2 && !count && !aov;
     const bool pooled = opt("pipeline", 0) == 3 && variantIndex <= 2 && !count && !aov;
+    const int64_t fg = opt("frame_group", 0);
+    const bool groups = !wavefront && !pooled && opt("pipeline", 0) == 0 && !count && !aov && !s.RenderModeRealTime && fg >= 0 && (fg > 0 || n >= 8);
+    /* launches of the kernels without the EXT features (no selected pixel, no AOVs: nothing but the sample buffer is written)
+     * may overlap the drain of the launch before them */
+    const bool overlap = groups && variantIndex != 4 && opt("overlap_launches", 1) != 0;
+    if (!overlap) c->sideOrdered = false;
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    if (clearStats && !overlap) HIP_TRY(hipMemsetAsync(c->stats.p, 0, 16, c->stream));
+    if (!groups) HIP_TRY(hipEventRecord(c->evKernelStart, c->stream));
     c->lastKernelFrames = 0;
     if (wavefront) renderWavefront(c, variantIndex, W, H, c->samplesRendered, n, pf);
     else if (pooled) renderPooled(c, variantIndex, W, H, c->samplesRendered, n, pf);
@@ -467,26 +481,35 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
          * to an ordered sample buffer and accumulate_samples_kernel folds them in frame order (bit-identical sums).  Keeps all
          * lanes of a workgroup busy to its end and gives a rank of a tile split enough workgroups; on whenever a call renders
          * enough frames to form groups.  Option "frame_group" = G > 0 forces the group size, < 0 forbids the mode. */
-        const int64_t fg = opt("frame_group", 0);
-        const bool groups = opt("pipeline", 0) == 0 && !count && !aov && !s.RenderModeRealTime && fg >= 0 && (fg > 0 || n >= 8);
         if (!groups) HIP_TRY(v->fn(c->stream, &c->ds, &pf, &tg, W, H, c->samplesRendered, n, &c->tiles, c->sceneInLds ? 1 : 0, count ? 1 : 0, (int)opt("pipeline", 0)));
         else {
             const uint64_t pixels = (uint64_t)W * H, budget = (uint64_t)opt("pooled_samples", 256ll << 20);
             const uint32_t batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n, budget / pixels));
-            ensure(c->wfSamples, pixels * batch * 16);
             /* automatic group size: about 49 152 work items per launch -- fine enough that the last items end together, coarse
              * enough that claiming them does not show (measured on 1080p, scripts/frame_group_sweep.py: Cornell x 64 frames best
              * at G = 8-16 on the whole frame and 2-4 on an eighth of it; 870 k triangles x 16 frames best at G = 2-4) */
             const uint64_t regions = std::max<uint64_t>(1, tb_persistent_grid(W, H, c->tiles));
             const uint32_t frames = std::min(batch, n);
             const uint32_t autoG = (uint32_t)std::min<uint64_t>(frames, std::max<uint64_t>(1, ((uint64_t)frames * regions + 49151) / 49152));
-            ensure(c->workCounter, 512);
-            tg.samples = (TbFloat4*)c->wfSamples.p; tg.frameGroup = fg > 0 ? (uint32_t)fg : autoG; tg.workCounter = (uint32_t*)c->workCounter.p;
+            ensure(c->workCounter, 1024);
+            tg.frameGroup = fg > 0 ? (uint32_t)fg : autoG;
+            if (overlap && !c->sideOrdered) { /* first overlapped launch after other work on the main stream: order the side streams behind it once */
+                HIP_TRY(hipEventRecord(c->evMain, c->stream));
+                for (int i = 0; i < 2; i++) HIP_TRY(hipStreamWaitEvent(c->side[i], c->evMain, 0));
+                c->sideOrdered = true;
+            }
             for (uint32_t f0 = 0; f0 < n; f0 += batch) {
-                const uint32_t nf = std::min(batch, n - f0);
-                HIP_TRY(v->fn(c->stream, &c->ds, &pf, &tg, W, H, c->samplesRendered + f0, nf, &c->tiles, c->sceneInLds ? 1 : 0, 0, 0));
-                if (f0 == 0) { HIP_TRY(hipEventRecord(c->evKernel, c->stream)); c->lastKernelFrames = nf; }
+                const uint32_t nf = std::min(batch, n - f0), par = c->fgLaunch++ & 1u;
+                hipStream_t ptStream = overlap ? c->side[par] : c->stream;
+                if (c->fgSamples[par].bytes < pixels * batch * 16) ensure(c->fgSamples[par], pixels * batch * 16); /* grow-only */
+                tg.samples = (TbFloat4*)c->fgSamples[par].p; tg.workCounter = (uint32_t*)c->workCounter.p + par * 128u;
+                if (overlap) HIP_TRY(hipStreamWaitEvent(ptStream, c->evFold[par], 0)); /* the fold that last read this sample buffer */
+                if (f0 == 0) { if (clearStats && overlap) HIP_TRY(hipMemsetAsync(c->stats.p, 0, 16, ptStream)); HIP_TRY(hipEventRecord(c->evKernelStart, ptStream)); }
+                HIP_TRY(v->fn(ptStream, &c->ds, &pf, &tg, W, H, c->samplesRendered + f0, nf, &c->tiles, c->sceneInLds ? 1 : 0, 0, 0));
+                if (f0 == 0) { HIP_TRY(hipEventRecord(c->evKernel, ptStream)); c->lastKernelFrames = nf; }
+                if (overlap) { HIP_TRY(hipEventRecord(c->evPt[par], ptStream)); HIP_TRY(hipStreamWaitEvent(c->stream, c->evPt[par], 0)); }
                 HIP_TRY(pt_launch_accumulate_samples(c->stream, tg.samples, W, H, c->samplesRendered + f0, nf, &c->tiles, tg.output, tg.jittered));
+                if (overlap) HIP_TRY(hipEventRecord(c->evFold[par], c->stream));
             }
         }
     }
@@ -495,7 +518,7 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
     c->samplesRendered += n;
     if (sync) {
         HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipEventElapsedTime(&c->lastMs, c->ev0, c->ev1));
-        HIP_TRY(hipEventElapsedTime(&c->lastKernelMs, c->ev0, c->evKernel));
+        HIP_TRY(hipEventElapsedTime(&c->lastKernelMs, c->evKernelStart, c->evKernel));
     }
     return TB_OK;
 }
@@ -517,7 +540,12 @@ int tb_create(tb_context** out, int device_id)
     try {
         HIP_TRY(hipSetDevice(device_id));
         HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-        HIP_TRY(hipEventCreate(&c->ev0)); HIP_TRY(hipEventCreate(&c->ev1)); HIP_TRY(hipEventCreate(&c->evKernel));
+        HIP_TRY(hipEventCreate(&c->ev0)); HIP_TRY(hipEventCreate(&c->ev1)); HIP_TRY(hipEventCreate(&c->evKernel)); HIP_TRY(hipEventCreate(&c->evKernelStart));
+        HIP_TRY(hipEventCreateWithFlags(&c->evMain, hipEventDisableTiming));
+        for (int i = 0; i < 2; i++) {
+            HIP_TRY(hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&c->evPt[i], hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&c->evFold[i], hipEventDisableTiming));
+        }
     } catch (const std::exception& ex) { g_createError = ex.what(); delete c; return TB_E_DEVICE; }
     *out = c;
     return TB_OK;
@@ -532,7 +560,7 @@ void tb_destroy(tb_context* c)
     c->output.release(); c->jittered.release(); c->stats.release(); c->rayStats.release(); c->packed.release();
     for (int q = 0; q < 2; q++) for (DevBuf& b : c->wfCols[q]) b.release();
     for (DevBuf& b : c->wfShadowCols) b.release();
-    c->wfHitA.release(); c->wfHitG.release(); c->wfSamples.release(); c->wfCounts.release();
+    c->wfHitA.release(); c->wfHitG.release(); c->wfSamples.release(); c->wfCounts.release(); c->workCounter.release(); c->fgSamples[0].release(); c->fgSamples[1].release();
     c->postOut.release(); c->postRgba8.release(); c->postHistogram.release(); c->postAverage.release();
     for (int i = 0; i < 2; i++) { c->rtIndirect[i].release(); c->rtMoment[i].release(); c->rtFinal[i].release(); c->rtDenoise[i].release(); }
     c->rtComposited.release();
@@ -540,6 +568,13 @@ void tb_destroy(tb_context* c)
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->evKernel) (void)hipEventDestroy(c->evKernel);
+    if (c->evKernelStart) (void)hipEventDestroy(c->evKernelStart);
+    if (c->evMain) (void)hipEventDestroy(c->evMain);
+    for (int i = 0; i < 2; i++) {
+        if (c->evPt[i]) (void)hipEventDestroy(c->evPt[i]);
+        if (c->evFold[i]) (void)hipEventDestroy(c->evFold[i]);
+        if (c->side[i]) { (void)hipStreamSynchronize(c->side[i]); (void)hipStreamDestroy(c->side[i]); }
+    }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -620,7 +655,7 @@ int tb_sync(tb_context* c)
 {
     return guarded(c, [&]() {
         HIP_TRY(hipStreamSynchronize(c->stream)); (void)hipEventElapsedTime(&c->lastMs, c->ev0, c->ev1);
-        if (hipEventElapsedTime(&c->lastKernelMs, c->ev0, c->evKernel) != hipSuccess) c->lastKernelMs = c->lastMs;
+        if (hipEventElapsedTime(&c->lastKernelMs, c->evKernelStart, c->evKernel) != hipSuccess) c->lastKernelMs = c->lastMs;
         return TB_OK;
     });
 }
@@ -881,7 +916,7 @@ int tb_unpack_gathered_host(uint32_t W, uint32_t H, uint32_t world, uint32_t tw,
 int tb_set_option(tb_context* c, const char* name, int64_t v)
 {
     if (!c || !name) return TB_E_INVALID;
-    static const char* known[] = {"pipeline", "count_rays", "bvh_builder", "flatten_instances", "aov", "scene_in_lds", "lds_scene_budget", "force_full_variant", "wavefront_paths", "wavefront_grid", "wavefront_segment", "pooled_paths", "pooled_samples", "pooled_profile", "park_min", "alpha_test", "node_order", "node_order_top_levels", "frame_group"};
+    static const char* known[] = {"pipeline", "count_rays", "bvh_builder", "flatten_instances", "aov", "scene_in_lds", "lds_scene_budget", "force_full_variant", "wavefront_paths", "wavefront_grid", "wavefront_segment", "pooled_paths", "pooled_samples", "pooled_profile", "park_min", "alpha_test", "node_order", "node_order_top_levels", "frame_group", "overlap_launches"};
     for (const char* k : known) if (!strcmp(k, name)) { c->options[name] = v; if (!strcmp(name, "count_rays") || !strcmp(name, "aov")) c->samplesRendered = 0; return TB_OK; }
     return fail(c, TB_E_INVALID, std::string("unknown option '") + name + "'");
 }
