@@ -148,6 +148,28 @@ def test_sah_builder_is_valid_and_cheaper(built):
     assert np.array_equal(ha["t"], hb["t"])
 
 
+def test_reinsertion_passes_keep_the_tree_valid_and_cut_box_tests(built, monkeypatch):
+    """The SAH builder's reinsertion passes (bvh_build.cpp, optimizeByReinsertion) only move subtrees: the result is still
+    a tree the reference's validator accepts, it is no deeper than the traversal stack allows, finds the same surfaces,
+    and a path-traced frame tests fewer boxes than with the passes turned off."""
+    from tracerboy_amd import api
+    s = api.GetDefaultOutputSettings(); s.EnableBlueNoise = 0; s.MaxBounces = 3
+    for make in (lambda: api.HostScene(CORNELL, bvh_builder=1), lambda: api.HostScene(procedural=(0, 6000, 1234), bvh_builder=1)):
+        monkeypatch.setenv("TB_REINSERT_PASSES", "0")
+        plain = make()
+        monkeypatch.delenv("TB_REINSERT_PASSES")
+        opt = make()
+        tri = opt.triangles()
+        assert np.array_equal(tri["positions"], plain.triangles()["positions"])
+        rc, depth = ol.validate_bvh(opt.bvh_bytes(), tri)
+        assert rc == 0 and depth == opt.info().bvhMaxDepth and depth <= 35 + 1
+        assert not np.array_equal(opt.bvh_bytes(), plain.bvh_bytes())
+        ra = ol.render(plain.view(), plain.frame_constants(s), 48, 32, 1, stats=True)
+        rb = ol.render(opt.view(), opt.frame_constants(s), 48, 32, 1, stats=True)
+        assert rb["stats"].boxesTested < ra["stats"].boxesTested
+        assert np.array_equal(ra["output"], rb["output"])
+
+
 def test_layout_b_is_the_same_tree_as_layout_a(cornell_host):
     nodes, tris, root = cornell_host.layout_b()
     bvh = cornell_host.bvh_bytes()
