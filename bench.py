@@ -66,7 +66,7 @@ def main():
     ap.add_argument("--spp", type=int, default=64)
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--scene", default="cornell-box")  # or proc0:<tris> / proc1:<tris> / proc2:<tris> / path.pbrt
-    ap.add_argument("--builder", type=int, default=1)  # 0 = LBVH (fallback-layer semantics), 1 = binned SAH
+    ap.add_argument("--builder", type=int, default=1)  # 0 LBVH, 1 binned SAH + reinsertion, 2 LBVH on the GPU, 3 LBVH + treelet passes (the reference's tree), 4 the same on the GPU
     ap.add_argument("--pipeline", type=int, default=0)  # 0 = lock-step bounce (fastest measured), 1 = streaming (resumable BVH walk)
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=INT")  # extra tb_set_option()s, applied before the scene is loaded
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -179,7 +179,7 @@ def main():
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s %dx%d %dspp depth%d" % (args.scene, W, H, SPP, args.depth), "triangles": int(info.numTriangles),
-                   "bvh_builder": "lbvh" if args.builder == 0 else "sah", "pipeline": ("lockstep", "stream", "wavefront", "pooled")[args.pipeline], "tile": TILE if world > 1 else None,
+                   "bvh_builder": ("lbvh", "sah", "lbvh-gpu", "lbvh+treelets", "lbvh+treelets-gpu")[args.builder], "pipeline": ("lockstep", "stream", "wavefront", "pooled")[args.pipeline], "tile": TILE if world > 1 else None,
                    "parallelism": "tiles%d" % world, "scene_in_lds": bool(tb.GetOption("scene_in_lds_active")),
                    "kernel_variant": ["matte", "env", "surf", "vol", "full"][tb.GetOption("last_variant")], "scene_load_s": round(load_s, 3)},
     }

@@ -195,7 +195,8 @@ int tb_unpack_gathered_host(uint32_t width, uint32_t height, uint32_t world, uin
 
 /* Tunables / instrumentation: "pipeline" (0 = lock-step-bounce persistent kernel [default, fastest measured],
  * 1 = streaming persistent kernel with a resumable BVH walk),
- * "count_rays" (0/1), "bvh_builder" (0 = LBVH as the reference, 1 = binned SAH), "flatten_instances". */
+ * "count_rays" (0/1), "bvh_builder" (0 = LBVH, 1 = binned SAH + reinsertion passes, 2 = LBVH built on the GPU, 3 = LBVH + the fallback layer's
+ * three treelet passes = the tree the reference's PREFER_FAST_TRACE build traverses, 4 = the same built on the GPU), "flatten_instances". */
 int tb_set_option(tb_context* ctx, const char* name, int64_t value);
 int64_t tb_get_option(tb_context* ctx, const char* name);
 

@@ -13,7 +13,13 @@
  *   AABB fit              ComputeAABBs.hlsli:69-172, RayTracingHelper.hlsli:229-285
  *                         (smaller subtree on the left; on equal counts the reference's result
  *                         depends on which thread arrives second -- this build keeps Karras order)
- * Not restated: TreeletReorder (3 passes, n = 7) -- see DESIGN.md "BVH quality".
+ *   treelet passes        ClearBuffers.hlsl, FindTreelets.hlsl:27-88, TreeletReorder.hlsl:38-311, TreeletReorder.cpp:38-109,
+ *                         TreeletReorderBindings.h:50-111 (Karras & Aila 2013, treelets of 7 leaves; 3 passes with
+ *                         MinTrianglesPerTreelet 7, 14, 28 for PREFER_FAST_TRACE, which TracerBoy.cpp:1970 asks for).
+ *                         Run between the hierarchy and the fit when treeletPasses > 0 (tbo_build_lbvh2).  The one
+ *                         race in the reference that can change the result is fixed by rule: a group gives up after
+ *                         33 treelets (`while (i++ < 32)`, TreeletReorder.hlsl:288-310) and which of two groups meeting
+ *                         at a node goes on is whichever arrives second; here the one that has done fewer goes on.
  */
 #include "tb_oracle.h"
 #include "../include/tb_vec.h"
@@ -67,8 +73,124 @@ inline Box AABBtoBox(tb3 mn, tb3 mx)
 
 } // namespace
 
-extern "C" int64_t tbo_build_lbvh(const float* positions, const uint32_t* triVertexIndex, const uint32_t* triGeometry,
-                                  const uint32_t* triPrimitive, const uint32_t* triFlags, uint32_t N, uint8_t* out, uint64_t capacity)
+/* ---- treelet reordering ------------------------------------------------------------------------------------------ */
+namespace {
+
+struct AABB { tb3 mn, mx; };
+inline AABB CombineAABB(const AABB& a, const AABB& b) { AABB r; r.mn = tb3_min(a.mn, b.mn); r.mx = tb3_max(a.mx, b.mx); return r; } /* TreeletReorderBindings.h:104-110 */
+inline float ComputeBoxSurfaceArea(const AABB& a) /* TreeletReorderBindings.h:98-102 */
+{
+    tb3 dim = a.mx - a.mn;
+    return 2.0f * (dim.x * dim.y + dim.x * dim.z + dim.y * dim.z);
+}
+
+const uint32_t FullTreeletSize = 7, NumInternalTreeletNodes = 6, NumTreeletSplitPermutations = 128, FullPartitionMask = 127;
+
+struct Treelets {
+    uint32_t N;
+    std::vector<uint32_t>&left, &right, &parent;
+    std::vector<AABB> aabb; /* AABBBuffer: every node */
+    bool isLeaf(uint32_t x) const { return x >= N - 1; }
+    uint32_t& L(uint32_t x) { return left[x]; }
+    uint32_t& R(uint32_t x) { return right[x]; }
+
+    /* one trip of TreeletReorder.hlsl main's loop body for the treelet rooted at nodeIndex (without TraverseToParent) */
+    void reorder(uint32_t nodeIndex)
+    {
+        uint32_t treeletToReorder[FullTreeletSize], internalNodes[NumInternalTreeletNodes];
+        float optimalCost[NumTreeletSplitPermutations]; uint32_t optimalPartition[NumTreeletSplitPermutations];
+        /* FormTreelet :38-80: grow from the root's two children by opening the node of largest surface area */
+        internalNodes[0] = nodeIndex;
+        treeletToReorder[0] = L(nodeIndex); treeletToReorder[1] = R(nodeIndex);
+        for (uint32_t treeletSize = 2; treeletSize < FullTreeletSize; treeletSize++) {
+            float largestSurfaceArea = 0.0f; uint32_t nodeIndexToTraverse = 0, indexOfNodeIndexToTraverse = 0;
+            for (uint32_t i = 0; i < treeletSize; i++) {
+                uint32_t treeletNodeIndex = treeletToReorder[i];
+                if (!isLeaf(treeletNodeIndex)) {
+                    float surfaceArea = ComputeBoxSurfaceArea(aabb[treeletNodeIndex]);
+                    if (surfaceArea > largestSurfaceArea) { largestSurfaceArea = surfaceArea; nodeIndexToTraverse = treeletNodeIndex; indexOfNodeIndexToTraverse = i; }
+                }
+            }
+            internalNodes[treeletSize - 1] = nodeIndexToTraverse;
+            treeletToReorder[indexOfNodeIndexToTraverse] = L(nodeIndexToTraverse);
+            treeletToReorder[treeletSize] = R(nodeIndexToTraverse);
+        }
+        /* FindOptimalPartitions :82-172.  Surface area of every subset's box first (:96-118) ... */
+        for (uint32_t treeletBitmask = 1; treeletBitmask < NumTreeletSplitPermutations; treeletBitmask++) {
+            AABB box; box.mn = tb3_splat(3.402823466e+38f); box.mx = tb3_splat(-3.402823466e+38f);
+            for (uint32_t i = 0; i < FullTreeletSize; i++) if ((1u << i) & treeletBitmask) box = CombineAABB(box, aabb[treeletToReorder[i]]);
+            optimalCost[treeletBitmask] = ComputeBoxSurfaceArea(box);
+        }
+        /* ... single leaves cost their area relative to the treelet root's (:121-127, CalculateCost :22-26) ... */
+        float rootAABBSurfaceArea = ComputeBoxSurfaceArea(aabb[nodeIndex]);
+        for (uint32_t i = 0; i < FullTreeletSize; i++) optimalCost[1u << i] = 1.0f * ComputeBoxSurfaceArea(aabb[treeletToReorder[i]]) / rootAABBSurfaceArea;
+        /* ... then subsets by growing size: best split into two smaller subsets (:131-171) */
+        for (uint32_t subsetSize = 2; subsetSize <= FullTreeletSize; subsetSize++) {
+            for (uint32_t treeletBitmask = 1; treeletBitmask < NumTreeletSplitPermutations; treeletBitmask++) {
+                if ((uint32_t)__builtin_popcount(treeletBitmask) != subsetSize) continue;
+                float lowestCost = 3.402823466e+38f; uint32_t bestPartition = 0;
+                uint32_t delta = (treeletBitmask - 1) & treeletBitmask;
+                uint32_t partitionBitmask = (0u - delta) & treeletBitmask;
+                do {
+                    const float cost = optimalCost[partitionBitmask] + optimalCost[treeletBitmask ^ partitionBitmask];
+                    if (cost < lowestCost) { lowestCost = cost; bestPartition = partitionBitmask; }
+                    partitionBitmask = (partitionBitmask - delta) & treeletBitmask;
+                } while (partitionBitmask != 0);
+                optimalCost[treeletBitmask] = 1.0f * optimalCost[treeletBitmask] + lowestCost;
+                optimalPartition[treeletBitmask] = bestPartition;
+            }
+        }
+        /* ReformTree :174-233 */
+        struct PartitionEntry { uint32_t Mask, NodeIndex; };
+        uint32_t nodesAllocated = 1, partitionStackSize = 1;
+        PartitionEntry partitionStack[FullTreeletSize];
+        partitionStack[0].Mask = FullPartitionMask; partitionStack[0].NodeIndex = internalNodes[0];
+        while (partitionStackSize > 0) {
+            PartitionEntry partition = partitionStack[--partitionStackSize];
+            PartitionEntry leftEntry; leftEntry.Mask = optimalPartition[partition.Mask];
+            if (__builtin_popcount(leftEntry.Mask) > 1) { leftEntry.NodeIndex = internalNodes[nodesAllocated++]; partitionStack[partitionStackSize++] = leftEntry; }
+            else leftEntry.NodeIndex = treeletToReorder[__builtin_ctz(leftEntry.Mask)];
+            PartitionEntry rightEntry; rightEntry.Mask = partition.Mask ^ leftEntry.Mask;
+            if (__builtin_popcount(rightEntry.Mask) > 1) { rightEntry.NodeIndex = internalNodes[nodesAllocated++]; partitionStack[partitionStackSize++] = rightEntry; }
+            else rightEntry.NodeIndex = treeletToReorder[__builtin_ctz(rightEntry.Mask)];
+            L(partition.NodeIndex) = leftEntry.NodeIndex; R(partition.NodeIndex) = rightEntry.NodeIndex;
+            parent[leftEntry.NodeIndex] = partition.NodeIndex; parent[rightEntry.NodeIndex] = partition.NodeIndex;
+        }
+        for (int j = (int)NumInternalTreeletNodes - 1; j >= 0; j--) { uint32_t n = internalNodes[j]; aabb[n] = CombineAABB(aabb[L(n)], aabb[R(n)]); }
+    }
+
+    /* ClearBuffers + FindTreelets + TreeletReorder dispatches of one pass, serially: children before parents */
+    void pass(uint32_t minTrianglesPerTreelet, const std::vector<AABB>& leafBox)
+    {
+        const uint32_t numNodes = 2 * N - 1;
+        std::vector<uint32_t> order; order.reserve(numNodes);
+        { std::vector<uint32_t> st; st.push_back(0);
+          while (!st.empty()) { uint32_t x = st.back(); st.pop_back(); order.push_back(x); if (!isLeaf(x)) { st.push_back(L(x)); st.push_back(R(x)); } }
+          std::reverse(order.begin(), order.end()); }
+        std::vector<uint32_t> numTriangles(numNodes, 0), trips(numNodes, 0); /* trips: how many treelets the group standing on a node has done */
+        for (uint32_t x : order) {
+            if (isLeaf(x)) { aabb[x] = leafBox[x - (N - 1)]; numTriangles[x] = 1; continue; } /* FindTreelets.hlsl:44-48 */
+            const uint32_t l = L(x), r = R(x);
+            aabb[x] = CombineAABB(aabb[l], aabb[r]); /* FindTreelets.hlsl:50-55, TreeletReorder.hlsl:258-262 */
+            numTriangles[x] = numTriangles[l] + numTriangles[r];
+            if (numTriangles[x] < minTrianglesPerTreelet) continue;
+            const bool lBig = numTriangles[l] >= minTrianglesPerTreelet, rBig = numTriangles[r] >= minTrianglesPerTreelet;
+            if (!lBig && !rBig) trips[x] = 1; /* a base treelet, FindTreelets.hlsl:61-67 */
+            else { /* reached by climbing groups, TreeletReorder.hlsl:235-268: every big child must have sent one */
+                uint32_t fewest = 0xffffffffu; bool all = true;
+                if (lBig) { if (trips[l] == 0) all = false; else fewest = std::min(fewest, trips[l]); }
+                if (rBig) { if (trips[r] == 0) all = false; else fewest = std::min(fewest, trips[r]); }
+                if (all && fewest < 33) trips[x] = fewest + 1;
+            }
+            if (trips[x]) reorder(x);
+        }
+    }
+};
+
+} // namespace
+
+static int64_t build_lbvh_impl(const float* positions, const uint32_t* triVertexIndex, const uint32_t* triGeometry,
+                                  const uint32_t* triPrimitive, const uint32_t* triFlags, uint32_t N, uint32_t treeletPasses, uint8_t* out, uint64_t capacity)
 {
     if (N == 0) return -1;
     const uint64_t numNodes = 2ull * N - 1;
@@ -128,6 +250,26 @@ extern "C" int64_t tbo_build_lbvh(const float* positions, const uint32_t* triVer
         uint32_t c = (split + 1 == last) ? leafOff + (uint32_t)split + 1 : (uint32_t)split + 1;
         left[(size_t)idx] = a; right[(size_t)idx] = c;
         parent[a] = (uint32_t)idx; parent[c] = (uint32_t)idx;
+    }
+
+    /* TreeletReorder::Optimize, TreeletReorder.cpp:38-109 */
+    if (treeletPasses > 0 && N >= FullTreeletSize) {
+        std::vector<AABB> leafBox(N);
+        for (uint32_t k = 0; k < N; k++) { /* FindTreelets.hlsl:14-27: the leaf's centre/half-extent box turned back into min/max */
+            uint32_t t = keyed[k].second;
+            tb3 v0 = vert(t, 0), v1 = vert(t, 1), v2 = vert(t, 2);
+            tb3 mn = tb3_min(tb3_min(v0, v1), v2), mx = tb3_max(tb3_max(v0, v1), v2);
+            mn = tb3_min(mn, mx - tb3_splat(0.001f));
+            Box bx = AABBtoBox(mn, mx);
+            leafBox[k].mn = bx.center - bx.halfDim; leafBox[k].mx = bx.center + bx.halfDim; /* RayTracingHelper.hlsli:237-243 */
+        }
+        Treelets tr{N, left, right, parent, std::vector<AABB>((size_t)numNodes)};
+        uint32_t minTrianglesPerTreelet = FullTreeletSize;
+        for (uint32_t i = 0; i < treeletPasses; i++) {
+            if (minTrianglesPerTreelet > N) break;
+            tr.pass(minTrianglesPerTreelet, leafBox);
+            minTrianglesPerTreelet *= 2;
+        }
     }
 
     memset(out, 0, (size_t)total);
@@ -192,6 +334,18 @@ extern "C" int64_t tbo_build_lbvh(const float* positions, const uint32_t* triVer
         }
     }
     return (int64_t)total;
+}
+
+extern "C" int64_t tbo_build_lbvh(const float* positions, const uint32_t* triVertexIndex, const uint32_t* triGeometry,
+                                  const uint32_t* triPrimitive, const uint32_t* triFlags, uint32_t N, uint8_t* out, uint64_t capacity)
+{
+    return build_lbvh_impl(positions, triVertexIndex, triGeometry, triPrimitive, triFlags, N, 0, out, capacity);
+}
+
+extern "C" int64_t tbo_build_lbvh2(const float* positions, const uint32_t* triVertexIndex, const uint32_t* triGeometry,
+                                   const uint32_t* triPrimitive, const uint32_t* triFlags, uint32_t N, uint32_t treeletPasses, uint8_t* out, uint64_t capacity)
+{
+    return build_lbvh_impl(positions, triVertexIndex, triGeometry, triPrimitive, triFlags, N, treeletPasses, out, capacity);
 }
 
 /* BVHValidator.cpp:60-190 restated as invariants checked in one pass:

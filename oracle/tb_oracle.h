@@ -80,6 +80,12 @@ int64_t tbo_build_lbvh(const float* positions /*3 per vertex, already world spac
                        const uint32_t* triGeometry, const uint32_t* triPrimitive,
                        const uint32_t* triFlags, uint32_t numTriangles, uint8_t* out, uint64_t capacity);
 
+/* The same with the fallback layer's treelet passes (TreeletReorder.cpp:38-109) between hierarchy and fit;
+ * treeletPasses = 3 is the tree a PREFER_FAST_TRACE build gives the software traversal. */
+int64_t tbo_build_lbvh2(const float* positions, const uint32_t* triVertexIndex, const uint32_t* triGeometry,
+                        const uint32_t* triPrimitive, const uint32_t* triFlags, uint32_t numTriangles,
+                        uint32_t treeletPasses, uint8_t* out, uint64_t capacity);
+
 /* BVHValidator restatement (BVHValidator.cpp:60-190): 0 if valid, else a negative code. */
 int tbo_validate_bvh(const uint8_t* bvh, uint32_t bvhBytes, const float* positions,
                      const uint32_t* triVertexIndex, uint32_t numTriangles, uint32_t* maxDepth);

@@ -59,6 +59,8 @@ def lib():
                                      C.POINTER(C.c_float * 3), C.POINTER(C.c_float * 3)]
         L.tbo_build_lbvh.restype = C.c_int64
         L.tbo_build_lbvh.argtypes = [vp, vp, vp, vp, vp, C.c_uint32, vp, C.c_uint64]
+        L.tbo_build_lbvh2.restype = C.c_int64
+        L.tbo_build_lbvh2.argtypes = [vp, vp, vp, vp, vp, C.c_uint32, C.c_uint32, vp, C.c_uint64]
         L.tbo_validate_bvh.restype = C.c_int
         L.tbo_validate_bvh.argtypes = [vp, C.c_uint32, vp, vp, C.c_uint32, C.POINTER(C.c_uint32)]
         _lib = L
@@ -150,13 +152,13 @@ def trace_closest(view, origins, dirs):
     return r
 
 
-def build_lbvh(tri):
+def build_lbvh(tri, treelet_passes=0):
     n = tri["tri_geometry"].shape[0]
     cap = 16 + 32 * (2 * n - 1) + 52 * n
     out = np.zeros(cap, np.uint8)
     pos = np.ascontiguousarray(tri["positions"], np.float32); tvi = np.ascontiguousarray(tri["tri_vertex_index"], np.uint32)
     g = np.ascontiguousarray(tri["tri_geometry"], np.uint32); p = np.ascontiguousarray(tri["tri_primitive"], np.uint32); f = np.ascontiguousarray(tri["tri_flags"], np.uint32)
-    got = lib().tbo_build_lbvh(_p(pos), _p(tvi), _p(g), _p(p), _p(f), n, _p(out), cap)
+    got = lib().tbo_build_lbvh2(_p(pos), _p(tvi), _p(g), _p(p), _p(f), n, treelet_passes, _p(out), cap)
     assert got == cap, got
     return out
 

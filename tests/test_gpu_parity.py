@@ -352,6 +352,49 @@ def test_gpu_lbvh_build_equals_host_build(gpu_tb, settings, scene):
         gpu_tb.SetOption("bvh_builder", 0)
 
 
+@pytest.mark.parametrize("scene", ["cornell", "teapot", "proc0", "proc2", "deep"])
+def test_gpu_treelet_build_equals_host_build(gpu_tb, settings, scene):
+    """Row f3: LBVH + the fallback layer's three treelet passes (TreeletReorder.hlsl, FindTreelets.hlsl) built on the GPU
+    (option bvh_builder = 4: one wave per climbing group) is byte-identical to host builder 3 (itself checked against
+    oracle/bvh_ref.cpp), run twice to show that the result does not depend on which group reaches a node first; same
+    depth, same picture, and fewer box tests than the plain LBVH."""
+    from tracerboy_amd import api
+    import ctypes as C
+
+    def load(tb):
+        if scene == "cornell": tb.LoadScene(CORNELL)
+        elif scene == "teapot": tb.LoadScene(TEAPOT)
+        elif scene == "proc0": tb.LoadProcedural(0, 200000, 5)
+        elif scene == "proc2": tb.LoadProcedural(2, 40000, 9)
+        else: tb.LoadProcedural(1, 700000, 3)   # deep tree: long climbs, many meeting groups
+
+    def image(tb):
+        v = tb.HostSceneView()
+        return np.ctypeslib.as_array(C.cast(v.bvh, C.POINTER(C.c_uint8)), shape=(v.bvhBytes,)).copy()
+
+    W, H, F = 96, 64, 2
+    try:
+        gpu_tb.SetOption("bvh_builder", 0); load(gpu_tb)
+        plain = image(gpu_tb)
+        gpu_tb.SetOption("count_rays", 1); gpu_tb.Render(W, H, 1, settings, 0.0); boxes_plain = gpu_tb.ReadbackStats().rays.boxesTested
+        gpu_tb.SetOption("count_rays", 0); gpu_tb.InvalidateHistory()
+        gpu_tb.Render(W, H, F, settings, 0.0); a = gpu_tb.ReadAccumulation()
+        gpu_tb.SetOption("bvh_builder", 3); load(gpu_tb)
+        host_img, host_depth = image(gpu_tb), gpu_tb.SceneInfo().bvhMaxDepth
+        assert not np.array_equal(host_img, plain)
+        for _ in range(2):
+            gpu_tb.SetOption("bvh_builder", 4); load(gpu_tb)
+            dev_img = image(gpu_tb)
+            assert dev_img.shape == host_img.shape and np.array_equal(dev_img, host_img)
+            assert gpu_tb.SceneInfo().bvhMaxDepth == host_depth
+        gpu_tb.Render(W, H, F, settings, 0.0)
+        assert np.array_equal(bits(a), bits(gpu_tb.ReadAccumulation()))
+        gpu_tb.SetOption("count_rays", 1); gpu_tb.InvalidateHistory(); gpu_tb.Render(W, H, 1, settings, 0.0)
+        assert gpu_tb.ReadbackStats().rays.boxesTested < boxes_plain
+    finally:
+        gpu_tb.SetOption("bvh_builder", 0); gpu_tb.SetOption("count_rays", 0)
+
+
 def test_alpha_tested_geometry_bit_exact(gpu_tb, settings):
     """Rows a12 / f1: the IsValidHit alpha test (SharedHitGroup.h:157-179) as a filter on candidate hits of non-opaque
     geometry, on a card textured with a PNG that has transparent texels.  Off (the reference's software path compiles
@@ -402,7 +445,7 @@ WorldEnd
     p = tmp_path / "tiny.pbrt"; p.write_text(scene)
     W, H, F = 48, 32, 2
     try:
-        for builder in (0, 1, 2):
+        for builder in (0, 1, 2, 3, 4):
             gpu_tb.SetOption("bvh_builder", builder)
             gpu_tb.LoadScene(str(p))
             assert gpu_tb.SceneInfo().numTriangles == triangles

@@ -9,6 +9,10 @@
  * builder 1 ("SAH"): top-down 32-bin surface-area-heuristic build in the spirit of the reference's
  *   unused CpuBVH2Builder.cpp:249-516; same node numbering (inner 0..N-2, leaf N-1+k), same box
  *   arithmetic, so both layouts and the traversal code are shared.
+ * builder 3 ("LBVH + treelets"): builder 0 followed by the fallback layer's treelet passes before the fit -- the tree a
+ *   PREFER_FAST_TRACE bottom-level build (TracerBoy.cpp:1970) hands to SoftwareRayTraceCS: three passes over treelets of
+ *   seven leaves with MinTrianglesPerTreelet 7, 14, 28 (TreeletReorder.cpp:38-109, TreeletReorder.hlsl:38-311,
+ *   FindTreelets.hlsl:27-88).  Checked bit-for-bit against oracle/bvh_ref.cpp; builder 4 is the same on the GPU.
  * Both emit layout A (the fallback layer's memory image, used by the CPU checker and exported through
  * tb_host_scene_view) and layout B (what the kernels fetch, tb_abi.h).
  */
@@ -239,6 +243,92 @@ void optimizeByReinsertion(const HostScene& s, Tree& t, int maxPasses, double mi
     }
 }
 
+/* ---- treelet passes (builder 3) -------------------------------------------------------------------------------------
+ * Karras & Aila 2013 as the fallback layer runs it.  A pass starts at the lowest nodes that hold at least `minTris`
+ * triangles and climbs; at every node on the way the 7-leaf treelet below it (grown by opening the largest box) is
+ * rebuilt as the binary tree of least cost over all 2^7 leaf subsets, the six inner node ids being reused.  Cost of a
+ * subset = area of its box + least cost of a split into two subsets; a single leaf costs area / root area
+ * (TreeletReorder.hlsl:22-26,121-127,158-168 -- mixed units, kept as they are).  Boxes are min/max of exact inputs, so
+ * the subset boxes here come from a running union (box[m] = box[m without its lowest leaf] U that leaf) instead of the
+ * reference's seven-way loop: same bits.  A climbing group of the reference stops after 33 treelets and, where two
+ * groups meet, the second to arrive goes on; the rule here (and in oracle/bvh_ref.cpp and bvh_kernels.hip): the group
+ * that has done fewer treelets goes on. */
+struct TreeletPass {
+    const uint32_t N; std::vector<uint32_t>&left, &right;
+    std::vector<Bounds> box;
+    static float sarea(const Bounds& b) { const tb3 d = b.mx - b.mn; return 2.0f * (d.x * d.y + d.x * d.z + d.y * d.z); }
+    bool leaf(uint32_t x) const { return x >= N - 1; }
+
+    void rebuild(uint32_t root)
+    {
+        uint32_t leafNode[7], inner[6]; Bounds sub[128]; float cost[128]; uint8_t cut[128];
+        inner[0] = root; leafNode[0] = left[root]; leafNode[1] = right[root];
+        for (uint32_t n = 2; n < 7; n++) { /* open the inner node with the largest box */
+            float best = 0.0f; uint32_t at = 0, node = 0;
+            for (uint32_t i = 0; i < n; i++) if (!leaf(leafNode[i])) { const float a = sarea(box[leafNode[i]]); if (a > best) { best = a; at = i; node = leafNode[i]; } }
+            inner[n - 1] = node; leafNode[at] = left[node]; leafNode[n] = right[node];
+        }
+        const float rootArea = sarea(box[root]);
+        for (uint32_t m = 1; m < 128; m++) {
+            const uint32_t low = (uint32_t)__builtin_ctz(m), rest = m & (m - 1);
+            sub[m] = box[leafNode[low]]; if (rest) grow(sub[m], sub[rest]);
+            cost[m] = rest ? sarea(sub[m]) : sarea(sub[m]) / rootArea;
+        }
+        static uint8_t bySize[8][35]; static uint8_t sizeCount[8]; static bool tables = false;
+        if (!tables) { for (uint32_t m = 1; m < 128; m++) { const int k = __builtin_popcount(m); bySize[k][sizeCount[k]++] = (uint8_t)m; } tables = true; }
+        for (int k = 2; k <= 7; k++) for (uint32_t q = 0; q < sizeCount[k]; q++) {
+            const uint32_t m = bySize[k][q], d = (m - 1) & m;
+            float least = 3.402823466e+38f; uint32_t arg = 0;
+            uint32_t p = (0u - d) & m;
+            do { const float c = cost[p] + cost[m ^ p]; if (c < least) { least = c; arg = p; } p = (p - d) & m; } while (p);
+            cost[m] += least; cut[m] = (uint8_t)arg;
+        }
+        /* hand the inner ids out again: parent first, left child's id before the right child's, right subtree first */
+        uint32_t used = 1; struct Todo { uint32_t mask, node; } todo[7]; uint32_t n = 0; todo[n++] = {127u, root};
+        while (n) {
+            const Todo t = todo[--n];
+            const uint32_t lm = cut[t.mask], rm = t.mask ^ lm; uint32_t ln, rn;
+            if (lm & (lm - 1)) { ln = inner[used++]; todo[n++] = {lm, ln}; } else ln = leafNode[__builtin_ctz(lm)];
+            if (rm & (rm - 1)) { rn = inner[used++]; todo[n++] = {rm, rn}; } else rn = leafNode[__builtin_ctz(rm)];
+            left[t.node] = ln; right[t.node] = rn;
+        }
+        for (int j = 5; j >= 0; j--) { const uint32_t x = inner[j]; box[x] = box[left[x]]; grow(box[x], box[right[x]]); }
+    }
+
+    void run(uint32_t minTris, const std::vector<Bounds>& leafBox)
+    {
+        const uint32_t M = 2 * N - 1;
+        std::vector<uint32_t> pre; pre.reserve(M); { std::vector<uint32_t> st(1, 0u); while (!st.empty()) { const uint32_t x = st.back(); st.pop_back(); pre.push_back(x); if (!leaf(x)) { st.push_back(left[x]); st.push_back(right[x]); } } }
+        std::vector<uint32_t> tris(M, 0); std::vector<uint8_t> done(M, 0); /* done: treelets rebuilt by the group standing here, 0 = nobody came */
+        for (size_t w = pre.size(); w-- > 0;) {
+            const uint32_t x = pre[w];
+            if (leaf(x)) { box[x] = leafBox[x - (N - 1)]; tris[x] = 1; continue; }
+            const uint32_t l = left[x], r = right[x];
+            box[x] = box[l]; grow(box[x], box[r]); tris[x] = tris[l] + tris[r];
+            if (tris[x] < minTris) continue;
+            uint32_t fewest = 0xffu; bool everyGroupCame = true, anyBig = false;
+            for (uint32_t c : {l, r}) if (tris[c] >= minTris) { anyBig = true; if (!done[c]) everyGroupCame = false; else fewest = std::min<uint32_t>(fewest, done[c]); }
+            if (!anyBig) done[x] = 1; else if (everyGroupCame && fewest < 33) done[x] = (uint8_t)(fewest + 1);
+            if (done[x]) rebuild(x);
+        }
+    }
+};
+
+void treeletPasses(const HostScene& s, Tree& t, uint32_t passes)
+{
+    const uint32_t N = t.N; if (N < 7) return;
+    std::vector<Bounds> leafBox(N);
+    for (uint32_t k = 0; k < N; k++) { /* the leaf's centre / half-extent box turned back into min / max (FindTreelets.hlsl:14-27) */
+        Bounds b = emptyB(); for (int v = 0; v < 3; v++) grow(b, P(s, t.order[k], v));
+        b.mn = tb3_min(b.mn, b.mx - tb3_splat(0.001f));
+        const tb3 c = (b.mn + b.mx) * 0.5f, h = b.mx - c;
+        leafBox[k].mn = c - h; leafBox[k].mx = c + h;
+    }
+    TreeletPass tp{N, t.left, t.right, std::vector<Bounds>(2 * (size_t)N - 1)};
+    uint32_t minTris = 7;
+    for (uint32_t i = 0; i < passes && minTris <= N; i++, minTris *= 2) tp.run(minTris, leafBox);
+}
+
 } // namespace
 
 void BuildBvh(HostScene& s, int builder)
@@ -254,7 +344,10 @@ void BuildBvh(HostScene& s, int builder)
         const char* cap = getenv("TB_REINSERT_PASSES"); /* experiments: 0 turns the passes off */
         const int passes = cap ? atoi(cap) : (N <= 4096 ? 16 : 3);
         if (passes > 0) optimizeByReinsertion(s, t, passes, N <= 4096 ? 1e-6 : 5e-3);
-    } else buildLbvh(s, t);
+    } else {
+        buildLbvh(s, t);
+        if (builder == 3) treeletPasses(s, t, 3);
+    }
 
     const uint64_t numNodes = 2ull * N - 1;
     const uint64_t offBoxes = 16, offPrims = offBoxes + 32 * numNodes, offMeta = offPrims + 40ull * N, total = offMeta + 12ull * N;

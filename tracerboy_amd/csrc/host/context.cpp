@@ -210,9 +210,10 @@ void reorderNodes(HostScene& s, int order_, uint32_t topLevels)
     s.rootRefB = 0;
 }
 
-/* option "bvh_builder" = 2: the LBVH of builder 0 constructed on the GPU (bvh_kernels.hip); the host copies are filled
+/* option "bvh_builder" = 2 / 4: the LBVH of builder 0 / the LBVH + treelet passes of builder 3 constructed on the GPU
+ * (bvh_kernels.hip); the host copies are filled
  * from the device result so that every host-side consumer (oracle view, layout queries) sees the same tree */
-void BuildBvhGpu(tb_context* c, HostScene& s)
+void BuildBvhGpu(tb_context* c, HostScene& s, uint32_t treeletPasses)
 {
     const uint64_t N64 = s.triGeometry.size();
     if (N64 == 0) throw std::runtime_error("BuildBvh: no triangles");
@@ -230,7 +231,7 @@ void BuildBvhGpu(tb_context* c, HostScene& s)
         ensure(dA, total); ensure(dNodes, nB * sizeof(TbNodeB)); ensure(dTris, (size_t)N * sizeof(TbTriB)); ensure(dScratch, scratchBytes); ensure(dHeight, 4);
         HIP_TRY(hipMemsetAsync(dNodes.p, 0, nB * sizeof(TbNodeB), c->stream));
         HIP_TRY(bvh_gpu_build(c->stream, (const float*)dPos.p, (const uint32_t*)dIdx.p, (const uint32_t*)dGeo.p, (const uint32_t*)dPrim.p, (const uint32_t*)dFlag.p, N,
-                              (uint8_t*)dScratch.p, scratchBytes, (uint8_t*)dA.p, (TbNodeB*)dNodes.p, (TbTriB*)dTris.p, (uint32_t*)dHeight.p));
+                              treeletPasses, (uint8_t*)dScratch.p, scratchBytes, (uint8_t*)dA.p, (TbNodeB*)dNodes.p, (TbTriB*)dTris.p, (uint32_t*)dHeight.p));
         s.bvhA.resize((size_t)total); s.nodesB.resize(nB); s.trisB.resize(N);
         HIP_TRY(hipMemcpy(s.bvhA.data(), dA.p, total, hipMemcpyDeviceToHost));
         HIP_TRY(hipMemcpy(s.nodesB.data(), dNodes.p, nB * sizeof(TbNodeB), hipMemcpyDeviceToHost));
@@ -248,7 +249,8 @@ void finalizeScene(tb_context* c)
 {
     HostScene& s = c->scene;
     auto opt = [&](const char* k, int64_t d) { auto it = c->options.find(k); return it == c->options.end() ? d : it->second; };
-    if (opt("bvh_builder", 0) == 2) BuildBvhGpu(c, s); else BuildBvh(s, (int)opt("bvh_builder", 0));
+    const int64_t builder = opt("bvh_builder", 0);
+    if (builder == 2 || builder == 4) BuildBvhGpu(c, s, builder == 4 ? 3u : 0u); else BuildBvh(s, (int)builder);
     reorderNodes(s, (int)opt("node_order", 2), (uint32_t)opt("node_order_top_levels", 10)); /* measured on the 870 k scene: 0 -> 2258, 1 -> 2283, 2 (10 levels) -> 2300 Msamples/s */
     c->camera = s.camera;
     releaseScene(c);

@@ -5,6 +5,9 @@
  *   bvh_morton      30-bit Morton code of the centroid (y,x,z interleave)         CalculateMortonCodesBindings.h:116-149
  *   rocprim sort    64-bit key = code << 32 | triangle index (ties by index)      BitonicSort in the reference
  *   bvh_hierarchy   Karras-2012 split search, one lane per inner node             BuildBVHSplits.hlsli:33-131
+ *   bvh_treelet_*   (treeletPasses > 0, option "bvh_builder" = 4) the fallback layer's treelet passes, one wave per
+ *                   climbing group, byte-identical to host builder 3                ClearBuffers.hlsl, FindTreelets.hlsl:27-88,
+ *                                                                                   TreeletReorder.hlsl:38-311, TreeletReorder.cpp:38-109
  *   bvh_fit         leaves (1 triangle, 0.001 thin-box padding), then bottom-up:  RayTracingHelper.hlsli:251-263,
  *                   the second lane to reach a node fits it, smaller subtree left ComputeAABBs.hlsli:152-156
  * Output: the reference's bottom-level memory image (layout A: header, 32-B nodes, 40-B primitives, 12-B metadata) plus
@@ -91,6 +94,169 @@ __global__ __launch_bounds__(BLOCK) void bvh_hierarchy(const unsigned long long*
     left[i] = lc; right[i] = rc; parent[lc] = (uint32_t)i; parent[rc] = (uint32_t)i;
 }
 
+/* ---- treelet passes (Karras & Aila 2013 as the fallback layer runs it; host twin: bvh_build.cpp TreeletPass) ------------
+ * Per pass: bvh_treelet_find = one lane per leaf climbs, writes min/max boxes, counts triangles per node and lists the lowest
+ * nodes that hold >= minTris triangles; bvh_treelet_reorder = one wave per listed node: lane 0 grows the 7-leaf treelet below
+ * the node, the 64 lanes price the 127 leaf subsets (2 per lane, subset sizes in turn), lane 0 rewires the six inner nodes
+ * and climbs to the parent, where the second group to arrive goes on.  The reference's groups stop after 33 treelets and which
+ * of two meeting groups goes on is a race there; here each group leaves its count at the meeting node and the smaller count
+ * is carried on (the rule of the host builder and the oracle), so the tree does not depend on timing.
+ * Cross-wave visibility: plain stores, __threadfence(), then the atomic that announces the arrival; the group that is let
+ * through fences again before it reads (agent-scope fences write back / invalidate the per-XCD L2). */
+struct TbBox6 { float mn[3], mx[3]; };
+
+__device__ __forceinline__ float box_area(const TbBox6& b)
+{
+    const float dx = b.mx[0] - b.mn[0], dy = b.mx[1] - b.mn[1], dz = b.mx[2] - b.mn[2];
+    return 2.0f * (dx * dy + dx * dz + dy * dz);
+}
+__device__ __forceinline__ TbBox6 box_union(const TbBox6& a, const TbBox6& b)
+{
+    TbBox6 r;
+    for (int k = 0; k < 3; k++) { r.mn[k] = tb_min(a.mn[k], b.mn[k]); r.mx[k] = tb_max(a.mx[k], b.mx[k]); }
+    return r;
+}
+__device__ __forceinline__ TbBox6 box_load(const TbBox6* boxes, uint32_t i)
+{
+    const volatile float* p = (const volatile float*)(boxes + i);
+    TbBox6 r; for (int k = 0; k < 3; k++) { r.mn[k] = p[k]; r.mx[k] = p[3 + k]; }
+    return r;
+}
+__device__ __forceinline__ void box_store(TbBox6* boxes, uint32_t i, const TbBox6& b)
+{
+    volatile float* p = (volatile float*)(boxes + i);
+    for (int k = 0; k < 3; k++) { p[k] = b.mn[k]; p[3 + k] = b.mx[k]; }
+}
+__device__ __forceinline__ uint32_t vload(const uint32_t* p) { return *(const volatile uint32_t*)p; }
+__device__ __forceinline__ void vstore(uint32_t* p, uint32_t v) { *(volatile uint32_t*)p = v; }
+
+struct TreeletBufs {
+    uint32_t* left; uint32_t* right; uint32_t* parent; /* hierarchy (node ids; leaf k = N-1+k) */
+    TbBox6* boxes;                                      /* min/max box per node */
+    uint32_t* numTris;                                  /* per inner node, zero at the start of a pass */
+    uint32_t* trips;                                    /* per inner node, 0xffffffff at the start of a pass */
+    uint32_t* baseCount; uint32_t* baseList;
+};
+
+__global__ __launch_bounds__(BLOCK) void bvh_treelet_find(const float* positions, const uint32_t* triVertexIndex, const unsigned long long* keys, uint32_t N,
+                                                          uint32_t minTris, TreeletBufs b)
+{
+    const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
+    if (k >= N) return;
+    uint32_t x = (N - 1) + k, tris = 1;
+    {
+        const uint32_t tri = (uint32_t)keys[k];
+        const tb3 v0 = vertex(positions, triVertexIndex, tri, 0), v1 = vertex(positions, triVertexIndex, tri, 1), v2 = vertex(positions, triVertexIndex, tri, 2);
+        tb3 mn = tb3_min(tb3_min(v0, v1), v2); const tb3 mx = tb3_max(tb3_max(v0, v1), v2);
+        mn = tb3_min(mn, mx - tb3_splat(0.001f));
+        const tb3 c = (mn + mx) * 0.5f, h = mx - c, lo = c - h, hi = c + h; /* the leaf's centre / half-extent box turned back into min / max */
+        TbBox6 bx; bx.mn[0] = lo.x; bx.mn[1] = lo.y; bx.mn[2] = lo.z; bx.mx[0] = hi.x; bx.mx[1] = hi.y; bx.mx[2] = hi.z;
+        box_store(b.boxes, x, bx);
+    }
+    for (;;) {
+        if (tris >= minTris) { b.baseList[atomicAdd(b.baseCount, 1u)] = x; return; }
+        const uint32_t up = vload(b.parent + x);
+        __threadfence();
+        const uint32_t other = atomicAdd(&b.numTris[up], tris);
+        if (other == 0u) return;
+        __threadfence();
+        box_store(b.boxes, up, box_union(box_load(b.boxes, vload(b.left + up)), box_load(b.boxes, vload(b.right + up))));
+        x = up; tris += other;
+    }
+}
+
+__global__ __launch_bounds__(64) void bvh_treelet_reorder(uint32_t N, TreeletBufs b)
+{
+    __shared__ uint32_t sNode, sGo;
+    __shared__ uint32_t sLeaf[7], sInner[6];
+    __shared__ TbBox6 sLeafBox[7];
+    __shared__ float sRootArea;
+    __shared__ float sCost[128];
+    __shared__ uint32_t sCut[128];
+    const uint32_t lane = threadIdx.x;
+    if (blockIdx.x >= *b.baseCount) return;
+    if (lane == 0) sNode = b.baseList[blockIdx.x];
+    uint32_t done = 0; /* lane 0: treelets this group has rebuilt */
+    __syncthreads();
+    for (;;) {
+        const uint32_t root = sNode;
+        if (lane == 0) { /* grow the treelet: open the inner node with the largest box, five times */
+            float area[7]; uint32_t node[7];
+            node[0] = vload(b.left + root); node[1] = vload(b.right + root);
+            area[0] = node[0] >= N - 1 ? -1.0f : box_area(box_load(b.boxes, node[0]));
+            area[1] = node[1] >= N - 1 ? -1.0f : box_area(box_load(b.boxes, node[1]));
+            sInner[0] = root;
+            for (uint32_t n = 2; n < 7; n++) {
+                float best = 0.0f; uint32_t at = 0, open = 0;
+                for (uint32_t i = 0; i < n; i++) if (area[i] > best) { best = area[i]; at = i; open = node[i]; }
+                sInner[n - 1] = open;
+                const uint32_t l = vload(b.left + open), r = vload(b.right + open);
+                node[at] = l; area[at] = l >= N - 1 ? -1.0f : box_area(box_load(b.boxes, l));
+                node[n] = r; area[n] = r >= N - 1 ? -1.0f : box_area(box_load(b.boxes, r));
+            }
+            for (int i = 0; i < 7; i++) sLeaf[i] = node[i];
+            sRootArea = box_area(box_load(b.boxes, root));
+        }
+        __syncthreads();
+        if (lane < 7) sLeafBox[lane] = box_load(b.boxes, sLeaf[lane]);
+        __syncthreads();
+        for (uint32_t m = lane; m < 128; m += 64) { /* box area of every leaf subset; a single leaf costs area / root area */
+            if (m == 0) continue;
+            const uint32_t low = (uint32_t)__ffs((int)m) - 1u;
+            TbBox6 u = sLeafBox[low];
+            for (uint32_t i = low + 1; i < 7; i++) if (m & (1u << i)) u = box_union(u, sLeafBox[i]);
+            const float a = box_area(u);
+            sCost[m] = (m & (m - 1)) ? a : a / sRootArea;
+        }
+        __syncthreads();
+        for (int size = 2; size <= 7; size++) { /* least cost of splitting a subset in two, by growing subset size */
+            for (uint32_t m = lane; m < 128; m += 64) {
+                if (__popc(m) != size) continue;
+                const uint32_t d = (m - 1) & m;
+                float least = 3.402823466e+38f; uint32_t arg = 0, p = (0u - d) & m;
+                do { const float c = sCost[p] + sCost[m ^ p]; if (c < least) { least = c; arg = p; } p = (p - d) & m; } while (p);
+                sCost[m] += least; sCut[m] = arg;
+            }
+            __syncthreads();
+        }
+        if (lane == 0) {
+            /* hand the six inner ids out again: parent first, left child's id before the right child's, right subtree first */
+            uint32_t used = 1, n = 0, todoMask[7], todoNode[7];
+            todoMask[n] = 127u; todoNode[n++] = root;
+            while (n) {
+                --n; const uint32_t mask = todoMask[n], node = todoNode[n];
+                const uint32_t lm = sCut[mask], rm = mask ^ lm; uint32_t ln, rn;
+                if (lm & (lm - 1)) { ln = sInner[used++]; todoMask[n] = lm; todoNode[n++] = ln; } else ln = sLeaf[__ffs((int)lm) - 1];
+                if (rm & (rm - 1)) { rn = sInner[used++]; todoMask[n] = rm; todoNode[n++] = rn; } else rn = sLeaf[__ffs((int)rm) - 1];
+                vstore(b.left + node, ln); vstore(b.right + node, rn); vstore(b.parent + ln, node); vstore(b.parent + rn, node);
+            }
+            for (int j = 5; j >= 0; j--) { const uint32_t x = sInner[j]; box_store(b.boxes, x, box_union(box_load(b.boxes, vload(b.left + x)), box_load(b.boxes, vload(b.right + x)))); }
+            done++;
+            /* climb: leave our count and triangles at the parent; whoever finds the sibling's already there goes on */
+            uint32_t go = 0;
+            if (root != 0) {
+                const uint32_t up = vload(b.parent + root), mine = vload(b.numTris + root);
+                atomicMin(&b.trips[up], done);
+                __threadfence();
+                const uint32_t other = atomicAdd(&b.numTris[up], mine);
+                if (other != 0u) {
+                    __threadfence();
+                    const uint32_t fewest = atomicMin(&b.trips[up], done); /* ours is in already: the smaller of the two counts */
+                    if (fewest < 33u) {
+                        done = fewest;
+                        box_store(b.boxes, up, box_union(box_load(b.boxes, vload(b.left + up)), box_load(b.boxes, vload(b.right + up))));
+                        sNode = up; go = 1;
+                    }
+                }
+            }
+            sGo = go;
+        }
+        __syncthreads();
+        if (!sGo) return;
+        __syncthreads();
+    }
+}
+
 struct FitOut {
     TbAabbNode* nodesA; uint8_t* primsA; TbPrimitiveMeta* metaA; /* layout A */
     TbNodeB* nodesB; TbTriB* trisB;                               /* layout B */
@@ -170,6 +336,10 @@ __global__ __launch_bounds__(BLOCK) void bvh_fit(const float* positions, const u
  * 16 + 32(2N-1) + 52N bytes), nodesB N-1 (at least 1) layout-B nodes, trisB N records; rootHeight the tree depth in
  * nodes (= HostScene::bvhMaxDepth).  scratch: bvh_gpu_scratch_bytes(N) bytes. */
 static size_t round256(size_t b) { return (b + 255) / 256 * 256; }
+static size_t treelet_scratch_bytes(uint32_t N)
+{
+    return round256(sizeof(TbBox6) * (2ull * N - 1)) /* boxes */ + 2 * round256(4ull * N) /* numTris, trips */ + round256(4ull * (N / 7 + 2)) /* count + list */;
+}
 extern "C" size_t bvh_gpu_scratch_bytes(uint32_t N)
 {
     size_t sortTmp = 0;
@@ -177,12 +347,12 @@ extern "C" size_t bvh_gpu_scratch_bytes(uint32_t N)
     (void)rocprim::radix_sort_keys(nullptr, sortTmp, nullKeys, nullKeys, (size_t)N, 0, 62, (hipStream_t)0);
     const size_t nodes = 2ull * N - 1;
     return 2 * round256(8ull * N) /* keys in/out */ + 3 * round256(4 * nodes) /* parent, count, height */ + 3 * round256(4ull * N) /* left, right, arrived */
-           + round256(64) /* bounds */ + round256(sortTmp);
+           + round256(64) /* bounds */ + round256(sortTmp) + treelet_scratch_bytes(N);
 }
 
 extern "C" hipError_t bvh_gpu_build(hipStream_t stream, const float* positions, const uint32_t* triVertexIndex, const uint32_t* triGeometry, const uint32_t* triPrimitive,
-                                    const uint32_t* triFlags, uint32_t N, uint8_t* scratch, size_t scratchBytes, uint8_t* bvhA, TbNodeB* nodesB, TbTriB* trisB,
-                                    uint32_t* rootHeight)
+                                    const uint32_t* triFlags, uint32_t N, uint32_t treeletPasses, uint8_t* scratch, size_t scratchBytes, uint8_t* bvhA, TbNodeB* nodesB,
+                                    TbTriB* trisB, uint32_t* rootHeight)
 {
     if (N == 0) return hipErrorInvalidValue;
     const size_t nodes = 2ull * N - 1;
@@ -200,6 +370,10 @@ extern "C" hipError_t bvh_gpu_build(hipStream_t stream, const float* positions, 
     size_t sortTmp = 0;
     BVH_TRY(rocprim::radix_sort_keys(nullptr, sortTmp, keysIn, keysOut, (size_t)N, 0, 62, stream));
     uint8_t* sortScratch = take(sortTmp);
+    TreeletBufs tb;
+    tb.left = left; tb.right = right; tb.parent = parent;
+    tb.boxes = (TbBox6*)take(sizeof(TbBox6) * nodes); tb.numTris = (uint32_t*)take(4ull * N); tb.trips = (uint32_t*)take(4ull * N);
+    tb.baseCount = (uint32_t*)take(4ull * (N / 7 + 2)); tb.baseList = tb.baseCount + 1;
     if ((size_t)(at - scratch) > scratchBytes) return hipErrorInvalidValue;
 
     BVH_TRY(hipMemsetAsync(bounds, 0xff, 12, stream));      /* ordMin = 0xffffffff */
@@ -210,6 +384,14 @@ extern "C" hipError_t bvh_gpu_build(hipStream_t stream, const float* positions, 
     hipLaunchKernelGGL(bvh_morton, dim3(blocksN), dim3(BLOCK), 0, stream, positions, triVertexIndex, N, (const uint32_t*)bounds, (const uint32_t*)(bounds + 4), keysIn);
     BVH_TRY(rocprim::radix_sort_keys(sortScratch, sortTmp, keysIn, keysOut, (size_t)N, 0, 62, stream));
     if (N > 1) hipLaunchKernelGGL(bvh_hierarchy, dim3((N - 1 + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, stream, (const unsigned long long*)keysOut, N, left, right, parent);
+    /* TreeletReorder::Optimize (TreeletReorder.cpp:38-109): MinTrianglesPerTreelet 7, 14, 28 for the three PREFER_FAST_TRACE passes */
+    for (uint32_t pass = 0, minTris = 7; pass < treeletPasses && minTris <= N; pass++, minTris *= 2) {
+        BVH_TRY(hipMemsetAsync(tb.numTris, 0, 4ull * N, stream));
+        BVH_TRY(hipMemsetAsync(tb.trips, 0xff, 4ull * N, stream));
+        BVH_TRY(hipMemsetAsync(tb.baseCount, 0, 4, stream));
+        hipLaunchKernelGGL(bvh_treelet_find, dim3(blocksN), dim3(BLOCK), 0, stream, positions, triVertexIndex, (const unsigned long long*)keysOut, N, minTris, tb);
+        hipLaunchKernelGGL(bvh_treelet_reorder, dim3(N / minTris > 0 ? N / minTris : 1), dim3(64), 0, stream, N, tb);
+    }
     const uint64_t offBoxes = 16, offPrims = offBoxes + 32 * nodes, offMeta = offPrims + 40ull * N, total = offMeta + 12ull * N;
     const TbBvhHeader hdr = {(uint32_t)offBoxes, (uint32_t)offPrims, (uint32_t)offMeta, (uint32_t)total};
     BVH_TRY(hipMemcpyAsync(bvhA, &hdr, 16, hipMemcpyHostToDevice, stream));

@@ -17,7 +17,8 @@ hipError_t pt_launch_pack_owned(hipStream_t stream, const TbFloat4* full, TbFloa
 /* GPU LBVH build (bvh_kernels.hip); every pointer is a device pointer */
 size_t bvh_gpu_scratch_bytes(uint32_t N);
 hipError_t bvh_gpu_build(hipStream_t stream, const float* positions, const uint32_t* triVertexIndex, const uint32_t* triGeometry, const uint32_t* triPrimitive,
-                         const uint32_t* triFlags, uint32_t N, uint8_t* scratch, size_t scratchBytes, uint8_t* bvhA, TbNodeB* nodesB, TbTriB* trisB, uint32_t* rootHeight);
+                         const uint32_t* triFlags, uint32_t N, uint32_t treeletPasses, uint8_t* scratch, size_t scratchBytes, uint8_t* bvhA, TbNodeB* nodesB, TbTriB* trisB,
+                         uint32_t* rootHeight);
 /* real-time chain (rt_kernels.hip): temporal accumulation, one a-trous denoiser iteration, albedo composite */
 hipError_t rt_launch_temporal(hipStream_t stream, const TbTemporalConstants* k, const TbFloat4* history, const TbFloat4* current, const TbFloat4* worldPos,
                               const TbFloat4* prevWorldPos, const TbFloat4* momentHistory, const TbFloat4* normals, TbFloat4* out, TbFloat4* outMoment);
