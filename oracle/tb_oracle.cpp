@@ -80,24 +80,18 @@ inline float hash13(tb3 p3)
 struct RayData { /* TraverseFunction.hlsli:464-471 */
     tb3 InverseDirection, OriginTimesRayInverseDirection, Shear;
     int kx, ky, kz;
-    tb3 o; uint32_t degen; /* bit k: direction component k is exactly 0 */
+    tb3 AbsInverseDirection; /* abs(InverseDirection), TraverseFunction.hlsli:209, except on degenerate axes (below) */
 };
 
 /* The one place where the checker does not follow the reference's box test to the letter: for a ray with
  * d.k == 0 the reference's c*inv - o*inv is inf - inf = NaN on axis k and that axis never rejects a box
  * (TraverseFunction.hlsli:212-214).  Hits are unaffected, but the ray visits every node in its slab.
- * TB_LITERAL_BOX_TEST=1 restores the literal behaviour (tests/test_host_scene.py shows the images are
- * bit-identical either way); by default the origin must lie inside the box on a degenerate axis. */
+ * By default the constants of a degenerate axis are replaced (inv = 2^80, o*inv = o 2^80, |inv| = 2^80 (1 + 2^-10)),
+ * which turns the same arithmetic into "the origin lies inside the box's slab widened by a thousandth of its
+ * half-width" -- see pt_device.hpp.  TB_LITERAL_BOX_TEST=1 restores the literal behaviour (tests/test_host_scene.py
+ * shows the images are bit-identical either way). */
 static const bool g_literalBoxTest = getenv("TB_LITERAL_BOX_TEST") && atoi(getenv("TB_LITERAL_BOX_TEST")) != 0;
-
-inline bool DegenerateAxesInside(const RayData& r, tb3 c, tb3 h)
-{
-    bool in = true;
-    if ((r.degen & 1u) && !(tb_abs(r.o.x - c.x) <= h.x + 4e-6f * (tb_abs(r.o.x) + tb_abs(c.x) + h.x))) in = false;
-    if ((r.degen & 2u) && !(tb_abs(r.o.y - c.y) <= h.y + 4e-6f * (tb_abs(r.o.y) + tb_abs(c.y) + h.y))) in = false;
-    if ((r.degen & 4u) && !(tb_abs(r.o.z - c.z) <= h.z + 4e-6f * (tb_abs(r.o.z) + tb_abs(c.z) + h.z))) in = false;
-    return in;
-}
+static const float DEGEN_INV = 1.2089258196146292e24f, DEGEN_AINV = 1.2101064112353466e24f;
 
 /* TraverseFunction.hlsli:431-445 */
 inline int GetIndexOfBiggestChannel(tb3 v)
@@ -117,7 +111,12 @@ inline RayData GetRayData(tb3 o, tb3 d)
     r.kx = (z + 1) % 3;
     r.ky = (z + 2) % 3;
     r.kz = z;
-    r.o = o; r.degen = (d.x == 0.0f ? 1u : 0u) | (d.y == 0.0f ? 2u : 0u) | (d.z == 0.0f ? 4u : 0u);
+    r.AbsInverseDirection = tb3_abs(r.InverseDirection);
+    if (!g_literalBoxTest) {
+        if (d.x == 0.0f) { r.InverseDirection.x = DEGEN_INV; r.AbsInverseDirection.x = DEGEN_AINV; r.OriginTimesRayInverseDirection.x = o.x * DEGEN_INV; }
+        if (d.y == 0.0f) { r.InverseDirection.y = DEGEN_INV; r.AbsInverseDirection.y = DEGEN_AINV; r.OriginTimesRayInverseDirection.y = o.y * DEGEN_INV; }
+        if (d.z == 0.0f) { r.InverseDirection.z = DEGEN_INV; r.AbsInverseDirection.z = DEGEN_AINV; r.OriginTimesRayInverseDirection.z = o.z * DEGEN_INV; }
+    }
     if (tb3_get(d, r.kz) < 0.0f) { int t = r.kx; r.kx = r.ky; r.ky = t; }
     r.Shear = tb3_make(tb3_get(d, r.kx) / tb3_get(d, r.kz), tb3_get(d, r.ky) / tb3_get(d, r.kz),
                        1.0f / tb3_get(d, r.kz));
@@ -130,16 +129,14 @@ inline bool RayBoxTest(float& resultT, float closestT, const RayData& rd, tb3 c,
     /* not `precise` in the reference, so the shader compiler may contract; the build pins the contraction
      * (one fma per component per line), see include/tb_vec.h */
     const tb3 inv = rd.InverseDirection, oi = rd.OriginTimesRayInverseDirection;
-    tb3 ai = tb3_abs(inv);
+    tb3 ai = rd.AbsInverseDirection;
     tb3 relativeMiddle = tb3_make(tb_fma(c.x, inv.x, -oi.x), tb_fma(c.y, inv.y, -oi.y), tb_fma(c.z, inv.z, -oi.z));
     tb3 maxL = tb3_make(tb_fma(h.x, ai.x, relativeMiddle.x), tb_fma(h.y, ai.y, relativeMiddle.y), tb_fma(h.z, ai.z, relativeMiddle.z));
     tb3 minL = tb3_make(tb_fma(-h.x, ai.x, relativeMiddle.x), tb_fma(-h.y, ai.y, relativeMiddle.y), tb_fma(-h.z, ai.z, relativeMiddle.z));
     float minT = tb_max(tb_max(minL.x, minL.y), minL.z);
     float maxT = tb_min(tb_min(maxL.x, maxL.y), maxL.z);
     resultT = tb_max(minT, 0.0f);
-    bool pass = tb_max(minT, 0.0f) < tb_min(maxT, closestT);
-    if (rd.degen && pass && !g_literalBoxTest) pass = DegenerateAxesInside(rd, c, h);
-    return pass;
+    return tb_max(minT, 0.0f) < tb_min(maxT, closestT);
 }
 
 /* TraverseFunction.hlsli:232-313, two-sided branch (:273-277, :295-307).  `precise` U,V,W: no

@@ -13,7 +13,7 @@ import numpy as np
 from . import _ctypes_abi as abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtracerboy_hip.so")
+LIB_PATH = os.environ.get("TB_LIB", os.path.join(_HERE, "libtracerboy_hip.so"))  # TB_LIB: an experimental build of the same library
 
 _lib = None
 

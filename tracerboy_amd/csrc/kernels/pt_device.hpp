@@ -80,28 +80,28 @@ TBD float hash13(float x, float y, float z)
 }
 
 /* ---- traversal ------------------------------------------------------------------------------- */
-struct RayPre { tb3 inv, ainv, oinv, shear; int kx, ky, kz; tb3 o, operm; uint32_t permUnits; uint32_t degen; /* bit k: direction component k is exactly 0 */ };
+struct RayPre { tb3 inv, ainv, oinv, shear; int kx, ky, kz; tb3 o, operm; uint32_t permUnits; };
 
 /* Axis-parallel rays.  With d.k == 0 the reference's slab arithmetic (c*inv - o*inv, TraverseFunction.hlsli:212-214)
  * yields inf - inf = NaN on axis k, which min/max ignore: the axis never rejects a box, so such a ray visits every
  * node inside its slab on the other axes (hundreds of thousands on a large scene) -- and the reference RNG produces
  * them routinely (rand() returns exactly 0 about once in 300 calls, giving a bounce direction equal to the normal).
- * The build adds the missing test: the origin must lie inside the box on a degenerate axis, with a tolerance of a few
- * ulps so that no box the reference would have needed is lost.  Hits are unchanged; only fewer boxes are visited. */
-TBD bool degenerate_axes_inside(const RayPre& r, tb3 c, tb3 h)
-{
-    bool in = true;
-    if ((r.degen & 1u) && !(tb_abs(r.o.x - c.x) <= h.x + 4e-6f * (tb_abs(r.o.x) + tb_abs(c.x) + h.x))) in = false;
-    if ((r.degen & 2u) && !(tb_abs(r.o.y - c.y) <= h.y + 4e-6f * (tb_abs(r.o.y) + tb_abs(c.y) + h.y))) in = false;
-    if ((r.degen & 4u) && !(tb_abs(r.o.z - c.z) <= h.z + 4e-6f * (tb_abs(r.o.z) + tb_abs(c.z) + h.z))) in = false;
-    return in;
-}
+ * The build adds the missing test without adding an instruction to the walk: on a degenerate axis the ray's constants
+ * become inv = 2^80, o*inv = o * 2^80 (exact) and |inv| = 2^80 (1 + 2^-10), so the same fmas give (c -+ 1.001 h - o) 2^80
+ * -- far below zero / far above `closest` when the origin is inside the box's slab (widened by a thousandth of its
+ * half-width so that no box the reference would have needed is lost), far above `closest` on the entry side when it
+ * is outside.  Hits are unchanged; only fewer boxes are visited.  oracle/tb_oracle.cpp does the same. */
+#define TB_DEGEN_INV 1.2089258196146292e24f       /* 2^80 */
+#define TB_DEGEN_AINV 1.2101064112353466e24f      /* 2^80 (1 + 2^-10) */
 
 TBD RayPre ray_prepare(tb3 o, tb3 d) /* GetRayData, TraverseFunction.hlsli:473-495 */
 {
     RayPre r;
     r.inv = tb3_make(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     r.oinv = o * r.inv; r.ainv = tb3_abs(r.inv);
+    if (d.x == 0.0f) { r.inv.x = TB_DEGEN_INV; r.ainv.x = TB_DEGEN_AINV; r.oinv.x = o.x * TB_DEGEN_INV; }
+    if (d.y == 0.0f) { r.inv.y = TB_DEGEN_INV; r.ainv.y = TB_DEGEN_AINV; r.oinv.y = o.y * TB_DEGEN_INV; }
+    if (d.z == 0.0f) { r.inv.z = TB_DEGEN_INV; r.ainv.z = TB_DEGEN_AINV; r.oinv.z = o.z * TB_DEGEN_INV; }
     tb3 a = tb3_abs(d);
     int z = (a.x > a.y && a.x > a.z) ? 0 : (a.y > a.z ? 1 : 2);
     int kx = z == 2 ? 0 : z + 1, ky = kx == 2 ? 0 : kx + 1;
@@ -110,7 +110,7 @@ TBD RayPre ray_prepare(tb3 o, tb3 d) /* GetRayData, TraverseFunction.hlsli:473-4
     r.kx = kx; r.ky = ky; r.kz = z;
     r.operm = tb3_make(tb3_get(o, kx), tb3_get(o, ky), tb3_get(o, z)); /* for the axis-permuted triangle copies */
     r.permUnits = (uint32_t)(z * 2 + (dz < 0.0f ? 1 : 0)) * 3u;        /* copy index * 48 B / 16 */
-    r.o = o; r.degen = (d.x == 0.0f ? 1u : 0u) | (d.y == 0.0f ? 2u : 0u) | (d.z == 0.0f ? 4u : 0u);
+    r.o = o;
     r.shear = tb3_make(tb3_get(d, kx) / dz, tb3_get(d, ky) / dz, 1.0f / dz);
     return r;
 }
@@ -118,16 +118,14 @@ TBD RayPre ray_prepare(tb3 o, tb3 d) /* GetRayData, TraverseFunction.hlsli:473-4
 TBD bool box_test(float& tEntry, float closest, const RayPre& r, tb3 c, tb3 h) /* RayBoxTest :204-221 */
 {
     /* (not `precise` in the reference: contraction allowed, pinned here as explicit fmas) */
-    tb3 ai = tb3_abs(r.inv);
+    tb3 ai = r.ainv;
     tb3 mid = tb3_make(tb_fma(c.x, r.inv.x, -r.oinv.x), tb_fma(c.y, r.inv.y, -r.oinv.y), tb_fma(c.z, r.inv.z, -r.oinv.z));
     tb3 hi = tb3_make(tb_fma(h.x, ai.x, mid.x), tb_fma(h.y, ai.y, mid.y), tb_fma(h.z, ai.z, mid.z));
     tb3 lo = tb3_make(tb_fma(-h.x, ai.x, mid.x), tb_fma(-h.y, ai.y, mid.y), tb_fma(-h.z, ai.z, mid.z));
     float tmin = tb_max(tb_max(lo.x, lo.y), lo.z);
     float tmax = tb_min(tb_min(hi.x, hi.y), hi.z);
     tEntry = tb_max(tmin, 0.0f);
-    bool pass = tb_max(tmin, 0.0f) < tb_min(tmax, closest);
-    if (r.degen && pass) pass = degenerate_axes_inside(r, c, h);
-    return pass;
+    return tb_max(tmin, 0.0f) < tb_min(tmax, closest);
 }
 
 /* Both children of a layout-B node at once: the same arithmetic as two box_test() calls, with the nine fmas of the
@@ -164,10 +162,6 @@ TBD void box_test2(bool& lh, bool& rh, float& lt, float& rt, float closest, cons
     const float tminR = tb_max(tb_max(lox.y, loy.y), loz.y), tmaxR = tb_min(tb_min(hix.y, hiy.y), hiz.y);
     lt = tb_max(tminL, 0.0f); rt = tb_max(tminR, 0.0f);
     lh = lt < tb_min(tmaxL, closest); rh = rt < tb_min(tmaxR, closest);
-    if (r.degen) {
-        if (lh) lh = degenerate_axes_inside(r, tb3_make(n.cx[0], n.cy[0], n.cz[0]), tb3_make(n.hx[0], n.hy[0], n.hz[0]));
-        if (rh) rh = degenerate_axes_inside(r, tb3_make(n.cx[1], n.cy[1], n.cz[1]), tb3_make(n.hx[1], n.hy[1], n.hz[1]));
-    }
 }
 
 struct Hit { float t, u, v; uint32_t prim, geom; };
