@@ -486,7 +486,7 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
         if (!groups) HIP_TRY(v->fn(c->stream, &c->ds, &pf, &tg, W, H, c->samplesRendered, n, &c->tiles, c->sceneInLds ? 1 : 0, count ? 1 : 0, (int)opt("pipeline", 0)));
         else {
             const uint64_t pixels = (uint64_t)W * H, budget = (uint64_t)opt("pooled_samples", 256ll << 20);
-            const uint32_t batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n, budget / pixels));
+            const uint32_t batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(n, 32768), budget / pixels)); /* a slot entry holds 15 bits of relative frame */
             /* automatic group size: about 49 152 work items per launch -- fine enough that the last items end together, coarse
              * enough that claiming them does not show (measured on 1080p, scripts/frame_group_sweep.py: Cornell x 64 frames best
              * at G = 8-16 on the whole frame and 2-4 on an eighth of it; 870 k triangles x 16 frames best at G = 2-4) */
@@ -495,6 +495,7 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
             const uint32_t autoG = (uint32_t)std::min<uint64_t>(frames, std::max<uint64_t>(1, ((uint64_t)frames * regions + 49151) / 49152));
             ensure(c->workCounter, 1024);
             tg.frameGroup = fg > 0 ? (uint32_t)fg : autoG;
+            while (tg.frameGroup & (tg.frameGroup - 1)) tg.frameGroup &= tg.frameGroup - 1; /* a power of two (rounded down): samples find their frame with shifts */
             if (overlap && !c->sideOrdered) { /* first overlapped launch after other work on the main stream: order the side streams behind it once */
                 HIP_TRY(hipEventRecord(c->evMain, c->stream));
                 for (int i = 0; i < 2; i++) HIP_TRY(hipStreamWaitEvent(c->side[i], c->evMain, 0));
