@@ -123,7 +123,8 @@ TB_HD float tb_sin(float x)
     if (!(tb_abs(x) < 1.0e9f)) return tb_u2f(0x7fc00000u); /* inf, nan, absurdly large */
     float r; int q;
     tb_sincos_reduce(x, &r, &q);
-    float s = (q & 1) ? tb_cos_poly(r) : tb_sin_poly(r);
+    const float sp = tb_sin_poly(r), cp = tb_cos_poly(r); /* both, then a select: the quadrant differs from lane to lane */
+    float s = (q & 1) ? cp : sp;
     return (q & 2) ? -s : s;
 }
 
@@ -132,7 +133,8 @@ TB_HD float tb_cos(float x)
     if (!(tb_abs(x) < 1.0e9f)) return tb_u2f(0x7fc00000u);
     float r; int q;
     tb_sincos_reduce(x, &r, &q);
-    float c = (q & 1) ? tb_sin_poly(r) : tb_cos_poly(r);
+    const float sp = tb_sin_poly(r), cp = tb_cos_poly(r);
+    float c = (q & 1) ? sp : cp;
     return ((q + 1) & 2) ? -c : c;
 }
 

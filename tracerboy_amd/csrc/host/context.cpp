@@ -170,7 +170,9 @@ uint32_t settingsFeatureMask(const tb_context* c, const tb_output_settings& s, b
 
 /* Storage order of the layout-B nodes (results do not depend on it).  order 0: breadth-first, the top of the tree is one
  * contiguous prefix; order 1: depth-first pre-order, a node's left child follows it (same 128-B line every other step of
- * a descent); order 2: breadth-first for the top `topLevels` levels, depth-first below (cached top + local subtrees). */
+ * a descent); order 2: breadth-first for the top `topLevels` levels, depth-first below (cached top + local subtrees);
+ * order 3: blocks of `topLevels` levels stored breadth-first, the blocks themselves depth-first (van Emde Boas style: a
+ * descent of `topLevels` steps stays inside one contiguous block). */
 void reorderNodes(HostScene& s, int order_, uint32_t topLevels)
 {
     const uint32_t n = (uint32_t)s.nodesB.size();
@@ -188,7 +190,20 @@ void reorderNodes(HostScene& s, int order_, uint32_t topLevels)
         }
     };
     if (order_ == 1) dfs(s.rootRefB);
-    else {
+    else if (order_ == 3) {
+        const uint32_t h = topLevels ? topLevels : 2;
+        std::vector<uint32_t> blocks; blocks.push_back(s.rootRefB);
+        std::vector<uint32_t> level, next, below;
+        while (!blocks.empty()) {
+            level.assign(1, blocks.back()); blocks.pop_back(); below.clear();
+            for (uint32_t d = 0; d < h && !level.empty(); d++) {
+                next.clear();
+                for (uint32_t x : level) { order.push_back(x); const TbNodeB& nd = s.nodesB[x]; if (inner(nd.left)) next.push_back(nd.left); if (inner(nd.right)) next.push_back(nd.right); }
+                level.swap(next);
+            }
+            for (size_t i = level.size(); i-- > 0;) blocks.push_back(level[i]); /* leftmost block below comes next */
+        }
+    } else {
         std::vector<uint32_t> level; level.push_back(s.rootRefB);
         uint32_t depth = 0;
         while (!level.empty() && (order_ == 0 || depth < topLevels)) {

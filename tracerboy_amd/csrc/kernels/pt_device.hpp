@@ -641,12 +641,14 @@ TBD float halton(int b, int i) /* RayGenCommon.h:49-59 */
     return r;
 }
 
-/* GetBlueNoise, RayGenCommon.h:104-122: 8 R, or 2 texel fetches + Halton23 */
+/* GetBlueNoise, RayGenCommon.h:104-122: 8 R, or 2 texel fetches + Halton23.  `need`: bit i set = out[i] is read by the caller;
+ * a rand() whose value nobody reads only moves the seed on (the compiler does not manage to drop all of an unused sin by
+ * itself: the range reduction and the quadrant test of five of them stayed in the regeneration path) */
 template <uint32_t F>
-TBD void blue_noise(const TbDeviceScene& ds, const TbPerFrameConstants& pf, uint32_t frame, float& seed, uint32_t x, uint32_t y, float out[8])
+TBD void blue_noise(const TbDeviceScene& ds, const TbPerFrameConstants& pf, uint32_t frame, float& seed, uint32_t x, uint32_t y, float out[8], uint32_t need)
 {
     if (!pf.UseBlueNoise) { /* a uniform branch in every variant: blue noise is the reference's default (TracerBoy.h:354) */
-        for (int i = 0; i < 8; i++) out[i] = rnd(seed, pf.Time);
+        for (int i = 0; i < 8; i++) { if ((need >> i) & 1u) out[i] = rnd(seed, pf.Time); else { out[i] = 0.0f; seed = seed + 1.0f; } }
     } else {
         uint32_t idx = (y % 256u) * 256u + (x % 256u);
         TbFloat4 z = {0, 0, 0, 0};
@@ -671,7 +673,7 @@ TBD void path_begin(Path& p, const TbDeviceScene& ds, const TbPerFrameConstants&
     float uvx = 0.0f + dux * 1.0f, uvy = 1.0f + duy * -1.0f;
     float pcx = uvx * resX, pcy = uvy * resY;
     float bn[8];
-    blue_noise<F>(ds, pf, frame, p.seed, x, y, bn); /* kernel.glsl:1830 */
+    blue_noise<F>(ds, pf, frame, p.seed, x, y, bn, (F & FEAT_EXT) ? 0xc3u : 0x03u); /* kernel.glsl:1830: the pixel jitter, with FEAT_EXT also the DOF jitter */
     float psx = 1.0f / resX, psy = 1.0f / resY;
     float u = pcx * psx, v = pcy * psy;
     float jx = bn[0], jy = bn[1];
@@ -711,7 +713,7 @@ TBD void path_begin(Path& p, const TbDeviceScene& ds, const TbPerFrameConstants&
     /* Trace() prologue :1280-1284 (second GetBlueNoise: 8 R whose values are unused) */
     p.L = tb3_splat(0.0f); p.T = tb3_splat(1.0f);
     float unused[8];
-    blue_noise<F>(ds, pf, frame, p.seed, x, y, unused);
+    blue_noise<F>(ds, pf, frame, p.seed, x, y, unused, 0u);
     p.state = pf.MaxBounces > 0 ? ST_EXTEND : ST_DONE;
 }
 
