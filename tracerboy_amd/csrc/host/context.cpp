@@ -26,6 +26,7 @@ typedef hipError_t (*pt_variant_fn)(hipStream_t, const TbDeviceScene*, const TbP
 hipError_t pt_launch_persistent_matte(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, uint32_t, uint32_t, uint32_t, uint32_t, const TbTileMap*, int, int, int);
 hipError_t pt_launch_persistent_env(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, uint32_t, uint32_t, uint32_t, uint32_t, const TbTileMap*, int, int, int);
 hipError_t pt_launch_persistent_surf(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, uint32_t, uint32_t, uint32_t, uint32_t, const TbTileMap*, int, int, int);
+hipError_t pt_launch_persistent_vol4(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, uint32_t, uint32_t, uint32_t, uint32_t, const TbTileMap*, int, int, int);
 hipError_t pt_launch_persistent_vol(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, uint32_t, uint32_t, uint32_t, uint32_t, const TbTileMap*, int, int, int);
 hipError_t pt_launch_persistent_full(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, uint32_t, uint32_t, uint32_t, uint32_t, const TbTileMap*, int, int, int);
 }
@@ -478,6 +479,9 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
     if (!v) v = &kVariants[4];
     c->lastVariant = v->name;
     const int variantIndex = (int)(v - kVariants);
+    /* "vol" exists at 3 and at 4 waves per SIMD (pt_variant_vol.hip / _vol4.hip): the second one when LDS has room for four workgroups per CU */
+    pt_variant_fn launch = v->fn;
+    if (variantIndex == 3 && (size_t)c->ds.stackDepth * 1024 + (c->sceneInLds ? c->ds.ldsBlobBytes : 0) + 256 <= 40 * 1024) launch = pt_launch_persistent_vol4;
     const bool wavefront = opt("pipeline", 0) == 2 && variantIndex <= 2 && !count && !aov;
     const bool pooled = opt("pipeline", 0) == 3 && variantIndex <= 2 && !count && !aov;
     const int64_t fg = opt("frame_group", 0);
@@ -498,7 +502,7 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
          * to an ordered sample buffer and accumulate_samples_kernel folds them in frame order (bit-identical sums).  Keeps all
          * lanes of a workgroup busy to its end and gives a rank of a tile split enough workgroups; on whenever a call renders
          * enough frames to form groups.  Option "frame_group" = G > 0 forces the group size, < 0 forbids the mode. */
-        if (!groups) HIP_TRY(v->fn(c->stream, &c->ds, &pf, &tg, W, H, c->samplesRendered, n, &c->tiles, c->sceneInLds ? 1 : 0, count ? 1 : 0, (int)opt("pipeline", 0)));
+        if (!groups) HIP_TRY(launch(c->stream, &c->ds, &pf, &tg, W, H, c->samplesRendered, n, &c->tiles, c->sceneInLds ? 1 : 0, count ? 1 : 0, (int)opt("pipeline", 0)));
         else {
             const uint64_t pixels = (uint64_t)W * H, budget = (uint64_t)opt("pooled_samples", 256ll << 20);
             const uint32_t batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(n, 32768), budget / pixels)); /* a slot entry holds 15 bits of relative frame */
@@ -523,7 +527,7 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
                 tg.samples = (TbFloat4*)c->fgSamples[par].p; tg.workCounter = (uint32_t*)c->workCounter.p + par * 128u;
                 if (overlap) HIP_TRY(hipStreamWaitEvent(ptStream, c->evFold[par], 0)); /* the fold that last read this sample buffer */
                 if (f0 == 0) { if (clearStats && overlap) HIP_TRY(hipMemsetAsync(c->stats.p, 0, 16, ptStream)); HIP_TRY(hipEventRecord(c->evKernelStart, ptStream)); }
-                HIP_TRY(v->fn(ptStream, &c->ds, &pf, &tg, W, H, c->samplesRendered + f0, nf, &c->tiles, c->sceneInLds ? 1 : 0, 0, 0));
+                HIP_TRY(launch(ptStream, &c->ds, &pf, &tg, W, H, c->samplesRendered + f0, nf, &c->tiles, c->sceneInLds ? 1 : 0, 0, 0));
                 if (f0 == 0) { HIP_TRY(hipEventRecord(c->evKernel, ptStream)); c->lastKernelFrames = nf; }
                 if (overlap) { HIP_TRY(hipEventRecord(c->evPt[par], ptStream)); HIP_TRY(hipStreamWaitEvent(c->stream, c->evPt[par], 0)); }
                 HIP_TRY(pt_launch_accumulate_samples(c->stream, tg.samples, W, H, c->samplesRendered + f0, nf, &c->tiles, tg.output, tg.jittered));

@@ -3,5 +3,8 @@
 #define PT_FEATURES (PT_FEAT_ENV | PT_FEAT_SPECULAR | PT_FEAT_TEXTURES)
 #define PT_NAME surf
 #define PT_COUNT 0
-#define PT_PERSISTENT_ATTR __attribute__((amdgpu_waves_per_eu(3)))
+#ifndef TB_SURF_WAVES
+#define TB_SURF_WAVES 3
+#endif
+#define PT_PERSISTENT_ATTR __attribute__((amdgpu_waves_per_eu(TB_SURF_WAVES)))
 #include "pt_variant.inc"
