@@ -193,7 +193,10 @@ void optimizeByReinsertion(const HostScene& s, Tree& t, int maxPasses, double mi
         while (!st.empty()) { uint32_t x = st.back(); st.pop_back(); pre.push_back(x); if (!isLeaf(x)) { st.push_back(t.left[x]); st.push_back(t.right[x]); } }
         for (size_t w = pre.size(); w-- > 0;) if (!isLeaf(pre[w])) pull(pre[w]);
     }
-    const uint32_t depthLimit = std::max<uint32_t>(height[0], std::min<uint32_t>(height[0] + 6u, 35u));
+    /* the traversal stack in LDS is as deep as the tree (1 KB per level and workgroup): 31 levels leave room for five workgroups
+     * per CU, 39 for four (context.cpp picks the kernel copy accordingly), so a tree is not allowed to grow across such a step */
+    const uint32_t h0 = height[0] + 1u; /* in nodes, like HostScene::bvhMaxDepth */
+    const uint32_t depthLimit = (h0 <= 31u ? 31u : (h0 <= 39u ? 39u : h0)) - 1u;
     auto refit = [&](uint32_t x) { for (; x != NONE; x = parent[x]) pull(x); };
     auto totalCost = [&]() { double c = 0; for (uint32_t i = 0; i + 1 < N; i++) c += sa[i]; return c; };
     auto replaceChild = [&](uint32_t p, uint32_t from, uint32_t to) { if (t.left[p] == from) t.left[p] = to; else t.right[p] = to; parent[to] = p; };

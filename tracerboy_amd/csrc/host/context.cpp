@@ -26,6 +26,8 @@ typedef hipError_t (*pt_variant_fn)(hipStream_t, const TbDeviceScene*, const TbP
 hipError_t pt_launch_persistent_matte(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, uint32_t, uint32_t, uint32_t, uint32_t, const TbTileMap*, int, int, int);
 hipError_t pt_launch_persistent_env(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, uint32_t, uint32_t, uint32_t, uint32_t, const TbTileMap*, int, int, int);
 hipError_t pt_launch_persistent_surf(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, uint32_t, uint32_t, uint32_t, uint32_t, const TbTileMap*, int, int, int);
+hipError_t pt_launch_persistent_matte5(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, uint32_t, uint32_t, uint32_t, uint32_t, const TbTileMap*, int, int, int);
+hipError_t pt_launch_persistent_env5(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, uint32_t, uint32_t, uint32_t, uint32_t, const TbTileMap*, int, int, int);
 hipError_t pt_launch_persistent_vol4(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, uint32_t, uint32_t, uint32_t, uint32_t, const TbTileMap*, int, int, int);
 hipError_t pt_launch_persistent_vol(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, uint32_t, uint32_t, uint32_t, uint32_t, const TbTileMap*, int, int, int);
 hipError_t pt_launch_persistent_full(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, uint32_t, uint32_t, uint32_t, uint32_t, const TbTileMap*, int, int, int);
@@ -45,13 +47,15 @@ namespace {
 std::string g_createError;
 const wf_variant_fn kWfVariants[3] = {wf_launch_matte, wf_launch_env, wf_launch_surf}; /* same order as kVariants[0..2] */
 
-struct Variant { uint32_t features; pt_variant_fn fn; const char* name; };
+/* fnHi: the same feature set compiled to `wavesHi` waves per SIMD (fewer VGPRs, more scratch; pipeline 0 only), used when LDS
+ * has room for that many workgroups per CU -- otherwise its spills would buy no residency */
+struct Variant { uint32_t features; pt_variant_fn fn; const char* name; pt_variant_fn fnHi; uint32_t wavesHi; };
 const Variant kVariants[] = {
-    {0u, pt_launch_persistent_matte, "matte"},
-    {PT_FEAT_ENV, pt_launch_persistent_env, "env"},
-    {PT_FEAT_ENV | PT_FEAT_SPECULAR | PT_FEAT_TEXTURES, pt_launch_persistent_surf, "surf"},
-    {PT_FEAT_ENV | PT_FEAT_SPECULAR | PT_FEAT_TEXTURES | PT_FEAT_SSS | PT_FEAT_MIX, pt_launch_persistent_vol, "vol"},
-    {PT_FEAT_ALL, pt_launch_persistent_full, "full"},
+    {0u, pt_launch_persistent_matte, "matte", pt_launch_persistent_matte5, 5},
+    {PT_FEAT_ENV, pt_launch_persistent_env, "env", pt_launch_persistent_env5, 5},
+    {PT_FEAT_ENV | PT_FEAT_SPECULAR | PT_FEAT_TEXTURES, pt_launch_persistent_surf, "surf", nullptr, 0},
+    {PT_FEAT_ENV | PT_FEAT_SPECULAR | PT_FEAT_TEXTURES | PT_FEAT_SSS | PT_FEAT_MIX, pt_launch_persistent_vol, "vol", pt_launch_persistent_vol4, 4},
+    {PT_FEAT_ALL, pt_launch_persistent_full, "full", nullptr, 0},
 };
 
 struct DevBuf {
@@ -303,7 +307,9 @@ void finalizeScene(tb_context* c)
     d.envMap = upload(c, s.envMap); d.envWidth = s.envWidth; d.envHeight = s.envHeight;
     d.blueNoise0 = upload(c, s.blueNoise0); d.blueNoise1 = upload(c, s.blueNoise1);
     d.config = s.config;
-    d.stackDepth = s.bvhMaxDepth + 2;
+    /* a root-to-leaf path of bvhMaxDepth nodes has bvhMaxDepth - 1 inner nodes, each of which parks at most one far child: the
+     * walk never holds more than bvhMaxDepth - 1 entries (one spare) */
+    d.stackDepth = s.bvhMaxDepth < 2 ? 2 : s.bvhMaxDepth;
     d.alphaTest = opt("alpha_test", 0) ? 1u : 0u;
     /* whole-scene LDS image */
     {
@@ -479,9 +485,11 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
     if (!v) v = &kVariants[4];
     c->lastVariant = v->name;
     const int variantIndex = (int)(v - kVariants);
-    /* "vol" exists at 3 and at 4 waves per SIMD (pt_variant_vol.hip / _vol4.hip): the second one when LDS has room for four workgroups per CU */
     pt_variant_fn launch = v->fn;
-    if (variantIndex == 3 && (size_t)c->ds.stackDepth * 1024 + (c->sceneInLds ? c->ds.ldsBlobBytes : 0) + 256 <= 40 * 1024) launch = pt_launch_persistent_vol4;
+    {
+        const size_t ldsPerGroup = ((size_t)c->ds.stackDepth * 1024 + (c->sceneInLds ? c->ds.ldsBlobBytes : 0) + 128 + 511) / 512 * 512; /* + static LDS, 512-B granules */
+        if (v->fnHi && opt("pipeline", 0) == 0 && !count && opt("high_occupancy", 1) != 0 && ldsPerGroup * v->wavesHi <= 160 * 1024) launch = v->fnHi;
+    }
     const bool wavefront = opt("pipeline", 0) == 2 && variantIndex <= 2 && !count && !aov;
     const bool pooled = opt("pipeline", 0) == 3 && variantIndex <= 2 && !count && !aov;
     const int64_t fg = opt("frame_group", 0);
@@ -938,7 +946,7 @@ int tb_unpack_gathered_host(uint32_t W, uint32_t H, uint32_t world, uint32_t tw,
 int tb_set_option(tb_context* c, const char* name, int64_t v)
 {
     if (!c || !name) return TB_E_INVALID;
-    static const char* known[] = {"pipeline", "count_rays", "bvh_builder", "flatten_instances", "aov", "scene_in_lds", "lds_scene_budget", "force_full_variant", "wavefront_paths", "wavefront_grid", "wavefront_segment", "pooled_paths", "pooled_samples", "pooled_profile", "park_min", "alpha_test", "node_order", "node_order_top_levels", "frame_group", "overlap_launches"};
+    static const char* known[] = {"pipeline", "count_rays", "bvh_builder", "flatten_instances", "aov", "scene_in_lds", "lds_scene_budget", "force_full_variant", "wavefront_paths", "wavefront_grid", "wavefront_segment", "pooled_paths", "pooled_samples", "pooled_profile", "park_min", "alpha_test", "node_order", "node_order_top_levels", "frame_group", "overlap_launches", "high_occupancy"};
     for (const char* k : known) if (!strcmp(k, name)) { c->options[name] = v; if (!strcmp(name, "count_rays") || !strcmp(name, "aov")) c->samplesRendered = 0; return TB_OK; }
     return fail(c, TB_E_INVALID, std::string("unknown option '") + name + "'");
 }

@@ -1,0 +1,9 @@
+/* pt_variant_matte5.hip -- feature set "matte" at 5 waves per SIMD (96 VGPRs, about ten registers in scratch), pipeline 0 only.
+ * Chosen when five workgroups per CU fit in LDS (stack + scene image <= 32 KB): cornell-box 1920x1080x64 +9 %. */
+#include "pt_device_features.h"
+#define PT_FEATURES 0u
+#define PT_NAME matte5
+#define PT_COUNT 0
+#define PT_ONLY_PERSISTENT 1
+#define PT_PERSISTENT_ATTR __attribute__((amdgpu_waves_per_eu(5)))
+#include "pt_variant.inc"

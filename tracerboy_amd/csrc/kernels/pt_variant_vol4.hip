@@ -4,5 +4,6 @@
 #define PT_FEATURES (PT_FEAT_ENV | PT_FEAT_SPECULAR | PT_FEAT_TEXTURES | PT_FEAT_SSS | PT_FEAT_MIX)
 #define PT_NAME vol4
 #define PT_COUNT 0
+#define PT_ONLY_PERSISTENT 1
 #define PT_PERSISTENT_ATTR __attribute__((amdgpu_waves_per_eu(4)))
 #include "pt_variant.inc"
