@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=INT")  # extra tb_set_option()s, applied before the scene is loaded
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--async-steps", action="store_true")  # run the N > 1 step pipeline (async render + pack + stream-ordered consumer) on one GPU
+    ap.add_argument("--sync-steps", action="store_true")   # N = 1: wait for every render before enqueuing the next (default: enqueue the K steps, wait once)
     ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
     args = ap.parse_args()
 
@@ -141,8 +142,14 @@ def main():
     def step():
         tb.InvalidateHistory()
         if not pipelined:
-            tb.Render(W, H, SPP, s, 0.0)          # synchronous; GPU time measured with HIP events on the library's stream
-            kernel_ms.append(tb.GetOption("last_kernel_us") / 1e3)  # the render's (first) path-tracing launch, without the sample fold
+            if args.sync_steps:
+                tb.Render(W, H, SPP, s, 0.0)          # synchronous; GPU time measured with HIP events on the library's stream
+                kernel_ms.append(tb.GetOption("last_kernel_us") / 1e3)  # the render's (first) path-tracing launch, without the sample fold
+            else:
+                # the K renders are enqueued back to back (tb_render_async) and waited for once by the closing barrier
+                # (torch.cuda.synchronize = device-wide), inside the timed region: the launch of step k+1 starts on the other
+                # side stream while the last paths of step k drain
+                tb.Render(W, H, SPP, s, 0.0, sync=False)
             return
         b = renders[0] & 1; renders[0] += 1
         tb.Render(W, H, SPP, s, 0.0, sync=False)
@@ -167,7 +174,7 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if pipelined:
+    if pipelined or not args.sync_steps:
         tb.Sync(); kernel_ms.append(tb.GetOption("last_kernel_us") / 1e3)   # HIP events of the last render of the timed region
     if world > 1:
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX); elapsed = float(t.item())

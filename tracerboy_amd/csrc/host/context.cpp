@@ -349,9 +349,9 @@ void finalizeScene(tb_context* c)
         c->sceneInLds = blob.size() + (size_t)d.stackDepth * 256 * 4 <= budget && opt("scene_in_lds", 1) != 0;
         if (c->sceneInLds) { d.ldsBlob = upload(c, blob); d.ldsBlobBytes = (uint32_t)blob.size(); }
         else { d.ldsBlob = nullptr; d.ldsBlobBytes = 0; }
-        /* measured on MI355X: LDS-resident scenes are insensitive (4 is marginally best), scenes fetched through the
-         * caches gain ~5 % from a late switch to the leaf phase */
-        d.parkMin = (uint32_t)std::max<int64_t>(1, opt("park_min", c->sceneInLds ? 4 : 24));
+        /* measured on MI355X: LDS-resident scenes are nearly insensitive (at five waves per SIMD 1-2 is best: 6 745 / 6 730 against
+         * 6 680 at 4, 6 230 at 12), scenes fetched through the caches gain ~5 % from a late switch to the leaf phase (16-24) */
+        d.parkMin = (uint32_t)std::max<int64_t>(1, opt("park_min", c->sceneInLds ? 2 : 24));
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->sceneFeatures = sceneFeatureMask(s);
