@@ -146,8 +146,9 @@ void tb_default_post_settings(tb_post_settings* out);
 int tb_post_process(tb_context* ctx, const tb_post_settings* post, uint32_t output_type, float* rgba_f32_or_null, uint8_t* rgba8_or_null);
 /* averaged luminance of the last auto-exposed tb_post_process (AveragedLuminance buffer) */
 int tb_read_averaged_luminance(tb_context* ctx, float* out);
-/* Image files for the headless CLI (the reference presents to a swap chain): ".png" (8-bit RGBA, stored deflate blocks) or
- * ".pfm" (RGB float, bottom-up per the format) chosen by extension; host-only, no context needed. */
+/* Image files for the headless CLI (the reference presents to a swap chain): ".png" (8-bit RGBA, stored deflate blocks),
+ * ".pfm" (RGB float, bottom-up per the format) or ".exr" (OpenEXR scan lines, four uncompressed FLOAT channels) chosen by
+ * extension; host-only, no context needed. */
 int tb_write_image_rgba8(const char* path, uint32_t width, uint32_t height, const uint8_t* rgba8);
 int tb_write_image_f32(const char* path, uint32_t width, uint32_t height, const float* rgba);
 /* The texture decoders of tb_load_scene on their own (<-> DirectX::LoadFromHDRFile / LoadFromTGAFile / LoadFromWICFile +

@@ -210,3 +210,39 @@ def test_gpu_post_process_aov_output_types(gpu_tb, settings):
             gpu_tb.PostProcess(ps, outputType=4)   # motion vectors: surface of the real-time chain, not built
     finally:
         gpu_tb.SetOption("aov", 0)
+
+
+def test_exr_writer_layout(built, tmp_path):
+    """The .exr writer (tb_write_image_f32) against the OpenEXR file layout: magic / version, the attribute list, the scan-line
+    offset table and channel-planar FLOAT pixels in alphabetical channel order -- parsed back here field by field."""
+    import struct
+    from tracerboy_amd import api
+    rng = np.random.default_rng(3)
+    W, H = 13, 7
+    img = rng.normal(size=(H, W, 4)).astype(np.float32)
+    p = str(tmp_path / "o.exr")
+    api.WriteImage(p, img)
+    b = open(p, "rb").read()
+    assert struct.unpack_from("<II", b, 0) == (20000630, 2)
+    at = 8; attrs = {}
+    while b[at] != 0:
+        e = b.index(b"\0", at); name = b[at:e].decode(); at = e + 1
+        e = b.index(b"\0", at); typ = b[at:e].decode(); at = e + 1
+        (size,) = struct.unpack_from("<i", b, at); at += 4
+        attrs[name] = (typ, b[at:at + size]); at += size
+    at += 1
+    assert set(attrs) >= {"channels", "compression", "dataWindow", "displayWindow", "lineOrder", "pixelAspectRatio", "screenWindowCenter", "screenWindowWidth"}
+    assert attrs["compression"] == ("compression", b"\0") and attrs["lineOrder"] == ("lineOrder", b"\0")
+    assert struct.unpack("<4i", attrs["dataWindow"][1]) == (0, 0, W - 1, H - 1) == struct.unpack("<4i", attrs["displayWindow"][1])
+    ch = attrs["channels"][1]; names = []; q = 0
+    while ch[q] != 0:
+        e = ch.index(b"\0", q); names.append(ch[q:e].decode()); q = e + 1
+        assert struct.unpack_from("<i4xii", ch, q) == (2, 1, 1); q += 16
+    assert names == ["A", "B", "G", "R"] and q + 1 == len(ch)
+    offsets = struct.unpack_from("<%dQ" % H, b, at)
+    assert offsets[0] == at + 8 * H and len(b) == offsets[-1] + 8 + 16 * W
+    for y in range(H):
+        yy, nbytes = struct.unpack_from("<ii", b, offsets[y])
+        assert (yy, nbytes) == (y, 16 * W)
+        px = np.frombuffer(b, np.float32, 4 * W, offsets[y] + 8).reshape(4, W)
+        assert np.array_equal(px[3], img[y, :, 0]) and np.array_equal(px[2], img[y, :, 1]) and np.array_equal(px[1], img[y, :, 2]) and np.array_equal(px[0], img[y, :, 3])

@@ -129,7 +129,7 @@ def GetDefaultPostProcessSettings():
 
 
 def WriteImage(path, image):
-    """uint8 HxWx4 -> .png, float32 HxWx4 -> .pfm (tb_write_image_*)."""
+    """uint8 HxWx4 -> .png, float32 HxWx4 -> .pfm / .exr (tb_write_image_*)."""
     a = np.ascontiguousarray(image)
     h, w = a.shape[:2]
     if a.dtype == np.uint8:

@@ -60,7 +60,7 @@ int main(int argc, char** argv)
         std::vector<float> acc((size_t)W * H * 4);
         if ((rc = tb_read_accum(ctx, acc.data(), nullptr))) return fail(ctx, "tb_read_accum", rc);
         for (size_t i = 0; i < (size_t)W * H; i++) { float w = acc[4 * i + 3], inv = w > 0 ? 1.0f / w : 0.0f; acc[4 * i] *= inv; acc[4 * i + 1] *= inv; acc[4 * i + 2] *= inv; }
-        if ((rc = tb_write_image_f32(out.c_str(), W, H, acc.data()))) return fail(ctx, "tb_write_image_f32 (use .png or .pfm)", rc);
+        if ((rc = tb_write_image_f32(out.c_str(), W, H, acc.data()))) return fail(ctx, "tb_write_image_f32 (use .png, .pfm or .exr)", rc);
     }
     printf("%s: %u triangles, %ux%u x %u spp, depth %d: %.2f ms on the GPU (%.1f Msamples/s), scene load + BVH %.2f s -> %s\n",
            scene.c_str(), info.numTriangles, W, H, spp, s.MaxBounces, ms, (double)W * H * spp / (ms * 1e3), loadS, out.c_str());

@@ -863,8 +863,9 @@ int tb_write_image_rgba8(const char* path, uint32_t W, uint32_t H, const uint8_t
 int tb_write_image_f32(const char* path, uint32_t W, uint32_t H, const float* rgba)
 {
     if (!path || !rgba || !W || !H) return TB_E_INVALID;
-    if (!hasSuffix(path, ".pfm")) return TB_E_UNSUPPORTED;
     std::string err;
+    if (hasSuffix(path, ".exr")) return tbhost::WriteExrRGBA(path, W, H, rgba, err) ? TB_OK : TB_E_IO;
+    if (!hasSuffix(path, ".pfm")) return TB_E_UNSUPPORTED;
     return tbhost::WritePfmRGB(path, W, H, rgba, err) ? TB_OK : TB_E_IO;
 }
 

@@ -53,6 +53,7 @@ void MakeProceduralScene(HostScene& out, int kind, uint32_t targetTriangles, uin
 /* images (images.cpp): Radiance RGBE .hdr and .pfm -> RGBA32F, top row first; PNG / PFM writers for the output stage */
 bool WritePngRGBA8(const std::string& file, uint32_t W, uint32_t H, const uint8_t* rgba, std::string& err);
 bool WritePfmRGB(const std::string& file, uint32_t W, uint32_t H, const float* rgba, std::string& err);
+bool WriteExrRGBA(const std::string& file, uint32_t W, uint32_t H, const float* rgba, std::string& err);
 bool LoadImageRGBA32F(const std::string& file, std::vector<TbFloat4>& texels, uint32_t& w, uint32_t& h, bool& normalizedFormat, std::string& err, bool* hasAlpha = nullptr);
 /* PNG / TGA (image_decode.cpp): texels as the DXGI typed load of what DirectXTex produces, top row first */
 struct DecodedImage { std::vector<TbFloat4> texels; uint32_t width = 0, height = 0; bool normalized = false, hasAlpha = false; };

@@ -214,4 +214,46 @@ bool WritePfmRGB(const std::string& file, uint32_t W, uint32_t H, const float* r
     return ok;
 }
 
+/* OpenEXR, the simplest conforming layout: single part, scan lines, no compression, four FLOAT channels (stored in the
+ * alphabetical order the format requires: A, B, G, R), increasing y.  Header = attributes "name\0type\0size value",
+ * then one 64-bit file offset per scan line, then per line {y, byte count, channel-planar pixels}. */
+bool WriteExrRGBA(const std::string& file, uint32_t W, uint32_t H, const float* rgba, std::string& err)
+{
+    std::vector<uint8_t> hd;
+    auto bytes = [&](const void* p, size_t n) { const uint8_t* b = (const uint8_t*)p; hd.insert(hd.end(), b, b + n); };
+    auto str = [&](const char* t) { bytes(t, strlen(t) + 1); };
+    auto i32 = [&](int32_t v) { bytes(&v, 4); };
+    auto f32 = [&](float v) { bytes(&v, 4); };
+    auto attr = [&](const char* name, const char* type, int32_t size) { str(name); str(type); i32(size); };
+    const uint32_t magic = 20000630u, version = 2u;
+    bytes(&magic, 4); bytes(&version, 4);
+    attr("channels", "chlist", 4 * 18 + 1);
+    for (const char* ch : {"A", "B", "G", "R"}) { str(ch); i32(2 /* FLOAT */); const uint8_t lin[4] = {0, 0, 0, 0}; bytes(lin, 4); i32(1); i32(1); }
+    hd.push_back(0);
+    attr("compression", "compression", 1); hd.push_back(0);
+    attr("dataWindow", "box2i", 16); i32(0); i32(0); i32((int32_t)W - 1); i32((int32_t)H - 1);
+    attr("displayWindow", "box2i", 16); i32(0); i32(0); i32((int32_t)W - 1); i32((int32_t)H - 1);
+    attr("lineOrder", "lineOrder", 1); hd.push_back(0);
+    attr("pixelAspectRatio", "float", 4); f32(1.0f);
+    attr("screenWindowCenter", "v2f", 8); f32(0.0f); f32(0.0f);
+    attr("screenWindowWidth", "float", 4); f32(1.0f);
+    hd.push_back(0);
+    FILE* f = fopen(file.c_str(), "wb");
+    if (!f) { err = "cannot open " + file + " for writing"; return false; }
+    const uint64_t lineBytes = 8 + 16ull * W, first = hd.size() + 8ull * H;
+    std::vector<uint64_t> table(H);
+    for (uint32_t y = 0; y < H; y++) table[y] = first + lineBytes * y;
+    bool ok = fwrite(hd.data(), 1, hd.size(), f) == hd.size() && fwrite(table.data(), 8, H, f) == H;
+    std::vector<float> line((size_t)W * 4);
+    for (uint32_t y = 0; y < H && ok; y++) {
+        const float* src = rgba + (size_t)y * W * 4;
+        for (uint32_t x = 0; x < W; x++) { line[x] = src[x * 4 + 3]; line[W + x] = src[x * 4 + 2]; line[2 * (size_t)W + x] = src[x * 4 + 1]; line[3 * (size_t)W + x] = src[x * 4]; }
+        const int32_t head[2] = {(int32_t)y, (int32_t)(16u * W)};
+        ok = fwrite(head, 4, 2, f) == 2 && fwrite(line.data(), 4, line.size(), f) == line.size();
+    }
+    fclose(f);
+    if (!ok) err = "short write to " + file;
+    return ok;
+}
+
 } // namespace tbhost
