@@ -225,6 +225,15 @@ def main():
                                       "sample": "scalar C++ oracle (oracle/tb_oracle.cpp, g++ -O2), the %dx%d frame x %d spp of %d, depth %d, %d threads over 8-row strips (%.1f s)"
                                                 % (W, H, frames, SPP, args.depth, cores, dt),
                                       "single_thread": round(W * rows1 / dt1 / 1e6, 4)}
+            if args.scene == "cornell-box":
+                # BASELINE.json configs[0], the reference's own CPU-runnable case, timed exactly: 512x512, 4 spp, depth 4
+                import copy
+                s0 = copy.copy(s); s0.MaxBounces = 4
+                pf0 = tb.FrameConstants(512, 512, 0, s0, 0.0)
+                t3 = time.perf_counter(); ol.render(view, pf0, 512, 512, 4, threads=cores); dt3 = time.perf_counter() - t3
+                t4 = time.perf_counter(); ol.render(view, pf0, 512, 512, 4, threads=1); dt4 = time.perf_counter() - t4
+                result["cpu_baseline"]["configs0"] = {"workload": "cornell-box 512x512 4spp depth4", "all_threads_s": round(dt3, 4), "single_thread_s": round(dt4, 3),
+                                                      "all_threads": round(512 * 512 * 4 / dt3 / 1e6, 3), "single_thread": round(512 * 512 * 4 / dt4 / 1e6, 4)}
         print(json.dumps(result))
     tb.close()
     if world > 1:
