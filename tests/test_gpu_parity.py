@@ -270,6 +270,30 @@ def test_all_kernel_variants_agree(gpu_tb, settings):
     gpu_tb.SetOption("pipeline", 0)
 
 
+@pytest.mark.parametrize("scene", ["cornell", "proc0", "proc1"])
+def test_occupancy_copies_agree(gpu_tb, settings, scene):
+    """The matte / env / vol feature sets exist twice: at the occupancy their registers allow and held to one more wave per SIMD
+    (pt_variant_{matte5,env5,vol4}.hip, picked when LDS has room for that many workgroups per CU; option high_occupancy).  Both
+    copies, in the one-pixel-per-lane form (3 frames) and the frame-group form (9 frames), against the oracle."""
+    if scene == "cornell": gpu_tb.LoadScene(CORNELL); variant = 0
+    elif scene == "proc0": gpu_tb.LoadProcedural(0, 20000, 3); variant = 1
+    else: gpu_tb.LoadProcedural(1, 30000, 7); variant = 3
+    W, H = 96, 64
+    s = copy.copy(settings); s.MaxBounces = 5
+    try:
+        for frames in (3, 9):
+            ref = None
+            for high in (1, 0):
+                gpu_tb.SetOption("high_occupancy", high); gpu_tb.InvalidateHistory()
+                gpu_tb.Render(W, H, frames, s, 0.0)
+                assert gpu_tb.GetOption("last_variant") == variant
+                out = gpu_tb.ReadAccumulation()
+                if ref is None: ref = _oracle(gpu_tb, W, H, frames, s)["output"]
+                assert np.array_equal(bits(out), bits(ref)), (frames, high)
+    finally:
+        gpu_tb.SetOption("high_occupancy", 1)
+
+
 @pytest.mark.parametrize("scene", ["cornell", "teapot", "proc0"])
 def test_wavefront_pipeline_bit_exact(gpu_tb, settings, scene):
     """SoA-queue wavefront pipeline (generate/extend/shade/connect kernels, ballot-prefix compaction, frames of a
