@@ -515,12 +515,14 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
         else {
             const uint64_t pixels = (uint64_t)W * H, budget = (uint64_t)opt("pooled_samples", 256ll << 20);
             const uint32_t batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(n, 32768), budget / pixels)); /* a slot entry holds 15 bits of relative frame */
-            /* automatic group size: about 49 152 work items per launch -- fine enough that the last items end together, coarse
-             * enough that claiming them does not show (measured on 1080p, scripts/frame_group_sweep.py: Cornell x 64 frames best
-             * at G = 8-16 on the whole frame and 2-4 on an eighth of it; 870 k triangles x 16 frames best at G = 2-4) */
+            /* automatic group size: about 24 576 work items per launch, rounded down to a power of two -- fine enough that the last
+             * items end together, coarse enough that claiming them does not show.  Measured on 1080p with launches enqueued back
+             * to back (bench.py): Cornell x 64 frames 6 370 / 6 730 / 6 870 / 6 910 / 6 850 Msamples/s at G = 4 / 8 / 16 / 32 / 64 (the
+             * rule gives 16), 870 k triangles x 16 frames 4 010 / 4 000 / 3 910 / 3 740 at G = 2 / 4 / 8 / 16 (the rule gives 4); an
+             * eighth of the frame (one rank of eight) is best at 2-4 */
             const uint64_t regions = std::max<uint64_t>(1, tb_persistent_grid(W, H, c->tiles));
             const uint32_t frames = std::min(batch, n);
-            const uint32_t autoG = (uint32_t)std::min<uint64_t>(frames, std::max<uint64_t>(1, ((uint64_t)frames * regions + 49151) / 49152));
+            const uint32_t autoG = (uint32_t)std::min<uint64_t>(frames, std::max<uint64_t>(1, ((uint64_t)frames * regions + 24575) / 24576));
             ensure(c->workCounter, 1024);
             tg.frameGroup = fg > 0 ? (uint32_t)fg : autoG;
             while (tg.frameGroup & (tg.frameGroup - 1)) tg.frameGroup &= tg.frameGroup - 1; /* a power of two (rounded down): samples find their frame with shifts */
