@@ -8,7 +8,9 @@ export TMPDIR=/tmp
 TAG=${TAG:-r1}
 OUT=gpurun_out/$TAG
 rm -rf $OUT; mkdir -p $OUT
-ARGS="--steps 3 --warmup 1 --no-cpu-baseline ${BENCH_ARGS:-}"
+# --sync-steps: one launch at a time, so that a kernel's duration in the trace is its own (bench.py's default overlaps the launches of
+# consecutive steps; its roofline block times non-overlapped launches the same way)
+ARGS="--steps 3 --warmup 1 --no-cpu-baseline --sync-steps ${BENCH_ARGS:-}"
 python3 bench.py $ARGS > $OUT/bench_plain.json 2> $OUT/bench_plain.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python3 bench.py $ARGS > $OUT/bench_trace.json 2> $OUT/trace.err
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o fetch -- python3 bench.py $ARGS > $OUT/bench_fetch.json 2> $OUT/fetch.err

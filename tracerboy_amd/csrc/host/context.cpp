@@ -532,16 +532,14 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
                 c->sideOrdered = true;
             }
             /* The kernel copies held to an occupancy keep a few registers in scratch, and the runtime sizes a queue's scratch at the
-             * first such dispatch on that queue (tens of ms, once per stream).  The first render with a given kernel therefore
-             * runs one frame group of it on BOTH side streams first, so that the one-off cost falls into that first call and not
-             * into whichever later call happens to reach the second stream. */
+             * first dispatch on that queue that needs it (milliseconds, once per stream).  The first render with a given kernel
+             * therefore sends a zero-frame launch of its one-pixel-per-lane form (same feature set, at least as much scratch, a
+             * full grid of workgroups that exit at once) down BOTH side streams, so that the one-off cost falls into that first
+             * call and not into whichever later call happens to reach the second stream. */
             if (overlap && std::find(c->warmedLaunchers.begin(), c->warmedLaunchers.end(), (const void*)launch) == c->warmedLaunchers.end()) {
-                for (uint32_t par = 0; par < 2; par++) {
-                    if (c->fgSamples[par].bytes < pixels * batch * 16) ensure(c->fgSamples[par], pixels * batch * 16);
-                    tg.samples = (TbFloat4*)c->fgSamples[par].p; tg.workCounter = (uint32_t*)c->workCounter.p + par * 128u;
-                    HIP_TRY(hipStreamWaitEvent(c->side[par], c->evFold[par], 0));
-                    HIP_TRY(launch(c->side[par], &c->ds, &pf, &tg, W, H, c->samplesRendered, std::min<uint32_t>(tg.frameGroup, n), &c->tiles, c->sceneInLds ? 1 : 0, 0, 0));
-                }
+                TbDeviceTargets none = tg; none.samples = nullptr;
+                for (uint32_t par = 0; par < 2; par++)
+                    HIP_TRY(launch(c->side[par], &c->ds, &pf, &none, W, H, c->samplesRendered, 0, &c->tiles, c->sceneInLds ? 1 : 0, 0, 0));
                 c->warmedLaunchers.push_back((const void*)launch);
             }
             for (uint32_t f0 = 0; f0 < n; f0 += batch) {
