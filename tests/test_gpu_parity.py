@@ -294,6 +294,26 @@ def test_occupancy_copies_agree(gpu_tb, settings, scene):
         gpu_tb.SetOption("high_occupancy", 1)
 
 
+@pytest.mark.parametrize("scene", ["proc0", "proc1"])
+def test_split_traversal_stack_bit_exact(gpu_tb, settings, scene):
+    """Trees too deep for the LDS share of a higher-occupancy kernel copy keep the first entries of the traversal stack in LDS
+    and the deepest ones in global memory (HYBRID kernels, frame-group launches).  Forced here with a tiny LDS part
+    (stack_lds_cap = 3, so that nearly every ray overflows) on the env and vol feature sets, against the oracle."""
+    if scene == "proc0": gpu_tb.LoadProcedural(0, 20000, 3); variant = 1
+    else: gpu_tb.LoadProcedural(1, 30000, 7); variant = 3
+    W, H, F = 96, 64, 9
+    s = copy.copy(settings); s.MaxBounces = 5
+    try:
+        gpu_tb.SetOption("stack_lds_cap", 3); gpu_tb.SetOption("stack_overflow_max", 64)
+        gpu_tb.Render(W, H, F, s, 0.0)
+        assert gpu_tb.GetOption("last_variant") == variant
+        out = gpu_tb.ReadAccumulation()
+        ref = _oracle(gpu_tb, W, H, F, s)["output"]
+        assert np.array_equal(bits(out), bits(ref))
+    finally:
+        gpu_tb.SetOption("stack_lds_cap", 0); gpu_tb.SetOption("stack_overflow_max", 16)
+
+
 @pytest.mark.parametrize("scene", ["cornell", "teapot", "proc0"])
 def test_wavefront_pipeline_bit_exact(gpu_tb, settings, scene):
     """SoA-queue wavefront pipeline (generate/extend/shade/connect kernels, ballot-prefix compaction, frames of a

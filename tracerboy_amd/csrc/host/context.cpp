@@ -74,6 +74,7 @@ struct tb_context {
     hipStream_t side[2] = {nullptr, nullptr};
     hipEvent_t evPt[2] = {nullptr, nullptr}, evFold[2] = {nullptr, nullptr}, evMain = nullptr;
     DevBuf fgSamples[2];
+    DevBuf stackOverflow; /* split traversal stack of the higher-occupancy kernel copies on deep trees (pt_scene.h) */
     std::vector<const void*> warmedLaunchers; /* frame-group kernels that have run once on both side streams (renderImpl) */
     uint32_t fgLaunch = 0; bool sideOrdered = false; /* sideOrdered: the side streams have been ordered after everything else on `stream` */
     uint32_t lastKernelFrames = 0; float lastKernelMs = 0.0f;
@@ -486,15 +487,33 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
     if (!v) v = &kVariants[4];
     c->lastVariant = v->name;
     const int variantIndex = (int)(v - kVariants);
-    pt_variant_fn launch = v->fn;
-    {
-        const size_t ldsPerGroup = ((size_t)c->ds.stackDepth * 1024 + (c->sceneInLds ? c->ds.ldsBlobBytes : 0) + 128 + 511) / 512 * 512; /* + static LDS, 512-B granules */
-        if (v->fnHi && opt("pipeline", 0) == 0 && !count && opt("high_occupancy", 1) != 0 && ldsPerGroup * v->wavesHi <= 160 * 1024) launch = v->fnHi;
-    }
     const bool wavefront = opt("pipeline", 0) == 2 && variantIndex <= 2 && !count && !aov;
     const bool pooled = opt("pipeline", 0) == 3 && variantIndex <= 2 && !count && !aov;
     const int64_t fg = opt("frame_group", 0);
     const bool groups = !wavefront && !pooled && opt("pipeline", 0) == 0 && !count && !aov && !s.RenderModeRealTime && fg >= 0 && (fg > 0 || n >= 8);
+    /* Which copy of the feature set: the higher-occupancy one when its workgroups fit in LDS.  LDS per workgroup = 1 KB per stack
+     * entry (+ the scene image); where the tree is too deep for that, a frame-group launch may still use the copy with a split
+     * stack -- as many entries in LDS as fit, the deepest few (option "stack_overflow_max", default 16) in global memory. */
+    pt_variant_fn launch = v->fn;
+    TbDeviceScene dsLaunch = c->ds; dsLaunch.stackOverflow = nullptr; dsLaunch.stackOverflowLanes = 0;
+    if (v->fnHi && opt("pipeline", 0) == 0 && !count && opt("high_occupancy", 1) != 0) {
+        const size_t share = (160 * 1024 / v->wavesHi) / 512 * 512, fixed = (c->sceneInLds ? c->ds.ldsBlobBytes : 0) + 128;
+        const size_t ldsPerGroup = ((size_t)c->ds.stackDepth * 1024 + fixed + 511) / 512 * 512; /* + static LDS, 512-B granules */
+        const int64_t forcedCap = opt("stack_lds_cap", 0); /* tests: split the stack although it would fit */
+        if (ldsPerGroup <= share && !(forcedCap > 0 && groups && !c->sceneInLds && (uint32_t)forcedCap < c->ds.stackDepth)) launch = v->fnHi;
+        else if (groups && !c->sceneInLds && share > fixed + 4 * 1024) {
+            uint32_t cap = (uint32_t)((share - fixed) / 1024);
+            if (forcedCap > 0) cap = std::min<uint32_t>(cap, (uint32_t)forcedCap);
+            const uint32_t over = c->ds.stackDepth > cap ? c->ds.stackDepth - cap : 0;
+            if (over > 0 && over <= (uint32_t)opt("stack_overflow_max", 16)) {
+                int numCUs = 0; HIP_TRY(hipDeviceGetAttribute(&numCUs, hipDeviceAttributeMultiprocessorCount, c->device));
+                const uint32_t lanes = 2u * 8u * (uint32_t)numCUs * 256u; /* the resident grid is at most 2 x 8 workgroups per CU */
+                ensure(c->stackOverflow, (size_t)over * lanes * 4);
+                dsLaunch.stackDepth = cap; dsLaunch.stackOverflow = (uint32_t*)c->stackOverflow.p; dsLaunch.stackOverflowLanes = lanes;
+                launch = v->fnHi;
+            }
+        }
+    }
     /* launches of the kernels without the EXT features (no selected pixel, no AOVs: nothing but the sample buffer is written)
      * may overlap the drain of the launch before them */
     const bool overlap = groups && variantIndex != 4 && opt("overlap_launches", 1) != 0;
@@ -511,7 +530,7 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
          * to an ordered sample buffer and accumulate_samples_kernel folds them in frame order (bit-identical sums).  Keeps all
          * lanes of a workgroup busy to its end and gives a rank of a tile split enough workgroups; on whenever a call renders
          * enough frames to form groups.  Option "frame_group" = G > 0 forces the group size, < 0 forbids the mode. */
-        if (!groups) HIP_TRY(launch(c->stream, &c->ds, &pf, &tg, W, H, c->samplesRendered, n, &c->tiles, c->sceneInLds ? 1 : 0, count ? 1 : 0, (int)opt("pipeline", 0)));
+        if (!groups) HIP_TRY(launch(c->stream, &dsLaunch, &pf, &tg, W, H, c->samplesRendered, n, &c->tiles, c->sceneInLds ? 1 : 0, count ? 1 : 0, (int)opt("pipeline", 0)));
         else {
             const uint64_t pixels = (uint64_t)W * H, budget = (uint64_t)opt("pooled_samples", 256ll << 20);
             const uint32_t batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(n, 32768), budget / pixels)); /* a slot entry holds 15 bits of relative frame */
@@ -549,7 +568,7 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
                 tg.samples = (TbFloat4*)c->fgSamples[par].p; tg.workCounter = (uint32_t*)c->workCounter.p + par * 128u;
                 if (overlap) HIP_TRY(hipStreamWaitEvent(ptStream, c->evFold[par], 0)); /* the fold that last read this sample buffer */
                 if (f0 == 0) { if (clearStats && overlap) HIP_TRY(hipMemsetAsync(c->stats.p, 0, 16, ptStream)); HIP_TRY(hipEventRecord(c->evKernelStart, ptStream)); }
-                HIP_TRY(launch(ptStream, &c->ds, &pf, &tg, W, H, c->samplesRendered + f0, nf, &c->tiles, c->sceneInLds ? 1 : 0, 0, 0));
+                HIP_TRY(launch(ptStream, &dsLaunch, &pf, &tg, W, H, c->samplesRendered + f0, nf, &c->tiles, c->sceneInLds ? 1 : 0, 0, 0));
                 if (f0 == 0) { HIP_TRY(hipEventRecord(c->evKernel, ptStream)); c->lastKernelFrames = nf; }
                 if (overlap) { HIP_TRY(hipEventRecord(c->evPt[par], ptStream)); HIP_TRY(hipStreamWaitEvent(c->stream, c->evPt[par], 0)); }
                 HIP_TRY(pt_launch_accumulate_samples(c->stream, tg.samples, W, H, c->samplesRendered + f0, nf, &c->tiles, tg.output, tg.jittered));
@@ -604,7 +623,7 @@ void tb_destroy(tb_context* c)
     c->output.release(); c->jittered.release(); c->stats.release(); c->rayStats.release(); c->packed.release();
     for (int q = 0; q < 2; q++) for (DevBuf& b : c->wfCols[q]) b.release();
     for (DevBuf& b : c->wfShadowCols) b.release();
-    c->wfHitA.release(); c->wfHitG.release(); c->wfSamples.release(); c->wfCounts.release(); c->workCounter.release(); c->fgSamples[0].release(); c->fgSamples[1].release();
+    c->wfHitA.release(); c->wfHitG.release(); c->wfSamples.release(); c->wfCounts.release(); c->workCounter.release(); c->fgSamples[0].release(); c->fgSamples[1].release(); c->stackOverflow.release();
     c->postOut.release(); c->postRgba8.release(); c->postHistogram.release(); c->postAverage.release();
     for (int i = 0; i < 2; i++) { c->rtIndirect[i].release(); c->rtMoment[i].release(); c->rtFinal[i].release(); c->rtDenoise[i].release(); }
     c->rtComposited.release();
@@ -961,7 +980,7 @@ int tb_unpack_gathered_host(uint32_t W, uint32_t H, uint32_t world, uint32_t tw,
 int tb_set_option(tb_context* c, const char* name, int64_t v)
 {
     if (!c || !name) return TB_E_INVALID;
-    static const char* known[] = {"pipeline", "count_rays", "bvh_builder", "flatten_instances", "aov", "scene_in_lds", "lds_scene_budget", "force_full_variant", "wavefront_paths", "wavefront_grid", "wavefront_segment", "pooled_paths", "pooled_samples", "pooled_profile", "park_min", "alpha_test", "node_order", "node_order_top_levels", "frame_group", "overlap_launches", "high_occupancy"};
+    static const char* known[] = {"pipeline", "count_rays", "bvh_builder", "flatten_instances", "aov", "scene_in_lds", "lds_scene_budget", "force_full_variant", "wavefront_paths", "wavefront_grid", "wavefront_segment", "pooled_paths", "pooled_samples", "pooled_profile", "park_min", "alpha_test", "node_order", "node_order_top_levels", "frame_group", "overlap_launches", "high_occupancy", "stack_lds_cap", "stack_overflow_max"};
     for (const char* k : known) if (!strcmp(k, name)) { c->options[name] = v; if (!strcmp(name, "count_rays") || !strcmp(name, "aov")) c->samplesRendered = 0; return TB_OK; }
     return fail(c, TB_E_INVALID, std::string("unknown option '") + name + "'");
 }

@@ -234,9 +234,9 @@ TBD void prof_hit(WaveProf* p, int slot)
     if ((int)(threadIdx.x & 63u) == __ffsll((long long)m) - 1) p->v[slot + 1] += 1; /* wave trips */
 }
 
-template <bool COUNT>
+template <bool COUNT, bool HYBRID = false>
 TBD bool traverse(const SceneRefs& sc, const TbDeviceScene& ds, tb3 o, tb3 d, Hit& best, uint32_t* stack, uint32_t stride,
-                  uint32_t& boxes, uint32_t& tris, WaveProf* prof = nullptr)
+                  uint32_t& boxes, uint32_t& tris, WaveProf* prof = nullptr, uint32_t* overflow = nullptr)
 {
     best.t = MAX_T; best.u = best.v = 0.0f; best.prim = best.geom = 0u;
     RayPre r = ray_prepare(o, d);
@@ -250,6 +250,12 @@ TBD bool traverse(const SceneRefs& sc, const TbDeviceScene& ds, tb3 o, tb3 d, Hi
     const int PARK_MIN = (int)ds.parkMin; /* option "park_min", default 8 */
     uint32_t top = 0;
     uint32_t ref = ds.rootRef;
+    auto pop = [&]() -> uint32_t {
+        if (!top) return DONE;
+        --top;
+        if (HYBRID && top >= ds.stackDepth) return overflow[(size_t)(top - ds.stackDepth) * ds.stackOverflowLanes];
+        return stack[top * stride];
+    };
     while (ref != DONE) {
         while (!(ref & TB_BVH_LEAF_FLAG)) {
             if (COUNT) prof_hit(prof, PROF_INNER);
@@ -259,12 +265,16 @@ TBD bool traverse(const SceneRefs& sc, const TbDeviceScene& ds, tb3 o, tb3 d, Hi
             if (COUNT) boxes += 2;
             if (lh && rh) {
                 bool rightFirst = rt < lt;
-                stack[(top++) * stride] = rightFirst ? n.left : n.right;
+                const uint32_t far = rightFirst ? n.left : n.right;
+                /* HYBRID: the first ds.stackDepth entries in LDS, deeper ones (rare) in the lane's global overflow column */
+                if (HYBRID && top >= ds.stackDepth) overflow[(size_t)(top - ds.stackDepth) * ds.stackOverflowLanes] = far;
+                else stack[top * stride] = far;
+                top++;
                 ref = rightFirst ? n.right : n.left;
             } else if (lh || rh) {
                 ref = rh ? n.right : n.left;
             } else {
-                ref = top ? stack[(--top) * stride] : DONE;
+                ref = pop();
             }
             if (__popcll(__ballot(!(ref & TB_BVH_LEAF_FLAG))) < PARK_MIN) break;
         }
@@ -273,7 +283,7 @@ TBD bool traverse(const SceneRefs& sc, const TbDeviceScene& ds, tb3 o, tb3 d, Hi
             const TbTriB tri = load_tri(sc, sc.trisPermuted ? ref + r.permUnits : ref);
             if (COUNT) tris++;
             tri_test<COUNT>(best, MIN_T, o, r, tri, sc.trisPermuted != 0, sc, ds);
-            ref = top ? stack[(--top) * stride] : DONE;
+            ref = pop();
         }
     }
     return best.t < MAX_T;

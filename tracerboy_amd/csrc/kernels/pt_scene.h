@@ -43,7 +43,11 @@ struct TbDeviceScene {
     TbConfigConstants config;
     uint32_t alphaTest;          /* option "alpha_test": IsValidHit filter on candidate hits of non-opaque geometry (full variant only) */
     uint32_t parkMin;            /* while-while scheduling of traverse(): leave the inner-node loop when fewer lanes than this still descend */
-    uint32_t stackDepth;         /* entries per lane of the traversal stack (bvh max depth + 2) */
+    uint32_t stackDepth;         /* entries per lane of the traversal stack held in LDS (= bvh max depth, unless the stack is split) */
+    /* split stack (HYBRID kernels, frame-group launches of the higher-occupancy copies on trees too deep for their LDS share):
+     * entries >= stackDepth live in global memory, entry e of lane L at stackOverflow[(e - stackDepth) * stackOverflowLanes + L],
+     * L = blockIdx.x * 256 + threadIdx.x */
+    uint32_t* stackOverflow;     uint32_t stackOverflowLanes;
     /* whole-scene-in-LDS image (small scenes): byte offsets inside one contiguous device blob */
     const uint8_t* ldsBlob;      uint32_t ldsBlobBytes;
     uint32_t offNodes, offTris, offHitGroups, offIndices, offVertices, offMaterials, offLights;
