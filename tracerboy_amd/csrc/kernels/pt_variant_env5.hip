@@ -1,9 +1,14 @@
-/* pt_variant_env5.hip -- feature set "env" at 5 waves per SIMD (96 VGPRs, about ten registers in scratch), pipeline 0 only.
- * Chosen when five workgroups per CU fit in LDS (traversal stack <= 31 entries): 870 k-triangle scene +10 %. */
+/* pt_variant_env5.hip -- feature set "env" at a higher occupancy, pipeline 0 only (the file name is historical: it began at 5 waves
+ * per SIMD).  Measured on the 870 k-triangle scene, 1080p x 16 spp: 4 waves 9.1 ms (wait after every render 9.97), 5 waves 8.27,
+ * 6 waves 7.99 (80 VGPRs, ~40 registers in scratch, the last 5 of its 31 stack levels in global memory), 7 waves 8.20, 8 waves 8.62.
+ * Chosen when six workgroups per CU fit in LDS, with a split stack (pt_scene.h) when the tree is deeper than the 26-entry share. */
 #include "pt_device_features.h"
 #define PT_FEATURES (PT_FEAT_ENV)
 #define PT_NAME env5
 #define PT_COUNT 0
 #define PT_ONLY_PERSISTENT 1
-#define PT_PERSISTENT_ATTR __attribute__((amdgpu_waves_per_eu(5)))
+#ifndef TB_ENV_HI_WAVES
+#define TB_ENV_HI_WAVES 6
+#endif
+#define PT_PERSISTENT_ATTR __attribute__((amdgpu_waves_per_eu(TB_ENV_HI_WAVES)))
 #include "pt_variant.inc"
