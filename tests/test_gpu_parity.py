@@ -294,12 +294,14 @@ def test_occupancy_copies_agree(gpu_tb, settings, scene):
         gpu_tb.SetOption("high_occupancy", 1)
 
 
-@pytest.mark.parametrize("scene", ["proc0", "proc1"])
+@pytest.mark.parametrize("scene", ["cornell", "proc0", "proc1"])
 def test_split_traversal_stack_bit_exact(gpu_tb, settings, scene):
     """Trees too deep for the LDS share of a higher-occupancy kernel copy keep the first entries of the traversal stack in LDS
     and the deepest ones in global memory (HYBRID kernels, frame-group launches).  Forced here with a tiny LDS part
-    (stack_lds_cap = 3, so that nearly every ray overflows) on the env and vol feature sets, against the oracle."""
-    if scene == "proc0": gpu_tb.LoadProcedural(0, 20000, 3); variant = 1
+    (stack_lds_cap = 3, so that nearly every ray overflows) on the matte (scene image in LDS), env and vol feature sets, against
+    the oracle."""
+    if scene == "cornell": gpu_tb.LoadScene(CORNELL); variant = 0
+    elif scene == "proc0": gpu_tb.LoadProcedural(0, 20000, 3); variant = 1
     else: gpu_tb.LoadProcedural(1, 30000, 7); variant = 3
     W, H, F = 96, 64, 9
     s = copy.copy(settings); s.MaxBounces = 5

@@ -51,7 +51,10 @@ const wf_variant_fn kWfVariants[3] = {wf_launch_matte, wf_launch_env, wf_launch_
  * has room for that many workgroups per CU -- otherwise its spills would buy no residency */
 struct Variant { uint32_t features; pt_variant_fn fn; const char* name; pt_variant_fn fnHi; uint32_t wavesHi; };
 const Variant kVariants[] = {
-    {0u, pt_launch_persistent_matte, "matte", pt_launch_persistent_matte5, 5},
+#ifndef TB_MATTE_HI_WAVES
+#define TB_MATTE_HI_WAVES 5
+#endif
+    {0u, pt_launch_persistent_matte, "matte", pt_launch_persistent_matte5, TB_MATTE_HI_WAVES},
     #ifndef TB_ENV_HI_WAVES
 #define TB_ENV_HI_WAVES 6
 #endif
@@ -506,8 +509,8 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
         const size_t share = (160 * 1024 / v->wavesHi) / 512 * 512, fixed = (c->sceneInLds ? c->ds.ldsBlobBytes : 0) + 128;
         const size_t ldsPerGroup = ((size_t)c->ds.stackDepth * 1024 + fixed + 511) / 512 * 512; /* + static LDS, 512-B granules */
         const int64_t forcedCap = opt("stack_lds_cap", 0); /* tests: split the stack although it would fit */
-        if (ldsPerGroup <= share && !(forcedCap > 0 && groups && !c->sceneInLds && (uint32_t)forcedCap < c->ds.stackDepth)) launch = v->fnHi;
-        else if (groups && !c->sceneInLds && share > fixed + 4 * 1024) {
+        if (ldsPerGroup <= share && !(forcedCap > 0 && groups && (uint32_t)forcedCap < c->ds.stackDepth)) launch = v->fnHi;
+        else if (groups && share > fixed + 4 * 1024) {
             uint32_t cap = (uint32_t)((share - fixed) / 1024);
             if (forcedCap > 0) cap = std::min<uint32_t>(cap, (uint32_t)forcedCap);
             const uint32_t over = c->ds.stackDepth > cap ? c->ds.stackDepth - cap : 0;
