@@ -51,7 +51,7 @@ def pmc_traffic_bytes(args, world):
     for name, passes in json.load(open(files[-1])).items():
         # pt_persistent<F, LDS, COUNT, GROUPS>: not the counters-on launch (COUNT = true), not the sample fold; the frame-group
         # kernel (GROUPS = true) is the timed one -- its one-pixel-per-lane twin only appears as the zero-frame warm launch
-        m = re.search(r"pt_persistent<\d+u, (true|false), (true|false), (true|false)>", name)
+        m = re.search(r"pt_persistent<\d+u, (true|false), (true|false), (true|false)(?:, (?:true|false))?>", name)  # <F, LDS, COUNT, GROUPS[, HYBRID]>
         if not m or m.group(2) == "true" or "fetch" not in passes or "write" not in passes:
             continue
         traffic = int((2.0 * passes["fetch"]["FETCH_SIZE"] + passes["write"]["WRITE_SIZE"]) * 1024)
