@@ -570,6 +570,14 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
                     HIP_TRY(launch(c->side[par], &c->ds, &pf, &none, W, H, c->samplesRendered, 0, &c->tiles, c->sceneInLds ? 1 : 0, 0, 0));
                 c->warmedLaunchers.push_back((const void*)launch);
             }
+            /* both sample buffers are sized -- and touched once, a fresh allocation is mapped lazily -- by the first call that needs
+             * them, not by the call that first reaches the second one */
+            for (uint32_t par = 0; par < 2u; par++)
+                if (c->fgSamples[par].bytes < pixels * batch * 16) {
+                    HIP_TRY(hipStreamSynchronize(c->side[par])); HIP_TRY(hipStreamSynchronize(c->stream)); /* nobody reads the old one any more */
+                    ensure(c->fgSamples[par], pixels * batch * 16);
+                    HIP_TRY(hipMemsetAsync(c->fgSamples[par].p, 0, pixels * batch * 16, overlap ? c->side[par] : c->stream));
+                }
             for (uint32_t f0 = 0; f0 < n; f0 += batch) {
                 const uint32_t nf = std::min(batch, n - f0), par = c->fgLaunch++ & 1u;
                 hipStream_t ptStream = overlap ? c->side[par] : c->stream;
