@@ -98,6 +98,7 @@ TBD RayPre ray_prepare(tb3 o, tb3 d) /* GetRayData, TraverseFunction.hlsli:473-4
 {
     RayPre r;
     r.inv = tb3_make(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const tb3 inv0 = r.inv; /* before the degenerate-axis substitution: 1 / d[kz] below is one of these three quotients */
     r.oinv = o * r.inv; r.ainv = tb3_abs(r.inv);
     if (d.x == 0.0f) { r.inv.x = TB_DEGEN_INV; r.ainv.x = TB_DEGEN_AINV; r.oinv.x = o.x * TB_DEGEN_INV; }
     if (d.y == 0.0f) { r.inv.y = TB_DEGEN_INV; r.ainv.y = TB_DEGEN_AINV; r.oinv.y = o.y * TB_DEGEN_INV; }
@@ -111,7 +112,7 @@ TBD RayPre ray_prepare(tb3 o, tb3 d) /* GetRayData, TraverseFunction.hlsli:473-4
     r.operm = tb3_make(tb3_get(o, kx), tb3_get(o, ky), tb3_get(o, z)); /* for the axis-permuted triangle copies */
     r.permUnits = (uint32_t)(z * 2 + (dz < 0.0f ? 1 : 0)) * 3u;        /* copy index * 48 B / 16 */
     r.o = o;
-    r.shear = tb3_make(tb3_get(d, kx) / dz, tb3_get(d, ky) / dz, 1.0f / dz);
+    r.shear = tb3_make(tb3_get(d, kx) / dz, tb3_get(d, ky) / dz, tb3_get(inv0, z)); /* Shear.z = 1 / d[kz]: the same division as inv0[kz], not repeated */
     return r;
 }
 
