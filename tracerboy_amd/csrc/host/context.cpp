@@ -51,19 +51,10 @@ const wf_variant_fn kWfVariants[3] = {wf_launch_matte, wf_launch_env, wf_launch_
  * has room for that many workgroups per CU -- otherwise its spills would buy no residency */
 struct Variant { uint32_t features; pt_variant_fn fn; const char* name; pt_variant_fn fnHi; uint32_t wavesHi; };
 const Variant kVariants[] = {
-#ifndef TB_MATTE_HI_WAVES
-#define TB_MATTE_HI_WAVES 5
-#endif
-    {0u, pt_launch_persistent_matte, "matte", pt_launch_persistent_matte5, TB_MATTE_HI_WAVES},
-    #ifndef TB_ENV_HI_WAVES
-#define TB_ENV_HI_WAVES 6
-#endif
-    {PT_FEAT_ENV, pt_launch_persistent_env, "env", pt_launch_persistent_env5, TB_ENV_HI_WAVES},
+    {0u, pt_launch_persistent_matte, "matte", pt_launch_persistent_matte5, 5},
+        {PT_FEAT_ENV, pt_launch_persistent_env, "env", pt_launch_persistent_env5, 6},
     {PT_FEAT_ENV | PT_FEAT_SPECULAR | PT_FEAT_TEXTURES, pt_launch_persistent_surf, "surf", nullptr, 0},
-    #ifndef TB_VOL_HI_WAVES
-#define TB_VOL_HI_WAVES 4
-#endif
-    {PT_FEAT_ENV | PT_FEAT_SPECULAR | PT_FEAT_TEXTURES | PT_FEAT_SSS | PT_FEAT_MIX, pt_launch_persistent_vol, "vol", pt_launch_persistent_vol4, TB_VOL_HI_WAVES},
+        {PT_FEAT_ENV | PT_FEAT_SPECULAR | PT_FEAT_TEXTURES | PT_FEAT_SSS | PT_FEAT_MIX, pt_launch_persistent_vol, "vol", pt_launch_persistent_vol4, 4},
     {PT_FEAT_ALL, pt_launch_persistent_full, "full", nullptr, 0},
 };
 

@@ -7,8 +7,5 @@
 #define PT_NAME env5
 #define PT_COUNT 0
 #define PT_ONLY_PERSISTENT 1
-#ifndef TB_ENV_HI_WAVES
-#define TB_ENV_HI_WAVES 6
-#endif
-#define PT_PERSISTENT_ATTR __attribute__((amdgpu_waves_per_eu(TB_ENV_HI_WAVES)))
+#define PT_PERSISTENT_ATTR __attribute__((amdgpu_waves_per_eu(6))) /* keep in step with kVariants[].wavesHi, context.cpp */
 #include "pt_variant.inc"

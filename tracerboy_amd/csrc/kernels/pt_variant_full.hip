@@ -3,8 +3,6 @@
 #define PT_FEATURES (PT_FEAT_ALL)
 #define PT_NAME full
 #define PT_COUNT 1
-#ifndef TB_FULL_WAVES
-#define TB_FULL_WAVES 3 /* 231-250 VGPRs (2 waves per SIMD) held to 168 + scratch: +27 % on cornell-box and the 870 k scene with every feature on */
-#endif
-#define PT_PERSISTENT_ATTR __attribute__((amdgpu_waves_per_eu(TB_FULL_WAVES)))
+/* 231-250 VGPRs (2 waves per SIMD) held to 168 + scratch: +27 % on cornell-box and the 870 k scene with every feature on; 4 waves lose */
+#define PT_PERSISTENT_ATTR __attribute__((amdgpu_waves_per_eu(3)))
 #include "pt_variant.inc"

@@ -3,8 +3,6 @@
 #define PT_FEATURES (PT_FEAT_ENV | PT_FEAT_SPECULAR | PT_FEAT_TEXTURES)
 #define PT_NAME surf
 #define PT_COUNT 0
-#ifndef TB_SURF_WAVES
-#define TB_SURF_WAVES 3
-#endif
-#define PT_PERSISTENT_ATTR __attribute__((amdgpu_waves_per_eu(TB_SURF_WAVES)))
+/* 168 VGPRs + scratch; Teapot 1080p: 2 690 Msamples/s at 3 waves per SIMD, 2 500 at 4 */
+#define PT_PERSISTENT_ATTR __attribute__((amdgpu_waves_per_eu(3)))
 #include "pt_variant.inc"

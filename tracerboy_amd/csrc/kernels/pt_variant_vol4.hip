@@ -5,8 +5,5 @@
 #define PT_NAME vol4
 #define PT_COUNT 0
 #define PT_ONLY_PERSISTENT 1
-#ifndef TB_VOL_HI_WAVES
-#define TB_VOL_HI_WAVES 4
-#endif
-#define PT_PERSISTENT_ATTR __attribute__((amdgpu_waves_per_eu(TB_VOL_HI_WAVES)))
+#define PT_PERSISTENT_ATTR __attribute__((amdgpu_waves_per_eu(4))) /* keep in step with kVariants[].wavesHi, context.cpp */
 #include "pt_variant.inc"
