@@ -19,7 +19,7 @@ OBJ = os.path.join(ROOT, "_build")
 LIB = os.path.join(ROOT, "libtracerboy_hip.so")
 CLI = os.path.join(ROOT, "tracerboy-hip")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-ARCH = "gfx950"
+ARCH = os.environ.get("TB_ARCH", "gfx950")  # e.g. gfx950:xnack- for experiments
 
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function",
           "-Wno-unused-variable", "-Wno-unused-but-set-variable", "-I" + os.path.join(REPO, "include")] + os.environ.get("TB_EXTRA_FLAGS", "").split()
