@@ -643,3 +643,33 @@ def test_material_edit_and_errors(gpu_tb, settings):
     with pytest.raises(api.TracerBoyError):
         gpu_tb.LoadScene("/nonexistent/scene.pbrt")
     gpu_tb.LoadScene(CORNELL)
+
+
+def test_headless_cli_writes_the_library_result(gpu_tb, settings, tmp_path):
+    """tracerboy-hip (cli.cpp, C ABI only): renders cornell-box with the GPU-built treelet tree and writes linear radiance as
+    OpenEXR and the tonemapped back buffer as PNG; the EXR pixels are the library's accumulation divided by its weight."""
+    import struct, subprocess
+    from tracerboy_amd import api
+    cli = os.path.join(os.path.dirname(api.__file__), "tracerboy-hip")
+    W, H, F = 64, 48, 9
+    exr, png = str(tmp_path / "o.exr"), str(tmp_path / "o.png")
+    for out in (exr, png):
+        r = subprocess.run([cli, CORNELL, "--width", str(W), "--height", str(H), "--spp", str(F), "--depth", "4", "--blue-noise", "0",
+                            "--builder", "treelets-gpu", "--out", out], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+    assert open(png, "rb").read(8) == b"\x89PNG\r\n\x1a\n"
+    b = open(exr, "rb").read()
+    assert struct.unpack_from("<I", b, 0)[0] == 20000630
+    start = len(b) - H * (8 + 16 * W)                     # H scan-line blocks of {y, bytes, A B G R planes} close the file
+    px = np.stack([np.frombuffer(b, np.float32, 4 * W, start + y * (8 + 16 * W) + 8).reshape(4, W) for y in range(H)])   # [y][A B G R][x]
+    s = copy.copy(settings); s.MaxBounces = 4
+    gpu_tb.SetOption("bvh_builder", 4)
+    try:
+        gpu_tb.LoadScene(CORNELL); gpu_tb.Render(W, H, F, s, 0.0)
+        acc = gpu_tb.ReadAccumulation()
+    finally:
+        gpu_tb.SetOption("bvh_builder", 0)
+    inv = np.where(acc[..., 3] > 0, np.float32(1.0) / acc[..., 3], np.float32(0.0)).astype(np.float32)
+    for c, plane in ((0, 3), (1, 2), (2, 1)):
+        assert np.array_equal(bits(px[:, plane, :]), bits(acc[..., c] * inv))
+    assert np.array_equal(px[:, 0, :], (acc[..., 3] > 0).astype(np.float32))
