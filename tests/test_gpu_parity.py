@@ -283,6 +283,7 @@ def test_occupancy_copies_agree(gpu_tb, settings, scene):
     try:
         for frames in (3, 9):
             ref = None
+            gpu_tb.SetOption("frame_group", -1 if frames == 3 else 0)
             for high in (1, 0):
                 gpu_tb.SetOption("high_occupancy", high); gpu_tb.InvalidateHistory()
                 gpu_tb.Render(W, H, frames, s, 0.0)
@@ -291,7 +292,7 @@ def test_occupancy_copies_agree(gpu_tb, settings, scene):
                 if ref is None: ref = _oracle(gpu_tb, W, H, frames, s)["output"]
                 assert np.array_equal(bits(out), bits(ref)), (frames, high)
     finally:
-        gpu_tb.SetOption("high_occupancy", 1)
+        gpu_tb.SetOption("high_occupancy", 1); gpu_tb.SetOption("frame_group", 0)
 
 
 @pytest.mark.parametrize("scene", ["cornell", "proc0", "proc1"])
