@@ -490,7 +490,7 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
     const bool wavefront = opt("pipeline", 0) == 2 && variantIndex <= 2 && !count && !aov;
     const bool pooled = opt("pipeline", 0) == 3 && variantIndex <= 2 && !count && !aov;
     const int64_t fg = opt("frame_group", 0);
-    const bool groups = !wavefront && !pooled && opt("pipeline", 0) == 0 && !count && !aov && !s.RenderModeRealTime && fg >= 0 && (fg > 0 || n >= 2); /* measured: frame groups win from 2 frames per call on (cornell-box 4 spp +23 %, 870 k scene 4 spp 2x); one frame: +17 % / -9 %, left alone */
+    const bool groups = !wavefront && !pooled && opt("pipeline", 0) == 0 && !count && !aov && !s.RenderModeRealTime && fg >= 0 && (fg > 0 || n >= (c->sceneInLds ? 1u : 2u)); /* measured: frame groups win from 2 frames per call on (cornell-box 4 spp +23 %, 870 k scene 4 spp 2x); one frame per call: +17 % with the scene in LDS, -9 % on the 870 k scene */
     /* Which copy of the feature set: the higher-occupancy one when its workgroups fit in LDS.  LDS per workgroup = 1 KB per stack
      * entry (+ the scene image); where the tree is too deep for that, a frame-group launch may still use the copy with a split
      * stack -- as many entries in LDS as fit, the deepest few (option "stack_overflow_max", default 16) in global memory. */
