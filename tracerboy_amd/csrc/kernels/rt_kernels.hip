@@ -152,7 +152,7 @@ __global__ __launch_bounds__(64) void rt_denoise_kernel(TbDenoiserConstants k, c
                 const float distance = len3(xyz(positions[c]) - position);
                 const float positionWeight = tb_exp(-distance / (k.IntersectionPositionWeightingMultiplier * tb_abs((float)ox * distanceToNeighborPixel + (float)oy * distanceToNeighborPixel) + EPS));
                 const float kw[3] = {3.0f / 8.0f, 1.0f / 4.0f, 1.0f / 16.0f};
-                const int ax = ox / mult < 0 ? -(ox / mult) : ox / mult, ay = oy / mult < 0 ? -(oy / mult) : oy / mult;
+                const int ax = xo < 0 ? -xo : xo, ay = yo < 0 ? -yo : yo; /* |offset / OffsetMultiplier| of DenoiserCS: the tap's index in the 5x5 kernel */
                 const float weight = (((lumaWeight * positionWeight) * normalWeight) * kw[ax]) * kw[ay];
                 const TbFloat4 n = input[c];
                 accumulatedColor = accumulatedColor + xyz(n) * weight;
