@@ -1130,6 +1130,19 @@ float tbo_math(int fn, float a, float b)
     }
 }
 
+/* vector form for tests/test_math.py; codes 14-18: min, max, frac, floor, 1/x */
+void tbo_math_array(int fn, uint32_t n, const float* a, const float* b, float* out)
+{
+    for (uint32_t i = 0; i < n; i++) {
+        const float x = a[i], y = b ? b[i] : 0.0f;
+        switch (fn) {
+        case 14: out[i] = tb_min(x, y); break; case 15: out[i] = tb_max(x, y); break; case 16: out[i] = tb_frac(x); break;
+        case 17: out[i] = tb_floor(x); break; case 18: out[i] = tb_rcp(x); break;
+        default: out[i] = tbo_math(fn, x, y);
+        }
+    }
+}
+
 void tbo_camera_ray(const TbPerFrameConstants* constants, float lensHeight, uint32_t W, uint32_t H, float pixelX, float pixelY,
                     float jitterX, float jitterY, float origin[3], float dir[3])
 {

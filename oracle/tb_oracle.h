@@ -70,6 +70,7 @@ void tbo_composite(uint32_t W, uint32_t H, const float* albedo, const float* lig
 void tbo_set_alpha_test(int enabled);
 
 float tbo_math(int fn, float a, float b); /* 0 sin 1 cos 2 acos 3 atan2 4 exp 5 log 6 pow 7 sqrt 8 exp2 9 log2 10 asin */
+void tbo_math_array(int fn, uint32_t n, const float* a, const float* b /* nullable */, float* out); /* + 14 min 15 max 16 frac 17 floor 18 rcp */
 void tbo_camera_ray(const TbPerFrameConstants* constants, float lensHeight, uint32_t width, uint32_t height,
                     float pixelX, float pixelY, float jitterX, float jitterY, float origin[3], float dir[3]);
 

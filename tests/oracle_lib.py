@@ -54,6 +54,8 @@ def lib():
         L.tbo_rand_stream.argtypes = [C.c_float, C.c_float, C.c_uint32, vp]
         L.tbo_math.restype = C.c_float
         L.tbo_math.argtypes = [C.c_int, C.c_float, C.c_float]
+        L.tbo_math_array.restype = None
+        L.tbo_math_array.argtypes = [C.c_int, C.c_uint32, vp, vp, vp]
         L.tbo_camera_ray.restype = None
         L.tbo_camera_ray.argtypes = [C.POINTER(abi.TbPerFrameConstants), C.c_float, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_float, C.c_float,
                                      C.POINTER(C.c_float * 3), C.POINTER(C.c_float * 3)]
@@ -172,7 +174,9 @@ def validate_bvh(bvh, tri):
 
 
 def math_fn(fn, a, b=None):
-    a = np.asarray(a, np.float32).ravel()
-    b = np.zeros_like(a) if b is None else np.asarray(b, np.float32).ravel()
-    L = lib()
-    return np.array([L.tbo_math(fn, float(x), float(y)) for x, y in zip(a, b)], np.float32)
+    """include/tb_math.h as compiled into the oracle, element-wise (codes: oracle/tb_oracle.h tbo_math_array)."""
+    a = np.ascontiguousarray(a, np.float32).ravel()
+    b = None if b is None else np.ascontiguousarray(b, np.float32).ravel()
+    out = np.empty_like(a)
+    lib().tbo_math_array(fn, a.size, _p(a), _p(b), _p(out))
+    return out

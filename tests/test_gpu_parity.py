@@ -629,6 +629,82 @@ def test_full_size_frame_groups_equal_one_pixel_per_lane(gpu_tb, settings, scene
     assert np.array_equal(bits(groups[536:544]), bits(ref[536:544]))
 
 
+def _strip_and_properties(gpu_tb, s, W, H, F, rows):
+    """Size-independent checks of a full-size render: every weight counts the frames, nothing is NaN or negative, and the
+    8-row strips `rows` are the oracle's bits."""
+    out, jit = gpu_tb.ReadAccumulation(jittered=True)
+    assert np.all(out[..., 3] == float(F)) and not np.isnan(out).any() and (out[..., :3] >= 0).all()
+    assert np.all(jit[..., 3] <= float(F)) and np.all(jit[..., 3] >= 1.0)      # frame 0 always lands in the jittered surface (RayGenCommon.h:715-727)
+    view, pf = gpu_tb.HostSceneView(), gpu_tb.FrameConstants(W, H, 0, s, 0.0)
+    for y0 in rows:
+        ref = ol.render(view, pf, W, H, F, y0=y0, y1=y0 + 8, threads=8, jittered=True)
+        assert np.array_equal(bits(out[y0:y0 + 8]), bits(ref["output"][y0:y0 + 8])), y0
+        assert np.array_equal(bits(jit[y0:y0 + 8]), bits(ref["jittered"][y0:y0 + 8])), y0
+    return out
+
+
+def test_config_c3_dragon_class_870k(gpu_tb, settings):
+    """BASELINE.json configs[2] shape: the 870 k-triangle procedural stand-in for Scenes/dragon, 1920x1080, depth 6,
+    constant white environment.  (a) 2 spp: weights / NaN properties and two 8-row strips against the oracle;
+    (b) the configuration's full 128 spp: the frame-group launch (what bench.py times) is bit-identical to the one-pixel-per-lane
+    launch over the whole frame, and a strip of the 128-spp image is the oracle's."""
+    W, H = 1920, 1080
+    s = copy.copy(settings); s.MaxBounces = 6
+    gpu_tb.SetOption("bvh_builder", 1)                                   # binned SAH + reinsertion, bench.py's default tree
+    try:
+        gpu_tb.LoadProcedural(0, 870000, 1234)
+    finally:
+        gpu_tb.SetOption("bvh_builder", 0)
+    info = gpu_tb.SceneInfo()
+    assert abs(info.numTriangles - 870000) <= 8700
+    gpu_tb.InvalidateHistory(); gpu_tb.Render(W, H, 2, s, 0.0)
+    _strip_and_properties(gpu_tb, s, W, H, 2, (400, 536))
+    gpu_tb.InvalidateHistory(); gpu_tb.Render(W, H, 128, s, 0.0)
+    groups, groups_jit = gpu_tb.ReadAccumulation(jittered=True)
+    assert np.all(groups[..., 3] == 128.0) and not np.isnan(groups).any()
+    gpu_tb.SetOption("frame_group", -1)
+    try:
+        gpu_tb.InvalidateHistory(); gpu_tb.Render(W, H, 128, s, 0.0)
+        classic, classic_jit = gpu_tb.ReadAccumulation(jittered=True)
+    finally:
+        gpu_tb.SetOption("frame_group", 0)
+    assert np.array_equal(bits(groups), bits(classic)) and np.array_equal(bits(groups_jit), bits(classic_jit))
+    ref = ol.render(gpu_tb.HostSceneView(), gpu_tb.FrameConstants(W, H, 0, s, 0.0), W, H, 128, y0=540, y1=542, threads=8)["output"]
+    assert np.array_equal(bits(groups[540:542]), bits(ref[540:542]))
+
+
+@pytest.mark.parametrize("cfg", ["c4_van_class", "c5_bistro_class"])
+def test_config_c4_c5_4k_scenes(gpu_tb, settings, cfg):
+    """BASELINE.json configs[3] / [4] shapes on ONE GPU (the 8-GPU run splits exactly this frame into tiles): 3840x2160,
+    C4-class = 0.7 M triangles with matte / plastic / metal / mirror / glass (SSS walk), default depth 6;
+    C5-class = 2.98 M triangles, 40 materials, 4 area lights, depth 16, tree built on the GPU (LBVH + treelet passes).
+    2 spp: properties over the whole frame + 8-row strips against the oracle; then the tile split of the 8-rank run
+    (this rank = 3 of 8) gives the same bits for its own pixels."""
+    W, H, F = 3840, 2160, 2
+    s = copy.copy(settings)
+    gpu_tb.SetOption("bvh_builder", 4)
+    try:
+        if cfg == "c4_van_class": gpu_tb.LoadProcedural(1, 700000, 1234); s.MaxBounces = 6
+        else: gpu_tb.LoadProcedural(2, 2980000, 1234); s.MaxBounces = 16
+    finally:
+        gpu_tb.SetOption("bvh_builder", 0)
+    gpu_tb.InvalidateHistory(); gpu_tb.Render(W, H, F, s, 0.0)
+    assert gpu_tb.GetOption("last_variant") == 3                           # "vol": SSS walk + mix materials
+    full = _strip_and_properties(gpu_tb, s, W, H, F, (1000, 1400))
+    try:
+        gpu_tb.SetTileAssignment(3, 8)
+        gpu_tb.InvalidateHistory(); gpu_tb.Render(W, H, F, s, 0.0)
+        mine = gpu_tb.ReadAccumulation()
+    finally:
+        gpu_tb.SetTileAssignment(0, 1)
+    owned = np.zeros((H, W), bool)
+    tx = (W + 63) // 64
+    for t in range(3, tx * ((H + 63) // 64), 8):
+        x0, y0 = (t % tx) * 64, (t // tx) * 64
+        owned[y0:y0 + 64, x0:x0 + 64] = True
+    assert np.array_equal(bits(mine[owned]), bits(full[owned]))
+
+
 def test_material_edit_and_errors(gpu_tb, settings):
     from tracerboy_amd import api
     gpu_tb.LoadScene(CORNELL)

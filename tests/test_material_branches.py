@@ -1,0 +1,178 @@
+"""Rows a13 / a14 / f1: the texture-driven material branches and the distant light.
+
+Fixture scene tests/golden/scenes/material-maps (written by hand; its parse is pinned by the REFERENCE parser's dump,
+tests/golden/material-maps.parser.txt): gamma-flagged image as Kd of an uber material (TracerBoy.cpp:205-209,335), SCALE textures
+(SharedRaytracing.h:119-137), checker, metal / mirror / plastic / unknown-type materials, one distant light
+(RayGenCommon.h:231-246) beside an area light.  The normal / specular / emissive maps reach a Material only through the Assimp
+importer in the reference (AssimpImporter.cpp:115-117); the tests bind them the way the reference's UI can: SetMaterial
+(TracerBoy.h GetMaterial/SetMaterial) with the TextureData index of a swatch material that uses the same image.
+
+CPU part: the loader against the reference parser, and that every branch changes the oracle's picture (so the GPU comparisons
+below cannot pass on dead code).  GPU part (-m gpu): every variant bit-exact against the oracle."""
+import copy
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from conftest import GOLDEN
+
+SCENE = os.path.join(GOLDEN, "scenes", "material-maps", "scene.pbrt")
+INVALID = 0xFFFFFFFF
+W, H, F = 96, 64, 3
+
+# material indices in creation order (the order of first use by a shape, TracerBoy.cpp:1578-1593)
+LIGHT, FLOOR, BACK, LEFT, METAL, HAIR, PLASTIC, MIRROR, SW_N, SW_S, SW_E = range(11)
+TB_MAT_METALLIC, TB_MAT_HAIR = 0x1, 0x40
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def edit_for(variant, mats):
+    """variant -> {material id: {field: value}}; mats[i] are the loaded materials (texture indices come from the swatches)."""
+    nmap, smap, emap = mats[SW_N].albedoIndex, mats[SW_S].albedoIndex, mats[SW_E].albedoIndex
+    assert INVALID not in (nmap, smap, emap)
+    return {
+        "as_loaded": {}, "distant_unsteered": {}, "flip_off": {}, "ris": {},
+        "normal_map": {LEFT: {"normalMapIndex": nmap}, FLOOR: {"normalMapIndex": nmap}, PLASTIC: {"normalMapIndex": nmap}},
+        "normal_map_disabled": {LEFT: {"normalMapIndex": nmap}, FLOOR: {"normalMapIndex": nmap}, PLASTIC: {"normalMapIndex": nmap}},
+        "specular_map": {LEFT: {"specularMapIndex": smap}, FLOOR: {"specularMapIndex": smap}},
+        "emissive_map": {BACK: {"emissiveIndex": emap}, LEFT: {"emissiveIndex": emap}},
+        "hair_flag": {HAIR: {"Flags": mats[HAIR].Flags | TB_MAT_HAIR}, LEFT: {"Flags": mats[LEFT].Flags | TB_MAT_HAIR}},
+        "all_maps": {LEFT: {"normalMapIndex": nmap, "specularMapIndex": smap, "emissiveIndex": emap}, FLOOR: {"normalMapIndex": nmap, "specularMapIndex": smap}},
+    }[variant]
+
+
+def settings_for(variant, base):
+    s = copy.copy(base); s.MaxBounces = 4
+    if variant in ("normal_map", "all_maps"): s.EnableNormalMaps = 1
+    if variant == "distant_unsteered": s.DebugValue = 0.0        # RayGenCommon.h:236: the DebugValue steer is off, the light's own direction counts
+    if variant == "ris": s.EnableSamplingImportanceResampling = 1  # RIS treats the distant light like an area light with P = N = 0 (RayGenCommon.h:180-211)
+    return s
+
+
+VARIANTS = ["as_loaded", "distant_unsteered", "normal_map", "normal_map_disabled", "specular_map", "emissive_map", "hair_flag", "all_maps", "flip_off", "ris"]
+
+
+# ---------------------------------------------------------------------------------------------- CPU
+def test_loader_matches_reference_parser_on_material_maps(built, tmp_path):
+    from tracerboy_amd import api
+    out = str(tmp_path / "dump.txt"); err = C.create_string_buffer(256)
+    assert api.lib().tb_host_pbrt_dump(SCENE.encode(), out.encode(), err, 256) == 0, err.value
+    assert open(out).read() == open(os.path.join(GOLDEN, "material-maps.parser.txt")).read()
+
+
+def test_material_maps_conversion(built):
+    """CreateMaterial / TextureAllocator on the fixture: gamma flag only on the normalized image used by an UBER Kd, SCALE
+    texture children, flags per material type, one directional + two area lights, FlipTextureUVs on (.pbrt load)."""
+    from tracerboy_amd import api
+    hs = api.HostScene(SCENE); i = hs.info(); v = hs.view()
+    assert (i.numTriangles, i.numMaterials, i.numLights, i.numTextures) == (34, 11, 3, 9)
+    assert v.config.FlipTextureUVs == 1                                      # TracerBoy.cpp:1208
+    td = [v.textureData[k] for k in range(9)]
+    assert (td[0].TextureType, td[0].TextureFlags) == (0, 1)                 # albedo.png as uber Kd: NEEDS_GAMMA (TracerBoy.cpp:205-209)
+    assert (td[1].TextureType, td[1].TextureFlags) == (0, 0)                 # the same image under a matte's scale texture: no gamma
+    assert (td[2].TextureType, td[2].TextureIndex1, td[2].TextureIndex2) == (2, 1, INVALID)
+    assert (td[5].TextureType, td[5].TextureIndex1, td[5].TextureIndex2) == (2, 3, 4) and td[3].TextureType == 1
+    m = [v.materials[k] for k in range(11)]
+    assert m[LIGHT].Flags & 0x10 and m[METAL].Flags & TB_MAT_METALLIC and m[MIRROR].Flags & TB_MAT_METALLIC and m[MIRROR].roughness == 0.0
+    assert abs(m[HAIR].albedo.x - 153.0 / 255.0) < 1e-7 and abs(m[HAIR].roughness - 0.2) < 1e-7   # unknown type: TracerBoy.cpp:492-497
+    assert abs(m[METAL].IOR - (0.2 + 0.9 + 1.1) / 3) < 1e-6
+    lights = [v.lights[k] for k in range(3)]
+    assert [l.LightType for l in lights] == [0, 0, 1]                        # area lights first (shape loop), then the distant light
+    d = np.array([lights[2].Direction.x, lights[2].Direction.y, lights[2].Direction.z])
+    assert np.allclose(d, -np.array([3, 6, 4]) / np.linalg.norm([3, 6, 4]), atol=1e-6)
+
+
+def _oracle_variant(hs, base, variant):
+    v = hs.view()
+    mats = [v.materials[k] for k in range(11)]
+    saved = [copy.copy(m) for m in mats]
+    try:
+        for mid, fields in edit_for(variant, saved).items():
+            for k, val in fields.items(): setattr(v.materials[mid], k, val)
+        s = settings_for(variant, base)
+        return ol.render(v, hs.frame_constants(s, 0, 0.0), W, H, F, threads=8)["output"]
+    finally:
+        for k in range(11): C.memmove(C.addressof(v.materials[k]), C.addressof(saved[k]), C.sizeof(saved[k]))
+
+
+def test_every_branch_changes_the_oracle_picture(built, settings):
+    """The branches are live in the checker: each variant moves a visible number of pixels, the disabled normal map none."""
+    from tracerboy_amd import api
+    hs = api.HostScene(SCENE)
+    base = _oracle_variant(hs, settings, "as_loaded")
+    assert not np.isnan(base).any() and base[..., :3].max() > 0
+    for variant in ("distant_unsteered", "normal_map", "specular_map", "emissive_map", "hair_flag", "all_maps", "ris"):
+        img = _oracle_variant(hs, settings, variant)
+        assert not np.isnan(img).any()
+        changed = int((bits(img) != bits(base)).any(axis=-1).sum())
+        assert changed > 200, (variant, changed)
+    assert np.array_equal(bits(_oracle_variant(hs, settings, "normal_map_disabled")), bits(base))
+    # the distant light lights the scene: without it the floor in front of the boxes is darker
+    v = hs.view(); pf = hs.frame_constants(settings_for("as_loaded", settings), 0, 0.0)
+    pf.LightCount = 2
+    fewer = ol.render(v, pf, W, H, F, threads=8)["output"]
+    assert fewer[..., :3].sum() != base[..., :3].sum()
+    # flipped / unflipped texture lookups differ
+    flip_off = api.HostScene(SCENE, flip_texture_uvs=False)
+    assert flip_off.view().config.FlipTextureUVs == 0
+    img = ol.render(flip_off.view(), flip_off.frame_constants(settings_for("as_loaded", settings), 0, 0.0), W, H, F, threads=8)["output"]
+    assert int((bits(img) != bits(base)).any(axis=-1).sum()) > 200
+
+
+# ---------------------------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_material_branches_bit_exact(gpu_tb, settings, variant):
+    gpu_tb.SetOption("flip_texture_uvs", 0 if variant == "flip_off" else 1)
+    try:
+        gpu_tb.LoadScene(SCENE)
+    finally:
+        gpu_tb.SetOption("flip_texture_uvs", 1)
+    mats = [gpu_tb.GetMaterial(k) for k in range(11)]
+    for mid, fields in edit_for(variant, mats).items():
+        m = gpu_tb.GetMaterial(mid)
+        for k, val in fields.items(): setattr(m, k, val)
+        gpu_tb.SetMaterial(mid, m)
+    s = settings_for(variant, settings)
+    gpu_tb.Render(W, H, F, s, 0.0)
+    out, jit = gpu_tb.ReadAccumulation(jittered=True)
+    view = gpu_tb.HostSceneView()
+    assert view.config.FlipTextureUVs == (0 if variant == "flip_off" else 1)
+    ref = ol.render(view, gpu_tb.FrameConstants(W, H, 0, s, 0.0), W, H, F, threads=8, jittered=True)
+    assert not np.isnan(out).any() and out[..., :3].max() > 0
+    assert np.array_equal(bits(out), bits(ref["output"])), variant
+    assert np.array_equal(bits(jit), bits(ref["jittered"])), variant
+    # the other schedulings of the same step functions and the full-feature kernel agree
+    if variant in ("all_maps", "as_loaded"):
+        try:
+            gpu_tb.SetOption("force_full_variant", 1); gpu_tb.InvalidateHistory()
+            gpu_tb.Render(W, H, F, s, 0.0)
+            assert np.array_equal(bits(gpu_tb.ReadAccumulation()), bits(ref["output"]))
+        finally:
+            gpu_tb.SetOption("force_full_variant", 0)
+
+
+@pytest.mark.gpu
+def test_material_maps_aovs_with_normal_map(gpu_tb, settings):
+    """The detail normal is what the normals AOV stores (RayGenCommon.h:1365-1376 -> OutputPrimaryNormal)."""
+    gpu_tb.LoadScene(SCENE)
+    mats = [gpu_tb.GetMaterial(k) for k in range(11)]
+    for mid, fields in edit_for("all_maps", mats).items():
+        m = gpu_tb.GetMaterial(mid)
+        for k, val in fields.items(): setattr(m, k, val)
+        gpu_tb.SetMaterial(mid, m)
+    s = settings_for("all_maps", settings)
+    gpu_tb.SetOption("aov", 1)
+    try:
+        gpu_tb.Render(W, H, 2, s, 0.0)
+        ref = ol.render(gpu_tb.HostSceneView(), gpu_tb.FrameConstants(W, H, 0, s, 0.0), W, H, 2, threads=8, aovs=True)
+        for which, key in ((2, "normals"), (3, "worldpos0"), (4, "worldpos1"), (5, "custom"), (6, "depth"), (7, "emissive")):
+            assert np.array_equal(bits(gpu_tb.ReadAOV(which)), bits(ref[key])), key
+    finally:
+        gpu_tb.SetOption("aov", 0)

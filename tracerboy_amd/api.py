@@ -161,11 +161,11 @@ def _np_ptr(a):
 class HostScene:
     """Host-only LoadScene (parse + convert + BVH build): no GPU needed, renders nothing."""
 
-    def __init__(self, path=None, procedural=None, bvh_builder=0, flatten_instances=True):
+    def __init__(self, path=None, procedural=None, bvh_builder=0, flatten_instances=True, flip_texture_uvs=True):
         self._h = C.c_void_p()
         err = C.create_string_buffer(512)
         if path is not None:
-            rc = lib().tb_host_scene_load(os.fsencode(path), bvh_builder, 1 if flatten_instances else 0, C.byref(self._h), err, 512)
+            rc = lib().tb_host_scene_load(os.fsencode(path), bvh_builder, (1 if flatten_instances else 0) | (0 if flip_texture_uvs else 2), C.byref(self._h), err, 512)
         else:
             kind, tris, seed = procedural
             rc = lib().tb_host_scene_procedural(kind, tris, seed, bvh_builder, C.byref(self._h), err, 512)

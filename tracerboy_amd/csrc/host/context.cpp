@@ -658,6 +658,7 @@ int tb_load_scene(tb_context* c, const char* path)
         if (!path) return fail(c, TB_E_INVALID, "tb_load_scene: null path");
         std::shared_ptr<PbrtScene> ps = importScene(path);
         ConvertOptions co; auto it = c->options.find("flatten_instances"); if (it != c->options.end()) co.flattenInstances = it->second != 0;
+        it = c->options.find("flip_texture_uvs"); if (it != c->options.end()) co.flipTextureUVs = it->second != 0;
         c->hasScene = false;
         ConvertScene(*ps, c->scene, co);
         finalizeScene(c);
@@ -988,7 +989,7 @@ int tb_unpack_gathered_host(uint32_t W, uint32_t H, uint32_t world, uint32_t tw,
 int tb_set_option(tb_context* c, const char* name, int64_t v)
 {
     if (!c || !name) return TB_E_INVALID;
-    static const char* known[] = {"pipeline", "count_rays", "bvh_builder", "flatten_instances", "aov", "scene_in_lds", "lds_scene_budget", "force_full_variant", "wavefront_paths", "wavefront_grid", "wavefront_segment", "pooled_paths", "pooled_samples", "pooled_profile", "park_min", "alpha_test", "node_order", "node_order_top_levels", "frame_group", "overlap_launches", "high_occupancy", "stack_lds_cap", "stack_overflow_max"};
+    static const char* known[] = {"pipeline", "count_rays", "bvh_builder", "flatten_instances", "aov", "scene_in_lds", "lds_scene_budget", "force_full_variant", "wavefront_paths", "wavefront_grid", "wavefront_segment", "pooled_paths", "pooled_samples", "pooled_profile", "park_min", "alpha_test", "node_order", "node_order_top_levels", "frame_group", "overlap_launches", "high_occupancy", "stack_lds_cap", "stack_overflow_max", "flip_texture_uvs"};
     for (const char* k : known) if (!strcmp(k, name)) { c->options[name] = v; if (!strcmp(name, "count_rays") || !strcmp(name, "aov")) c->samplesRendered = 0; return TB_OK; }
     return fail(c, TB_E_INVALID, std::string("unknown option '") + name + "'");
 }
@@ -1083,14 +1084,14 @@ struct tb_host_scene { HostScene scene; };
 
 static int hostFail(char* err, uint32_t n, int code, const std::string& m) { if (err && n) { strncpy(err, m.c_str(), n - 1); err[n - 1] = 0; } return code; }
 
-int tb_host_scene_load(const char* path, int builder, int flatten, tb_host_scene** out, char* err, uint32_t errLen)
+int tb_host_scene_load(const char* path, int builder, int loadFlags, tb_host_scene** out, char* err, uint32_t errLen)
 {
     if (!path || !out) return TB_E_INVALID;
     *out = nullptr;
     try {
         std::shared_ptr<PbrtScene> ps = importScene(path);
         tb_host_scene* h = new tb_host_scene();
-        ConvertOptions co; co.flattenInstances = flatten != 0;
+        ConvertOptions co; co.flattenInstances = (loadFlags & 1) != 0; co.flipTextureUVs = (loadFlags & 2) == 0;
         try { ConvertScene(*ps, h->scene, co); BuildBvh(h->scene, builder); } catch (...) { delete h; throw; }
         *out = h; return TB_OK;
     } catch (const std::exception& e) {

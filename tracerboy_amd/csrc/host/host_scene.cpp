@@ -305,7 +305,7 @@ void ConvertScene(const PbrtScene& in, HostScene& out, const ConvertOptions& opt
     /* UpdateConfigConstants (:3372-3384) */
     memset(&out.config, 0, sizeof out.config);
     out.config.CameraLensHeight = out.camera.LensHeight;
-    out.config.FlipTextureUVs = 0; /* m_flipTextureUVs is only set by the Assimp path */
+    out.config.FlipTextureUVs = opt.flipTextureUVs ? 1u : 0u; /* m_flipTextureUVs: true for .pbrt / .pbf scenes (TracerBoy.cpp:1208,1222,3376) */
     out.config.EnvMapTransformVx = {envL.vx.x, envL.vx.y, envL.vx.z, 0.0f};
     out.config.EnvMapTransformVy = {envL.vy.x, envL.vy.y, envL.vy.z, 0.0f};
     out.config.EnvMapTransformVz = {envL.vz.x, envL.vz.y, envL.vz.z, 0.0f};

@@ -39,6 +39,9 @@ struct HostScene {
 struct ConvertOptions {
     bool flattenInstances = true; /* reference SW path traces BLAS[0] only and uses shapes[0] of an instance
                                      (TracerBoy.cpp:1370-1375, 2861-2866); the build flattens all of them */
+    bool flipTextureUVs = true;   /* ConfigConstants.FlipTextureUVs = m_flipTextureUVs: TRUE for .pbrt and .pbf loads ("PBRT uses GL style
+                                     texture sampling", TracerBoy.cpp:1207-1208,1221-1222), false only on the Assimp path; option
+                                     "flip_texture_uvs" = 0 gives the Assimp convention */
 };
 
 /* TracerBoy::LoadScene steps 2-4 (camera :1243-1272, shape loop :1356-1835, lights :1896-1917) */

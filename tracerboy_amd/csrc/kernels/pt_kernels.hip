@@ -58,6 +58,7 @@ __global__ void device_math_kernel(int fn, uint32_t n, const float* a, const flo
     case 4: r = tb_exp(x); break; case 5: r = tb_log(x); break; case 6: r = tb_pow(x, y); break; case 7: r = tb_sqrt(x); break;
     case 8: r = tb_exp2(x); break; case 9: r = tb_log2(x); break; case 10: r = tb_asin(x); break;
     case 11: r = x / y; break; case 12: r = tb_frac(tb_sin(x + y) * 43758.5453123f); break; case 13: r = hash13(x, y, 0.0f); break;
+    case 14: r = tb_min(x, y); break; case 15: r = tb_max(x, y); break; case 16: r = tb_frac(x); break; case 17: r = tb_floor(x); break; case 18: r = tb_rcp(x); break;
     default: break;
     }
     out[i] = r;
