@@ -1,20 +1,30 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the hot path: Msamples/s (W x H x spp / s) on BASELINE.json
-configs[1]: Scenes/cornell-box, 1920x1080, 64 spp, depth 8, wavefront HIP on MI355X.
+configs[1]: Scenes/cornell-box, 1920x1080, 64 spp, depth 8, persistent-thread HIP on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W        (N > 1 without a launcher: starts the N ranks itself)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one full render of the workload (W*H*spp samples).  With N > 1 the frame is cut into
-64x64 tiles dealt round-robin to the ranks (tile t -> rank t % N); each rank renders its
-tiles, packs them and the packed HDR buffers are gathered to rank 0 over RCCL inside the timed region.
-The total work is fixed, so scaling is "strong".  Scene + BVH are resident in HBM before the timed
-region starts; nothing is read from the host inside it.
+One "step" = one full render of the workload (W*H*spp samples).  With N > 1 the frame is cut into 64x64 tiles dealt
+round-robin to the ranks (tile t -> rank t % N); each rank renders its tiles, packs them, the packed HDR
+buffers are gathered to rank 0 over RCCL and rank 0 un-permutes them into the full frame in HBM -- all inside the timed
+region.  The total work is fixed, so scaling is "strong".  Scene + BVH are resident in HBM before the timed region
+starts; nothing is read from the host inside it.
+
+The JSON line carries two roofline objects:
+  "roofline"     the timed kernel on the timed workload.  cornell-box is LDS-resident, so the resource is VALU issue:
+                 frac = SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x launch time x 2.4 GHz); the instruction count per launch is a
+                 property of the workload (same seeds, same control flow) and comes from the committed rocprofv3 PMC pass of this
+                 command (profiles/rN/c2_pmc_summary.json), the launch time is measured live with HIP events.
+  "roofline_c3"  BASELINE.json configs[2] (870 k-triangle dragon-class scene, 1920x1080 x 128 spp, depth 6) rendered in the
+                 same invocation: the HBM roofline SURVEY.md 8d asks for (algorithmic bytes / launch time / 8 TB/s) with the PMC
+                 traffic of that launch shape beside it.  Skipped with --no-c3 and at N > 1.
 """
 import argparse
-import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -23,46 +33,13 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 CORNELL = os.path.join(ROOT, "tests", "golden", "scenes", "cornell-box", "scene.pbrt")
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+SIMDS, CLOCK_GHZ, VALU_CYCLES = 1024, 2.4, 2   # 256 CUs x 4 SIMD-32; a wave64 VALU instruction issues over 2 cycles (guide + scripts/microbench/valu_issue.hip)
+VALU_PEAK_GINST = SIMDS * CLOCK_GHZ / VALU_CYCLES   # 1228.8 G wave-instructions / s
+TILE = 64
 
 
-def byte_model(st):
-    """Algorithmic bytes of DESIGN.md section 'Byte model' (layout-A accounting of SURVEY.md 8d, with the
-    reference's real 72-B hit-group record): traversal + attribute + material + light + accumulation."""
-    return (32 * st.boxesTested + 48 * st.trianglesTested + 180 * st.hitsShaded + 84 * st.materialFetches
-            + 104 * st.lightSamples + 32 * st.samples)
-
-
-def pmc_traffic_bytes(args, world):
-    """HBM bytes per launch of the timed kernel from the committed rocprofv3 PMC passes of this exact command
-    (profiles/<round>/<key>_pmc_summary.json, separate --pmc FETCH_SIZE / WRITE_SIZE runs, scripts/profile_r1.sh):
-    (2 * FETCH_SIZE + WRITE_SIZE) * 1024 -- the counters are in KiB and gfx950's FETCH_SIZE reads half the bytes of
-    16-B/lane loads (MI355X_MICROARCH.md, HBM).  None when no profile of this workload is committed."""
-    key = {("cornell-box", 1920, 1080, 64, 8): "c2", ("proc0:870000", 1920, 1080, 16, 6): "c3"}.get(
-        (args.scene, args.width, args.height, args.spp, args.depth))
-    if key is None or world != 1 or args.pipeline != 0:
-        return None
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", key + "_pmc_summary.json")))
-    if not files:
-        return None
-    import re
-    best = None
-    for name, passes in json.load(open(files[-1])).items():
-        # pt_persistent<F, LDS, COUNT, GROUPS>: not the counters-on launch (COUNT = true), not the sample fold; the frame-group
-        # kernel (GROUPS = true) is the timed one -- its one-pixel-per-lane twin only appears as the zero-frame warm launch
-        m = re.search(r"pt_persistent<\d+u, (true|false), (true|false), (true|false)(?:, (?:true|false))?>", name)  # <F, LDS, COUNT, GROUPS[, HYBRID]>
-        if not m or m.group(2) == "true" or "fetch" not in passes or "write" not in passes:
-            continue
-        traffic = int((2.0 * passes["fetch"]["FETCH_SIZE"] + passes["write"]["WRITE_SIZE"]) * 1024)
-        if m.group(3) == "true":
-            return traffic
-        best = traffic if best is None else best
-    return best
-    return None
-
-
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -73,25 +50,145 @@ def main():
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--scene", default="cornell-box")  # or proc0:<tris> / proc1:<tris> / proc2:<tris> / path.pbrt
     ap.add_argument("--builder", type=int, default=1)  # 0 LBVH, 1 binned SAH + reinsertion, 2 LBVH on the GPU, 3 LBVH + treelet passes (the reference's tree), 4 the same on the GPU
-    ap.add_argument("--pipeline", type=int, default=0)  # 0 = lock-step bounce (fastest measured), 1 = streaming (resumable BVH walk)
+    ap.add_argument("--pipeline", type=int, default=0)  # 0 = lock-step bounce (fastest measured), 1 = streaming, 2 = wavefront queues, 3 = pooled
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=INT")  # extra tb_set_option()s, applied before the scene is loaded
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-c3", action="store_true")         # skip the second roofline object (configs[2] at 128 spp)
     ap.add_argument("--async-steps", action="store_true")  # run the N > 1 step pipeline (async render + pack + stream-ordered consumer) on one GPU
     ap.add_argument("--sync-steps", action="store_true")   # N = 1: wait for every render before enqueuing the next (default: enqueue the K steps, wait once)
-    ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
-    args = ap.parse_args()
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=10.0)
+    ap.add_argument("--selftest-cpu", action="store_true")  # plumbing test without a GPU: spawn -> gloo rendezvous -> tile gather -> assemble -> one JSON line (tests/)
+    return ap.parse_args(argv)
 
+
+# --------------------------------------------------------------------------------------------- self-spawn
+def self_spawn(args):
+    """`python bench.py --gpus N` typed without a launcher: start the N ranks as fresh processes through torch.distributed.run
+    BEFORE this process touches torch or the GPU, relay rank 0's JSON line, exit with the launcher's code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0"); env.setdefault("OMP_NUM_THREADS", "1")
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for ln in p.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line)
+    elif p.returncode == 0:
+        print("bench.py: the ranks printed no result line", file=sys.stderr); return 1
+    return p.returncode
+
+
+def selftest_cpu(args, rank, world):
+    """No GPU: the ranks rendezvous over gloo, every rank packs its tiles of a synthetic frame (numpy restatement of the pack
+    kernel), ONE gather moves them to rank 0, rank 0 un-permutes (tb_unpack_gathered_host) and checks the frame.  Exercises the
+    launch / relay / collective plumbing of the N > 1 path; measures nothing."""
     import numpy as np
     import torch
     import torch.distributed as dist
-    from tracerboy_amd import api
+    from tracerboy_amd import tiles
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    W, H = 200, 136
+    full = (np.arange(W * H * 4, dtype=np.float32).reshape(H, W, 4) * np.float32(0.25))
+    packed = torch.from_numpy(tiles.pack_owned_reference(full, rank, world, TILE, TILE))
+    gathered = tiles.gather_to_rank0(packed, rank, world)
+    ok = True
+    if rank == 0:
+        ok = bool(np.array_equal(tiles.assemble(W, H, world, TILE, TILE, gathered), full))
+        print(json.dumps({"metric": "Msamples/s (WxHxspp/s)", "value": None, "unit": "Msamples/s", "n_gpus": world, "selftest": "cpu-gloo", "assembled_ok": ok}))
+    if world > 1:
+        dist.barrier(); dist.destroy_process_group()
+    return 0 if ok else 1
 
+
+# --------------------------------------------------------------------------------------------- roofline helpers
+def byte_model(st):
+    """Algorithmic bytes of DESIGN.md section 'Byte model' (layout-A accounting of SURVEY.md 8d, with the
+    reference's real 72-B hit-group record): traversal + attribute + material + light + accumulation."""
+    return (32 * st.boxesTested + 48 * st.trianglesTested + 180 * st.hitsShaded + 84 * st.materialFetches
+            + 104 * st.lightSamples + 32 * st.samples)
+
+
+def pmc_summary(key):
+    """Counters per launch of the timed path-tracing kernel from the newest committed rocprofv3 PMC passes of workload `key`
+    (profiles/rN/<key>_pmc_summary.json; separate --pmc runs of this command, scripts/profile_bench.sh).  Returns
+    (dict of pass -> counters, file) or (None, None)."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", key + "_pmc_summary.json")), key=lambda f: int(re.search(r"profiles/r(\d+)", f).group(1)))
+    if not files:
+        return None, None
+    best = None
+    for name, passes in json.load(open(files[-1])).items():
+        # pt_persistent<F, LDS, COUNT, GROUPS[, HYBRID]>: not the counters-on launch (COUNT = true), not the sample fold; the frame-group
+        # kernel (GROUPS = true) is the timed one -- its one-pixel-per-lane twin only appears as the zero-frame warm launch
+        m = re.search(r"pt_persistent<\d+u, (true|false), (true|false), (true|false)(?:, (?:true|false))?>", name)
+        if not m or m.group(2) == "true":
+            continue
+        if m.group(3) == "true":
+            return passes, os.path.relpath(files[-1], ROOT)
+        best = passes if best is None else best
+    return best, (os.path.relpath(files[-1], ROOT) if best else None)
+
+
+def traffic_bytes(passes):
+    """HBM bytes per launch: (2 * FETCH_SIZE + WRITE_SIZE) * 1024 -- the counters are in KiB and gfx950's FETCH_SIZE reads half the
+    bytes of 16-B/lane loads (MI355X_MICROARCH.md, HBM section)."""
+    if not passes or "fetch" not in passes or "write" not in passes:
+        return None
+    return int((2.0 * passes["fetch"]["FETCH_SIZE"] + passes["write"]["WRITE_SIZE"]) * 1024)
+
+
+def measure_kernel(tb, api, np, W, H, spp, s, runs):
+    """HIP-event duration of `runs` path-tracing launches run one at a time + the kernels' own event counters (1-spp launch)."""
+    ms = []
+    for _ in range(runs):
+        tb.InvalidateHistory(); tb.Render(W, H, spp, s, 0.0); ms.append(tb.GetOption("last_kernel_us") / 1e3)
+    frames = tb.GetOption("last_kernel_frames")
+    tb.SetOption("count_rays", 1)
+    tb.Render(W, H, 1, s, 0.0)           # counters-on launch of the same kernels, 1 spp, outside every timed region
+    st = tb.ReadbackStats().rays
+    tb.SetOption("count_rays", 0); tb.InvalidateHistory()
+    return float(np.mean(ms)), frames, st
+
+
+def hbm_roofline(avg_ms, frames, pixels, st, passes, src):
+    bps = byte_model(st) / max(st.samples, 1)
+    achieved = bps * pixels * frames / (avg_ms * 1e-3) / 1e9
+    traffic = traffic_bytes(passes)
+    r = {"bound": "hbm", "kernel": "pt_persistent", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+         "traffic": traffic, "avg_launch_ms": round(avg_ms, 3), "frames_per_launch": int(frames), "algorithmic_bytes_per_sample": round(bps, 1),
+         "boxes_per_sample": round(st.boxesTested / max(st.samples, 1), 2), "tris_per_sample": round(st.trianglesTested / max(st.samples, 1), 2),
+         "rays_per_sample": round(st.rays / max(st.samples, 1), 3), "pmc_source": src}
+    if traffic:
+        r["traffic_GBs"] = round(traffic / (avg_ms * 1e-3) / 1e9, 1); r["traffic_frac_of_peak"] = round(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    return r
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_spawn(args))          # nothing above this line imports torch or touches the GPU
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs the torch.distributed launcher (WORLD_SIZE is 1)" % args.gpus)
+        raise SystemExit("--gpus %d but the launcher started %d ranks" % (args.gpus, world))
+    if args.selftest_cpu:
+        sys.exit(selftest_cpu(args, rank, world))
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from tracerboy_amd import api, tiles
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path is HIP-only (no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -108,25 +205,31 @@ def main():
     tb.SetOption("pipeline", args.pipeline)
     for kv in args.opt:
         k, v = kv.split("="); tb.SetOption(k, int(v))
-    t0 = time.time()
-    if args.scene == "cornell-box":
-        tb.LoadScene(CORNELL)
-    elif args.scene.startswith("proc"):
-        kind, tris = args.scene[4:].split(":")
-        tb.LoadProcedural(int(kind), int(tris), 1234)
-    else:
-        tb.LoadScene(args.scene)
-    load_s = time.time() - t0
+
+    def load(scene):
+        t0 = time.time()
+        if scene == "cornell-box":
+            tb.LoadScene(CORNELL)
+        elif scene.startswith("proc"):
+            kind, tris = scene[4:].split(":")
+            tb.LoadProcedural(int(kind), int(tris), 1234)
+        else:
+            tb.LoadScene(scene)
+        return time.time() - t0
+
+    load_s = load(args.scene)
     info = tb.SceneInfo()
-    TILE = 64
     tb.SetTileAssignment(rank, world, TILE, TILE)
-    from tracerboy_amd import tiles
     owned = tb.OwnedPixels(W, H)
-    # equal-sized slices: every rank pads to the largest owner (rank 0) so ONE gather per render suffices
-    # two packed buffers: the gather of one render runs on RCCL's stream while the next render traces, and a buffer is packed
-    # again only after the gather that read it (two renders ago) has finished
-    packed = [torch.zeros((max(tiles.packed_capacity(W, H, world, TILE, TILE), 1), 4), dtype=torch.float32, device="cuda") for _ in range(2)]
-    gather_list = [torch.zeros_like(packed[0]) for _ in range(world)] if (world > 1 and rank == 0) else None
+    # equal-sized slices: every rank pads to the largest owner (rank 0) so ONE gather per render suffices.  Two packed buffers: the
+    # gather of one render runs on RCCL's stream while the next render traces, and a buffer is packed again only after the gather
+    # that read it (two renders ago) has finished.  Rank 0 gathers into ONE contiguous world x capacity buffer (views per rank)
+    # and un-permutes it on the device into the full frame (tb_unpack_gathered_device), ordered behind the gather.
+    capacity = max(tiles.packed_capacity(W, H, world, TILE, TILE), 1)
+    packed = [torch.zeros((capacity, 4), dtype=torch.float32, device="cuda") for _ in range(2)]
+    gathered = torch.zeros((world, capacity, 4), dtype=torch.float32, device="cuda") if (world > 1 and rank == 0) else None
+    gather_list = [gathered[r] for r in range(world)] if gathered is not None else None
+    frame = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda") if gathered is not None else None
     scratch = torch.zeros_like(packed[0]) if (world == 1 and args.async_steps) else None
     in_flight = [None, None]
     renders = [0]
@@ -135,13 +238,18 @@ def main():
     kernel_ms = []
 
     # N > 1 (and --async-steps): nothing in a step blocks the host -- the render and the pack are enqueued on the library's
-    # stream, the gather on RCCL's, ordered by stream waits -- so host-side launch gaps do not idle the GPU between renders
+    # stream, the gather on RCCL's, the un-permute on torch's stream behind the gather, ordered by stream waits -- so host-side
+    # launch gaps do not idle the GPU between renders
     pipelined = world > 1 or args.async_steps
     lib_stream = torch.cuda.ExternalStream(tb.Stream()) if pipelined else None
 
     def exchange(buf):
         if world > 1:
-            return dist.gather(buf, gather_list if rank == 0 else None, dst=0, async_op=True)
+            work = dist.gather(buf, gather_list if rank == 0 else None, dst=0, async_op=True)
+            if rank == 0:
+                work.wait()       # torch's current stream waits for the gather (the host does not) ...
+                tb.UnpackGatheredTo(gathered.data_ptr(), capacity, W, H, world, TILE, TILE, frame.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)   # ... and the un-permute runs behind it
+            return work
         scratch.copy_(buf, non_blocking=True)   # --async-steps on one GPU: a stand-in consumer on torch's stream
         return None
 
@@ -197,48 +305,103 @@ def main():
                    "kernel_variant": ["matte", "env", "surf", "vol", "full"][tb.GetOption("last_variant")], "scene_load_s": round(load_s, 3)},
     }
 
+    if world > 1:
+        # after the timed region: the frame rank 0 assembled from the gathered tiles equals a single-GPU render of the whole frame
+        if rank == 0:
+            assembled = frame.cpu().numpy()
+            tb.SetTileAssignment(0, 1); tb.InvalidateHistory(); tb.Render(W, H, SPP, s, 0.0)
+            whole = tb.ReadAccumulation()
+            tb.SetTileAssignment(rank, world, TILE, TILE)
+            result["config"]["assembled_frame_equals_single_gpu"] = bool(np.array_equal(assembled.view(np.uint32), whole.view(np.uint32)))
+        dist.barrier()
+
     if rank == 0:
+        lds = bool(tb.GetOption("scene_in_lds_active"))
         # ---- roofline of the dominant (only) kernel: pt_persistent ------------------------------------
-        launch_timing = "HIP events around the path-tracing launch of every timed step (tb_last_render_ms)"
+        launch_timing = "HIP events around the path-tracing launch of the last timed step (tb_last_render_ms)"
         if world == 1 and not args.sync_steps and not args.async_steps:
             # the timed steps overlap (the next launch starts while the last paths of the previous one drain), which stretches
             # every launch's own start-to-end time: the roofline uses launches that run alone, right after the timed region
-            kernel_ms.clear()
-            for _ in range(max(1, min(args.steps, 3))):
-                tb.InvalidateHistory(); tb.Render(W, H, SPP, s, 0.0); kernel_ms.append(tb.GetOption("last_kernel_us") / 1e3)
-            launch_timing = "HIP events around %d path-tracing launches run one at a time after the timed region (the timed steps overlap)" % len(kernel_ms)
-        avg_ms = float(np.mean(kernel_ms)); launch_frames = tb.GetOption("last_kernel_frames")
-        tb.SetOption("count_rays", 1)
-        tb.Render(W, H, 1, s, 0.0)           # counters-on launch of the same kernels, 1 spp, outside the timed region
-        st = tb.ReadbackStats().rays
-        tb.SetOption("count_rays", 0)
-        bytes_per_sample = byte_model(st) / max(st.samples, 1)
-        samples_per_launch = owned_samples = (W * H if world == 1 else owned) * launch_frames
-        achieved = bytes_per_sample * samples_per_launch / (avg_ms * 1e-3) / 1e9
-        result["roofline"] = {
-            "bound": "hbm", "kernel": ("pt_persistent", "pt_stream", "wf_* (all stages)", "pt_pooled")[args.pipeline], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic_bytes(args, world),
-            "avg_launch_ms": round(avg_ms, 3), "launch_timing": launch_timing, "algorithmic_bytes_per_sample": round(bytes_per_sample, 1),
-            "boxes_per_sample": round(st.boxesTested / max(st.samples, 1), 2), "tris_per_sample": round(st.trianglesTested / max(st.samples, 1), 2),
-            "rays_per_sample": round(st.rays / max(st.samples, 1), 3),
-            "note": ("scene image is LDS-resident: algorithmic bytes are served by LDS, HBM only sees the sample buffer / accumulation surfaces"
-                     if tb.GetOption("scene_in_lds_active") else "BVH fetched from L2/MALL/HBM"),
-        }
+            runs = max(1, min(args.steps, 3))
+            avg_ms, launch_frames, st = measure_kernel(tb, api, np, W, H, SPP, s, runs)
+            launch_timing = "HIP events around %d path-tracing launches run one at a time after the timed region (the timed steps overlap)" % runs
+        else:
+            avg_ms = float(np.mean(kernel_ms)); launch_frames = tb.GetOption("last_kernel_frames")
+            tb.SetOption("count_rays", 1); tb.Render(W, H, 1, s, 0.0); st = tb.ReadbackStats().rays; tb.SetOption("count_rays", 0)
+        key = {("cornell-box", 1920, 1080, 64, 8): "c2", ("proc0:870000", 1920, 1080, 128, 6): "c3", ("proc0:870000", 1920, 1080, 16, 6): "c3_16spp"}.get((args.scene, W, H, SPP, args.depth))
+        passes, src = pmc_summary(key) if (key and world == 1 and args.pipeline == 0) else (None, None)
+        pixels = W * H if world == 1 else owned
+        hbm = hbm_roofline(avg_ms, launch_frames, pixels, st, passes, src)
+        hbm["launch_timing"] = launch_timing
+        insts = passes.get("lds", {}).get("SQ_INSTS_VALU") if passes else None
+        if lds:
+            # LDS-resident scene: the algorithmic bytes never leave the CU; the resource the kernel can saturate is VALU issue
+            roof = {"bound": "valu", "kernel": "pt_persistent", "unit": "Gwave-instr/s", "peak": round(VALU_PEAK_GINST, 1),
+                    "peak_model": "%d SIMDs x %.1f GHz / %d cycles per wave64 VALU instruction" % (SIMDS, CLOCK_GHZ, VALU_CYCLES),
+                    "avg_launch_ms": round(avg_ms, 3), "launch_timing": launch_timing, "traffic": hbm["traffic"], "pmc_source": src}
+            if insts:
+                ach = insts / (avg_ms * 1e-3) / 1e9
+                roof.update({"achieved": round(ach, 1), "frac": round(ach / VALU_PEAK_GINST, 4), "valu_insts_per_launch": int(insts),
+                             "valu_lane_utilisation": round(passes["util"]["SQ_THREAD_CYCLES_VALU"] / (64.0 * passes["util"]["SQ_ACTIVE_INST_VALU"]), 4) if "util" in passes else None})
+            else:
+                roof.update({"achieved": None, "frac": None, "note": "no committed PMC pass for this workload: instruction count unknown"})
+            roof["algorithmic"] = {k: hbm[k] for k in ("achieved", "unit", "algorithmic_bytes_per_sample", "boxes_per_sample", "tris_per_sample", "rays_per_sample")}
+            roof["algorithmic"]["note"] = "SURVEY 8d byte model; served by the LDS scene image, not HBM (achieved / 8 TB/s = %.2f says nothing about HBM)" % (hbm["achieved"] / HBM_PEAK_GBS)
+            result["roofline"] = roof
+        else:
+            hbm["note"] = "BVH fetched from L2 / Infinity Cache / HBM"
+            result["roofline"] = hbm
+
+        # ---- second object: configs[2] at its full 128 spp, the workload whose roofline IS HBM ---------
+        if world == 1 and not args.no_c3 and args.scene == "cornell-box" and args.pipeline == 0:
+            W3, H3, SPP3, D3 = 1920, 1080, 128, 6
+            s3 = api.GetDefaultOutputSettings(); s3.EnableBlueNoise = 0; s3.MaxBounces = D3
+            load3 = load("proc0:870000")
+            info3 = tb.SceneInfo()
+            tb.InvalidateHistory(); tb.Render(W3, H3, SPP3, s3, 0.0)      # warm-up (first launch of this kernel copy)
+            torch.cuda.synchronize(); t3 = time.perf_counter()
+            for _ in range(3):
+                tb.InvalidateHistory(); tb.Render(W3, H3, SPP3, s3, 0.0, sync=False)
+            torch.cuda.synchronize(); dt3 = time.perf_counter() - t3
+            avg3, frames3, st3 = measure_kernel(tb, api, np, W3, H3, SPP3, s3, 3)
+            passes3, src3 = pmc_summary("c3")
+            r3 = hbm_roofline(avg3, frames3, W3 * H3, st3, passes3, src3)
+            r3.update({"workload": "proc0:870000 %dx%d %dspp depth%d" % (W3, H3, SPP3, D3), "triangles": int(info3.numTriangles), "value": round(W3 * H3 * SPP3 * 3 / dt3 / 1e6, 1),
+                       "unit_value": "Msamples/s", "ms_per_step": round(dt3 / 3 * 1e3, 3), "steps": 3, "scene_load_s": round(load3, 2),
+                       "kernel_variant": ["matte", "env", "surf", "vol", "full"][tb.GetOption("last_variant")],
+                       "note": "launches of 128 frames are batched by the sample-buffer budget: avg_launch_ms / frames_per_launch are per batch launch"})
+            if passes3 and "sq" in passes3 and "SQ_WAIT_ANY" in passes3["sq"]:
+                r3["sq_wait_any_frac"] = round(passes3["sq"]["SQ_WAIT_ANY"] / passes3["sq"]["SQ_WAVE_CYCLES"], 3)
+            result["roofline_c3"] = r3
+            load(args.scene)   # back to the timed workload for the CPU baseline below
+
         # ---- CPU baseline: the scalar oracle on a bounded sample of the same workload ------------------
         if not args.no_cpu_baseline:
             import oracle_lib as ol
-            cores = os.cpu_count() or 1
+            cores = len(os.sched_getaffinity(0))      # the CPUs this process may run on, not the machine's
             view = tb.HostSceneView(); pf = tb.FrameConstants(W, H, 0, s, 0.0)
-            # probe the rate on one full 1-spp frame, then size the sample (whole frames) to ~cpu_baseline_seconds
+            # probe the all-threads rate on one full 1-spp frame, size the sample (whole frames) to ~cpu_baseline_seconds; the
+            # single-thread figure is measured on whole frames too (the same rows), sized to about the same time
             t1 = time.perf_counter(); ol.render(view, pf, W, H, 1, threads=cores); dt = time.perf_counter() - t1
             frames = int(max(1, min(SPP, args.cpu_baseline_seconds / max(dt, 1e-3))))
             t1 = time.perf_counter(); ol.render(view, pf, W, H, frames, threads=cores); dt = time.perf_counter() - t1
-            rows1 = 8 * max(1, H // 8 // 32)
-            t2 = time.perf_counter(); ol.render(view, pf, W, H, 1, y0=(H - rows1) // 2, y1=(H - rows1) // 2 + rows1, threads=1); dt1 = time.perf_counter() - t2
+            if cores == 1:
+                dt1, n1, rows1 = dt, W * H * frames, "the same run"
+            else:
+                est1 = dt * cores / max(frames, 1)     # estimated single-thread seconds per whole frame
+                f1 = int(max(1, min(frames, args.cpu_baseline_seconds / max(est1, 1e-3))))
+                if est1 <= 3.0 * args.cpu_baseline_seconds:
+                    t2 = time.perf_counter(); ol.render(view, pf, W, H, f1, threads=1); dt1 = time.perf_counter() - t2; n1 = W * H * f1; rows1 = "whole frame x %d spp" % f1
+                else:                                    # a whole frame on one thread would take minutes: every k-th 8-row strip of the frame instead
+                    k = int(est1 / args.cpu_baseline_seconds) + 1
+                    strips = list(range(0, H, 8 * k)); t2 = time.perf_counter()
+                    for y0 in strips: ol.render(view, pf, W, H, 1, y0=y0, y1=min(H, y0 + 8), threads=1)
+                    dt1 = time.perf_counter() - t2; n1 = sum(W * (min(H, y0 + 8) - y0) for y0 in strips); rows1 = "every %d-th 8-row strip of the frame x 1 spp" % k
             result["cpu_baseline"] = {"value": round(W * H * frames / dt / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
                                       "sample": "scalar C++ oracle (oracle/tb_oracle.cpp, g++ -O2), the %dx%d frame x %d spp of %d, depth %d, %d threads over 8-row strips (%.1f s)"
                                                 % (W, H, frames, SPP, args.depth, cores, dt),
-                                      "single_thread": round(W * rows1 / dt1 / 1e6, 4)}
+                                      "single_thread": round(n1 / dt1 / 1e6, 4), "single_thread_sample": rows1 + " (%.1f s)" % dt1,
+                                      "machine_cpus": os.cpu_count()}
             if args.scene == "cornell-box":
                 # BASELINE.json configs[0], the reference's own CPU-runnable case, timed exactly: 512x512, 4 spp, depth 4
                 import copy

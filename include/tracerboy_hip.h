@@ -191,6 +191,11 @@ int tb_pack_owned_device_async(tb_context* ctx, void* device_dst);   /* same, re
  * blocking the host -- e.g. an RCCL gather of the packed tiles after tb_render_async + tb_pack_owned_device_async
  * (torch.cuda.ExternalStream(tb_stream(ctx)) on the Python side).  Owned by the context. */
 void* tb_stream(tb_context* ctx);
+/* Rank 0, device side: un-permute the gathered buffers (world x capacity_pixels RGBA32F, rank r's packed tiles at
+ * r * capacity_pixels -- the layout one RCCL gather into a contiguous buffer gives) into the full W x H frame, both in HBM.
+ * Enqueued on `stream` (a hipStream_t, e.g. the stream the gather was ordered on; NULL = the context stream); returns at once. */
+int tb_unpack_gathered_device(tb_context* ctx, void* stream, const void* gathered, uint64_t capacity_pixels, uint32_t width, uint32_t height,
+                              uint32_t world, uint32_t tile_w, uint32_t tile_h, void* full_frame);
 int tb_unpack_gathered_host(uint32_t width, uint32_t height, uint32_t world, uint32_t tile_w, uint32_t tile_h,
                             const float* const* per_rank_packed, float* full_rgba);
 

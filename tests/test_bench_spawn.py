@@ -1,0 +1,40 @@
+"""`python bench.py --gpus N` as typed (no launcher): the parent starts the N ranks itself before touching torch / the GPU, relays
+rank 0's single JSON line and exits with the launcher's code.  Here without a GPU: --selftest-cpu makes the ranks rendezvous over
+gloo, gather their packed tiles of a synthetic frame to rank 0 and un-permute them (the N > 1 data path minus the render)."""
+import json
+import os
+import subprocess
+import sys
+
+from conftest import ROOT
+
+
+def run_bench(*extra, env_extra=None):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *extra], capture_output=True, text=True, timeout=600, env=env)
+
+
+def test_self_spawn_two_ranks_relays_one_json_line(built):
+    r = run_bench("--gpus", "2", "--selftest-cpu")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["assembled_ok"] is True and out["selftest"] == "cpu-gloo"
+
+
+def test_single_rank_selftest_and_launcher_mismatch(built):
+    r = run_bench("--gpus", "1", "--selftest-cpu")
+    assert r.returncode == 0 and json.loads(r.stdout.strip())["n_gpus"] == 1
+    # a launcher that started a different number of ranks than --gpus says is an error, not a silent 1-GPU run
+    r = run_bench("--gpus", "4", "--selftest-cpu", env_extra={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "launcher started 1 ranks" in (r.stderr + r.stdout)
+
+
+def test_without_gpu_the_bench_refuses_instead_of_falling_back(built):
+    import torch
+    if torch.cuda.is_available():
+        return
+    r = run_bench("--steps", "1")
+    assert r.returncode != 0 and "HIP-only" in (r.stderr + r.stdout)

@@ -587,6 +587,16 @@ def test_tile_split_reproduces_the_single_gpu_image(gpu_tb, settings):
     finally:
         gpu_tb.SetTileAssignment(0, 1)
     assert np.array_equal(bits(api.unpack_gathered(W, H, world, tw, th, packed)), bits(full))
+    # the device-side un-permute rank 0 runs behind the gather (tb_unpack_gathered_device): same frame, in HBM
+    cap = max(p.shape[0] for p in packed)
+    gathered = torch.zeros((world, cap, 4), dtype=torch.float32, device="cuda:0")
+    for r, p in enumerate(packed): gathered[r, :p.shape[0]] = torch.from_numpy(p).to("cuda:0")
+    frame = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
+    torch.cuda.synchronize()
+    gpu_tb.UnpackGatheredTo(gathered.data_ptr(), cap, W, H, world, tw, th, frame.data_ptr()); gpu_tb.Sync()
+    assert np.array_equal(bits(frame.cpu().numpy()), bits(full))
+    with pytest.raises(api.TracerBoyError):
+        gpu_tb.UnpackGatheredTo(gathered.data_ptr(), 16, W, H, world, tw, th, frame.data_ptr())   # capacity too small for rank 0's tiles
 
 
 def test_full_size_properties_c2(gpu_tb, settings):

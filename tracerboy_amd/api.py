@@ -79,6 +79,7 @@ def lib():
         "tb_pack_owned_device": (C.c_int, [vp, vp]),
         "tb_pack_owned_device_async": (C.c_int, [vp, vp]),
         "tb_stream": (vp, [vp]),
+        "tb_unpack_gathered_device": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp]),
         "tb_unpack_gathered_host": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, P(vp), vp]),
         "tb_set_option": (C.c_int, [vp, C.c_char_p, C.c_int64]),
         "tb_get_option": (C.c_int64, [vp, C.c_char_p]),
@@ -369,6 +370,10 @@ class TracerBoy:
     def PackOwnedTo(self, device_ptr, sync=True):
         fn = self._L.tb_pack_owned_device if sync else self._L.tb_pack_owned_device_async
         self._check(fn(self._ctx, C.c_void_p(device_ptr)))
+
+    def UnpackGatheredTo(self, gathered_ptr, capacity_pixels, width, height, world, tile_w, tile_h, full_ptr, stream=0):
+        """Rank 0: device-side un-permute of the gathered per-rank buffers into the full frame (tb_unpack_gathered_device)."""
+        self._check(self._L.tb_unpack_gathered_device(self._ctx, C.c_void_p(stream or None), C.c_void_p(gathered_ptr), capacity_pixels, width, height, world, tile_w, tile_h, C.c_void_p(full_ptr)))
 
     def Stream(self):
         """the context's hipStream_t as an integer (torch.cuda.ExternalStream(tb.Stream()))"""

@@ -533,7 +533,8 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
         if (!groups) HIP_TRY(launch(c->stream, &dsLaunch, &pf, &tg, W, H, c->samplesRendered, n, &c->tiles, c->sceneInLds ? 1 : 0, count ? 1 : 0, (int)opt("pipeline", 0)));
         else {
             const uint64_t pixels = (uint64_t)W * H, budget = (uint64_t)opt("pooled_samples", 256ll << 20);
-            const uint32_t batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(n, 32768), budget / pixels)); /* a slot entry holds 15 bits of relative frame */
+            uint32_t batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(n, 32768), budget / pixels)); /* a slot entry holds 15 bits of relative frame */
+            batch = (n + (n + batch - 1) / batch - 1) / ((n + batch - 1) / batch); /* equal batches: 128 frames under a 123-frame budget run as 64 + 64, not 123 + 5 */
             /* automatic group size: about 24 576 work items per launch, rounded down to a power of two -- fine enough that the last
              * items end together, coarse enough that claiming them does not show.  Measured on 1080p with launches enqueued back
              * to back (bench.py): Cornell x 64 frames 6 370 / 6 730 / 6 870 / 6 910 / 6 850 Msamples/s at G = 4 / 8 / 16 / 32 / 64 (the
@@ -971,6 +972,17 @@ int tb_pack_owned_device_async(tb_context* c, void* dst)
 }
 
 void* tb_stream(tb_context* c) { return c ? (void*)c->stream : nullptr; }
+
+int tb_unpack_gathered_device(tb_context* c, void* stream, const void* gathered, uint64_t capacityPixels, uint32_t W, uint32_t H, uint32_t world, uint32_t tw, uint32_t th, void* full)
+{
+    return guarded(c, [&]() {
+        if (!gathered || !full || world == 0 || tw == 0 || th == 0 || W == 0 || H == 0) return fail(c, TB_E_INVALID, "tb_unpack_gathered_device: bad argument");
+        const uint64_t tilesTotal = (uint64_t)((W + tw - 1) / tw) * ((H + th - 1) / th);
+        if (((tilesTotal + world - 1) / world) * tw * th > capacityPixels) return fail(c, TB_E_INVALID, "tb_unpack_gathered_device: per-rank capacity smaller than rank 0's tiles");
+        HIP_TRY(pt_launch_unpack_gathered(stream ? (hipStream_t)stream : c->stream, (const TbFloat4*)gathered, (size_t)capacityPixels, (TbFloat4*)full, W, H, world, tw, th));
+        return TB_OK;
+    });
+}
 
 int tb_unpack_gathered_host(uint32_t W, uint32_t H, uint32_t world, uint32_t tw, uint32_t th, const float* const* perRank, float* full)
 {

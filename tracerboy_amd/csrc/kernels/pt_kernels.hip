@@ -81,6 +81,21 @@ __global__ void pack_owned_kernel(const TbFloat4* full, TbFloat4* packed, uint32
     }
 }
 
+/* rank 0 of a tile split: the inverse of pack_owned_kernel over the gathered buffers of all ranks (tb_unpack_gathered_device).
+ * gathered = world x capacity pixels, rank r's packed tiles at r * capacity; one workgroup per tile of the frame. */
+__global__ void unpack_gathered_kernel(const TbFloat4* gathered, size_t capacity, TbFloat4* full, uint32_t W, uint32_t H, uint32_t world, uint32_t tileW, uint32_t tileH)
+{
+    const uint32_t tilesX = (W + tileW - 1) / tileW, t = blockIdx.x;
+    const uint32_t rank = t % world, local = t / world;
+    const uint32_t x0 = (t % tilesX) * tileW, y0 = (t / tilesX) * tileH;
+    const uint32_t tw = min(tileW, W - x0), th = min(tileH, H - y0);
+    const TbFloat4* src = gathered + (size_t)rank * capacity + (size_t)local * tileW * tileH;
+    for (uint32_t i = threadIdx.x; i < tw * th; i += blockDim.x) {
+        const uint32_t lx = i % tw, ly = i / tw;
+        full[(size_t)(y0 + ly) * W + (x0 + lx)] = src[i];
+    }
+}
+
 /* Ordered sum of the frame-group mode's sample buffer (TbDeviceTargets::samples): RayGenCommon.h:721-727 per pixel,
  * frames in order.  One lane per owned pixel; reads numFrames x 16 B, HBM-bound. */
 __global__ __launch_bounds__(256) void accumulate_samples_kernel(const TbFloat4* samples, uint32_t W, uint32_t H, uint32_t firstFrame, uint32_t numFrames, TbTileMap tiles,
@@ -135,6 +150,14 @@ hipError_t pt_launch_trace_closest(hipStream_t stream, const TbDeviceScene* ds, 
 hipError_t pt_launch_device_math(hipStream_t stream, int fn, uint32_t n, const float* a, const float* b, float* out)
 {
     hipLaunchKernelGGL(device_math_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, fn, n, a, b, out);
+    return hipGetLastError();
+}
+
+hipError_t pt_launch_unpack_gathered(hipStream_t stream, const TbFloat4* gathered, size_t capacity, TbFloat4* full, uint32_t W, uint32_t H, uint32_t world, uint32_t tileW, uint32_t tileH)
+{
+    const uint32_t tilesTotal = ((W + tileW - 1) / tileW) * ((H + tileH - 1) / tileH);
+    if (tilesTotal == 0) return hipSuccess;
+    hipLaunchKernelGGL(unpack_gathered_kernel, dim3(tilesTotal), dim3(256), 0, stream, gathered, capacity, full, W, H, world, tileW, tileH);
     return hipGetLastError();
 }
 

@@ -13,6 +13,7 @@ hipError_t pt_launch_trace_closest(hipStream_t stream, const TbDeviceScene* ds, 
 hipError_t pt_launch_accumulate_samples(hipStream_t stream, const TbFloat4* samples, uint32_t W, uint32_t H, uint32_t firstFrame, uint32_t numFrames, const TbTileMap* tiles,
                                         TbFloat4* output, TbFloat4* jittered);
 hipError_t pt_launch_device_math(hipStream_t stream, int fn, uint32_t n, const float* a, const float* b, float* out);
+hipError_t pt_launch_unpack_gathered(hipStream_t stream, const TbFloat4* gathered, size_t capacity, TbFloat4* full, uint32_t W, uint32_t H, uint32_t world, uint32_t tileW, uint32_t tileH);
 hipError_t pt_launch_pack_owned(hipStream_t stream, const TbFloat4* full, TbFloat4* packed, uint32_t W, uint32_t H, const TbTileMap* tiles, uint32_t numOwnedTiles);
 /* GPU LBVH build (bvh_kernels.hip); every pointer is a device pointer */
 size_t bvh_gpu_scratch_bytes(uint32_t N);
