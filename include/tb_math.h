@@ -97,9 +97,9 @@ TB_HD void tb_sincos_reduce(float x, float* r, int* quadrant)
     double rd = __builtin_fma(-k, pio2_hi, xd);
     rd = __builtin_fma(-k, pio2_lo, rd);
     *r = (float)rd;
-    /* k is integral and |k| < 2^53; take it modulo 4 without overflowing an int */
-    double k4 = k - 4.0 * __builtin_floor(k * 0.25);
-    *quadrant = (int)k4;
+    /* k is integral and |k| <= 1e9 * 2 / pi < 2^31 (callers reject |x| >= 1e9): k mod 4 is the low two bits of the two's
+     * complement int (three binary64 operations fewer per sin / cos than k - 4 floor(k / 4); same value) */
+    *quadrant = (int)k & 3;
 }
 
 TB_HD float tb_sin_poly(float r)

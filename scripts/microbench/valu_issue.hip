@@ -24,6 +24,8 @@ __global__ __launch_bounds__(1024) void issue_kernel(float* out, unsigned long l
     typedef float f2 __attribute__((ext_vector_type(2)));
     f2 acc2[UNROLL], a2 = {a, a}, b2 = {b, b};
     uint32_t iacc[UNROLL];
+    double dacc[UNROLL], da = (double)a, db = 0.999;
+    for (int i = 0; i < UNROLL; i++) dacc[i] = (double)i + 0.5;
     for (int i = 0; i < UNROLL; i++) { acc[i] = (float)i; acc2[i] = f2{(float)i, (float)i}; iacc[i] = (uint32_t)i; }
     __syncthreads();
     const unsigned long long t0 = __builtin_readcyclecounter(), r0 = wall_clock64();
@@ -38,10 +40,36 @@ __global__ __launch_bounds__(1024) void issue_kernel(float* out, unsigned long l
             if (KIND == 5) asm volatile("v_add_u32 %0, %1, %0" : "+v"(iacc[i]) : "v"(iacc[0]));
             if (KIND == 6) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(acc[0]) : "v"(a), "v"(b));   /* one dependent chain */
             if (KIND == 7) asm volatile("v_min3_f32 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
+            if (KIND == 8) asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[10:11]" : "+v"(acc[i]) : "v"(a));              /* mask in an SGPR pair */
+            if (KIND == 9) asm volatile("v_cmp_lt_f32 vcc, %1, %0\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(acc[i]) : "v"(a) : "vcc");   /* compare + select pair (2 instrs) */
+            if (KIND == 10) asm volatile("v_cmp_lt_f32 vcc, %1, %0" : : "v"(acc[i]), "v"(a) : "vcc");
+            if (KIND == 11) asm volatile("v_cmp_lt_f32_e64 s[10:11], %1, %0" : : "v"(acc[i]), "v"(a) : "s10", "s11");
+            if (KIND == 12) asm volatile("v_lshl_add_u32 %0, %1, 4, %0" : "+v"(iacc[i]) : "v"(iacc[0]));
+            if (KIND == 13) asm volatile("v_max_f32 %0, %1, %2" : "=v"(acc[i]) : "v"(a), "v"(b));                       /* no read of the destination */
+            if (KIND == 14) asm volatile("v_mov_b32 %0, %1" : "=v"(acc[i]) : "v"(a));
+            if (KIND == 15) asm volatile("v_mov_b32_dpp %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(acc[i]) : "v"(a));
+            if (KIND == 16) asm volatile("s_and_b64 s[10:11], s[10:11], exec" : : : "s10", "s11", "scc");                 /* SALU issue */
+            if (KIND == 18) asm volatile("v_fma_f64 %0, %1, %2, %0" : "+v"(dacc[i]) : "v"(da), "v"(db));
+            if (KIND == 19) asm volatile("v_mul_f64 %0, %1, %0" : "+v"(dacc[i]) : "v"(db));
+            if (KIND == 20) asm volatile("v_rndne_f64 %0, %0" : "+v"(dacc[i]));
+            if (KIND == 21) asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(dacc[i]) : "v"(acc[i]));
+            if (KIND == 22) asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(acc[i]) : "v"(dacc[i]));
+            if (KIND == 23) asm volatile("v_rcp_f32 %0, %0" : "+v"(acc[i]));
+            if (KIND == 24) asm volatile("v_sqrt_f32 %0, %0" : "+v"(acc[i]));
+            if (KIND == 25) asm volatile("v_div_scale_f32 %0, vcc, %1, %1, %0" : "+v"(acc[i]) : "v"(a) : "vcc");
+            if (KIND == 26) asm volatile("v_div_fmas_f32 %0, %0, %1, %2" : "+v"(acc[i]) : "v"(a), "v"(b));
+            if (KIND == 27) asm volatile("v_div_fixup_f32 %0, %0, %1, %2" : "+v"(acc[i]) : "v"(a), "v"(b));
+            if (KIND == 28) asm volatile("v_floor_f32 %0, %0" : "+v"(acc[i]));
+            if (KIND == 29) asm volatile("v_add_f32 %0, %1, %0" : "+v"(acc[i]) : "v"(a));
+            if (KIND == 30) asm volatile("v_pk_mul_f32 %0, %1, %0" : "+v"(acc2[i]) : "v"(a2));
+            if (KIND == 31) asm volatile("v_med3_f32 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
+            if (KIND == 32) asm volatile("v_cvt_i32_f64 %0, %1" : "=v"(iacc[i]) : "v"(dacc[i]));
+            if (KIND == 33) asm volatile("v_floor_f64 %0, %0" : "+v"(dacc[i]));
+            if (KIND == 17) asm volatile("v_fma_f32 %0, %1, %2, %0\n\ts_and_b64 s[10:11], s[10:11], exec" : "+v"(acc[i]) : "v"(a), "v"(b) : "s10", "s11", "scc");   /* VALU + SALU pair */
         }
     }
     const unsigned long long t1 = __builtin_readcyclecounter(), r1 = wall_clock64();
-    float s = 0; for (int i = 0; i < UNROLL; i++) s += acc[i] + acc2[i].x + acc2[i].y + (float)iacc[i];
+    float s = 0; for (int i = 0; i < UNROLL; i++) s += acc[i] + acc2[i].x + acc2[i].y + (float)iacc[i] + (float)dacc[i];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
     if ((threadIdx.x & 63) == 0) { cycles[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0; realtime[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = r1 - r0; }
 }
@@ -75,9 +103,14 @@ int main()
 {
     hipDeviceProp_t p; CHECK(hipGetDeviceProperties(&p, 0));
     printf("%s, %d CUs, clockRate %d kHz\n", p.gcnArchName, p.multiProcessorCount, p.clockRate);
-    for (int w : {1, 2, 4}) {
+    for (int w : {1, 4}) {
         run<0>("v_fma_f32", w); run<1>("v_pk_fma_f32", w); run<2>("v_mul_f32", w); run<3>("v_max_f32", w);
-        run<7>("v_min3_f32", w); run<4>("v_cndmask_b32", w); run<5>("v_add_u32", w); run<6>("v_fma_f32 dependent", w);
+        run<7>("v_min3_f32", w); run<4>("v_cndmask_b32 vcc", w); run<8>("v_cndmask_b32 sgpr", w); run<9>("v_cmp+v_cndmask (2)", w); run<10>("v_cmp_lt_f32 vcc", w);
+        run<11>("v_cmp_lt_f32 sgpr", w); run<12>("v_lshl_add_u32", w); run<13>("v_max_f32 (no dst read)", w); run<14>("v_mov_b32", w); run<15>("v_mov_b32 dpp quad", w);
+        run<18>("v_fma_f64", w); run<19>("v_mul_f64", w); run<20>("v_rndne_f64", w); run<33>("v_floor_f64", w); run<21>("v_cvt_f64_f32", w); run<22>("v_cvt_f32_f64", w); run<32>("v_cvt_i32_f64", w);
+        run<23>("v_rcp_f32", w); run<24>("v_sqrt_f32", w); run<25>("v_div_scale_f32", w); run<26>("v_div_fmas_f32", w); run<27>("v_div_fixup_f32", w); run<28>("v_floor_f32", w);
+        run<29>("v_add_f32", w); run<30>("v_pk_mul_f32", w); run<31>("v_med3_f32", w);
+        run<16>("s_and_b64", w); run<17>("v_fma_f32 + s_and_b64 (2)", w); run<5>("v_add_u32", w); run<6>("v_fma_f32 dependent", w);
     }
     printf("ns per wave-instr per SIMD x shader clock (GHz) = cycles; at 2.4 GHz: 2 cycles = 0.833 ns, 4 cycles = 1.667 ns\n");
     return 0;
