@@ -317,25 +317,36 @@ def test_split_traversal_stack_bit_exact(gpu_tb, settings, scene):
         gpu_tb.SetOption("stack_lds_cap", 0); gpu_tb.SetOption("stack_overflow_max", 16)
 
 
-@pytest.mark.parametrize("scene", ["cornell", "teapot", "proc0"])
-def test_wavefront_pipeline_bit_exact(gpu_tb, settings, scene):
+@pytest.mark.parametrize("sort", [0, 1])
+@pytest.mark.parametrize("scene", ["cornell", "teapot", "proc0", "proc1", "proc2"])
+def test_wavefront_pipeline_bit_exact(gpu_tb, settings, scene, sort):
     """SoA-queue wavefront pipeline (generate/extend/shade/connect kernels, ballot-prefix compaction, frames of a
     batch in flight together, ordered accumulation from the sample buffer) against the oracle; the path budget is
-    forced small so that several batches and partially filled queues occur."""
+    forced small so that several batches and partially filled queues occur.  proc1 / proc2: the SSS interior walk as
+    queue entries of their own (glass, mix-free "vol" feature set; rounds until the queues are empty).  sort = 1:
+    wf_shade shades every segment in material order (option wavefront_sort) -- same bits."""
     if scene == "cornell":
         gpu_tb.LoadScene(CORNELL); W, H, F, depth = 200, 120, 7, 8
     elif scene == "teapot":
         gpu_tb.LoadScene(TEAPOT); W, H, F, depth = 96, 54, 3, 5
-    else:
+    elif scene == "proc0":
         gpu_tb.LoadProcedural(0, 30000, 11); W, H, F, depth = 120, 72, 4, 6
+    elif scene == "proc1":
+        gpu_tb.LoadProcedural(1, 30000, 7); W, H, F, depth = 120, 72, 4, 6
+    else:
+        gpu_tb.LoadProcedural(2, 60000, 9); W, H, F, depth = 120, 72, 3, 16
     s = copy.copy(settings); s.MaxBounces = depth
-    gpu_tb.SetOption("pipeline", 2); gpu_tb.SetOption("wavefront_paths", W * H * 3)
+    gpu_tb.SetOption("pipeline", 2); gpu_tb.SetOption("wavefront_paths", W * H * 3); gpu_tb.SetOption("wavefront_sort", sort)
+    gpu_tb.SetOption("wavefront_segment", 1024 if scene == "proc2" else 4096)
     try:
         gpu_tb.Render(W, H, F - 2, s, 0.0)
         gpu_tb.Render(W, H, 2, s, 0.0)   # progressive: second call continues the accumulation
         out, jit = gpu_tb.ReadAccumulation(jittered=True)
+        variant = gpu_tb.GetOption("last_variant")
+        assert gpu_tb.GetOption("last_pipeline") == 2
     finally:
-        gpu_tb.SetOption("pipeline", 0); gpu_tb.SetOption("wavefront_paths", 16 << 20)
+        gpu_tb.SetOption("pipeline", 0); gpu_tb.SetOption("wavefront_paths", 16 << 20); gpu_tb.SetOption("wavefront_sort", 0); gpu_tb.SetOption("wavefront_segment", 4096)
+    if scene in ("proc1", "proc2"): assert variant == 3          # "vol": SSS + mix
     ref = _oracle(gpu_tb, W, H, F, s, jittered=True)
     assert np.array_equal(bits(out), bits(ref["output"]))
     assert np.array_equal(bits(jit), bits(ref["jittered"]))

@@ -40,12 +40,13 @@ typedef hipError_t (*wf_variant_fn)(hipStream_t, int, const TbDeviceScene*, cons
 hipError_t wf_launch_matte(hipStream_t, int, const TbDeviceScene*, const TbPerFrameConstants*, const WfParams*, const WfQueue*, const WfQueue*, const WfQueue*, const WfHits*, int, TbFloat4*, TbFloat4*, uint32_t);
 hipError_t wf_launch_env(hipStream_t, int, const TbDeviceScene*, const TbPerFrameConstants*, const WfParams*, const WfQueue*, const WfQueue*, const WfQueue*, const WfHits*, int, TbFloat4*, TbFloat4*, uint32_t);
 hipError_t wf_launch_surf(hipStream_t, int, const TbDeviceScene*, const TbPerFrameConstants*, const WfParams*, const WfQueue*, const WfQueue*, const WfQueue*, const WfHits*, int, TbFloat4*, TbFloat4*, uint32_t);
+hipError_t wf_launch_vol(hipStream_t, int, const TbDeviceScene*, const TbPerFrameConstants*, const WfParams*, const WfQueue*, const WfQueue*, const WfQueue*, const WfHits*, int, TbFloat4*, TbFloat4*, uint32_t);
 }
 
 namespace {
 
 std::string g_createError;
-const wf_variant_fn kWfVariants[3] = {wf_launch_matte, wf_launch_env, wf_launch_surf}; /* same order as kVariants[0..2] */
+const wf_variant_fn kWfVariants[4] = {wf_launch_matte, wf_launch_env, wf_launch_surf, wf_launch_vol}; /* same order as kVariants[0..3]; pipeline 3 (pooled) exists for 0..2 */
 
 /* fnHi: the same feature set compiled to `wavesHi` waves per SIMD (fewer VGPRs, more scratch; pipeline 0 only), used when LDS
  * has room for that many workgroups per CU -- otherwise its spills would buy no residency */
@@ -93,8 +94,9 @@ struct tb_context {
     uint32_t rtActive = 0, rtWidth = 0, rtHeight = 0; int rtLast[5] = {-1, -1, -1, -1, -1}; /* which buffer holds each stage's last output */
     bool lastRenderRealtime = false; tb_camera prevCamera{};
     /* wavefront pipeline: two ping-pong extend queues (4 columns), one shadow queue (11 columns), hits, samples, counters */
-    DevBuf wfCols[2][4], wfShadowCols[11], wfHitA, wfHitG, wfSamples, wfCounts, workCounter;
+    DevBuf wfCols[2][6], wfShadowCols[12], wfHitA, wfHitG, wfSamples, wfCounts, workCounter;
     uint64_t wfCapacity = 0, wfSampleCapacity = 0;
+    int lastPipeline = 0;
     uint32_t samplesRendered = 0;
     tb_output_settings lastSettings{}; bool haveLastSettings = false;
     float lastTime = 0.0f;
@@ -383,38 +385,56 @@ void renderWavefront(tb_context* c, int variant, uint32_t W, uint32_t H, uint32_
     const uint64_t maxSegments = (perFrame * batch + segCap - 1) / segCap;
     const uint64_t capacity = maxSegments * segCap;
     if (capacity > 0xffffff00ull) throw std::runtime_error("wavefront batch exceeds 2^32 paths");
+    const bool sss = (kVariants[variant].features & PT_FEAT_SSS) != 0; /* entries may be steps of the interior walk: two more columns per queue */
     {
-        for (int q = 0; q < 2; q++) for (int k = 0; k < 4; k++) ensure(c->wfCols[q][k], capacity * 16);
-        for (int k = 0; k < 11; k++) ensure(c->wfShadowCols[k], capacity * 16);
+        for (int q = 0; q < 2; q++) for (int k = 0; k < (sss ? 6 : 4); k++) ensure(c->wfCols[q][k], capacity * 16);
+        for (int k = 0; k < (sss ? 12 : 11); k++) if (sss || k != 8) ensure(c->wfShadowCols[k], capacity * 16); /* column i (8) and l (11): FEAT_SSS only */
         ensure(c->wfHitA, capacity * 16); ensure(c->wfHitG, capacity * 4);
         ensure(c->wfSamples, pixels * batch * 16);
         ensure(c->wfCounts, maxSegments * 3 * 4);
         c->wfCapacity = capacity;
     }
     WfQueue E[2], S; memset(E, 0, sizeof E); memset(&S, 0, sizeof S);
-    for (int q = 0; q < 2; q++) { E[q].a = (float4*)c->wfCols[q][0].p; E[q].b = (float4*)c->wfCols[q][1].p; E[q].c = (float4*)c->wfCols[q][2].p; E[q].d = (float4*)c->wfCols[q][3].p; }
-    float4** sc[11] = {&S.a, &S.b, &S.c, &S.d, &S.e, &S.f, &S.g, &S.h, &S.i, &S.j, &S.k};
-    for (int k = 0; k < 11; k++) *sc[k] = (float4*)c->wfShadowCols[k].p;
+    for (int q = 0; q < 2; q++) {
+        E[q].a = (float4*)c->wfCols[q][0].p; E[q].b = (float4*)c->wfCols[q][1].p; E[q].c = (float4*)c->wfCols[q][2].p; E[q].d = (float4*)c->wfCols[q][3].p;
+        E[q].e = (float4*)c->wfCols[q][4].p; E[q].f = (float4*)c->wfCols[q][5].p;
+    }
+    float4** sc[12] = {&S.a, &S.b, &S.c, &S.d, &S.e, &S.f, &S.g, &S.h, &S.i, &S.j, &S.k, &S.l};
+    for (int k = 0; k < 12; k++) *sc[k] = (float4*)c->wfShadowCols[k].p;
     /* per-segment fill counts; every stage writes the counts of all segments of its output queues, so no clearing */
     E[0].segCount = (uint32_t*)c->wfCounts.p; E[1].segCount = E[0].segCount + maxSegments; S.segCount = E[1].segCount + maxSegments;
     WfHits hits; hits.tuv_prim = (float4*)c->wfHitA.p; hits.geom = (uint32_t*)c->wfHitG.p;
     const wf_variant_fn fn = kWfVariants[variant];
     const uint32_t gridOpt = (uint32_t)opt("wavefront_grid", 256 * 8);
     const uint32_t depth = pf.MaxBounces;
+    std::vector<uint32_t> counts;
     for (uint32_t f0 = 0; f0 < n; f0 += batch) {
         const uint32_t nf = std::min(batch, n - f0);
         WfParams wp; memset(&wp, 0, sizeof wp);
         wp.W = W; wp.H = H; wp.firstFrame = firstFrame + f0; wp.numFrames = nf; wp.tiles = c->tiles;
         wp.samples = (float4*)c->wfSamples.p;
         wp.segCapacity = segCap; wp.numSegments = (uint32_t)((perFrame * nf + segCap - 1) / segCap);
+        wp.sortByMaterial = opt("wavefront_sort", 0) ? 1u : 0u;
         const uint32_t grid = std::min(gridOpt, wp.numSegments);
         const int lds = c->sceneInLds ? 1 : 0;
         HIP_TRY(fn(c->stream, WF_STAGE_GENERATE_EXTEND, &c->ds, &pf, &wp, nullptr, nullptr, &E[0], &hits, lds, nullptr, nullptr, grid));
-        for (uint32_t b = 0; b < depth; b++) {
+        /* One round = one ray per live path.  Without SSS a path casts one extension ray per bounce, so MaxBounces rounds empty the
+         * queues.  With SSS every step of an interior walk is a round of its own (up to 100 per bounce, kernel.glsl:1565): past the
+         * first MaxBounces rounds the host reads the segment counts back before each round and stops when nothing is left. */
+        for (uint32_t b = 0; depth > 0; b++) {
             const WfQueue& in = E[b & 1]; const WfQueue& next = E[(b + 1) & 1];
             HIP_TRY(fn(c->stream, WF_STAGE_SHADE, &c->ds, &pf, &wp, &in, &S, &next, &hits, lds, nullptr, nullptr, grid));
             HIP_TRY(fn(c->stream, WF_STAGE_CONNECT, &c->ds, &pf, &wp, nullptr, &S, &next, &hits, lds, nullptr, nullptr, grid));
-            if (b + 1 < depth) HIP_TRY(fn(c->stream, WF_STAGE_EXTEND, &c->ds, &pf, &wp, nullptr, nullptr, &next, &hits, lds, nullptr, nullptr, grid));
+            if (!sss && b + 1 >= depth) break;
+            if (sss && b + 1 >= depth) {
+                counts.resize(wp.numSegments);
+                HIP_TRY(hipMemcpyAsync(counts.data(), next.segCount, (size_t)wp.numSegments * 4, hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(hipStreamSynchronize(c->stream));
+                uint64_t live = 0; for (uint32_t v : counts) live += v;
+                if (live == 0) break;
+                if (b > depth * 101u + 8u) throw std::runtime_error("wavefront pipeline: paths still alive after MaxBounces x 101 rounds");
+            }
+            HIP_TRY(fn(c->stream, WF_STAGE_EXTEND, &c->ds, &pf, &wp, nullptr, nullptr, &next, &hits, lds, nullptr, nullptr, grid));
         }
         HIP_TRY(fn(c->stream, WF_STAGE_ACCUMULATE, &c->ds, &pf, &wp, nullptr, nullptr, nullptr, &hits, lds, (TbFloat4*)c->output.p, (TbFloat4*)c->jittered.p, gridOpt));
     }
@@ -487,7 +507,7 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
     if (!v) v = &kVariants[4];
     c->lastVariant = v->name;
     const int variantIndex = (int)(v - kVariants);
-    const bool wavefront = opt("pipeline", 0) == 2 && variantIndex <= 2 && !count && !aov;
+    const bool wavefront = opt("pipeline", 0) == 2 && variantIndex <= 3 && !count && !aov;
     const bool pooled = opt("pipeline", 0) == 3 && variantIndex <= 2 && !count && !aov;
     const int64_t fg = opt("frame_group", 0);
     const bool groups = !wavefront && !pooled && opt("pipeline", 0) == 0 && !count && !aov && !s.RenderModeRealTime && fg >= 0 && (fg > 0 || n >= (c->sceneInLds ? 1u : 2u)); /* measured: frame groups win from 2 frames per call on (cornell-box 4 spp +23 %, 870 k scene 4 spp 2x); one frame per call: +17 % with the scene in LDS, -9 % on the 870 k scene */
@@ -522,6 +542,7 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
     if (clearStats && !overlap) HIP_TRY(hipMemsetAsync(c->stats.p, 0, 16, c->stream));
     if (!groups) HIP_TRY(hipEventRecord(c->evKernelStart, c->stream));
     c->lastKernelFrames = 0;
+    c->lastPipeline = wavefront ? 2 : (pooled ? 3 : (int)(opt("pipeline", 0) == 1 ? 1 : 0));
     if (wavefront) renderWavefront(c, variantIndex, W, H, c->samplesRendered, n, pf);
     else if (pooled) renderPooled(c, variantIndex, W, H, c->samplesRendered, n, pf);
     else {
@@ -1001,7 +1022,7 @@ int tb_unpack_gathered_host(uint32_t W, uint32_t H, uint32_t world, uint32_t tw,
 int tb_set_option(tb_context* c, const char* name, int64_t v)
 {
     if (!c || !name) return TB_E_INVALID;
-    static const char* known[] = {"pipeline", "count_rays", "bvh_builder", "flatten_instances", "aov", "scene_in_lds", "lds_scene_budget", "force_full_variant", "wavefront_paths", "wavefront_grid", "wavefront_segment", "pooled_paths", "pooled_samples", "pooled_profile", "park_min", "alpha_test", "node_order", "node_order_top_levels", "frame_group", "overlap_launches", "high_occupancy", "stack_lds_cap", "stack_overflow_max", "flip_texture_uvs"};
+    static const char* known[] = {"pipeline", "count_rays", "bvh_builder", "flatten_instances", "aov", "scene_in_lds", "lds_scene_budget", "force_full_variant", "wavefront_paths", "wavefront_grid", "wavefront_segment", "pooled_paths", "pooled_samples", "pooled_profile", "park_min", "alpha_test", "node_order", "node_order_top_levels", "frame_group", "overlap_launches", "high_occupancy", "stack_lds_cap", "stack_overflow_max", "flip_texture_uvs", "wavefront_sort"};
     for (const char* k : known) if (!strcmp(k, name)) { c->options[name] = v; if (!strcmp(name, "count_rays") || !strcmp(name, "aov")) c->samplesRendered = 0; return TB_OK; }
     return fail(c, TB_E_INVALID, std::string("unknown option '") + name + "'");
 }
@@ -1012,6 +1033,7 @@ int64_t tb_get_option(tb_context* c, const char* name)
     if (!strcmp(name, "scene_features")) return c->sceneFeatures;
     if (!strcmp(name, "last_kernel_us")) return (int64_t)(c->lastKernelMs * 1000.0f + 0.5f); /* first path-tracing launch of the last synchronous render */
     if (!strcmp(name, "last_kernel_frames")) return c->lastKernelFrames;
+    if (!strcmp(name, "last_pipeline")) return c->lastPipeline; /* the pipeline the last render actually ran (2 / 3 fall back to 0 for feature sets they lack) */
     if (!strcmp(name, "last_variant")) { for (int i = 0; i < 5; i++) if (c->lastVariant == kVariants[i].name) return i; return -1; }
     auto it = c->options.find(name); return it == c->options.end() ? 0 : it->second;
 }

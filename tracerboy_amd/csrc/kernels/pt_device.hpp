@@ -211,6 +211,7 @@ TBD void tri_test(Hit& best, float tMin, tb3 o, const RayPre& r, const TbTriB& t
     float t0 = T * rcpDet;
     if (t0 < best.t && t0 > tMin) {
         const float bu = V * rcpDet, bv = W * rcpDet;
+        /* non-opaque candidate (D3D12_RAYTRACING_GEOMETRY_FLAG_OPAQUE clear): RayGenCommon.h:423-434 */
         if (ALPHA && ds.alphaTest && !(tri.geometryFlags & 1u) && !is_valid_hit(sc, ds, tri.geometryIndex, tri.primitiveIndex, bu, bv)) return;
         best.t = t0; best.u = bu; best.v = bv;
         best.prim = tri.primitiveIndex; best.geom = tri.geometryIndex;
