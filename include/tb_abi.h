@@ -232,6 +232,28 @@ typedef struct TbTriB {
 } TbTriB;
 TB_STATIC_ASSERT(sizeof(TbTriB) == 48, "layout-B triangle is 48 B");
 
+/* ---- two-level (instanced) acceleration structures ---------------------------------------------
+ * Layout A of a top-level structure, as the fallback layer writes it (TopLevelLoadAABBs.hlsli:62-105): the same 16-B header
+ * and 32-B AABB nodes as a bottom level (inner 0..M-2, leaf M-1+k, leaf flag | k), then one BVHMetadata per SORTED leaf. */
+typedef struct TbBvhMetadata { /* BVHMetadata, RayTracingHlslCompat.h:226-235 (SizeOfBVHMetadata 116) */
+    float WorldToObject[12];   /* RaytracingInstanceDesc.Transform after the build inverted it (three float4 rows) */
+    uint32_t InstanceIDAndMask;                            /* id: low 24 bits, mask: high 8 */
+    uint32_t InstanceContributionToHitGroupIndexAndFlags;  /* contribution: low 24 bits, flags: high 8 */
+    uint32_t BlasIndex, BlasPad;                           /* stands in for the 8-B GpuVA of the bottom-level structure */
+    float ObjectToWorld[12];
+    uint32_t InstanceIndex;
+} TbBvhMetadata;
+TB_STATIC_ASSERT(sizeof(TbBvhMetadata) == 116, "BVHMetadata is 116 B");
+
+/* Layout B of an instance: what the kernels fetch at a top-level leaf (64 B, four aligned 16-B loads) */
+typedef struct TbInstanceB {
+    float worldToObject[12];
+    uint32_t blasRootRef;      /* child-ref encoding of the bottom-level root inside the shared node / triangle arrays */
+    uint32_t hitGroupBase;     /* InstanceContributionToHitGroupIndex */
+    uint32_t instanceId, pad;
+} TbInstanceB;
+TB_STATIC_ASSERT(sizeof(TbInstanceB) == 64, "layout-B instance is 64 B");
+
 /* ---- image / environment textures ---------------------------------------------------------- */
 typedef struct TbImageDesc {
     uint32_t width, height;
@@ -259,6 +281,12 @@ typedef struct TbSceneView {
     const TbFloat4* blueNoise0;          /* 256x256, null unless UseBlueNoise */
     const TbFloat4* blueNoise1;
     TbConfigConstants config;
+    /* two-level scenes (option flatten_instances = 0): `bvh` holds the bottom-level images back to back, image b at
+     * blasOffsets[b]; `tlas` is the top-level image.  numInstances == 0: one bottom level at offset 0, traced directly
+     * (the reference's FAST_PATH). */
+    const uint8_t* tlas;                 uint32_t tlasBytes;
+    uint32_t numInstances;               uint32_t numBlas;
+    const uint32_t* blasOffsets;         /* numBlas + 1 entries */
 } TbSceneView;
 
 /* Per-sample traversal counters with the reference's semantics

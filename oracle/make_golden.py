@@ -5,7 +5,8 @@ and `make -C oracle ref`).  TEST INFRASTRUCTURE ONLY.
   cornell-box.pbf             Scenes/cornell-box serialised by the REFERENCE parser's own binary writer (pbrt_dump --save-pbf)
   cornell-box.parser.txt      the REFERENCE parser's view of Scenes/cornell-box (oracle/_ref/pbrt_dump),
                               bit patterns in hex; pins tracerboy_amd's own PBRT loader
-  material-maps.parser.txt    the same dump for the hand-written fixture scene tests/golden/scenes/material-maps
+  material-maps.parser.txt    the same dump for the hand-written fixture scenes tests/golden/scenes/material-maps
+  instances.parser.txt        and tests/golden/scenes/instances (ObjectBegin / ObjectInstance, nested)
   teapot.parser.digest.json   per-record sha256 digest of the same dump for Scenes/Teapot (126 050 tris)
   scenes/cornell-box/         the scene file itself (input data)
   scenes/Teapot/              geometry (CC0) + scene file with the infinite light pointed at a synthetic
@@ -96,12 +97,13 @@ def main():
                 g.write(line)
     # the same scene serialised by the REFERENCE parser's own binary writer (pbrt::Scene::saveTo): fixture of the .pbf reader
     subprocess.run([DUMP, "--save-pbf", os.path.join(REF, "Scenes", "cornell-box", "scene.pbrt"), os.path.join(GOLD, "cornell-box.pbf")], check=True)
-    # the hand-written material-maps fixture scene (tests/golden/scenes/material-maps) as the REFERENCE parser sees it
-    subprocess.run([DUMP, os.path.join(GOLD, "scenes/material-maps/scene.pbrt"), tmp], check=True, stdout=subprocess.DEVNULL)
-    with open(tmp) as f, open(os.path.join(GOLD, "material-maps.parser.txt"), "w") as g:
-        for line in f:
-            if not line.startswith("material_ptr"):
-                g.write(line)
+    # the hand-written fixture scenes (tests/golden/scenes/{material-maps,instances}) as the REFERENCE parser sees them
+    for name in ("material-maps", "instances"):
+        subprocess.run([DUMP, os.path.join(GOLD, "scenes/%s/scene.pbrt" % name), tmp], check=True, stdout=subprocess.DEVNULL)
+        with open(tmp) as f, open(os.path.join(GOLD, name + ".parser.txt"), "w") as g:
+            for line in f:
+                if not line.startswith("material_ptr"):
+                    g.write(line)
     subprocess.run([DUMP, os.path.join(REF, "Scenes/Teapot/scene.pbrt"), tmp], check=True, stdout=subprocess.DEVNULL)
     json.dump(digest_records(tmp), open(os.path.join(GOLD, "teapot.parser.digest.json"), "w"), indent=0)
     # 3. blue-noise tiles (data files of the reference: TracerBoy/Textures/LDR_RGBA_{0,1}.png, TracerBoy.cpp:2129-2130)

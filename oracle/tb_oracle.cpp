@@ -189,9 +189,11 @@ static int g_alphaTest = 0;
 bool IsValidHit(const TbSceneView* sc, uint32_t geometryIndex, uint32_t primitiveIndex, float b0, float b1);
 
 /* TraverseFunction.hlsli:537-779 */
+bool TraverseTwoLevel(const TbSceneView* sc, tb3 origin, tb3 direction, float TMin, float TMax, Committed& hit, uint32_t& trianglesTested, uint32_t& boxesTested);
 bool Traverse(const TbSceneView* sc, tb3 origin, tb3 direction, float TMin, float TMax, Committed& hit,
               uint32_t& trianglesTested, uint32_t& boxesTested)
 {
+    if (sc->numInstances) return TraverseTwoLevel(sc, origin, direction, TMin, TMax, hit, trianglesTested, boxesTested);
     const uint8_t* bvh = sc->bvh;
     trianglesTested = 0; boxesTested = 0;
     hit.t = TMax; hit.bary[0] = hit.bary[1] = 0; hit.primitiveIndex = hit.geometryIndex = 0;
@@ -250,6 +252,102 @@ bool Traverse(const TbSceneView* sc, tb3 origin, tb3 direction, float TMin, floa
         }
     }
     return hit.t < TMax; /* :776 */
+}
+
+/* TraverseFunction.hlsli:537-779 with FAST_PATH 0: the two-level walk of instanced scenes (the !FAST_PATH branch :603-640).
+ * Top-level image sc->tlas (TopLevelLoadAABBs.hlsli layout: header, AABB nodes, one BVHMetadata per sorted leaf), bottom-level
+ * images inside sc->bvh at sc->blasOffsets[BlasIndex].  One stack, a node counter per level (nodesToProcess[2], :549,:594):
+ * a bottom level runs until its counter is zero, then the world ray data come back (:769-773).  The committed hit's hit-group
+ * index is InstanceContributionToHitGroupIndex + GeometryContributionToHitGroupIndex (RayGenCommon.h:392 adds the instance INDEX,
+ * which is the same number in the reference's own instance table, TracerBoy.cpp:2050). */
+inline tb3 MulPoint34(const float* m, tb3 v) /* mul(float3x4, float4(v, 1)): the order of the dp4 pinned as one fma chain per row */
+{
+    return tb3_make(tb_fma(m[2], v.z, tb_fma(m[1], v.y, tb_fma(m[0], v.x, m[3]))), tb_fma(m[6], v.z, tb_fma(m[5], v.y, tb_fma(m[4], v.x, m[7]))),
+                    tb_fma(m[10], v.z, tb_fma(m[9], v.y, tb_fma(m[8], v.x, m[11]))));
+}
+inline tb3 MulVector34(const float* m, tb3 v) /* mul(float3x4, float4(v, 0)) */
+{
+    return tb3_make(tb_fma(m[2], v.z, tb_fma(m[1], v.y, m[0] * v.x)), tb_fma(m[6], v.z, tb_fma(m[5], v.y, m[4] * v.x)), tb_fma(m[10], v.z, tb_fma(m[9], v.y, m[8] * v.x)));
+}
+
+bool TraverseTwoLevel(const TbSceneView* sc, tb3 origin, tb3 direction, float TMin, float TMax, Committed& hit,
+                      uint32_t& trianglesTested, uint32_t& boxesTested)
+{
+    trianglesTested = 0; boxesTested = 0;
+    hit.t = TMax; hit.bary[0] = hit.bary[1] = 0; hit.primitiveIndex = hit.geometryIndex = 0;
+    const uint8_t* tlas = sc->tlas;
+    if (!tlas || !sc->bvh || !sc->blasOffsets || sc->numInstances == 0) return false;
+    const uint32_t offBoxes = 16, offInstanceDescs = ld32(tlas + 4); /* GetOffsetToInstanceDesc, RayTracingHelper.hlsli:66-67 */
+    RayData rd = GetRayData(origin, direction); /* :545 */
+    enum { TOP = 0, BOTTOM = 1 };
+    uint32_t nodesToProcess[2] = {0, 0};
+    bool processingBottom = false;
+    const uint8_t* current = tlas;
+    uint32_t instanceOffset = 0;
+    tb3 objectOrigin = origin;
+    uint32_t stack[ORACLE_STACK];
+    int top = 0;
+    {
+        const uint8_t* n = tlas + offBoxes;
+        float unusedT;
+        if (RayBoxTest(unusedT, hit.t, rd, to3((const float*)n), to3((const float*)(n + 16)))) { stack[top++] = 0; nodesToProcess[TOP]++; } /* :566-580 */
+    }
+    while (nodesToProcess[TOP] != 0) { /* :584 */
+        do {
+            const uint32_t node = stack[--top]; /* :589 */
+            nodesToProcess[processingBottom ? BOTTOM : TOP]--;
+            const uint8_t* n = current + offBoxes + 32u * node;
+            const uint32_t flagsX = ld32(n + 12), flagsY = ld32(n + 28);
+            if (flagsX & TB_BVH_LEAF_FLAG) {
+                if (!processingBottom) { /* :603-640 */
+                    const uint32_t leafIndex = flagsX & ~(TB_BVH_LEAF_FLAG | TB_BVH_PROCEDURAL_FLAG);
+                    TbBvhMetadata md; memcpy(&md, tlas + offInstanceDescs + 116u * leafIndex, 116);
+                    instanceOffset = md.InstanceContributionToHitGroupIndexAndFlags & 0x00ffffffu;
+                    const bool validInstance = ((md.InstanceIDAndMask >> 24) & 0xffu /* ~0 inclusion mask */) != 0;
+                    if (validInstance && md.BlasIndex < sc->numBlas) {
+                        processingBottom = true;
+                        if (top + 1 > ORACLE_STACK) return false;
+                        stack[top++] = 0; /* the bottom level's root, untested (:625) */
+                        current = sc->bvh + sc->blasOffsets[md.BlasIndex];
+                        objectOrigin = MulPoint34(md.WorldToObject, origin);
+                        const tb3 objectDirection = MulVector34(md.WorldToObject, direction);
+                        rd = GetRayData(objectOrigin, objectDirection); /* :632-634 */
+                        nodesToProcess[BOTTOM] = 1;
+                    }
+                } else { /* :641-709 */
+                    const uint32_t offPrims = ld32(current + 4), offMeta = ld32(current + 8);
+                    const uint32_t leafIndex = flagsX & ~(TB_BVH_LEAF_FLAG | TB_BVH_PROCEDURAL_FLAG);
+                    const uint8_t* m = current + offMeta + 12u * leafIndex;
+                    const uint32_t geomContribution = ld32(m), primIdx = ld32(m + 4);
+                    trianglesTested++;
+                    const uint8_t* p = current + offPrims + 40u * (flagsX & TB_BVH_INDEX_MASK) + 4;
+                    const tb3 v0 = tb3_make(ldf(p), ldf(p + 4), ldf(p + 8)), v1 = tb3_make(ldf(p + 12), ldf(p + 16), ldf(p + 20)), v2 = tb3_make(ldf(p + 24), ldf(p + 28), ldf(p + 32));
+                    float t0 = hit.t, b[2] = {0, 0};
+                    RayTriangleIntersect(t0, b, objectOrigin, rd, v0, v1, v2); /* ObjectRayOrigin / ObjectRayDirection, :667-668 */
+                    if (t0 < hit.t && t0 > TMin) {
+                        hit.t = t0; hit.bary[0] = b[0]; hit.bary[1] = b[1];
+                        hit.primitiveIndex = primIdx; hit.geometryIndex = instanceOffset + geomContribution;
+                    }
+                }
+            } else { /* :717-766 */
+                const uint32_t l = flagsX & TB_BVH_INDEX_MASK, r = flagsY;
+                const uint8_t* ln = current + offBoxes + 32u * l;
+                const uint8_t* rn = current + offBoxes + 32u * r;
+                float lt, rt;
+                const bool lh = RayBoxTest(lt, hit.t, rd, to3((const float*)ln), to3((const float*)(ln + 16)));
+                const bool rh = RayBoxTest(rt, hit.t, rd, to3((const float*)rn), to3((const float*)(rn + 16)));
+                boxesTested += 2;
+                if (top + 2 > ORACLE_STACK) return false;
+                if (lh && rh) { const bool rightFirst = rt < lt; stack[top++] = rightFirst ? l : r; stack[top++] = rightFirst ? r : l; nodesToProcess[processingBottom ? BOTTOM : TOP] += 2; }
+                else if (lh || rh) { stack[top++] = rh ? r : l; nodesToProcess[processingBottom ? BOTTOM : TOP] += 1; }
+            }
+        } while (nodesToProcess[processingBottom ? BOTTOM : TOP] != 0);
+        processingBottom = false; /* :769-773 */
+        rd = GetRayData(origin, direction);
+        objectOrigin = origin;
+        current = tlas;
+    }
+    return hit.t < TMax;
 }
 
 /* ------------------------------------------------------------------------------------------

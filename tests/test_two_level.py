@@ -1,0 +1,160 @@
+"""Row f3, second half: two-level (instanced) traversal -- TraverseFunction.hlsli:603-640, the !FAST_PATH branch -- with
+flatten_instances = 0.  Fixture tests/golden/scenes/instances: one two-geometry object instanced three times (translation,
+rotation + non-uniform scale, mirror), a nested object holding two more instances of it, instanced twice, and a single-triangle
+object (its bottom-level root is a leaf), beside world-level shapes (the reference's "global BLAS" under an identity instance).
+
+CPU: the loader against the REFERENCE parser's dump; the structure the host builds (instances, hit-group bases, top-level boxes,
+inverse transforms); the oracle's two-level picture against its own picture of the flattened scene.
+GPU (-m gpu): closest hits (t, barycentrics, primitive, hit-group index, counters) and radiance bit-exact against the oracle."""
+import copy
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from conftest import GOLDEN
+from tracerboy_amd import _ctypes_abi as abi
+
+SCENE = os.path.join(GOLDEN, "scenes", "instances", "scene.pbrt")
+W, H, F = 96, 64, 3
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def test_loader_matches_reference_parser_on_instances(built, tmp_path):
+    """ObjectBegin / ObjectEnd / ObjectInstance incl. nesting; the reference parser does not restore the graphics state at
+    ObjectEnd (Parser.inl:621-635) and neither does the build's."""
+    from tracerboy_amd import api
+    out = str(tmp_path / "dump.txt"); err = C.create_string_buffer(256)
+    assert api.lib().tb_host_pbrt_dump(SCENE.encode(), out.encode(), err, 256) == 0, err.value
+    assert open(out).read() == open(os.path.join(GOLDEN, "instances.parser.txt")).read()
+
+
+def _aabb_nodes(img):
+    n = (np.frombuffer(img, np.uint32, 1, 4)[0] - 16) // 32
+    raw = np.frombuffer(img, np.uint8, n * 32, 16).reshape(n, 32)
+    return raw[:, :12].copy().view(np.float32), raw[:, 12:16].copy().view(np.uint32)[:, 0], raw[:, 16:28].copy().view(np.float32), raw[:, 28:32].copy().view(np.uint32)[:, 0]
+
+
+def test_two_level_structure(built):
+    from tracerboy_amd import api
+    hs = api.HostScene(SCENE, flatten_instances=False)
+    flat = api.HostScene(SCENE, flatten_instances=True)
+    v, i = hs.view(), hs.info()
+    # world shapes (3) -> structure 0 under an identity instance; gadget x 3 + pair x 2 x 2 nested + shard = 8 more instances
+    assert (v.numInstances, v.numBlas) == (9, 3)
+    assert i.numTriangles == 6 + 14 + 1 and flat.info().numTriangles == 6 + 7 * 14 + 1
+    assert i.numGeometries == 3 + 7 * 2 + 1 == flat.info().numGeometries   # one hit-group record per (instance, geometry)
+    assert i.numLights == flat.info().numLights == 2
+    offs = [v.blasOffsets[k] for k in range(v.numBlas + 1)]
+    assert offs[0] == 0 and offs[-1] == v.bvhBytes and all(o % 16 == 0 for o in offs[:-1])
+    tl = C.string_at(v.tlas, v.tlasBytes)
+    M = v.numInstances
+    off_meta = np.frombuffer(tl, np.uint32, 4, 0)
+    assert off_meta[0] == 16 and off_meta[1] == 16 + 32 * (2 * M - 1) and off_meta[3] == v.tlasBytes == off_meta[1] + 116 * M
+    c, fx, h, fy = _aabb_nodes(tl)
+    md = [abi.TbBvhMetadata.from_buffer_copy(tl, int(off_meta[1]) + 116 * k) for k in range(M)]
+    assert sorted(m.InstanceIndex for m in md) == list(range(M))
+    bases = sorted(m.InstanceContributionToHitGroupIndexAndFlags & 0xFFFFFF for m in md)
+    assert bases == [0, 3, 5, 7, 9, 11, 13, 15, 17]                          # structure 0 has 3 geometries, the gadget 2, the shard 1
+    bvh = C.string_at(v.bvh, v.bvhBytes)
+    for k, m in enumerate(md):
+        w2o = np.array(m.WorldToObject[:], np.float64).reshape(3, 4); o2w = np.array(m.ObjectToWorld[:], np.float64).reshape(3, 4)
+        prod = np.vstack([o2w, [0, 0, 0, 1]]) @ np.vstack([w2o, [0, 0, 0, 1]])
+        assert np.allclose(prod, np.eye(4), atol=2e-6)                         # InverseAffineTransform (RayTracingHelper.hlsli:297-316)
+        # leaf box = the eight transformed corners of the structure's root box (TransformAABB :318-344)
+        bc, _, bh, _ = _aabb_nodes(bvh[offs[m.BlasIndex]:offs[m.BlasIndex + 1]])
+        lo, hi = (bc[0] - bh[0]).astype(np.float64), (bc[0] + bh[0]).astype(np.float64)
+        corners = np.array([[x, y, z, 1.0] for x in (lo[0], hi[0]) for y in (lo[1], hi[1]) for z in (lo[2], hi[2])])
+        wc = corners @ o2w.T
+        leaf = M - 1 + k
+        assert fx[leaf] == (0x80000000 | k) and fy[leaf] == 1
+        assert np.allclose(c[leaf] - h[leaf], wc.min(0), atol=1e-5) and np.allclose(c[leaf] + h[leaf], wc.max(0), atol=1e-5)
+    for n in range(M - 1):                                                     # every inner box is the union of its children's
+        l, r = fx[n] & 0xFFFFFF, fy[n]
+        lo = np.minimum(c[l] - h[l], c[r] - h[r]); hi = np.maximum(c[l] + h[l], c[r] + h[r])
+        assert np.allclose(c[n] - h[n], lo, atol=1e-5) and np.allclose(c[n] + h[n], hi, atol=1e-5)
+    # every bottom-level image passes the reference validator's invariants on its own triangles
+    tri = hs.triangles()
+    assert tri["tri_geometry"].max() == 2                                      # geometry index INSIDE a structure
+
+
+def test_two_level_oracle_agrees_with_flattened_oracle(built, settings):
+    """The same rays find the same surfaces: closest-hit t of the two-level walk equals the flattened scene's up to the rounding
+    of the object-space arithmetic, and the pictures differ only where unrotated instance normals matter (the reference keeps
+    instanced vertex attributes in object space, TracerBoy.cpp:1623-1624)."""
+    from tracerboy_amd import api
+    two = api.HostScene(SCENE, flatten_instances=False); flat = api.HostScene(SCENE, flatten_instances=True)
+    rng = np.random.default_rng(5)
+    o = np.tile(np.array([[0.5, 3.2, 8.5]], np.float32), (4000, 1))
+    d = (rng.uniform([-3.5, 0.0, -2.5], [3.5, 1.6, 4.0], (4000, 3)) - o).astype(np.float32)      # aimed at the objects
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    a, b = ol.trace_closest(two.view(), o, d), ol.trace_closest(flat.view(), o, d)
+    hit = b["t"] > 0
+    assert hit.sum() > 3000 and np.array_equal(a["t"] > 0, hit)
+    assert np.allclose(a["t"][hit], b["t"][hit], rtol=2e-5)
+    assert np.array_equal(a["material"][hit], b["material"][hit])
+    s = copy.copy(settings)
+    ia = ol.render(two.view(), two.frame_constants(s, 0, 0.0), W, H, 4, threads=8)["output"]
+    ib = ol.render(flat.view(), flat.frame_constants(s, 0, 0.0), W, H, 4, threads=8)["output"]
+    assert not np.isnan(ia).any()
+    assert abs(ia[..., :3].sum() - ib[..., :3].sum()) / ib[..., :3].sum() < 0.03
+
+
+@pytest.mark.gpu
+def test_two_level_closest_hits_bit_exact(gpu_tb, settings):
+    gpu_tb.SetOption("flatten_instances", 0)
+    try:
+        gpu_tb.LoadScene(SCENE)
+    finally:
+        gpu_tb.SetOption("flatten_instances", 1)
+    view = gpu_tb.HostSceneView()
+    assert view.numInstances == 9
+    rng = np.random.default_rng(9)
+    info = gpu_tb.SceneInfo()
+    lo, hi = np.array(info.sceneMin[:]), np.array(info.sceneMax[:])
+    ro = rng.uniform(lo - 0.5, hi + 0.5, (6000, 3)).astype(np.float32)
+    rd = rng.normal(size=(6000, 3)).astype(np.float32); rd /= np.linalg.norm(rd, axis=1, keepdims=True)
+    axis = np.eye(3, dtype=np.float32)[rng.integers(0, 3, 300)] * rng.choice([-1, 1], 300)[:, None]
+    O = np.concatenate([ro, ro[:300]]); D = np.concatenate([rd, axis.astype(np.float32)])
+    g = gpu_tb.TraceClosest(O, D); c = ol.trace_closest(view, O, D)
+    assert (c["t"] > 0).sum() > 2000
+    for k in ("t", "bary", "normal", "uv"):
+        assert np.array_equal(bits(g[k]), bits(c[k])), k
+    for k in ("material", "prim", "geom", "boxes", "tris"):
+        assert np.array_equal(g[k], c[k]), k
+    assert len(np.unique(c["geom"][c["t"] > 0])) >= 12                       # rays reach most (instance, geometry) records
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("builder", [0, 1, 3, 4])
+def test_two_level_radiance_bit_exact(gpu_tb, settings, builder):
+    gpu_tb.SetOption("flatten_instances", 0); gpu_tb.SetOption("bvh_builder", builder)
+    try:
+        gpu_tb.LoadScene(SCENE)
+    finally:
+        gpu_tb.SetOption("flatten_instances", 1); gpu_tb.SetOption("bvh_builder", 0)
+    s = copy.copy(settings); s.MaxBounces = 5
+    gpu_tb.Render(W, H, F, s, 0.0)
+    assert gpu_tb.GetOption("last_variant") == 4                              # the two-level walk lives in the full-feature kernels
+    out, jit = gpu_tb.ReadAccumulation(jittered=True)
+    ref = ol.render(gpu_tb.HostSceneView(), gpu_tb.FrameConstants(W, H, 0, s, 0.0), W, H, F, threads=8, jittered=True)
+    assert not np.isnan(out).any() and out[..., :3].max() > 0
+    assert np.array_equal(bits(out), bits(ref["output"])) and np.array_equal(bits(jit), bits(ref["jittered"]))
+    # frame-group launches (12 frames) and the counters of the counting kernel agree with the oracle as well
+    gpu_tb.InvalidateHistory(); gpu_tb.Render(W, H, 12, s, 0.0)
+    ref12 = ol.render(gpu_tb.HostSceneView(), gpu_tb.FrameConstants(W, H, 0, s, 0.0), W, H, 12, threads=8)
+    assert np.array_equal(bits(gpu_tb.ReadAccumulation()), bits(ref12["output"]))
+    gpu_tb.SetOption("count_rays", 1)
+    try:
+        gpu_tb.Render(W, H, 2, s, 0.0)
+        st = gpu_tb.ReadbackStats().rays
+        rs = ol.render(gpu_tb.HostSceneView(), gpu_tb.FrameConstants(W, H, 0, s, 0.0), W, H, 2, threads=8, stats=True)["stats"]
+        for k in ("boxesTested", "trianglesTested", "hitsShaded", "samples", "rays"):
+            assert getattr(st, k) == getattr(rs, k), k
+    finally:
+        gpu_tb.SetOption("count_rays", 0)

@@ -90,7 +90,14 @@ class TbSceneView(C.Structure):
         ("envMap", C.POINTER(TbFloat4)), ("envWidth", C.c_uint32), ("envHeight", C.c_uint32),
         ("blueNoise0", C.POINTER(TbFloat4)), ("blueNoise1", C.POINTER(TbFloat4)),
         ("config", TbConfigConstants),
+        ("tlas", C.c_void_p), ("tlasBytes", C.c_uint32), ("numInstances", C.c_uint32), ("numBlas", C.c_uint32),
+        ("blasOffsets", C.POINTER(C.c_uint32)),
     ]
+
+
+class TbBvhMetadata(C.Structure):
+    _fields_ = [("WorldToObject", C.c_float * 12), ("InstanceIDAndMask", C.c_uint32), ("InstanceContributionToHitGroupIndexAndFlags", C.c_uint32),
+                ("BlasIndex", C.c_uint32), ("BlasPad", C.c_uint32), ("ObjectToWorld", C.c_float * 12), ("InstanceIndex", C.c_uint32)]
 
 
 class TbRayStats(C.Structure):

@@ -50,24 +50,19 @@ template <class F> void parallelFor(size_t n, F f)
 
 inline uint32_t expand10(uint32_t v) { v &= 0x3ff; v = (v | (v << 16)) & 0x030000FF; v = (v | (v << 8)) & 0x0300F00F; v = (v | (v << 4)) & 0x030C30C3; v = (v | (v << 2)) & 0x09249249; return v; }
 
-void buildLbvh(const HostScene& s, Tree& t)
+/* 30-bit Morton code of a centroid inside the scene box (CalculateMortonCodesBindings.h:116-149): axis 0 <- y, axis 1 <- x, axis 2 <- z */
+inline uint32_t mortonCode(tb3 c, tb3 smin, tb3 dim)
+{
+    tb3 u = (c - smin) / dim;
+    float ax = tb_min(tb_max(u.x * 1024.0f, 0.0f), 1023.0f), ay = tb_min(tb_max(u.y * 1024.0f, 0.0f), 1023.0f), az = tb_min(tb_max(u.z * 1024.0f, 0.0f), 1023.0f);
+    return expand10((uint32_t)ay) | (expand10((uint32_t)ax) << 1) | (expand10((uint32_t)az) << 2);
+}
+
+/* sort by (code, element index) and build the Karras-2012 hierarchy over the sorted codes (BuildBVHSplits.hlsli:33-131) */
+void sortAndSplit(std::vector<uint64_t>& keys, Tree& t)
 {
     const uint32_t N = t.N;
-    tb3 smin = tb3_splat(3.402823466e+38f), smax = tb3_splat(-3.402823466e+38f);
-    for (uint32_t i = 0; i < N; i++) for (int k = 0; k < 3; k++) { tb3 v = P(s, i, k); smin = tb3_min(v, smin); smax = tb3_max(v, smax); }
-    tb3 dim = tb3_max(smax - smin, tb3_splat(0.00001f));
-    std::vector<uint64_t> keys(N);
-    parallelFor(N, [&](size_t a, size_t b) {
-        for (size_t i = a; i < b; i++) {
-            tb3 c = (P(s, (uint32_t)i, 0) + P(s, (uint32_t)i, 1) + P(s, (uint32_t)i, 2)) / 3.0f;
-            tb3 u = (c - smin) / dim;
-            float ax = tb_min(tb_max(u.x * 1024.0f, 0.0f), 1023.0f), ay = tb_min(tb_max(u.y * 1024.0f, 0.0f), 1023.0f), az = tb_min(tb_max(u.z * 1024.0f, 0.0f), 1023.0f);
-            /* axis 0 <- y, axis 1 <- x, axis 2 <- z: bit (3*b + axis) */
-            uint32_t code = expand10((uint32_t)ay) | (expand10((uint32_t)ax) << 1) | (expand10((uint32_t)az) << 2);
-            keys[i] = ((uint64_t)code << 32) | (uint64_t)i;
-        }
-    });
-    std::sort(keys.begin(), keys.end()); /* ties broken by triangle index: the build's definition */
+    std::sort(keys.begin(), keys.end()); /* ties broken by element index: the build's definition */
     t.order.resize(N);
     std::vector<uint32_t> codes(N);
     for (uint32_t i = 0; i < N; i++) { t.order[i] = (uint32_t)keys[i]; codes[i] = (uint32_t)(keys[i] >> 32); }
@@ -94,6 +89,22 @@ void buildLbvh(const HostScene& s, Tree& t)
             t.right[(size_t)i] = (split + 1 == last) ? (N - 1) + (uint32_t)split + 1 : (uint32_t)split + 1;
         }
     });
+}
+
+void buildLbvh(const HostScene& s, Tree& t)
+{
+    const uint32_t N = t.N;
+    tb3 smin = tb3_splat(3.402823466e+38f), smax = tb3_splat(-3.402823466e+38f);
+    for (uint32_t i = 0; i < N; i++) for (int k = 0; k < 3; k++) { tb3 v = P(s, i, k); smin = tb3_min(v, smin); smax = tb3_max(v, smax); }
+    tb3 dim = tb3_max(smax - smin, tb3_splat(0.00001f));
+    std::vector<uint64_t> keys(N);
+    parallelFor(N, [&](size_t a, size_t b) {
+        for (size_t i = a; i < b; i++) {
+            tb3 c = (P(s, (uint32_t)i, 0) + P(s, (uint32_t)i, 1) + P(s, (uint32_t)i, 2)) / 3.0f;
+            keys[i] = ((uint64_t)mortonCode(c, smin, dim) << 32) | (uint64_t)i;
+        }
+    });
+    sortAndSplit(keys, t);
 }
 
 /* ---- binned SAH ---------------------------------------------------------------------------- */
@@ -332,14 +343,12 @@ void treeletPasses(const HostScene& s, Tree& t, uint32_t passes)
     for (uint32_t i = 0; i < passes && minTris <= N; i++, minTris *= 2) tp.run(minTris, leafBox);
 }
 
-} // namespace
-
-void BuildBvh(HostScene& s, int builder)
+/* one bottom-level structure over ALL triangles of s */
+void BuildBvhSingle(HostScene& s, int builder)
 {
     const uint64_t N64 = s.triGeometry.size();
     if (N64 == 0) throw std::runtime_error("BuildBvh: no triangles");
     if (N64 > 0x00ffffffull) throw std::runtime_error("BuildBvh: more than 2^24-1 triangles does not fit the 24-bit node indices of the reference layout");
-    if (s.blueNoise0.empty()) LoadBlueNoiseTiles(s); /* system textures are bound with the scene (TracerBoy.cpp:2126-2134) */
     Tree t; t.N = (uint32_t)N64;
     const uint32_t N = t.N;
     if (builder == 1) {
@@ -427,6 +436,156 @@ void BuildBvh(HostScene& s, int builder)
         s.nodesB[i] = nb;
     }
     s.rootRefB = ref(0);
+}
+
+/* mul(AffineMatrix, float4(v, 1)) of TransformAABB (RayTracingHelper.hlsli:339); HLSL leaves the order of the dp4 open, the build
+ * pins it as an fma chain (include/tb_vec.h) */
+inline tb3 xfmPoint34(const float m[12], tb3 v)
+{
+    return tb3_make(tb_fma(m[2], v.z, tb_fma(m[1], v.y, tb_fma(m[0], v.x, m[3]))), tb_fma(m[6], v.z, tb_fma(m[5], v.y, tb_fma(m[4], v.x, m[7]))),
+                    tb_fma(m[10], v.z, tb_fma(m[9], v.y, tb_fma(m[8], v.x, m[11]))));
+}
+
+/* Top level over the instances (fallback layer: TopLevelLoadAABBs.hlsli:62-105 leaf boxes + metadata, CalculateSceneAABBFromBVHs.hlsl,
+ * CalculateMortonCodesForAABBs.hlsl, the same sort / BuildBVHSplits / ComputeAABBs passes as a bottom level; no treelet pass:
+ * GpuBVH2Builder.cpp:498-501).  blasRoot[b] = root box (min, max) of structure b read back from its image. */
+void BuildTlas(HostScene& s, const std::vector<Bounds>& blasRoot, std::vector<TbNodeB>& nodesOut /* M - 1 entries */, uint32_t& rootRef, uint32_t& depthOut,
+               float rootCenter[3], float rootHalf[3])
+{
+    const uint32_t M = (uint32_t)s.instances.size();
+    struct Box { tb3 c, h; };
+    std::vector<Box> leaf(M);
+    for (uint32_t i = 0; i < M; i++) { /* TransformAABB (:318-344): the eight corners, then AABBtoBoundingBox */
+        const Bounds& b = blasRoot[s.instances[i].blas];
+        Bounds w = emptyB();
+        for (int k = 0; k < 8; k++) {
+            const tb3 v = tb3_make((k & 4) ? b.mx.x : b.mn.x, (k & 2) ? b.mx.y : b.mn.y, (k & 1) ? b.mx.z : b.mn.z);
+            grow(w, xfmPoint34(s.instances[i].objectToWorld, v));
+        }
+        leaf[i].c = (w.mn + w.mx) * 0.5f; leaf[i].h = w.mx - leaf[i].c;
+    }
+    Tree t; t.N = M;
+    { /* scene box from the stored centre / half-extent boxes (RawDataToAABB: centre -+ half), Morton codes of the box centres */
+        tb3 smin = tb3_splat(3.402823466e+38f), smax = tb3_splat(-3.402823466e+38f);
+        for (uint32_t i = 0; i < M; i++) { smin = tb3_min(leaf[i].c - leaf[i].h, smin); smax = tb3_max(leaf[i].c + leaf[i].h, smax); }
+        const tb3 dim = tb3_max(smax - smin, tb3_splat(0.00001f));
+        std::vector<uint64_t> keys(M);
+        for (uint32_t i = 0; i < M; i++) keys[i] = ((uint64_t)mortonCode(leaf[i].c, smin, dim) << 32) | (uint64_t)i;
+        sortAndSplit(keys, t);
+    }
+    const uint64_t numNodes = 2ull * M - 1, offBoxes = 16, offMeta = offBoxes + 32 * numNodes, total = offMeta + 116ull * M;
+    s.tlasA.assign((size_t)total, 0);
+    const TbBvhHeader hdr = {(uint32_t)offBoxes, (uint32_t)offMeta, (uint32_t)offMeta, (uint32_t)total};
+    memcpy(s.tlasA.data(), &hdr, 16);
+    TbAabbNode* nodes = (TbAabbNode*)(s.tlasA.data() + offBoxes);
+    for (uint32_t k = 0; k < M; k++) { /* metadata of sorted leaf k */
+        const HostScene::Instance& in = s.instances[t.order[k]];
+        TbBvhMetadata md; memset(&md, 0, sizeof md);
+        memcpy(md.WorldToObject, in.worldToObject, 48); memcpy(md.ObjectToWorld, in.objectToWorld, 48);
+        md.InstanceIDAndMask = (0u & 0x00ffffffu) | (1u << 24);                   /* InstanceID 0, InstanceMask 1 (TracerBoy.cpp:2049) */
+        md.InstanceContributionToHitGroupIndexAndFlags = in.hitGroupBase & 0x00ffffffu; /* flags 0 */
+        md.BlasIndex = in.blas; md.InstanceIndex = t.order[k];
+        memcpy(s.tlasA.data() + offMeta + 116ull * k, &md, 116);
+    }
+    /* fit: same bottom-up pass as a bottom level (ComputeAABBs.hlsli), leaf = one "triangle" (flags.y = 1), no thin-box padding */
+    std::vector<uint32_t> walk; walk.reserve((size_t)numNodes);
+    std::vector<uint32_t> depth((size_t)numNodes, 0), count((size_t)numNodes, 0);
+    { std::vector<uint32_t> st; st.push_back(0); depth[0] = 1; uint32_t maxD = 1;
+      while (!st.empty()) { uint32_t x = st.back(); st.pop_back(); walk.push_back(x);
+          if (M > 1 && x < M - 1) { uint32_t l = t.left[x], r = t.right[x]; depth[l] = depth[r] = depth[x] + 1; if (depth[l] > maxD) maxD = depth[l]; st.push_back(l); st.push_back(r); } }
+      depthOut = maxD; }
+    auto center = [&](uint32_t i) { return tb3_make(nodes[i].center[0], nodes[i].center[1], nodes[i].center[2]); };
+    auto half = [&](uint32_t i) { return tb3_make(nodes[i].halfDim[0], nodes[i].halfDim[1], nodes[i].halfDim[2]); };
+    auto putCH = [&](uint32_t i, tb3 c, tb3 h, uint32_t fx, uint32_t fy) {
+        nodes[i].center[0] = c.x; nodes[i].center[1] = c.y; nodes[i].center[2] = c.z; nodes[i].flags = fx;
+        nodes[i].halfDim[0] = h.x; nodes[i].halfDim[1] = h.y; nodes[i].halfDim[2] = h.z; nodes[i].rightNodeIndex = fy;
+    };
+    for (size_t w = walk.size(); w-- > 0;) {
+        const uint32_t x = walk[w];
+        if (x >= M - 1) { const uint32_t k = x - (M - 1); putCH(x, leaf[t.order[k]].c, leaf[t.order[k]].h, k | TB_BVH_LEAF_FLAG, 1); count[x] = 1; }
+        else {
+            uint32_t l = t.left[x], r = t.right[x];
+            if (count[l] > count[r]) std::swap(l, r);
+            const tb3 mn = tb3_min(center(l) - half(l), center(r) - half(r)), mx = tb3_max(center(l) + half(l), center(r) + half(r));
+            const tb3 c = (mn + mx) * 0.5f;
+            putCH(x, c, mx - c, l & TB_BVH_INDEX_MASK, r);
+            count[x] = count[l] + count[r];
+        }
+    }
+    /* layout B: inner nodes 0..M-2 at the head of the shared node array, a leaf ref is LEAF | instance index */
+    auto ref = [&](uint32_t node) -> uint32_t { return node >= M - 1 ? (TB_BVH_LEAF_FLAG | t.order[node - (M - 1)]) : node; };
+    nodesOut.assign(M > 1 ? M - 1 : 0, TbNodeB{});
+    for (uint32_t i = 0; i + 1 < M; i++) {
+        const uint32_t child[2] = {nodes[i].flags & TB_BVH_INDEX_MASK, nodes[i].rightNodeIndex};
+        TbNodeB nb; memset(&nb, 0, sizeof nb);
+        for (int k = 0; k < 2; k++) {
+            nb.cx[k] = nodes[child[k]].center[0]; nb.cy[k] = nodes[child[k]].center[1]; nb.cz[k] = nodes[child[k]].center[2];
+            nb.hx[k] = nodes[child[k]].halfDim[0]; nb.hy[k] = nodes[child[k]].halfDim[1]; nb.hz[k] = nodes[child[k]].halfDim[2];
+        }
+        nb.left = ref(child[0]); nb.right = ref(child[1]);
+        nodesOut[i] = nb;
+    }
+    rootRef = ref(0);
+    memcpy(rootCenter, nodes[0].center, 12); memcpy(rootHalf, nodes[0].halfDim, 12);
+}
+
+} // namespace
+
+void BuildBvh(HostScene& s, int builder)
+{
+    if (s.blueNoise0.empty()) LoadBlueNoiseTiles(s); /* system textures are bound with the scene (TracerBoy.cpp:2126-2134) */
+    if (s.instances.empty()) {
+        BuildBvhSingle(s, builder);
+        s.blasOffsets.assign({0u, (uint32_t)s.bvhA.size()});
+        return;
+    }
+    /* two-level: every bottom-level structure is built by the single-level builder over its own triangle range (object space); the
+     * layout-A images go back to back into bvhA, the layout-B nodes and triangles into the shared arrays behind the top-level nodes,
+     * their child refs rebased */
+    const uint32_t M = (uint32_t)s.instances.size();
+    const uint32_t tlasNodes = M > 1 ? M - 1 : 0;
+    std::vector<uint8_t> allA; std::vector<TbNodeB> allNodes(tlasNodes); std::vector<TbTriB> allTris;
+    std::vector<Bounds> blasRoot(s.blas.size());
+    s.blasOffsets.clear();
+    uint32_t maxBlasDepth = 0;
+    for (size_t b = 0; b < s.blas.size(); b++) {
+        HostScene::Blas& bl = s.blas[b];
+        HostScene tmp;
+        tmp.positions.swap(s.positions);
+        tmp.triVertexIndex.assign(s.triVertexIndex.begin() + 3ull * bl.firstTri, s.triVertexIndex.begin() + 3ull * (bl.firstTri + bl.numTris));
+        tmp.triGeometry.assign(s.triGeometry.begin() + bl.firstTri, s.triGeometry.begin() + bl.firstTri + bl.numTris);
+        tmp.triPrimitive.assign(s.triPrimitive.begin() + bl.firstTri, s.triPrimitive.begin() + bl.firstTri + bl.numTris);
+        tmp.triFlags.assign(s.triFlags.begin() + bl.firstTri, s.triFlags.begin() + bl.firstTri + bl.numTris);
+        try { BuildBvhSingle(tmp, builder); } catch (...) { tmp.positions.swap(s.positions); throw; }
+        tmp.positions.swap(s.positions);
+        while (allA.size() % 16) allA.push_back(0);
+        bl.offsetA = (uint32_t)allA.size(); s.blasOffsets.push_back(bl.offsetA);
+        allA.insert(allA.end(), tmp.bvhA.begin(), tmp.bvhA.end());
+        const uint32_t nodeBase = (uint32_t)allNodes.size(), triBase = (uint32_t)allTris.size();
+        auto rebase = [&](uint32_t ref) { return (ref & TB_BVH_LEAF_FLAG) ? (TB_BVH_LEAF_FLAG | ((ref & ~TB_BVH_LEAF_FLAG) + triBase)) : ref + nodeBase; };
+        if (bl.numTris > 1) for (TbNodeB nd : tmp.nodesB) { nd.left = rebase(nd.left); nd.right = rebase(nd.right); allNodes.push_back(nd); }
+        allTris.insert(allTris.end(), tmp.trisB.begin(), tmp.trisB.end());
+        bl.rootRefB = rebase(tmp.rootRefB); bl.depth = tmp.bvhMaxDepth;
+        maxBlasDepth = std::max(maxBlasDepth, bl.depth);
+        const TbAabbNode* root = (const TbAabbNode*)(tmp.bvhA.data() + 16);
+        const tb3 c = tb3_make(root->center[0], root->center[1], root->center[2]), h = tb3_make(root->halfDim[0], root->halfDim[1], root->halfDim[2]);
+        blasRoot[b].mn = c - h; blasRoot[b].mx = c + h; /* BoundingBoxToAABB (RayTracingHelper.hlsli:237-243) */
+    }
+    if ((uint64_t)allA.size() > 0xffffffffull) throw std::runtime_error("BuildBvh: BVH images exceed 4 GiB");
+    s.blasOffsets.push_back((uint32_t)allA.size());
+    std::vector<TbNodeB> top; uint32_t tlasDepth = 0; float rc[3], rh[3];
+    BuildTlas(s, blasRoot, top, s.rootRefB, tlasDepth, rc, rh);
+    for (uint32_t i = 0; i < tlasNodes; i++) allNodes[i] = top[i];
+    if (allNodes.empty()) allNodes.push_back(TbNodeB{});
+    s.instancesB.resize(M);
+    for (uint32_t i = 0; i < M; i++) {
+        TbInstanceB ib; memset(&ib, 0, sizeof ib);
+        memcpy(ib.worldToObject, s.instances[i].worldToObject, 48);
+        ib.blasRootRef = s.blas[s.instances[i].blas].rootRefB; ib.hitGroupBase = s.instances[i].hitGroupBase; ib.instanceId = 0;
+        s.instancesB[i] = ib;
+    }
+    s.bvhA.swap(allA); s.nodesB.swap(allNodes); s.trisB.swap(allTris);
+    s.bvhMaxDepth = tlasDepth + maxBlasDepth; /* the walk's stack holds top-level entries below the bottom-level ones */
 }
 
 } // namespace tbhost

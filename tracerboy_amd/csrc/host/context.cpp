@@ -166,6 +166,7 @@ uint32_t sceneFeatureMask(const HostScene& s)
         if (m.Flags & TB_MAT_MIX) f |= PT_FEAT_MIX;
     }
     for (const TbLight& l : s.lights) if (l.LightType != TB_LIGHT_TYPE_AREA) f |= PT_FEAT_EXT;
+    if (!s.instances.empty()) f |= PT_FEAT_EXT; /* the two-level walk lives in the full-feature kernels only */
     return f;
 }
 
@@ -274,8 +275,11 @@ void finalizeScene(tb_context* c)
     HostScene& s = c->scene;
     auto opt = [&](const char* k, int64_t d) { auto it = c->options.find(k); return it == c->options.end() ? d : it->second; };
     const int64_t builder = opt("bvh_builder", 0);
-    if (builder == 2 || builder == 4) BuildBvhGpu(c, s, builder == 4 ? 3u : 0u); else BuildBvh(s, (int)builder);
-    reorderNodes(s, (int)opt("node_order", 2), (uint32_t)opt("node_order_top_levels", 10)); /* measured on the 870 k scene: 0 -> 2258, 1 -> 2283, 2 (10 levels) -> 2300 Msamples/s */
+    const bool twoLevel = !s.instances.empty();
+    if (twoLevel) BuildBvh(s, builder == 2 ? 0 : (builder == 4 ? 3 : (int)builder)); /* the GPU builders construct one structure; instanced scenes use their host twins (same trees) */
+    else if (builder == 2 || builder == 4) BuildBvhGpu(c, s, builder == 4 ? 3u : 0u);
+    else BuildBvh(s, (int)builder);
+    if (!twoLevel) reorderNodes(s, (int)opt("node_order", 2), (uint32_t)opt("node_order_top_levels", 10)); /* measured on the 870 k scene: 0 -> 2258, 1 -> 2283, 2 (10 levels) -> 2300 Msamples/s */
     c->camera = s.camera;
     releaseScene(c);
     TbDeviceScene& d = c->ds;
@@ -284,12 +288,23 @@ void finalizeScene(tb_context* c)
     auto deviceRef = [](uint32_t ref, uint32_t nodeUnits) { return (ref & TB_BVH_LEAF_FLAG) ? (TB_BVH_LEAF_FLAG | ((ref & ~TB_BVH_LEAF_FLAG) * 3u)) : ref * nodeUnits; };
     {
         std::vector<TbNodeB> dev(s.nodesB);
-        for (TbNodeB& nd : dev) { nd.left = deviceRef(nd.left, 4); nd.right = deviceRef(nd.right, 4); }
+        /* two-level scenes: the first M - 1 nodes are the top level, whose leaf refs address 64-B instance records (4 units) */
+        const size_t topNodes = s.instances.size() > 1 ? s.instances.size() - 1 : 0;
+        auto topRef = [](uint32_t ref) { return (ref & TB_BVH_LEAF_FLAG) ? (TB_BVH_LEAF_FLAG | ((ref & ~TB_BVH_LEAF_FLAG) * 4u)) : ref * 4u; };
+        for (size_t i = 0; i < dev.size(); i++) {
+            TbNodeB& nd = dev[i];
+            if (i < topNodes) { nd.left = topRef(nd.left); nd.right = topRef(nd.right); } else { nd.left = deviceRef(nd.left, 4); nd.right = deviceRef(nd.right, 4); }
+        }
         d.nodes = upload(c, dev);
     }
     d.tris = upload(c, s.trisB);
-    d.rootRef = deviceRef(s.rootRefB, 4); /* 0 or LEAF|0: the same in both images */ d.numNodes = (uint32_t)s.nodesB.size(); d.numTris = (uint32_t)s.trisB.size();
-    { const TbAabbNode* root = (const TbAabbNode*)(s.bvhA.data() + 16); memcpy(d.rootCenter, root->center, 12); memcpy(d.rootHalf, root->halfDim, 12); }
+    d.rootRef = twoLevel ? ((s.rootRefB & TB_BVH_LEAF_FLAG) ? (TB_BVH_LEAF_FLAG | ((s.rootRefB & ~TB_BVH_LEAF_FLAG) * 4u)) : s.rootRefB * 4u) : deviceRef(s.rootRefB, 4); /* 0 or LEAF|0: the same in both images */ d.numNodes = (uint32_t)s.nodesB.size(); d.numTris = (uint32_t)s.trisB.size();
+    { const TbAabbNode* root = (const TbAabbNode*)((twoLevel ? s.tlasA.data() : s.bvhA.data()) + 16); memcpy(d.rootCenter, root->center, 12); memcpy(d.rootHalf, root->halfDim, 12); }
+    {   /* instances in their device form: the bottom-level root as a device child ref */
+        std::vector<TbInstanceB> devInst(s.instancesB);
+        for (TbInstanceB& ib : devInst) ib.blasRootRef = deviceRef(ib.blasRootRef, 4);
+        d.instances = upload(c, devInst); d.numInstances = (uint32_t)devInst.size();
+    }
     /* shading records in their 16-B aligned device form (pt_scene.h) */
     std::vector<TbDevHitGroup> devHit(s.hitGroups.size());
     for (size_t i = 0; i < devHit.size(); i++) {
@@ -349,7 +364,7 @@ void finalizeScene(tb_context* c)
         d.offLights = put(devLight.data(), devLight.size() * sizeof(TbDevLight));
         while (blob.size() % 16) blob.push_back(0);
         size_t budget = (size_t)opt("lds_scene_budget", 40 * 1024);
-        c->sceneInLds = blob.size() + (size_t)d.stackDepth * 256 * 4 <= budget && opt("scene_in_lds", 1) != 0;
+        c->sceneInLds = blob.size() + (size_t)d.stackDepth * 256 * 4 <= budget && opt("scene_in_lds", 1) != 0 && !twoLevel;
         if (c->sceneInLds) { d.ldsBlob = upload(c, blob); d.ldsBlobBytes = (uint32_t)blob.size(); }
         else { d.ldsBlob = nullptr; d.ldsBlobBytes = 0; }
         /* measured on MI355X: LDS-resident scenes are nearly insensitive (at five waves per SIMD 1-2 is best: 6 745 / 6 730 against
@@ -1038,24 +1053,12 @@ int64_t tb_get_option(tb_context* c, const char* name)
     auto it = c->options.find(name); return it == c->options.end() ? 0 : it->second;
 }
 
+static void fillView(const HostScene& s, TbSceneView* v);
 int tb_host_scene_view(tb_context* c, TbSceneView* v)
 {
     if (!c || !v) return TB_E_INVALID;
     if (!c->hasScene) return fail(c, TB_E_NO_SCENE, "no scene loaded");
-    const HostScene& s = c->scene;
-    memset(v, 0, sizeof *v);
-    v->bvh = s.bvhA.data(); v->bvhBytes = (uint32_t)s.bvhA.size(); v->numTriangles = (uint32_t)s.triGeometry.size();
-    v->hitGroups = s.hitGroups.data(); v->numHitGroups = (uint32_t)s.hitGroups.size();
-    v->indexBuffer = s.indexBuffer.data(); v->numIndices = (uint32_t)s.indexBuffer.size();
-    v->vertexBuffer = s.vertexBuffer.data(); v->numVertexFloats = (uint32_t)s.vertexBuffer.size();
-    v->materials = s.materials.data(); v->numMaterials = (uint32_t)s.materials.size();
-    v->textureData = s.textureData.empty() ? nullptr : s.textureData.data(); v->numTextureData = (uint32_t)s.textureData.size();
-    v->lights = s.lights.empty() ? nullptr : s.lights.data(); v->numLights = (uint32_t)s.lights.size();
-    v->images = s.images.empty() ? nullptr : s.images.data(); v->numImages = (uint32_t)s.images.size();
-    v->texelPool = s.texelPool.empty() ? nullptr : s.texelPool.data();
-    v->envMap = s.envMap.empty() ? nullptr : s.envMap.data(); v->envWidth = s.envWidth; v->envHeight = s.envHeight;
-    v->blueNoise0 = s.blueNoise0.empty() ? nullptr : s.blueNoise0.data(); v->blueNoise1 = s.blueNoise1.empty() ? nullptr : s.blueNoise1.data();
-    v->config = s.config;
+    fillView(c->scene, v);
     return TB_OK;
 }
 
@@ -1164,6 +1167,8 @@ static void fillView(const HostScene& s, TbSceneView* v)
     v->envMap = s.envMap.empty() ? nullptr : s.envMap.data(); v->envWidth = s.envWidth; v->envHeight = s.envHeight;
     v->blueNoise0 = s.blueNoise0.empty() ? nullptr : s.blueNoise0.data(); v->blueNoise1 = s.blueNoise1.empty() ? nullptr : s.blueNoise1.data();
     v->config = s.config;
+    if (!s.instances.empty()) { v->tlas = s.tlasA.data(); v->tlasBytes = (uint32_t)s.tlasA.size(); v->numInstances = (uint32_t)s.instances.size(); }
+    v->numBlas = s.blasOffsets.empty() ? 0u : (uint32_t)s.blasOffsets.size() - 1u; v->blasOffsets = s.blasOffsets.empty() ? nullptr : s.blasOffsets.data();
 }
 
 int tb_host_scene_view_get(tb_host_scene* s, TbSceneView* v) { if (!s || !v) return TB_E_INVALID; fillView(s->scene, v); return TB_OK; }

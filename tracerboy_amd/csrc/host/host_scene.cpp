@@ -164,6 +164,134 @@ void Flatten(const PbrtObject& obj, const Affine& xfm, bool isWorldLevel, bool a
     for (const PbrtInstance& inst : obj.instances) if (inst.object) Flatten(*inst.object, xfm * inst.xfm, false, allShapes, out, depth + 1);
 }
 
+inline bool usable(const PbrtMesh& mesh) { return !(mesh.index.empty() || mesh.vertex.empty()); }
+
+/* area lights, one per triangle (TracerBoy.cpp:1526-1576); instanced emitters get their world positions */
+void AppendAreaLights(HostScene& out, const PbrtMesh& mesh, const Affine& xf)
+{
+    const Vec3 emissive = mesh.areaLightL;
+    const uint32_t numTris = (uint32_t)(mesh.index.size() / 3);
+    for (uint32_t i = 0; i < numTris; i++) {
+        TbLight light; memset(&light, 0, sizeof light);
+        light.LightType = TB_LIGHT_TYPE_AREA;
+        light.LightColor = F3(emissive);
+        Vec3 p0 = xf * mesh.vertex[mesh.index[3 * i]], p1 = xf * mesh.vertex[mesh.index[3 * i + 1]], p2 = xf * mesh.vertex[mesh.index[3 * i + 2]];
+        {
+            Vec3 v0 = p1 - p0, v1 = p2 - p0;
+            float v0Length = sqrtf(dot(v0, v0)), v1Length = sqrtf(dot(v1, v1));
+            float angle = acosf(dot(v0, v1) / (v0Length * v1Length));
+            light.SurfaceArea = (float)(v0Length * v1Length * sinf(angle) / 2.0);
+        }
+        light.P0 = F3(p0); light.P1 = F3(p1); light.P2 = F3(p2);
+        if (!mesh.normal.empty()) {
+            light.N0 = F3(xfmNormal(xf, mesh.normal[mesh.index[3 * i]]));
+            light.N1 = F3(xfmNormal(xf, mesh.normal[mesh.index[3 * i + 1]]));
+            light.N2 = F3(xfmNormal(xf, mesh.normal[mesh.index[3 * i + 2]]));
+        } else {
+            Vec3 n = normalize(cross(p1 - p0, p2 - p0));
+            light.N0 = light.N1 = light.N2 = F3(n);
+        }
+        out.lights.push_back(light);
+    }
+}
+
+/* material of a shape (TracerBoy.cpp:1578-1593) */
+uint32_t MaterialOf(const PbrtMesh& mesh, MaterialTracker& tracker, TextureAllocator& textures)
+{
+    if (mesh.material && tracker.Exists(mesh.material.get())) return tracker.index[mesh.material.get()];
+    auto a = mesh.textures.find("alpha");
+    const PbrtTextureSP* alpha = a != mesh.textures.end() ? &a->second : nullptr;
+    const Vec3 emissive = mesh.hasAreaLight ? mesh.areaLightL : Vec3(0.0f);
+    TbMaterial created = CreateMaterial(mesh.material, alpha, emissive, tracker, textures);
+    return tracker.Add(mesh.material.get(), created);
+}
+
+struct GeometrySlot { uint32_t vertexBufferOffset, indexBufferOffset, materialIndex; };
+
+/* vertex / position / index buffers and the builder's per-triangle arrays (TracerBoy.cpp:1595-1802).  xf is baked into the
+ * positions and attributes (identity for the geometry of an instanced structure: bBakeTransformIntoVertexBuffer, :1623-1624);
+ * geometryIndexForTris is what a triangle reports as GeometryContributionToHitGroupIndex. */
+GeometrySlot AppendGeometry(HostScene& out, const PbrtMesh& mesh, const Affine& xf, uint32_t geometryIndexForTris, uint32_t materialIndex)
+{
+    const uint32_t numTris = (uint32_t)(mesh.index.size() / 3);
+    const uint32_t firstVertex = (uint32_t)(out.positions.size() / 3);
+    const uint32_t vertexBufferOffset = (uint32_t)(out.vertexBuffer.size() * 4);
+    const bool bNormalsProvided = !mesh.normal.empty();
+    for (size_t v = 0; v < mesh.vertex.size(); v++) {
+        Vec3 P = xf * mesh.vertex[v];
+        Vec3 N(0, 1, 0), T(0, 0, 1);
+        if (bNormalsProvided && v < mesh.normal.size()) N = normalize(xfmNormal(xf, mesh.normal[v]));
+        if (v < mesh.tangents.size()) T = normalize(xfmNormal(xf, mesh.tangents[v]));
+        Vec2 uv; if (v < mesh.texcoord.size()) uv = mesh.texcoord[v];
+        const float vert[8] = {N.x, N.y, N.z, uv.x, uv.y, T.x, T.y, T.z};
+        out.vertexBuffer.insert(out.vertexBuffer.end(), vert, vert + 8);
+        out.positions.push_back(P.x); out.positions.push_back(P.y); out.positions.push_back(P.z);
+    }
+    while (out.indexBuffer.size() % 4) out.indexBuffer.push_back(0); /* D3D12_RAW_UAV_SRV_BYTE_ALIGNMENT (:1694) */
+    const uint32_t indexBufferOffset = (uint32_t)(out.indexBuffer.size() * 4);
+    const uint32_t geometryFlag = (out.materials[materialIndex].Flags & TB_MAT_NO_ALPHA) ? 1u : 0u; /* USE_ANYHIT 1, :1756-1760 */
+    for (uint32_t i = 0; i < numTris; i++) {
+        uint32_t ix = mesh.index[3 * i], iy = mesh.index[3 * i + 1], iz = mesh.index[3 * i + 2];
+        if (ix >= mesh.vertex.size() || iy >= mesh.vertex.size() || iz >= mesh.vertex.size()) throw std::runtime_error("triangle index out of range");
+        out.indexBuffer.push_back(ix); out.indexBuffer.push_back(iy); out.indexBuffer.push_back(iz);
+        if (!bNormalsProvided) { /* flat normals :1710-1729 */
+            Vec3 edge1 = mesh.vertex[iz] - mesh.vertex[ix], edge2 = mesh.vertex[iz] - mesh.vertex[iy];
+            Vec3 normal = cross(edge1, edge2);
+            if (dot(normal, normal) <= 0.0000000001f) normal = Vec3(0, 1, 0);
+            else normal = normalize(xfmNormal(xf, normal));
+            for (uint32_t vi : {ix, iy, iz}) { float* p = &out.vertexBuffer[(size_t)vertexBufferOffset / 4 + 8 * (size_t)vi]; p[0] = normal.x; p[1] = normal.y; p[2] = normal.z; }
+        }
+        out.triVertexIndex.push_back(firstVertex + ix); out.triVertexIndex.push_back(firstVertex + iy); out.triVertexIndex.push_back(firstVertex + iz);
+        out.triGeometry.push_back(geometryIndexForTris); out.triPrimitive.push_back(i); out.triFlags.push_back(geometryFlag);
+    }
+    return GeometrySlot{vertexBufferOffset, indexBufferOffset, materialIndex};
+}
+
+void AppendHitGroup(HostScene& out, const GeometrySlot& g)
+{
+    TbHitGroupRecord rec; memset(&rec, 0, sizeof rec); /* :1804-1817 */
+    rec.GeometryIndex = (uint32_t)out.hitGroups.size();
+    rec.MaterialIndex = g.materialIndex;
+    rec.VertexBufferIndex = 0; rec.VertexBufferOffset = g.vertexBufferOffset;
+    rec.IndexBufferIndex = 0; rec.IndexBufferOffset = g.indexBufferOffset;
+    out.hitGroups.push_back(rec);
+}
+
+/* rows of a 3x4 matrix as D3D12_RAYTRACING_INSTANCE_DESC::Transform stores them (ConvertAffine3f, TracerBoy.cpp:2048) */
+void Rows(const Affine& a, float r[12])
+{
+    const float m[12] = {a.l.vx.x, a.l.vy.x, a.l.vz.x, a.p.x, a.l.vx.y, a.l.vy.y, a.l.vz.y, a.p.y, a.l.vx.z, a.l.vy.z, a.l.vz.z, a.p.z};
+    memcpy(r, m, sizeof m);
+}
+
+float Determinant(const float t[12]) /* RayTracingHelper.hlsli:287-295 */
+{
+#define M(r, c) t[(r) * 4 + (c)]
+    return M(0, 0) * M(1, 1) * M(2, 2) - M(0, 0) * M(2, 1) * M(1, 2) - M(1, 0) * M(0, 1) * M(2, 2) + M(1, 0) * M(2, 1) * M(0, 2) + M(2, 0) * M(0, 1) * M(1, 2) - M(2, 0) * M(1, 1) * M(0, 2);
+}
+
+/* InverseAffineTransform, RayTracingHelper.hlsli:297-316 -- the fallback layer inverts ObjectToWorld on the GPU in fp32
+ * (TopLevelLoadAABBs.hlsli:83-87); the same expressions term by term (products with the literal 0 / 1 of the implied fourth row kept) */
+void InverseAffineTransform(const float t[12], float o[12])
+{
+    const float invDet = 1.0f / Determinant(t);
+#define O(r, c) o[(r) * 4 + (c)]
+    O(0, 0) = invDet * (M(1, 1) * (M(2, 2) * 1.0f - 0.0f * M(2, 3)) + M(2, 1) * (0.0f * M(1, 3) - M(1, 2) * 1.0f) + 0.0f * (M(1, 2) * M(2, 3) - M(2, 2) * M(1, 3)));
+    O(1, 0) = invDet * (M(1, 2) * (M(2, 0) * 1.0f - 0.0f * M(2, 3)) + M(2, 2) * (0.0f * M(1, 3) - M(1, 0) * 1.0f) + 0.0f * (M(1, 0) * M(2, 3) - M(2, 0) * M(1, 3)));
+    O(2, 0) = invDet * (M(1, 3) * (M(2, 0) * 0.0f - 0.0f * M(2, 1)) + M(2, 3) * (0.0f * M(1, 1) - M(1, 0) * 0.0f) + 1.0f * (M(1, 0) * M(2, 1) - M(2, 0) * M(1, 1)));
+    O(0, 1) = invDet * (M(2, 1) * (M(0, 2) * 1.0f - 0.0f * M(0, 3)) + 0.0f * (M(2, 2) * M(0, 3) - M(0, 2) * M(2, 3)) + M(0, 1) * (0.0f * M(2, 3) - M(2, 2) * 1.0f));
+    O(1, 1) = invDet * (M(2, 2) * (M(0, 0) * 1.0f - 0.0f * M(0, 3)) + 0.0f * (M(2, 0) * M(0, 3) - M(0, 0) * M(2, 3)) + M(0, 2) * (0.0f * M(2, 3) - M(2, 0) * 1.0f));
+    O(2, 1) = invDet * (M(2, 3) * (M(0, 0) * 0.0f - 0.0f * M(0, 1)) + 1.0f * (M(2, 0) * M(0, 1) - M(0, 0) * M(2, 1)) + M(0, 3) * (0.0f * M(2, 1) - M(2, 0) * 0.0f));
+    O(0, 2) = invDet * (0.0f * (M(0, 2) * M(1, 3) - M(1, 2) * M(0, 3)) + M(0, 1) * (M(1, 2) * 1.0f - 0.0f * M(1, 3)) + M(1, 1) * (0.0f * M(0, 3) - M(0, 2) * 1.0f));
+    O(1, 2) = invDet * (0.0f * (M(0, 0) * M(1, 3) - M(1, 0) * M(0, 3)) + M(0, 2) * (M(1, 0) * 1.0f - 0.0f * M(1, 3)) + M(1, 2) * (0.0f * M(0, 3) - M(0, 0) * 1.0f));
+    O(2, 2) = invDet * (1.0f * (M(0, 0) * M(1, 1) - M(1, 0) * M(0, 1)) + M(0, 3) * (M(1, 0) * 0.0f - 0.0f * M(1, 1)) + M(1, 3) * (0.0f * M(0, 1) - M(0, 0) * 0.0f));
+    O(0, 3) = invDet * (M(0, 1) * (M(2, 2) * M(1, 3) - M(1, 2) * M(2, 3)) + M(1, 1) * (M(0, 2) * M(2, 3) - M(2, 2) * M(0, 3)) + M(2, 1) * (M(1, 2) * M(0, 3) - M(0, 2) * M(1, 3)));
+    O(1, 3) = invDet * (M(0, 2) * (M(2, 0) * M(1, 3) - M(1, 0) * M(2, 3)) + M(1, 2) * (M(0, 0) * M(2, 3) - M(2, 0) * M(0, 3)) + M(2, 2) * (M(1, 0) * M(0, 3) - M(0, 0) * M(1, 3)));
+    O(2, 3) = invDet * (M(0, 3) * (M(2, 0) * M(1, 1) - M(1, 0) * M(2, 1)) + M(1, 3) * (M(0, 0) * M(2, 1) - M(2, 0) * M(0, 1)) + M(2, 3) * (M(1, 0) * M(0, 1) - M(0, 0) * M(1, 1)));
+#undef O
+#undef M
+}
+
 } // namespace
 
 void ConvertScene(const PbrtScene& in, HostScene& out, const ConvertOptions& opt)
@@ -190,97 +318,85 @@ void ConvertScene(const PbrtScene& in, HostScene& out, const ConvertOptions& opt
 
     TextureAllocator textures(out);
     MaterialTracker tracker(out.materials);
-
-    /* world shapes first, then instances (TracerBoy.cpp:1356-1376) */
-    std::vector<FlatShape> shapes;
-    for (const PbrtMeshSP& m : in.world.shapes) { FlatShape f; f.mesh = m; f.baked = true; shapes.push_back(f); }
-    if (opt.flattenInstances) Flatten(in.world, Affine(), true, true, shapes, 0);
-
     Vec3 smin(3.402823466e+38f), smax(-3.402823466e+38f);
-    uint32_t geometryCount = 0;
-    for (const FlatShape& fs : shapes) {
-        const PbrtMesh& mesh = *fs.mesh;
-        if (mesh.index.empty() || mesh.vertex.empty()) continue;
-        const Affine xf = fs.baked ? Affine() : fs.xfm;
-        const uint32_t numTris = (uint32_t)(mesh.index.size() / 3);
-
-        /* area lights, one per triangle (:1526-1576); instanced emitters get their world positions */
-        Vec3 emissive(0.0f);
-        if (mesh.hasAreaLight) {
-            emissive = mesh.areaLightL;
-            for (uint32_t i = 0; i < numTris; i++) {
-                TbLight light; memset(&light, 0, sizeof light);
-                light.LightType = TB_LIGHT_TYPE_AREA;
-                light.LightColor = F3(emissive);
-                Vec3 p0 = xf * mesh.vertex[mesh.index[3 * i]], p1 = xf * mesh.vertex[mesh.index[3 * i + 1]], p2 = xf * mesh.vertex[mesh.index[3 * i + 2]];
-                {
-                    Vec3 v0 = p1 - p0, v1 = p2 - p0;
-                    float v0Length = sqrtf(dot(v0, v0)), v1Length = sqrtf(dot(v1, v1));
-                    float angle = acosf(dot(v0, v1) / (v0Length * v1Length));
-                    light.SurfaceArea = (float)(v0Length * v1Length * sinf(angle) / 2.0);
-                }
-                light.P0 = F3(p0); light.P1 = F3(p1); light.P2 = F3(p2);
-                if (!mesh.normal.empty()) {
-                    light.N0 = F3(xfmNormal(xf, mesh.normal[mesh.index[3 * i]]));
-                    light.N1 = F3(xfmNormal(xf, mesh.normal[mesh.index[3 * i + 1]]));
-                    light.N2 = F3(xfmNormal(xf, mesh.normal[mesh.index[3 * i + 2]]));
-                } else {
-                    Vec3 n = normalize(cross(p1 - p0, p2 - p0));
-                    light.N0 = light.N1 = light.N2 = F3(n);
-                }
-                out.lights.push_back(light);
-            }
-        }
-
-        /* material (:1578-1593) */
-        uint32_t materialIndex;
-        if (mesh.material && tracker.Exists(mesh.material.get())) materialIndex = tracker.index[mesh.material.get()];
-        else {
-            auto a = mesh.textures.find("alpha");
-            const PbrtTextureSP* alpha = a != mesh.textures.end() ? &a->second : nullptr;
-            TbMaterial created = CreateMaterial(mesh.material, alpha, emissive, tracker, textures);
-            materialIndex = tracker.Add(mesh.material.get(), created);
-        }
-
-        /* vertex / position / index buffers (:1595-1802) */
-        const uint32_t firstVertex = (uint32_t)(out.positions.size() / 3);
-        const uint32_t vertexBufferOffset = (uint32_t)(out.vertexBuffer.size() * 4);
-        const bool bNormalsProvided = !mesh.normal.empty();
-        for (size_t v = 0; v < mesh.vertex.size(); v++) {
-            Vec3 P = xf * mesh.vertex[v];
-            Vec3 N(0, 1, 0), T(0, 0, 1);
-            if (bNormalsProvided && v < mesh.normal.size()) N = normalize(xfmNormal(xf, mesh.normal[v]));
-            if (v < mesh.tangents.size()) T = normalize(xfmNormal(xf, mesh.tangents[v]));
-            Vec2 uv; if (v < mesh.texcoord.size()) uv = mesh.texcoord[v];
-            const float vert[8] = {N.x, N.y, N.z, uv.x, uv.y, T.x, T.y, T.z};
-            out.vertexBuffer.insert(out.vertexBuffer.end(), vert, vert + 8);
-            out.positions.push_back(P.x); out.positions.push_back(P.y); out.positions.push_back(P.z);
+    auto growWorld = [&](const PbrtMesh& mesh, const Affine& xf) {
+        for (const Vec3& v : mesh.vertex) {
+            const Vec3 P = xf * v;
             smin = Vec3(fminf(smin.x, P.x), fminf(smin.y, P.y), fminf(smin.z, P.z));
             smax = Vec3(fmaxf(smax.x, P.x), fmaxf(smax.y, P.y), fmaxf(smax.z, P.z));
         }
-        while (out.indexBuffer.size() % 4) out.indexBuffer.push_back(0); /* D3D12_RAW_UAV_SRV_BYTE_ALIGNMENT (:1694) */
-        const uint32_t indexBufferOffset = (uint32_t)(out.indexBuffer.size() * 4);
-        const uint32_t geometryFlag = (out.materials[materialIndex].Flags & TB_MAT_NO_ALPHA) ? 1u : 0u; /* USE_ANYHIT 1, :1756-1760 */
-        for (uint32_t i = 0; i < numTris; i++) {
-            uint32_t ix = mesh.index[3 * i], iy = mesh.index[3 * i + 1], iz = mesh.index[3 * i + 2];
-            if (ix >= mesh.vertex.size() || iy >= mesh.vertex.size() || iz >= mesh.vertex.size()) throw std::runtime_error("triangle index out of range");
-            out.indexBuffer.push_back(ix); out.indexBuffer.push_back(iy); out.indexBuffer.push_back(iz);
-            if (!bNormalsProvided) { /* flat normals :1710-1729 */
-                Vec3 edge1 = mesh.vertex[iz] - mesh.vertex[ix], edge2 = mesh.vertex[iz] - mesh.vertex[iy];
-                Vec3 normal = cross(edge1, edge2);
-                if (dot(normal, normal) <= 0.0000000001f) normal = Vec3(0, 1, 0);
-                else normal = normalize(xfmNormal(xf, normal));
-                for (uint32_t vi : {ix, iy, iz}) { float* p = &out.vertexBuffer[(size_t)vertexBufferOffset / 4 + 8 * (size_t)vi]; p[0] = normal.x; p[1] = normal.y; p[2] = normal.z; }
-            }
-            out.triVertexIndex.push_back(firstVertex + ix); out.triVertexIndex.push_back(firstVertex + iy); out.triVertexIndex.push_back(firstVertex + iz);
-            out.triGeometry.push_back(geometryCount); out.triPrimitive.push_back(i); out.triFlags.push_back(geometryFlag);
+    };
+
+    const bool twoLevel = !opt.flattenInstances && !in.world.instances.empty();
+    if (!twoLevel) {
+        /* world shapes first, then instances (TracerBoy.cpp:1356-1376) */
+        std::vector<FlatShape> shapes;
+        for (const PbrtMeshSP& m : in.world.shapes) { FlatShape f; f.mesh = m; f.baked = true; shapes.push_back(f); }
+        if (opt.flattenInstances) Flatten(in.world, Affine(), true, true, shapes, 0);
+        for (const FlatShape& fs : shapes) {
+            const PbrtMesh& mesh = *fs.mesh;
+            if (!usable(mesh)) continue;
+            const Affine xf = fs.baked ? Affine() : fs.xfm;
+            if (mesh.hasAreaLight) AppendAreaLights(out, mesh, xf);
+            const uint32_t materialIndex = MaterialOf(mesh, tracker, textures);
+            const GeometrySlot g = AppendGeometry(out, mesh, xf, (uint32_t)out.hitGroups.size(), materialIndex);
+            growWorld(mesh, xf);
+            AppendHitGroup(out, g);
         }
-        TbHitGroupRecord rec; memset(&rec, 0, sizeof rec); /* :1804-1817 */
-        rec.GeometryIndex = geometryCount++;
-        rec.MaterialIndex = materialIndex;
-        rec.VertexBufferIndex = 0; rec.VertexBufferOffset = vertexBufferOffset;
-        rec.IndexBufferIndex = 0; rec.IndexBufferOffset = indexBufferOffset;
-        out.hitGroups.push_back(rec);
+    } else {
+        /* Two-level: the structure the reference hands its hardware path.  Structure 0 = every world-level shape under an identity
+         * instance ("global BLAS", TracerBoy.cpp:1363-1368); every ObjectInstance -- nested ones with their transforms composed --
+         * becomes an instance of its object's structure (all of the object's shapes: the reference takes shapes[0], :1374).
+         * Geometry is stored once per structure, in object space; hit-group records exist once per (instance, geometry) and an
+         * instance's first record is its InstanceContributionToHitGroupIndex.  Vertex attributes are NOT transformed for
+         * instanced geometry (bBakeTransformIntoVertexBuffer is false, :1623-1624): shading normals of instances are the
+         * object's, exactly as in the reference. */
+        struct BlasDef { const PbrtObject* key; std::vector<PbrtMeshSP> meshes; std::vector<GeometrySlot> slots; };
+        struct InstDef { uint32_t blas; Affine xfm; };
+        std::vector<BlasDef> defs; std::vector<InstDef> insts;
+        { BlasDef world; world.key = nullptr; for (const PbrtMeshSP& m : in.world.shapes) if (m && usable(*m)) world.meshes.push_back(m);
+          if (!world.meshes.empty()) { defs.push_back(world); insts.push_back(InstDef{0, Affine()}); } }
+        std::unordered_map<const PbrtObject*, uint32_t> blasOf;
+        struct Walker {
+            std::vector<BlasDef>& defs; std::vector<InstDef>& insts; std::unordered_map<const PbrtObject*, uint32_t>& blasOf;
+            void visit(const PbrtObject& obj, const Affine& xfm, int depth)
+            {
+                if (depth > 16) throw std::runtime_error("instance nesting too deep");
+                for (const PbrtInstance& inst : obj.instances) {
+                    if (!inst.object) continue;
+                    const Affine X = xfm * inst.xfm;
+                    const PbrtObject* o = inst.object.get();
+                    auto it = blasOf.find(o);
+                    if (it == blasOf.end()) {
+                        BlasDef d; d.key = o; for (const PbrtMeshSP& m : o->shapes) if (m && usable(*m)) d.meshes.push_back(m);
+                        uint32_t idx = 0xffffffffu;
+                        if (!d.meshes.empty()) { idx = (uint32_t)defs.size(); defs.push_back(d); }
+                        it = blasOf.emplace(o, idx).first;
+                    }
+                    if (it->second != 0xffffffffu) insts.push_back(InstDef{it->second, X});
+                    visit(*o, X, depth + 1);
+                }
+            }
+        } walker{defs, insts, blasOf};
+        walker.visit(in.world, Affine(), 0);
+        if (insts.size() > 0x00ffffffu) throw std::runtime_error("more than 2^24-1 instances");
+        for (BlasDef& d : defs) {
+            HostScene::Blas b; b.firstTri = (uint32_t)out.triGeometry.size();
+            for (const PbrtMeshSP& m : d.meshes) d.slots.push_back(AppendGeometry(out, *m, Affine(), (uint32_t)d.slots.size(), MaterialOf(*m, tracker, textures)));
+            b.numTris = (uint32_t)out.triGeometry.size() - b.firstTri;
+            out.blas.push_back(b);
+        }
+        for (const InstDef& i : insts) {
+            HostScene::Instance hi; hi.blas = i.blas; hi.hitGroupBase = (uint32_t)out.hitGroups.size();
+            Rows(i.xfm, hi.objectToWorld); InverseAffineTransform(hi.objectToWorld, hi.worldToObject);
+            const BlasDef& d = defs[i.blas];
+            for (size_t g = 0; g < d.slots.size(); g++) {
+                AppendHitGroup(out, d.slots[g]);
+                if (d.meshes[g]->hasAreaLight) AppendAreaLights(out, *d.meshes[g], i.xfm);
+                growWorld(*d.meshes[g], i.xfm);
+            }
+            out.instances.push_back(hi);
+        }
     }
     if (out.triGeometry.empty()) throw std::runtime_error("scene has no triangles");
     out.sceneMin[0] = smin.x; out.sceneMin[1] = smin.y; out.sceneMin[2] = smin.z;

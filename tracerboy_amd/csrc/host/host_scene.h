@@ -28,6 +28,15 @@ struct HostScene {
     TbConfigConstants config{};
     int filmWidth = 0, filmHeight = 0;
     float sceneMin[3] = {0, 0, 0}, sceneMax[3] = {0, 0, 0};
+    /* two-level scenes (ConvertOptions::flattenInstances = false): bottom-level structures = triangle ranges of the arrays above
+     * (object space, triGeometry = geometry index INSIDE the structure), instances = (structure, transform, first hit-group record) */
+    struct Blas { uint32_t firstTri = 0, numTris = 0, offsetA = 0, rootRefB = 0, depth = 0; };
+    struct Instance { uint32_t blas = 0; float objectToWorld[12]; float worldToObject[12]; uint32_t hitGroupBase = 0; };
+    std::vector<Blas> blas;
+    std::vector<Instance> instances;
+    std::vector<uint8_t> tlasA;            /* layout A of the top level (tb_abi.h TbBvhMetadata) */
+    std::vector<uint32_t> blasOffsets;     /* layout-A image b starts at bvhA[blasOffsets[b]]; numBlas + 1 entries */
+    std::vector<TbInstanceB> instancesB;   /* layout B; top-level nodes lead nodesB, a top-level leaf ref is LEAF | instance index */
     /* acceleration structure */
     std::vector<uint8_t> bvhA;
     std::vector<TbNodeB> nodesB;
@@ -38,7 +47,10 @@ struct HostScene {
 
 struct ConvertOptions {
     bool flattenInstances = true; /* reference SW path traces BLAS[0] only and uses shapes[0] of an instance
-                                     (TracerBoy.cpp:1370-1375, 2861-2866); the build flattens all of them */
+                                     (TracerBoy.cpp:1370-1375, 2861-2866); the build flattens all of them.  false: the reference's
+                                     hardware-path structure -- world-level shapes form one bottom-level structure under an identity
+                                     instance, every ObjectInstance becomes an instance of its object's structure (TracerBoy.cpp:1356-1376,
+                                     2032-2052), traced by the two-level walk of TraverseFunction.hlsli:603-640 */
     bool flipTextureUVs = true;   /* ConfigConstants.FlipTextureUVs = m_flipTextureUVs: TRUE for .pbrt and .pbf loads ("PBRT uses GL style
                                      texture sampling", TracerBoy.cpp:1207-1208,1221-1222), false only on the Assimp path; option
                                      "flip_texture_uvs" = 0 gives the Assimp convention */

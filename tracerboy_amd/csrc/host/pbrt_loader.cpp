@@ -346,12 +346,13 @@ private:
             }
             else if (d == "Shape") { Token ty = next(); ParamSet ps = parseParams(); emitShape(ty.text, ps); }
             else if (d == "ObjectBegin") {
+                /* the reference parser neither saves nor restores the graphics state or the CTM around an object definition
+                 * (Parser.inl:621-635, unlike pbrt-v3's pbrtObjectBegin): a material or transform set inside leaks out */
                 Token n = next(); auto o = std::make_shared<PbrtObject>(); o->name = n.text; objects[n.text] = o; objectStack.push_back(o);
-                attributeStack.push_back(gs); transformStack.push_back(ctm);
             }
             else if (d == "ObjectEnd") {
                 if (objectStack.empty()) throw std::runtime_error("unmatched ObjectEnd");
-                objectStack.pop_back(); gs = attributeStack.back(); attributeStack.pop_back(); ctm = transformStack.back(); transformStack.pop_back();
+                objectStack.pop_back();
             }
             else if (d == "ObjectInstance") {
                 Token n = next(); auto it = objects.find(n.text);

@@ -290,6 +290,73 @@ TBD bool traverse(const SceneRefs& sc, const TbDeviceScene& ds, tb3 o, tb3 d, Hi
     return best.t < MAX_T;
 }
 
+/* Two-level walk for instanced scenes (option flatten_instances = 0): TraverseFunction.hlsli:537-779 with FAST_PATH 0 -- the
+ * !FAST_PATH branch :603-640.  The top level is walked with the world ray; at a top-level leaf the ray is taken into the instance's
+ * object space (mul(WorldToObject, float4(o, 1)) / float4(d, 0): the direction is NOT renormalised, so t is the same number in
+ * both spaces and `closest` carries over), GetRayData is evaluated again, and the bottom-level structure is walked from its root
+ * -- whose own box is never tested (:625: StackPush(0)) -- until the stack is back at the height it had on entry; then the world
+ * ray data are recomputed (:769-773) and the top level goes on.  Visit order at both levels as in traverse().  A plain
+ * one-lane-one-ray loop: this is the functional path for instanced scenes, the single-level walk above is the tuned one.
+ * The IsValidHit filter (option alpha_test) is not applied here. */
+struct __attribute__((aligned(16))) InstB16 { TbInstanceB i; };
+TBD tb3 xfm_point34(const float* m, tb3 v) /* pinned order of the dp4: one fma chain per row, as host_scene / bvh_build / the oracle */
+{
+    return tb3_make(tb_fma(m[2], v.z, tb_fma(m[1], v.y, tb_fma(m[0], v.x, m[3]))), tb_fma(m[6], v.z, tb_fma(m[5], v.y, tb_fma(m[4], v.x, m[7]))),
+                    tb_fma(m[10], v.z, tb_fma(m[9], v.y, tb_fma(m[8], v.x, m[11]))));
+}
+TBD tb3 xfm_vector34(const float* m, tb3 v)
+{
+    return tb3_make(tb_fma(m[2], v.z, tb_fma(m[1], v.y, m[0] * v.x)), tb_fma(m[6], v.z, tb_fma(m[5], v.y, m[4] * v.x)), tb_fma(m[10], v.z, tb_fma(m[9], v.y, m[8] * v.x)));
+}
+
+template <bool COUNT>
+TBD bool traverse_instanced(const SceneRefs& sc, const TbDeviceScene& ds, tb3 o, tb3 d, Hit& best, uint32_t* stack, uint32_t stride, uint32_t& boxes, uint32_t& tris)
+{
+    best.t = MAX_T; best.u = best.v = 0.0f; best.prim = best.geom = 0u;
+    RayPre r = ray_prepare(o, d);
+    float unusedT;
+    if (!box_test(unusedT, best.t, r, ld3(ds.rootCenter), ld3(ds.rootHalf))) return false; /* :566-580, the top level's root box */
+    constexpr uint32_t DONE = 0xffffffffu;
+    uint32_t top = 0, floor = 0, hitBase = 0;
+    bool inBottom = false;
+    tb3 ro = o;
+    uint32_t ref = ds.rootRef;
+    auto pop = [&]() -> uint32_t {
+        if (inBottom && top == floor) { inBottom = false; r = ray_prepare(o, d); ro = o; } /* bottom level exhausted: back to the world ray (:769-773) */
+        if (!top) return DONE;
+        --top;
+        return stack[top * stride];
+    };
+    while (ref != DONE) {
+        if (!(ref & TB_BVH_LEAF_FLAG)) {
+            const TbNodeB n = load_node(sc, ref);
+            float lt, rt; bool lh, rh;
+            box_test2(lh, rh, lt, rt, best.t, r, n);
+            if (COUNT) boxes += 2;
+            if (lh && rh) {
+                const bool rightFirst = rt < lt;
+                stack[top * stride] = rightFirst ? n.left : n.right; top++;
+                ref = rightFirst ? n.right : n.left;
+            } else if (lh || rh) ref = rh ? n.right : n.left;
+            else ref = pop();
+        } else if (!inBottom) { /* top-level leaf = instance (:603-640; InstanceMask 1 & inclusion mask 0xff: always valid) */
+            const TbInstanceB in = ((const InstB16*)((const uint8_t*)ds.instances + ((size_t)(ref & TB_DEVICE_REF_MASK) << 4)))->i;
+            ro = xfm_point34(in.worldToObject, o);
+            r = ray_prepare(ro, xfm_vector34(in.worldToObject, d));
+            inBottom = true; floor = top; hitBase = in.hitGroupBase;
+            ref = in.blasRootRef;
+        } else {
+            const TbTriB tri = load_tri(sc, ref);
+            if (COUNT) tris++;
+            const float before = best.t;
+            tri_test<false>(best, MIN_T, ro, r, tri, false, sc, ds);
+            if (best.t != before) best.geom += hitBase; /* InstanceContributionToHitGroupIndex + GeometryContributionToHitGroupIndex */
+            ref = pop();
+        }
+    }
+    return best.t < MAX_T;
+}
+
 /* Resumable form of the same walk for the streaming kernel: the traversal state lives in registers
  * across calls, so a lane whose ray has finished can wait for shading while the others keep walking. */
 struct Trav { RayPre r; Hit best; uint32_t ref, top; uint32_t boxes, tris; };

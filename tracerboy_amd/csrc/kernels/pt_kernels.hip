@@ -34,7 +34,7 @@ __global__ __launch_bounds__(BLOCK) void trace_closest_kernel(TbDeviceScene ds, 
     if (i >= n) return;
     tb3 o = ld3(origins + 3 * i), d = ld3(dirs + 3 * i);
     Hit h; uint32_t nb = 0, nt = 0;
-    bool hit = traverse<true>(sc, ds, o, d, h, stack, BLOCK, nb, nt);
+    bool hit = ds.numInstances ? traverse_instanced<true>(sc, ds, o, d, h, stack, BLOCK, nb, nt) : traverse<true>(sc, ds, o, d, h, stack, BLOCK, nb, nt);
     outT[i] = hit ? h.t : -1.0f;
     if (outBary) { outBary[2 * i] = hit ? h.u : 0.0f; outBary[2 * i + 1] = hit ? h.v : 0.0f; }
     if (outPrim) outPrim[i] = hit ? h.prim : 0xffffffffu;
