@@ -302,7 +302,7 @@ def main():
         "config": {"workload": "%s %dx%d %dspp depth%d" % (args.scene, W, H, SPP, args.depth), "triangles": int(info.numTriangles),
                    "bvh_builder": ("lbvh", "sah", "lbvh-gpu", "lbvh+treelets", "lbvh+treelets-gpu")[args.builder], "pipeline": ("lockstep", "stream", "wavefront", "pooled")[args.pipeline], "tile": TILE if world > 1 else None,
                    "parallelism": "tiles%d" % world, "scene_in_lds": bool(tb.GetOption("scene_in_lds_active")),
-                   "kernel_variant": ["matte", "env", "surf", "vol", "full"][tb.GetOption("last_variant")], "scene_load_s": round(load_s, 3)},
+                   "kernel_variant": ["matte", "env", "surf", "vol", "full", "sss"][tb.GetOption("last_variant")], "scene_load_s": round(load_s, 3)},
     }
 
     if world > 1:
@@ -368,7 +368,7 @@ def main():
             r3 = hbm_roofline(avg3, frames3, W3 * H3, st3, passes3, src3)
             r3.update({"workload": "proc0:870000 %dx%d %dspp depth%d" % (W3, H3, SPP3, D3), "triangles": int(info3.numTriangles), "value": round(W3 * H3 * SPP3 * 3 / dt3 / 1e6, 1),
                        "unit_value": "Msamples/s", "ms_per_step": round(dt3 / 3 * 1e3, 3), "steps": 3, "scene_load_s": round(load3, 2),
-                       "kernel_variant": ["matte", "env", "surf", "vol", "full"][tb.GetOption("last_variant")],
+                       "kernel_variant": ["matte", "env", "surf", "vol", "full", "sss"][tb.GetOption("last_variant")],
                        "note": "launches of 128 frames are batched by the sample-buffer budget: avg_launch_ms / frames_per_launch are per batch launch"})
             if passes3 and "sq" in passes3 and "SQ_WAIT_ANY" in passes3["sq"]:
                 r3["sq_wait_any_frac"] = round(passes3["sq"]["SQ_WAIT_ANY"] / passes3["sq"]["SQ_WAVE_CYCLES"], 3)

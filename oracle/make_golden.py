@@ -98,7 +98,7 @@ def main():
     # the same scene serialised by the REFERENCE parser's own binary writer (pbrt::Scene::saveTo): fixture of the .pbf reader
     subprocess.run([DUMP, "--save-pbf", os.path.join(REF, "Scenes", "cornell-box", "scene.pbrt"), os.path.join(GOLD, "cornell-box.pbf")], check=True)
     # the hand-written fixture scenes (tests/golden/scenes/{material-maps,instances}) as the REFERENCE parser sees them
-    for name in ("material-maps", "instances"):
+    for name in ("material-maps", "instances", "mix-glass"):
         subprocess.run([DUMP, os.path.join(GOLD, "scenes/%s/scene.pbrt" % name), tmp], check=True, stdout=subprocess.DEVNULL)
         with open(tmp) as f, open(os.path.join(GOLD, name + ".parser.txt"), "w") as g:
             for line in f:

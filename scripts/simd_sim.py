@@ -11,7 +11,7 @@ inner-node body and the leaf body (the two hot loops of traverse(), pt_device.hp
 import collections
 import sys
 
-CI, CL = 45.0, 80.0   # wave-instructions per trip through the inner-node body / the leaf body (from the gfx950 ISA)
+CI, CL = 85.0, 160.0   # VALU cycles per trip through the inner-node body / the leaf body (gfx950 ISA x scripts/microbench/valu_issue.hip costs)
 
 
 def load(path):
@@ -88,7 +88,7 @@ def lockstep(samples, park_min=8):
     return total
 
 
-def lockstep_regen(samples, regen_thresh=1, park_min=8, costs=(450.0, 300.0, 150.0, 100.0, 80.0)):
+def lockstep_regen(samples, regen_thresh=1, park_min=8, costs=(1100.0, 750.0, 400.0, 250.0, 300.0)):
     """pt_persistent with its non-traversal phases priced too (wave-instructions per trip: regenerate, closest-hit
     shading, scatter, shadow slot, ray setup) and a regeneration threshold: finished lanes start their next sample only
     when at least regen_thresh lanes of the wave are waiting (or nobody is alive)."""
@@ -125,6 +125,62 @@ def lockstep_regen(samples, regen_thresh=1, park_min=8, costs=(450.0, 300.0, 150
     n = len(samples)
     print("%-44s traversal %7.1f  other %7.1f  total %7.1f per sample   (regen trips/64 samples %.2f, iterations %.2f)" % (
         "lock-step regen_thresh=%d" % regen_thresh, total.cost() / n, other / n, (total.cost() + other) / n, regen_trips * 64.0 / n, iters * 64.0 / n))
+
+
+def lockstep_sliced(samples, cap=8, park_min=2, costs=(1100.0, 750.0, 400.0, 250.0, 300.0)):
+    """pt_persistent with TIME-SLICED traversal: a traversal slot runs at most `cap` rounds (round = inner loop + one leaf step);
+    lanes whose ray is not finished keep their walk state (ref, stack height, best hit; the ray constants are recomputed) and
+    resume in the same slot of the next iteration, next to the new rays of the lanes that went on -- the slot is no longer as long
+    as its slowest ray.  Non-traversal phases are priced as in lockstep_regen (regenerate, closest-hit shading, scatter, shadow
+    slot, ray setup); a phase costs its price whenever at least one lane runs it."""
+    c_regen, c_shade, c_scatter, c_shadow, c_setup = costs
+    total = Wave(park_min); other = 0.0; iters = 0
+    for tile, lanes in tiles(samples).items():
+        todo = {l: [fr[f] for f in sorted(fr)] for l, fr in lanes.items()}
+        cur = {l: None for l in todo}; pos = {l: 0 for l in todo}
+        walk = {l: None for l in todo}      # lane -> [kind, steps, position] of a walk in flight
+        while True:
+            can = [l for l in cur if cur[l] is None and todo[l]]
+            if can:
+                for l in can: cur[l] = todo[l].pop(0); pos[l] = 0
+                other += c_regen
+            alive = [l for l in cur if cur[l] is not None]
+            if not alive: break
+            iters += 1
+            scatter = False
+            for kind in ("E", "S"):
+                w = Wave(park_min); members = []
+                for l in alive:
+                    if walk[l] is not None:
+                        if walk[l][0] == kind: w.s[l] = walk[l][1]; w.p[l] = walk[l][2]; members.append(l)
+                        continue
+                    q = cur[l]
+                    if pos[l] < len(q) and (q[pos[l]][0] == kind or (kind == "E" and q[pos[l]][0] == "W")):
+                        w.give(l, q[pos[l]][1]); walk[l] = [kind, q[pos[l]][1], 0]; pos[l] += 1; members.append(l)
+                if not members: continue
+                other += c_setup
+                rounds = 0
+                while w.nbusy() and rounds < cap: w.round(); rounds += 1
+                total.merge(w)
+                fin = [l for l in members if not w.busy(l)]
+                for l in members:
+                    if w.busy(l): walk[l][2] = w.p[l]
+                    else: walk[l] = None
+                if fin:
+                    other += c_shade if kind == "E" else c_shadow
+                    if kind == "S": scatter = True
+                    else:
+                        # a lane whose bounce ray is done and has no shadow feeler next scatters (or ends) in this iteration
+                        for l in fin:
+                            q = cur[l]
+                            if not (pos[l] < len(q) and q[pos[l]][0] == "S"): scatter = True
+            if scatter: other += c_scatter
+            for l in alive:
+                if walk[l] is None and pos[l] >= len(cur[l]): cur[l] = None
+    n = len(samples)
+    print("%-44s traversal %7.1f  other %7.1f  total %7.1f per sample   (iterations/64 samples %.2f, inner occ %.3f leaf occ %.3f)" % (
+        "lock-step sliced cap=%d park_min=%d" % (cap, park_min), total.cost() / n, other / n, (total.cost() + other) / n, iters * 64.0 / n,
+        total.inner_active / max(total.inner_trips, 1) / 64, total.leaf_active / max(total.leaf_trips, 1) / 64))
 
 
 def lockstep_hoisted(samples, park_min=8, share_wave=False, refill_below=48):
@@ -242,9 +298,10 @@ def main():
     nr = sum(len(v) for v in samples.values())
     print("%d samples, %.2f rays/sample, %.2f inner + %.2f leaf steps per ray" % (
         n, nr / n, sum(r[1].count("I") for v in samples.values() for r in v) / nr, sum(r[1].count("L") for v in samples.values() for r in v) / nr))
-    report("lock-step (pt_persistent) PARK_MIN=8", lockstep(samples, 8), n)
-    for th in (1, 4, 8, 16, 24, 32):
-        lockstep_regen(samples, th)
+    report("lock-step (pt_persistent) PARK_MIN=2", lockstep(samples, 2), n)
+    lockstep_regen(samples, 1, park_min=2)
+    for cap in (1000, 16, 8, 6, 4, 3, 2, 1):
+        lockstep_sliced(samples, cap, park_min=2)
     return
     report("lock-step + hoisted bounce ray, own lane", lockstep_hoisted(samples), n)
     report("lock-step + hoisted, wave-local pool", lockstep_hoisted(samples, share_wave=True), n)

@@ -11,6 +11,7 @@ from conftest import CORNELL, GOLDEN
 
 pytestmark = pytest.mark.gpu
 TEAPOT = os.path.join(GOLDEN, "scenes", "Teapot", "scene.pbrt")
+MIX_GLASS = os.path.join(GOLDEN, "scenes", "mix-glass", "scene.pbrt")
 
 
 def bits(a):
@@ -270,14 +271,15 @@ def test_all_kernel_variants_agree(gpu_tb, settings):
     gpu_tb.SetOption("pipeline", 0)
 
 
-@pytest.mark.parametrize("scene", ["cornell", "proc0", "proc1"])
+@pytest.mark.parametrize("scene", ["cornell", "proc0", "proc1", "mix-glass"])
 def test_occupancy_copies_agree(gpu_tb, settings, scene):
     """The matte / env / vol feature sets exist twice: at the occupancy their registers allow and held to one more wave per SIMD
     (pt_variant_{matte5,env5,vol4}.hip, picked when LDS has room for that many workgroups per CU; option high_occupancy).  Both
     copies, in the one-pixel-per-lane form (3 frames) and the frame-group form (9 frames), against the oracle."""
     if scene == "cornell": gpu_tb.LoadScene(CORNELL); variant = 0
     elif scene == "proc0": gpu_tb.LoadProcedural(0, 20000, 3); variant = 1
-    else: gpu_tb.LoadProcedural(1, 30000, 7); variant = 3
+    elif scene == "proc1": gpu_tb.LoadProcedural(1, 30000, 7); variant = 5
+    else: gpu_tb.LoadScene(MIX_GLASS); variant = 3
     W, H = 96, 64
     s = copy.copy(settings); s.MaxBounces = 5
     try:
@@ -295,7 +297,7 @@ def test_occupancy_copies_agree(gpu_tb, settings, scene):
         gpu_tb.SetOption("high_occupancy", 1); gpu_tb.SetOption("frame_group", 0)
 
 
-@pytest.mark.parametrize("scene", ["cornell", "proc0", "proc1"])
+@pytest.mark.parametrize("scene", ["cornell", "proc0", "proc1", "mix-glass"])
 def test_split_traversal_stack_bit_exact(gpu_tb, settings, scene):
     """Trees too deep for the LDS share of a higher-occupancy kernel copy keep the first entries of the traversal stack in LDS
     and the deepest ones in global memory (HYBRID kernels, frame-group launches).  Forced here with a tiny LDS part
@@ -303,7 +305,8 @@ def test_split_traversal_stack_bit_exact(gpu_tb, settings, scene):
     the oracle."""
     if scene == "cornell": gpu_tb.LoadScene(CORNELL); variant = 0
     elif scene == "proc0": gpu_tb.LoadProcedural(0, 20000, 3); variant = 1
-    else: gpu_tb.LoadProcedural(1, 30000, 7); variant = 3
+    elif scene == "proc1": gpu_tb.LoadProcedural(1, 30000, 7); variant = 5
+    else: gpu_tb.LoadScene(MIX_GLASS); variant = 3
     W, H, F = 96, 64, 9
     s = copy.copy(settings); s.MaxBounces = 5
     try:
@@ -318,7 +321,7 @@ def test_split_traversal_stack_bit_exact(gpu_tb, settings, scene):
 
 
 @pytest.mark.parametrize("sort", [0, 1])
-@pytest.mark.parametrize("scene", ["cornell", "teapot", "proc0", "proc1", "proc2"])
+@pytest.mark.parametrize("scene", ["cornell", "teapot", "proc0", "proc1", "proc2", "mix-glass"])
 def test_wavefront_pipeline_bit_exact(gpu_tb, settings, scene, sort):
     """SoA-queue wavefront pipeline (generate/extend/shade/connect kernels, ballot-prefix compaction, frames of a
     batch in flight together, ordered accumulation from the sample buffer) against the oracle; the path budget is
@@ -333,8 +336,10 @@ def test_wavefront_pipeline_bit_exact(gpu_tb, settings, scene, sort):
         gpu_tb.LoadProcedural(0, 30000, 11); W, H, F, depth = 120, 72, 4, 6
     elif scene == "proc1":
         gpu_tb.LoadProcedural(1, 30000, 7); W, H, F, depth = 120, 72, 4, 6
-    else:
+    elif scene == "proc2":
         gpu_tb.LoadProcedural(2, 60000, 9); W, H, F, depth = 120, 72, 3, 16
+    else:
+        gpu_tb.LoadScene(MIX_GLASS); W, H, F, depth = 96, 64, 4, 7
     s = copy.copy(settings); s.MaxBounces = depth
     gpu_tb.SetOption("pipeline", 2); gpu_tb.SetOption("wavefront_paths", W * H * 3); gpu_tb.SetOption("wavefront_sort", sort)
     gpu_tb.SetOption("wavefront_segment", 1024 if scene == "proc2" else 4096)
@@ -346,7 +351,8 @@ def test_wavefront_pipeline_bit_exact(gpu_tb, settings, scene, sort):
         assert gpu_tb.GetOption("last_pipeline") == 2
     finally:
         gpu_tb.SetOption("pipeline", 0); gpu_tb.SetOption("wavefront_paths", 16 << 20); gpu_tb.SetOption("wavefront_sort", 0); gpu_tb.SetOption("wavefront_segment", 4096)
-    if scene in ("proc1", "proc2"): assert variant == 3          # "vol": SSS + mix
+    if scene in ("proc1", "proc2"): assert variant == 5          # "sss": SSS interior walk, no mix materials
+    if scene == "mix-glass": assert variant == 3                 # "vol": SSS + mix
     ref = _oracle(gpu_tb, W, H, F, s, jittered=True)
     assert np.array_equal(bits(out), bits(ref["output"]))
     assert np.array_equal(bits(jit), bits(ref["jittered"]))
@@ -710,7 +716,7 @@ def test_config_c4_c5_4k_scenes(gpu_tb, settings, cfg):
     finally:
         gpu_tb.SetOption("bvh_builder", 0)
     gpu_tb.InvalidateHistory(); gpu_tb.Render(W, H, F, s, 0.0)
-    assert gpu_tb.GetOption("last_variant") == 3                           # "vol": SSS walk + mix materials
+    assert gpu_tb.GetOption("last_variant") == 5                           # "sss": SSS walk, no mix materials
     full = _strip_and_properties(gpu_tb, s, W, H, F, (1000, 1400))
     try:
         gpu_tb.SetTileAssignment(3, 8)

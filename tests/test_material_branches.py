@@ -88,6 +88,26 @@ def test_material_maps_conversion(built):
     assert np.allclose(d, -np.array([3, 6, 4]) / np.linalg.norm([3, 6, 4]), atol=1e-6)
 
 
+def test_mix_glass_fixture(built, tmp_path):
+    """tests/golden/scenes/mix-glass: the loader against the reference parser's dump, and CreateMaterial's mix branch
+    (TracerBoy.cpp:365-373: both sub-materials are created and tracked anew, their indices ride in albedo.xy, the weight in albedo.z)."""
+    from tracerboy_amd import api
+    scene = os.path.join(GOLDEN, "scenes", "mix-glass", "scene.pbrt")
+    out = str(tmp_path / "dump.txt"); err = C.create_string_buffer(256)
+    assert api.lib().tb_host_pbrt_dump(scene.encode(), out.encode(), err, 256) == 0, err.value
+    assert open(out).read() == open(os.path.join(GOLDEN, "mix-glass.parser.txt")).read()
+    hs = api.HostScene(scene); v = hs.view(); n = hs.info().numMaterials
+    mats = [v.materials[k] for k in range(n)]
+    mixes = [m for m in mats if m.Flags & 0x8]
+    assert len(mixes) == 2
+    for m in mixes:
+        i0, i1 = int(m.albedo.x), int(m.albedo.y)
+        assert 0 <= i0 < n and 0 <= i1 < n and i0 != i1 and 0.0 < m.albedo.z < 1.0
+        assert not (mats[i0].Flags & 0x8) and not (mats[i1].Flags & 0x8)
+    assert any(m.Flags & 0x2 for m in mats)                                    # glass: SUBSURFACE_SCATTER
+    assert sum(1 for m in mats if m.Flags & 0x10) == 1                         # only the lamp's own material is emissive
+
+
 def _oracle_variant(hs, base, variant):
     v = hs.view()
     mats = [v.materials[k] for k in range(11)]

@@ -23,10 +23,11 @@ ARCH = os.environ.get("TB_ARCH", "gfx950")  # e.g. gfx950:xnack- for experiments
 
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function",
           "-Wno-unused-variable", "-Wno-unused-but-set-variable", "-I" + os.path.join(REPO, "include")] + os.environ.get("TB_EXTRA_FLAGS", "").split()
-DEVICE = ["--offload-arch=" + ARCH, "-fgpu-flush-denormals-to-zero=false"] if False else ["--offload-arch=" + ARCH]
+DEVICE = ["--offload-arch=" + ARCH]
 
 HOST_SRCS = ["host/pbrt_loader.cpp", "host/pbf_loader.cpp", "host/host_scene.cpp", "host/images.cpp", "host/image_decode.cpp", "host/bvh_build.cpp", "host/procedural.cpp", "host/context.cpp", "host/pbrt_dump.cpp"]
 KERNEL_SRCS = ["kernels/pt_kernels.hip", "kernels/post_kernels.hip", "kernels/bvh_kernels.hip", "kernels/rt_kernels.hip", "kernels/pt_variant_matte.hip", "kernels/pt_variant_matte5.hip", "kernels/pt_variant_env.hip", "kernels/pt_variant_env5.hip", "kernels/pt_variant_surf.hip",
+               "kernels/pt_variant_sss.hip", "kernels/pt_variant_sss4.hip",
                "kernels/pt_variant_vol.hip", "kernels/pt_variant_vol4.hip", "kernels/pt_variant_full.hip"]
 
 

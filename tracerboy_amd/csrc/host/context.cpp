@@ -28,6 +28,8 @@ hipError_t pt_launch_persistent_env(hipStream_t, const TbDeviceScene*, const TbP
 hipError_t pt_launch_persistent_surf(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, uint32_t, uint32_t, uint32_t, uint32_t, const TbTileMap*, int, int, int);
 hipError_t pt_launch_persistent_matte5(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, uint32_t, uint32_t, uint32_t, uint32_t, const TbTileMap*, int, int, int);
 hipError_t pt_launch_persistent_env5(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, uint32_t, uint32_t, uint32_t, uint32_t, const TbTileMap*, int, int, int);
+hipError_t pt_launch_persistent_sss(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, uint32_t, uint32_t, uint32_t, uint32_t, const TbTileMap*, int, int, int);
+hipError_t pt_launch_persistent_sss4(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, uint32_t, uint32_t, uint32_t, uint32_t, const TbTileMap*, int, int, int);
 hipError_t pt_launch_persistent_vol4(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, uint32_t, uint32_t, uint32_t, uint32_t, const TbTileMap*, int, int, int);
 hipError_t pt_launch_persistent_vol(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, uint32_t, uint32_t, uint32_t, uint32_t, const TbTileMap*, int, int, int);
 hipError_t pt_launch_persistent_full(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, uint32_t, uint32_t, uint32_t, uint32_t, const TbTileMap*, int, int, int);
@@ -40,24 +42,27 @@ typedef hipError_t (*wf_variant_fn)(hipStream_t, int, const TbDeviceScene*, cons
 hipError_t wf_launch_matte(hipStream_t, int, const TbDeviceScene*, const TbPerFrameConstants*, const WfParams*, const WfQueue*, const WfQueue*, const WfQueue*, const WfHits*, int, TbFloat4*, TbFloat4*, uint32_t);
 hipError_t wf_launch_env(hipStream_t, int, const TbDeviceScene*, const TbPerFrameConstants*, const WfParams*, const WfQueue*, const WfQueue*, const WfQueue*, const WfHits*, int, TbFloat4*, TbFloat4*, uint32_t);
 hipError_t wf_launch_surf(hipStream_t, int, const TbDeviceScene*, const TbPerFrameConstants*, const WfParams*, const WfQueue*, const WfQueue*, const WfQueue*, const WfHits*, int, TbFloat4*, TbFloat4*, uint32_t);
+hipError_t wf_launch_sss(hipStream_t, int, const TbDeviceScene*, const TbPerFrameConstants*, const WfParams*, const WfQueue*, const WfQueue*, const WfQueue*, const WfHits*, int, TbFloat4*, TbFloat4*, uint32_t);
 hipError_t wf_launch_vol(hipStream_t, int, const TbDeviceScene*, const TbPerFrameConstants*, const WfParams*, const WfQueue*, const WfQueue*, const WfQueue*, const WfHits*, int, TbFloat4*, TbFloat4*, uint32_t);
 }
 
 namespace {
 
 std::string g_createError;
-const wf_variant_fn kWfVariants[4] = {wf_launch_matte, wf_launch_env, wf_launch_surf, wf_launch_vol}; /* same order as kVariants[0..3]; pipeline 3 (pooled) exists for 0..2 */
-
 /* fnHi: the same feature set compiled to `wavesHi` waves per SIMD (fewer VGPRs, more scratch; pipeline 0 only), used when LDS
- * has room for that many workgroups per CU -- otherwise its spills would buy no residency */
-struct Variant { uint32_t features; pt_variant_fn fn; const char* name; pt_variant_fn fnHi; uint32_t wavesHi; };
+ * has room for that many workgroups per CU -- otherwise its spills would buy no residency.  Searched in order: the first feature
+ * set that covers what scene + settings need.  id: what option "last_variant" reports (stable across insertions).
+ * wf: the wavefront pipeline's launcher of the feature set (pipeline 2; none for the full set); pooled: pipeline 3 exists. */
+struct Variant { uint32_t features; pt_variant_fn fn; const char* name; pt_variant_fn fnHi; uint32_t wavesHi; int id; wf_variant_fn wf; bool pooled; };
 const Variant kVariants[] = {
-    {0u, pt_launch_persistent_matte, "matte", pt_launch_persistent_matte5, 5},
-        {PT_FEAT_ENV, pt_launch_persistent_env, "env", pt_launch_persistent_env5, 6},
-    {PT_FEAT_ENV | PT_FEAT_SPECULAR | PT_FEAT_TEXTURES, pt_launch_persistent_surf, "surf", nullptr, 0},
-        {PT_FEAT_ENV | PT_FEAT_SPECULAR | PT_FEAT_TEXTURES | PT_FEAT_SSS | PT_FEAT_MIX, pt_launch_persistent_vol, "vol", pt_launch_persistent_vol4, 4},
-    {PT_FEAT_ALL, pt_launch_persistent_full, "full", nullptr, 0},
+    {0u, pt_launch_persistent_matte, "matte", pt_launch_persistent_matte5, 5, 0, wf_launch_matte, true},
+        {PT_FEAT_ENV, pt_launch_persistent_env, "env", pt_launch_persistent_env5, 6, 1, wf_launch_env, true},
+    {PT_FEAT_ENV | PT_FEAT_SPECULAR | PT_FEAT_TEXTURES, pt_launch_persistent_surf, "surf", nullptr, 0, 2, wf_launch_surf, true},
+        {PT_FEAT_ENV | PT_FEAT_SPECULAR | PT_FEAT_TEXTURES | PT_FEAT_SSS, pt_launch_persistent_sss, "sss", pt_launch_persistent_sss4, 4, 5, wf_launch_sss, false},
+    {PT_FEAT_ENV | PT_FEAT_SPECULAR | PT_FEAT_TEXTURES | PT_FEAT_SSS | PT_FEAT_MIX, pt_launch_persistent_vol, "vol", pt_launch_persistent_vol4, 4, 3, wf_launch_vol, false},
+        {PT_FEAT_ALL, pt_launch_persistent_full, "full", nullptr, 0, 4, nullptr, false},
 };
+constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 
 struct DevBuf {
     void* p = nullptr; size_t bytes = 0;
@@ -419,7 +424,7 @@ void renderWavefront(tb_context* c, int variant, uint32_t W, uint32_t H, uint32_
     /* per-segment fill counts; every stage writes the counts of all segments of its output queues, so no clearing */
     E[0].segCount = (uint32_t*)c->wfCounts.p; E[1].segCount = E[0].segCount + maxSegments; S.segCount = E[1].segCount + maxSegments;
     WfHits hits; hits.tuv_prim = (float4*)c->wfHitA.p; hits.geom = (uint32_t*)c->wfHitG.p;
-    const wf_variant_fn fn = kWfVariants[variant];
+    const wf_variant_fn fn = kVariants[variant].wf;
     const uint32_t gridOpt = (uint32_t)opt("wavefront_grid", 256 * 8);
     const uint32_t depth = pf.MaxBounces;
     std::vector<uint32_t> counts;
@@ -465,7 +470,7 @@ void renderPooled(tb_context* c, int variant, uint32_t W, uint32_t H, uint32_t f
     const uint32_t batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n, budget / pixels));
     if (pixels * batch > 0xffffff00ull) throw std::runtime_error("pooled batch exceeds 2^32 samples");
     ensure(c->wfSamples, pixels * batch * 16);
-    const wf_variant_fn fn = kWfVariants[variant];
+    const wf_variant_fn fn = kVariants[variant].wf;
     const uint32_t blocks = tb_persistent_grid(W, H, c->tiles);
     if (blocks == 0) return; /* this rank owns no tile */
     for (uint32_t f0 = 0; f0 < n; f0 += batch) {
@@ -519,11 +524,11 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
     if (count || opt("force_full_variant", 0)) need = PT_FEAT_ALL;
     const Variant* v = nullptr;
     for (const Variant& k : kVariants) if ((need & ~k.features) == 0) { v = &k; break; }
-    if (!v) v = &kVariants[4];
+    if (!v) v = &kVariants[kNumVariants - 1];
     c->lastVariant = v->name;
     const int variantIndex = (int)(v - kVariants);
-    const bool wavefront = opt("pipeline", 0) == 2 && variantIndex <= 3 && !count && !aov;
-    const bool pooled = opt("pipeline", 0) == 3 && variantIndex <= 2 && !count && !aov;
+    const bool wavefront = opt("pipeline", 0) == 2 && v->wf && !count && !aov;
+    const bool pooled = opt("pipeline", 0) == 3 && v->pooled && !count && !aov;
     const int64_t fg = opt("frame_group", 0);
     const bool groups = !wavefront && !pooled && opt("pipeline", 0) == 0 && !count && !aov && !s.RenderModeRealTime && fg >= 0 && (fg > 0 || n >= (c->sceneInLds ? 1u : 2u)); /* measured: frame groups win from 2 frames per call on (cornell-box 4 spp +23 %, 870 k scene 4 spp 2x); one frame per call: +17 % with the scene in LDS, -9 % on the 870 k scene */
     /* Which copy of the feature set: the higher-occupancy one when its workgroups fit in LDS.  LDS per workgroup = 1 KB per stack
@@ -551,7 +556,7 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
     }
     /* launches of the kernels without the EXT features (no selected pixel, no AOVs: nothing but the sample buffer is written)
      * may overlap the drain of the launch before them */
-    const bool overlap = groups && variantIndex != 4 && opt("overlap_launches", 1) != 0;
+    const bool overlap = groups && v->features != PT_FEAT_ALL && opt("overlap_launches", 1) != 0;
     if (!overlap) c->sideOrdered = false;
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
     if (clearStats && !overlap) HIP_TRY(hipMemsetAsync(c->stats.p, 0, 16, c->stream));
@@ -580,8 +585,11 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
             const uint32_t frames = std::min(batch, n);
             const uint32_t autoG = (uint32_t)std::min<uint64_t>(frames, std::max<uint64_t>(1, ((uint64_t)frames * regions + 24575) / 24576));
             ensure(c->workCounter, 1024);
+            tg.bandedItems = (uint32_t)opt("banded_items", 0);
             tg.frameGroup = fg > 0 ? (uint32_t)fg : autoG;
             while (tg.frameGroup & (tg.frameGroup - 1)) tg.frameGroup &= tg.frameGroup - 1; /* a power of two (rounded down): samples find their frame with shifts */
+            while ((frames + tg.frameGroup - 1) / tg.frameGroup > 4095u) tg.frameGroup *= 2;   /* a claimed item is group << 20 | region (claim_work_item) */
+            if (regions > 0xfffffu) throw std::runtime_error("frame too large for the frame-group launch (more than 2^20 16x16 regions)");
             if (overlap && !c->sideOrdered) { /* first overlapped launch after other work on the main stream: order the side streams behind it once */
                 HIP_TRY(hipEventRecord(c->evMain, c->stream));
                 for (int i = 0; i < 2; i++) HIP_TRY(hipStreamWaitEvent(c->side[i], c->evMain, 0));
@@ -1037,7 +1045,7 @@ int tb_unpack_gathered_host(uint32_t W, uint32_t H, uint32_t world, uint32_t tw,
 int tb_set_option(tb_context* c, const char* name, int64_t v)
 {
     if (!c || !name) return TB_E_INVALID;
-    static const char* known[] = {"pipeline", "count_rays", "bvh_builder", "flatten_instances", "aov", "scene_in_lds", "lds_scene_budget", "force_full_variant", "wavefront_paths", "wavefront_grid", "wavefront_segment", "pooled_paths", "pooled_samples", "pooled_profile", "park_min", "alpha_test", "node_order", "node_order_top_levels", "frame_group", "overlap_launches", "high_occupancy", "stack_lds_cap", "stack_overflow_max", "flip_texture_uvs", "wavefront_sort"};
+    static const char* known[] = {"pipeline", "count_rays", "bvh_builder", "flatten_instances", "aov", "scene_in_lds", "lds_scene_budget", "force_full_variant", "wavefront_paths", "wavefront_grid", "wavefront_segment", "pooled_paths", "pooled_samples", "pooled_profile", "park_min", "alpha_test", "node_order", "node_order_top_levels", "frame_group", "overlap_launches", "high_occupancy", "stack_lds_cap", "stack_overflow_max", "flip_texture_uvs", "wavefront_sort", "banded_items"};
     for (const char* k : known) if (!strcmp(k, name)) { c->options[name] = v; if (!strcmp(name, "count_rays") || !strcmp(name, "aov")) c->samplesRendered = 0; return TB_OK; }
     return fail(c, TB_E_INVALID, std::string("unknown option '") + name + "'");
 }
@@ -1049,7 +1057,7 @@ int64_t tb_get_option(tb_context* c, const char* name)
     if (!strcmp(name, "last_kernel_us")) return (int64_t)(c->lastKernelMs * 1000.0f + 0.5f); /* first path-tracing launch of the last synchronous render */
     if (!strcmp(name, "last_kernel_frames")) return c->lastKernelFrames;
     if (!strcmp(name, "last_pipeline")) return c->lastPipeline; /* the pipeline the last render actually ran (2 / 3 fall back to 0 for feature sets they lack) */
-    if (!strcmp(name, "last_variant")) { for (int i = 0; i < 5; i++) if (c->lastVariant == kVariants[i].name) return i; return -1; }
+    if (!strcmp(name, "last_variant")) { for (const Variant& k : kVariants) if (c->lastVariant == k.name) return k.id; return -1; } /* 0 matte 1 env 2 surf 3 vol 4 full 5 sss */
     auto it = c->options.find(name); return it == c->options.end() ? 0 : it->second;
 }
 

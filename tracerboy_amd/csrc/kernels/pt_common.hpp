@@ -35,14 +35,23 @@ __device__ __forceinline__ bool block_region(const TbTileMap& tiles, uint32_t W,
     return true;
 }
 
-/* Frame-group mode of pt_persistent: work items come from 8 interleaved lists (item = 8 * count + list), a workgroup starting
- * at list blockIdx % 8 and moving on when a list is empty -- one counter for the whole device would serialise every claim on a
- * single address.  Out of line: it runs once per few thousand samples and must not cost the path loop any registers. */
-__device__ __noinline__ uint32_t claim_work_item(uint32_t* counters, uint32_t totalItems)
+/* Frame-group mode of pt_persistent: work items (region x frame group) come from 8 lists, a workgroup starting at list
+ * blockIdx % 8 -- the XCD it runs on -- and moving on when a list is empty; one counter for the whole device would serialise
+ * every claim on a single address.  banded = 0: item = 8 * count + list (every list is spread over the whole frame);
+ * banded = 1: list q owns the q-th contiguous eighth of the regions, all frame groups of it, so that an XCD's L2 keeps seeing the
+ * same part of the scene until its band is done and only then helps the others.  Returns group << 20 | region, or ~0 when
+ * nothing is left.  Out of line: it runs once per few thousand samples and must not cost the path loop any registers. */
+__device__ __noinline__ uint32_t claim_work_item(uint32_t* counters, uint32_t regions, uint32_t numGroups, uint32_t banded)
 {
     for (uint32_t t = 0; t < 8; t++) {
-        const uint32_t q = (blockIdx.x + t) & 7u, item = atomicAdd(counters + q * 16u, 1u) * 8u + q;
-        if (item < totalItems) return item;
+        const uint32_t q = (blockIdx.x + t) & 7u, c = atomicAdd(counters + q * 16u, 1u);
+        if (banded) {
+            const uint32_t b0 = (uint32_t)(((unsigned long long)regions * q) >> 3), n = (uint32_t)(((unsigned long long)regions * (q + 1u)) >> 3) - b0;
+            if (n && c < n * numGroups) { const uint32_t group = c / n; return group << 20 | (b0 + (c - group * n)); }
+        } else {
+            const uint32_t item = c * 8u + q;
+            if (item < regions * numGroups) { const uint32_t group = item / regions; return group << 20 | (item - group * regions); }
+        }
     }
     return 0xffffffffu;
 }

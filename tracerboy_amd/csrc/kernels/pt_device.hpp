@@ -975,6 +975,24 @@ TBD void path_on_shadow(Path& p, const SceneRefs& sc, const TbDeviceScene& ds, c
     p.state = ST_SCATTER;
 }
 
+/* The same visibility test for kernels that scatter BEFORE they trace the feeler (pt_persistent.inc, feature sets without mix
+ * materials): lightDir is the feeler's direction, the path's own ray already is the next bounce.  Touches nothing but L. */
+template <uint32_t F>
+TBD void path_apply_shadow(Path& p, const SceneRefs& sc, const TbDeviceScene& ds, const TbPerFrameConstants& pf, bool isHit, const Hit& h, tb3 lightDir, tb3 contrib)
+{
+    static_assert(!(F & FEAT_MIX), "GetMaterial of the blocker draws a random number for mix materials: the feeler must be judged before the scatter");
+    bool lit = true;
+    if (isHit) {
+        Surface s;
+        fetch_surface(sc, h, s, false);
+        const bool back = tb3_dot(s.normal, lightDir) > 0.0f;
+        const TbMaterial m = get_material<F>(sc, ds, p.seed, pf.Time, s.material, s.u, s.v, back);
+        p.nMat++;
+        if ((m.Flags & TB_MAT_LIGHT) == 0) lit = false;
+    }
+    p.L = p.L + (lit ? contrib : contrib * 0.0f);
+}
+
 TBD void finish_bounce(Path& p, const TbPerFrameConstants& pf)
 {
     p.bounce++;

@@ -72,6 +72,7 @@ struct TbDeviceTargets {
      * accumulate_samples_kernel then sums them in frame order, which keeps the fp32 accumulation of RayGenCommon.h:704-727
      * bit for bit while no lane waits for its neighbours' longer paths. */
     TbFloat4* samples; uint32_t frameGroup; uint32_t* workCounter;
+    uint32_t bandedItems;  /* claim_work_item (pt_common.hpp): every XCD's list covers a contiguous eighth of the regions instead of every eighth region */
 };
 
 struct TbTileMap { /* multi-GPU tile ownership: tile t is rendered iff t % world == rank; tileW, tileH multiples of 16 */
