@@ -187,14 +187,30 @@ uint32_t settingsFeatureMask(const tb_context* c, const tb_output_settings& s, b
  * contiguous prefix; order 1: depth-first pre-order, a node's left child follows it (same 128-B line every other step of
  * a descent); order 2: breadth-first for the top `topLevels` levels, depth-first below (cached top + local subtrees);
  * order 3: blocks of `topLevels` levels stored breadth-first, the blocks themselves depth-first (van Emde Boas style: a
- * descent of `topLevels` steps stays inside one contiguous block). */
+ * descent of `topLevels` steps stays inside one contiguous block); order 4: depth-first by SIBLING PAIRS -- the two inner children
+ * of a node lie side by side in one aligned 128-B line (a dummy node pads where needed), so fetching the near child brings the
+ * far child's record along for when it is popped; order 5: order 4 below a breadth-first top of `topLevels` levels. */
 void reorderNodes(HostScene& s, int order_, uint32_t topLevels)
 {
     const uint32_t n = (uint32_t)s.nodesB.size();
     if (s.rootRefB & TB_BVH_LEAF_FLAG) return;
-    std::vector<uint32_t> order; order.reserve(n);
+    constexpr uint32_t PAD = 0xffffffffu;
+    std::vector<uint32_t> order; order.reserve(n + n / 4);
     std::vector<uint32_t> newIndex(n, 0);
     auto inner = [](uint32_t ref) { return !(ref & TB_BVH_LEAF_FLAG); };
+    auto pairDfs = [&](uint32_t root) { /* `root` itself is already placed */
+        std::vector<uint32_t> st; st.push_back(root);
+        while (!st.empty()) {
+            const uint32_t x = st.back(); st.pop_back();
+            const TbNodeB& nd = s.nodesB[x];
+            const bool li = inner(nd.left), ri = inner(nd.right);
+            if (li && ri && (order.size() & 1u)) order.push_back(PAD);
+            if (li) order.push_back(nd.left);
+            if (ri) order.push_back(nd.right);
+            if (ri) st.push_back(nd.right);
+            if (li) st.push_back(nd.left);
+        }
+    };
     auto dfs = [&](uint32_t root) {
         std::vector<uint32_t> st; st.push_back(root);
         while (!st.empty()) {
@@ -205,6 +221,7 @@ void reorderNodes(HostScene& s, int order_, uint32_t topLevels)
         }
     };
     if (order_ == 1) dfs(s.rootRefB);
+    else if (order_ == 4) { order.push_back(s.rootRefB); pairDfs(s.rootRefB); }
     else if (order_ == 3) {
         const uint32_t h = topLevels ? topLevels : 2;
         std::vector<uint32_t> blocks; blocks.push_back(s.rootRefB);
@@ -221,16 +238,18 @@ void reorderNodes(HostScene& s, int order_, uint32_t topLevels)
     } else {
         std::vector<uint32_t> level; level.push_back(s.rootRefB);
         uint32_t depth = 0;
-        while (!level.empty() && (order_ == 0 || depth < topLevels)) {
+        while (!level.empty() && (order_ == 0 || depth < topLevels)) { /* orders 0, 2, 5 */
             std::vector<uint32_t> next;
             for (uint32_t x : level) { order.push_back(x); const TbNodeB& nd = s.nodesB[x]; if (inner(nd.left)) next.push_back(nd.left); if (inner(nd.right)) next.push_back(nd.right); }
             level.swap(next); depth++;
         }
-        for (uint32_t x : level) dfs(x); /* order 2: the subtrees hanging below the breadth-first top */
+        if (order_ == 5) { if ((order.size() & 1u) && !level.empty()) order.push_back(PAD); for (uint32_t x : level) order.push_back(x); for (uint32_t x : level) pairDfs(x); }
+        else for (uint32_t x : level) dfs(x); /* order 2: the subtrees hanging below the breadth-first top */
     }
-    for (uint32_t i = 0; i < (uint32_t)order.size(); i++) newIndex[order[i]] = i;
+    for (uint32_t i = 0; i < (uint32_t)order.size(); i++) if (order[i] != PAD) newIndex[order[i]] = i;
     std::vector<TbNodeB> out(order.size());
     for (uint32_t i = 0; i < (uint32_t)order.size(); i++) {
+        if (order[i] == PAD) { memset(&out[i], 0, sizeof(TbNodeB)); out[i].left = out[i].right = TB_BVH_LEAF_FLAG; continue; }
         TbNodeB nd = s.nodesB[order[i]];
         if (inner(nd.left)) nd.left = newIndex[nd.left];
         if (inner(nd.right)) nd.right = newIndex[nd.right];
