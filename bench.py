@@ -138,6 +138,30 @@ def pmc_summary(key):
     return best, (os.path.relpath(files[-1], ROOT) if best else None)
 
 
+def derived_busy(key, passes):
+    """Pipe utilisations of the timed kernel from the same committed PMC passes, with rocprof's own definitions:
+    VALUBusy = 4 * SQ_ACTIVE_INST_VALU / (1024 SIMDs * cycles), cycles = GRBM_GUI_ACTIVE / 8 XCDs; TA busy = TA_TA_BUSY_sum /
+    (256 TAs * cycles) from profiles/rN/<key>_mem_counters.json (scripts/pmc_mem.sh) when that file exists."""
+    import glob
+    import re
+    out = {}
+    if passes and "sq" in passes and "lds" in passes and passes["lds"].get("GRBM_GUI_ACTIVE"):
+        cyc = passes["lds"]["GRBM_GUI_ACTIVE"] / 8.0
+        out["valu_busy"] = round(4.0 * passes["sq"]["SQ_ACTIVE_INST_VALU"] / (SIMDS * cyc), 3)
+        out["salu_busy"] = round(passes["lds"]["SQ_INSTS_SALU"] / (256.0 * cyc), 3)       # one scalar instruction per cycle per CU (valu_issue.hip)
+        out["lds_busy"] = round(passes["lds"]["SQ_LDS_IDX_ACTIVE"] / (256.0 * cyc), 3)
+        out["wait_any"] = round(passes["sq"]["SQ_WAIT_ANY"] / passes["sq"]["SQ_WAVE_CYCLES"], 3)
+        if "util" in passes:
+            out["valu_lane_utilisation"] = round(passes["util"]["SQ_THREAD_CYCLES_VALU"] / (64.0 * passes["util"]["SQ_ACTIVE_INST_VALU"]), 3)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", key + "_mem_counters.json")), key=lambda f: int(re.search(r"profiles/r(\d+)", f).group(1)))
+    if files:
+        for name, c in json.load(open(files[-1])).items():
+            m = re.search(r"pt_persistent<\d+u, (true|false), (true|false), (true|false)", name)
+            if m and m.group(2) == "false" and m.group(3) == "true" and c.get("TA_TA_BUSY_sum") and c.get("GRBM_GUI_ACTIVE"):
+                out["ta_busy"] = round(c["TA_TA_BUSY_sum"] / (256.0 * c["GRBM_GUI_ACTIVE"] / 8.0), 3)
+    return out
+
+
 def traffic_bytes(passes):
     """HBM bytes per launch: (2 * FETCH_SIZE + WRITE_SIZE) * 1024 -- the counters are in KiB and gfx950's FETCH_SIZE reads half the
     bytes of 16-B/lane loads (MI355X_MICROARCH.md, HBM section)."""
@@ -342,14 +366,17 @@ def main():
             if insts:
                 ach = insts / (avg_ms * 1e-3) / 1e9
                 roof.update({"achieved": round(ach, 1), "frac": round(ach / VALU_PEAK_GINST, 4), "valu_insts_per_launch": int(insts),
-                             "valu_lane_utilisation": round(passes["util"]["SQ_THREAD_CYCLES_VALU"] / (64.0 * passes["util"]["SQ_ACTIVE_INST_VALU"]), 4) if "util" in passes else None})
+                             "frac_note": "counts every VALU instruction at the 2-cycle rate of v_fma/v_mul/v_add; the kernel's mix (v_pk_fma 3.3, min/max/cndmask 3.2-3.5, "
+                                          "v_cmp 4, f64 3.1-3.7, rcp/sqrt 6.2 cycles: profiles/r2/valu_issue.txt) keeps the VALU pipe busy pipes.valu_busy of the time"})
             else:
                 roof.update({"achieved": None, "frac": None, "note": "no committed PMC pass for this workload: instruction count unknown"})
+            roof["pipes"] = derived_busy(key, passes) if key else {}
             roof["algorithmic"] = {k: hbm[k] for k in ("achieved", "unit", "algorithmic_bytes_per_sample", "boxes_per_sample", "tris_per_sample", "rays_per_sample")}
             roof["algorithmic"]["note"] = "SURVEY 8d byte model; served by the LDS scene image, not HBM (achieved / 8 TB/s = %.2f says nothing about HBM)" % (hbm["achieved"] / HBM_PEAK_GBS)
             result["roofline"] = roof
         else:
             hbm["note"] = "BVH fetched from L2 / Infinity Cache / HBM"
+            if key: hbm["pipes"] = derived_busy(key, passes)
             result["roofline"] = hbm
 
         # ---- second object: configs[2] at its full 128 spp, the workload whose roofline IS HBM ---------
@@ -370,8 +397,9 @@ def main():
                        "unit_value": "Msamples/s", "ms_per_step": round(dt3 / 3 * 1e3, 3), "steps": 3, "scene_load_s": round(load3, 2),
                        "kernel_variant": ["matte", "env", "surf", "vol", "full", "sss"][tb.GetOption("last_variant")],
                        "note": "launches of 128 frames are batched by the sample-buffer budget: avg_launch_ms / frames_per_launch are per batch launch"})
-            if passes3 and "sq" in passes3 and "SQ_WAIT_ANY" in passes3["sq"]:
-                r3["sq_wait_any_frac"] = round(passes3["sq"]["SQ_WAIT_ANY"] / passes3["sq"]["SQ_WAVE_CYCLES"], 3)
+            r3["pipes"] = derived_busy("c3", passes3)
+            r3["what_limits_it"] = ("vector-memory issue: a CU's texture addresser takes ~17 cycles per wave-level load whatever the number of active lanes "
+                                    "(scripts/microbench/gather64.hip), four loads per node visit at ~16 active lanes of 64: TA busy 81 %, DESIGN.md section 6")
             result["roofline_c3"] = r3
             load(args.scene)   # back to the timed workload for the CPU baseline below
 
