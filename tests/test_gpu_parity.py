@@ -732,6 +732,30 @@ def test_config_c4_c5_4k_scenes(gpu_tb, settings, cfg):
     assert np.array_equal(bits(mine[owned]), bits(full[owned]))
 
 
+def test_headless_cli_native_rccl_gather_plumbing(tmp_path):
+    """tracerboy-hip --ranks N gathers the ranks' packed tiles with librccl (dlopen; ncclGroupStart / Recv / Send / GroupEnd on the
+    context's stream) and un-permutes them on the device into rank 0's accumulation surface.  One GPU here: TB_CLI_FORCE_RCCL=1
+    runs that sequence with a communicator of one rank (self-gather) -- the EXR must be the plain run's, byte for byte."""
+    import subprocess
+    from tracerboy_amd import api
+    cli = os.path.join(os.path.dirname(api.__file__), "tracerboy-hip")
+    outs = []
+    for force in ("0", "1"):
+        out = str(tmp_path / ("o%s.exr" % force))
+        env = dict(os.environ, TB_CLI_FORCE_RCCL=force)
+        r = subprocess.run([cli, CORNELL, "--width", "200", "--height", "120", "--spp", "5", "--depth", "4", "--blue-noise", "0", "--out", out],
+                           capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr
+        outs.append(open(out, "rb").read())
+    assert outs[0] == outs[1]
+    # more ranks than GPUs: the rank without a device fails, the launcher ends the others instead of hanging in the communicator
+    import torch
+    n = torch.cuda.device_count()
+    r = subprocess.run([cli, CORNELL, "--width", "64", "--height", "48", "--spp", "1", "--ranks", str(n + 1), "--out", str(tmp_path / "x.exr")],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+
+
 def test_material_edit_and_errors(gpu_tb, settings):
     from tracerboy_amd import api
     gpu_tb.LoadScene(CORNELL)
