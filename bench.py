@@ -390,12 +390,13 @@ def main():
             for _ in range(3):
                 tb.InvalidateHistory(); tb.Render(W3, H3, SPP3, s3, 0.0, sync=False)
             torch.cuda.synchronize(); dt3 = time.perf_counter() - t3
+            variant3 = ["matte", "env", "surf", "vol", "full", "sss"][tb.GetOption("last_variant")]
             avg3, frames3, st3 = measure_kernel(tb, api, np, W3, H3, SPP3, s3, 3)
             passes3, src3 = pmc_summary("c3")
             r3 = hbm_roofline(avg3, frames3, W3 * H3, st3, passes3, src3)
             r3.update({"workload": "proc0:870000 %dx%d %dspp depth%d" % (W3, H3, SPP3, D3), "triangles": int(info3.numTriangles), "value": round(W3 * H3 * SPP3 * 3 / dt3 / 1e6, 1),
                        "unit_value": "Msamples/s", "ms_per_step": round(dt3 / 3 * 1e3, 3), "steps": 3, "scene_load_s": round(load3, 2),
-                       "kernel_variant": ["matte", "env", "surf", "vol", "full", "sss"][tb.GetOption("last_variant")],
+                       "kernel_variant": variant3,
                        "note": "launches of 128 frames are batched by the sample-buffer budget: avg_launch_ms / frames_per_launch are per batch launch"})
             r3["pipes"] = derived_busy("c3", passes3)
             r3["what_limits_it"] = ("vector-memory issue: a CU's texture addresser takes ~17 cycles per wave-level load whatever the number of active lanes "
