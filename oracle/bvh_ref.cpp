@@ -336,6 +336,123 @@ static int64_t build_lbvh_impl(const float* positions, const uint32_t* triVertex
     return (int64_t)total;
 }
 
+/* ---- top level (two-level scenes) ---------------------------------------------------------------------------------------
+ * Serial restatement of the fallback layer's top-level build: TopLevelLoadAABBs.hlsli:62-105 (per instance: root box of its
+ * bottom-level structure, InverseAffineTransform of ObjectToWorld, TransformAABB, leaf node + BVHMetadata),
+ * CalculateSceneAABBFromBVHs.hlsl:16-41 (scene box from the stored centre / half-extent boxes), CalculateMortonCodesForAABBs.hlsl
+ * (code of the box centre), the same sort / BuildBVHSplits / ComputeAABBs passes as a bottom level; no treelet pass for
+ * Level::Top (GpuBVH2Builder.cpp:498-501).  mul(float3x4, float4) is pinned as one fma chain per row like everywhere in this build.
+ * instances: objectToWorld rows (12 floats each); rootBoxes: min xyz, max xyz of each instance's bottom-level root box. */
+namespace {
+float Determinant34(const float* t) /* RayTracingHelper.hlsli:287-295 */
+{
+#define M(r, c) t[(r) * 4 + (c)]
+    return M(0, 0) * M(1, 1) * M(2, 2) - M(0, 0) * M(2, 1) * M(1, 2) - M(1, 0) * M(0, 1) * M(2, 2) + M(1, 0) * M(2, 1) * M(0, 2) + M(2, 0) * M(0, 1) * M(1, 2) - M(2, 0) * M(1, 1) * M(0, 2);
+}
+void InverseAffine34(const float* t, float* o) /* RayTracingHelper.hlsli:297-316, term by term */
+{
+    const float invDet = 1.0f / Determinant34(t);
+#define O(r, c) o[(r) * 4 + (c)]
+    O(0, 0) = invDet * (M(1, 1) * (M(2, 2) * 1.0f - 0.0f * M(2, 3)) + M(2, 1) * (0.0f * M(1, 3) - M(1, 2) * 1.0f) + 0.0f * (M(1, 2) * M(2, 3) - M(2, 2) * M(1, 3)));
+    O(1, 0) = invDet * (M(1, 2) * (M(2, 0) * 1.0f - 0.0f * M(2, 3)) + M(2, 2) * (0.0f * M(1, 3) - M(1, 0) * 1.0f) + 0.0f * (M(1, 0) * M(2, 3) - M(2, 0) * M(1, 3)));
+    O(2, 0) = invDet * (M(1, 3) * (M(2, 0) * 0.0f - 0.0f * M(2, 1)) + M(2, 3) * (0.0f * M(1, 1) - M(1, 0) * 0.0f) + 1.0f * (M(1, 0) * M(2, 1) - M(2, 0) * M(1, 1)));
+    O(0, 1) = invDet * (M(2, 1) * (M(0, 2) * 1.0f - 0.0f * M(0, 3)) + 0.0f * (M(2, 2) * M(0, 3) - M(0, 2) * M(2, 3)) + M(0, 1) * (0.0f * M(2, 3) - M(2, 2) * 1.0f));
+    O(1, 1) = invDet * (M(2, 2) * (M(0, 0) * 1.0f - 0.0f * M(0, 3)) + 0.0f * (M(2, 0) * M(0, 3) - M(0, 0) * M(2, 3)) + M(0, 2) * (0.0f * M(2, 3) - M(2, 0) * 1.0f));
+    O(2, 1) = invDet * (M(2, 3) * (M(0, 0) * 0.0f - 0.0f * M(0, 1)) + 1.0f * (M(2, 0) * M(0, 1) - M(0, 0) * M(2, 1)) + M(0, 3) * (0.0f * M(2, 1) - M(2, 0) * 0.0f));
+    O(0, 2) = invDet * (0.0f * (M(0, 2) * M(1, 3) - M(1, 2) * M(0, 3)) + M(0, 1) * (M(1, 2) * 1.0f - 0.0f * M(1, 3)) + M(1, 1) * (0.0f * M(0, 3) - M(0, 2) * 1.0f));
+    O(1, 2) = invDet * (0.0f * (M(0, 0) * M(1, 3) - M(1, 0) * M(0, 3)) + M(0, 2) * (M(1, 0) * 1.0f - 0.0f * M(1, 3)) + M(1, 2) * (0.0f * M(0, 3) - M(0, 0) * 1.0f));
+    O(2, 2) = invDet * (1.0f * (M(0, 0) * M(1, 1) - M(1, 0) * M(0, 1)) + M(0, 3) * (M(1, 0) * 0.0f - 0.0f * M(1, 1)) + M(1, 3) * (0.0f * M(0, 1) - M(0, 0) * 0.0f));
+    O(0, 3) = invDet * (M(0, 1) * (M(2, 2) * M(1, 3) - M(1, 2) * M(2, 3)) + M(1, 1) * (M(0, 2) * M(2, 3) - M(2, 2) * M(0, 3)) + M(2, 1) * (M(1, 2) * M(0, 3) - M(0, 2) * M(1, 3)));
+    O(1, 3) = invDet * (M(0, 2) * (M(2, 0) * M(1, 3) - M(1, 0) * M(2, 3)) + M(1, 2) * (M(0, 0) * M(2, 3) - M(2, 0) * M(0, 3)) + M(2, 2) * (M(1, 0) * M(0, 3) - M(0, 0) * M(1, 3)));
+    O(2, 3) = invDet * (M(0, 3) * (M(2, 0) * M(1, 1) - M(1, 0) * M(2, 1)) + M(1, 3) * (M(0, 0) * M(2, 1) - M(2, 0) * M(0, 1)) + M(2, 3) * (M(1, 0) * M(0, 1) - M(0, 0) * M(1, 1)));
+#undef O
+#undef M
+}
+inline tb3 MulPoint(const float* m, tb3 v)
+{
+    return tb3_make(tb_fma(m[2], v.z, tb_fma(m[1], v.y, tb_fma(m[0], v.x, m[3]))), tb_fma(m[6], v.z, tb_fma(m[5], v.y, tb_fma(m[4], v.x, m[7]))),
+                    tb_fma(m[10], v.z, tb_fma(m[9], v.y, tb_fma(m[8], v.x, m[11]))));
+}
+} // namespace
+
+extern "C" int64_t tbo_build_tlas(const float* objectToWorld, const float* rootBoxes, const uint32_t* blasIndex, const uint32_t* hitGroupBase,
+                                  uint32_t M, uint8_t* out, uint64_t capacity)
+{
+    if (M == 0) return -1;
+    const uint64_t numNodes = 2ull * M - 1, offBoxes = 16, offMeta = offBoxes + 32 * numNodes, total = offMeta + 116ull * M;
+    if (total > capacity) return -2;
+    std::vector<Box> leaf(M);
+    std::vector<float> w2o(12ull * M);
+    for (uint32_t i = 0; i < M; i++) {
+        const float* o2w = objectToWorld + 12ull * i;
+        InverseAffine34(o2w, &w2o[12ull * i]);
+        const tb3 mn = tb3_make(rootBoxes[6 * i], rootBoxes[6 * i + 1], rootBoxes[6 * i + 2]), mx = tb3_make(rootBoxes[6 * i + 3], rootBoxes[6 * i + 4], rootBoxes[6 * i + 5]);
+        /* TransformAABB :318-344: the eight corners in the order of the listing (the min / max of a set does not depend on it) */
+        const tb3 corner[8] = {mn, tb3_make(mn.x, mn.y, mx.z), tb3_make(mn.x, mx.y, mx.z), tb3_make(mn.x, mx.y, mn.z), tb3_make(mx.x, mn.y, mn.z),
+                               tb3_make(mx.x, mx.y, mn.z), tb3_make(mx.x, mn.y, mx.z), mx};
+        tb3 tmn = tb3_splat(3.402823466e+38f), tmx = tb3_splat(-3.402823466e+38f);
+        for (int k = 0; k < 8; k++) { const tb3 v = MulPoint(o2w, corner[k]); tmn = tb3_min(tmn, v); tmx = tb3_max(tmx, v); }
+        leaf[i] = AABBtoBox(tmn, tmx);
+    }
+    tb3 smin = tb3_splat(3.402823466e+38f), smax = tb3_splat(-3.402823466e+38f);
+    for (uint32_t i = 0; i < M; i++) { smin = tb3_min(leaf[i].center - leaf[i].halfDim, smin); smax = tb3_max(leaf[i].center + leaf[i].halfDim, smax); }
+    const tb3 dim = tb3_max(smax - smin, tb3_splat(0.00001f));
+    std::vector<std::pair<uint32_t, uint32_t>> keyed(M);
+    for (uint32_t i = 0; i < M; i++) keyed[i] = std::make_pair(MortonFromUnit((leaf[i].center - smin) / dim), i);
+    std::sort(keyed.begin(), keyed.end());
+    Builder b; b.n = M; b.codes.resize(M);
+    for (uint32_t i = 0; i < M; i++) b.codes[i] = keyed[i].first;
+    std::vector<uint32_t> left(M > 1 ? M - 1 : 0), right(M > 1 ? M - 1 : 0);
+    for (int64_t idx = 0; idx + 1 < (int64_t)M; idx++) { /* BuildBVHSplits.hlsli:56-131, as in build_lbvh_impl */
+        int d = b.lcp(idx, idx + 1) - b.lcp(idx, idx - 1);
+        d = d < -1 ? -1 : (d > 1 ? 1 : d);
+        const int minPrefix = b.lcp(idx, idx - d);
+        int64_t maxLength = 2;
+        while (b.lcp(idx, idx + maxLength * d) > minPrefix) maxLength *= 4;
+        int64_t length = 0;
+        for (int64_t t = maxLength / 2; t > 0; t /= 2) if (b.lcp(idx, idx + (length + t) * d) > minPrefix) length = length + t;
+        const int64_t j = idx + length * d, first = std::min(idx, j), last = std::max(idx, j);
+        const int commonPrefix = b.lcp(first, last);
+        int64_t split = first, step = last - first;
+        do { step = (step + 1) >> 1; const int64_t ns = split + step; if (ns < last && b.lcp(first, ns) > commonPrefix) split = ns; } while (step > 1);
+        left[(size_t)idx] = (split == first) ? (M - 1) + (uint32_t)split : (uint32_t)split;
+        right[(size_t)idx] = (split + 1 == last) ? (M - 1) + (uint32_t)split + 1 : (uint32_t)split + 1;
+    }
+    memset(out, 0, (size_t)total);
+    const TbBvhHeader hdr = {(uint32_t)offBoxes, (uint32_t)offMeta, (uint32_t)offMeta, (uint32_t)total};
+    memcpy(out, &hdr, 16);
+    TbAabbNode* nodes = (TbAabbNode*)(out + offBoxes);
+    for (uint32_t k = 0; k < M; k++) { /* BVHMetadata of sorted leaf k (TopLevelLoadAABBs.hlsli:94-104) */
+        const uint32_t i = keyed[k].second;
+        TbBvhMetadata md; memset(&md, 0, sizeof md);
+        memcpy(md.WorldToObject, &w2o[12ull * i], 48); memcpy(md.ObjectToWorld, objectToWorld + 12ull * i, 48);
+        md.InstanceIDAndMask = 1u << 24; md.InstanceContributionToHitGroupIndexAndFlags = hitGroupBase[i] & 0x00ffffffu;
+        md.BlasIndex = blasIndex[i]; md.InstanceIndex = i;
+        memcpy(out + offMeta + 116ull * k, &md, 116);
+    }
+    std::vector<uint32_t> count((size_t)numNodes, 0), order; order.reserve((size_t)numNodes);
+    { std::vector<uint32_t> st; st.push_back(0);
+      while (!st.empty()) { uint32_t x = st.back(); st.pop_back(); order.push_back(x); if (M > 1 && x < M - 1) { st.push_back(left[x]); st.push_back(right[x]); } }
+      std::reverse(order.begin(), order.end()); }
+    auto writeNode = [&](uint32_t idx, const Box& bx, uint32_t fx, uint32_t fy) {
+        TbAabbNode nd; nd.center[0] = bx.center.x; nd.center[1] = bx.center.y; nd.center[2] = bx.center.z; nd.flags = fx;
+        nd.halfDim[0] = bx.halfDim.x; nd.halfDim[1] = bx.halfDim.y; nd.halfDim[2] = bx.halfDim.z; nd.rightNodeIndex = fy; nodes[idx] = nd;
+    };
+    auto readBox = [&](uint32_t idx) { Box bx; bx.center = tb3_make(nodes[idx].center[0], nodes[idx].center[1], nodes[idx].center[2]);
+                                        bx.halfDim = tb3_make(nodes[idx].halfDim[0], nodes[idx].halfDim[1], nodes[idx].halfDim[2]); return bx; };
+    for (uint32_t x : order) {
+        if (x >= M - 1) { const uint32_t k = x - (M - 1); writeNode(x, leaf[keyed[k].second], k | TB_BVH_LEAF_FLAG, 1); count[x] = 1; } /* TopLevelComputeAABBs.hlsl:16-33 */
+        else {
+            uint32_t l = left[x], r = right[x];
+            if (count[l] > count[r]) { uint32_t t = l; l = r; r = t; }
+            const Box lb = readBox(l), rb = readBox(r);
+            writeNode(x, AABBtoBox(tb3_min(lb.center - lb.halfDim, rb.center - rb.halfDim), tb3_max(lb.center + lb.halfDim, rb.center + rb.halfDim)), l & TB_BVH_INDEX_MASK, r);
+            count[x] = count[l] + count[r];
+        }
+    }
+    return (int64_t)total;
+}
+
 extern "C" int64_t tbo_build_lbvh(const float* positions, const uint32_t* triVertexIndex, const uint32_t* triGeometry,
                                   const uint32_t* triPrimitive, const uint32_t* triFlags, uint32_t N, uint8_t* out, uint64_t capacity)
 {

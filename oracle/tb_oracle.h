@@ -69,6 +69,9 @@ void tbo_composite(uint32_t W, uint32_t H, const float* albedo, const float* lig
 /* IsValidHit alpha test on candidate hits of non-opaque geometry (off by default, like the reference's software path) */
 void tbo_set_alpha_test(int enabled);
 
+/* serial restatement of the fallback layer's top-level build (oracle/bvh_ref.cpp); returns the image size or < 0 */
+int64_t tbo_build_tlas(const float* objectToWorld /* 12 per instance */, const float* rootBoxes /* min xyz, max xyz per instance */, const uint32_t* blasIndex,
+                       const uint32_t* hitGroupBase, uint32_t numInstances, uint8_t* out, uint64_t capacity);
 float tbo_math(int fn, float a, float b); /* 0 sin 1 cos 2 acos 3 atan2 4 exp 5 log 6 pow 7 sqrt 8 exp2 9 log2 10 asin */
 void tbo_math_array(int fn, uint32_t n, const float* a, const float* b /* nullable */, float* out); /* + 14 min 15 max 16 frac 17 floor 18 rcp */
 void tbo_camera_ray(const TbPerFrameConstants* constants, float lensHeight, uint32_t width, uint32_t height,

@@ -63,6 +63,8 @@ def lib():
         L.tbo_build_lbvh.argtypes = [vp, vp, vp, vp, vp, C.c_uint32, vp, C.c_uint64]
         L.tbo_build_lbvh2.restype = C.c_int64
         L.tbo_build_lbvh2.argtypes = [vp, vp, vp, vp, vp, C.c_uint32, C.c_uint32, vp, C.c_uint64]
+        L.tbo_build_tlas.restype = C.c_int64
+        L.tbo_build_tlas.argtypes = [vp, vp, vp, vp, C.c_uint32, vp, C.c_uint64]
         L.tbo_validate_bvh.restype = C.c_int
         L.tbo_validate_bvh.argtypes = [vp, C.c_uint32, vp, vp, C.c_uint32, C.POINTER(C.c_uint32)]
         _lib = L
@@ -161,6 +163,17 @@ def build_lbvh(tri, treelet_passes=0):
     pos = np.ascontiguousarray(tri["positions"], np.float32); tvi = np.ascontiguousarray(tri["tri_vertex_index"], np.uint32)
     g = np.ascontiguousarray(tri["tri_geometry"], np.uint32); p = np.ascontiguousarray(tri["tri_primitive"], np.uint32); f = np.ascontiguousarray(tri["tri_flags"], np.uint32)
     got = lib().tbo_build_lbvh2(_p(pos), _p(tvi), _p(g), _p(p), _p(f), n, treelet_passes, _p(out), cap)
+    assert got == cap, got
+    return out
+
+
+def build_tlas(object_to_world, root_boxes, blas_index, hit_group_base):
+    """Oracle restatement of the top-level build: (M, 12) ObjectToWorld rows, (M, 6) bottom-level root boxes (min, max)."""
+    o2w = np.ascontiguousarray(object_to_world, np.float32); rb = np.ascontiguousarray(root_boxes, np.float32)
+    bi = np.ascontiguousarray(blas_index, np.uint32); hb = np.ascontiguousarray(hit_group_base, np.uint32)
+    m = o2w.shape[0]; cap = 16 + 32 * (2 * m - 1) + 116 * m
+    out = np.zeros(cap, np.uint8)
+    got = lib().tbo_build_tlas(_p(o2w), _p(rb), _p(bi), _p(hb), m, _p(out), cap)
     assert got == cap, got
     return out
 

@@ -732,6 +732,37 @@ def test_config_c4_c5_4k_scenes(gpu_tb, settings, cfg):
     assert np.array_equal(bits(mine[owned]), bits(full[owned]))
 
 
+@pytest.mark.parametrize("order", [0, 1, 3, 4, 5])
+def test_node_orders_and_banded_items_do_not_change_the_picture(gpu_tb, settings, order):
+    """Storage order of the layout-B nodes (option node_order: breadth-first, depth-first, van-Emde-Boas blocks, sibling pairs
+    with padding nodes) and the XCD-banded work-item lists of frame-group launches (banded_items) only move data and work around:
+    same bits as the default layout, which test_full_size_* compare with the oracle."""
+    W, H, F = 200, 120, 9
+    s = copy.copy(settings); s.MaxBounces = 5
+    gpu_tb.SetOption("bvh_builder", 1)
+    try:
+        gpu_tb.LoadProcedural(0, 30000, 11)
+        gpu_tb.Render(W, H, F, s, 0.0); ref = gpu_tb.ReadAccumulation()
+        nodes_default = gpu_tb.SceneInfo().bvhNodesB
+        gpu_tb.SetOption("node_order", order); gpu_tb.SetOption("banded_items", 1)
+        gpu_tb.LoadProcedural(0, 30000, 11)
+        if order in (4, 5): assert gpu_tb.SceneInfo().bvhNodesB >= nodes_default      # padding nodes keep sibling pairs in one 128-B line
+        gpu_tb.Render(W, H, F, s, 0.0)
+        assert np.array_equal(bits(gpu_tb.ReadAccumulation()), bits(ref))
+    finally:
+        gpu_tb.SetOption("node_order", 2); gpu_tb.SetOption("banded_items", 0); gpu_tb.SetOption("bvh_builder", 0)
+    assert np.array_equal(bits(ref), bits(_oracle_after_reload(gpu_tb, W, H, F, s)))
+
+
+def _oracle_after_reload(gpu_tb, W, H, F, s):
+    gpu_tb.SetOption("bvh_builder", 1)
+    try:
+        gpu_tb.LoadProcedural(0, 30000, 11)
+    finally:
+        gpu_tb.SetOption("bvh_builder", 0)
+    return _oracle(gpu_tb, W, H, F, s)["output"]
+
+
 def test_headless_cli_native_rccl_gather_plumbing(tmp_path):
     """tracerboy-hip --ranks N gathers the ranks' packed tiles with librccl (dlopen; ncclGroupStart / Recv / Send / GroupEnd on the
     context's stream) and un-permutes them on the device into rank 0's accumulation surface.  One GPU here: TB_CLI_FORCE_RCCL=1

@@ -78,9 +78,58 @@ def test_two_level_structure(built):
         l, r = fx[n] & 0xFFFFFF, fy[n]
         lo = np.minimum(c[l] - h[l], c[r] - h[r]); hi = np.maximum(c[l] + h[l], c[r] + h[r])
         assert np.allclose(c[n] - h[n], lo, atol=1e-5) and np.allclose(c[n] + h[n], hi, atol=1e-5)
-    # every bottom-level image passes the reference validator's invariants on its own triangles
     tri = hs.triangles()
     assert tri["tri_geometry"].max() == 2                                      # geometry index INSIDE a structure
+    # the whole top-level image equals the oracle's serial restatement of the fallback layer's top-level build, byte for byte
+    by_instance = sorted(md, key=lambda m: m.InstanceIndex)
+    roots = []
+    for m in by_instance:
+        bc, _, bh, _ = _aabb_nodes(bvh[offs[m.BlasIndex]:offs[m.BlasIndex + 1]])
+        roots.append(np.concatenate([bc[0] - bh[0], bc[0] + bh[0]]))
+    ref = ol.build_tlas(np.array([m.ObjectToWorld[:] for m in by_instance], np.float32), np.array(roots, np.float32),
+                        [m.BlasIndex for m in by_instance], [m.InstanceContributionToHitGroupIndexAndFlags & 0xFFFFFF for m in by_instance])
+    assert ref.tobytes() == tl
+
+
+def test_many_instances_top_level_equals_oracle_build(built, tmp_path):
+    """300 instances with random rotations, non-uniform scales and translations (duplicate Morton codes included): the host's
+    top-level image is the oracle restatement's bytes, and two-level closest hits agree with the flattened scene's."""
+    from tracerboy_amd import api
+    rng = np.random.default_rng(17)
+    lines = ['LookAt 0 6 30  0 0 0  0 1 0', 'Camera "perspective" "float fov" [40]', 'Film "image" "integer xresolution" [64] "integer yresolution" [48]', 'WorldBegin',
+             'MakeNamedMaterial "A" "string type" ["matte"] "rgb Kd" [0.6 0.5 0.4]', 'NamedMaterial "A"', 'ObjectBegin "tet"',
+             'Shape "trianglemesh" "integer indices" [0 1 2 0 1 3 1 2 3 0 2 3] "point P" [0 0 0  1 0 0  0.5 0 0.9  0.5 0.8 0.3]', 'ObjectEnd',
+             'AttributeBegin', 'AreaLightSource "diffuse" "rgb L" [5 5 5]',
+             'Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-3 12 -3 3 12 -3 3 12 3 -3 12 3]', 'AttributeEnd']
+    for k in range(300):
+        t = rng.uniform(-8, 8, 3) if k % 7 else np.array([1.0, 2.0, 3.0])          # every seventh instance sits at the same place
+        ax = rng.normal(size=3); ax /= np.linalg.norm(ax)
+        sc = rng.uniform(0.4, 2.0, 3)
+        lines += ['AttributeBegin', 'Translate %.6f %.6f %.6f' % tuple(t), 'Rotate %.4f %.6f %.6f %.6f' % ((rng.uniform(0, 360),) + tuple(ax)),
+                  'Scale %.6f %.6f %.6f' % tuple(sc), 'ObjectInstance "tet"', 'AttributeEnd']
+    lines.append('WorldEnd')
+    path = tmp_path / "many.pbrt"; path.write_text("\n".join(lines))
+    two = api.HostScene(str(path), flatten_instances=False); flat = api.HostScene(str(path), flatten_instances=True)
+    v = two.view()
+    assert v.numInstances == 301 and v.numBlas == 2
+    tl = C.string_at(v.tlas, v.tlasBytes); bvh = C.string_at(v.bvh, v.bvhBytes)
+    offs = [v.blasOffsets[k] for k in range(v.numBlas + 1)]
+    off_meta = int(np.frombuffer(tl, np.uint32, 1, 4)[0])
+    md = sorted((abi.TbBvhMetadata.from_buffer_copy(tl, off_meta + 116 * k) for k in range(v.numInstances)), key=lambda m: m.InstanceIndex)
+    roots = []
+    for m in md:
+        bc, _, bh, _ = _aabb_nodes(bvh[offs[m.BlasIndex]:offs[m.BlasIndex + 1]])
+        roots.append(np.concatenate([bc[0] - bh[0], bc[0] + bh[0]]))
+    ref = ol.build_tlas(np.array([m.ObjectToWorld[:] for m in md], np.float32), np.array(roots, np.float32), [m.BlasIndex for m in md],
+                        [m.InstanceContributionToHitGroupIndexAndFlags & 0xFFFFFF for m in md])
+    assert ref.tobytes() == tl
+    o = rng.uniform(-12, 12, (5000, 3)).astype(np.float32)
+    d = (rng.uniform(-8, 8, (5000, 3)) - o).astype(np.float32); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    a, b = ol.trace_closest(v, o, d), ol.trace_closest(flat.view(), o, d)
+    both = (a["t"] > 0) & (b["t"] > 0)
+    assert both.sum() > 1000 and (a["t"] > 0).sum() - both.sum() < 5 and (b["t"] > 0).sum() - both.sum() < 5   # grazing rays may differ by rounding
+    close = np.isclose(a["t"][both], b["t"][both], rtol=1e-4)
+    assert close.mean() > 0.995
 
 
 def test_two_level_oracle_agrees_with_flattened_oracle(built, settings):
