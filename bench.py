@@ -405,7 +405,7 @@ def main():
             load(args.scene)   # back to the timed workload for the CPU baseline below
 
         # ---- CPU baseline: the scalar oracle on a bounded sample of the same workload ------------------
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only
             import oracle_lib as ol
             cores = len(os.sched_getaffinity(0))      # the CPUs this process may run on, not the machine's
             view = tb.HostSceneView(); pf = tb.FrameConstants(W, H, 0, s, 0.0)
