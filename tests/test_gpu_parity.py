@@ -543,6 +543,29 @@ def test_frame_group_mode_bit_exact(gpu_tb, settings, group):
     assert np.array_equal(bits(jit), bits(ref["jittered"]))
 
 
+def test_frame_group_many_frames_small_image(gpu_tb, settings):
+    """Maximum-size edge of the frame-group launch: thousands of frames of a tiny image with frame_group forced to 1 would need
+    more frame groups per region than a claimed work item can name (group << 20 | region, 12 bits): the host widens the groups.
+    5 000 frames of a 24x20 image (one full and one ragged 16x16 region per row) against the one-pixel-per-lane kernel, bit for bit,
+    and the weights count every frame."""
+    gpu_tb.LoadScene(CORNELL)
+    W, H, F = 24, 20, 5000
+    s = copy.copy(settings); s.MaxBounces = 3
+    gpu_tb.SetOption("frame_group", 1)
+    try:
+        gpu_tb.InvalidateHistory(); gpu_tb.Render(W, H, F, s, 0.0)
+        groups, groups_jit = gpu_tb.ReadAccumulation(jittered=True)
+    finally:
+        gpu_tb.SetOption("frame_group", -1)
+    try:
+        gpu_tb.InvalidateHistory(); gpu_tb.Render(W, H, F, s, 0.0)
+        classic, classic_jit = gpu_tb.ReadAccumulation(jittered=True)
+    finally:
+        gpu_tb.SetOption("frame_group", 0)
+    assert np.all(groups[..., 3] == float(F))
+    assert np.array_equal(bits(groups), bits(classic)) and np.array_equal(bits(groups_jit), bits(classic_jit))
+
+
 def test_frame_group_default_and_classic_agree(gpu_tb, settings):
     """A call of 8 or more frames takes the frame-group mode by itself (lanes draw (pixel, frame) pairs of their region from an
     LDS counter); frame_group = -1 keeps the one-pixel-per-lane kernel.  Both are the oracle's bits, on a frame whose last
