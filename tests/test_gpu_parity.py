@@ -810,6 +810,29 @@ def test_headless_cli_native_rccl_gather_plumbing(tmp_path):
     assert r.returncode != 0
 
 
+@pytest.mark.parametrize("cfg", ["c4_256spp", "c5_1024spp"])
+def test_config_c4_c5_full_sample_counts(gpu_tb, settings, cfg):
+    """BASELINE.json configs[3] / [4] at their FULL sample counts on one GPU: 3840x2160 x 256 spp (depth 6, 0.7 M triangles with
+    glass) and x 1024 spp (depth 16, 2.98 M triangles, 40 materials) -- 2.1 and 8.5 G samples through the frame-group launches in
+    batches of the sample-buffer budget.  Size-independent properties over the whole frame (every weight counts the frames, no NaN,
+    nothing negative) and one full row of the picture against the oracle at the same sample count, bit for bit."""
+    W, H = 3840, 2160
+    s = copy.copy(settings)
+    gpu_tb.SetOption("bvh_builder", 4)
+    try:
+        if cfg == "c4_256spp": gpu_tb.LoadProcedural(1, 700000, 1234); s.MaxBounces = 6; F = 256
+        else: gpu_tb.LoadProcedural(2, 2980000, 1234); s.MaxBounces = 16; F = 1024
+    finally:
+        gpu_tb.SetOption("bvh_builder", 0)
+    gpu_tb.InvalidateHistory(); gpu_tb.Render(W, H, F, s, 0.0)
+    assert gpu_tb.GetNumberOfSamplesSinceLastInvalidate() == F
+    out = gpu_tb.ReadAccumulation()
+    assert np.all(out[..., 3] == float(F)) and not np.isnan(out).any() and (out[..., :3] >= 0).all()
+    y = 1203
+    ref = ol.render(gpu_tb.HostSceneView(), gpu_tb.FrameConstants(W, H, 0, s, 0.0), W, H, F, y0=y, y1=y + 1, threads=1)["output"]
+    assert np.array_equal(bits(out[y]), bits(ref[y]))
+
+
 def test_material_edit_and_errors(gpu_tb, settings):
     from tracerboy_amd import api
     gpu_tb.LoadScene(CORNELL)
