@@ -13,7 +13,7 @@ def main():
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "k.s")
         cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-I" + os.path.join(ROOT, "include"),
-               "--offload-arch=gfx950", "-S", "--cuda-device-only", "-o", out, src]
+               "--offload-arch=gfx950", "-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-S", "--cuda-device-only", "-o", out, src]
         subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
         text = open(out).read()
     meta = text[text.index("amdhsa.kernels:"):]

@@ -23,7 +23,11 @@ ARCH = os.environ.get("TB_ARCH", "gfx950")  # e.g. gfx950:xnack- for experiments
 
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function",
           "-Wno-unused-variable", "-Wno-unused-but-set-variable", "-I" + os.path.join(REPO, "include")] + os.environ.get("TB_EXTRA_FLAGS", "").split()
-DEVICE = ["--offload-arch=" + ARCH]
+# Kernel TUs: no SLP vectorisation (the packed fp32 math is written out where it pays -- v_pk_fma_f32 in the box test; what the SLP
+# pass adds on top are v_pk_add / v_pk_mul pairs with v_mov shuffles around them, at 3.3 cycles against 2 x 2.0) and the max-ILP
+# machine scheduler.  Measured on MI355X (scripts/ab_flags.sh): cornell-box 6 894 -> 7 054, 870 k scene 4 106 -> 4 247, bistro-class 4K
+# 1 171 -> 1 213 Msamples/s; neither changes a result bit (-ffp-contract=off pins the arithmetic, tests/ -m gpu).
+DEVICE = ["--offload-arch=" + ARCH, "-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]
 
 HOST_SRCS = ["host/pbrt_loader.cpp", "host/pbf_loader.cpp", "host/host_scene.cpp", "host/images.cpp", "host/image_decode.cpp", "host/bvh_build.cpp", "host/procedural.cpp", "host/context.cpp", "host/pbrt_dump.cpp"]
 KERNEL_SRCS = ["kernels/pt_kernels.hip", "kernels/post_kernels.hip", "kernels/bvh_kernels.hip", "kernels/rt_kernels.hip", "kernels/pt_variant_matte.hip", "kernels/pt_variant_matte5.hip", "kernels/pt_variant_env.hip", "kernels/pt_variant_env5.hip", "kernels/pt_variant_surf.hip",
