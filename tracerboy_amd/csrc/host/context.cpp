@@ -53,13 +53,25 @@ std::string g_createError;
  * has room for that many workgroups per CU -- otherwise its spills would buy no residency.  Searched in order: the first feature
  * set that covers what scene + settings need.  id: what option "last_variant" reports (stable across insertions).
  * wf: the wavefront pipeline's launcher of the feature set (pipeline 2; none for the full set); pooled: pipeline 3 exists. */
+#ifndef TB_MATTE_WAVES
+#define TB_MATTE_WAVES 5
+#endif
+#ifndef TB_ENV_WAVES
+#define TB_ENV_WAVES 6
+#endif
+#ifndef TB_SSS_WAVES
+#define TB_SSS_WAVES 5
+#endif
+#ifndef TB_VOL_WAVES
+#define TB_VOL_WAVES 5
+#endif
 struct Variant { uint32_t features; pt_variant_fn fn; const char* name; pt_variant_fn fnHi; uint32_t wavesHi; int id; wf_variant_fn wf; bool pooled; };
 const Variant kVariants[] = {
-    {0u, pt_launch_persistent_matte, "matte", pt_launch_persistent_matte5, 5, 0, wf_launch_matte, true},
-        {PT_FEAT_ENV, pt_launch_persistent_env, "env", pt_launch_persistent_env5, 6, 1, wf_launch_env, true},
+    {0u, pt_launch_persistent_matte, "matte", pt_launch_persistent_matte5, TB_MATTE_WAVES, 0, wf_launch_matte, true},
+        {PT_FEAT_ENV, pt_launch_persistent_env, "env", pt_launch_persistent_env5, TB_ENV_WAVES, 1, wf_launch_env, true},
     {PT_FEAT_ENV | PT_FEAT_SPECULAR | PT_FEAT_TEXTURES, pt_launch_persistent_surf, "surf", nullptr, 0, 2, wf_launch_surf, true},
-        {PT_FEAT_ENV | PT_FEAT_SPECULAR | PT_FEAT_TEXTURES | PT_FEAT_SSS, pt_launch_persistent_sss, "sss", pt_launch_persistent_sss4, 4, 5, wf_launch_sss, false},
-    {PT_FEAT_ENV | PT_FEAT_SPECULAR | PT_FEAT_TEXTURES | PT_FEAT_SSS | PT_FEAT_MIX, pt_launch_persistent_vol, "vol", pt_launch_persistent_vol4, 4, 3, wf_launch_vol, false},
+        {PT_FEAT_ENV | PT_FEAT_SPECULAR | PT_FEAT_TEXTURES | PT_FEAT_SSS, pt_launch_persistent_sss, "sss", pt_launch_persistent_sss4, TB_SSS_WAVES, 5, wf_launch_sss, false},
+    {PT_FEAT_ENV | PT_FEAT_SPECULAR | PT_FEAT_TEXTURES | PT_FEAT_SSS | PT_FEAT_MIX, pt_launch_persistent_vol, "vol", pt_launch_persistent_vol4, TB_VOL_WAVES, 3, wf_launch_vol, false},
         {PT_FEAT_ALL, pt_launch_persistent_full, "full", nullptr, 0, 4, nullptr, false},
 };
 constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));

@@ -7,5 +7,8 @@
 #define PT_NAME env5
 #define PT_COUNT 0
 #define PT_ONLY_PERSISTENT 1
-#define PT_PERSISTENT_ATTR __attribute__((amdgpu_waves_per_eu(6))) /* keep in step with kVariants[].wavesHi, context.cpp */
+#ifndef TB_ENV_WAVES
+#define TB_ENV_WAVES 6 /* experiments: -DTB_ENV_WAVES=n (scripts/ab_flags.sh); context.cpp reads the same macro */
+#endif
+#define PT_PERSISTENT_ATTR __attribute__((amdgpu_waves_per_eu(TB_ENV_WAVES))) /* keep in step with kVariants[].wavesHi, context.cpp */
 #include "pt_variant.inc"

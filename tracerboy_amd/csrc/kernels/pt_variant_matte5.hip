@@ -5,5 +5,8 @@
 #define PT_NAME matte5
 #define PT_COUNT 0
 #define PT_ONLY_PERSISTENT 1
-#define PT_PERSISTENT_ATTR __attribute__((amdgpu_waves_per_eu(5))) /* keep in step with kVariants[].wavesHi, context.cpp */
+#ifndef TB_MATTE_WAVES
+#define TB_MATTE_WAVES 5 /* experiments: -DTB_MATTE_WAVES=n (scripts/ab_flags.sh); context.cpp reads the same macro */
+#endif
+#define PT_PERSISTENT_ATTR __attribute__((amdgpu_waves_per_eu(TB_MATTE_WAVES))) /* keep in step with kVariants[].wavesHi, context.cpp */
 #include "pt_variant.inc"
