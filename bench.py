@@ -215,10 +215,19 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path is HIP-only (no CPU fallback)")
+    # Test hooks for boxes with fewer GPUs than ranks (tests/test_gpu_parity.py): TB_BENCH_SHARE_DEVICE=1 puts every rank on device 0,
+    # TB_BENCH_BACKEND=gloo moves the gather through host memory (RCCL refuses two ranks on one device).  Everything else of the
+    # N > 1 step -- own-tiles launch, pack, one gather per render, device-side un-permute, the assembled-frame check -- is the real code.
+    backend = os.environ.get("TB_BENCH_BACKEND", "nccl")
+    if os.environ.get("TB_BENCH_SHARE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     W, H, SPP = args.width, args.height, args.spp
     s = api.GetDefaultOutputSettings()
@@ -268,6 +277,15 @@ def main():
     lib_stream = torch.cuda.ExternalStream(tb.Stream()) if pipelined else None
 
     def exchange(buf):
+        if world > 1 and backend != "nccl":      # test hook: the same collective through host memory, synchronously
+            torch.cuda.current_stream().synchronize()
+            host = buf.cpu()
+            parts = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
+            dist.gather(host, parts, dst=0)
+            if rank == 0:
+                gathered.copy_(torch.stack(parts))
+                tb.UnpackGatheredTo(gathered.data_ptr(), capacity, W, H, world, TILE, TILE, frame.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+            return None
         if world > 1:
             work = dist.gather(buf, gather_list if rank == 0 else None, dst=0, async_op=True)
             if rank == 0:
@@ -315,7 +333,7 @@ def main():
     if pipelined or not args.sync_steps:
         tb.Sync(); kernel_ms.append(tb.GetOption("last_kernel_us") / 1e3)   # HIP events of the last render of the timed region
     if world > 1:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX); elapsed = float(t.item())
+        t = torch.tensor([elapsed], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX); elapsed = float(t.item())
 
     samples_per_step = W * H * SPP
     value = samples_per_step * args.steps / elapsed / 1e6

@@ -786,6 +786,26 @@ def _oracle_after_reload(gpu_tb, W, H, F, s):
     return _oracle(gpu_tb, W, H, F, s)["output"]
 
 
+def test_bench_multi_rank_step_on_one_gpu(tmp_path):
+    """bench.py --gpus 2 as the driver types it, on a one-GPU box: both ranks share device 0 and the gather goes through host memory
+    (TB_BENCH_SHARE_DEVICE / TB_BENCH_BACKEND=gloo; RCCL refuses two ranks on one device) -- everything else is the real N > 1 step:
+    self-spawn, own-tiles launches, pack, one gather per render, device-side un-permute.  The line must say n_gpus = 2 and that the
+    frame rank 0 assembled equals a single-GPU render of the whole frame, bit for bit."""
+    import json, subprocess, sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(TB_BENCH_SHARE_DEVICE="1", TB_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--width", "712", "--height", "400", "--spp", "6",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "tiles2" and out["config"]["tile"] == 64
+    assert out["config"]["assembled_frame_equals_single_gpu"] is True
+    assert out["value"] > 0 and out["scaling"] == "strong"
+
+
 def test_headless_cli_native_rccl_gather_plumbing(tmp_path):
     """tracerboy-hip --ranks N gathers the ranks' packed tiles with librccl (dlopen; ncclGroupStart / Recv / Send / GroupEnd on the
     context's stream) and un-permutes them on the device into rank 0's accumulation surface.  One GPU here: TB_CLI_FORCE_RCCL=1
