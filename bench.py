@@ -53,6 +53,7 @@ def parse_args(argv=None):
     ap.add_argument("--pipeline", type=int, default=0)  # 0 = lock-step bounce (fastest measured), 1 = streaming, 2 = wavefront queues, 3 = pooled
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=INT")  # extra tb_set_option()s, applied before the scene is loaded
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-readback", action="store_true")   # skip the PCIe-inclusive side measurement
     ap.add_argument("--no-c3", action="store_true")         # skip the second roofline object (configs[2] at 128 spp)
     ap.add_argument("--async-steps", action="store_true")  # run the N > 1 step pipeline (async render + pack + stream-ordered consumer) on one GPU
     ap.add_argument("--sync-steps", action="store_true")   # N = 1: wait for every render before enqueuing the next (default: enqueue the K steps, wait once)
@@ -423,6 +424,20 @@ def main():
             load(args.scene)   # back to the timed workload for the CPU baseline below
 
         # ---- CPU baseline: the scalar oracle on a bounded sample of the same workload ------------------
+        # ---- the same render with the frame handed to the host (tb_read_accum: one D2H copy of the RGBA32F sums into a host
+        #      array the caller owns, pageable memory as a ctypes/numpy caller has it).  Reported beside `value`, never as it.
+        if world == 1 and not args.no_readback:
+            import numpy as np
+            host = np.zeros((H, W, 4), np.float32)
+            hp = host.ctypes.data_as(__import__("ctypes").c_void_p)
+            tb.InvalidateHistory(); tb.Render(W, H, SPP, s, 0.0); tb._check(tb._L.tb_read_accum(tb._ctx, hp, None))
+            n_rb = max(2, min(args.steps, 10)); t_rb = time.perf_counter()
+            for _ in range(n_rb):
+                tb.InvalidateHistory(); tb.Render(W, H, SPP, s, 0.0); tb._check(tb._L.tb_read_accum(tb._ctx, hp, None))
+            t_rb = (time.perf_counter() - t_rb) / n_rb
+            result["pcie_inclusive"] = {"value": round(samples_per_step / t_rb / 1e6, 3), "unit": "Msamples/s", "ms_per_step": round(t_rb * 1e3, 3),
+                                        "readback_bytes": int(host.nbytes), "note": "render + tb_read_accum into pageable host memory, synchronous, %d steps" % n_rb}
+
         if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only
             import oracle_lib as ol
             cores = len(os.sched_getaffinity(0))      # the CPUs this process may run on, not the machine's
