@@ -92,6 +92,47 @@ __global__ __launch_bounds__(256) void walk_quad(const uint4* __restrict__ nodes
     out[blockIdx.x * 256 + threadIdx.x] = acc;
 }
 
+/* Sparse waves, cooperative fetch: only every `every`-th lane owns a chain (like a wave whose other rays have finished), but ALL
+ * lanes load: the n owners publish their node index in LDS by rank, LPR lanes per owner fetch the node's 4 / LPR 16-B pieces each
+ * (one or two full-width load instructions instead of four sparse ones), the pieces go through LDS, the owner reads its 64 B back. */
+template <int LPR>
+__global__ __launch_bounds__(256) void walk_sparse_coop(const uint4* __restrict__ nodes, uint32_t mask, uint32_t steps, uint32_t* out, uint32_t every)
+{
+    constexpr int PPL = 4 / LPR;
+    __shared__ uint32_t refs[4][64];
+    __shared__ uint4 stage[4][64 / LPR * 4];
+    const uint32_t salt = (blockIdx.x * 256 + threadIdx.x) * 2654435761u;
+    uint32_t ref = salt & mask;
+    uint32_t acc = 0;
+    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    const bool active = (lane % every) == 0;
+    const uint32_t q = lane / LPR, j = lane % LPR;
+    for (uint32_t s = 0; s < steps; s++) {
+        const unsigned long long m = __ballot(active && ref != 0xffffffffu); /* recomputed every step, as a walk would have to */
+        const uint32_t n = (uint32_t)__popcll(m);
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        if (active) refs[w][rank] = ref;
+        __builtin_amdgcn_wave_barrier();
+        uint4 c[PPL];
+        if (q < n) {
+            const uint32_t r = refs[w][q];
+#pragma unroll
+            for (int p = 0; p < PPL; p++) c[p] = nodes[(size_t)r * 4 + j * PPL + p];
+#pragma unroll
+            for (int p = 0; p < PPL; p++) stage[w][q * 4 + ((j * PPL + p) ^ ((q >> 2) & 3u))] = c[p];
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (active) {
+            uint32_t h = 0;
+#pragma unroll
+            for (int p = 0; p < 4; p++) h += mix(stage[w][rank * 4 + (p ^ ((rank >> 2) & 3u))]);
+            acc += h; ref = (h + salt + s * 40503u) & mask;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = acc;
+}
+
 int main()
 {
     hipDeviceProp_t prop; CHECK(hipGetDeviceProperties(&prop, 0));
@@ -113,7 +154,7 @@ int main()
                 CHECK(hipEventRecord(e0)); launch(); CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
                 float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
                 const double visits = (double)grid * 256 * steps;
-                printf("table %7.2f MB  %d waves/SIMD  %-12s %8.1f Gvisits/s  %6.0f clk per wave-visit per CU  %7.0f GB/s\n", N * 64.0 / 1e6, blocksPerCu, name,
+                printf("table %7.2f MB  %d waves/SIMD  %-18s %8.1f Gvisits/s  %6.0f clk per wave-visit per CU  %7.0f GB/s\n", N * 64.0 / 1e6, blocksPerCu, name,
                        visits / ms * 1e-6, ghz * 1e9 * (ms * 1e-3) / (visits / 64 / cus), visits * bytesPerVisit / ms * 1e-6);
             };
             run("A own 4x16B", [&] { hipLaunchKernelGGL(walk_own<4>, dim3(grid), dim3(256), 0, 0, nodes, N - 1, steps, out); }, 64);
@@ -124,6 +165,10 @@ int main()
                 char nm[32]; snprintf(nm, sizeof nm, "A 1/%u %s", every, contig ? "contig" : "strided");
                 run(nm, [&] { hipLaunchKernelGGL(walk_sparse, dim3(grid), dim3(256), 0, 0, nodes, N - 1, steps, out, every, contig); }, 64.0 / every);
             }
+            run("S 1/2 coop 2/ray", [&] { hipLaunchKernelGGL(walk_sparse_coop<2>, dim3(grid), dim3(256), 0, 0, nodes, N - 1, steps, out, 2u); }, 32);
+            run("S 1/4 coop 4/ray", [&] { hipLaunchKernelGGL(walk_sparse_coop<4>, dim3(grid), dim3(256), 0, 0, nodes, N - 1, steps, out, 4u); }, 16);
+            run("S 1/8 coop 4/ray", [&] { hipLaunchKernelGGL(walk_sparse_coop<4>, dim3(grid), dim3(256), 0, 0, nodes, N - 1, steps, out, 8u); }, 8);
+            run("S 1/4 coop 2/ray", [&] { hipLaunchKernelGGL(walk_sparse_coop<2>, dim3(grid), dim3(256), 0, 0, nodes, N - 1, steps, out, 4u); }, 16);
             run("P 2 chains", [&] { hipLaunchKernelGGL(walk_two_chains, dim3(grid), dim3(256), 0, 0, nodes, N - 1, steps, out); }, 64);
         }
         CHECK(hipFree(nodes));
