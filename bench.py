@@ -171,6 +171,45 @@ def traffic_bytes(passes):
     return int((2.0 * passes["fetch"]["FETCH_SIZE"] + passes["write"]["WRITE_SIZE"]) * 1024)
 
 
+def cpu_allowance():
+    """What the box lets this process use: the affinity mask, the cgroup CPU quota (v2 cpu.max, v1 cfs_quota / cfs_period; found by
+    walking up from this process's cgroup) and the load others put on the machine.  A quota or busy neighbours explain an
+    all-threads rate far below threads x single-thread rate; os.sched_getaffinity alone does not show either."""
+    out = {"affinity_cpus": len(os.sched_getaffinity(0)), "machine_cpus": os.cpu_count(), "cgroup_quota_cpus": None, "cgroup_source": None}
+    try:
+        rel = ""
+        for line in open("/proc/self/cgroup"):
+            parts = line.strip().split(":", 2)
+            if len(parts) == 3 and (parts[1] == "" or "cpu" in parts[1].split(",")):
+                rel = parts[2]
+                if parts[1] == "": break
+        cands = []
+        d = rel
+        while True:
+            cands.append("/sys/fs/cgroup" + d + "/cpu.max"); cands.append("/sys/fs/cgroup/cpu" + d + "/cpu.cfs_quota_us"); cands.append("/sys/fs/cgroup/cpu,cpuacct" + d + "/cpu.cfs_quota_us")
+            if d in ("", "/"): break
+            d = os.path.dirname(d)
+        best = None
+        for f in cands:
+            if not os.path.exists(f): continue
+            if f.endswith("cpu.max"):
+                q, per = open(f).read().split()[:2]
+                val = None if q == "max" else float(q) / float(per)
+            else:
+                q = float(open(f).read()); per = float(open(os.path.join(os.path.dirname(f), "cpu.cfs_period_us")).read())
+                val = None if q <= 0 else q / per
+            if out["cgroup_source"] is None: out["cgroup_source"] = f + (" (no limit)" if val is None else "")
+            if val is not None and (best is None or val < best[0]): best = (val, f)
+        if best: out["cgroup_quota_cpus"] = round(best[0], 2); out["cgroup_source"] = best[1]
+    except Exception as e:  # noqa: BLE001 -- diagnostics only
+        out["cgroup_source"] = "unreadable: %s" % e
+    try:
+        out["loadavg_1min"] = float(open("/proc/loadavg").read().split()[0])
+    except Exception:  # noqa: BLE001
+        pass
+    return out
+
+
 def measure_kernel(tb, api, np, W, H, spp, s, runs):
     """HIP-event duration of `runs` path-tracing launches run one at a time + the kernels' own event counters (1-spp launch)."""
     ms = []
@@ -418,8 +457,33 @@ def main():
                        "kernel_variant": variant3,
                        "note": "launches of 128 frames are batched by the sample-buffer budget: avg_launch_ms / frames_per_launch are per batch launch"})
             r3["pipes"] = derived_busy("c3", passes3)
-            r3["what_limits_it"] = ("vector-memory issue: a CU's texture addresser takes ~17 cycles per wave-level load whatever the number of active lanes "
-                                    "(scripts/microbench/gather64.hip), four loads per node visit at ~16 active lanes of 64: TA busy 81 %, DESIGN.md section 6")
+            # What the committed counters say limits it is not the fabric (traffic_frac_of_peak) but the issue of vector-memory and vector-ALU
+            # instructions at ~19 of 64 lanes: the texture addresser is pipes.ta_busy busy, the VALU pipes.valu_busy.
+            # `frac` is therefore the busier of the two pipes; the SURVEY 8d algorithmic rate / 8 TB/s stays under `algorithmic`.
+            r3["algorithmic"] = {"achieved": r3["achieved"], "unit": "GB/s", "peak": HBM_PEAK_GBS, "frac": r3["frac"],
+                                 "note": "SURVEY 8d byte model x samples / launch time; the bytes are served mostly by L2 / Infinity Cache (traffic_GBs is what the fabric carries)"}
+            pipes3 = r3["pipes"]
+            if pipes3.get("ta_busy") is not None:
+                busiest = max(("vmem_issue", pipes3["ta_busy"]), ("valu", pipes3.get("valu_busy", 0.0)), key=lambda kv: kv[1])
+                r3.update({"bound": busiest[0], "frac": busiest[1], "achieved": busiest[1], "peak": 1.0, "unit": "busy fraction of the launch (TA_TA_BUSY / 256 TAs, or 4 x SQ_ACTIVE_INST_VALU / 1024 SIMDs)"})
+            r3["what_limits_it"] = ("instruction issue at ~19 of 64 lanes: a CU's texture addresser takes ~17 cycles per wave-level load whatever the number of active lanes "
+                                    "(scripts/microbench/gather64.hip) and every VALU instruction of the walk pays for 64 lanes; halving the node loads (layout C) moves "
+                                    "the time by 1-2 % because the conversions it adds fill the VALU instead (profiles/r3/pmcab_c3.json, DESIGN.md section 6)")
+            # the same workload through the compact nodes (option node_layout = 1: 32-B nodes on a 16-bit grid, within 1e-4 rel. L2 of the bit-exact path)
+            tb.SetOption("node_layout", 1)
+            tb.InvalidateHistory(); tb.Render(W3, H3, SPP3, s3, 0.0)
+            if tb.GetOption("last_node_layout") == 1:
+                torch.cuda.synchronize(); t3c = time.perf_counter()
+                for _ in range(3):
+                    tb.InvalidateHistory(); tb.Render(W3, H3, SPP3, s3, 0.0, sync=False)
+                torch.cuda.synchronize(); dt3c = time.perf_counter() - t3c
+                ms3c = []
+                for _ in range(3):
+                    tb.InvalidateHistory(); tb.Render(W3, H3, SPP3, s3, 0.0); ms3c.append(tb.GetOption("last_kernel_us") / 1e3)
+                r3["compact_nodes"] = {"value": round(W3 * H3 * SPP3 * 3 / dt3c / 1e6, 1), "unit_value": "Msamples/s", "ms_per_step": round(dt3c / 3 * 1e3, 3),
+                                       "avg_launch_ms": round(float(np.mean(ms3c)), 3), "option": "node_layout=1",
+                                       "contract": "relative L2 <= 1e-4 against the bit-exact layout-B path (tests/test_compact_nodes.py), not bit equality"}
+            tb.SetOption("node_layout", 0)
             result["roofline_c3"] = r3
             load(args.scene)   # back to the timed workload for the CPU baseline below
 
@@ -446,7 +510,8 @@ def main():
             # single-thread figure is measured on whole frames too (the same rows), sized to about the same time
             t1 = time.perf_counter(); ol.render(view, pf, W, H, 1, threads=cores); dt = time.perf_counter() - t1
             frames = int(max(1, min(SPP, args.cpu_baseline_seconds / max(dt, 1e-3))))
-            t1 = time.perf_counter(); ol.render(view, pf, W, H, frames, threads=cores); dt = time.perf_counter() - t1
+            c0 = os.times(); t1 = time.perf_counter(); ol.render(view, pf, W, H, frames, threads=cores); dt = time.perf_counter() - t1; c1 = os.times()
+            cpu_seconds = (c1.user - c0.user) + (c1.system - c0.system)    # CPU time the threads actually got: cpu_seconds / dt = CPUs' worth of service
             if cores == 1:
                 dt1, n1, rows1 = dt, W * H * frames, "the same run"
             else:
@@ -464,6 +529,15 @@ def main():
                                                 % (W, H, frames, SPP, args.depth, cores, dt),
                                       "single_thread": round(n1 / dt1 / 1e6, 4), "single_thread_sample": rows1 + " (%.1f s)" % dt1,
                                       "machine_cpus": os.cpu_count()}
+            cb = result["cpu_baseline"]
+            cb["box"] = cpu_allowance()
+            cb["effective_parallelism"] = round(cb["value"] / max(cb["single_thread"], 1e-9), 1)        # all-threads rate / single-thread rate
+            cb["cpus_worth_of_service"] = round(cpu_seconds / max(dt, 1e-9), 1)                        # process CPU time / wall time of the all-threads run
+            cb["unthrottled_estimate"] = {"value": round(cb["single_thread"] * cores, 2), "unit": "Msamples/s",
+                                          "note": "single-thread rate x %d threads: what the same port would reach if every thread had a core to itself" % cores}
+            cb["sample"] = cb["sample"].replace("over 8-row strips", "over row strips (>= 4 work items per thread)")
+            cb["note"] = ("the all-threads figure is what THIS lease delivers: effective_parallelism is well below the thread count when the box throttles "
+                          "(cgroup quota in box.cgroup_quota_cpus) or shares its cores (cpus_worth_of_service << threads); quote speed-ups against both figures")
             if args.scene == "cornell-box":
                 # BASELINE.json configs[0], the reference's own CPU-runnable case, timed exactly: 512x512, 4 spp, depth 4
                 import copy

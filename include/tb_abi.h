@@ -225,6 +225,27 @@ typedef struct TbNodeB {
 } TbNodeB;
 TB_STATIC_ASSERT(sizeof(TbNodeB) == 64, "layout-B node is 64 B");
 
+/* ---- BVH "layout C": the compact node (option "node_layout" = 1) ------------------------------------
+ * The same tree in half the bytes: both children's boxes as centre / half-extent on a 16-bit grid laid over the
+ * (slightly inflated) root box, rounded OUTWARD so that every quantised box contains its layout-B box, + the two child
+ * refs: 32 B = two aligned 16-B loads per inner-node visit instead of four.  A CU's texture addresser charges a
+ * divergent load per instruction at the ~16 active lanes the walk runs at (scripts/microbench/gather64.hip:
+ * 36 against 69 cycles per visit), so the large scenes, which are bound by exactly that, walk faster.  Boxes only
+ * grow: no hit the reference finds can be culled, the near-child order is decided by the quantised entry distances.
+ * Not bit-exact by contract (a grown box may admit a hit the reference's own slab arithmetic culls by an ulp, and
+ * exact distance ties may resolve to the other triangle): validated at north_star's 1e-4 relative L2
+ * (tests/test_gpu_parity.py, test_compact_nodes_*).  World coordinate of grid value q on axis k: origin[k] + cell[k] * q. */
+typedef struct TbNodeC {
+    /* dword k (k = 0..2) = centre of axis k: left child in the low half, right child in the high half; dword 3 + k =
+     * half-extents likewise.  One v_cvt_f32_u32 (SDWA word select) per value, then the packed fmas of layout B. */
+    uint16_t c[3][2];
+    uint16_t h[3][2];
+    uint32_t left, right;         /* child refs, as in TbNodeB */
+} TbNodeC;
+TB_STATIC_ASSERT(sizeof(TbNodeC) == 32, "layout-C node is 32 B");
+
+typedef struct TbQuantFrame { float origin[3], cell[3]; } TbQuantFrame;
+
 typedef struct TbTriB {
     float v0[3]; uint32_t geometryIndex;
     float v1[3]; uint32_t primitiveIndex;

@@ -51,6 +51,7 @@ struct Ctx {
     bool aovDepthWritten, aovEmissiveWritten;
     uint32_t lastTris, lastBoxes;
     bool heatmapWritten;
+    bool selWritten; float selDistance; int selMaterial; /* StatsBuffer +8 / +12 of the selected pixel (RayGenCommon.h:632-648) */
     char rayKind; /* ray-step log only: E bounce ray, S shadow feeler, W interior walk */
 };
 
@@ -324,7 +325,9 @@ bool TraverseTwoLevel(const TbSceneView* sc, tb3 origin, tb3 direction, float TM
                     const tb3 v0 = tb3_make(ldf(p), ldf(p + 4), ldf(p + 8)), v1 = tb3_make(ldf(p + 12), ldf(p + 16), ldf(p + 20)), v2 = tb3_make(ldf(p + 24), ldf(p + 28), ldf(p + 32));
                     float t0 = hit.t, b[2] = {0, 0};
                     RayTriangleIntersect(t0, b, objectOrigin, rd, v0, v1, v2); /* ObjectRayOrigin / ObjectRayDirection, :667-668 */
-                    if (t0 < hit.t && t0 > TMin) {
+                    bool valid = true; /* the any-hit filter sees CandidateInstanceIndex() + CandidateGeometryIndex(), RayGenCommon.h:427 */
+                    if (g_alphaTest && t0 < hit.t && t0 > TMin && !(ld32(m + 8) & 1u)) valid = IsValidHit(sc, instanceOffset + geomContribution, primIdx, b[0], b[1]);
+                    if (valid && t0 < hit.t && t0 > TMin) {
                         hit.t = t0; hit.bary[0] = b[0]; hit.bary[1] = b[1];
                         hit.primitiveIndex = primIdx; hit.geometryIndex = instanceOffset + geomContribution;
                     }
@@ -843,6 +846,7 @@ tb3 Trace(Ctx& c, Ray ray, Ray neighborRay)
             c.aovDistanceToNeighbor += tb3_length(NeighborRayPoint - RayPoint);
             c.aovNormal = detailNormal;
             c.aovDepth = tb_saturate(resT / pf.MaxZ); c.aovDepthWritten = true;
+            if (c.x == pf.SelectedPixelX && c.y == pf.SelectedPixelY) { c.selWritten = true; c.selDistance = resT; c.selMaterial = resMat; } /* IsSelectedPixel :593-596; OutputMaterial(int(result.y)) */
             if (pf.OutputMode == TB_OUTPUT_TYPE_HEATMAP) break;
         }
         bool IsInsidePrimitve = IsBacksideOfGeometry;
@@ -1143,9 +1147,11 @@ int tbo_render(const TbSceneView* scene, const TbPerFrameConstants* constants, u
     struct LogGuard { LogGuard() { const char* e = getenv("TB_ORACLE_RAY_LOG"); if (e && *e && !g_rayLog) g_rayLog = fopen(e, "a"); }
                       ~LogGuard() { if (g_rayLog) { fclose(g_rayLog); g_rayLog = nullptr; } } } logGuard;
     if (numThreads <= 1) { render_rows(scene, constants, W, H, y0, y1, firstFrame, numFrames, output, jittered, aovs, stats); return 0; }
-    /* 8-row strips handed out dynamically; each pixel is touched by exactly one thread per frame and
-     * frames stay in order inside a strip, so the image is identical to the serial one. */
-    const uint32_t strip = 8;
+    /* Strips of rows handed out dynamically; each pixel is touched by exactly one thread per frame and frames stay in order
+     * inside a strip, so the image is identical to the serial one.  8 rows per strip, fewer when that would leave threads without
+     * work (at least four strips per thread, down to single rows: 1080 rows on 256 threads are 1080 work items). */
+    uint32_t strip = (y1 - y0) / (4u * (uint32_t)numThreads);
+    strip = strip < 1u ? 1u : (strip > 8u ? 8u : strip);
     uint32_t nStrips = (y1 - y0 + strip - 1) / strip;
     std::atomic<uint32_t> next(0);
     std::vector<TbRayStats> local((size_t)numThreads);
@@ -1216,6 +1222,45 @@ void tbo_rand_stream(float seed, float time, uint32_t n, float* out)
     TbPerFrameConstants pf; memset(&pf, 0, sizeof pf); pf.Time = time;
     Ctx c; memset(&c, 0, sizeof c); c.pf = &pf; c.seed = seed;
     for (uint32_t i = 0; i < n; i++) out[i] = rnd(c);
+}
+
+/* Known-answer probes of the BSDF sampling pieces (tests/test_oracle_furnace.py): the functions themselves, not restatements */
+float tbo_ggx_pdf(const float* normal, const float* incoming, const float* outgoing, float roughness) /* the pdf the throughput update uses, kernel.glsl:1701-1706 */
+{
+    const tb3 n = to3(normal), in = to3(incoming), out = to3(outgoing);
+    return ImportanceSampleGGXPDF(n, out, GetHalfVectorSafe(-in, out, n), roughness);
+}
+void tbo_sample_directions(int kind, float seed, float time, const float* incoming, const float* normal, float roughness, uint32_t n, float* outDirs, float* outPdf)
+{
+    TbPerFrameConstants pf; memset(&pf, 0, sizeof pf); pf.Time = time;
+    Ctx c; memset(&c, 0, sizeof c); c.pf = &pf; c.seed = seed;
+    const tb3 nn = to3(normal), in = incoming ? to3(incoming) : tb3_splat(0);
+    for (uint32_t i = 0; i < n; i++) {
+        tb3 d; float pdf = 0.0f;
+        if (kind == 0) d = ImportanceSampleGGX(c, in, nn, roughness);                                  /* :1066-1082 */
+        else if (kind == 1) d = GenerateRandomImportanceSampledDirection(c, nn, roughness, pdf);        /* :1048-1064,1096-1099 */
+        else { float r0 = rnd(c); float r1 = rnd(c); d = GenerateCosineWeightedDirection(nn, r0, r1, pdf); } /* :1025-1046 */
+        outDirs[3 * i] = d.x; outDirs[3 * i + 1] = d.y; outDirs[3 * i + 2] = d.z;
+        if (outPdf) outPdf[i] = pdf;
+    }
+}
+
+/* SelectPixel -> ReadbackStats (TracerBoy.h:362-368): what StatsBuffer +8 / +12 hold after frames [firstFrame, firstFrame + numFrames)
+ * of the pixel (constants->SelectedPixelX, Y): OutputDistanceToFirstHit / OutputMaterial of the last frame whose primary ray hit
+ * (RayGenCommon.h:632-648, kernel.glsl:1370-1371).  Returns 0 when no frame wrote them. */
+int tbo_selected_pixel(const TbSceneView* scene, const TbPerFrameConstants* constants, uint32_t W, uint32_t H, uint32_t firstFrame, uint32_t numFrames,
+                       float* distance, int32_t* materialId)
+{
+    int written = 0;
+    if (constants->SelectedPixelX >= W || constants->SelectedPixelY >= H) return 0;
+    for (uint32_t f = 0; f < numFrames; f++) {
+        TbPerFrameConstants pf = *constants; pf.GlobalFrameCount = firstFrame + f;
+        Ctx c; memset(&c, 0, sizeof c);
+        c.scene = scene; c.pf = &pf; c.width = W; c.height = H; c.x = pf.SelectedPixelX; c.y = pf.SelectedPixelY;
+        float s[4]; sample_pixel(c, s);
+        if (c.selWritten) { *distance = c.selDistance; *materialId = c.selMaterial; written = 1; }
+    }
+    return written;
 }
 
 float tbo_math(int fn, float a, float b)

@@ -35,6 +35,7 @@ __global__ __launch_bounds__(256) void walk_own(const uint4* __restrict__ nodes,
 
 /* mode A with only every `every`-th lane of the wave walking (the others idle): does a divergent load cost per
  * instruction or per active lane? */
+template <int PIECES = 4>
 __global__ __launch_bounds__(256) void walk_sparse(const uint4* __restrict__ nodes, uint32_t mask, uint32_t steps, uint32_t* out, uint32_t every, uint32_t contiguous)
 {
     const uint32_t salt = (blockIdx.x * 256 + threadIdx.x) * 2654435761u;
@@ -46,7 +47,7 @@ __global__ __launch_bounds__(256) void walk_sparse(const uint4* __restrict__ nod
         for (uint32_t s = 0; s < steps; s++) {
             uint32_t h = 0;
 #pragma unroll
-            for (int p = 0; p < 4; p++) h += mix(nodes[(size_t)ref * 4 + p]);
+            for (int p = 0; p < PIECES; p++) h += mix(nodes[(size_t)ref * PIECES + p]);
             acc += h; ref = (h + salt + s * 40503u) & mask;
         }
     out[blockIdx.x * 256 + threadIdx.x] = acc;
@@ -163,7 +164,14 @@ int main()
             run("C quad+LDS", [&] { hipLaunchKernelGGL(walk_quad, dim3(grid), dim3(256), 0, 0, nodes, N - 1, steps, out); }, 64);
             for (uint32_t every : {2u, 4u, 8u}) for (uint32_t contig : {0u, 1u}) {
                 char nm[32]; snprintf(nm, sizeof nm, "A 1/%u %s", every, contig ? "contig" : "strided");
-                run(nm, [&] { hipLaunchKernelGGL(walk_sparse, dim3(grid), dim3(256), 0, 0, nodes, N - 1, steps, out, every, contig); }, 64.0 / every);
+                run(nm, [&] { hipLaunchKernelGGL(walk_sparse<4>, dim3(grid), dim3(256), 0, 0, nodes, N - 1, steps, out, every, contig); }, 64.0 / every);
+            }
+            /* round 3: the half-size (layout C) and quarter-size node at the lane counts the real walk runs at */
+            for (uint32_t every : {2u, 4u, 8u}) {
+                char nm[32]; snprintf(nm, sizeof nm, "B 1/%u strided", every);
+                run(nm, [&] { hipLaunchKernelGGL(walk_sparse<2>, dim3(grid), dim3(256), 0, 0, nodes, N - 1, steps, out, every, 0u); }, 32.0 / every);
+                snprintf(nm, sizeof nm, "D 1/%u strided", every);
+                run(nm, [&] { hipLaunchKernelGGL(walk_sparse<1>, dim3(grid), dim3(256), 0, 0, nodes, N - 1, steps, out, every, 0u); }, 16.0 / every);
             }
             run("S 1/2 coop 2/ray", [&] { hipLaunchKernelGGL(walk_sparse_coop<2>, dim3(grid), dim3(256), 0, 0, nodes, N - 1, steps, out, 2u); }, 32);
             run("S 1/4 coop 4/ray", [&] { hipLaunchKernelGGL(walk_sparse_coop<4>, dim3(grid), dim3(256), 0, 0, nodes, N - 1, steps, out, 4u); }, 16);

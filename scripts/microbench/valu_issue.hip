@@ -65,6 +65,23 @@ __global__ __launch_bounds__(1024) void issue_kernel(float* out, unsigned long l
             if (KIND == 31) asm volatile("v_med3_f32 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
             if (KIND == 32) asm volatile("v_cvt_i32_f64 %0, %1" : "=v"(iacc[i]) : "v"(dacc[i]));
             if (KIND == 33) asm volatile("v_floor_f64 %0, %0" : "+v"(dacc[i]));
+            /* round 3: what a compact (16-bit) BVH node costs to unpack */
+            if (KIND == 34) asm volatile("v_cvt_f32_u32 %0, %1" : "=v"(acc[i]) : "v"(iacc[i]));
+            if (KIND == 35) asm volatile("v_cvt_f32_u32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(acc[i]) : "v"(iacc[i]));
+            if (KIND == 36) asm volatile("v_cvt_f32_ubyte2 %0, %1" : "=v"(acc[i]) : "v"(iacc[i]));
+            if (KIND == 37) asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc[i]) : "v"(iacc[i]), "v"(b));   /* f16 (high half) x f32 + f32 */
+            if (KIND == 38) asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(iacc[i]) : "v"(iacc[0]), "v"(a), "v"(b));
+            if (KIND == 39) asm volatile("v_and_or_b32 %0, %1, %2, %0" : "+v"(iacc[i]) : "v"(iacc[0]), "v"(a));
+            if (KIND == 40) asm volatile("v_cvt_f32_f16 %0, %1" : "=v"(acc[i]) : "v"(iacc[i]));
+            if (KIND == 41) asm volatile("v_pk_add_f32 %0, %1, %0" : "+v"(acc2[i]) : "v"(a2));
+            if (KIND == 42) asm volatile("v_max3_f32 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
+            if (KIND == 43) asm volatile("v_pk_fma_f16 %0, %1, %2, %0" : "+v"(iacc[i]) : "v"(a), "v"(b));
+            if (KIND == 44) asm volatile("v_lshl_or_b32 %0, %1, 7, %0" : "+v"(iacc[i]) : "v"(iacc[0]));
+            if (KIND == 45) asm volatile("v_bfe_u32 %0, %1, 16, 16" : "=v"(iacc[i]) : "v"(iacc[0]));
+            if (KIND == 46) asm volatile("v_dot2_f32_f16 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
+            if (KIND == 47) asm volatile("v_cvt_f32_f16_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(acc[i]) : "v"(iacc[i]));
+            if (KIND == 48) asm volatile("v_min_f32 %0, %1, %2" : "=v"(acc[i]) : "v"(a), "v"(b));
+            if (KIND == 49) asm volatile("v_max_f32_e64 %0, %1, %2" : "=v"(acc[i]) : "v"(a), "v"(b));
             if (KIND == 17) asm volatile("v_fma_f32 %0, %1, %2, %0\n\ts_and_b64 s[10:11], s[10:11], exec" : "+v"(acc[i]) : "v"(a), "v"(b) : "s10", "s11", "scc");   /* VALU + SALU pair */
         }
     }
@@ -110,6 +127,9 @@ int main()
         run<18>("v_fma_f64", w); run<19>("v_mul_f64", w); run<20>("v_rndne_f64", w); run<33>("v_floor_f64", w); run<21>("v_cvt_f64_f32", w); run<22>("v_cvt_f32_f64", w); run<32>("v_cvt_i32_f64", w);
         run<23>("v_rcp_f32", w); run<24>("v_sqrt_f32", w); run<25>("v_div_scale_f32", w); run<26>("v_div_fmas_f32", w); run<27>("v_div_fixup_f32", w); run<28>("v_floor_f32", w);
         run<29>("v_add_f32", w); run<30>("v_pk_mul_f32", w); run<31>("v_med3_f32", w);
+        run<34>("v_cvt_f32_u32", w); run<35>("v_cvt_f32_u32 sdwa WORD_1", w); run<36>("v_cvt_f32_ubyte2", w); run<37>("v_fma_mix_f32 (f16 hi)", w); run<38>("v_perm_b32", w);
+        run<39>("v_and_or_b32", w); run<40>("v_cvt_f32_f16", w); run<47>("v_cvt_f32_f16 sdwa WORD_1", w); run<41>("v_pk_add_f32", w); run<42>("v_max3_f32", w); run<43>("v_pk_fma_f16", w);
+        run<44>("v_lshl_or_b32", w); run<45>("v_bfe_u32", w); run<46>("v_dot2_f32_f16", w); run<48>("v_min_f32 3-operand", w); run<49>("v_max_f32_e64", w);
         run<16>("s_and_b64", w); run<17>("v_fma_f32 + s_and_b64 (2)", w); run<5>("v_add_u32", w); run<6>("v_fma_f32 dependent", w);
     }
     printf("ns per wave-instr per SIMD x shader clock (GHz) = cycles; at 2.4 GHz: 2 cycles = 0.833 ns, 4 cycles = 1.667 ns\n");

@@ -129,6 +129,18 @@ def composite(albedo, lighting, emissive):
     return out
 
 
+def selected_pixel(view, pf, width, height, frames, first_frame=0):
+    """StatsBuffer +8 / +12 after the frames (tbo_selected_pixel): (distance, material id) or None if no frame wrote them."""
+    L = lib()
+    L.tbo_selected_pixel.restype = C.c_int
+    L.tbo_selected_pixel.argtypes = [C.POINTER(abi.TbSceneView), C.POINTER(abi.TbPerFrameConstants), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                     C.POINTER(C.c_float), C.POINTER(C.c_int32)]
+    dist = C.c_float(0.0); mat = C.c_int32(0)
+    if not L.tbo_selected_pixel(C.byref(view), C.byref(pf), width, height, first_frame, frames, C.byref(dist), C.byref(mat)):
+        return None
+    return dist.value, mat.value
+
+
 def set_alpha_test(enabled):
     lib().tbo_set_alpha_test(1 if enabled else 0)
 

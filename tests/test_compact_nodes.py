@@ -1,0 +1,118 @@
+"""-m gpu: the compact BVH node (layout C, include/tb_abi.h TbNodeC; option node_layout = 1) against the bit-exact layout-B path.
+
+Layout C stores both children's boxes on a 16-bit grid, rounded outward, in 32 B (two 16-B loads per visit instead of four).  Boxes only
+grow, so no hit can be lost; what may change is (a) a hit the reference's own slab arithmetic culls by an ulp and a grown box admits and
+(b) the near-child order on almost-equal entry distances, which decides exact distance ties.  The contract is therefore north_star's
+tolerance -- relative L2 <= 1e-4 -- not bit equality; the tests also report how many pixels / rays differ at all (expected: none)."""
+import copy
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4  # BASELINE.json north_star: "within 1e-4 relative L2"
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def rel_l2(a, b):
+    return float(np.sqrt(((a.astype(np.float64) - b) ** 2).sum()) / max(np.sqrt((b.astype(np.float64) ** 2).sum()), 1e-30))
+
+
+def _render(tb, layout, W, H, F, s):
+    tb.SetOption("node_layout", layout)
+    tb.InvalidateHistory(); tb.Render(W, H, F, s, 0.0)
+    assert tb.GetOption("last_node_layout") == layout
+    return tb.ReadAccumulation()
+
+
+def _compare(tb, W, H, F, s, what):
+    try:
+        b = _render(tb, 0, W, H, F, s)
+        c = _render(tb, 1, W, H, F, s)
+    finally:
+        tb.SetOption("node_layout", 0)
+    differing = int((bits(b) != bits(c)).any(axis=-1).sum())
+    per_pixel = np.sqrt(((c[..., :3].astype(np.float64) - b[..., :3]) ** 2).sum(-1)) / np.maximum(np.sqrt((b[..., :3].astype(np.float64) ** 2).sum(-1)), 1e-30)
+    print("%s: %d of %d pixels differ; image rel-L2 %.3e; worst pixel rel-L2 %.3e" % (what, differing, W * H, rel_l2(c[..., :3], b[..., :3]), float(per_pixel.max())))
+    assert np.array_equal(c[..., 3], b[..., 3])              # every sample landed
+    assert rel_l2(c[..., :3], b[..., :3]) <= TOL
+    assert differing <= W * H * 1e-4                         # "expect ~0": at most one pixel in 10 000 may see a tie resolved the other way
+    return b, c
+
+
+@pytest.mark.parametrize("scene", ["proc0", "proc1", "teapot_flat"])
+def test_compact_nodes_closest_hits(gpu_tb, settings, scene):
+    """10^5 random rays + axis-parallel ones: t, barycentrics, primitive and hit-group index through layout C equal layout B's
+    (which test_trace_closest_matches_oracle_exactly pins to the oracle); layout C may test MORE boxes, never fewer hits."""
+    gpu_tb.SetOption("bvh_builder", 4)
+    try:
+        if scene == "proc0": gpu_tb.LoadProcedural(0, 200000, 1234)
+        elif scene == "proc1": gpu_tb.LoadProcedural(1, 150000, 7)
+        else: gpu_tb.LoadProcedural(2, 120000, 5)
+    finally:
+        gpu_tb.SetOption("bvh_builder", 0)
+    rng = np.random.default_rng(11)
+    info = gpu_tb.SceneInfo()
+    lo, hi = np.array(info.sceneMin[:]), np.array(info.sceneMax[:])
+    n = 100000
+    ro = rng.uniform(lo - 0.05 * (hi - lo), hi + 0.05 * (hi - lo), (n, 3)).astype(np.float32)
+    rd = rng.normal(size=(n, 3)).astype(np.float32); rd /= np.linalg.norm(rd, axis=1, keepdims=True)
+    axis = np.eye(3, dtype=np.float32)[rng.integers(0, 3, 2000)] * rng.choice([-1, 1], 2000)[:, None]
+    O = np.concatenate([ro, ro[:2000]]); D = np.concatenate([rd, axis.astype(np.float32)])
+    try:
+        gpu_tb.SetOption("node_layout", 0); b = gpu_tb.TraceClosest(O, D)
+        gpu_tb.SetOption("node_layout", 1); c = gpu_tb.TraceClosest(O, D)
+    finally:
+        gpu_tb.SetOption("node_layout", 0)
+    assert (b["t"] > 0).sum() > n // 4
+    same = (bits(b["t"]) == bits(c["t"])) & (b["prim"] == c["prim"]) & (b["geom"] == c["geom"])
+    print("%s: %d of %d closest hits differ; boxes tested %.2f -> %.2f per ray, triangles %.2f -> %.2f" %
+          (scene, int((~same).sum()), len(same), b["boxes"].mean(), c["boxes"].mean(), b["tris"].mean(), c["tris"].mean()))
+    assert same.all()
+    assert np.array_equal(bits(b["bary"]), bits(c["bary"])) and np.array_equal(bits(b["normal"]), bits(c["normal"]))
+    # conservative boxes: a ray never visits less -- per ray the visit sets may differ in order, in total they only grow, and by little
+    assert c["boxes"].sum() >= b["boxes"].sum() and c["boxes"].sum() <= 1.10 * b["boxes"].sum()
+    # and against the oracle itself on a subset
+    view = gpu_tb.HostSceneView()
+    k = 4000
+    ref = ol.trace_closest(view, O[:k], D[:k])
+    assert np.array_equal(bits(c["t"][:k]), bits(ref["t"])) and np.array_equal(c["prim"][:k], ref["prim"])
+
+
+def test_compact_nodes_small_scene_and_split_stack(gpu_tb, settings):
+    """Feature sets env / sss / vol-free scenes at test size, with and without the split traversal stack, both layouts; the small
+    frames also go against the oracle (layout C is expected to reproduce it bit for bit here; the contract is TOL)."""
+    W, H, F = 96, 64, 9
+    s = copy.copy(settings); s.MaxBounces = 5
+    for kind, tris, seed, variant in ((0, 20000, 3, 1), (1, 30000, 7, 5)):
+        gpu_tb.LoadProcedural(kind, tris, seed)
+        ref = ol.render(gpu_tb.HostSceneView(), gpu_tb.FrameConstants(W, H, 0, s, 0.0), W, H, F, threads=8)["output"]
+        for cap in (0, 3):
+            try:
+                gpu_tb.SetOption("stack_lds_cap", cap); gpu_tb.SetOption("stack_overflow_max", 64 if cap else 16)
+                b, c = _compare(gpu_tb, W, H, F, s, "proc%d cap %d" % (kind, cap))
+                assert gpu_tb.GetOption("last_variant") == variant
+            finally:
+                gpu_tb.SetOption("stack_lds_cap", 0); gpu_tb.SetOption("stack_overflow_max", 16)
+            assert np.array_equal(bits(b), bits(ref))
+            assert rel_l2(c[..., :3], ref[..., :3]) <= TOL
+
+
+@pytest.mark.parametrize("cfg", ["c3_870k_128spp", "c4_van_class", "c5_bistro_class"])
+def test_compact_nodes_full_size_configs(gpu_tb, settings, cfg):
+    """BASELINE.json configs[2] at its full 1920x1080x128 and the C4- / C5-class 4K scenes (8 spp): layout C against layout B."""
+    s = copy.copy(settings)
+    gpu_tb.SetOption("bvh_builder", 4)
+    try:
+        if cfg == "c3_870k_128spp": gpu_tb.LoadProcedural(0, 870000, 1234); s.MaxBounces = 6; W, H, F = 1920, 1080, 128
+        elif cfg == "c4_van_class": gpu_tb.LoadProcedural(1, 700000, 1234); s.MaxBounces = 6; W, H, F = 3840, 2160, 8
+        else: gpu_tb.LoadProcedural(2, 2980000, 1234); s.MaxBounces = 16; W, H, F = 3840, 2160, 8
+    finally:
+        gpu_tb.SetOption("bvh_builder", 0)
+    _compare(gpu_tb, W, H, F, s, cfg)

@@ -853,6 +853,40 @@ def test_config_c4_c5_full_sample_counts(gpu_tb, settings, cfg):
     assert np.array_equal(bits(out[y]), bits(ref[y]))
 
 
+@pytest.mark.parametrize("scene", ["cornell", "mix-glass"])
+def test_select_pixel_readback_stats(gpu_tb, settings, scene):
+    """SelectPixel -> ReadbackStats (TracerBoy.h:362-368): OutputDistanceToFirstHit / OutputMaterial of the selected pixel
+    (RayGenCommon.h:632-648, kernel.glsl:1370-1371) against the oracle, over several frames (the last frame that hit wins), for
+    pixels on different materials -- incl. a mix material, whose id is reported before the mix coin -- and for a pixel that
+    misses (cornell's camera sees nothing but the box: use a pixel of the mix-glass scene that sees the background)."""
+    gpu_tb.LoadScene(CORNELL if scene == "cornell" else MIX_GLASS)
+    W, H, F = 96, 64, 5
+    s = copy.copy(settings); s.MaxBounces = 3
+    view = gpu_tb.HostSceneView()
+    seen = set()
+    try:
+        for (x, y) in [(10, 32), (48, 60), (48, 5), (85, 32), (40, 40), (60, 44), (30, 20), (2, 2), (93, 61)]:
+            gpu_tb.SelectPixel(x, y); gpu_tb.InvalidateHistory()
+            gpu_tb.Render(W, H, F, s, 0.0)
+            st = gpu_tb.ReadbackStats()
+            pf = gpu_tb.FrameConstants(W, H, 0, s, 0.0)
+            assert (pf.SelectedPixelX, pf.SelectedPixelY) == (x, y)
+            ref = ol.selected_pixel(view, pf, W, H, F)
+            if ref is None:
+                assert st.SelectedPixelDistance == 0.0 and st.SelectedMaterialID == 0          # cleared with the history, never written
+            else:
+                assert np.float32(st.SelectedPixelDistance).view(np.uint32) == np.float32(ref[0]).view(np.uint32), (x, y)
+                assert st.SelectedMaterialID == ref[1], (x, y)
+                seen.add(ref[1])
+            # the picture itself is unchanged by selecting a pixel
+        out = gpu_tb.ReadAccumulation()
+        gpu_tb.SelectPixel(0xffffffff, 0xffffffff); gpu_tb.InvalidateHistory(); gpu_tb.Render(W, H, F, s, 0.0)
+        assert np.array_equal(bits(out), bits(gpu_tb.ReadAccumulation()))
+    finally:
+        gpu_tb.SelectPixel(0xffffffff, 0xffffffff)
+    assert len(seen) >= 3, seen
+
+
 def test_material_edit_and_errors(gpu_tb, settings):
     from tracerboy_amd import api
     gpu_tb.LoadScene(CORNELL)

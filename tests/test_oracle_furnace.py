@@ -1,0 +1,301 @@
+"""Independent evidence for the CPU oracle's radiance path (VERDICT r2, weak point 1): closed forms that hold for the REFERENCE's
+estimator whatever its implementation, evaluated on oracle/liboracle.so alone (no GPU).  A transcription slip in the GGX pdf, the
+matte throughput, the Russian roulette, the emissive rule, the refraction or the Beer-Lambert step moves these numbers.
+
+Scenes: tests/golden/scenes/furnace/*.pbrt (hand-written); the tests edit the one material of a scene in place through the host
+view (the oracle reads the same memory) and bind a constant environment to TbSceneView::envMap.
+"""
+import copy
+import ctypes as C
+import math
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from conftest import GOLDEN
+from tracerboy_amd import _ctypes_abi as abi
+from tracerboy_amd import api
+
+FURNACE = os.path.join(GOLDEN, "scenes", "furnace")
+MAT_SSS, MAT_NO_SPECULAR, MAT_METALLIC, MAT_NO_ALPHA = 0x2, 0x4, 0x1, 0x20
+
+
+def _scene(name):
+    h = api.HostScene(os.path.join(FURNACE, name + ".pbrt"))
+    return h, h.view()
+
+
+def _set_material(view, **kw):
+    m = view.materials[0]
+    for k, val in kw.items():
+        if k in ("albedo", "emissive", "absorption", "scattering"):
+            f = getattr(m, k); f.x, f.y, f.z = val
+        else:
+            setattr(m, k, val)
+
+
+def _bind_constant_environment(view, L):
+    env = np.tile(np.array([L[0], L[1], L[2], 1.0], np.float32), (4, 1))   # 2 x 2 texels
+    view.envMap = env.ctypes.data_as(C.POINTER(abi.TbFloat4)); view.envWidth = 2; view.envHeight = 2
+    return env  # keep alive
+
+
+def _mean_rgb(view, pf, W, H, spp, threads=8):
+    img = ol.render(view, pf, W, H, spp, threads=threads)["output"]
+    assert np.all(img[..., 3] == float(spp)) and not np.isnan(img).any()
+    return (img[..., :3] / img[..., 3:]).reshape(-1, 3)
+
+
+@pytest.mark.parametrize("albedo,bounces", [((0.5, 0.5, 0.5), 1), ((0.5, 0.5, 0.5), 2), ((0.5, 0.5, 0.5), 4), ((0.8, 0.5, 0.6), 6), ((0.9, 0.9, 0.9), 12)])
+def test_closed_furnace_geometric_series_with_russian_roulette(built, settings, albedo, bounces):
+    """Closed matte box, walls emit E and reflect `albedo`, no light list (no NEE): a path of k bounces returns E * sum_{i<k} a^i.
+    From bounce 2 on the survival probability is max(T) and survivors are divided by it (kernel.glsl:1288-1302): the MEAN must not
+    move -- per channel, also when the channels differ.
+    Tolerance: without roulette (k <= 2) every pixel is the closed form to 1e-4.  With roulette the estimator is unbiased for a
+    uniform rand(); the reference's rand() = frac(sin(seed++ + Time) * 43758.5453123) is not quite (fp32 leaves the product 8 to 10
+    fractional bits, and the k-th call of every sample sees sin over the same unit interval): P(rand() <= p) is off by up to
+    ~1.5 % at a given call index (test_reference_rng_resolution), which moves the mean by the same order, with a sign that
+    depends on Time.  So: each Time within 2.5 %, the mean over three Time values within 1.2 %."""
+    h, view = _scene("box")
+    E = (0.7, 1.1, 0.4)
+    _set_material(view, albedo=albedo, emissive=E)
+    s = copy.copy(settings); s.MaxBounces = bounces
+    expect = np.array([E[c] * sum(albedo[c] ** i for i in range(bounces)) for c in range(3)])
+    if bounces <= 2:  # no roulette yet: matte throughput is albedo * cos / pi / (cos / pi)
+        rgb = _mean_rgb(view, h.frame_constants(s, 0, 0.0), 16, 16, 8)
+        assert np.all(np.abs(rgb - expect) / expect < 1e-4)
+        return
+    devs = []
+    for time_seed in (0.0, 1.7, 13.0):
+        rgb = _mean_rgb(view, h.frame_constants(s, 0, time_seed), 16, 16, 2048)
+        devs.append(rgb.mean(axis=0) / expect - 1.0)
+        assert np.all(np.abs(devs[-1]) < 0.025), (time_seed, devs[-1])
+    assert np.all(np.abs(np.mean(devs, axis=0)) < 0.012), devs
+
+
+def test_reference_rng_resolution(built):
+    """What the furnace tolerance rests on: rand() (kernel.glsl:39-40) at the call indices a path uses.  Uniform to about a
+    percent, not better; exactly 0 about once in 300-700 calls (degenerate-axis rays)."""
+    rng = np.random.default_rng(1)
+    seeds = rng.random(20000).astype(np.float32)
+    vals = np.zeros((len(seeds), 48), np.float32)
+    for i, sd in enumerate(seeds):
+        ol.lib().tbo_rand_stream(float(sd), 0.0, 48, vals[i].ctypes.data_as(C.c_void_p))
+    assert vals.min() >= 0.0 and vals.max() < 1.0
+    for k in range(8, 48):
+        for p in (0.25, 0.5, 0.81):
+            assert abs((vals[:, k] <= p).mean() - p) < 0.02        # 20 000 draws: sigma 0.0035
+    worst = max(abs((vals[:, k] <= 0.25).mean() / 0.25 - 1.0) for k in range(8, 48))
+    assert 0.004 < worst < 0.06                                     # visibly non-uniform at single call indices
+    zeros = (vals == 0.0).mean()
+    assert 1.0 / 2000 < zeros < 1.0 / 150
+
+
+def test_matte_plane_under_constant_environment_is_albedo_times_L(built, settings):
+    """One scattering event into a constant environment: L * albedo exactly (cosine sampling cancels the BRDF's cosine), and with
+    MaxBounces = 1 the camera sees nothing but the primary hit's emission (0)."""
+    h, view = _scene("plane")
+    L = (2.0, 1.5, 0.25)
+    keep = _bind_constant_environment(view, L)
+    _set_material(view, albedo=(0.6, 0.3, 0.9))
+    s = copy.copy(settings); s.MaxBounces = 2
+    rgb = _mean_rgb(view, h.frame_constants(s, 0, 0.0), 8, 8, 16)
+    expect = np.array(L) * np.array([0.6, 0.3, 0.9])
+    assert np.all(np.abs(rgb - expect) / expect < 2e-4), (rgb.mean(axis=0), expect)
+    s.MaxBounces = 1
+    assert np.all(_mean_rgb(view, h.frame_constants(s, 0, 0.0), 8, 8, 4) == 0.0)
+    del keep
+
+
+@pytest.mark.parametrize("kind", ["plastic", "substrate_rough", "metal"])
+def test_specular_lobes_conserve_energy(built, settings, kind):
+    """White specular-capable materials on the plane under a unit environment: the pixel is E[f cos / pdf] of one scattering event,
+    i.e. the directional albedo of the lobe, which may not exceed 1 (diffuse 28/(23 pi) term + Fresnel-weighted GGX over the
+    half-half mixture pdf, kernel.glsl:1699-1772).  Lower bounds keep the test from passing on a black image."""
+    h, view = _scene("plane")
+    keep = _bind_constant_environment(view, (1.0, 1.0, 1.0))
+    if kind == "plastic": _set_material(view, albedo=(1.0, 1.0, 1.0), roughness=0.3, SpecularCoef=0.04, Flags=MAT_NO_ALPHA)
+    elif kind == "substrate_rough": _set_material(view, albedo=(1.0, 1.0, 1.0), roughness=0.7, SpecularCoef=0.2, Flags=MAT_NO_ALPHA)
+    else: _set_material(view, albedo=(1.0, 1.0, 1.0), roughness=0.4, SpecularCoef=0.9, Flags=MAT_NO_ALPHA | MAT_METALLIC)
+    s = copy.copy(settings); s.MaxBounces = 2
+    rgb = _mean_rgb(view, h.frame_constants(s, 0, 0.0), 8, 8, 8192)
+    got = rgb.mean(axis=0)
+    assert np.all(got <= 1.02), got          # energy <= 1 (2 % Monte-Carlo slack at 524 288 samples)
+    assert np.all(got >= 0.25), got
+    del keep
+
+
+def _sphere_quadrature(axis, n_theta=1200, n_phi=720):
+    """Midpoint rule on the unit sphere in polar coordinates about `axis`, the polar angle graded cubically so that a lobe as narrow
+    as a degree about the axis is resolved: directions (N, 3) and solid-angle weights (N,)."""
+    u = (np.arange(n_theta) + 0.5) / n_theta
+    t = math.pi * u ** 3; dt = 3.0 * math.pi * u ** 2 / n_theta
+    p = (np.arange(n_phi) + 0.5) * 2 * math.pi / n_phi
+    T, P = np.meshgrid(t, p, indexing="ij")
+    axis = np.asarray(axis, np.float64) / np.linalg.norm(axis)
+    a = np.cross(axis, [0.0, 0.0, 1.0] if abs(axis[2]) < 0.9 else [1.0, 0.0, 0.0]); a /= np.linalg.norm(a)
+    b = np.cross(axis, a)
+    d = (np.cos(T)[..., None] * axis + (np.sin(T) * np.cos(P))[..., None] * a + (np.sin(T) * np.sin(P))[..., None] * b).reshape(-1, 3)
+    w = (np.sin(T) * dt[:, None] * (2 * math.pi / n_phi)).reshape(-1)
+    return d.astype(np.float32), w
+
+
+@pytest.mark.parametrize("roughness", [0.15, 0.3, 0.6, 1.0])
+@pytest.mark.parametrize("incidence_deg", [0.0, 40.0, 75.0])
+def test_ggx_pdf_integrates_to_one_and_matches_its_sampler(built, roughness, incidence_deg):
+    """ImportanceSampleGGXPDF (kernel.glsl:1084-1094) is D(h) cos(theta_h) / (4 |o.h|): the density of reflect(incoming, h) for h
+    drawn by ImportanceSampleGGX (:1066-1082).  (a) Its integral over all outgoing directions is 1 -- so is the half-half mixture
+    with the cosine pdf on the upper hemisphere (:1708-1709).  (b) Of the directions drawn by the oracle's sampler, the share inside
+    a cone about the mirror direction equals the quadrature of the pdf over that cone (sampler and pdf belong together)."""
+    L = ol.lib()
+    n = np.array([0.0, 1.0, 0.0], np.float32)
+    a = math.radians(incidence_deg)
+    incoming = np.array([math.sin(a), -math.cos(a), 0.0], np.float32)        # direction of travel, towards the surface
+    fp = C.POINTER(C.c_float)
+    L.tbo_ggx_pdf.restype = C.c_float
+    L.tbo_ggx_pdf.argtypes = [fp, fp, fp, C.c_float]
+    L.tbo_sample_directions.restype = None
+    L.tbo_sample_directions.argtypes = [C.c_int, C.c_float, C.c_float, fp, fp, C.c_float, C.c_uint32, fp, fp]
+    # (a) quadrature about the mirror direction, where the lobe sits
+    mirror = incoming.astype(np.float64) - 2.0 * float(incoming @ n) * n
+    dirs, w = _sphere_quadrature(mirror)
+    assert abs(w.sum() - 4 * math.pi) < 1e-3
+    pdf = np.empty(len(dirs), np.float32)
+    nn, ii = n.ctypes.data_as(fp), incoming.ctypes.data_as(fp)
+    for k in range(len(dirs)):
+        pdf[k] = L.tbo_ggx_pdf(nn, ii, dirs[k].ctypes.data_as(fp), roughness)
+    total = float((pdf.astype(np.float64) * w).sum())
+    assert abs(total - 1.0) < 0.02, total
+    upper = dirs[:, 1] > 0
+    mixture = float(((0.5 * pdf.astype(np.float64) + 0.5 * np.maximum(dirs[:, 1], 0) / math.pi) * w)[upper].sum()) + 0.5 * float((pdf.astype(np.float64) * w)[~upper].sum())
+    assert abs(mixture - 1.0) < 0.02, mixture
+    # (b) sampler vs pdf: the share of sampled directions inside a cone about the mirror direction equals the pdf's mass there
+    N = 200000
+    out = np.empty((N, 3), np.float32)
+    L.tbo_sample_directions(0, 0.37, 0.0, ii, nn, roughness, N, out.ctypes.data_as(fp), None)
+    assert np.allclose(np.linalg.norm(out, axis=1), 1.0, atol=1e-4)
+    cos_s = out.astype(np.float64) @ mirror
+    cos_q = dirs.astype(np.float64) @ mirror
+    mass = pdf.astype(np.float64) * w
+    for share in (0.25, 0.5, 0.8):
+        c = np.quantile(cos_s, 1.0 - share)                                   # cone holding `share` of the samples
+        assert abs(float(mass[cos_q >= c].sum()) - share) < 0.015, (share, c)
+
+
+def test_cosine_and_refraction_lobe_samplers_match_their_pdfs(built):
+    """GenerateCosineWeightedDirection (:1025-1046): pdf cos/pi, mean cosine 2/3.  The refraction lobe (:1048-1064):
+    reports pdf (m + 1) cos^m / (2 pi) with m = (1 - roughness)^5 * 1000, and draws cos = sqrt(u^(1 / (m + 1)))."""
+    L = ol.lib(); fp = C.POINTER(C.c_float)
+    L.tbo_sample_directions.restype = None
+    L.tbo_sample_directions.argtypes = [C.c_int, C.c_float, C.c_float, fp, fp, C.c_float, C.c_uint32, fp, fp]
+    n = np.array([0.36, 0.8, -0.48], np.float32); n /= np.linalg.norm(n)
+    N = 200000
+    d = np.empty((N, 3), np.float32); pdf = np.empty(N, np.float32)
+    L.tbo_sample_directions(2, 0.11, 0.0, None, n.ctypes.data_as(fp), 0.0, N, d.ctypes.data_as(fp), pdf.ctypes.data_as(fp))
+    cos = d.astype(np.float64) @ n
+    assert np.all(cos > -1e-5) and abs(cos.mean() - 2.0 / 3.0) < 3e-3
+    assert np.allclose(pdf, np.sqrt(np.maximum(1e-6, cos ** 2)) / math.pi, atol=2e-3)
+    for c in (0.3, 0.6, 0.9):
+        assert abs((cos <= c).mean() - c * c) < 0.01                   # P(cos <= c) = c^2 under the density cos / pi
+    for rough in (0.2, 0.5, 0.8):
+        mlobe = (1.0 - rough) ** 5 * 1000.0
+        L.tbo_sample_directions(1, 0.23, 0.0, None, n.ctypes.data_as(fp), rough, N, d.ctypes.data_as(fp), pdf.ctypes.data_as(fp))
+        cos = np.clip(d.astype(np.float64) @ n, 0, 1)
+        # as written (:1053-1055) cos(phi) = sqrt(u1^(1 / (m + 1))), i.e. P(cos <= c) = c^(2 (m + 1)): a lobe of exponent 2 m + 1, not the
+        # exponent m of the PDFValue it reports -- a quirk of the reference (the caller's division by that pdf is commented out,
+        # :1556-1557 "Overly darkens rough refractions for some reason"); the restatement must reproduce the sampler as written
+        k2 = 2.0 * (mlobe + 1.0)
+        zero = float((cos < 1e-6).mean())          # rand() == 0 exactly (test_reference_rng_resolution) puts the direction into the surface plane
+        assert zero < 1.0 / 150
+        assert abs(cos.mean() - (1.0 - zero) * k2 / (k2 + 1.0)) < 1.5e-3, rough
+        for q in (0.2, 0.5, 0.8):
+            assert abs((cos <= q ** (1.0 / k2)).mean() - q) < 0.01, (rough, q)
+        ok = cos > 1e-6                              # (the in-plane samples report pow(cos(pi / 2) < 0, m) = NaN, as HLSL would)
+        assert np.allclose(pdf[ok], (mlobe + 1) * cos[ok] ** mlobe / (2 * math.pi), rtol=5e-2, atol=1e-3), rough
+
+
+def test_direct_light_on_cornell_floor_is_analytic_to_one_and_a_half_percent(cornell_host, settings):
+    """test_oracle_known_answers.py checks this at 8 % / 64 spp; here 4 096 spp and 1.5 %: NEE estimator (uniform triangle pick,
+    uniform barycentrics, pdf 1 / (n * area), cos cos / r^2), matte BRDF, camera."""
+    s = copy.copy(settings); s.MaxBounces = 1
+    view = cornell_host.view()
+    W = H = 64
+    pf = cornell_host.frame_constants(s, 0, 0.0)
+    rows, cols = (62, 64), (18, 22)
+    img = ol.render(view, pf, W, H, 4096, y0=rows[0], y1=rows[1], threads=8)["output"]
+    rgb = img[..., :3] / np.maximum(img[..., 3:], 1)
+    n = 256
+    xs = np.linspace(-0.24, 0.23, n, endpoint=False) + 0.47 / n / 2
+    zs = np.linspace(-0.22, 0.16, n, endpoint=False) + 0.38 / n / 2
+    X, Z = np.meshgrid(xs, zs)
+    got, expect = [], []
+    for y in range(*rows):
+        for x in range(*cols):
+            acc = np.zeros(3)
+            # the pixel integrates over its footprint (box filter): average the closed form over a 4 x 4 grid of sub-pixel positions
+            for jy in (0.125, 0.375, 0.625, 0.875):
+                for jx in (0.125, 0.375, 0.625, 0.875):
+                    o = (C.c_float * 3)(); d = (C.c_float * 3)()
+                    ol.lib().tbo_camera_ray(C.byref(pf), 2.0, W, H, x + 0.5, H - (y + 0.5), jx, jy, C.byref(o), C.byref(d))
+                    t = -o[1] / d[1]
+                    P = np.array([o[0] + t * d[0], 0.0, o[2] + t * d[2]])
+                    dx, dy, dz = X - P[0], 1.98 - P[1], Z - P[2]
+                    r2 = dx * dx + dy * dy + dz * dz
+                    cos = dy / np.sqrt(r2)
+                    Eirr = (cos * cos / r2).sum() * (0.47 / n) * (0.38 / n)
+                    acc += np.array([0.725, 0.71, 0.68]) / math.pi * np.array([17.0, 12.0, 4.0]) * Eirr
+            expect.append(acc / 16.0); got.append(rgb[y, x])
+    got, expect = np.mean(got, axis=0), np.mean(expect, axis=0)
+    assert np.all(np.abs(got - expect) / expect < 0.015), (got, expect)
+
+
+def test_glass_slab_snell_and_beer_lambert(built, settings):
+    """Clear absorbing glass (IOR 1.5, absorption sigma, no scattering, NO_SPECULAR so that every path refracts): through a slab of
+    thickness d the radiance is L exp(-sigma d / cos(theta_t)), sin(theta_t) = sin(theta_i) / 1.5 (kernel.glsl:1531-1536,1612-1613,
+    1636-1640).  Facing slab: theta_i ~ 0; slab turned by 45 degrees: the path inside is 1 / cos(asin(sin 45 / 1.5)) = 1.134 times
+    longer, not the 1.414 of an unrefracted ray.  The refraction lobe of roughness 0 (exponent 1000) blurs directions by ~2.5
+    degrees, which moves the expectation by well under the 1.5 % tolerance."""
+    h, view = _scene("slab")
+    Lenv = (1.0, 2.0, 0.5)
+    keep = _bind_constant_environment(view, Lenv)
+    sigma = (1.2, 0.6, 2.0)
+    _set_material(view, albedo=(0.0, 0.0, 0.0), absorption=sigma, scattering=(0.0, 0.0, 0.0), IOR=1.5, roughness=0.0,
+                  Flags=MAT_SSS | MAT_NO_SPECULAR | MAT_NO_ALPHA)
+    s = copy.copy(settings); s.MaxBounces = 2
+    W, H = 32, 8
+    pf = h.frame_constants(s, 0, 0.0)
+    img = ol.render(view, pf, W, H, 2048, threads=8)["output"]
+    rgb = img[..., :3] / img[..., 3:]
+    lens = h.camera().LensHeight
+
+    def expected(px, py):
+        """Which slab the pixel's centre ray enters (well inside its front face), and the closed form there; None elsewhere."""
+        o = (C.c_float * 3)(); d = (C.c_float * 3)()
+        ol.lib().tbo_camera_ray(C.byref(pf), lens, W, H, px + 0.5, H - (py + 0.5), 0.5, 0.5, C.byref(o), C.byref(d))
+        o, d = np.array(o[:], np.float64), np.array(d[:], np.float64)
+        for centre, tilt_deg, half in (((-4.0, 0.0, 0.0), 0.0, 3.0), ((4.0, 0.0, 0.0), 45.0, 3.0)):
+            a = math.radians(tilt_deg)
+            nrm = np.array([math.sin(a), 0.0, math.cos(a)]); along = np.array([math.cos(a), 0.0, -math.sin(a)])   # Rotate 45 about y
+            front = np.array(centre) + 0.25 * nrm
+            t = float(np.dot(front - o, nrm) / np.dot(d, nrm))
+            hit = o + t * d - np.array(centre)
+            if abs(float(np.dot(hit, along))) < half - 1.0 and abs(hit[1]) < 1.0:       # a margin wider than the lateral shift inside the glass
+                cos_i = abs(float(np.dot(d, nrm)))
+                sin_t = math.sqrt(max(0.0, 1 - cos_i * cos_i)) / 1.5
+                return tilt_deg, np.array(Lenv) * np.exp(-np.array(sigma) * 0.5 / math.sqrt(1 - sin_t * sin_t)), cos_i
+        return None
+    seen = {0.0: 0, 45.0: 0}
+    for px in range(W):
+        for py in range(H):
+            e = expected(px, py)
+            if e is None: continue
+            seen[e[0]] += 1
+            assert np.all(np.abs(rgb[py, px] - e[1]) / e[1] < 0.015), (px, py, e[0], rgb[py, px], e[1])
+            if e[0] == 45.0:   # what an unrefracted ray through the tilted slab would give: clearly not what is rendered
+                straight = np.array(Lenv) * np.exp(-np.array(sigma) * 0.5 / e[2])
+                assert np.all(np.abs(rgb[py, px] - straight) / straight > 0.04)
+    assert seen[0.0] >= 8 and seen[45.0] >= 4, seen
+    assert np.allclose(rgb[0, 0], Lenv, rtol=1e-5) or np.allclose(rgb[0, W - 1], Lenv, rtol=1e-5)   # past the slabs: the environment itself
+    del keep

@@ -207,3 +207,37 @@ def test_two_level_radiance_bit_exact(gpu_tb, settings, builder):
             assert getattr(st, k) == getattr(rs, k), k
     finally:
         gpu_tb.SetOption("count_rays", 0)
+
+
+@pytest.mark.gpu
+def test_two_level_alpha_tested_instances_bit_exact(gpu_tb, settings):
+    """IsValidHit on candidate hits of instanced geometry (RayGenCommon.h:423-434): fixture alpha-card/instanced.pbrt, the alpha-tested
+    card as an object instanced twice, walked two-level.  Filter off and on against the oracle -- radiance and closest hits -- and the
+    two pictures differ (round 2 skipped the filter in the two-level walk)."""
+    scene = os.path.join(GOLDEN, "scenes", "alpha-card", "instanced.pbrt")
+    gpu_tb.SetOption("flatten_instances", 0)
+    try:
+        gpu_tb.LoadScene(scene)
+    finally:
+        gpu_tb.SetOption("flatten_instances", 1)
+    view = gpu_tb.HostSceneView()
+    assert view.numInstances == 3
+    s = copy.copy(settings); s.MaxBounces = 3
+    rng = np.random.default_rng(2)
+    o = np.tile(np.array([[0.0, 1.0, 4.0]], np.float32), (5000, 1))
+    d = (rng.uniform([-2.0, 0.0, 0.0], [2.0, 2.4, 1.0], (5000, 3)) - o).astype(np.float32); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    pictures, hits = [], []
+    try:
+        for on in (0, 1):
+            gpu_tb.SetOption("alpha_test", on); ol.set_alpha_test(on)
+            gpu_tb.InvalidateHistory(); gpu_tb.Render(W, H, F, s, 0.0)
+            out = gpu_tb.ReadAccumulation()
+            ref = ol.render(view, gpu_tb.FrameConstants(W, H, 0, s, 0.0), W, H, F, threads=8)["output"]
+            assert np.array_equal(bits(out), bits(ref)), on
+            g = gpu_tb.TraceClosest(o, d); c = ol.trace_closest(view, o, d)
+            for k in ("t", "bary"): assert np.array_equal(bits(g[k]), bits(c[k])), (on, k)
+            for k in ("prim", "geom", "material"): assert np.array_equal(g[k], c[k]), (on, k)
+            pictures.append(out); hits.append(g["geom"].copy())
+    finally:
+        gpu_tb.SetOption("alpha_test", 0); ol.set_alpha_test(0)
+    assert np.any(pictures[0] != pictures[1]) and np.any(hits[0] != hits[1])    # rays pass through the transparent texels of the cards

@@ -122,6 +122,7 @@ struct tb_context {
     std::map<std::string, int64_t> options;
     float lastMs = 0.0f;
     std::string lastVariant;
+    int lastNodeLayout = 0; /* 1: the last render walked the compact layout-C nodes */
 };
 
 namespace {
@@ -306,6 +307,45 @@ void BuildBvhGpu(tb_context* c, HostScene& s, uint32_t treeletPasses)
     for (DevBuf* b : {&dPos, &dIdx, &dGeo, &dPrim, &dFlag, &dA, &dNodes, &dTris, &dScratch, &dHeight}) b->release();
 }
 
+/* Layout C (tb_abi.h TbNodeC): the layout-B nodes, same order, boxes rounded outward onto a 16-bit grid over the root box.
+ * A quantised box [c - h, c + h] contains its layout-B box with at least an eighth of a cell to spare on every side, which is
+ * what covers the different rounding of the two slab computations (the kernel evaluates q * (cell * inv) - (o - origin) * inv
+ * where layout B evaluates c * inv - o * inv: errors of a few ulp of |c * inv| + |o * inv|, i.e. below 2^-6 cells while ray origin
+ * and box lie within a few scene extents of each other). */
+void buildCompactNodes(const HostScene& s, std::vector<TbNodeC>& out, TbQuantFrame& q, uint32_t nodeUnits)
+{
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    auto grow = [&](const float* cc, const float* hh, int k) { for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], (double)cc[a * 2 + k] - hh[a * 2 + k]); hi[a] = std::max(hi[a], (double)cc[a * 2 + k] + hh[a * 2 + k]); } };
+    auto boxOf = [](const TbNodeB& n, float* cc, float* hh) { /* [axis * 2 + child] */
+        cc[0] = n.cx[0]; cc[1] = n.cx[1]; cc[2] = n.cy[0]; cc[3] = n.cy[1]; cc[4] = n.cz[0]; cc[5] = n.cz[1];
+        hh[0] = n.hx[0]; hh[1] = n.hx[1]; hh[2] = n.hy[0]; hh[3] = n.hy[1]; hh[4] = n.hz[0]; hh[5] = n.hz[1];
+    };
+    auto isPad = [](const TbNodeB& n) { return n.left == TB_BVH_LEAF_FLAG && n.right == TB_BVH_LEAF_FLAG && n.hx[0] == 0.0f && n.hx[1] == 0.0f && n.cx[0] == 0.0f && n.cx[1] == 0.0f; };
+    for (const TbNodeB& n : s.nodesB) { if (isPad(n)) continue; float cc[6], hh[6]; boxOf(n, cc, hh); grow(cc, hh, 0); grow(cc, hh, 1); }
+    double ext = 0; for (int a = 0; a < 3; a++) ext = std::max(ext, hi[a] - lo[a]);
+    if (!(ext > 0)) ext = 1.0;
+    for (int a = 0; a < 3; a++) {
+        const double e = std::max(hi[a] - lo[a], ext * 1e-6); /* flat scenes: keep the cell finite */
+        q.origin[a] = (float)(lo[a] - 0.002 * e); q.cell[a] = (float)(e * 1.004 / 65535.0);
+        if (!((double)q.origin[a] + 2.0 * q.cell[a] <= lo[a])) q.origin[a] = (float)(lo[a] - 0.004 * e - 4.0 * q.cell[a]); /* fp32 rounding of the origin itself */
+    }
+    out.assign(s.nodesB.size(), TbNodeC{});
+    auto ref = [nodeUnits](uint32_t r) { return (r & TB_BVH_LEAF_FLAG) ? (TB_BVH_LEAF_FLAG | ((r & ~TB_BVH_LEAF_FLAG) * 3u)) : r * nodeUnits; };
+    for (size_t i = 0; i < s.nodesB.size(); i++) {
+        const TbNodeB& n = s.nodesB[i]; TbNodeC& o = out[i];
+        o.left = ref(n.left); o.right = ref(n.right);
+        if (isPad(n)) continue;
+        float cc[6], hh[6]; boxOf(n, cc, hh);
+        for (int a = 0; a < 3; a++) for (int k = 0; k < 2; k++) {
+            const double bl = ((double)cc[a * 2 + k] - hh[a * 2 + k] - q.origin[a]) / q.cell[a], bh = ((double)cc[a * 2 + k] + hh[a * 2 + k] - q.origin[a]) / q.cell[a];
+            long ql = (long)std::floor(bl - 0.125), qh = (long)std::ceil(bh + 0.125);
+            if (ql < 0 || qh > 65535 || !(bl == bl) || !(bh == bh)) throw std::runtime_error("compact nodes: a box lies outside the quantisation grid");
+            const long cq = (ql + qh) >> 1, hq = qh - cq; /* cq - hq <= ql and cq + hq == qh */
+            o.c[a][k] = (uint16_t)cq; o.h[a][k] = (uint16_t)hq;
+        }
+    }
+}
+
 void finalizeScene(tb_context* c)
 {
     HostScene& s = c->scene;
@@ -334,6 +374,12 @@ void finalizeScene(tb_context* c)
         d.nodes = upload(c, dev);
     }
     d.tris = upload(c, s.trisB);
+    d.nodesC = nullptr;
+    if (!twoLevel && !(s.rootRefB & TB_BVH_LEAF_FLAG)) { /* layout C beside layout B (32 B per node more); option "node_layout" = 1 selects it at render time */
+        std::vector<TbNodeC> compact;
+        buildCompactNodes(s, compact, d.quant, 2u);
+        d.nodesC = upload(c, compact);
+    }
     d.rootRef = twoLevel ? ((s.rootRefB & TB_BVH_LEAF_FLAG) ? (TB_BVH_LEAF_FLAG | ((s.rootRefB & ~TB_BVH_LEAF_FLAG) * 4u)) : s.rootRefB * 4u) : deviceRef(s.rootRefB, 4); /* 0 or LEAF|0: the same in both images */ d.numNodes = (uint32_t)s.nodesB.size(); d.numTris = (uint32_t)s.trisB.size();
     { const TbAabbNode* root = (const TbAabbNode*)((twoLevel ? s.tlasA.data() : s.bvhA.data()) + 16); memcpy(d.rootCenter, root->center, 12); memcpy(d.rootHalf, root->halfDim, 12); }
     {   /* instances in their device form: the bottom-level root as a device child ref */
@@ -561,7 +607,7 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
     const bool wavefront = opt("pipeline", 0) == 2 && v->wf && !count && !aov;
     const bool pooled = opt("pipeline", 0) == 3 && v->pooled && !count && !aov;
     const int64_t fg = opt("frame_group", 0);
-    const bool groups = !wavefront && !pooled && opt("pipeline", 0) == 0 && !count && !aov && !s.RenderModeRealTime && fg >= 0 && (fg > 0 || n >= (c->sceneInLds ? 1u : 2u)); /* measured: frame groups win from 2 frames per call on (cornell-box 4 spp +23 %, 870 k scene 4 spp 2x); one frame per call: +17 % with the scene in LDS, -9 % on the 870 k scene */
+    const bool groups = !wavefront && !pooled && opt("pipeline", 0) == 0 && !count && !aov && !s.RenderModeRealTime && c->selX == 0xffffffffu && fg >= 0 && (fg > 0 || n >= (c->sceneInLds ? 1u : 2u)); /* measured: frame groups win from 2 frames per call on (cornell-box 4 spp +23 %, 870 k scene 4 spp 2x); one frame per call: +17 % with the scene in LDS, -9 % on the 870 k scene */
     /* Which copy of the feature set: the higher-occupancy one when its workgroups fit in LDS.  LDS per workgroup = 1 KB per stack
      * entry (+ the scene image); where the tree is too deep for that, a frame-group launch may still use the copy with a split
      * stack -- as many entries in LDS as fit, the deepest few (option "stack_overflow_max", default 16) in global memory. */
@@ -585,6 +631,10 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
             }
         }
     }
+    /* Compact nodes (option "node_layout" = 1): in the frame-group kernels of the higher-occupancy copies, scenes fetched from memory */
+    const bool compactNodes = opt("node_layout", 0) == 1 && c->ds.nodesC && v->fnHi && launch == v->fnHi && groups && !c->sceneInLds;
+    if (!compactNodes) dsLaunch.nodesC = nullptr;
+    c->lastNodeLayout = compactNodes ? 1 : 0;
     /* launches of the kernels without the EXT features (no selected pixel, no AOVs: nothing but the sample buffer is written)
      * may overlap the drain of the launch before them */
     const bool overlap = groups && v->features != PT_FEAT_ALL && opt("overlap_launches", 1) != 0;
@@ -633,8 +683,9 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
              * call and not into whichever later call happens to reach the second stream. */
             if (overlap && std::find(c->warmedLaunchers.begin(), c->warmedLaunchers.end(), (const void*)launch) == c->warmedLaunchers.end()) {
                 TbDeviceTargets none = tg; none.samples = nullptr;
+                TbDeviceScene dsWarm = c->ds; dsWarm.nodesC = nullptr; /* the one-pixel-per-lane twin fetches layout B */
                 for (uint32_t par = 0; par < 2; par++)
-                    HIP_TRY(launch(c->side[par], &c->ds, &pf, &none, W, H, c->samplesRendered, 0, &c->tiles, c->sceneInLds ? 1 : 0, 0, 0));
+                    HIP_TRY(launch(c->side[par], &dsWarm, &pf, &none, W, H, c->samplesRendered, 0, &c->tiles, c->sceneInLds ? 1 : 0, 0, 0));
                 c->warmedLaunchers.push_back((const void*)launch);
             }
             /* both sample buffers are sized -- and touched once, a fresh allocation is mapped lazily -- by the first call that needs
@@ -1076,7 +1127,7 @@ int tb_unpack_gathered_host(uint32_t W, uint32_t H, uint32_t world, uint32_t tw,
 int tb_set_option(tb_context* c, const char* name, int64_t v)
 {
     if (!c || !name) return TB_E_INVALID;
-    static const char* known[] = {"pipeline", "count_rays", "bvh_builder", "flatten_instances", "aov", "scene_in_lds", "lds_scene_budget", "force_full_variant", "wavefront_paths", "wavefront_grid", "wavefront_segment", "pooled_paths", "pooled_samples", "pooled_profile", "park_min", "alpha_test", "node_order", "node_order_top_levels", "frame_group", "overlap_launches", "high_occupancy", "stack_lds_cap", "stack_overflow_max", "flip_texture_uvs", "wavefront_sort", "banded_items"};
+    static const char* known[] = {"pipeline", "count_rays", "bvh_builder", "flatten_instances", "aov", "scene_in_lds", "lds_scene_budget", "force_full_variant", "wavefront_paths", "wavefront_grid", "wavefront_segment", "pooled_paths", "pooled_samples", "pooled_profile", "park_min", "alpha_test", "node_order", "node_order_top_levels", "frame_group", "overlap_launches", "high_occupancy", "stack_lds_cap", "stack_overflow_max", "flip_texture_uvs", "wavefront_sort", "banded_items", "node_layout"};
     for (const char* k : known) if (!strcmp(k, name)) { c->options[name] = v; if (!strcmp(name, "count_rays") || !strcmp(name, "aov")) c->samplesRendered = 0; return TB_OK; }
     return fail(c, TB_E_INVALID, std::string("unknown option '") + name + "'");
 }
@@ -1087,6 +1138,7 @@ int64_t tb_get_option(tb_context* c, const char* name)
     if (!strcmp(name, "scene_features")) return c->sceneFeatures;
     if (!strcmp(name, "last_kernel_us")) return (int64_t)(c->lastKernelMs * 1000.0f + 0.5f); /* first path-tracing launch of the last synchronous render */
     if (!strcmp(name, "last_kernel_frames")) return c->lastKernelFrames;
+    if (!strcmp(name, "last_node_layout")) return c->lastNodeLayout; /* 0: layout B (64-B nodes), 1: layout C (32-B nodes on the 16-bit grid) */
     if (!strcmp(name, "last_pipeline")) return c->lastPipeline; /* the pipeline the last render actually ran (2 / 3 fall back to 0 for feature sets they lack) */
     if (!strcmp(name, "last_variant")) { for (const Variant& k : kVariants) if (c->lastVariant == k.name) return k.id; return -1; } /* 0 matte 1 env 2 surf 3 vol 4 full 5 sss */
     auto it = c->options.find(name); return it == c->options.end() ? 0 : it->second;
@@ -1125,7 +1177,9 @@ int tb_trace_closest(tb_context* c, uint32_t n, const float* origins, const floa
         in(dO, origins, (size_t)n * 12); in(dD, dirs, (size_t)n * 12);
         ensure(dT.b, (size_t)n * 4); ensure(dM.b, (size_t)n * 4); ensure(dB.b, (size_t)n * 8); ensure(dP.b, (size_t)n * 4); ensure(dG.b, (size_t)n * 4);
         ensure(dN.b, (size_t)n * 12); ensure(dU.b, (size_t)n * 8); ensure(dBx.b, (size_t)n * 4); ensure(dTr.b, (size_t)n * 4);
-        HIP_TRY(pt_launch_trace_closest(c->stream, &c->ds, n, (const float*)dO.b.p, (const float*)dD.b.p, (float*)dT.b.p, (int*)dM.b.p, (float*)dB.b.p, (uint32_t*)dP.b.p,
+        TbDeviceScene dsTrace = c->ds; /* option "node_layout" = 1: the batch walks the compact nodes too (one-level scenes) */
+        { auto it = c->options.find("node_layout"); if (it == c->options.end() || it->second != 1 || dsTrace.numInstances) dsTrace.nodesC = nullptr; }
+        HIP_TRY(pt_launch_trace_closest(c->stream, &dsTrace, n, (const float*)dO.b.p, (const float*)dD.b.p, (float*)dT.b.p, (int*)dM.b.p, (float*)dB.b.p, (uint32_t*)dP.b.p,
                                         (uint32_t*)dG.b.p, (float*)dN.b.p, (float*)dU.b.p, (uint32_t*)dBx.b.p, (uint32_t*)dTr.b.p));
         HIP_TRY(hipStreamSynchronize(c->stream));
         auto outc = [&](void* h, Tmp& t, size_t bytes) { if (h) HIP_TRY(hipMemcpy(h, t.b.p, bytes, hipMemcpyDeviceToHost)); };

@@ -165,6 +165,35 @@ TBD void box_test2(bool& lh, bool& rh, float& lt, float& rt, float closest, cons
     lh = lt < tb_min(tmaxL, closest); rh = rt < tb_min(tmaxR, closest);
 }
 
+/* Layout C (tb_abi.h TbNodeC): both boxes as centre / half-extent on the 16-bit grid ds.quant, fetched with two aligned 16-B loads.
+ * The ray's slab constants are taken into grid units once per ray (ray_to_grid), after which the arithmetic is box_test2()'s:
+ * mid = c * inv - o * inv with c = origin + cell * q becomes q * (cell * inv) - (o - origin) * inv. */
+struct __attribute__((aligned(16))) NodeC16 { uint32_t cx, cy, cz, hx, hy, hz, left, right; };
+TBD NodeC16 load_node_c(const TbDeviceScene& ds, uint32_t ref) { return *(const NodeC16*)((const uint8_t*)ds.nodesC + ((size_t)ref << 4)); }
+TBD tbf2 f2_u16x2(uint32_t w) { tbf2 r; r.x = (float)(w & 0xffffu); r.y = (float)(w >> 16); return r; } /* v_cvt_f32_u32 with an SDWA word select each */
+
+TBD void ray_to_grid(RayPre& r, const TbDeviceScene& ds, tb3 o)
+{
+    const tb3 cell = ld3(ds.quant.cell), org = ld3(ds.quant.origin);
+    r.oinv = (o - org) * r.inv;          /* r.inv already carries the degenerate-axis substitution (2^80: the product stays exact) */
+    r.inv = r.inv * cell; r.ainv = r.ainv * cell;
+}
+
+TBD void box_test2_c(bool& lh, bool& rh, float& lt, float& rt, float closest, const RayPre& r, const NodeC16& n)
+{
+    const tbf2 cx = f2_u16x2(n.cx), cy = f2_u16x2(n.cy), cz = f2_u16x2(n.cz), hx = f2_u16x2(n.hx), hy = f2_u16x2(n.hy), hz = f2_u16x2(n.hz);
+    const tbf2 mx = __builtin_elementwise_fma(cx, f2_splat(r.inv.x), f2_splat(-r.oinv.x));
+    const tbf2 my = __builtin_elementwise_fma(cy, f2_splat(r.inv.y), f2_splat(-r.oinv.y));
+    const tbf2 mz = __builtin_elementwise_fma(cz, f2_splat(r.inv.z), f2_splat(-r.oinv.z));
+    const tbf2 hix = __builtin_elementwise_fma(hx, f2_splat(r.ainv.x), mx), lox = __builtin_elementwise_fma(-hx, f2_splat(r.ainv.x), mx);
+    const tbf2 hiy = __builtin_elementwise_fma(hy, f2_splat(r.ainv.y), my), loy = __builtin_elementwise_fma(-hy, f2_splat(r.ainv.y), my);
+    const tbf2 hiz = __builtin_elementwise_fma(hz, f2_splat(r.ainv.z), mz), loz = __builtin_elementwise_fma(-hz, f2_splat(r.ainv.z), mz);
+    const float tminL = tb_max(tb_max(lox.x, loy.x), loz.x), tmaxL = tb_min(tb_min(hix.x, hiy.x), hiz.x);
+    const float tminR = tb_max(tb_max(lox.y, loy.y), loz.y), tmaxR = tb_min(tb_min(hix.y, hiy.y), hiz.y);
+    lt = tb_max(tminL, 0.0f); rt = tb_max(tminR, 0.0f);
+    lh = lt < tb_min(tmaxL, closest); rh = rt < tb_min(tmaxR, closest);
+}
+
 struct Hit { float t, u, v; uint32_t prim, geom; };
 
 /* Woop/Benthin/Wald watertight test, two-sided branch: RayTriangleIntersect :232-313 + :420-426 */
@@ -174,7 +203,7 @@ struct Hit { float t, u, v; uint32_t prim, geom; };
 TBD bool is_valid_hit(const SceneRefs& sc, const TbDeviceScene& ds, uint32_t geom, uint32_t prim, float u, float v);
 
 template <bool ALPHA>
-TBD void tri_test(Hit& best, float tMin, tb3 o, const RayPre& r, const TbTriB& tri, bool permuted, const SceneRefs& sc, const TbDeviceScene& ds)
+TBD void tri_test(Hit& best, float tMin, tb3 o, const RayPre& r, const TbTriB& tri, bool permuted, const SceneRefs& sc, const TbDeviceScene& ds, uint32_t geomBase = 0u)
 {
     float Az, Bz, Cz, U, V, W;
     if (permuted) {
@@ -212,9 +241,10 @@ TBD void tri_test(Hit& best, float tMin, tb3 o, const RayPre& r, const TbTriB& t
     if (t0 < best.t && t0 > tMin) {
         const float bu = V * rcpDet, bv = W * rcpDet;
         /* non-opaque candidate (D3D12_RAYTRACING_GEOMETRY_FLAG_OPAQUE clear): RayGenCommon.h:423-434 */
-        if (ALPHA && ds.alphaTest && !(tri.geometryFlags & 1u) && !is_valid_hit(sc, ds, tri.geometryIndex, tri.primitiveIndex, bu, bv)) return;
+        /* geomBase: InstanceContributionToHitGroupIndex of the instance being walked (two-level scenes), :427 */
+        if (ALPHA && ds.alphaTest && !(tri.geometryFlags & 1u) && !is_valid_hit(sc, ds, tri.geometryIndex + geomBase, tri.primitiveIndex, bu, bv)) return;
         best.t = t0; best.u = bu; best.v = bv;
-        best.prim = tri.primitiveIndex; best.geom = tri.geometryIndex;
+        best.prim = tri.primitiveIndex; best.geom = tri.geometryIndex + geomBase;
     }
 }
 
@@ -235,7 +265,9 @@ TBD void prof_hit(WaveProf* p, int slot)
     if ((int)(threadIdx.x & 63u) == __ffsll((long long)m) - 1) p->v[slot + 1] += 1; /* wave trips */
 }
 
-template <bool COUNT, bool HYBRID = false>
+/* COUNT: box / triangle counters and the wave-occupancy profile; ALPHA: the IsValidHit filter on non-opaque candidates is compiled in
+ * (it still needs ds.alphaTest at run time); HYBRID: split stack; NODEC: fetch layout-C nodes (ds.nodesC) instead of layout B. */
+template <bool COUNT, bool ALPHA, bool HYBRID = false, bool NODEC = false>
 TBD bool traverse(const SceneRefs& sc, const TbDeviceScene& ds, tb3 o, tb3 d, Hit& best, uint32_t* stack, uint32_t stride,
                   uint32_t& boxes, uint32_t& tris, WaveProf* prof = nullptr, uint32_t* overflow = nullptr)
 {
@@ -243,6 +275,7 @@ TBD bool traverse(const SceneRefs& sc, const TbDeviceScene& ds, tb3 o, tb3 d, Hi
     RayPre r = ray_prepare(o, d);
     float unusedT;
     if (!box_test(unusedT, best.t, r, ld3(ds.rootCenter), ld3(ds.rootHalf))) return false; /* :566-580 */
+    if (NODEC) ray_to_grid(r, ds, o);
     /* "while-while" scheduling: a lane that reaches a leaf parks on it until the other lanes of the
      * wave have reached theirs (or fewer than PARK_MIN are still descending), then the wave runs the
      * triangle test once for everybody.  Only the interleaving ACROSS lanes changes; each lane's own
@@ -260,20 +293,20 @@ TBD bool traverse(const SceneRefs& sc, const TbDeviceScene& ds, tb3 o, tb3 d, Hi
     while (ref != DONE) {
         while (!(ref & TB_BVH_LEAF_FLAG)) {
             if (COUNT) prof_hit(prof, PROF_INNER);
-            const TbNodeB n = load_node(sc, ref);
-            float lt, rt; bool lh, rh;
-            box_test2(lh, rh, lt, rt, best.t, r, n);
+            float lt, rt; bool lh, rh; uint32_t nl, nr;
+            if (NODEC) { const NodeC16 n = load_node_c(ds, ref); box_test2_c(lh, rh, lt, rt, best.t, r, n); nl = n.left; nr = n.right; }
+            else { const TbNodeB n = load_node(sc, ref); box_test2(lh, rh, lt, rt, best.t, r, n); nl = n.left; nr = n.right; }
             if (COUNT) boxes += 2;
             if (lh && rh) {
                 bool rightFirst = rt < lt;
-                const uint32_t far = rightFirst ? n.left : n.right;
+                const uint32_t far = rightFirst ? nl : nr;
                 /* HYBRID: the first ds.stackDepth entries in LDS, deeper ones (rare) in the lane's global overflow column */
                 if (HYBRID && top >= ds.stackDepth) overflow[(size_t)(top - ds.stackDepth) * ds.stackOverflowLanes] = far;
                 else stack[top * stride] = far;
                 top++;
-                ref = rightFirst ? n.right : n.left;
+                ref = rightFirst ? nr : nl;
             } else if (lh || rh) {
-                ref = rh ? n.right : n.left;
+                ref = rh ? nr : nl;
             } else {
                 ref = pop();
             }
@@ -283,7 +316,7 @@ TBD bool traverse(const SceneRefs& sc, const TbDeviceScene& ds, tb3 o, tb3 d, Hi
             if (COUNT) prof_hit(prof, PROF_LEAF);
             const TbTriB tri = load_tri(sc, sc.trisPermuted ? ref + r.permUnits : ref);
             if (COUNT) tris++;
-            tri_test<COUNT>(best, MIN_T, o, r, tri, sc.trisPermuted != 0, sc, ds);
+            tri_test<ALPHA>(best, MIN_T, o, r, tri, sc.trisPermuted != 0, sc, ds);
             ref = pop();
         }
     }
@@ -297,7 +330,7 @@ TBD bool traverse(const SceneRefs& sc, const TbDeviceScene& ds, tb3 o, tb3 d, Hi
  * -- whose own box is never tested (:625: StackPush(0)) -- until the stack is back at the height it had on entry; then the world
  * ray data are recomputed (:769-773) and the top level goes on.  Visit order at both levels as in traverse().  A plain
  * one-lane-one-ray loop: this is the functional path for instanced scenes, the single-level walk above is the tuned one.
- * The IsValidHit filter (option alpha_test) is not applied here. */
+ * ALPHA: the IsValidHit filter (option alpha_test) on non-opaque candidates of the bottom levels, RayGenCommon.h:423-434. */
 struct __attribute__((aligned(16))) InstB16 { TbInstanceB i; };
 TBD tb3 xfm_point34(const float* m, tb3 v) /* pinned order of the dp4: one fma chain per row, as host_scene / bvh_build / the oracle */
 {
@@ -309,7 +342,7 @@ TBD tb3 xfm_vector34(const float* m, tb3 v)
     return tb3_make(tb_fma(m[2], v.z, tb_fma(m[1], v.y, m[0] * v.x)), tb_fma(m[6], v.z, tb_fma(m[5], v.y, m[4] * v.x)), tb_fma(m[10], v.z, tb_fma(m[9], v.y, m[8] * v.x)));
 }
 
-template <bool COUNT>
+template <bool COUNT, bool ALPHA>
 TBD bool traverse_instanced(const SceneRefs& sc, const TbDeviceScene& ds, tb3 o, tb3 d, Hit& best, uint32_t* stack, uint32_t stride, uint32_t& boxes, uint32_t& tris)
 {
     best.t = MAX_T; best.u = best.v = 0.0f; best.prim = best.geom = 0u;
@@ -348,9 +381,9 @@ TBD bool traverse_instanced(const SceneRefs& sc, const TbDeviceScene& ds, tb3 o,
         } else {
             const TbTriB tri = load_tri(sc, ref);
             if (COUNT) tris++;
-            const float before = best.t;
-            tri_test<false>(best, MIN_T, ro, r, tri, false, sc, ds);
-            if (best.t != before) best.geom += hitBase; /* InstanceContributionToHitGroupIndex + GeometryContributionToHitGroupIndex */
+            /* committed record: InstanceContributionToHitGroupIndex + GeometryContributionToHitGroupIndex; the IsValidHit filter sees the
+             * same index (RayGenCommon.h:427: CandidateInstanceIndex() + CandidateGeometryIndex()) */
+            tri_test<ALPHA>(best, MIN_T, ro, r, tri, false, sc, ds, hitBase);
             ref = pop();
         }
     }
@@ -374,7 +407,7 @@ TBD bool trav_begin(Trav& t, const TbDeviceScene& ds, tb3 o, tb3 d) /* returns f
 }
 
 /* One while-while round for the lanes with `busy` set; clears `busy` when a lane's walk is complete. */
-template <bool COUNT, int PARK_MIN>
+template <bool COUNT, bool ALPHA, int PARK_MIN>
 TBD void trav_round(Trav& t, bool& busy, const SceneRefs& sc, const TbDeviceScene& ds, uint32_t* stack, uint32_t stride, WaveProf* prof)
 {
     while (busy && !(t.ref & TB_BVH_LEAF_FLAG)) {
@@ -399,7 +432,7 @@ TBD void trav_round(Trav& t, bool& busy, const SceneRefs& sc, const TbDeviceScen
             if (COUNT) prof_hit(prof, PROF_LEAF);
             const TbTriB tri = load_tri(sc, sc.trisPermuted ? t.ref + t.r.permUnits : t.ref);
             if (COUNT) t.tris++;
-            tri_test<COUNT>(t.best, MIN_T, t.r.o, t.r, tri, sc.trisPermuted != 0, sc, ds);
+            tri_test<ALPHA>(t.best, MIN_T, t.r.o, t.r, tri, sc.trisPermuted != 0, sc, ds);
             t.ref = t.top ? stack[(--t.top) * stride] : TRAV_DONE;
         }
         if (t.ref == TRAV_DONE) busy = false;
@@ -440,6 +473,14 @@ TBD void fetch_surface(const SceneRefs& sc, const Hit& h, Surface& s, bool needT
         s.tangent = tb3_normalize(tb3_bary(bx, by, bz, t0, t1, t2));
     } else s.tangent = tb3_splat(0.0f);
     s.material = (int)rec.MaterialIndex;
+}
+
+/* OutputDistanceToFirstHit + OutputMaterial for the selected pixel (RayGenCommon.h:632-648, called at kernel.glsl:1370-1371 for a
+ * primary ray that hit): StatsBuffer +8 = asuint(distance), +12 = the hit group's MaterialIndex (result.y, before any mix coin). */
+TBD void output_selected_pixel(uint32_t* stats, const SceneRefs& sc, const Hit& h)
+{
+    stats[2] = __float_as_uint(h.t);
+    stats[3] = h.geom < sc.numHitGroups ? sc.hitGroups[h.geom].MaterialIndex : 0u;
 }
 
 /* ---- textures: SharedRaytracing.h:55-137 -------------------------------------------------------- */

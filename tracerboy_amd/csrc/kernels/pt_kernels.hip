@@ -22,7 +22,9 @@
 
 namespace {
 
-/* Closest-hit batch for the traversal parity tests (IntersectWithMaxDistance, RayGenCommon.h:365-414) */
+/* Closest-hit batch for the traversal parity tests (IntersectWithMaxDistance, RayGenCommon.h:365-414); NODEC: through the compact
+ * layout-C nodes (one-level scenes) */
+template <bool NODEC>
 __global__ __launch_bounds__(BLOCK) void trace_closest_kernel(TbDeviceScene ds, uint32_t n, const float* origins, const float* dirs, float* outT, int* outMat,
                                                                float* outBary, uint32_t* outPrim, uint32_t* outGeom, float* outNormal, float* outUV,
                                                                uint32_t* outBoxes, uint32_t* outTris)
@@ -34,7 +36,9 @@ __global__ __launch_bounds__(BLOCK) void trace_closest_kernel(TbDeviceScene ds, 
     if (i >= n) return;
     tb3 o = ld3(origins + 3 * i), d = ld3(dirs + 3 * i);
     Hit h; uint32_t nb = 0, nt = 0;
-    bool hit = ds.numInstances ? traverse_instanced<true>(sc, ds, o, d, h, stack, BLOCK, nb, nt) : traverse<true>(sc, ds, o, d, h, stack, BLOCK, nb, nt);
+    bool hit;
+    if (NODEC) hit = traverse<true, true, false, true>(sc, ds, o, d, h, stack, BLOCK, nb, nt);
+    else hit = ds.numInstances ? traverse_instanced<true, true>(sc, ds, o, d, h, stack, BLOCK, nb, nt) : traverse<true, true>(sc, ds, o, d, h, stack, BLOCK, nb, nt);
     outT[i] = hit ? h.t : -1.0f;
     if (outBary) { outBary[2 * i] = hit ? h.u : 0.0f; outBary[2 * i + 1] = hit ? h.v : 0.0f; }
     if (outPrim) outPrim[i] = hit ? h.prim : 0xffffffffu;
@@ -141,9 +145,12 @@ hipError_t pt_launch_trace_closest(hipStream_t stream, const TbDeviceScene* ds, 
                                    float* outBary, uint32_t* outPrim, uint32_t* outGeom, float* outNormal, float* outUV, uint32_t* outBoxes, uint32_t* outTris)
 {
     size_t lds = (size_t)ds->stackDepth * BLOCK * 4;
-    hipError_t e = hipFuncSetAttribute((const void*)trace_closest_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (ds->nodesC && ds->numInstances) return hipErrorInvalidValue; /* layout C is built for one-level scenes */
+    const void* fn = ds->nodesC ? (const void*)trace_closest_kernel<true> : (const void*)trace_closest_kernel<false>;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(trace_closest_kernel, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), lds, stream, *ds, n, origins, dirs, outT, outMat, outBary, outPrim, outGeom, outNormal, outUV, outBoxes, outTris);
+    if (ds->nodesC) hipLaunchKernelGGL(trace_closest_kernel<true>, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), lds, stream, *ds, n, origins, dirs, outT, outMat, outBary, outPrim, outGeom, outNormal, outUV, outBoxes, outTris);
+    else hipLaunchKernelGGL(trace_closest_kernel<false>, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), lds, stream, *ds, n, origins, dirs, outT, outMat, outBary, outPrim, outGeom, outNormal, outUV, outBoxes, outTris);
     return hipGetLastError();
 }
 

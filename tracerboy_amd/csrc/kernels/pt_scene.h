@@ -26,6 +26,8 @@ struct __attribute__((aligned(16))) TbDevLight { TbLight l; uint32_t pad[2]; }; 
 struct TbDeviceScene {
     const TbNodeB* nodes;        /* layout B, breadth-first order: the first `ldsNodes` are the top of the tree */
     const TbTriB* tris;
+    const TbNodeC* nodesC;       /* layout C (tb_abi.h): the same tree, same storage order, 32-B nodes with boxes on a 16-bit grid; null unless built */
+    TbQuantFrame quant;          /* the grid of nodesC */
     uint32_t rootRef;            /* child-ref of the root (two-level scenes: of the top level, whose leaf refs are LEAF | instance index) */
     const TbInstanceB* instances; uint32_t numInstances; /* two-level scenes (flatten_instances = 0), else null / 0 */
     uint32_t numNodes, numTris;
