@@ -127,7 +127,12 @@ def pmc_summary(key):
     if not files:
         return None, None
     best = None
-    for name, passes in json.load(open(files[-1])).items():
+    doc = json.load(open(files[-1]))
+    from tracerboy_amd import build as tb_build
+    stamp = doc.pop("_kernel_digest", None)
+    stale = stamp != tb_build.kernel_digest()       # counters of other device code (or unstamped, pre-round-3 files)
+    for name, passes in doc.items():
+        passes["_stale"] = stale
         # pt_persistent<F, LDS, COUNT, GROUPS[, HYBRID]>: not the counters-on launch (COUNT = true), not the sample fold; the frame-group
         # kernel (GROUPS = true) is the timed one -- its one-pixel-per-lane twin only appears as the zero-frame warm launch
         m = re.search(r"pt_persistent<\d+u, (true|false), (true|false), (true|false)(?:, (?:true|false))?>", name)
@@ -388,6 +393,37 @@ def main():
     }
 
     if world > 1:
+        # ---- where a step's time goes, per rank (after the timed region, stages run one at a time with a device sync between them, so
+        #      the figures are each stage's own cost, not its share of the overlapped pipeline): this rank's own-tiles render, the
+        #      device-side pack of its tiles, the gather to rank 0 (RCCL over xGMI; every rank's buffer is `capacity` pixels) and rank 0's
+        #      device-side un-permute.  Per stage the MAX over ranks (the slowest rank is what a step waits for) and the mean.
+        stages = {"render_ms": [], "pack_ms": [], "gather_ms": [], "unpack_ms": []}
+        for _ in range(3):
+            barrier()
+            t = time.perf_counter(); tb.InvalidateHistory(); tb.Render(W, H, SPP, s, 0.0); stages["render_ms"].append((time.perf_counter() - t) * 1e3)
+            t = time.perf_counter(); tb.PackOwnedTo(packed[0].data_ptr(), sync=False); tb.Sync(); stages["pack_ms"].append((time.perf_counter() - t) * 1e3)
+            barrier()
+            t = time.perf_counter()
+            if backend == "nccl":
+                dist.gather(packed[0], gather_list if rank == 0 else None, dst=0); torch.cuda.synchronize()
+            else:
+                host = packed[0].cpu(); parts = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
+                dist.gather(host, parts, dst=0)
+                if rank == 0: gathered.copy_(torch.stack(parts)); torch.cuda.synchronize()
+            stages["gather_ms"].append((time.perf_counter() - t) * 1e3)
+            t = time.perf_counter()
+            if rank == 0:
+                tb.UnpackGatheredTo(gathered.data_ptr(), capacity, W, H, world, TILE, TILE, frame.data_ptr(), stream=torch.cuda.current_stream().cuda_stream); torch.cuda.synchronize()
+            stages["unpack_ms"].append((time.perf_counter() - t) * 1e3)
+        mine = torch.tensor([min(v) for v in stages.values()], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")   # best of 3 per stage
+        mx = mine.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = mine.clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        result["scale_breakdown"] = {k: round(float(mx[i]), 3) for i, k in enumerate(stages)}
+        result["scale_breakdown"].update({"mean_over_ranks": {k: round(float(sm[i]) / world, 3) for i, k in enumerate(stages)},
+                                          "gather_bytes_per_rank": int(capacity) * 16, "owned_pixels_rank0": int(owned),
+                                          "note": "stages run one at a time after the timed region (best of 3, max over ranks); in the timed steps render k+1 overlaps gather k"})
+        result["rccl_ranks"] = int(dist.get_world_size())
+        result["collective_backend"] = backend
         # after the timed region: the frame rank 0 assembled from the gathered tiles equals a single-GPU render of the whole frame
         if rank == 0:
             assembled = frame.cpu().numpy()
@@ -416,6 +452,8 @@ def main():
         hbm = hbm_roofline(avg_ms, launch_frames, pixels, st, passes, src)
         hbm["launch_timing"] = launch_timing
         insts = passes.get("lds", {}).get("SQ_INSTS_VALU") if passes else None
+        pmc_stale = bool(passes and passes.get("_stale"))
+        if pmc_stale: insts = None      # an instruction count of other code says nothing about this build's issue rate
         if lds:
             # LDS-resident scene: the algorithmic bytes never leave the CU; the resource the kernel can saturate is VALU issue
             roof = {"bound": "valu", "kernel": "pt_persistent", "unit": "Gwave-instr/s", "peak": round(VALU_PEAK_GINST, 1),
@@ -427,8 +465,10 @@ def main():
                              "frac_note": "counts every VALU instruction at the 2-cycle rate of v_fma/v_mul/v_add; the kernel's mix (v_pk_fma 3.3, min/max/cndmask 3.2-3.5, "
                                           "v_cmp 4, f64 3.1-3.7, rcp/sqrt 6.2 cycles: profiles/r2/valu_issue.txt) keeps the VALU pipe busy pipes.valu_busy of the time"})
             else:
-                roof.update({"achieved": None, "frac": None, "note": "no committed PMC pass for this workload: instruction count unknown"})
+                roof.update({"achieved": None, "frac": None, "note": ("the committed PMC passes (%s) were taken of other kernel code (kernel digest differs): re-run scripts/profile_bench.sh" % src) if pmc_stale
+                             else "no committed PMC pass for this workload: instruction count unknown"})
             roof["pipes"] = derived_busy(key, passes) if key else {}
+            roof["pmc_stale"] = pmc_stale
             roof["algorithmic"] = {k: hbm[k] for k in ("achieved", "unit", "algorithmic_bytes_per_sample", "boxes_per_sample", "tris_per_sample", "rays_per_sample")}
             roof["algorithmic"]["note"] = "SURVEY 8d byte model; served by the LDS scene image, not HBM (achieved / 8 TB/s = %.2f says nothing about HBM)" % (hbm["achieved"] / HBM_PEAK_GBS)
             result["roofline"] = roof
@@ -457,6 +497,7 @@ def main():
                        "kernel_variant": variant3,
                        "note": "launches of 128 frames are batched by the sample-buffer budget: avg_launch_ms / frames_per_launch are per batch launch"})
             r3["pipes"] = derived_busy("c3", passes3)
+            r3["pmc_stale"] = bool(passes3 and passes3.get("_stale"))   # true: the committed counters were taken of other kernel code
             # What the committed counters say limits it is not the fabric (traffic_frac_of_peak) but the issue of vector-memory and vector-ALU
             # instructions at ~19 of 64 lanes: the texture addresser is pipes.ta_busy busy, the VALU pipes.valu_busy.
             # `frac` is therefore the busier of the two pipes; the SURVEY 8d algorithmic rate / 8 TB/s stays under `algorithmic`.

@@ -29,7 +29,11 @@ for f in glob.glob(out + "/**/*counter_collection.csv", recursive=True):
         if not m or "63u" in m.group(1): continue
         agg[m.group(1)][r["Counter_Name"]] += float(r["Counter_Value"]); disp[(m.group(1), r["Counter_Name"])].add(r["Dispatch_Id"])
 res = {k: {c: v / max(1, len(disp[(k, c)])) for c, v in d.items()} for k, d in agg.items()}
+sys.path.insert(0, ".")
+from tracerboy_amd import build as tb_build
+res["_kernel_digest"] = {"digest": tb_build.kernel_digest()}
 json.dump(res, open("gpurun_out/pmcmem_%s.json" % tag, "w"), indent=1)
+del res["_kernel_digest"]
 for k, d in res.items():
     if d.get("SQ_WAVE_CYCLES", 0) < 1e6 and d.get("GRBM_GUI_ACTIVE", 0) < 1e7: continue
     print(k); print("  ", {c: (round(v / 1e6, 2) if v > 1000 else round(v, 3)) for c, v in sorted(d.items())})

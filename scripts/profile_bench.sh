@@ -38,8 +38,12 @@ for tag in ("fetch", "write", "sq", "lds", "tcc", "util"):
         for k, v in agg.items():
             d = len({s for s in seen if s[0][:80] == k})
             summary.setdefault(k, {})[tag] = {"dispatches": d, **{c: val / max(d, 1) for c, val in v.items()}}
+sys.path.insert(0, ".")
+from tracerboy_amd import build as tb_build
+summary["_kernel_digest"] = tb_build.kernel_digest()   # bench.py compares it with the code it runs
 open(out + "/pmc_summary.json", "w").write(json.dumps(summary, indent=1))
 for k, v in summary.items():
+    if k.startswith("_"): continue
     print(k, {t: {c: round(x / 1e6, 2) for c, x in d.items() if c != "dispatches"} for t, d in v.items()})
 PY
 cat $OUT/bench.json

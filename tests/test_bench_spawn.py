@@ -38,3 +38,22 @@ def test_without_gpu_the_bench_refuses_instead_of_falling_back(built):
         return
     r = run_bench("--steps", "1")
     assert r.returncode != 0 and "HIP-only" in (r.stderr + r.stdout)
+
+
+def test_cli_ranks_return_the_failing_ranks_status_and_leave_nothing_behind(built):
+    """tracerboy-hip --ranks N (the C++ host's own multi-GPU launcher): a rank that cannot get its device ends the others, the tool
+    returns THAT rank's exit status (not the 128 + SIGTERM of the ranks it stopped), and the private rendezvous directory of the RCCL
+    unique id (mkdtemp, mode 0700) is removed.  Runs the same way with no GPU (every rank fails) and with one (rank 1 has no device)."""
+    import glob
+    from conftest import CORNELL, ROOT
+    exe = os.path.join(ROOT, "tracerboy_amd", "tracerboy-hip")
+    before = set(glob.glob("/tmp/tracerboy-hip-rccl-*"))
+    r = subprocess.run([exe, CORNELL, "--ranks", "2", "--spp", "1", "--width", "64", "--height", "48", "--out", "/tmp/tb_never_written.pfm"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 1, (r.returncode, r.stderr[-2000:])
+    assert "tb_create failed" in r.stderr
+    assert set(glob.glob("/tmp/tracerboy-hip-rccl-*")) == before
+    # rank variables set by hand, incompletely: refused before anything is rendered
+    env = dict(os.environ, TB_CLI_RANK="1")
+    r = subprocess.run([exe, CORNELL], capture_output=True, text=True, timeout=60, env=env)
+    assert r.returncode == 2 and "TB_CLI_WORLD" in r.stderr

@@ -804,6 +804,11 @@ def test_bench_multi_rank_step_on_one_gpu(tmp_path):
     assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "tiles2" and out["config"]["tile"] == 64
     assert out["config"]["assembled_frame_equals_single_gpu"] is True
     assert out["value"] > 0 and out["scaling"] == "strong"
+    # the per-stage breakdown the driver's SCALE record needs to say where a step's time goes, and how many ranks the collective saw
+    sb = out["scale_breakdown"]
+    assert out["rccl_ranks"] == 2 and out["collective_backend"] == "gloo"
+    assert all(sb[k] > 0 for k in ("render_ms", "pack_ms", "gather_ms", "unpack_ms")) and sb["gather_bytes_per_rank"] > 0
+    assert set(sb["mean_over_ranks"]) == {"render_ms", "pack_ms", "gather_ms", "unpack_ms"}
 
 
 def test_headless_cli_native_rccl_gather_plumbing(tmp_path):

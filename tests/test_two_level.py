@@ -241,3 +241,52 @@ def test_two_level_alpha_tested_instances_bit_exact(gpu_tb, settings):
     finally:
         gpu_tb.SetOption("alpha_test", 0); ol.set_alpha_test(0)
     assert np.any(pictures[0] != pictures[1]) and np.any(hits[0] != hits[1])    # rays pass through the transparent texels of the cards
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["matte", "sss"])
+def test_two_level_tuned_kernel_copies_bit_exact(gpu_tb, settings, kind, tmp_path):
+    """The tuned two-level walk (while-while parking, split stack) of the frame-group kernels in the higher-occupancy copies of the
+    matte / env / sss / vol feature sets (TWOLEVEL kernels, pt_variant.inc): the instances fixture with its plastic / metal materials
+    turned into matte (feature set `matte`) or glass (feature set `sss`, interior walks through instanced geometry), 9 frames so that
+    the launch is a frame-group one, with the stack in LDS and split (stack_lds_cap = 3), against the oracle; a one-frame call of
+    the same scene goes through the full-feature kernels and must give the same first frame."""
+    text = open(SCENE).read()
+    if kind == "matte":
+        text = text.replace('"string type" ["plastic"] "rgb Kd" [0.1 0.3 0.7] "rgb Ks" [0.4 0.4 0.4] "float roughness" [0.1]', '"string type" ["matte"] "rgb Kd" [0.1 0.3 0.7]')
+        text = text.replace('"string type" ["metal"] "float uroughness" [0.15] "float vroughness" [0.15] "rgb eta" [0.9 0.9 0.9]', '"string type" ["matte"] "rgb Kd" [0.6 0.6 0.65]')
+        variant = 0
+    else:
+        text = text.replace('"string type" ["plastic"] "rgb Kd" [0.1 0.3 0.7] "rgb Ks" [0.4 0.4 0.4] "float roughness" [0.1]', '"string type" ["glass"] "float index" [1.45]')
+        variant = 5
+    assert text != open(SCENE).read()
+    path = tmp_path / "scene.pbrt"; path.write_text(text)
+    gpu_tb.SetOption("flatten_instances", 0)
+    try:
+        gpu_tb.LoadScene(str(path))
+    finally:
+        gpu_tb.SetOption("flatten_instances", 1)
+    view = gpu_tb.HostSceneView()
+    assert view.numInstances == 9
+    s = copy.copy(settings); s.MaxBounces = 5
+    ref = ol.render(view, gpu_tb.FrameConstants(W, H, 0, s, 0.0), W, H, 9, threads=8, jittered=True)
+    try:
+        for cap in (0, 3):
+            gpu_tb.SetOption("stack_lds_cap", cap); gpu_tb.SetOption("stack_overflow_max", 64 if cap else 16)
+            gpu_tb.InvalidateHistory(); gpu_tb.Render(W, H, 9, s, 0.0)
+            assert gpu_tb.GetOption("last_variant") == variant, (kind, cap)          # not the full feature set: the tuned copy ran
+            out, jit = gpu_tb.ReadAccumulation(jittered=True)
+            assert np.array_equal(bits(out), bits(ref["output"])) and np.array_equal(bits(jit), bits(ref["jittered"])), (kind, cap)
+    finally:
+        gpu_tb.SetOption("stack_lds_cap", 0); gpu_tb.SetOption("stack_overflow_max", 16)
+    gpu_tb.InvalidateHistory(); gpu_tb.Render(W, H, 1, s, 0.0)
+    assert gpu_tb.GetOption("last_variant") == 4
+    one = ol.render(view, gpu_tb.FrameConstants(W, H, 0, s, 0.0), W, H, 1, threads=8)["output"]
+    assert np.array_equal(bits(gpu_tb.ReadAccumulation()), bits(one))
+    # the other pipelines have no two-level walk: refused, not silently wrong
+    gpu_tb.SetOption("pipeline", 2)
+    try:
+        with pytest.raises(Exception):
+            gpu_tb.Render(W, H, 2, s, 0.0)
+    finally:
+        gpu_tb.SetOption("pipeline", 0)

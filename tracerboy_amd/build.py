@@ -29,7 +29,7 @@ COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "
 # 1 171 -> 1 213 Msamples/s; neither changes a result bit (-ffp-contract=off pins the arithmetic, tests/ -m gpu).
 DEVICE = ["--offload-arch=" + ARCH, "-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]
 
-HOST_SRCS = ["host/pbrt_loader.cpp", "host/pbf_loader.cpp", "host/host_scene.cpp", "host/images.cpp", "host/image_decode.cpp", "host/bvh_build.cpp", "host/procedural.cpp", "host/context.cpp", "host/pbrt_dump.cpp"]
+HOST_SRCS = ["host/pbrt_loader.cpp", "host/pbf_loader.cpp", "host/host_scene.cpp", "host/images.cpp", "host/image_decode.cpp", "host/image_formats.cpp", "host/bvh_build.cpp", "host/procedural.cpp", "host/context.cpp", "host/pbrt_dump.cpp"]
 KERNEL_SRCS = ["kernels/pt_kernels.hip", "kernels/post_kernels.hip", "kernels/bvh_kernels.hip", "kernels/rt_kernels.hip", "kernels/pt_variant_matte.hip", "kernels/pt_variant_matte5.hip", "kernels/pt_variant_env.hip", "kernels/pt_variant_env5.hip", "kernels/pt_variant_surf.hip",
                "kernels/pt_variant_sss.hip", "kernels/pt_variant_sss4.hip",
                "kernels/pt_variant_vol.hip", "kernels/pt_variant_vol4.hip", "kernels/pt_variant_full.hip"]
@@ -45,6 +45,20 @@ def _deps_digest():
                         h.update(f.encode()); h.update(fh.read())
     h.update(" ".join(COMMON + DEVICE).encode())
     return h.hexdigest()
+
+
+def kernel_digest():
+    """Digest of what decides the device code: the kernel sources, the shared headers and the device flags.  scripts/profile_bench.sh
+    stamps the PMC summaries it writes with it; bench.py refuses to derive a roofline fraction from counters taken of other code."""
+    h = hashlib.sha1()
+    for base in (os.path.join(CSRC, "kernels"), os.path.join(REPO, "include")):
+        for dp, _, fs in sorted(os.walk(base)):
+            for f in sorted(fs):
+                if f.endswith((".h", ".hpp", ".inc", ".hip")):
+                    with open(os.path.join(dp, f), "rb") as fh:
+                        h.update(f.encode()); h.update(fh.read())
+    h.update(" ".join(COMMON + DEVICE).encode())
+    return h.hexdigest()[:16]
 
 
 def _compile(src):

@@ -21,11 +21,13 @@
 
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <signal.h>
 #include <spawn.h>
 #include <sys/wait.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -69,34 +71,44 @@ static const int kNcclFloat = 7; /* ncclFloat32 */
 /* start `world` copies of this program, one per rank, and wait for them; nothing here touches HIP */
 static int spawnRanks(int argc, char** argv, int world)
 {
-    char idFile[] = "/tmp/tracerboy-hip-rccl-XXXXXX";
-    const int fd = mkstemp(idFile); if (fd >= 0) { close(fd); unlink(idFile); }
+    /* The RCCL unique id travels from rank 0 to the others through a file in a directory only this user can enter (mkdtemp: mode
+     * 0700, unpredictable name): nobody else can pre-create the file, plant a symlink where rank 0 writes, or read the id. */
+    char idDir[] = "/tmp/tracerboy-hip-rccl-XXXXXX";
+    if (!mkdtemp(idDir)) { perror("tracerboy-hip: mkdtemp"); return 1; }
+    const std::string idFile = std::string(idDir) + "/id", idTmp = idFile + ".tmp";
+    auto cleanup = [&]() { unlink(idFile.c_str()); unlink(idTmp.c_str()); rmdir(idDir); };
     std::vector<pid_t> kids;
     for (int r = 0; r < world; r++) {
         std::vector<std::string> envs;
         for (char** e = environ; *e; e++) if (strncmp(*e, "TB_CLI_", 7)) envs.push_back(*e);
-        envs.push_back("TB_CLI_RANK=" + std::to_string(r)); envs.push_back("TB_CLI_WORLD=" + std::to_string(world)); envs.push_back(std::string("TB_CLI_ID_FILE=") + idFile);
+        envs.push_back("TB_CLI_RANK=" + std::to_string(r)); envs.push_back("TB_CLI_WORLD=" + std::to_string(world)); envs.push_back("TB_CLI_ID_FILE=" + idFile);
         bool ipc = false; for (const std::string& e : envs) ipc |= e.rfind("HSA_ENABLE_IPC_MODE_LEGACY=", 0) == 0;
         if (!ipc) envs.push_back("HSA_ENABLE_IPC_MODE_LEGACY=0"); /* this pool's driver only supports dmabuf IPC */
         std::vector<char*> envp; for (std::string& e : envs) envp.push_back(&e[0]); envp.push_back(nullptr);
         pid_t pid = 0;
-        if (posix_spawn(&pid, "/proc/self/exe", nullptr, nullptr, argv, envp.data()) != 0) { perror("tracerboy-hip: posix_spawn"); for (pid_t k : kids) kill(k, SIGTERM); return 1; }
+        if (posix_spawn(&pid, "/proc/self/exe", nullptr, nullptr, argv, envp.data()) != 0) {
+            perror("tracerboy-hip: posix_spawn");
+            for (pid_t k : kids) kill(k, SIGTERM);
+            for (size_t i = 0; i < kids.size(); i++) { int st = 0; (void)waitpid(kids[i], &st, 0); }
+            cleanup(); return 1;
+        }
         kids.push_back(pid);
     }
     /* a rank that fails (no such device, scene error ...) would leave the others waiting in the communicator forever: the first
-     * non-zero exit ends them all */
-    int worst = 0; size_t left = kids.size();
-    while (left) {
+     * non-zero exit ends the ranks still running, and ITS status is what the tool returns (the others then die of the SIGTERM) */
+    int first = 0;
+    while (!kids.empty()) {
         int st = 0; const pid_t k = waitpid(-1, &st, 0);
         if (k < 0) break;
-        left--;
-        const int rc = WIFEXITED(st) ? WEXITSTATUS(st) : 128;
-        if (rc > worst) worst = rc;
-        if (rc != 0) for (pid_t o : kids) if (o != k) kill(o, SIGTERM);
+        auto it = std::find(kids.begin(), kids.end(), k);
+        if (it == kids.end()) continue;                 /* not one of ours */
+        kids.erase(it);                                 /* reaped: its pid may be reused, never signal it again */
+        const int rc = WIFEXITED(st) ? WEXITSTATUS(st) : 128 + (WIFSIGNALED(st) ? WTERMSIG(st) : 0);
+        if (rc != 0 && first == 0) { first = rc; for (pid_t o : kids) kill(o, SIGTERM); }
     }
-    unlink(idFile);
+    cleanup();
     (void)argc;
-    return worst;
+    return first;
 }
 
 int main(int argc, char** argv)
@@ -119,6 +131,10 @@ int main(int argc, char** argv)
     const bool forceRccl = getenv("TB_CLI_FORCE_RCCL") && atoi(getenv("TB_CLI_FORCE_RCCL")) != 0;
     if (ranks < 1) { fprintf(stderr, "--ranks must be at least 1\n"); return 2; }
     if (ranks > 1 && !envRank) return spawnRanks(argc, argv, ranks);
+    if (envRank && (!getenv("TB_CLI_WORLD") || atoi(getenv("TB_CLI_WORLD")) < 1 || atoi(envRank) < 0 || atoi(envRank) >= atoi(getenv("TB_CLI_WORLD")) ||
+                    (atoi(getenv("TB_CLI_WORLD")) > 1 && !getenv("TB_CLI_ID_FILE")))) {
+        fprintf(stderr, "tracerboy-hip: TB_CLI_RANK needs TB_CLI_WORLD (rank < world) and, for more than one rank, TB_CLI_ID_FILE -- these are set by --ranks, not by hand\n"); return 2;
+    }
     const int rank = envRank ? atoi(envRank) : 0, world = envRank ? atoi(getenv("TB_CLI_WORLD")) : 1;
     if (world > 1) device = rank; /* one process per GPU */
     tb_context* ctx = nullptr;
@@ -151,8 +167,9 @@ int main(int argc, char** argv)
             if (world > 1) { /* publish atomically: write beside, rename */
                 if (!idFile) { fprintf(stderr, "tracerboy-hip: TB_CLI_ID_FILE is not set\n"); return 1; }
                 const std::string tmp = std::string(idFile) + ".tmp";
-                FILE* f = fopen(tmp.c_str(), "wb"); if (!f || fwrite(&id, sizeof id, 1, f) != 1) { perror("tracerboy-hip: unique id file"); return 1; }
-                fclose(f); if (rename(tmp.c_str(), idFile)) { perror("tracerboy-hip: rename"); return 1; }
+                const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW | O_CLOEXEC, 0600); /* never through a link, never over an existing file */
+                if (fd < 0 || write(fd, &id, sizeof id) != (ssize_t)sizeof id) { perror("tracerboy-hip: unique id file"); if (fd >= 0) close(fd); return 1; }
+                close(fd); if (rename(tmp.c_str(), idFile)) { perror("tracerboy-hip: rename"); return 1; }
             }
         } else {
             bool got = false;

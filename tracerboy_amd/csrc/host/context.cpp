@@ -184,7 +184,8 @@ uint32_t sceneFeatureMask(const HostScene& s)
         if (m.Flags & TB_MAT_MIX) f |= PT_FEAT_MIX;
     }
     for (const TbLight& l : s.lights) if (l.LightType != TB_LIGHT_TYPE_AREA) f |= PT_FEAT_EXT;
-    if (!s.instances.empty()) f |= PT_FEAT_EXT; /* the two-level walk lives in the full-feature kernels only */
+    /* two-level scenes: renderImpl picks a kernel copy that walks instances (the frame-group kernels of the higher-occupancy copies,
+     * else the full feature set) */
     return f;
 }
 
@@ -604,6 +605,8 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
     if (!v) v = &kVariants[kNumVariants - 1];
     c->lastVariant = v->name;
     const int variantIndex = (int)(v - kVariants);
+    const bool twoLevel = c->ds.numInstances != 0; /* instanced scene (flatten_instances = 0): pipeline 0 only */
+    if (twoLevel && opt("pipeline", 0) != 0) return fail(c, TB_E_UNSUPPORTED, "tb_render: two-level (instanced) scenes are not supported by pipelines 1-3; use pipeline 0 or flatten_instances = 1");
     const bool wavefront = opt("pipeline", 0) == 2 && v->wf && !count && !aov;
     const bool pooled = opt("pipeline", 0) == 3 && v->pooled && !count && !aov;
     const int64_t fg = opt("frame_group", 0);
@@ -630,6 +633,12 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
                 launch = v->fnHi;
             }
         }
+    }
+    /* Two-level scenes: the tuned walk (while-while, split stack) is compiled into the frame-group kernels of the higher-occupancy
+     * copies; every other launch of an instanced scene goes to the full feature set, whose kernels carry the walk in all their forms */
+    if (twoLevel && !(v->fnHi && launch == v->fnHi && groups)) {
+        v = &kVariants[kNumVariants - 1]; launch = v->fn; c->lastVariant = v->name;
+        dsLaunch = c->ds; dsLaunch.stackOverflow = nullptr; dsLaunch.stackOverflowLanes = 0;
     }
     /* Compact nodes (option "node_layout" = 1): in the frame-group kernels of the higher-occupancy copies, scenes fetched from memory */
     const bool compactNodes = opt("node_layout", 0) == 1 && c->ds.nodesC && v->fnHi && launch == v->fnHi && groups && !c->sceneInLds;

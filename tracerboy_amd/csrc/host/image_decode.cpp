@@ -299,6 +299,8 @@ bool decodeTga(const std::vector<uint8_t>& d, DecodedImage& img, std::string& er
 
 } // namespace
 
+bool DecodeJpegBmpDds(const std::string& file, const std::vector<uint8_t>& d, int kind, DecodedImage& img, std::string& err); /* image_formats.cpp */
+
 bool DecodeImageFile(const std::string& file, DecodedImage& img, std::string& err)
 {
     std::vector<uint8_t> d;
@@ -307,8 +309,11 @@ bool DecodeImageFile(const std::string& file, DecodedImage& img, std::string& er
     try {
         if (ends(".png")) return decodePng(d, img, err);
         if (ends(".tga")) return decodeTga(d, img, err);
+        if (ends(".jpg") || ends(".jpeg")) return DecodeJpegBmpDds(file, d, 0, img, err);
+        if (ends(".bmp")) return DecodeJpegBmpDds(file, d, 1, img, err);
+        if (ends(".dds")) return DecodeJpegBmpDds(file, d, 2, img, err);
     } catch (const std::exception& e) { err = std::string(e.what()) + " ('" + file + "')"; return false; }
-    err = "unsupported image format for '" + file + "' (this build decodes .hdr, .pfm, .png and .tga)";
+    err = "unsupported image format for '" + file + "' (this build decodes .hdr, .pfm, .png, .tga, .jpg, .bmp and .dds)";
     return false;
 }
 

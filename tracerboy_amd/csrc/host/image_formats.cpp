@@ -1,0 +1,429 @@
+/* image_formats.cpp -- JPEG, BMP and DDS decoders for image textures.
+ *
+ * The reference hands .dds files to DirectXTex::LoadFromDDSFile(DDS_FLAGS_NO_16BPP) and everything that is not .hdr / .tga / .dds to
+ * Windows Imaging (LoadFromWICFile): /root/reference/TracerBoy/TracerBoy.cpp:2214-2226.  What reaches the shaders is the typed
+ * load of the resulting DXGI format, reproduced here as RGBA32F texels like image_decode.cpp does for PNG / TGA:
+ *   JPEG  baseline / extended sequential Huffman, 8-bit, 1 or 3 components (YCbCr or Adobe RGB), any sampling factors, restart
+ *         intervals.  Arithmetic as in the IJG library every decoder is measured against: the "slow integer" inverse DCT
+ *         (jidctint), triangle ("fancy") chroma upsampling for 2:1 horizontally and 2:1 x 2:1 (jdsample), 16-bit fixed-point
+ *         YCbCr -> RGB (jdcolor).  WIC's own decoder is not bit-specified; tests pin this one against Pillow (libjpeg-turbo).
+ *         Grey -> (g, 0, 0, 1) like 8bppGray -> R8_UNORM; colour -> R8G8B8A8_UNORM, alpha 1.  Progressive files are refused.
+ *   BMP   BITMAPINFOHEADER / V4 / V5; 1, 4, 8 bit palettes, 16 (5-5-5 or bit fields), 24, 32 bit, BI_RGB / BI_BITFIELDS, both row orders
+ *   DDS   top mip of the first surface: uncompressed 8 / 16 / 24 / 32-bit masks (16-bit formats expanded to 8888: NO_16BPP),
+ *         L8 / A8L8 / A8, BC1-BC5 (DXT1-5, ATI1/2; DX10 header incl. _SRGB, which only flags gamma), R16G16B16A16_FLOAT / UNORM,
+ *         R32G32B32A32_FLOAT, R32_FLOAT.  Block formats are decoded the way D3D specifies the sampler's view of them (endpoints
+ *         as UNORM, interpolated in floating point).
+ * No third-party code. */
+#include "host_scene.h"
+
+#include <cmath>
+#include <cstring>
+#include <stdexcept>
+
+namespace tbhost {
+namespace {
+
+TbFloat4 px(float r, float g, float b, float a) { TbFloat4 t; t.x = r; t.y = g; t.z = b; t.w = a; return t; }
+
+/* ---- JPEG ------------------------------------------------------------------------------------------------------------------ */
+struct JpegHuff { uint8_t bits[17] = {0}; uint8_t vals[256] = {0}; int mincode[17], maxcode[18], valptr[17]; bool present = false;
+    void build()
+    {
+        int code = 0, k = 0;
+        for (int l = 1; l <= 16; l++) { valptr[l] = k; mincode[l] = code; code += bits[l]; k += bits[l]; maxcode[l] = bits[l] ? code - 1 : -1; code <<= 1; }
+        maxcode[17] = 0x7fffffff;
+    }
+};
+
+struct JpegBits {
+    const uint8_t* p; size_t n, at; uint32_t acc = 0; int cnt = 0; bool hitMarker = false;
+    JpegBits(const uint8_t* d, size_t len, size_t start) : p(d), n(len), at(start) {}
+    void fill()
+    {
+        while (cnt <= 24) {
+            uint32_t b = 0;
+            if (!hitMarker && at < n) {
+                b = p[at];
+                if (b == 0xff) {
+                    if (at + 1 < n && p[at + 1] == 0x00) at += 2;            /* stuffed zero */
+                    else { hitMarker = true; b = 0; }                        /* a marker: feed zeros until the caller deals with it */
+                } else at++;
+            }
+            acc |= b << (24 - cnt); cnt += 8;
+        }
+    }
+    int get(int k) { if (!k) return 0; if (cnt < k) fill(); const int v = (int)(acc >> (32 - k)); acc <<= k; cnt -= k; return v; }
+    int decode(const JpegHuff& h)
+    {
+        int code = 0;
+        for (int l = 1; l <= 16; l++) { code = (code << 1) | get(1); if (h.maxcode[l] >= 0 && code <= h.maxcode[l] && code >= h.mincode[l]) return h.vals[h.valptr[l] + code - h.mincode[l]]; }
+        throw std::runtime_error("jpeg: bad Huffman code");
+    }
+    static int extend(int v, int t) { return v < (1 << (t - 1)) ? v - (1 << t) + 1 : v; }
+    void restart() /* at an RSTn: drop the bit buffer, step over the marker */
+    {
+        acc = 0; cnt = 0;
+        if (hitMarker) { hitMarker = false; if (at + 1 < n && p[at] == 0xff && p[at + 1] >= 0xd0 && p[at + 1] <= 0xd7) at += 2; else throw std::runtime_error("jpeg: restart marker expected"); }
+        else { /* the marker may not have been reached by the bit reader yet */
+            while (at + 1 < n && !(p[at] == 0xff && p[at + 1] >= 0xd0 && p[at + 1] <= 0xd7)) at++;
+            if (at + 1 >= n) throw std::runtime_error("jpeg: restart marker expected");
+            at += 2;
+        }
+    }
+};
+
+const uint8_t kZigzag[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+                             35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+inline uint8_t clamp255(int v) { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+
+/* jidctint.c (IJG "slow but accurate integer" inverse DCT, Loeffler-Ligtenberg-Moschytz): CONST_BITS 13, PASS1_BITS 2 */
+void idctIslow(const int* coef /* dequantised, natural order */, uint8_t* out, size_t stride)
+{
+    const int CONST_BITS = 13, PASS1_BITS = 2;
+    const int F_0_298 = 2446, F_0_390 = 3196, F_0_541 = 4433, F_0_765 = 6270, F_0_899 = 7373, F_1_175 = 9633, F_1_501 = 12299, F_1_847 = 15137, F_1_961 = 16069, F_2_053 = 16819, F_2_562 = 20995, F_3_072 = 25172;
+    auto descale = [](long x, int n) { return (int)((x + (1L << (n - 1))) >> n); };
+    int ws[64];
+    for (int c = 0; c < 8; c++) {
+        const int* in = coef + c; int* w = ws + c;
+        if (!in[8] && !in[16] && !in[24] && !in[32] && !in[40] && !in[48] && !in[56]) { const int dc = in[0] << PASS1_BITS; for (int r = 0; r < 8; r++) w[8 * r] = dc; continue; }
+        long z2 = in[16], z3 = in[48];
+        long z1 = (z2 + z3) * F_0_541, tmp2 = z1 + z3 * (-F_1_847), tmp3 = z1 + z2 * F_0_765;
+        z2 = in[0]; z3 = in[32];
+        long tmp0 = (z2 + z3) << CONST_BITS, tmp1 = (z2 - z3) << CONST_BITS;
+        const long tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+        tmp0 = in[56]; tmp1 = in[40]; tmp2 = in[24]; tmp3 = in[8];
+        z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2; long z4 = tmp1 + tmp3, z5 = (z3 + z4) * F_1_175;
+        tmp0 *= F_0_298; tmp1 *= F_2_053; tmp2 *= F_3_072; tmp3 *= F_1_501;
+        z1 *= -F_0_899; z2 *= -F_2_562; z3 *= -F_1_961; z4 *= -F_0_390;
+        z3 += z5; z4 += z5;
+        tmp0 += z1 + z3; tmp1 += z2 + z4; tmp2 += z2 + z3; tmp3 += z1 + z4;
+        w[0] = descale(tmp10 + tmp3, CONST_BITS - PASS1_BITS); w[56] = descale(tmp10 - tmp3, CONST_BITS - PASS1_BITS);
+        w[8] = descale(tmp11 + tmp2, CONST_BITS - PASS1_BITS); w[48] = descale(tmp11 - tmp2, CONST_BITS - PASS1_BITS);
+        w[16] = descale(tmp12 + tmp1, CONST_BITS - PASS1_BITS); w[40] = descale(tmp12 - tmp1, CONST_BITS - PASS1_BITS);
+        w[24] = descale(tmp13 + tmp0, CONST_BITS - PASS1_BITS); w[32] = descale(tmp13 - tmp0, CONST_BITS - PASS1_BITS);
+    }
+    for (int r = 0; r < 8; r++) {
+        const int* w = ws + 8 * r; uint8_t* o = out + stride * r;
+        long z2 = w[2], z3 = w[6];
+        long z1 = (z2 + z3) * F_0_541, tmp2 = z1 + z3 * (-F_1_847), tmp3 = z1 + z2 * F_0_765;
+        long tmp0 = ((long)w[0] + w[4]) << CONST_BITS, tmp1 = ((long)w[0] - w[4]) << CONST_BITS;
+        const long tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+        tmp0 = w[7]; tmp1 = w[5]; tmp2 = w[3]; tmp3 = w[1];
+        z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2; long z4 = tmp1 + tmp3, z5 = (z3 + z4) * F_1_175;
+        tmp0 *= F_0_298; tmp1 *= F_2_053; tmp2 *= F_3_072; tmp3 *= F_1_501;
+        z1 *= -F_0_899; z2 *= -F_2_562; z3 *= -F_1_961; z4 *= -F_0_390;
+        z3 += z5; z4 += z5;
+        tmp0 += z1 + z3; tmp1 += z2 + z4; tmp2 += z2 + z3; tmp3 += z1 + z4;
+        const int S = CONST_BITS + PASS1_BITS + 3;
+        o[0] = clamp255(descale(tmp10 + tmp3, S) + 128); o[7] = clamp255(descale(tmp10 - tmp3, S) + 128);
+        o[1] = clamp255(descale(tmp11 + tmp2, S) + 128); o[6] = clamp255(descale(tmp11 - tmp2, S) + 128);
+        o[2] = clamp255(descale(tmp12 + tmp1, S) + 128); o[5] = clamp255(descale(tmp12 - tmp1, S) + 128);
+        o[3] = clamp255(descale(tmp13 + tmp0, S) + 128); o[4] = clamp255(descale(tmp13 - tmp0, S) + 128);
+    }
+}
+
+struct JpegComp { int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0, pred = 0; uint32_t bw = 0, bh = 0 /* blocks */, dw = 0, dh = 0 /* downsampled size */; std::vector<uint8_t> plane; size_t stride = 0; };
+
+bool decodeJpeg(const std::vector<uint8_t>& d, DecodedImage& img, std::string& err)
+{
+    if (d.size() < 4 || d[0] != 0xff || d[1] != 0xd8) { err = "not a JPEG file"; return false; }
+    uint16_t qt[4][64]; bool qtSet[4] = {false, false, false, false};
+    JpegHuff dc[4], ac[4];
+    std::vector<JpegComp> comps; uint32_t W = 0, H = 0; int hmax = 1, vmax = 1, restartInterval = 0; int adobeTransform = -1; bool sawSof = false;
+    size_t at = 2;
+    auto u16 = [&](size_t o) -> uint32_t { if (o + 1 >= d.size()) throw std::runtime_error("jpeg: truncated"); return ((uint32_t)d[o] << 8) | d[o + 1]; };
+    for (;;) {
+        while (at < d.size() && d[at] != 0xff) at++;
+        while (at < d.size() && d[at] == 0xff) at++;
+        if (at >= d.size()) throw std::runtime_error("jpeg: no scan found");
+        const uint8_t m = d[at++];
+        if (m == 0xd8 || (m >= 0xd0 && m <= 0xd7) || m == 0x01) continue;
+        if (m == 0xd9) throw std::runtime_error("jpeg: end of image before any scan");
+        const uint32_t len = u16(at); if (len < 2 || at + len > d.size()) throw std::runtime_error("jpeg: bad segment length");
+        const size_t seg = at + 2, end = at + len;
+        if (m == 0xdb) { /* DQT */
+            size_t p = seg;
+            while (p < end) { const int pq = d[p] >> 4, tq = d[p] & 15; p++; if (tq > 3) throw std::runtime_error("jpeg: bad quantisation table id");
+                for (int i = 0; i < 64; i++) { if (p + (pq ? 1 : 0) >= end + 0 && p >= end) throw std::runtime_error("jpeg: truncated DQT"); qt[tq][kZigzag[i]] = pq ? (uint16_t)u16(p) : d[p]; p += pq ? 2 : 1; }
+                qtSet[tq] = true; }
+        } else if (m == 0xc4) { /* DHT */
+            size_t p = seg;
+            while (p < end) { const int tc = d[p] >> 4, th = d[p] & 15; p++; if (tc > 1 || th > 3) throw std::runtime_error("jpeg: bad Huffman table id");
+                JpegHuff& h = tc ? ac[th] : dc[th]; int total = 0;
+                for (int l = 1; l <= 16; l++) { h.bits[l] = d[p++]; total += h.bits[l]; }
+                if (total > 256 || p + total > end) throw std::runtime_error("jpeg: bad Huffman table");
+                memcpy(h.vals, &d[p], (size_t)total); p += total; h.build(); h.present = true; }
+        } else if (m == 0xc0 || m == 0xc1) { /* SOF0 / SOF1 */
+            if (d[seg] != 8) throw std::runtime_error("jpeg: only 8-bit precision is supported");
+            H = u16(seg + 1); W = u16(seg + 3); const int nc = d[seg + 5];
+            if (!W || !H || (nc != 1 && nc != 3)) throw std::runtime_error("jpeg: unsupported component count (grey and three-component files are decoded)");
+            comps.resize((size_t)nc);
+            for (int i = 0; i < nc; i++) { JpegComp& c = comps[(size_t)i]; c.id = d[seg + 6 + 3 * i]; c.h = d[seg + 7 + 3 * i] >> 4; c.v = d[seg + 7 + 3 * i] & 15; c.tq = d[seg + 8 + 3 * i];
+                if (c.h < 1 || c.h > 4 || c.v < 1 || c.v > 4 || c.tq > 3) throw std::runtime_error("jpeg: bad sampling factors"); hmax = std::max(hmax, c.h); vmax = std::max(vmax, c.v); }
+            sawSof = true;
+        } else if (m == 0xc2 || (m >= 0xc3 && m <= 0xcf && m != 0xc4 && m != 0xc8 && m != 0xcc)) {
+            err = "progressive / lossless / arithmetic-coded JPEG is not supported (baseline and extended sequential Huffman are)"; return false;
+        } else if (m == 0xdd) restartInterval = (int)u16(seg);
+        else if (m == 0xee && len >= 14 && !memcmp(&d[seg], "Adobe", 5)) adobeTransform = d[seg + 11];
+        else if (m == 0xda) { /* SOS: baseline files carry one scan with all components */
+            if (!sawSof) throw std::runtime_error("jpeg: scan before frame header");
+            const int ns = d[seg]; if (ns != (int)comps.size()) { err = "multi-scan sequential JPEG is not supported"; return false; }
+            for (int i = 0; i < ns; i++) { const int cid = d[seg + 1 + 2 * i]; bool found = false;
+                for (JpegComp& c : comps) if (c.id == cid) { c.td = d[seg + 2 + 2 * i] >> 4; c.ta = d[seg + 2 + 2 * i] & 15; found = true; }
+                if (!found) throw std::runtime_error("jpeg: scan names an unknown component"); }
+            at = end; break;
+        }
+        at = end;
+    }
+    /* geometry */
+    const uint32_t mcuW = (uint32_t)(8 * hmax), mcuH = (uint32_t)(8 * vmax);
+    const bool single = comps.size() == 1;
+    uint32_t mcusX = (W + mcuW - 1) / mcuW, mcusY = (H + mcuH - 1) / mcuH;
+    if (single) { mcusX = (W + 7) / 8; mcusY = (H + 7) / 8; } /* a one-component scan is not interleaved: one block per MCU whatever its sampling factors */
+    for (JpegComp& c : comps) {
+        if (!qtSet[c.tq] || !dc[c.td].present || !ac[c.ta].present) throw std::runtime_error("jpeg: scan refers to a table that was not defined");
+        c.dw = (W * (uint32_t)c.h + (uint32_t)hmax - 1) / (uint32_t)hmax; c.dh = (H * (uint32_t)c.v + (uint32_t)vmax - 1) / (uint32_t)vmax;
+        if (single) { c.h = c.v = 1; c.dw = W; c.dh = H; }
+        c.bw = mcusX * (uint32_t)c.h; c.bh = mcusY * (uint32_t)c.v;
+        c.stride = (size_t)c.bw * 8; c.plane.assign(c.stride * c.bh * 8, 0);
+    }
+    if (single) { hmax = vmax = 1; }
+    JpegBits br(d.data(), d.size(), at);
+    int coef[64];
+    int toRestart = restartInterval;
+    for (uint32_t my = 0; my < mcusY; my++) for (uint32_t mx = 0; mx < mcusX; mx++) {
+        if (restartInterval && toRestart == 0) { br.restart(); for (JpegComp& c : comps) c.pred = 0; toRestart = restartInterval; }
+        for (JpegComp& c : comps) for (int by = 0; by < c.v; by++) for (int bx = 0; bx < c.h; bx++) {
+            memset(coef, 0, sizeof coef);
+            const int t = br.decode(dc[c.td]); if (t > 11) throw std::runtime_error("jpeg: bad DC size");
+            c.pred += t ? JpegBits::extend(br.get(t), t) : 0;
+            coef[0] = c.pred * qt[c.tq][0];
+            for (int k = 1; k < 64;) {
+                const int rs = br.decode(ac[c.ta]), r = rs >> 4, sz = rs & 15;
+                if (!sz) { if (r == 15) { k += 16; continue; } break; }
+                k += r; if (k > 63) throw std::runtime_error("jpeg: AC run past the block");
+                coef[kZigzag[k]] = JpegBits::extend(br.get(sz), sz) * qt[c.tq][kZigzag[k]]; k++;
+            }
+            idctIslow(coef, c.plane.data() + ((size_t)(my * (uint32_t)c.v + (uint32_t)by) * 8) * c.stride + (size_t)(mx * (uint32_t)c.h + (uint32_t)bx) * 8, c.stride);
+        }
+        if (restartInterval) toRestart--;
+    }
+    /* upsample every component to W x H (jdsample.c) */
+    std::vector<std::vector<uint8_t>> full(comps.size());
+    for (size_t ci = 0; ci < comps.size(); ci++) {
+        const JpegComp& c = comps[ci]; std::vector<uint8_t>& o = full[ci]; o.assign((size_t)W * H, 0);
+        const int hx = hmax / c.h, vx = vmax / c.v; const bool exact = hmax % c.h == 0 && vmax % c.v == 0;
+        auto in = [&](uint32_t x, uint32_t y) -> int { return c.plane[(size_t)y * c.stride + x]; };
+        if (hx == 1 && vx == 1) { for (uint32_t y = 0; y < H; y++) memcpy(&o[(size_t)y * W], &c.plane[(size_t)y * c.stride], W); }
+        else if (exact && hx == 2 && vx == 1 && c.dw > 2) { /* h2v1_fancy_upsample: 3/4 nearer + 1/4 further, rounding 1 / 2 alternately */
+            for (uint32_t y = 0; y < H; y++) for (uint32_t x = 0; x < W; x++) {
+                const uint32_t i = x >> 1; int v;
+                if (x & 1) v = i + 1 < c.dw ? (3 * in(i, y) + in(i + 1, y) + 2) >> 2 : in(i, y);
+                else v = i > 0 ? (3 * in(i, y) + in(i - 1, y) + 1) >> 2 : in(i, y);
+                o[(size_t)y * W + x] = (uint8_t)v;
+            }
+        } else if (exact && hx == 2 && vx == 2 && c.dw > 2) { /* h2v2_fancy_upsample: 9/16, 3/16, 3/16, 1/16, rounding 8 / 7 alternately */
+            for (uint32_t y = 0; y < H; y++) {
+                const uint32_t j = y >> 1; const uint32_t far = (y & 1) ? (j + 1 < c.dh ? j + 1 : j) : (j > 0 ? j - 1 : j); /* the context row beyond an edge repeats the edge row */
+                auto colsum = [&](uint32_t i) { return 3 * in(i, j) + in(i, far); };
+                for (uint32_t x = 0; x < W; x++) {
+                    const uint32_t i = x >> 1; const int cur = colsum(i); int v;
+                    if (x & 1) v = i + 1 < c.dw ? (3 * cur + colsum(i + 1) + 7) >> 4 : (4 * cur + 7) >> 4;
+                    else v = i > 0 ? (3 * cur + colsum(i - 1) + 8) >> 4 : (4 * cur + 8) >> 4;
+                    o[(size_t)y * W + x] = (uint8_t)v;
+                }
+            }
+        } else { /* replication (int_upsample) for every other ratio; ratios that are not whole numbers take the nearest sample below */
+            for (uint32_t y = 0; y < H; y++) for (uint32_t x = 0; x < W; x++) {
+                const uint32_t sx = std::min<uint32_t>((uint32_t)((uint64_t)x * (uint32_t)c.h / (uint32_t)hmax), c.bw * 8 - 1), sy = std::min<uint32_t>((uint32_t)((uint64_t)y * (uint32_t)c.v / (uint32_t)vmax), c.bh * 8 - 1);
+                o[(size_t)y * W + x] = (uint8_t)in(sx, sy);
+            }
+        }
+    }
+    img.width = W; img.height = H; img.normalized = true; img.hasAlpha = false;
+    img.texels.resize((size_t)W * H);
+    if (comps.size() == 1) { for (size_t i = 0; i < img.texels.size(); i++) img.texels[i] = px((float)full[0][i] / 255.0f, 0.0f, 0.0f, 1.0f); return true; }
+    const bool ycc = adobeTransform < 0 ? !(comps[0].id == 'R' && comps[1].id == 'G' && comps[2].id == 'B') : adobeTransform == 1;
+    /* jdcolor.c build_ycc_rgb_table: SCALEBITS 16 */
+    int crR[256], cbB[256]; long crG[256], cbG[256];
+    for (int i = 0; i < 256; i++) { const long x = i - 128;
+        crR[i] = (int)((91881L * x + 32768L) >> 16); cbB[i] = (int)((116130L * x + 32768L) >> 16); crG[i] = -46802L * x; cbG[i] = -22554L * x + 32768L; }
+    for (size_t i = 0; i < img.texels.size(); i++) {
+        int r = full[0][i], g = full[1][i], b = full[2][i];
+        if (ycc) { const int y = r, cb = g, cr = b; r = clamp255(y + crR[cr]); g = clamp255(y + (int)((cbG[cb] + crG[cr]) >> 16)); b = clamp255(y + cbB[cb]); }
+        img.texels[i] = px((float)r / 255.0f, (float)g / 255.0f, (float)b / 255.0f, 1.0f);
+    }
+    return true;
+}
+
+/* ---- BMP ------------------------------------------------------------------------------------------------------------------- */
+uint32_t rd32(const std::vector<uint8_t>& d, size_t o) { if (o + 4 > d.size()) throw std::runtime_error("image: truncated"); return (uint32_t)d[o] | ((uint32_t)d[o + 1] << 8) | ((uint32_t)d[o + 2] << 16) | ((uint32_t)d[o + 3] << 24); }
+uint32_t rd16(const std::vector<uint8_t>& d, size_t o) { if (o + 2 > d.size()) throw std::runtime_error("image: truncated"); return (uint32_t)d[o] | ((uint32_t)d[o + 1] << 8); }
+
+/* value of a bit field scaled to [0, 1]: UNORM of the field's own width */
+float maskUnorm(uint32_t v, uint32_t mask)
+{
+    if (!mask) return 0.0f;
+    int shift = 0; while (!((mask >> shift) & 1u)) shift++;
+    const uint32_t top = mask >> shift;
+    return (float)((v & mask) >> shift) / (float)top;
+}
+
+bool decodeBmp(const std::vector<uint8_t>& d, DecodedImage& img, std::string& err)
+{
+    if (d.size() < 26 || d[0] != 'B' || d[1] != 'M') { err = "not a BMP file"; return false; }
+    const uint32_t dataOff = rd32(d, 10), hdr = rd32(d, 14);
+    if (hdr < 40) { err = "BMP: OS/2 core headers are not supported"; return false; }
+    const int32_t w = (int32_t)rd32(d, 18), hs = (int32_t)rd32(d, 22);
+    const uint32_t bpp = rd16(d, 28), comp = rd32(d, 30); uint32_t colours = rd32(d, 46);
+    if (w <= 0 || hs == 0 || w > 65536 || std::abs(hs) > 65536) { err = "BMP: bad dimensions"; return false; }
+    const uint32_t W = (uint32_t)w, H = (uint32_t)std::abs(hs); const bool topDown = hs < 0;
+    if (comp != 0 && comp != 3) { err = "BMP: RLE / embedded JPEG / PNG compression is not supported"; return false; }
+    uint32_t rm = 0, gm = 0, bm = 0, am = 0;
+    if (comp == 3) { const size_t mo = hdr >= 52 ? 54 : 14 + 40; rm = rd32(d, mo); gm = rd32(d, mo + 4); bm = rd32(d, mo + 8); if (hdr >= 56) am = rd32(d, mo + 12); }
+    else if (bpp == 16) { rm = 0x7c00; gm = 0x03e0; bm = 0x001f; }
+    else if (bpp == 32) { rm = 0x00ff0000; gm = 0x0000ff00; bm = 0x000000ff; if (hdr >= 56) am = rd32(d, 14 + 40 + 12); if (hdr < 108) am = 0; }
+    std::vector<TbFloat4> pal;
+    if (bpp <= 8) {
+        if (!colours) colours = 1u << bpp;
+        const size_t po = 14 + (size_t)hdr + (comp == 3 && hdr == 40 ? 12 : 0);
+        for (uint32_t i = 0; i < colours; i++) { if (po + 4 * i + 3 >= d.size()) throw std::runtime_error("BMP: truncated palette"); pal.push_back(px(d[po + 4 * i + 2] / 255.0f, d[po + 4 * i + 1] / 255.0f, d[po + 4 * i] / 255.0f, 1.0f)); }
+    }
+    if (bpp != 1 && bpp != 4 && bpp != 8 && bpp != 16 && bpp != 24 && bpp != 32) { err = "BMP: unsupported bit depth"; return false; }
+    const size_t rowBytes = ((size_t)W * bpp + 31) / 32 * 4;
+    if ((size_t)dataOff + rowBytes * H > d.size()) { err = "BMP: truncated pixel data"; return false; }
+    img.width = W; img.height = H; img.normalized = true; img.texels.resize((size_t)W * H);
+    bool anyAlpha = false;
+    for (uint32_t y = 0; y < H; y++) {
+        const uint8_t* row = &d[dataOff + rowBytes * (topDown ? y : H - 1 - y)];
+        for (uint32_t x = 0; x < W; x++) {
+            TbFloat4 t;
+            if (bpp <= 8) { const uint32_t per = 8 / bpp, idx = (row[x / per] >> ((per - 1 - x % per) * bpp)) & ((1u << bpp) - 1); t = idx < pal.size() ? pal[idx] : px(0, 0, 0, 1); }
+            else if (bpp == 24) t = px(row[3 * x + 2] / 255.0f, row[3 * x + 1] / 255.0f, row[3 * x] / 255.0f, 1.0f);
+            else { const uint32_t v = bpp == 16 ? ((uint32_t)row[2 * x] | ((uint32_t)row[2 * x + 1] << 8)) : ((uint32_t)row[4 * x] | ((uint32_t)row[4 * x + 1] << 8) | ((uint32_t)row[4 * x + 2] << 16) | ((uint32_t)row[4 * x + 3] << 24));
+                   t = px(maskUnorm(v, rm), maskUnorm(v, gm), maskUnorm(v, bm), am ? maskUnorm(v, am) : 1.0f); }
+            if (t.w != 1.0f) anyAlpha = true;
+            img.texels[(size_t)y * W + x] = t;
+        }
+    }
+    img.hasAlpha = anyAlpha;
+    return true;
+}
+
+/* ---- DDS ------------------------------------------------------------------------------------------------------------------- */
+float halfToFloat(uint16_t h)
+{
+    const uint32_t s = (uint32_t)(h >> 15) << 31, e = (h >> 10) & 31u, m = h & 1023u; uint32_t u;
+    if (e == 0) { if (!m) u = s; else { int k = 0; uint32_t mm = m; while (!(mm & 1024u)) { mm <<= 1; k++; } u = s | ((uint32_t)(113 - k) << 23) | ((mm & 1023u) << 13); } }
+    else if (e == 31) u = s | 0x7f800000u | (m << 13);
+    else u = s | ((e + 112u) << 23) | (m << 13);
+    float f; memcpy(&f, &u, 4); return f;
+}
+
+void bcColours(const uint8_t* b, TbFloat4 c[4], bool bc1) /* the colour half of a BC1 / BC2 / BC3 block */
+{
+    const uint32_t c0 = (uint32_t)b[0] | ((uint32_t)b[1] << 8), c1 = (uint32_t)b[2] | ((uint32_t)b[3] << 8);
+    auto e = [](uint32_t v) { return px((float)(v >> 11) / 31.0f, (float)((v >> 5) & 63u) / 63.0f, (float)(v & 31u) / 31.0f, 1.0f); };
+    c[0] = e(c0); c[1] = e(c1);
+    auto mix = [](const TbFloat4& a, const TbFloat4& q, float wa, float wq) { return px(a.x * wa + q.x * wq, a.y * wa + q.y * wq, a.z * wa + q.z * wq, 1.0f); };
+    if (!bc1 || c0 > c1) { c[2] = mix(c[0], c[1], 2.0f / 3.0f, 1.0f / 3.0f); c[3] = mix(c[0], c[1], 1.0f / 3.0f, 2.0f / 3.0f); }
+    else { c[2] = mix(c[0], c[1], 0.5f, 0.5f); c[3] = px(0, 0, 0, 0); }
+}
+void bcAlpha8(const uint8_t* b, float a[8], bool snorm) /* the interpolated-alpha block of BC3 / BC4 / BC5 */
+{
+    float a0, a1;
+    if (snorm) { auto s = [](uint8_t v) { const int i = (int8_t)v; return i <= -127 ? -1.0f : (float)i / 127.0f; }; a0 = s(b[0]); a1 = s(b[1]); }
+    else { a0 = b[0] / 255.0f; a1 = b[1] / 255.0f; }
+    a[0] = a0; a[1] = a1;
+    const bool eight = snorm ? (int8_t)b[0] > (int8_t)b[1] : b[0] > b[1];
+    if (eight) for (int i = 1; i < 7; i++) a[1 + i] = ((float)(7 - i) * a0 + (float)i * a1) / 7.0f;
+    else { for (int i = 1; i < 5; i++) a[1 + i] = ((float)(5 - i) * a0 + (float)i * a1) / 5.0f; a[6] = snorm ? -1.0f : 0.0f; a[7] = 1.0f; }
+}
+uint32_t bcAlphaIndex(const uint8_t* b, int texel) { uint64_t bits = 0; for (int i = 0; i < 6; i++) bits |= (uint64_t)b[2 + i] << (8 * i); return (uint32_t)(bits >> (3 * texel)) & 7u; }
+
+bool decodeDds(const std::vector<uint8_t>& d, DecodedImage& img, std::string& err)
+{
+    if (d.size() < 128 || memcmp(d.data(), "DDS ", 4) || rd32(d, 4) != 124) { err = "not a DDS file"; return false; }
+    const uint32_t H = rd32(d, 12), W = rd32(d, 16), pfFlags = rd32(d, 80), fourcc = rd32(d, 84), bits = rd32(d, 88);
+    const uint32_t rm = rd32(d, 92), gm = rd32(d, 96), bm = rd32(d, 100), am = rd32(d, 104);
+    if (!W || !H || W > 65536 || H > 65536) { err = "DDS: bad dimensions"; return false; }
+    size_t off = 128; uint32_t dxgi = 0;
+    auto cc = [](const char* s) { return (uint32_t)(uint8_t)s[0] | ((uint32_t)(uint8_t)s[1] << 8) | ((uint32_t)(uint8_t)s[2] << 16) | ((uint32_t)(uint8_t)s[3] << 24); };
+    enum { RAW, BC1, BC2, BC3, BC4, BC5, BC4S, BC5S, F16, F32, F32R, U16 } kind = RAW;
+    if (pfFlags & 4u) {
+        if (fourcc == cc("DX10")) { if (d.size() < 148) { err = "DDS: truncated DX10 header"; return false; } dxgi = rd32(d, 128); off = 148; }
+        else if (fourcc == cc("DXT1")) kind = BC1; else if (fourcc == cc("DXT2") || fourcc == cc("DXT3")) kind = BC2; else if (fourcc == cc("DXT4") || fourcc == cc("DXT5")) kind = BC3;
+        else if (fourcc == cc("ATI1") || fourcc == cc("BC4U")) kind = BC4; else if (fourcc == cc("BC4S")) kind = BC4S; else if (fourcc == cc("ATI2") || fourcc == cc("BC5U")) kind = BC5; else if (fourcc == cc("BC5S")) kind = BC5S;
+        else if (fourcc == 113) kind = F16; else if (fourcc == 116) kind = F32; else if (fourcc == 114) kind = F32R; else if (fourcc == 36) kind = U16;
+        else { err = "DDS: unsupported FourCC"; return false; }
+    }
+    uint32_t m[4] = {rm, gm, bm, (pfFlags & 1u) ? am : 0u}; uint32_t rawBits = bits; bool lum = (pfFlags & 0x20000u) != 0, alphaOnly = (pfFlags & 2u) != 0 && !(pfFlags & 0x40u) && !lum;
+    if (dxgi) {
+        switch (dxgi) {
+        case 71: case 72: kind = BC1; break; case 74: case 75: kind = BC2; break; case 77: case 78: kind = BC3; break; case 80: kind = BC4; break; case 81: kind = BC4S; break;
+        case 83: kind = BC5; break; case 84: kind = BC5S; break; case 10: kind = F16; break; case 2: kind = F32; break; case 41: kind = F32R; break; case 11: kind = U16; break;
+        case 28: case 29: kind = RAW; rawBits = 32; m[0] = 0xff; m[1] = 0xff00; m[2] = 0xff0000; m[3] = 0xff000000u; break;          /* R8G8B8A8_UNORM(_SRGB) */
+        case 87: case 91: kind = RAW; rawBits = 32; m[0] = 0xff0000; m[1] = 0xff00; m[2] = 0xff; m[3] = 0xff000000u; break;          /* B8G8R8A8 */
+        case 88: case 93: kind = RAW; rawBits = 32; m[0] = 0xff0000; m[1] = 0xff00; m[2] = 0xff; m[3] = 0; break;                    /* B8G8R8X8 */
+        case 61: kind = RAW; rawBits = 8; m[0] = 0xff; m[1] = m[2] = m[3] = 0; lum = false; break;                                  /* R8_UNORM */
+        case 85: kind = RAW; rawBits = 16; m[0] = 0xf800; m[1] = 0x07e0; m[2] = 0x001f; m[3] = 0; break;                           /* B5G6R5 */
+        case 86: kind = RAW; rawBits = 16; m[0] = 0x7c00; m[1] = 0x03e0; m[2] = 0x001f; m[3] = 0x8000; break;                      /* B5G5R5A1 */
+        default: err = "DDS: unsupported DXGI format " + std::to_string(dxgi); return false;
+        }
+    }
+    img.width = W; img.height = H; img.texels.assign((size_t)W * H, px(0, 0, 0, 1)); img.normalized = !(kind == F16 || kind == F32 || kind == F32R);
+    auto need = [&](size_t bytes) { if (off + bytes > d.size()) throw std::runtime_error("DDS: truncated surface"); };
+    if (kind == RAW) {
+        if (rawBits != 8 && rawBits != 16 && rawBits != 24 && rawBits != 32) { err = "DDS: unsupported bit count"; return false; }
+        const size_t bpp = rawBits / 8; need((size_t)W * H * bpp);
+        for (size_t i = 0; i < (size_t)W * H; i++) {
+            uint32_t v = 0; for (size_t k = 0; k < bpp; k++) v |= (uint32_t)d[off + i * bpp + k] << (8 * k);
+            TbFloat4 t;
+            if (alphaOnly) t = px(0, 0, 0, maskUnorm(v, am ? am : 0xffu));
+            else if (lum) { const float l = maskUnorm(v, m[0]); t = px(l, l, l, m[3] ? maskUnorm(v, m[3]) : 1.0f); }       /* L8 / A8L8: DirectXTex expands luminance to grey RGB */
+            else if (!m[1] && !m[2] && dxgi == 61) t = px(maskUnorm(v, m[0]), 0.0f, 0.0f, 1.0f);
+            else t = px(maskUnorm(v, m[0]), maskUnorm(v, m[1]), maskUnorm(v, m[2]), m[3] ? maskUnorm(v, m[3]) : 1.0f);
+            img.texels[i] = t;
+        }
+    } else if (kind == F16 || kind == F32 || kind == F32R || kind == U16) {
+        const size_t bpp = kind == F32 ? 16 : (kind == F32R ? 4 : 8); need((size_t)W * H * bpp);
+        for (size_t i = 0; i < (size_t)W * H; i++) {
+            const size_t o = off + i * bpp; float f[4] = {0, 0, 0, 1};
+            if (kind == F32) memcpy(f, &d[o], 16); else if (kind == F32R) memcpy(f, &d[o], 4);
+            else for (int k = 0; k < 4; k++) { const uint16_t h = (uint16_t)rd16(d, o + 2 * (size_t)k); f[k] = kind == F16 ? halfToFloat(h) : (float)h / 65535.0f; }
+            img.texels[i] = px(f[0], f[1], f[2], f[3]);
+        }
+    } else {
+        const size_t blockBytes = (kind == BC1 || kind == BC4 || kind == BC4S) ? 8 : 16; const uint32_t bw = (W + 3) / 4, bh = (H + 3) / 4;
+        need((size_t)bw * bh * blockBytes);
+        for (uint32_t by = 0; by < bh; by++) for (uint32_t bx = 0; bx < bw; bx++) {
+            const uint8_t* b = &d[off + ((size_t)by * bw + bx) * blockBytes];
+            TbFloat4 texel[16];
+            if (kind == BC1 || kind == BC2 || kind == BC3) {
+                const uint8_t* cb = kind == BC1 ? b : b + 8; TbFloat4 c[4]; bcColours(cb, c, kind == BC1);
+                const uint32_t idx = (uint32_t)cb[4] | ((uint32_t)cb[5] << 8) | ((uint32_t)cb[6] << 16) | ((uint32_t)cb[7] << 24);
+                float a8[8]; if (kind == BC3) bcAlpha8(b, a8, false);
+                for (int t = 0; t < 16; t++) { texel[t] = c[(idx >> (2 * t)) & 3u];
+                    if (kind == BC2) texel[t].w = (float)((b[t / 2] >> (4 * (t & 1))) & 15) / 15.0f; else if (kind == BC3) texel[t].w = a8[bcAlphaIndex(b, t)]; }
+            } else {
+                const bool sn = kind == BC4S || kind == BC5S; float r8[8], g8[8]; bcAlpha8(b, r8, sn); if (kind == BC5 || kind == BC5S) bcAlpha8(b + 8, g8, sn);
+                for (int t = 0; t < 16; t++) texel[t] = px(r8[bcAlphaIndex(b, t)], (kind == BC5 || kind == BC5S) ? g8[bcAlphaIndex(b + 8, t)] : 0.0f, 0.0f, 1.0f);
+            }
+            for (int t = 0; t < 16; t++) { const uint32_t x = bx * 4 + (uint32_t)(t & 3), y = by * 4 + (uint32_t)(t >> 2); if (x < W && y < H) img.texels[(size_t)y * W + x] = texel[t]; }
+        }
+    }
+    bool anyAlpha = false; for (const TbFloat4& t : img.texels) if (t.w != 1.0f) { anyAlpha = true; break; }
+    img.hasAlpha = anyAlpha;
+    return true;
+}
+
+} // namespace
+
+bool DecodeJpegBmpDds(const std::string& file, const std::vector<uint8_t>& d, int kind, DecodedImage& img, std::string& err)
+{
+    try { return kind == 0 ? decodeJpeg(d, img, err) : (kind == 1 ? decodeBmp(d, img, err) : decodeDds(d, img, err)); }
+    catch (const std::exception& e) { err = std::string(e.what()) + " ('" + file + "')"; return false; }
+}
+
+} // namespace tbhost

@@ -6,10 +6,14 @@
  *   rocprim sort    64-bit key = code << 32 | triangle index (ties by index)      BitonicSort in the reference
  *   bvh_hierarchy   Karras-2012 split search, one lane per inner node             BuildBVHSplits.hlsli:33-131
  *   bvh_treelet_*   (treeletPasses > 0, option "bvh_builder" = 4) the fallback layer's treelet passes, one wave per
- *                   climbing group, byte-identical to host builder 3                ClearBuffers.hlsl, FindTreelets.hlsl:27-88,
+ *                   treelet, byte-identical to host builder 3                       ClearBuffers.hlsl, FindTreelets.hlsl:27-88,
  *                                                                                   TreeletReorder.hlsl:38-311, TreeletReorder.cpp:38-109
- *   bvh_fit         leaves (1 triangle, 0.001 thin-box padding), then bottom-up:  RayTracingHelper.hlsli:251-263,
- *                   the second lane to reach a node fits it, smaller subtree left ComputeAABBs.hlsli:152-156
+ *   bvh_fit_*       leaves (1 triangle, 0.001 thin-box padding), then bottom-up:  RayTracingHelper.hlsli:251-263,
+ *                   a node is fitted from its children's boxes, smaller subtree left ComputeAABBs.hlsli:152-156
+ * Everything bottom-up is LEVEL-SYNCHRONOUS (round 3): one launch per wave-front of nodes whose children are finished, results of a
+ * wave-front become visible to the next one at the kernel boundary.  Rounds 1-2 climbed inside one kernel -- one lane per leaf, the
+ * second arrival at a node going on, an agent-scope __threadfence() on either side of every arrival counter -- and spent 170 of the
+ * 171 ms of a 3 M-triangle build in those fences (each writes back / invalidates the XCD's L2): profiles/r2/c5_kernel_stats.csv.
  * Output: the reference's bottom-level memory image (layout A: header, 32-B nodes, 40-B primitives, 12-B metadata) plus
  * the layout-B arrays the kernels fetch.  Boxes are min/max of exact inputs, so the fit order cannot change a bit.
  * Integer / bit work apart from the box arithmetic: one pass over the triangles per stage, HBM-bound; the sort is
@@ -94,15 +98,11 @@ __global__ __launch_bounds__(BLOCK) void bvh_hierarchy(const unsigned long long*
     left[i] = lc; right[i] = rc; parent[lc] = (uint32_t)i; parent[rc] = (uint32_t)i;
 }
 
-/* ---- treelet passes (Karras & Aila 2013 as the fallback layer runs it; host twin: bvh_build.cpp TreeletPass) ------------
- * Per pass: bvh_treelet_find = one lane per leaf climbs, writes min/max boxes, counts triangles per node and lists the lowest
- * nodes that hold >= minTris triangles; bvh_treelet_reorder = one wave per listed node: lane 0 grows the 7-leaf treelet below
- * the node, the 64 lanes price the 127 leaf subsets (2 per lane, subset sizes in turn), lane 0 rewires the six inner nodes
- * and climbs to the parent, where the second group to arrive goes on.  The reference's groups stop after 33 treelets and which
- * of two meeting groups goes on is a race there; here each group leaves its count at the meeting node and the smaller count
- * is carried on (the rule of the host builder and the oracle), so the tree does not depend on timing.
- * Cross-wave visibility: plain stores, __threadfence(), then the atomic that announces the arrival; the group that is let
- * through fences again before it reads (agent-scope fences write back / invalidate the per-XCD L2). */
+/* ---- bottom-up passes, level-synchronous ------------------------------------------------------------------------------------
+ * stamp[i] (inner nodes; leaves count as finished) = the launch t >= 1 that finished node i, 0 = not yet.  Launch t finishes the
+ * nodes whose children carry stamps in [1, t): a stamp written by the same launch does not count, because the data behind it need
+ * not be visible yet; at the next launch it is.  Every launch adds the number of nodes it finished to *progress; the host stops
+ * when all N - 1 are done (it reads the counter back every few launches).  Tree height launches in all. */
 struct TbBox6 { float mn[3], mx[3]; };
 
 __device__ __forceinline__ float box_area(const TbBox6& b)
@@ -116,89 +116,108 @@ __device__ __forceinline__ TbBox6 box_union(const TbBox6& a, const TbBox6& b)
     for (int k = 0; k < 3; k++) { r.mn[k] = tb_min(a.mn[k], b.mn[k]); r.mx[k] = tb_max(a.mx[k], b.mx[k]); }
     return r;
 }
-__device__ __forceinline__ TbBox6 box_load(const TbBox6* boxes, uint32_t i)
-{
-    const volatile float* p = (const volatile float*)(boxes + i);
-    TbBox6 r; for (int k = 0; k < 3; k++) { r.mn[k] = p[k]; r.mx[k] = p[3 + k]; }
-    return r;
-}
-__device__ __forceinline__ void box_store(TbBox6* boxes, uint32_t i, const TbBox6& b)
-{
-    volatile float* p = (volatile float*)(boxes + i);
-    for (int k = 0; k < 3; k++) { p[k] = b.mn[k]; p[3 + k] = b.mx[k]; }
-}
-__device__ __forceinline__ uint32_t vload(const uint32_t* p) { return *(const volatile uint32_t*)p; }
-__device__ __forceinline__ void vstore(uint32_t* p, uint32_t v) { *(volatile uint32_t*)p = v; }
 
+__device__ __forceinline__ bool children_finished(const uint32_t* stamp, uint32_t N, uint32_t l, uint32_t r, uint32_t t)
+{
+    const uint32_t sl = l >= N - 1 ? 1u : stamp[l], sr = r >= N - 1 ? 1u : stamp[r];
+    return sl != 0u && sr != 0u && (l >= N - 1 || sl < t) && (r >= N - 1 || sr < t);
+}
+__device__ __forceinline__ void count_progress(uint32_t* progress, bool did)
+{
+    const unsigned long long m = __ballot(did);
+    if (m && (threadIdx.x & 63u) == (uint32_t)__ffsll((long long)m) - 1u) atomicAdd(progress, (uint32_t)__popcll(m));
+}
+
+/* ---- treelet passes (Karras & Aila 2013 as the fallback layer runs it; host twin: bvh_build.cpp TreeletPass) ------------
+ * Per pass (MinTrianglesPerTreelet m = 7, 14, 28):
+ *   bvh_treelet_leaves   min / max box and triangle count 1 of every leaf (first pass only; later passes keep the arrays)
+ *   bvh_treelet_up       level-synchronous: box = union of the children's, numTris = sum, for every inner node (first pass; a
+ *                        treelet rebuild keeps both arrays exact for the six nodes it rewires, so later passes reuse them)
+ *   bvh_treelet_classify a node with numTris >= m waits for as many groups as it has children with numTris >= m; one with none
+ *                        is the root of a first treelet (FindTreelets.hlsl: the lowest nodes holding >= m triangles)
+ *   bvh_treelet_rebuild  one wave per listed node: lane 0 grows the 7-leaf treelet below it, the 64 lanes price the 127 leaf
+ *                        subsets (2 per lane, subset sizes in turn), lane 0 rewires the six inner nodes and leaves the number
+ *                        of treelets its chain has rebuilt in trips[node]
+ *   bvh_treelet_advance  per rebuilt node: the parent goes on the next list once every child it waits for has been rebuilt and
+ *                        the shortest of their chains is below 33 (the reference's groups stop after 33 treelets; which of two
+ *                        meeting groups goes on is a race there -- here, as in the host builder and the oracle, the smaller count)
+ * rebuild / advance alternate until a list comes up empty: as many rounds as the longest chain of dependent treelets. */
 struct TreeletBufs {
     uint32_t* left; uint32_t* right; uint32_t* parent; /* hierarchy (node ids; leaf k = N-1+k) */
     TbBox6* boxes;                                      /* min/max box per node */
-    uint32_t* numTris;                                  /* per inner node, zero at the start of a pass */
-    uint32_t* trips;                                    /* per inner node, 0xffffffff at the start of a pass */
-    uint32_t* baseCount; uint32_t* baseList;
+    uint32_t* numTris;                                  /* triangles below every node (2N - 1 entries) */
+    uint32_t* trips;                                    /* per inner node: treelets rebuilt by the chain that rebuilt this node, 0 = not rebuilt in this pass */
+    uint32_t* chain;                                    /* per inner node: what trips[] becomes when the node is rebuilt (set when it is listed) */
+    uint32_t* queued;                                   /* per inner node: already on a list in this pass */
+    uint32_t* stamp;                                    /* per inner node: bvh_treelet_up */
 };
 
-__global__ __launch_bounds__(BLOCK) void bvh_treelet_find(const float* positions, const uint32_t* triVertexIndex, const unsigned long long* keys, uint32_t N,
-                                                          uint32_t minTris, TreeletBufs b)
+__global__ __launch_bounds__(BLOCK) void bvh_treelet_leaves(const float* positions, const uint32_t* triVertexIndex, const unsigned long long* keys, uint32_t N, TreeletBufs b)
 {
     const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
     if (k >= N) return;
-    uint32_t x = (N - 1) + k, tris = 1;
-    {
-        const uint32_t tri = (uint32_t)keys[k];
-        const tb3 v0 = vertex(positions, triVertexIndex, tri, 0), v1 = vertex(positions, triVertexIndex, tri, 1), v2 = vertex(positions, triVertexIndex, tri, 2);
-        tb3 mn = tb3_min(tb3_min(v0, v1), v2); const tb3 mx = tb3_max(tb3_max(v0, v1), v2);
-        mn = tb3_min(mn, mx - tb3_splat(0.001f));
-        const tb3 c = (mn + mx) * 0.5f, h = mx - c, lo = c - h, hi = c + h; /* the leaf's centre / half-extent box turned back into min / max */
-        TbBox6 bx; bx.mn[0] = lo.x; bx.mn[1] = lo.y; bx.mn[2] = lo.z; bx.mx[0] = hi.x; bx.mx[1] = hi.y; bx.mx[2] = hi.z;
-        box_store(b.boxes, x, bx);
-    }
-    for (;;) {
-        if (tris >= minTris) { b.baseList[atomicAdd(b.baseCount, 1u)] = x; return; }
-        const uint32_t up = vload(b.parent + x);
-        __threadfence();
-        const uint32_t other = atomicAdd(&b.numTris[up], tris);
-        if (other == 0u) return;
-        __threadfence();
-        box_store(b.boxes, up, box_union(box_load(b.boxes, vload(b.left + up)), box_load(b.boxes, vload(b.right + up))));
-        x = up; tris += other;
-    }
+    const uint32_t tri = (uint32_t)keys[k];
+    const tb3 v0 = vertex(positions, triVertexIndex, tri, 0), v1 = vertex(positions, triVertexIndex, tri, 1), v2 = vertex(positions, triVertexIndex, tri, 2);
+    tb3 mn = tb3_min(tb3_min(v0, v1), v2); const tb3 mx = tb3_max(tb3_max(v0, v1), v2);
+    mn = tb3_min(mn, mx - tb3_splat(0.001f));
+    const tb3 c = (mn + mx) * 0.5f, h = mx - c, lo = c - h, hi = c + h; /* the leaf's centre / half-extent box turned back into min / max */
+    TbBox6 bx; bx.mn[0] = lo.x; bx.mn[1] = lo.y; bx.mn[2] = lo.z; bx.mx[0] = hi.x; bx.mx[1] = hi.y; bx.mx[2] = hi.z;
+    b.boxes[(N - 1) + k] = bx; b.numTris[(N - 1) + k] = 1u;
 }
 
-__global__ __launch_bounds__(64) void bvh_treelet_reorder(uint32_t N, TreeletBufs b)
+__global__ __launch_bounds__(BLOCK) void bvh_treelet_up(uint32_t N, TreeletBufs b, uint32_t t, uint32_t* progress)
 {
-    __shared__ uint32_t sNode, sGo;
-    __shared__ uint32_t sLeaf[7], sInner[6];
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    bool did = false;
+    if (i < N - 1 && b.stamp[i] == 0u) {
+        const uint32_t l = b.left[i], r = b.right[i];
+        if (children_finished(b.stamp, N, l, r, t)) {
+            b.boxes[i] = box_union(b.boxes[l], b.boxes[r]); b.numTris[i] = b.numTris[l] + b.numTris[r];
+            b.stamp[i] = t; did = true;
+        }
+    }
+    count_progress(progress, did);
+}
+
+__global__ __launch_bounds__(BLOCK) void bvh_treelet_classify(uint32_t N, uint32_t minTris, TreeletBufs b, uint32_t* listCount, uint32_t* list)
+{
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= N - 1) return;
+    b.trips[i] = 0u; b.queued[i] = 0u; b.chain[i] = 0u;
+    if (b.numTris[i] < minTris) return;
+    if (b.numTris[b.left[i]] < minTris && b.numTris[b.right[i]] < minTris) { b.queued[i] = 1u; b.chain[i] = 1u; list[atomicAdd(listCount, 1u)] = i; }
+}
+
+__global__ __launch_bounds__(64) void bvh_treelet_rebuild(uint32_t N, uint32_t minTris, TreeletBufs b, const uint32_t* listCount, const uint32_t* list)
+{
+    __shared__ uint32_t sLeaf[7], sInner[6], sLeafTris[7];
     __shared__ TbBox6 sLeafBox[7];
     __shared__ float sRootArea;
     __shared__ float sCost[128];
     __shared__ uint32_t sCut[128];
     const uint32_t lane = threadIdx.x;
-    if (blockIdx.x >= *b.baseCount) return;
-    if (lane == 0) sNode = b.baseList[blockIdx.x];
-    uint32_t done = 0; /* lane 0: treelets this group has rebuilt */
-    __syncthreads();
-    for (;;) {
-        const uint32_t root = sNode;
+    const uint32_t count = *listCount;
+    for (uint32_t at0 = blockIdx.x; at0 < count; at0 += gridDim.x) {
+        const uint32_t root = list[at0];
         if (lane == 0) { /* grow the treelet: open the inner node with the largest box, five times */
             float area[7]; uint32_t node[7];
-            node[0] = vload(b.left + root); node[1] = vload(b.right + root);
-            area[0] = node[0] >= N - 1 ? -1.0f : box_area(box_load(b.boxes, node[0]));
-            area[1] = node[1] >= N - 1 ? -1.0f : box_area(box_load(b.boxes, node[1]));
+            node[0] = b.left[root]; node[1] = b.right[root];
+            area[0] = node[0] >= N - 1 ? -1.0f : box_area(b.boxes[node[0]]);
+            area[1] = node[1] >= N - 1 ? -1.0f : box_area(b.boxes[node[1]]);
             sInner[0] = root;
             for (uint32_t n = 2; n < 7; n++) {
                 float best = 0.0f; uint32_t at = 0, open = 0;
                 for (uint32_t i = 0; i < n; i++) if (area[i] > best) { best = area[i]; at = i; open = node[i]; }
                 sInner[n - 1] = open;
-                const uint32_t l = vload(b.left + open), r = vload(b.right + open);
-                node[at] = l; area[at] = l >= N - 1 ? -1.0f : box_area(box_load(b.boxes, l));
-                node[n] = r; area[n] = r >= N - 1 ? -1.0f : box_area(box_load(b.boxes, r));
+                const uint32_t l = b.left[open], r = b.right[open];
+                node[at] = l; area[at] = l >= N - 1 ? -1.0f : box_area(b.boxes[l]);
+                node[n] = r; area[n] = r >= N - 1 ? -1.0f : box_area(b.boxes[r]);
             }
             for (int i = 0; i < 7; i++) sLeaf[i] = node[i];
-            sRootArea = box_area(box_load(b.boxes, root));
+            sRootArea = box_area(b.boxes[root]);
         }
         __syncthreads();
-        if (lane < 7) sLeafBox[lane] = box_load(b.boxes, sLeaf[lane]);
+        if (lane < 7) { sLeafBox[lane] = b.boxes[sLeaf[lane]]; sLeafTris[lane] = b.numTris[sLeaf[lane]]; }
         __syncthreads();
         for (uint32_t m = lane; m < 128; m += 64) { /* box area of every leaf subset; a single leaf costs area / root area */
             if (m == 0) continue;
@@ -228,39 +247,47 @@ __global__ __launch_bounds__(64) void bvh_treelet_reorder(uint32_t N, TreeletBuf
                 const uint32_t lm = sCut[mask], rm = mask ^ lm; uint32_t ln, rn;
                 if (lm & (lm - 1)) { ln = sInner[used++]; todoMask[n] = lm; todoNode[n++] = ln; } else ln = sLeaf[__ffs((int)lm) - 1];
                 if (rm & (rm - 1)) { rn = sInner[used++]; todoMask[n] = rm; todoNode[n++] = rn; } else rn = sLeaf[__ffs((int)rm) - 1];
-                vstore(b.left + node, ln); vstore(b.right + node, rn); vstore(b.parent + ln, node); vstore(b.parent + rn, node);
+                b.left[node] = ln; b.right[node] = rn; b.parent[ln] = node; b.parent[rn] = node;
+                uint32_t tris = 0; for (uint32_t i = 0; i < 7; i++) if (mask & (1u << i)) tris += sLeafTris[i];
+                b.numTris[node] = tris; /* the root's is unchanged; the five nodes below it now hold other subsets */
             }
-            for (int j = 5; j >= 0; j--) { const uint32_t x = sInner[j]; box_store(b.boxes, x, box_union(box_load(b.boxes, vload(b.left + x)), box_load(b.boxes, vload(b.right + x)))); }
-            done++;
-            /* climb: leave our count and triangles at the parent; whoever finds the sibling's already there goes on */
-            uint32_t go = 0;
-            if (root != 0) {
-                const uint32_t up = vload(b.parent + root), mine = vload(b.numTris + root);
-                atomicMin(&b.trips[up], done);
-                __threadfence();
-                const uint32_t other = atomicAdd(&b.numTris[up], mine);
-                if (other != 0u) {
-                    __threadfence();
-                    const uint32_t fewest = atomicMin(&b.trips[up], done); /* ours is in already: the smaller of the two counts */
-                    if (fewest < 33u) {
-                        done = fewest;
-                        box_store(b.boxes, up, box_union(box_load(b.boxes, vload(b.left + up)), box_load(b.boxes, vload(b.right + up))));
-                        sNode = up; go = 1;
-                    }
-                }
-            }
-            sGo = go;
+            for (int j = 5; j >= 0; j--) { const uint32_t x = sInner[j]; b.boxes[x] = box_union(b.boxes[b.left[x]], b.boxes[b.right[x]]); }
+            b.trips[root] = b.chain[root]; /* rebuilt: the length of the chain of treelets that ends here (set when the node was listed) */
         }
         __syncthreads();
-        if (!sGo) return;
-        __syncthreads();
     }
+}
+
+/* After a round of rebuilds: which parents are ready?  trips[] is written by the rebuild launches only, so everything read here was
+ * finished by an earlier launch.  The parent link of a rebuilt node and the child links of its parent are still the ones the pass
+ * started with: only a treelet rooted at an ancestor rewires them, and ancestors come strictly later. */
+__global__ __launch_bounds__(BLOCK) void bvh_treelet_advance(uint32_t N, uint32_t minTris, TreeletBufs b,
+                                                            const uint32_t* listCount, const uint32_t* list, uint32_t* nextCount, uint32_t* next)
+{
+    const uint32_t at = blockIdx.x * BLOCK + threadIdx.x;
+    if (at >= *listCount) return;
+    const uint32_t x = list[at];
+    if (x == 0u) return;
+    const uint32_t up = b.parent[x];
+    /* every child of `up` that holds >= minTris triangles must have been rebuilt; the shortest chain goes on */
+    uint32_t fewest = 0xffffffffu; bool all = true;
+    const uint32_t kids[2] = {b.left[up], b.right[up]};
+    for (int k = 0; k < 2; k++) {
+        const uint32_t c = kids[k];
+        if (c >= N - 1 || b.numTris[c] < minTris) continue;
+        const uint32_t tr = b.trips[c];
+        if (tr == 0u) all = false; else fewest = tr < fewest ? tr : fewest;
+    }
+    if (!all || fewest >= 33u) return;
+    if (atomicExch(&b.queued[up], 1u) != 0u) return; /* both children finished in the same round: one of them lists the parent */
+    b.chain[up] = fewest + 1u;
+    next[atomicAdd(nextCount, 1u)] = up;
 }
 
 struct FitOut {
     TbAabbNode* nodesA; uint8_t* primsA; TbPrimitiveMeta* metaA; /* layout A */
     TbNodeB* nodesB; TbTriB* trisB;                               /* layout B */
-    uint32_t* count; uint32_t* height; uint32_t* arrived;         /* per node scratch */
+    uint32_t* count; uint32_t* height; uint32_t* stamp;           /* per node scratch */
 };
 
 __device__ __forceinline__ void put_node(TbAabbNode* nodes, uint32_t i, tb3 mn, tb3 mx, uint32_t fx, uint32_t fy)
@@ -272,60 +299,60 @@ __device__ __forceinline__ void put_node(TbAabbNode* nodes, uint32_t i, tb3 mn, 
     nodes[i] = n;
 }
 
-__global__ __launch_bounds__(BLOCK) void bvh_fit(const float* positions, const uint32_t* triVertexIndex, const uint32_t* triGeometry, const uint32_t* triPrimitive,
-                                                 const uint32_t* triFlags, const unsigned long long* keys, uint32_t N, const uint32_t* left, const uint32_t* right,
-                                                 const uint32_t* parent, FitOut o)
+__global__ __launch_bounds__(BLOCK) void bvh_fit_leaves(const float* positions, const uint32_t* triVertexIndex, const uint32_t* triGeometry, const uint32_t* triPrimitive,
+                                                        const uint32_t* triFlags, const unsigned long long* keys, uint32_t N, FitOut o)
 {
     const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
     if (k >= N) return;
     const uint32_t tri = (uint32_t)keys[k]; /* sorted position k -> input triangle */
     const tb3 v0 = vertex(positions, triVertexIndex, tri, 0), v1 = vertex(positions, triVertexIndex, tri, 1), v2 = vertex(positions, triVertexIndex, tri, 2);
-    {
-        float* p = (float*)(o.primsA + 40ull * k); /* 40-B packed primitive: type + 9 floats */
-        ((uint32_t*)p)[0] = 1u;
-        p[1] = v0.x; p[2] = v0.y; p[3] = v0.z; p[4] = v1.x; p[5] = v1.y; p[6] = v1.z; p[7] = v2.x; p[8] = v2.y; p[9] = v2.z;
-        TbPrimitiveMeta m; m.GeometryContributionToHitGroupIndex = triGeometry[tri]; m.PrimitiveIndex = triPrimitive[tri]; m.GeometryFlags = triFlags[tri];
-        o.metaA[k] = m;
-        TbTriB t;
-        t.v0[0] = v0.x; t.v0[1] = v0.y; t.v0[2] = v0.z; t.geometryIndex = m.GeometryContributionToHitGroupIndex;
-        t.v1[0] = v1.x; t.v1[1] = v1.y; t.v1[2] = v1.z; t.primitiveIndex = m.PrimitiveIndex;
-        t.v2[0] = v2.x; t.v2[1] = v2.y; t.v2[2] = v2.z; t.geometryFlags = m.GeometryFlags;
-        o.trisB[k] = t;
-    }
-    uint32_t x = (N - 1) + k;
-    {
-        tb3 mn = tb3_min(tb3_min(v0, v1), v2), mx = tb3_max(tb3_max(v0, v1), v2);
-        mn = tb3_min(mn, mx - tb3_splat(0.001f));
-        put_node(o.nodesA, x, mn, mx, k | TB_BVH_LEAF_FLAG, 1);
-        o.count[x] = 1; o.height[x] = 1;
-    }
-    /* climb: the first lane to reach an inner node stops, the second one (which sees both children) fits it */
-    if (N == 1) return;
-    while (x != 0) {
-        const uint32_t up = parent[x];
-        __threadfence();
-        if (atomicAdd(&o.arrived[up], 1u) == 0u) return;
-        __threadfence();
+    float* p = (float*)(o.primsA + 40ull * k); /* 40-B packed primitive: type + 9 floats */
+    ((uint32_t*)p)[0] = 1u;
+    p[1] = v0.x; p[2] = v0.y; p[3] = v0.z; p[4] = v1.x; p[5] = v1.y; p[6] = v1.z; p[7] = v2.x; p[8] = v2.y; p[9] = v2.z;
+    TbPrimitiveMeta m; m.GeometryContributionToHitGroupIndex = triGeometry[tri]; m.PrimitiveIndex = triPrimitive[tri]; m.GeometryFlags = triFlags[tri];
+    o.metaA[k] = m;
+    TbTriB t;
+    t.v0[0] = v0.x; t.v0[1] = v0.y; t.v0[2] = v0.z; t.geometryIndex = m.GeometryContributionToHitGroupIndex;
+    t.v1[0] = v1.x; t.v1[1] = v1.y; t.v1[2] = v1.z; t.primitiveIndex = m.PrimitiveIndex;
+    t.v2[0] = v2.x; t.v2[1] = v2.y; t.v2[2] = v2.z; t.geometryFlags = m.GeometryFlags;
+    o.trisB[k] = t;
+    const uint32_t x = (N - 1) + k;
+    tb3 mn = tb3_min(tb3_min(v0, v1), v2), mx = tb3_max(tb3_max(v0, v1), v2);
+    mn = tb3_min(mn, mx - tb3_splat(0.001f));
+    put_node(o.nodesA, x, mn, mx, k | TB_BVH_LEAF_FLAG, 1);
+    o.count[x] = 1; o.height[x] = 1;
+}
+
+/* one wave-front of the bottom-up fit: the parent box comes from the children's STORED centre / half-extent boxes (ComputeAABBs.hlsli), so
+ * the rounding of one level feeds the next and the order is a true dependency; smaller subtree left */
+__global__ __launch_bounds__(BLOCK) void bvh_fit_up(uint32_t N, const uint32_t* left, const uint32_t* right, FitOut o, uint32_t t, uint32_t* progress)
+{
+    const uint32_t up = blockIdx.x * BLOCK + threadIdx.x;
+    bool did = false;
+    if (up < N - 1 && o.stamp[up] == 0u) {
         uint32_t l = left[up], r = right[up];
-        const uint32_t cl = ((volatile uint32_t*)o.count)[l], cr = ((volatile uint32_t*)o.count)[r];
-        if (cl > cr) { const uint32_t t = l; l = r; r = t; }
-        const volatile TbAabbNode* nl = o.nodesA + l; const volatile TbAabbNode* nr = o.nodesA + r;
-        const tb3 lcen = tb3_make(nl->center[0], nl->center[1], nl->center[2]), lhal = tb3_make(nl->halfDim[0], nl->halfDim[1], nl->halfDim[2]);
-        const tb3 rcen = tb3_make(nr->center[0], nr->center[1], nr->center[2]), rhal = tb3_make(nr->halfDim[0], nr->halfDim[1], nr->halfDim[2]);
-        const tb3 mn = tb3_min(lcen - lhal, rcen - rhal), mx = tb3_max(lcen + lhal, rcen + rhal);
-        put_node(o.nodesA, up, mn, mx, l & TB_BVH_INDEX_MASK, r);
-        o.count[up] = cl + cr;
-        const uint32_t hl = ((volatile uint32_t*)o.height)[l], hr = ((volatile uint32_t*)o.height)[r];
-        o.height[up] = 1u + (hl > hr ? hl : hr);
-        TbNodeB nb;
-        nb.cx[0] = lcen.x; nb.cy[0] = lcen.y; nb.cz[0] = lcen.z; nb.hx[0] = lhal.x; nb.hy[0] = lhal.y; nb.hz[0] = lhal.z;
-        nb.cx[1] = rcen.x; nb.cy[1] = rcen.y; nb.cz[1] = rcen.z; nb.hx[1] = rhal.x; nb.hy[1] = rhal.y; nb.hz[1] = rhal.z;
-        nb.left = l >= N - 1 ? (TB_BVH_LEAF_FLAG | (l - (N - 1))) : l;
-        nb.right = r >= N - 1 ? (TB_BVH_LEAF_FLAG | (r - (N - 1))) : r;
-        nb.pad[0] = nb.pad[1] = 0;
-        o.nodesB[up] = nb;
-        x = up;
+        if (children_finished(o.stamp, N, l, r, t)) {
+            const uint32_t cl = o.count[l], cr = o.count[r];
+            if (cl > cr) { const uint32_t x = l; l = r; r = x; }
+            const TbAabbNode nl = o.nodesA[l], nr = o.nodesA[r];
+            const tb3 lcen = tb3_make(nl.center[0], nl.center[1], nl.center[2]), lhal = tb3_make(nl.halfDim[0], nl.halfDim[1], nl.halfDim[2]);
+            const tb3 rcen = tb3_make(nr.center[0], nr.center[1], nr.center[2]), rhal = tb3_make(nr.halfDim[0], nr.halfDim[1], nr.halfDim[2]);
+            const tb3 mn = tb3_min(lcen - lhal, rcen - rhal), mx = tb3_max(lcen + lhal, rcen + rhal);
+            put_node(o.nodesA, up, mn, mx, l & TB_BVH_INDEX_MASK, r);
+            o.count[up] = cl + cr;
+            const uint32_t hl = o.height[l], hr = o.height[r];
+            o.height[up] = 1u + (hl > hr ? hl : hr);
+            TbNodeB nb;
+            nb.cx[0] = lcen.x; nb.cy[0] = lcen.y; nb.cz[0] = lcen.z; nb.hx[0] = lhal.x; nb.hy[0] = lhal.y; nb.hz[0] = lhal.z;
+            nb.cx[1] = rcen.x; nb.cy[1] = rcen.y; nb.cz[1] = rcen.z; nb.hx[1] = rhal.x; nb.hy[1] = rhal.y; nb.hz[1] = rhal.z;
+            nb.left = l >= N - 1 ? (TB_BVH_LEAF_FLAG | (l - (N - 1))) : l;
+            nb.right = r >= N - 1 ? (TB_BVH_LEAF_FLAG | (r - (N - 1))) : r;
+            nb.pad[0] = nb.pad[1] = 0;
+            o.nodesB[up] = nb;
+            o.stamp[up] = t; did = true;
+        }
     }
+    count_progress(progress, did);
 }
 
 } // namespace
@@ -338,7 +365,9 @@ __global__ __launch_bounds__(BLOCK) void bvh_fit(const float* positions, const u
 static size_t round256(size_t b) { return (b + 255) / 256 * 256; }
 static size_t treelet_scratch_bytes(uint32_t N)
 {
-    return round256(sizeof(TbBox6) * (2ull * N - 1)) /* boxes */ + 2 * round256(4ull * N) /* numTris, trips */ + round256(4ull * (N / 7 + 2)) /* count + list */;
+    const size_t nodes = 2ull * N - 1;
+    return round256(sizeof(TbBox6) * nodes) /* boxes */ + round256(4 * nodes) /* numTris */ + 3 * round256(4ull * N) /* trips, chain, queued */
+           + 2 * round256(4ull * (N / 7 + 2)) /* two lists */;
 }
 extern "C" size_t bvh_gpu_scratch_bytes(uint32_t N)
 {
@@ -346,8 +375,25 @@ extern "C" size_t bvh_gpu_scratch_bytes(uint32_t N)
     unsigned long long* nullKeys = nullptr;
     (void)rocprim::radix_sort_keys(nullptr, sortTmp, nullKeys, nullKeys, (size_t)N, 0, 62, (hipStream_t)0);
     const size_t nodes = 2ull * N - 1;
-    return 2 * round256(8ull * N) /* keys in/out */ + 3 * round256(4 * nodes) /* parent, count, height */ + 3 * round256(4ull * N) /* left, right, arrived */
-           + round256(64) /* bounds */ + round256(sortTmp) + treelet_scratch_bytes(N);
+    return 2 * round256(8ull * N) /* keys in/out */ + 3 * round256(4 * nodes) /* parent, count, height */ + 3 * round256(4ull * N) /* left, right, stamp */
+           + round256(64) /* bounds */ + round256(256) /* counters */ + round256(sortTmp) + treelet_scratch_bytes(N);
+}
+
+/* Runs `launch(t)` for t = 1, 2, ... until the device counter *progress says that all `total` inner nodes are finished; the counter
+ * is read back every `batch` launches (a launch that finds nothing to do costs a few microseconds, a read-back a round trip). */
+template <class L>
+static hipError_t run_levels(hipStream_t stream, uint32_t* progress, uint32_t total, L launch)
+{
+    BVH_TRY(hipMemsetAsync(progress, 0, 4, stream));
+    uint32_t done = 0, t = 1;
+    const uint32_t batch = 8;
+    while (done < total) {
+        if (t > 65536u) return hipErrorLaunchFailure; /* a cycle in the hierarchy: cannot happen for a tree */
+        for (uint32_t k = 0; k < batch; k++, t++) launch(t);
+        BVH_TRY(hipMemcpyAsync(&done, progress, 4, hipMemcpyDeviceToHost, stream));
+        BVH_TRY(hipStreamSynchronize(stream));
+    }
+    return hipSuccess;
 }
 
 extern "C" hipError_t bvh_gpu_build(hipStream_t stream, const float* positions, const uint32_t* triVertexIndex, const uint32_t* triGeometry, const uint32_t* triPrimitive,
@@ -365,41 +411,58 @@ extern "C" hipError_t bvh_gpu_build(hipStream_t stream, const float* positions, 
     uint32_t* height = (uint32_t*)take(4 * nodes);
     uint32_t* left = (uint32_t*)take(4ull * N);
     uint32_t* right = (uint32_t*)take(4ull * N);
-    uint32_t* arrived = (uint32_t*)take(4ull * N);
+    uint32_t* stamp = (uint32_t*)take(4ull * N);
     uint32_t* bounds = (uint32_t*)take(64);
+    uint32_t* counters = (uint32_t*)take(256); /* [0] progress of a level-synchronous pass, [1] / [2] the two treelet lists' lengths */
     size_t sortTmp = 0;
     BVH_TRY(rocprim::radix_sort_keys(nullptr, sortTmp, keysIn, keysOut, (size_t)N, 0, 62, stream));
     uint8_t* sortScratch = take(sortTmp);
     TreeletBufs tb;
-    tb.left = left; tb.right = right; tb.parent = parent;
-    tb.boxes = (TbBox6*)take(sizeof(TbBox6) * nodes); tb.numTris = (uint32_t*)take(4ull * N); tb.trips = (uint32_t*)take(4ull * N);
-    tb.baseCount = (uint32_t*)take(4ull * (N / 7 + 2)); tb.baseList = tb.baseCount + 1;
+    tb.left = left; tb.right = right; tb.parent = parent; tb.stamp = stamp;
+    tb.boxes = (TbBox6*)take(sizeof(TbBox6) * nodes); tb.numTris = (uint32_t*)take(4 * nodes);
+    tb.trips = (uint32_t*)take(4ull * N); tb.chain = (uint32_t*)take(4ull * N); tb.queued = (uint32_t*)take(4ull * N);
+    uint32_t* lists[2]; lists[0] = (uint32_t*)take(4ull * (N / 7 + 2)); lists[1] = (uint32_t*)take(4ull * (N / 7 + 2));
     if ((size_t)(at - scratch) > scratchBytes) return hipErrorInvalidValue;
 
     BVH_TRY(hipMemsetAsync(bounds, 0xff, 12, stream));      /* ordMin = 0xffffffff */
     BVH_TRY(hipMemsetAsync(bounds + 4, 0x00, 12, stream));  /* ordMax = 0 */
-    BVH_TRY(hipMemsetAsync(arrived, 0, 4ull * N, stream));
-    const uint32_t blocksN = (N + BLOCK - 1) / BLOCK;
+    const uint32_t blocksN = (N + BLOCK - 1) / BLOCK, blocksInner = N > 1 ? (N - 1 + BLOCK - 1) / BLOCK : 1;
     hipLaunchKernelGGL(bvh_bounds, dim3(blocksN < 2048u ? blocksN : 2048u), dim3(BLOCK), 0, stream, positions, triVertexIndex, N, bounds, bounds + 4);
     hipLaunchKernelGGL(bvh_morton, dim3(blocksN), dim3(BLOCK), 0, stream, positions, triVertexIndex, N, (const uint32_t*)bounds, (const uint32_t*)(bounds + 4), keysIn);
     BVH_TRY(rocprim::radix_sort_keys(sortScratch, sortTmp, keysIn, keysOut, (size_t)N, 0, 62, stream));
-    if (N > 1) hipLaunchKernelGGL(bvh_hierarchy, dim3((N - 1 + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, stream, (const unsigned long long*)keysOut, N, left, right, parent);
+    if (N > 1) hipLaunchKernelGGL(bvh_hierarchy, dim3(blocksInner), dim3(BLOCK), 0, stream, (const unsigned long long*)keysOut, N, left, right, parent);
     /* TreeletReorder::Optimize (TreeletReorder.cpp:38-109): MinTrianglesPerTreelet 7, 14, 28 for the three PREFER_FAST_TRACE passes */
     for (uint32_t pass = 0, minTris = 7; pass < treeletPasses && minTris <= N; pass++, minTris *= 2) {
-        BVH_TRY(hipMemsetAsync(tb.numTris, 0, 4ull * N, stream));
-        BVH_TRY(hipMemsetAsync(tb.trips, 0xff, 4ull * N, stream));
-        BVH_TRY(hipMemsetAsync(tb.baseCount, 0, 4, stream));
-        hipLaunchKernelGGL(bvh_treelet_find, dim3(blocksN), dim3(BLOCK), 0, stream, positions, triVertexIndex, (const unsigned long long*)keysOut, N, minTris, tb);
-        hipLaunchKernelGGL(bvh_treelet_reorder, dim3(N / minTris > 0 ? N / minTris : 1), dim3(64), 0, stream, N, tb);
+        if (pass == 0) { /* boxes and triangle counts of the LBVH; the rebuilds keep both exact from here on */
+            hipLaunchKernelGGL(bvh_treelet_leaves, dim3(blocksN), dim3(BLOCK), 0, stream, positions, triVertexIndex, (const unsigned long long*)keysOut, N, tb);
+            BVH_TRY(hipMemsetAsync(stamp, 0, 4ull * N, stream));
+            BVH_TRY(run_levels(stream, counters, N - 1, [&](uint32_t t) { hipLaunchKernelGGL(bvh_treelet_up, dim3(blocksInner), dim3(BLOCK), 0, stream, N, tb, t, counters); }));
+        }
+        uint32_t cur = 0, n = 0;
+        BVH_TRY(hipMemsetAsync(counters + 1, 0, 8, stream));
+        hipLaunchKernelGGL(bvh_treelet_classify, dim3(blocksInner), dim3(BLOCK), 0, stream, N, minTris, tb, counters + 1, lists[0]);
+        BVH_TRY(hipMemcpyAsync(&n, counters + 1, 4, hipMemcpyDeviceToHost, stream)); BVH_TRY(hipStreamSynchronize(stream));
+        while (n) { /* one round per link of the longest chain of dependent treelets */
+            if (n > N / 7 + 1) return hipErrorLaunchFailure;
+            hipLaunchKernelGGL(bvh_treelet_rebuild, dim3(n), dim3(64), 0, stream, N, minTris, tb, (const uint32_t*)(counters + 1 + cur), (const uint32_t*)lists[cur]);
+            BVH_TRY(hipMemsetAsync(counters + 1 + (cur ^ 1u), 0, 4, stream));
+            hipLaunchKernelGGL(bvh_treelet_advance, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, stream, N, minTris, tb, (const uint32_t*)(counters + 1 + cur), (const uint32_t*)lists[cur],
+                               counters + 1 + (cur ^ 1u), lists[cur ^ 1u]);
+            cur ^= 1u;
+            BVH_TRY(hipMemcpyAsync(&n, counters + 1 + cur, 4, hipMemcpyDeviceToHost, stream)); BVH_TRY(hipStreamSynchronize(stream));
+        }
     }
     const uint64_t offBoxes = 16, offPrims = offBoxes + 32 * nodes, offMeta = offPrims + 40ull * N, total = offMeta + 12ull * N;
     const TbBvhHeader hdr = {(uint32_t)offBoxes, (uint32_t)offPrims, (uint32_t)offMeta, (uint32_t)total};
     BVH_TRY(hipMemcpyAsync(bvhA, &hdr, 16, hipMemcpyHostToDevice, stream));
     FitOut o;
     o.nodesA = (TbAabbNode*)(bvhA + offBoxes); o.primsA = bvhA + offPrims; o.metaA = (TbPrimitiveMeta*)(bvhA + offMeta);
-    o.nodesB = nodesB; o.trisB = trisB; o.count = count; o.height = height; o.arrived = arrived;
-    hipLaunchKernelGGL(bvh_fit, dim3(blocksN), dim3(BLOCK), 0, stream, positions, triVertexIndex, triGeometry, triPrimitive, triFlags, (const unsigned long long*)keysOut, N,
-                       (const uint32_t*)left, (const uint32_t*)right, (const uint32_t*)parent, o);
+    o.nodesB = nodesB; o.trisB = trisB; o.count = count; o.height = height; o.stamp = stamp;
+    hipLaunchKernelGGL(bvh_fit_leaves, dim3(blocksN), dim3(BLOCK), 0, stream, positions, triVertexIndex, triGeometry, triPrimitive, triFlags, (const unsigned long long*)keysOut, N, o);
+    if (N > 1) {
+        BVH_TRY(hipMemsetAsync(stamp, 0, 4ull * N, stream));
+        BVH_TRY(run_levels(stream, counters, N - 1, [&](uint32_t t) { hipLaunchKernelGGL(bvh_fit_up, dim3(blocksInner), dim3(BLOCK), 0, stream, N, (const uint32_t*)left, (const uint32_t*)right, o, t, counters); }));
+    }
     BVH_TRY(hipMemcpyAsync(rootHeight, height, 4, hipMemcpyDeviceToDevice, stream)); /* node 0 is the root (the only leaf when N == 1) */
     BVH_TRY(hipStreamSynchronize(stream)); /* hdr lives on this stack frame */
     return hipGetLastError();

@@ -328,8 +328,9 @@ TBD bool traverse(const SceneRefs& sc, const TbDeviceScene& ds, tb3 o, tb3 d, Hi
  * object space (mul(WorldToObject, float4(o, 1)) / float4(d, 0): the direction is NOT renormalised, so t is the same number in
  * both spaces and `closest` carries over), GetRayData is evaluated again, and the bottom-level structure is walked from its root
  * -- whose own box is never tested (:625: StackPush(0)) -- until the stack is back at the height it had on entry; then the world
- * ray data are recomputed (:769-773) and the top level goes on.  Visit order at both levels as in traverse().  A plain
- * one-lane-one-ray loop: this is the functional path for instanced scenes, the single-level walk above is the tuned one.
+ * ray data are recomputed (:769-773) and the top level goes on.  Visit order at both levels as in traverse(), and since round 3
+ * its scheduling too: while-while parking, the split stack (HYBRID), and a place in the frame-group kernels of the env / sss / vol
+ * feature sets (TWOLEVEL copies, pt_variant.inc) beside the full-feature kernels.
  * ALPHA: the IsValidHit filter (option alpha_test) on non-opaque candidates of the bottom levels, RayGenCommon.h:423-434. */
 struct __attribute__((aligned(16))) InstB16 { TbInstanceB i; };
 TBD tb3 xfm_point34(const float* m, tb3 v) /* pinned order of the dp4: one fma chain per row, as host_scene / bvh_build / the oracle */
@@ -342,49 +343,64 @@ TBD tb3 xfm_vector34(const float* m, tb3 v)
     return tb3_make(tb_fma(m[2], v.z, tb_fma(m[1], v.y, m[0] * v.x)), tb_fma(m[6], v.z, tb_fma(m[5], v.y, m[4] * v.x)), tb_fma(m[10], v.z, tb_fma(m[9], v.y, m[8] * v.x)));
 }
 
-template <bool COUNT, bool ALPHA>
-TBD bool traverse_instanced(const SceneRefs& sc, const TbDeviceScene& ds, tb3 o, tb3 d, Hit& best, uint32_t* stack, uint32_t stride, uint32_t& boxes, uint32_t& tris)
+template <bool COUNT, bool ALPHA, bool HYBRID = false>
+TBD bool traverse_instanced(const SceneRefs& sc, const TbDeviceScene& ds, tb3 o, tb3 d, Hit& best, uint32_t* stack, uint32_t stride, uint32_t& boxes, uint32_t& tris,
+                            uint32_t* overflow = nullptr)
 {
     best.t = MAX_T; best.u = best.v = 0.0f; best.prim = best.geom = 0u;
     RayPre r = ray_prepare(o, d);
     float unusedT;
     if (!box_test(unusedT, best.t, r, ld3(ds.rootCenter), ld3(ds.rootHalf))) return false; /* :566-580, the top level's root box */
+    /* the world ray's slab constants, kept for the way back out of an instance (:769-773 recomputes GetRayData there: the same values;
+     * the top level tests boxes only, so the triangle-test half of RayPre may stay the object ray's) */
+    const tb3 wInv = r.inv, wOinv = r.oinv, wAinv = r.ainv;
     constexpr uint32_t DONE = 0xffffffffu;
+    const int PARK_MIN = (int)ds.parkMin;
     uint32_t top = 0, floor = 0, hitBase = 0;
     bool inBottom = false;
     tb3 ro = o;
     uint32_t ref = ds.rootRef;
     auto pop = [&]() -> uint32_t {
-        if (inBottom && top == floor) { inBottom = false; r = ray_prepare(o, d); ro = o; } /* bottom level exhausted: back to the world ray (:769-773) */
+        if (inBottom && top == floor) { inBottom = false; r.inv = wInv; r.oinv = wOinv; r.ainv = wAinv; } /* bottom level exhausted: back to the world ray */
         if (!top) return DONE;
         --top;
+        if (HYBRID && top >= ds.stackDepth) return overflow[(size_t)(top - ds.stackDepth) * ds.stackOverflowLanes];
         return stack[top * stride];
     };
+    /* while-while like traverse(): lanes that reach a leaf of either level -- an instance to enter or a triangle to test -- park
+     * until fewer than PARK_MIN lanes still descend; each lane's own sequence of tests is unchanged */
     while (ref != DONE) {
-        if (!(ref & TB_BVH_LEAF_FLAG)) {
+        while (!(ref & TB_BVH_LEAF_FLAG)) {
             const TbNodeB n = load_node(sc, ref);
             float lt, rt; bool lh, rh;
             box_test2(lh, rh, lt, rt, best.t, r, n);
             if (COUNT) boxes += 2;
             if (lh && rh) {
                 const bool rightFirst = rt < lt;
-                stack[top * stride] = rightFirst ? n.left : n.right; top++;
+                const uint32_t far = rightFirst ? n.left : n.right;
+                if (HYBRID && top >= ds.stackDepth) overflow[(size_t)(top - ds.stackDepth) * ds.stackOverflowLanes] = far;
+                else stack[top * stride] = far;
+                top++;
                 ref = rightFirst ? n.right : n.left;
             } else if (lh || rh) ref = rh ? n.right : n.left;
             else ref = pop();
-        } else if (!inBottom) { /* top-level leaf = instance (:603-640; InstanceMask 1 & inclusion mask 0xff: always valid) */
-            const TbInstanceB in = ((const InstB16*)((const uint8_t*)ds.instances + ((size_t)(ref & TB_DEVICE_REF_MASK) << 4)))->i;
-            ro = xfm_point34(in.worldToObject, o);
-            r = ray_prepare(ro, xfm_vector34(in.worldToObject, d));
-            inBottom = true; floor = top; hitBase = in.hitGroupBase;
-            ref = in.blasRootRef;
-        } else {
-            const TbTriB tri = load_tri(sc, ref);
-            if (COUNT) tris++;
-            /* committed record: InstanceContributionToHitGroupIndex + GeometryContributionToHitGroupIndex; the IsValidHit filter sees the
-             * same index (RayGenCommon.h:427: CandidateInstanceIndex() + CandidateGeometryIndex()) */
-            tri_test<ALPHA>(best, MIN_T, ro, r, tri, false, sc, ds, hitBase);
-            ref = pop();
+            if (__popcll(__ballot(!(ref & TB_BVH_LEAF_FLAG))) < PARK_MIN) break;
+        }
+        if ((ref & TB_BVH_LEAF_FLAG) && ref != DONE) {
+            if (!inBottom) { /* top-level leaf = instance (:603-640; InstanceMask 1 & inclusion mask 0xff: always valid) */
+                const TbInstanceB in = ((const InstB16*)((const uint8_t*)ds.instances + ((size_t)(ref & TB_DEVICE_REF_MASK) << 4)))->i;
+                ro = xfm_point34(in.worldToObject, o);
+                r = ray_prepare(ro, xfm_vector34(in.worldToObject, d));
+                inBottom = true; floor = top; hitBase = in.hitGroupBase;
+                ref = in.blasRootRef;
+            } else {
+                const TbTriB tri = load_tri(sc, ref);
+                if (COUNT) tris++;
+                /* committed record: InstanceContributionToHitGroupIndex + GeometryContributionToHitGroupIndex; the IsValidHit filter sees the
+                 * same index (RayGenCommon.h:427: CandidateInstanceIndex() + CandidateGeometryIndex()) */
+                tri_test<ALPHA>(best, MIN_T, ro, r, tri, false, sc, ds, hitBase);
+                ref = pop();
+            }
         }
     }
     return best.t < MAX_T;
