@@ -95,6 +95,14 @@ typedef struct tb_scene_info {
 
 /* <-> TracerBoy::TracerBoy(ID3D12CommandQueue*)  (TracerBoy.cpp:507-960).  device_id = HIP ordinal. */
 int tb_create(tb_context** out, int device_id);
+/* One context driving several devices of this process (SURVEY 8b "one context per process may drive N GPUs"; the reference's
+ * TracerBoy object owns one D3D12 device).  The returned context is device_ids[0]'s and owns the frame: tb_load_scene builds once and
+ * uploads to every device, tb_render deals the frame's 64x64 tiles round-robin over the devices, gathers the others' tiles with
+ * peer-to-peer copies (xGMI) and un-permutes them into this context's accumulation surfaces, so tb_read_accum / tb_post_process /
+ * tb_accum_device_ptr see the whole frame.  Options, camera, materials and history resets apply to all devices.  Not gathered: AOV
+ * targets, the real-time chain, ray counters (TB_E_UNSUPPORTED / the owner's share).  The same id may be listed more than once. */
+int tb_create_multi(tb_context** out, const int* device_ids, int n_devices);
+int tb_group_size(tb_context* ctx); /* devices behind this context: 1 for tb_create */
 void tb_destroy(tb_context* ctx);
 const char* tb_last_error(tb_context* ctx); /* ctx may be NULL: error of a failed tb_create */
 

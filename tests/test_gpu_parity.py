@@ -358,6 +358,26 @@ def test_wavefront_pipeline_bit_exact(gpu_tb, settings, scene, sort):
     assert np.array_equal(bits(jit), bits(ref["jittered"]))
 
 
+@pytest.mark.parametrize("refill", [1, 24, 64])
+@pytest.mark.parametrize("scene", ["cornell", "proc0", "proc1"])
+def test_wavefront_extend_with_refill_bit_exact(gpu_tb, settings, scene, refill):
+    """wf_extend in its persistent form (option wavefront_refill = n: a wave claims new queue entries whenever n of its lanes are idle;
+    resumable per-lane walks): the same hits, hence the same picture, for a refill at every finished lane (1), at 24 idle lanes and
+    only when the whole wave is idle (64)."""
+    if scene == "cornell": gpu_tb.LoadScene(CORNELL); W, H, F, depth = 200, 120, 5, 8
+    elif scene == "proc0": gpu_tb.LoadProcedural(0, 30000, 11); W, H, F, depth = 120, 72, 4, 6
+    else: gpu_tb.LoadProcedural(1, 30000, 7); W, H, F, depth = 120, 72, 4, 6
+    s = copy.copy(settings); s.MaxBounces = depth
+    gpu_tb.SetOption("pipeline", 2); gpu_tb.SetOption("wavefront_refill", refill); gpu_tb.SetOption("wavefront_paths", W * H * 2)
+    try:
+        gpu_tb.Render(W, H, F, s, 0.0)
+        out = gpu_tb.ReadAccumulation()
+        assert gpu_tb.GetOption("last_pipeline") == 2
+    finally:
+        gpu_tb.SetOption("pipeline", 0); gpu_tb.SetOption("wavefront_refill", 0); gpu_tb.SetOption("wavefront_paths", 16 << 20)
+    assert np.array_equal(bits(out), bits(_oracle(gpu_tb, W, H, F, s)["output"]))
+
+
 @pytest.mark.parametrize("paths", [1, 2])
 @pytest.mark.parametrize("scene", ["cornell", "teapot", "proc0"])
 def test_pooled_pipeline_bit_exact(gpu_tb, settings, scene, paths):

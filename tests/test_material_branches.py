@@ -196,3 +196,59 @@ def test_material_maps_aovs_with_normal_map(gpu_tb, settings):
             assert np.array_equal(bits(gpu_tb.ReadAOV(which)), bits(ref[key])), key
     finally:
         gpu_tb.SetOption("aov", 0)
+
+
+def test_create_material_disney_translucent_fourier_uber_opacity(built, tmp_path):
+    """The CreateMaterial branches no fixture reached before (VERDICT r2, weak point 7d), against values derived by hand from
+    TracerBoy.cpp:309-330 (disney), :331-364 (uber: uroughness wins over roughness, opacity < 1 -> SSS | SINGLE_SIDED with IOR =
+    index and absorption = Kt), :417-422 (fourier: fixed grey, roughness 0.2), :477-491 (translucent: without a Kd map black albedo,
+    absorption 0.001, SSS; with one only the map), :492-497 (unknown type: the brown default)."""
+    import shutil
+    from tracerboy_amd import api
+    shutil.copy(os.path.join(GOLDEN, "scenes", "material-maps", "albedo.png"), tmp_path / "albedo.png")
+    names = ["DisneyBright", "DisneyMetalGlass", "UberPlain", "UberOpacity", "Fourier", "TranslucentPlain", "TranslucentMap", "Unknown"]
+    defs = [
+        'MakeNamedMaterial "DisneyBright" "string type" ["disney"] "rgb color" [0.9 0.5 0.4] "float roughness" [0.35] "float eta" [1.33] "float metallic" [0.2]',
+        'MakeNamedMaterial "DisneyMetalGlass" "string type" ["disney"] "rgb color" [0.6 0.5 0.4] "float roughness" [0.35] "float eta" [1.2] "float metallic" [0.8] "float spectrans" [0.5]',
+        'MakeNamedMaterial "UberPlain" "string type" ["uber"] "rgb Kd" [0.3 0.4 0.5] "float roughness" [0.25] "float uroughness" [0.1] "float vroughness" [0.1]',
+        'MakeNamedMaterial "UberOpacity" "string type" ["uber"] "rgb Kd" [0.3 0.4 0.5] "float roughness" [0.25] "rgb opacity" [0.5 0.5 0.9] "float index" [1.7] "rgb Kt" [0.2 0.1 0.3]',
+        'MakeNamedMaterial "Fourier" "string type" ["fourier"] "string bsdffile" ["none.bsdf"]',
+        'MakeNamedMaterial "TranslucentPlain" "string type" ["translucent"] "rgb Kd" [0.4 0.4 0.4]',
+        'Texture "alb" "spectrum" "imagemap" "string filename" ["albedo.png"]',
+        'MakeNamedMaterial "TranslucentMap" "string type" ["translucent"] "texture Kd" ["alb"]',
+        'MakeNamedMaterial "Unknown" "string type" ["kdsubsurface"]',
+    ]
+    shapes = []
+    for i, n in enumerate(names):
+        x = -3.5 + i
+        shapes.append('NamedMaterial "%s"\nShape "trianglemesh" "integer indices" [0 1 2] "point P" [%g 0 0  %g 0 0  %g 1 0] "float uv" [0 0 1 0 0 1]' % (n, x, x + 0.8, x))
+    scene = 'LookAt 0 1 8  0 0.5 0  0 1 0\nCamera "perspective" "float fov" [40]\nFilm "image" "integer xresolution" [64] "integer yresolution" [32]\nWorldBegin\n' + "\n".join(defs) + "\n" + "\n".join(shapes) + "\nWorldEnd\n"
+    p = tmp_path / "scene.pbrt"; p.write_text(scene)
+    hs = api.HostScene(str(p))
+    v = hs.view()
+    mats = [v.materials[v.hitGroups[i].MaterialIndex] for i in range(v.numHitGroups)]
+    assert len(mats) == len(names)
+    M = dict(zip(names, mats))
+    NO_ALPHA, METAL, SSS, SINGLE = 0x20, 0x1, 0x2, 0x80
+    f32 = np.float32
+
+    def rgb(t): return (t.x, t.y, t.z)
+    m = M["DisneyBright"]      # albedo.x > 0.7 -> grey 0.2; not metallic (0.2 <= 0.5); no transmission
+    assert rgb(m.albedo) == (f32(0.2), f32(0.2), f32(0.2)) and m.roughness == f32(0.35) and m.IOR == f32(1.33) and m.Flags == NO_ALPHA
+    m = M["DisneyMetalGlass"]  # metallic > 0.5, specTrans > 0.001 -> SSS with absorption 0 and roughness 0
+    assert rgb(m.albedo) == (f32(0.6), f32(0.5), f32(0.4)) and m.IOR == f32(1.2) and m.roughness == 0.0 and rgb(m.absorption) == (0, 0, 0)
+    assert m.Flags == (NO_ALPHA | METAL | SSS)
+    m = M["UberPlain"]         # uRoughness > 0 wins over roughness; default IOR 1.5; specular allowed (no NO_SPECULAR)
+    assert rgb(m.albedo) == (f32(0.3), f32(0.4), f32(0.5)) and m.roughness == f32(0.1) and m.IOR == 1.5 and m.Flags == NO_ALPHA and m.albedoIndex == 0xffffffff
+    m = M["UberOpacity"]       # ChannelAverage(opacity) = 0.633 < 1
+    assert m.Flags == (NO_ALPHA | SSS | SINGLE) and m.IOR == f32(1.7) and rgb(m.absorption) == (f32(0.2), f32(0.1), f32(0.3)) and m.roughness == f32(0.25)
+    m = M["Fourier"]
+    assert rgb(m.albedo) == (f32(0.6), f32(0.6), f32(0.6)) and m.roughness == f32(0.2) and m.Flags == NO_ALPHA and m.IOR == 1.5
+    m = M["TranslucentPlain"]
+    assert rgb(m.albedo) == (0, 0, 0) and rgb(m.absorption) == (f32(0.001), f32(0.001), f32(0.001)) and m.Flags == (NO_ALPHA | SSS)
+    m = M["TranslucentMap"]    # only the map: albedo stays 0, no SSS flag; the fixture PNG is opaque -> NO_ALPHA
+    assert m.albedoIndex != 0xffffffff and rgb(m.albedo) == (0, 0, 0) and not (m.Flags & SSS) and rgb(m.absorption) == (0, 0, 0)
+    m = M["Unknown"]           # falls through to the default: { 153/255, 102/255, 58/255 }, roughness 0.2
+    assert rgb(m.albedo) == (f32(153.0 / 255.0), f32(102.0 / 255.0), f32(58.0 / 255.0)) and m.roughness == f32(0.2) and m.Flags == NO_ALPHA
+    for m in mats:
+        assert m.SpecularCoef == 0.0 and rgb(m.emissive) == (0, 0, 0)

@@ -43,6 +43,8 @@ def lib():
     vp = C.c_void_p
     sig = {
         "tb_create": (C.c_int, [P(vp), C.c_int]),
+        "tb_create_multi": (C.c_int, [P(vp), P(C.c_int), C.c_int]),
+        "tb_group_size": (C.c_int, [vp]),
         "tb_destroy": (None, [vp]),
         "tb_last_error": (C.c_char_p, [vp]),
         "tb_load_scene": (C.c_int, [vp, C.c_char_p]),
@@ -228,10 +230,16 @@ class HostScene:
 class TracerBoy:
     """Drop-in for the hot-path surface of the reference's `class TracerBoy` on one MI355X."""
 
-    def __init__(self, device_id=0):
+    def __init__(self, device_id=0, devices=None):
+        """device_id: one HIP device.  devices=[...]: ONE object driving several devices of this process (tb_create_multi): the frame's
+        tiles are dealt over them, gathered peer-to-peer and assembled on devices[0]."""
         self._L = lib()
         self._ctx = C.c_void_p()
-        rc = self._L.tb_create(C.byref(self._ctx), int(device_id))
+        if devices is not None:
+            ids = (C.c_int * len(devices))(*[int(d) for d in devices])
+            rc = self._L.tb_create_multi(C.byref(self._ctx), ids, len(devices))
+        else:
+            rc = self._L.tb_create(C.byref(self._ctx), int(device_id))
         if rc != 0:
             raise TracerBoyError(rc, (self._L.tb_last_error(None) or b"").decode(errors="replace"))
         self.width = self.height = 0

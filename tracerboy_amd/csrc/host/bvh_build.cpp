@@ -531,11 +531,15 @@ void BuildTlas(HostScene& s, const std::vector<Bounds>& blasRoot, std::vector<Tb
 
 } // namespace
 
-void BuildBvh(HostScene& s, int builder)
+void BuildBvh(HostScene& s, int builder) { BuildBvhWith(s, [builder](HostScene& one) { BuildBvhSingle(one, builder); }, nullptr); }
+
+/* `single` builds one structure over ALL triangles of the scene it is handed (layout A + B, rootRefB, bvhMaxDepth); `tlas` (may be
+ * null: the host's BuildTlas) builds the top level from the structures' root boxes.  The GPU builders pass their own (context.cpp). */
+void BuildBvhWith(HostScene& s, const std::function<void(HostScene&)>& single, const TlasBuilder& tlas)
 {
     if (s.blueNoise0.empty()) LoadBlueNoiseTiles(s); /* system textures are bound with the scene (TracerBoy.cpp:2126-2134) */
     if (s.instances.empty()) {
-        BuildBvhSingle(s, builder);
+        single(s);
         s.blasOffsets.assign({0u, (uint32_t)s.bvhA.size()});
         return;
     }
@@ -556,7 +560,7 @@ void BuildBvh(HostScene& s, int builder)
         tmp.triGeometry.assign(s.triGeometry.begin() + bl.firstTri, s.triGeometry.begin() + bl.firstTri + bl.numTris);
         tmp.triPrimitive.assign(s.triPrimitive.begin() + bl.firstTri, s.triPrimitive.begin() + bl.firstTri + bl.numTris);
         tmp.triFlags.assign(s.triFlags.begin() + bl.firstTri, s.triFlags.begin() + bl.firstTri + bl.numTris);
-        try { BuildBvhSingle(tmp, builder); } catch (...) { tmp.positions.swap(s.positions); throw; }
+        try { single(tmp); } catch (...) { tmp.positions.swap(s.positions); throw; }
         tmp.positions.swap(s.positions);
         while (allA.size() % 16) allA.push_back(0);
         bl.offsetA = (uint32_t)allA.size(); s.blasOffsets.push_back(bl.offsetA);
@@ -574,7 +578,11 @@ void BuildBvh(HostScene& s, int builder)
     if ((uint64_t)allA.size() > 0xffffffffull) throw std::runtime_error("BuildBvh: BVH images exceed 4 GiB");
     s.blasOffsets.push_back((uint32_t)allA.size());
     std::vector<TbNodeB> top; uint32_t tlasDepth = 0; float rc[3], rh[3];
-    BuildTlas(s, blasRoot, top, s.rootRefB, tlasDepth, rc, rh);
+    if (tlas) {
+        std::vector<float> boxes(6 * blasRoot.size());
+        for (size_t b = 0; b < blasRoot.size(); b++) { boxes[6 * b] = blasRoot[b].mn.x; boxes[6 * b + 1] = blasRoot[b].mn.y; boxes[6 * b + 2] = blasRoot[b].mn.z; boxes[6 * b + 3] = blasRoot[b].mx.x; boxes[6 * b + 4] = blasRoot[b].mx.y; boxes[6 * b + 5] = blasRoot[b].mx.z; }
+        tlas(s, boxes, top, s.rootRefB, tlasDepth);
+    } else BuildTlas(s, blasRoot, top, s.rootRefB, tlasDepth, rc, rh);
     for (uint32_t i = 0; i < tlasNodes; i++) allNodes[i] = top[i];
     if (allNodes.empty()) allNodes.push_back(TbNodeB{});
     s.instancesB.resize(M);

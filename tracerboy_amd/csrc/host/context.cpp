@@ -123,6 +123,14 @@ struct tb_context {
     float lastMs = 0.0f;
     std::string lastVariant;
     int lastNodeLayout = 0; /* 1: the last render walked the compact layout-C nodes */
+    /* Multi-device group (tb_create_multi): this context is device 0 of the group and owns the assembled frame; `peers` are the
+     * contexts of the other devices.  A render splits the frame into 64x64 tiles dealt round-robin over the devices (DESIGN.md
+     * section 7), every device renders its own, the peers' packed tiles come over with hipMemcpyPeerAsync (xGMI) and are un-permuted
+     * into this context's accumulation surfaces.  One host thread drives all devices; nothing blocks until the final wait. */
+    std::vector<tb_context*> peers;
+    tb_context* groupOwner = nullptr;          /* set on a peer: API calls on a peer handle are refused */
+    DevBuf groupPacked[2], groupGathered[2];   /* [0] output, [1] jittered: this device's packed tiles; (owner) world x capacity gathered tiles */
+    hipEvent_t evGroup = nullptr;
 };
 
 namespace {
@@ -347,16 +355,49 @@ void buildCompactNodes(const HostScene& s, std::vector<TbNodeC>& out, TbQuantFra
     }
 }
 
-void finalizeScene(tb_context* c)
+/* the top level of a two-level scene on the GPU (bvh_gpu_build_tlas): same bytes as bvh_build.cpp BuildTlas / the oracle's tbo_build_tlas */
+void BuildTlasGpu(tb_context* c, HostScene& s, const std::vector<float>& blasBoxes, std::vector<TbNodeB>& top, uint32_t& rootRef, uint32_t& depth)
+{
+    const uint32_t M = (uint32_t)s.instances.size();
+    std::vector<float> o2w(12ull * M), w2o(12ull * M); std::vector<uint32_t> blas(M), base(M);
+    for (uint32_t i = 0; i < M; i++) { memcpy(&o2w[12ull * i], s.instances[i].objectToWorld, 48); memcpy(&w2o[12ull * i], s.instances[i].worldToObject, 48); blas[i] = s.instances[i].blas; base[i] = s.instances[i].hitGroupBase; }
+    const size_t total = 16 + 32 * (2ull * M - 1) + 116ull * M, scratchBytes = bvh_gpu_tlas_scratch_bytes(M);
+    DevBuf dO, dW, dB, dH, dBox, dScratch, dA, dTop, dWords;
+    auto up = [&](DevBuf& b, const void* p, size_t bytes) { ensure(b, bytes); HIP_TRY(hipMemcpyAsync(b.p, p, bytes, hipMemcpyHostToDevice, c->stream)); };
+    try {
+        up(dO, o2w.data(), o2w.size() * 4); up(dW, w2o.data(), w2o.size() * 4); up(dB, blas.data(), 4ull * M); up(dH, base.data(), 4ull * M); up(dBox, blasBoxes.data(), blasBoxes.size() * 4);
+        ensure(dScratch, scratchBytes); ensure(dA, total); ensure(dTop, std::max<size_t>(1, M - 1) * sizeof(TbNodeB)); ensure(dWords, 8);
+        HIP_TRY(hipMemsetAsync(dA.p, 0, total, c->stream));
+        HIP_TRY(bvh_gpu_build_tlas(c->stream, M, (const float*)dO.p, (const float*)dW.p, (const uint32_t*)dB.p, (const uint32_t*)dH.p, (const float*)dBox.p, (uint8_t*)dScratch.p, scratchBytes,
+                                   (uint8_t*)dA.p, (TbNodeB*)dTop.p, (uint32_t*)dWords.p, (uint32_t*)dWords.p + 1));
+        s.tlasA.resize(total); top.assign(M > 1 ? M - 1 : 0, TbNodeB{});
+        uint32_t words[2];
+        HIP_TRY(hipMemcpy(s.tlasA.data(), dA.p, total, hipMemcpyDeviceToHost));
+        if (M > 1) HIP_TRY(hipMemcpy(top.data(), dTop.p, (size_t)(M - 1) * sizeof(TbNodeB), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(words, dWords.p, 8, hipMemcpyDeviceToHost));
+        rootRef = words[0]; depth = words[1];
+    } catch (...) {
+        for (DevBuf* b : {&dO, &dW, &dB, &dH, &dBox, &dScratch, &dA, &dTop, &dWords}) b->release();
+        throw;
+    }
+    for (DevBuf* b : {&dO, &dW, &dB, &dH, &dBox, &dScratch, &dA, &dTop, &dWords}) b->release();
+}
+
+void finalizeScene(tb_context* c, bool build = true) /* build = false: c->scene already holds a built, reordered tree (a peer of a multi-device group) */
 {
     HostScene& s = c->scene;
     auto opt = [&](const char* k, int64_t d) { auto it = c->options.find(k); return it == c->options.end() ? d : it->second; };
     const int64_t builder = opt("bvh_builder", 0);
     const bool twoLevel = !s.instances.empty();
-    if (twoLevel) BuildBvh(s, builder == 2 ? 0 : (builder == 4 ? 3 : (int)builder)); /* the GPU builders construct one structure; instanced scenes use their host twins (same trees) */
+    if (build) {
+    if (twoLevel && (builder == 2 || builder == 4)) /* every bottom-level structure and the top level on the GPU (GpuBVH2Builder.cpp:498-501: the same passes, no treelets at the top) */
+        BuildBvhWith(s, [&](HostScene& one) { BuildBvhGpu(c, one, builder == 4 ? 3u : 0u); },
+                     [&](HostScene& all, const std::vector<float>& boxes, std::vector<TbNodeB>& top, uint32_t& rootRef, uint32_t& depth) { BuildTlasGpu(c, all, boxes, top, rootRef, depth); });
+    else if (twoLevel) BuildBvh(s, (int)builder);
     else if (builder == 2 || builder == 4) BuildBvhGpu(c, s, builder == 4 ? 3u : 0u);
     else BuildBvh(s, (int)builder);
     if (!twoLevel) reorderNodes(s, (int)opt("node_order", 2), (uint32_t)opt("node_order_top_levels", 10)); /* measured on the 870 k scene: 0 -> 2258, 1 -> 2283, 2 (10 levels) -> 2300 Msamples/s */
+    }
     c->camera = s.camera;
     releaseScene(c);
     TbDeviceScene& d = c->ds;
@@ -513,6 +554,7 @@ void renderWavefront(tb_context* c, int variant, uint32_t W, uint32_t H, uint32_
         wp.samples = (float4*)c->wfSamples.p;
         wp.segCapacity = segCap; wp.numSegments = (uint32_t)((perFrame * nf + segCap - 1) / segCap);
         wp.sortByMaterial = opt("wavefront_sort", 0) ? 1u : 0u;
+        wp.refillBelow = (uint32_t)std::min<int64_t>(64, std::max<int64_t>(0, opt("wavefront_refill", 0)));
         const uint32_t grid = std::min(gridOpt, wp.numSegments);
         const int lds = c->sceneInLds ? 1 : 0;
         HIP_TRY(fn(c->stream, WF_STAGE_GENERATE_EXTEND, &c->ds, &pf, &wp, nullptr, nullptr, &E[0], &hits, lds, nullptr, nullptr, grid));
@@ -758,9 +800,41 @@ int tb_create(tb_context** out, int device_id)
     return TB_OK;
 }
 
+int tb_create_multi(tb_context** out, const int* device_ids, int n_devices)
+{
+    if (!out) return TB_E_INVALID;
+    *out = nullptr;
+    if (!device_ids || n_devices < 1) return fail(nullptr, TB_E_INVALID, "tb_create_multi: need at least one device id");
+    tb_context* owner = nullptr;
+    int rc = tb_create(&owner, device_ids[0]);
+    if (rc != TB_OK) return rc;
+    for (int i = 1; i < n_devices; i++) {
+        tb_context* p = nullptr;
+        rc = tb_create(&p, device_ids[i]);
+        if (rc == TB_OK && hipEventCreateWithFlags(&p->evGroup, hipEventDisableTiming) != hipSuccess) { g_createError = "tb_create_multi: hipEventCreate failed"; rc = TB_E_DEVICE; }
+        if (rc != TB_OK) { if (p) tb_destroy(p); tb_destroy(owner); return rc; }
+        p->groupOwner = owner; owner->peers.push_back(p);
+        if (device_ids[i] != device_ids[0]) { /* direct peer copies over xGMI where the devices allow it; the copy works (staged) without */
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, device_ids[0], device_ids[i]) == hipSuccess && can) { (void)hipSetDevice(device_ids[0]); (void)hipDeviceEnablePeerAccess(device_ids[i], 0); (void)hipGetLastError(); }
+            if (hipDeviceCanAccessPeer(&can, device_ids[i], device_ids[0]) == hipSuccess && can) { (void)hipSetDevice(device_ids[i]); (void)hipDeviceEnablePeerAccess(device_ids[0], 0); (void)hipGetLastError(); }
+        }
+    }
+    (void)hipSetDevice(device_ids[0]);
+    *out = owner;
+    return TB_OK;
+}
+
+int tb_group_size(tb_context* c) { return c ? 1 + (int)c->peers.size() : 0; }
+
 void tb_destroy(tb_context* c)
 {
     if (!c) return;
+    for (tb_context* p : c->peers) { p->groupOwner = nullptr; tb_destroy(p); }
+    c->peers.clear();
+    (void)hipSetDevice(c->device);
+    for (int k = 0; k < 2; k++) { c->groupPacked[k].release(); c->groupGathered[k].release(); }
+    if (c->evGroup) (void)hipEventDestroy(c->evGroup);
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     releaseScene(c);
@@ -788,8 +862,26 @@ void tb_destroy(tb_context* c)
 
 const char* tb_last_error(tb_context* c) { return c ? c->err.c_str() : g_createError.c_str(); }
 
+static uint32_t ownedTiles(uint32_t W, uint32_t H, const TbTileMap& t)
+{
+    uint32_t total = ((W + t.tileW - 1) / t.tileW) * ((H + t.tileH - 1) / t.tileH);
+    return total > t.rank ? (total - t.rank + t.world - 1) / t.world : 0;
+}
+
+/* multi-device group: hand the owner's built scene to every peer (host arrays copied once per peer, then only the upload runs) */
+static int shareSceneWithPeers(tb_context* c)
+{
+    for (tb_context* p : c->peers) {
+        const int rc = guarded(p, [&]() { p->hasScene = false; p->options = c->options; p->scene = c->scene; finalizeScene(p, false); return TB_OK; });
+        if (rc != TB_OK) return fail(c, rc, "peer device " + std::to_string(p->device) + ": " + p->err);
+    }
+    return TB_OK;
+}
+#define TB_REFUSE_PEER(c) do { if ((c) && (c)->groupOwner) return fail((c), TB_E_INVALID, "this context is a member of a multi-device group: call the group's context"); } while (0)
+
 int tb_load_scene(tb_context* c, const char* path)
 {
+    TB_REFUSE_PEER(c);
     return guarded(c, [&]() {
         if (!path) return fail(c, TB_E_INVALID, "tb_load_scene: null path");
         std::shared_ptr<PbrtScene> ps = importScene(path);
@@ -798,17 +890,18 @@ int tb_load_scene(tb_context* c, const char* path)
         c->hasScene = false;
         ConvertScene(*ps, c->scene, co);
         finalizeScene(c);
-        return TB_OK;
+        return shareSceneWithPeers(c);
     });
 }
 
 int tb_load_procedural(tb_context* c, int kind, uint32_t targetTriangles, uint32_t seed)
 {
+    TB_REFUSE_PEER(c);
     return guarded(c, [&]() {
         c->hasScene = false;
         MakeProceduralScene(c->scene, kind, targetTriangles, seed);
         finalizeScene(c);
-        return TB_OK;
+        return shareSceneWithPeers(c);
     });
 }
 
@@ -834,6 +927,7 @@ int tb_set_camera(tb_context* c, const tb_camera* cam)
     if (!c || !cam) return TB_E_INVALID;
     if (!c->hasScene) return fail(c, TB_E_NO_SCENE, "no scene loaded");
     c->camera = *cam; c->ds.config.CameraLensHeight = cam->LensHeight; c->scene.config.CameraLensHeight = cam->LensHeight; c->samplesRendered = 0;
+    for (tb_context* p : c->peers) { const int rc = tb_set_camera(p, cam); if (rc != TB_OK) return rc; }
     return TB_OK;
 }
 
@@ -853,14 +947,69 @@ int tb_set_material(tb_context* c, int id, const TbMaterial* in)
         if (c->sceneInLds) HIP_TRY(hipMemcpy((void*)(c->ds.ldsBlob + c->ds.offMaterials + sizeof(TbDevMaterial) * (size_t)id), in, sizeof *in, hipMemcpyHostToDevice));
         c->sceneFeatures = sceneFeatureMask(c->scene);
         c->samplesRendered = 0;
+        for (tb_context* p : c->peers) { const int rc = tb_set_material(p, id, in); if (rc != TB_OK) return rc; }
         return TB_OK;
     });
 }
 
-int tb_render(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_output_settings* s, float t) { return guarded(c, [&]() { c->lastRenderRealtime = false; return renderImpl(c, W, H, n, s, t, true); }); }
-int tb_render_async(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_output_settings* s, float t) { return guarded(c, [&]() { c->lastRenderRealtime = false; return renderImpl(c, W, H, n, s, t, false); }); }
+/* A render of a multi-device group: every device renders the tiles it owns (tile t -> device t % world, 64x64 tiles), then the peers'
+ * packed tiles travel to the owner (hipMemcpyPeerAsync on the peer's stream, the owner's stream waits on the peer's event) and one
+ * un-permute per surface writes the whole frame into the owner's accumulation surfaces.  Enqueues only; the caller syncs. */
+static int renderGroup(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_output_settings* s, float t)
+{
+    const uint32_t world = 1u + (uint32_t)c->peers.size();
+    if (c->options.count("aov") && c->options["aov"]) return fail(c, TB_E_UNSUPPORTED, "tb_render: AOV targets are not gathered across the devices of a group");
+    std::vector<tb_context*> all; all.push_back(c); for (tb_context* p : c->peers) all.push_back(p);
+    for (uint32_t i = 0; i < world; i++) if (all[i]->tiles.world != world || all[i]->tiles.rank != i) { all[i]->tiles = TbTileMap{i, world, 64, 64}; all[i]->samplesRendered = 0; }
+    for (uint32_t i = world; i-- > 0;) { /* the peers first: their launches are in flight while the owner's are enqueued */
+        tb_context* x = all[i];
+        const int rc = guarded(x, [&]() { x->options = c->options; x->selX = c->selX; x->selY = c->selY; x->lastRenderRealtime = false; return renderImpl(x, W, H, n, s, t, false); });
+        if (rc != TB_OK) return x == c ? rc : fail(c, rc, "peer device " + std::to_string(x->device) + ": " + x->err);
+    }
+    if (n == 0) return TB_OK;
+    const uint64_t tilesTotal = (uint64_t)((W + 63) / 64) * ((H + 63) / 64), capacity = ((tilesTotal + world - 1) / world) * 64 * 64; /* pixels per device, padded to the largest owner */
+    const size_t bytes = (size_t)capacity * sizeof(TbFloat4);
+    return guarded(c, [&]() {
+        for (int k = 0; k < 2; k++) ensure(c->groupGathered[k], bytes * world);
+        for (uint32_t i = 1; i < world; i++) {
+            tb_context* p = all[i];
+            HIP_TRY(hipSetDevice(p->device));
+            for (int k = 0; k < 2; k++) {
+                ensure(p->groupPacked[k], bytes);
+                const TbFloat4* surface = (const TbFloat4*)(k ? p->jittered.p : p->output.p);
+                HIP_TRY(pt_launch_pack_owned(p->stream, surface, (TbFloat4*)p->groupPacked[k].p, W, H, &p->tiles, ownedTiles(W, H, p->tiles)));
+                HIP_TRY(hipMemcpyPeerAsync((uint8_t*)c->groupGathered[k].p + bytes * i, c->device, p->groupPacked[k].p, p->device, bytes, p->stream));
+            }
+            HIP_TRY(hipEventRecord(p->evGroup, p->stream));
+            HIP_TRY(hipSetDevice(c->device));
+            HIP_TRY(hipStreamWaitEvent(c->stream, p->evGroup, 0));
+        }
+        HIP_TRY(hipSetDevice(c->device));
+        for (int k = 0; k < 2; k++) {
+            TbFloat4* surface = (TbFloat4*)(k ? c->jittered.p : c->output.p);
+            HIP_TRY(pt_launch_pack_owned(c->stream, surface, (TbFloat4*)c->groupGathered[k].p, W, H, &c->tiles, ownedTiles(W, H, c->tiles)));
+            HIP_TRY(pt_launch_unpack_gathered(c->stream, (const TbFloat4*)c->groupGathered[k].p, (size_t)capacity, surface, W, H, world, 64, 64));
+        }
+        HIP_TRY(hipEventRecord(c->ev1, c->stream)); /* tb_last_render_ms of a group: render + gather + un-permute on the owner's stream */
+        return TB_OK;
+    });
+}
+
+int tb_render(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_output_settings* s, float t)
+{
+    TB_REFUSE_PEER(c);
+    if (c && !c->peers.empty()) { const int rc = renderGroup(c, W, H, n, s, t); return rc != TB_OK ? rc : tb_sync(c); }
+    return guarded(c, [&]() { c->lastRenderRealtime = false; return renderImpl(c, W, H, n, s, t, true); });
+}
+int tb_render_async(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_output_settings* s, float t)
+{
+    TB_REFUSE_PEER(c);
+    if (c && !c->peers.empty()) return renderGroup(c, W, H, n, s, t);
+    return guarded(c, [&]() { c->lastRenderRealtime = false; return renderImpl(c, W, H, n, s, t, false); });
+}
 int tb_sync(tb_context* c)
 {
+    if (c) for (tb_context* p : c->peers) { const int rc = tb_sync(p); if (rc != TB_OK) return fail(c, rc, "peer device " + std::to_string(p->device) + ": " + p->err); }
     return guarded(c, [&]() {
         HIP_TRY(hipStreamSynchronize(c->stream)); (void)hipEventElapsedTime(&c->lastMs, c->ev0, c->ev1);
         if (hipEventElapsedTime(&c->lastKernelMs, c->evKernelStart, c->evKernel) != hipSuccess) c->lastKernelMs = c->lastMs;
@@ -901,6 +1050,7 @@ void tb_default_denoiser_settings(tb_denoiser_settings* o) /* TracerBoy.h:338-34
  * TracerBoy.cpp:3060-3160: TAA on the indirect lighting (with luminance moments), a-trous denoiser, albedo composite, TAA. */
 int tb_render_realtime(tb_context* c, uint32_t W, uint32_t H, const tb_output_settings* settings, const tb_denoiser_settings* denoiser, float timeSeed)
 {
+    if (c && (!c->peers.empty() || c->groupOwner)) return fail(c, TB_E_UNSUPPORTED, "tb_render_realtime: the real-time chain runs on one device");
     return guarded(c, [&]() {
         if (!c->hasScene) return fail(c, TB_E_NO_SCENE, "tb_render_realtime: no scene loaded");
         tb_output_settings s; if (settings) s = *settings; else DefaultOutputSettings(s);
@@ -1067,23 +1217,19 @@ int tb_read_wave_profile(tb_context* c, uint64_t* out14)
     });
 }
 
-void tb_invalidate_history(tb_context* c) { if (c) c->samplesRendered = 0; }
+void tb_invalidate_history(tb_context* c) { if (c) { c->samplesRendered = 0; for (tb_context* p : c->peers) p->samplesRendered = 0; } }
 uint32_t tb_samples_rendered(tb_context* c) { return c ? c->samplesRendered : 0; }
-int tb_select_pixel(tb_context* c, uint32_t x, uint32_t y) { if (!c) return TB_E_INVALID; c->selX = x; c->selY = y; return TB_OK; }
+int tb_select_pixel(tb_context* c, uint32_t x, uint32_t y) { if (!c) return TB_E_INVALID; c->selX = x; c->selY = y; return TB_OK; } /* (a group renders the selection on the device that owns the pixel's tile; ReadbackStats reads the owner's buffer) */
 
 int tb_set_tile_assignment(tb_context* c, uint32_t rank, uint32_t world, uint32_t tw, uint32_t th)
 {
+    if (c && (!c->peers.empty() || c->groupOwner)) return fail(c, TB_E_INVALID, "tb_set_tile_assignment: a multi-device group deals its tiles itself");
     if (!c || world == 0 || rank >= world || tw == 0 || th == 0) return c ? fail(c, TB_E_INVALID, "tb_set_tile_assignment: bad arguments") : TB_E_INVALID;
     if (world > 1 && (tw % 16 || th % 16)) return fail(c, TB_E_INVALID, "tb_set_tile_assignment: tile width and height must be multiples of 16 (a workgroup renders 16x16 pixels)");
     c->tiles = TbTileMap{rank, world, tw, th}; c->samplesRendered = 0;
     return TB_OK;
 }
 
-static uint32_t ownedTiles(uint32_t W, uint32_t H, const TbTileMap& t)
-{
-    uint32_t total = ((W + t.tileW - 1) / t.tileW) * ((H + t.tileH - 1) / t.tileH);
-    return total > t.rank ? (total - t.rank + t.world - 1) / t.world : 0;
-}
 
 uint64_t tb_owned_pixels(tb_context* c, uint32_t W, uint32_t H) { return c ? (uint64_t)ownedTiles(W, H, c->tiles) * c->tiles.tileW * c->tiles.tileH : 0; }
 
@@ -1136,7 +1282,7 @@ int tb_unpack_gathered_host(uint32_t W, uint32_t H, uint32_t world, uint32_t tw,
 int tb_set_option(tb_context* c, const char* name, int64_t v)
 {
     if (!c || !name) return TB_E_INVALID;
-    static const char* known[] = {"pipeline", "count_rays", "bvh_builder", "flatten_instances", "aov", "scene_in_lds", "lds_scene_budget", "force_full_variant", "wavefront_paths", "wavefront_grid", "wavefront_segment", "pooled_paths", "pooled_samples", "pooled_profile", "park_min", "alpha_test", "node_order", "node_order_top_levels", "frame_group", "overlap_launches", "high_occupancy", "stack_lds_cap", "stack_overflow_max", "flip_texture_uvs", "wavefront_sort", "banded_items", "node_layout"};
+    static const char* known[] = {"pipeline", "count_rays", "bvh_builder", "flatten_instances", "aov", "scene_in_lds", "lds_scene_budget", "force_full_variant", "wavefront_paths", "wavefront_grid", "wavefront_segment", "pooled_paths", "pooled_samples", "pooled_profile", "park_min", "alpha_test", "node_order", "node_order_top_levels", "frame_group", "overlap_launches", "high_occupancy", "stack_lds_cap", "stack_overflow_max", "flip_texture_uvs", "wavefront_sort", "banded_items", "node_layout", "wavefront_refill"};
     for (const char* k : known) if (!strcmp(k, name)) { c->options[name] = v; if (!strcmp(name, "count_rays") || !strcmp(name, "aov")) c->samplesRendered = 0; return TB_OK; }
     return fail(c, TB_E_INVALID, std::string("unknown option '") + name + "'");
 }

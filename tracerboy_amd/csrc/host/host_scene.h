@@ -6,6 +6,7 @@
 #include "pbrt_scene.h"
 
 #include <string>
+#include <functional>
 #include <vector>
 
 namespace tbhost {
@@ -61,6 +62,11 @@ void ConvertScene(const PbrtScene& in, HostScene& out, const ConvertOptions& opt
 
 /* BVH build (bvh_build.cpp).  builder 0 = LBVH with the fallback layer's semantics, 1 = binned SAH. */
 void BuildBvh(HostScene& scene, int builder);
+/* the same with the construction of a single structure / of the top level supplied by the caller (the GPU builders, context.cpp);
+ * tlas fills scene.tlasA, the M - 1 layout-B top-level nodes, the root reference and the top level's depth from the structures' root
+ * boxes (min xyz, max xyz per structure) */
+typedef std::function<void(HostScene&, const std::vector<float>& blasRootBoxes, std::vector<TbNodeB>& topNodes, uint32_t& rootRef, uint32_t& depth)> TlasBuilder;
+void BuildBvhWith(HostScene& scene, const std::function<void(HostScene&)>& single, const TlasBuilder& tlas);
 
 /* Procedural stand-ins (procedural.cpp) */
 void MakeProceduralScene(HostScene& out, int kind, uint32_t targetTriangles, uint32_t seed);

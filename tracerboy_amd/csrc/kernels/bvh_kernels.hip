@@ -288,6 +288,7 @@ struct FitOut {
     TbAabbNode* nodesA; uint8_t* primsA; TbPrimitiveMeta* metaA; /* layout A */
     TbNodeB* nodesB; TbTriB* trisB;                               /* layout B */
     uint32_t* count; uint32_t* height; uint32_t* stamp;           /* per node scratch */
+    const uint32_t* leafMap;                                      /* top level: sorted leaf k -> instance index (a layout-B leaf ref names the instance); null for triangles */
 };
 
 __device__ __forceinline__ void put_node(TbAabbNode* nodes, uint32_t i, tb3 mn, tb3 mx, uint32_t fx, uint32_t fy)
@@ -345,14 +346,73 @@ __global__ __launch_bounds__(BLOCK) void bvh_fit_up(uint32_t N, const uint32_t* 
             TbNodeB nb;
             nb.cx[0] = lcen.x; nb.cy[0] = lcen.y; nb.cz[0] = lcen.z; nb.hx[0] = lhal.x; nb.hy[0] = lhal.y; nb.hz[0] = lhal.z;
             nb.cx[1] = rcen.x; nb.cy[1] = rcen.y; nb.cz[1] = rcen.z; nb.hx[1] = rhal.x; nb.hy[1] = rhal.y; nb.hz[1] = rhal.z;
-            nb.left = l >= N - 1 ? (TB_BVH_LEAF_FLAG | (l - (N - 1))) : l;
-            nb.right = r >= N - 1 ? (TB_BVH_LEAF_FLAG | (r - (N - 1))) : r;
+            nb.left = l >= N - 1 ? (TB_BVH_LEAF_FLAG | (o.leafMap ? o.leafMap[l - (N - 1)] : l - (N - 1))) : l;
+            nb.right = r >= N - 1 ? (TB_BVH_LEAF_FLAG | (o.leafMap ? o.leafMap[r - (N - 1)] : r - (N - 1))) : r;
             nb.pad[0] = nb.pad[1] = 0;
             o.nodesB[up] = nb;
             o.stamp[up] = t; did = true;
         }
     }
     count_progress(progress, did);
+}
+
+/* ---- top level over instances (two-level scenes; fallback layer: TopLevelLoadAABBs.hlsli:62-105, CalculateSceneAABBFromBVHs.hlsl,
+ * CalculateMortonCodesForAABBs.hlsl, then the same sort / BuildBVHSplits / ComputeAABBs passes as a bottom level and no treelet pass:
+ * GpuBVH2Builder.cpp:498-501).  Host twin: bvh_build.cpp BuildTlas; oracle: tbo_build_tlas. */
+struct TlasIn { const float* objectToWorld; const float* worldToObject; const uint32_t* blasIndex; const uint32_t* hitGroupBase; const float* blasBoxes; };
+
+__device__ __forceinline__ tb3 xfm_point34_b(const float* m, tb3 v) /* the pinned dp4 order of TransformAABB: one fma chain per row */
+{
+    return tb3_make(tb_fma(m[2], v.z, tb_fma(m[1], v.y, tb_fma(m[0], v.x, m[3]))), tb_fma(m[6], v.z, tb_fma(m[5], v.y, tb_fma(m[4], v.x, m[7]))),
+                    tb_fma(m[10], v.z, tb_fma(m[9], v.y, tb_fma(m[8], v.x, m[11]))));
+}
+
+__global__ __launch_bounds__(BLOCK) void tlas_leaf_boxes(uint32_t M, TlasIn in, float* leafC, float* leafH, uint32_t* ordMin, uint32_t* ordMax)
+{
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= M) return;
+    const float* b = in.blasBoxes + 6ull * in.blasIndex[i]; /* min xyz, max xyz of the structure's root box */
+    tb3 mn = tb3_splat(3.402823466e+38f), mx = tb3_splat(-3.402823466e+38f);
+    for (int k = 0; k < 8; k++) { /* TransformAABB (RayTracingHelper.hlsli:318-344): the eight corners */
+        const tb3 v = xfm_point34_b(in.objectToWorld + 12ull * i, tb3_make((k & 4) ? b[3] : b[0], (k & 2) ? b[4] : b[1], (k & 1) ? b[5] : b[2]));
+        mn = tb3_min(mn, v); mx = tb3_max(mx, v);
+    }
+    const tb3 c = (mn + mx) * 0.5f, h = mx - c;
+    leafC[3 * i] = c.x; leafC[3 * i + 1] = c.y; leafC[3 * i + 2] = c.z; leafH[3 * i] = h.x; leafH[3 * i + 1] = h.y; leafH[3 * i + 2] = h.z;
+    const tb3 lo = c - h, hi = c + h; /* the scene box is taken from the STORED centre / half-extent boxes (RawDataToAABB) */
+    atomicMin(&ordMin[0], f2ord(lo.x)); atomicMin(&ordMin[1], f2ord(lo.y)); atomicMin(&ordMin[2], f2ord(lo.z));
+    atomicMax(&ordMax[0], f2ord(hi.x)); atomicMax(&ordMax[1], f2ord(hi.y)); atomicMax(&ordMax[2], f2ord(hi.z));
+}
+
+__global__ __launch_bounds__(BLOCK) void tlas_morton(uint32_t M, const float* leafC, const uint32_t* ordMin, const uint32_t* ordMax, unsigned long long* keys)
+{
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= M) return;
+    const tb3 smin = tb3_make(ord2f(ordMin[0]), ord2f(ordMin[1]), ord2f(ordMin[2])), smax = tb3_make(ord2f(ordMax[0]), ord2f(ordMax[1]), ord2f(ordMax[2]));
+    const tb3 dim = tb3_max(smax - smin, tb3_splat(0.00001f));
+    const tb3 u = (tb3_make(leafC[3 * i], leafC[3 * i + 1], leafC[3 * i + 2]) - smin) / dim;
+    const float ax = tb_min(tb_max(u.x * 1024.0f, 0.0f), 1023.0f), ay = tb_min(tb_max(u.y * 1024.0f, 0.0f), 1023.0f), az = tb_min(tb_max(u.z * 1024.0f, 0.0f), 1023.0f);
+    const uint32_t code = expand10((uint32_t)ay) | (expand10((uint32_t)ax) << 1) | (expand10((uint32_t)az) << 2);
+    keys[i] = ((unsigned long long)code << 32) | (unsigned long long)i;
+}
+
+__global__ __launch_bounds__(BLOCK) void tlas_fit_leaves(uint32_t M, const unsigned long long* keys, const float* leafC, const float* leafH, TlasIn in,
+                                                         TbAabbNode* nodesA, uint8_t* metaA, uint32_t* count, uint32_t* height, uint32_t* order)
+{
+    const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
+    if (k >= M) return;
+    const uint32_t i = (uint32_t)keys[k]; /* sorted leaf k = instance i */
+    order[k] = i;
+    TbAabbNode n;
+    n.center[0] = leafC[3 * i]; n.center[1] = leafC[3 * i + 1]; n.center[2] = leafC[3 * i + 2]; n.flags = k | TB_BVH_LEAF_FLAG;
+    n.halfDim[0] = leafH[3 * i]; n.halfDim[1] = leafH[3 * i + 1]; n.halfDim[2] = leafH[3 * i + 2]; n.rightNodeIndex = 1;
+    nodesA[(M - 1) + k] = n; count[(M - 1) + k] = 1; height[(M - 1) + k] = 1;
+    TbBvhMetadata md; memset(&md, 0, sizeof md);
+    for (int j = 0; j < 12; j++) { md.WorldToObject[j] = in.worldToObject[12ull * i + j]; md.ObjectToWorld[j] = in.objectToWorld[12ull * i + j]; }
+    md.InstanceIDAndMask = (0u & 0x00ffffffu) | (1u << 24);                          /* InstanceID 0, InstanceMask 1 (TracerBoy.cpp:2049) */
+    md.InstanceContributionToHitGroupIndexAndFlags = in.hitGroupBase[i] & 0x00ffffffu; /* flags 0 */
+    md.BlasIndex = in.blasIndex[i]; md.InstanceIndex = i;
+    memcpy(metaA + 116ull * k, &md, 116);
 }
 
 } // namespace
@@ -457,7 +517,7 @@ extern "C" hipError_t bvh_gpu_build(hipStream_t stream, const float* positions, 
     BVH_TRY(hipMemcpyAsync(bvhA, &hdr, 16, hipMemcpyHostToDevice, stream));
     FitOut o;
     o.nodesA = (TbAabbNode*)(bvhA + offBoxes); o.primsA = bvhA + offPrims; o.metaA = (TbPrimitiveMeta*)(bvhA + offMeta);
-    o.nodesB = nodesB; o.trisB = trisB; o.count = count; o.height = height; o.stamp = stamp;
+    o.nodesB = nodesB; o.trisB = trisB; o.count = count; o.height = height; o.stamp = stamp; o.leafMap = nullptr;
     hipLaunchKernelGGL(bvh_fit_leaves, dim3(blocksN), dim3(BLOCK), 0, stream, positions, triVertexIndex, triGeometry, triPrimitive, triFlags, (const unsigned long long*)keysOut, N, o);
     if (N > 1) {
         BVH_TRY(hipMemsetAsync(stamp, 0, 4ull * N, stream));
@@ -465,5 +525,72 @@ extern "C" hipError_t bvh_gpu_build(hipStream_t stream, const float* positions, 
     }
     BVH_TRY(hipMemcpyAsync(rootHeight, height, 4, hipMemcpyDeviceToDevice, stream)); /* node 0 is the root (the only leaf when N == 1) */
     BVH_TRY(hipStreamSynchronize(stream)); /* hdr lives on this stack frame */
+    return hipGetLastError();
+}
+
+/* Top level on the GPU.  Device inputs: per instance objectToWorld / worldToObject (12 floats each), structure index, first hit-group
+ * record; per structure its root box (min xyz, max xyz).  Outputs: the layout-A image (16 + 32 (2M - 1) + 116 M bytes), M - 1 layout-B
+ * nodes whose leaf refs name instances, rootRef (LEAF | instance when M == 1), the depth in nodes.  scratch: bvh_gpu_tlas_scratch_bytes(M). */
+extern "C" size_t bvh_gpu_tlas_scratch_bytes(uint32_t M)
+{
+    size_t sortTmp = 0;
+    unsigned long long* nullKeys = nullptr;
+    (void)rocprim::radix_sort_keys(nullptr, sortTmp, nullKeys, nullKeys, (size_t)M, 0, 62, (hipStream_t)0);
+    const size_t nodes = 2ull * M - 1;
+    return 2 * round256(8ull * M) + 3 * round256(4 * nodes) + 4 * round256(4ull * M) + 2 * round256(12ull * M) + round256(64) + round256(256) + round256(sortTmp);
+}
+
+extern "C" hipError_t bvh_gpu_build_tlas(hipStream_t stream, uint32_t M, const float* objectToWorld, const float* worldToObject, const uint32_t* blasIndex, const uint32_t* hitGroupBase,
+                                         const float* blasBoxes, uint8_t* scratch, size_t scratchBytes, uint8_t* tlasA, TbNodeB* topNodes, uint32_t* rootRefOut, uint32_t* rootHeight)
+{
+    if (M == 0) return hipErrorInvalidValue;
+    const size_t nodes = 2ull * M - 1;
+    uint8_t* at = scratch;
+    auto take = [&](size_t bytes) { uint8_t* p = at; at += (bytes + 255) / 256 * 256; return p; };
+    unsigned long long* keysIn = (unsigned long long*)take(8ull * M);
+    unsigned long long* keysOut = (unsigned long long*)take(8ull * M);
+    uint32_t* parent = (uint32_t*)take(4 * nodes);
+    uint32_t* count = (uint32_t*)take(4 * nodes);
+    uint32_t* height = (uint32_t*)take(4 * nodes);
+    uint32_t* left = (uint32_t*)take(4ull * M);
+    uint32_t* right = (uint32_t*)take(4ull * M);
+    uint32_t* stamp = (uint32_t*)take(4ull * M);
+    uint32_t* order = (uint32_t*)take(4ull * M);
+    float* leafC = (float*)take(12ull * M);
+    float* leafH = (float*)take(12ull * M);
+    uint32_t* bounds = (uint32_t*)take(64);
+    uint32_t* counters = (uint32_t*)take(256);
+    size_t sortTmp = 0;
+    BVH_TRY(rocprim::radix_sort_keys(nullptr, sortTmp, keysIn, keysOut, (size_t)M, 0, 62, stream));
+    uint8_t* sortScratch = take(sortTmp);
+    if ((size_t)(at - scratch) > scratchBytes) return hipErrorInvalidValue;
+    const TlasIn in = {objectToWorld, worldToObject, blasIndex, hitGroupBase, blasBoxes};
+    BVH_TRY(hipMemsetAsync(bounds, 0xff, 12, stream));
+    BVH_TRY(hipMemsetAsync(bounds + 4, 0x00, 12, stream));
+    const uint32_t blocksM = (M + BLOCK - 1) / BLOCK, blocksInner = M > 1 ? (M - 1 + BLOCK - 1) / BLOCK : 1;
+    hipLaunchKernelGGL(tlas_leaf_boxes, dim3(blocksM), dim3(BLOCK), 0, stream, M, in, leafC, leafH, bounds, bounds + 4);
+    hipLaunchKernelGGL(tlas_morton, dim3(blocksM), dim3(BLOCK), 0, stream, M, (const float*)leafC, (const uint32_t*)bounds, (const uint32_t*)(bounds + 4), keysIn);
+    BVH_TRY(rocprim::radix_sort_keys(sortScratch, sortTmp, keysIn, keysOut, (size_t)M, 0, 62, stream));
+    if (M > 1) hipLaunchKernelGGL(bvh_hierarchy, dim3(blocksInner), dim3(BLOCK), 0, stream, (const unsigned long long*)keysOut, M, left, right, parent);
+    const uint64_t offBoxes = 16, offMeta = offBoxes + 32 * nodes, total = offMeta + 116ull * M;
+    const TbBvhHeader hdr = {(uint32_t)offBoxes, (uint32_t)offMeta, (uint32_t)offMeta, (uint32_t)total};
+    BVH_TRY(hipMemcpyAsync(tlasA, &hdr, 16, hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(tlas_fit_leaves, dim3(blocksM), dim3(BLOCK), 0, stream, M, (const unsigned long long*)keysOut, (const float*)leafC, (const float*)leafH, in,
+                       (TbAabbNode*)(tlasA + offBoxes), tlasA + offMeta, count, height, order);
+    if (M > 1) {
+        FitOut o; memset(&o, 0, sizeof o);
+        o.nodesA = (TbAabbNode*)(tlasA + offBoxes); o.nodesB = topNodes; o.count = count; o.height = height; o.stamp = stamp; o.leafMap = order;
+        BVH_TRY(hipMemsetAsync(stamp, 0, 4ull * M, stream));
+        BVH_TRY(run_levels(stream, counters, M - 1, [&](uint32_t t) { hipLaunchKernelGGL(bvh_fit_up, dim3(blocksInner), dim3(BLOCK), 0, stream, M, (const uint32_t*)left, (const uint32_t*)right, o, t, counters); }));
+        const uint32_t zero = 0;
+        BVH_TRY(hipMemcpyAsync(rootRefOut, &zero, 4, hipMemcpyHostToDevice, stream));
+    } else {
+        uint32_t first = 0;
+        BVH_TRY(hipMemcpyAsync(&first, order, 4, hipMemcpyDeviceToHost, stream)); BVH_TRY(hipStreamSynchronize(stream));
+        first |= TB_BVH_LEAF_FLAG;
+        BVH_TRY(hipMemcpyAsync(rootRefOut, &first, 4, hipMemcpyHostToDevice, stream));
+    }
+    BVH_TRY(hipMemcpyAsync(rootHeight, height, 4, hipMemcpyDeviceToDevice, stream));
+    BVH_TRY(hipStreamSynchronize(stream)); /* hdr / zero live on this stack frame */
     return hipGetLastError();
 }

@@ -20,6 +20,10 @@ size_t bvh_gpu_scratch_bytes(uint32_t N);
 hipError_t bvh_gpu_build(hipStream_t stream, const float* positions, const uint32_t* triVertexIndex, const uint32_t* triGeometry, const uint32_t* triPrimitive,
                          const uint32_t* triFlags, uint32_t N, uint32_t treeletPasses, uint8_t* scratch, size_t scratchBytes, uint8_t* bvhA, TbNodeB* nodesB, TbTriB* trisB,
                          uint32_t* rootHeight);
+/* top level over instances on the GPU (two-level scenes); rootRef / rootHeight are device words */
+size_t bvh_gpu_tlas_scratch_bytes(uint32_t M);
+hipError_t bvh_gpu_build_tlas(hipStream_t stream, uint32_t M, const float* objectToWorld, const float* worldToObject, const uint32_t* blasIndex, const uint32_t* hitGroupBase,
+                              const float* blasBoxes, uint8_t* scratch, size_t scratchBytes, uint8_t* tlasA, TbNodeB* topNodes, uint32_t* rootRef, uint32_t* rootHeight);
 /* real-time chain (rt_kernels.hip): temporal accumulation, one a-trous denoiser iteration, albedo composite */
 hipError_t rt_launch_temporal(hipStream_t stream, const TbTemporalConstants* k, const TbFloat4* history, const TbFloat4* current, const TbFloat4* worldPos,
                               const TbFloat4* prevWorldPos, const TbFloat4* momentHistory, const TbFloat4* normals, TbFloat4* out, TbFloat4* outMoment);

@@ -27,6 +27,7 @@ struct WfParams {
     unsigned long long* prof;                /* pipeline 3, counting launch: WaveProf slots (pt_device.hpp), else null */
     uint32_t pathsPerLane;                   /* pipeline 3 (pt_pooled.inc): samples of its pixel a lane keeps in flight, 1 or 2 */
     uint32_t sortByMaterial;                 /* wf_shade: shade the entries of a segment in material order (counting sort of indices in LDS) */
+    uint32_t refillBelow;                    /* wf_extend: > 0 = the persistent form, a wave claims new entries when this many of its lanes are idle */
 };
 
 #define WF_STAGE_GENERATE_EXTEND 0
