@@ -135,7 +135,7 @@ def pmc_summary(key):
         passes["_stale"] = stale
         # pt_persistent<F, LDS, COUNT, GROUPS[, HYBRID]>: not the counters-on launch (COUNT = true), not the sample fold; the frame-group
         # kernel (GROUPS = true) is the timed one -- its one-pixel-per-lane twin only appears as the zero-frame warm launch
-        m = re.search(r"pt_persistent<\d+u, (true|false), (true|false), (true|false)(?:, (?:true|false))?>", name)
+        m = re.search(r"pt_persistent<\d+u, (true|false), (true|false), (true|false)", name)   # <F, LDS, COUNT, GROUPS, ...: the later parameters (split stack, node layout, two-level) do not matter here
         if not m or m.group(2) == "true":
             continue
         if m.group(3) == "true":
@@ -545,7 +545,10 @@ def main():
 
         if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only
             import oracle_lib as ol
-            cores = len(os.sched_getaffinity(0))      # the CPUs this process may run on, not the machine's
+            allowance = cpu_allowance()
+            cores = len(os.sched_getaffinity(0))      # the CPUs this process may run on, not the machine's ...
+            if allowance.get("cgroup_quota_cpus"):    # ... and not more threads than the cgroup lets run at once: 256 threads on a 16-CPU quota
+                cores = max(1, min(cores, int(allowance["cgroup_quota_cpus"] + 0.999)))   # time-slice each other to 8.8x; 16 threads reach the quota
             view = tb.HostSceneView(); pf = tb.FrameConstants(W, H, 0, s, 0.0)
             # probe the all-threads rate on one full 1-spp frame, size the sample (whole frames) to ~cpu_baseline_seconds; the
             # single-thread figure is measured on whole frames too (the same rows), sized to about the same time
@@ -571,11 +574,11 @@ def main():
                                       "single_thread": round(n1 / dt1 / 1e6, 4), "single_thread_sample": rows1 + " (%.1f s)" % dt1,
                                       "machine_cpus": os.cpu_count()}
             cb = result["cpu_baseline"]
-            cb["box"] = cpu_allowance()
+            cb["box"] = allowance
             cb["effective_parallelism"] = round(cb["value"] / max(cb["single_thread"], 1e-9), 1)        # all-threads rate / single-thread rate
             cb["cpus_worth_of_service"] = round(cpu_seconds / max(dt, 1e-9), 1)                        # process CPU time / wall time of the all-threads run
-            cb["unthrottled_estimate"] = {"value": round(cb["single_thread"] * cores, 2), "unit": "Msamples/s",
-                                          "note": "single-thread rate x %d threads: what the same port would reach if every thread had a core to itself" % cores}
+            cb["unthrottled_estimate"] = {"value": round(cb["single_thread"] * len(os.sched_getaffinity(0)), 2), "unit": "Msamples/s",
+                                          "note": "single-thread rate x the %d hardware threads of the box: what the same port would reach there without a quota" % len(os.sched_getaffinity(0))}
             cb["sample"] = cb["sample"].replace("over 8-row strips", "over row strips (>= 4 work items per thread)")
             cb["note"] = ("the all-threads figure is what THIS lease delivers: effective_parallelism is well below the thread count when the box throttles "
                           "(cgroup quota in box.cgroup_quota_cpus) or shares its cores (cpus_worth_of_service << threads); quote speed-ups against both figures")

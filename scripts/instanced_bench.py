@@ -35,7 +35,7 @@ K = a.grid; ext = K * 1.0
 mat = {"matte": '"string type" ["matte"] "rgb Kd" [0.6 0.45 0.3]', "glass": '"string type" ["glass"] "float index" [1.5]', "plastic": '"string type" ["plastic"] "rgb Kd" [0.2 0.4 0.6] "rgb Ks" [0.3 0.3 0.3] "float roughness" [0.15]'}[a.material]
 lines = ['LookAt 0 %.3f %.3f  0 0.3 0  0 1 0' % (0.75 * ext, 1.25 * ext), 'Camera "perspective" "float fov" [38]', 'Film "image" "integer xresolution" [%d] "integer yresolution" [%d]' % (a.width, a.height), "WorldBegin",
          'MakeNamedMaterial "Ground" "string type" ["matte"] "rgb Kd" [0.5 0.5 0.5]', 'MakeNamedMaterial "Blob" ' + mat,
-         "AttributeBegin", '  AreaLightSource "diffuse" "rgb L" [9 9 8]',
+         'NamedMaterial "Ground"', "AttributeBegin", '  AreaLightSource "diffuse" "rgb L" [9 9 8]',
          '  Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [%g %g %g  %g %g %g  %g %g %g  %g %g %g] "normal N" [0 -1 0 0 -1 0 0 -1 0 0 -1 0]' % (-ext / 3, ext, -ext / 3, ext / 3, ext, -ext / 3, ext / 3, ext, ext / 3, -ext / 3, ext, ext / 3),
          "AttributeEnd", 'NamedMaterial "Ground"',
          'Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [%g 0 %g  %g 0 %g  %g 0 %g  %g 0 %g] "normal N" [0 1 0 0 1 0 0 1 0 0 1 0]' % (-ext, ext, ext, ext, ext, -ext, -ext, -ext),

@@ -524,6 +524,15 @@ void renderWavefront(tb_context* c, int variant, uint32_t W, uint32_t H, uint32_
     const uint64_t maxSegments = (perFrame * batch + segCap - 1) / segCap;
     const uint64_t capacity = maxSegments * segCap;
     if (capacity > 0xffffff00ull) throw std::runtime_error("wavefront batch exceeds 2^32 paths");
+    {   /* the LDS a stage asks for, checked here so that a large segment fails with a sentence instead of a launch error */
+        const size_t blobBytes = c->sceneInLds ? c->ds.ldsBlobBytes : 0, ldsLimit = 160 * 1024;
+        if (opt("wavefront_sort", 0)) {
+            if (segCap > 65536u) throw std::runtime_error("wavefront_sort: wavefront_segment must not exceed 65536 (the index permutation is 16-bit); unsupported");
+            const size_t sortBytes = 64 * 4 + ((size_t)segCap * 3 + 15) / 16 * 16;
+            if (16 + blobBytes + sortBytes > ldsLimit) throw std::runtime_error("wavefront_sort: a segment of " + std::to_string(segCap) + " entries needs " + std::to_string(16 + blobBytes + sortBytes) + " B of LDS (limit 163840): lower wavefront_segment; unsupported");
+        }
+        if (16 + (size_t)c->ds.stackDepth * 1024 + blobBytes > ldsLimit) throw std::runtime_error("wavefront pipeline: traversal stack of depth " + std::to_string(c->ds.stackDepth) + " does not fit LDS; unsupported");
+    }
     const bool sss = (kVariants[variant].features & PT_FEAT_SSS) != 0; /* entries may be steps of the interior walk: two more columns per queue */
     {
         for (int q = 0; q < 2; q++) for (int k = 0; k < (sss ? 6 : 4); k++) ensure(c->wfCols[q][k], capacity * 16);
@@ -566,7 +575,9 @@ void renderWavefront(tb_context* c, int variant, uint32_t W, uint32_t H, uint32_
             HIP_TRY(fn(c->stream, WF_STAGE_SHADE, &c->ds, &pf, &wp, &in, &S, &next, &hits, lds, nullptr, nullptr, grid));
             HIP_TRY(fn(c->stream, WF_STAGE_CONNECT, &c->ds, &pf, &wp, nullptr, &S, &next, &hits, lds, nullptr, nullptr, grid));
             if (!sss && b + 1 >= depth) break;
-            if (sss && b + 1 >= depth) {
+            /* SSS: past the first MaxBounces rounds the queues are looked at every FOURTH round only (a round over empty queues is a
+             * few no-op launches; a look is a copy + a wait of the host, which used to serialise host and device once per round) */
+            if (sss && b + 1 >= depth && ((b + 1 - depth) & 3u) == 0u) {
                 counts.resize(wp.numSegments);
                 HIP_TRY(hipMemcpyAsync(counts.data(), next.segCount, (size_t)wp.numSegments * 4, hipMemcpyDeviceToHost, c->stream));
                 HIP_TRY(hipStreamSynchronize(c->stream));
