@@ -16,6 +16,29 @@
 
 constexpr int UNROLL = 16, ITERS = 2048;
 
+/* round 3: does a VALU instruction cost less when part of the wave is masked off?  (it would pay to pack the live rays of a walk into
+ * the low lanes if it did)  LANES = how many lanes of each wave run the loop: 64, the low 32, the low 16, every 4th (16 lanes spread). */
+template <int LANES>
+__global__ __launch_bounds__(1024) void masked_kernel(float* out, unsigned long long* cycles, unsigned long long* realtime)
+{
+    float a = (float)threadIdx.x * 1e-3f + 1.0f, b = 0.999f;
+    float acc[UNROLL], acd[UNROLL];
+    for (int i = 0; i < UNROLL; i++) { acc[i] = (float)i; acd[i] = (float)i * 0.5f; }
+    const unsigned lane = threadIdx.x & 63u;
+    const bool on = LANES == 64 ? true : (LANES == 32 ? lane < 32 : (LANES == 16 ? lane < 16 : (lane & 3u) == 0));
+    __syncthreads();
+    const unsigned long long t0 = __builtin_readcyclecounter(), r0 = wall_clock64();
+    if (on)
+        for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+            for (int i = 0; i < UNROLL; i++) asm volatile("v_fma_f32 %0, %2, %3, %0\n\tv_max_f32 %1, %2, %1" : "+v"(acc[i]), "+v"(acd[i]) : "v"(a), "v"(b));
+        }
+    const unsigned long long t1 = __builtin_readcyclecounter(), r1 = wall_clock64();
+    float s = 0; for (int i = 0; i < UNROLL; i++) s += acc[i] + acd[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if ((threadIdx.x & 63) == 0) { cycles[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0; realtime[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = r1 - r0; }
+}
+
 template <int KIND>
 __global__ __launch_bounds__(1024) void issue_kernel(float* out, unsigned long long* cycles, unsigned long long* realtime)
 {
@@ -116,6 +139,24 @@ void run(const char* name, int wavesPerSimd)
     CHECK(hipFree(out)); CHECK(hipFree(cyc)); CHECK(hipFree(rt));
 }
 
+template <int LANES>
+void run_masked(const char* name, int wavesPerSimd)
+{
+    int dev = 0, cus = 0; CHECK(hipGetDevice(&dev)); CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    const int block = 256 * wavesPerSimd, waves = block / 64, grid = cus;
+    float* out; unsigned long long *cyc, *rt;
+    CHECK(hipMalloc(&out, (size_t)grid * block * 4)); CHECK(hipMalloc(&cyc, (size_t)grid * waves * 8)); CHECK(hipMalloc(&rt, (size_t)grid * waves * 8));
+    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    masked_kernel<LANES><<<grid, block>>>(out, cyc, rt);
+    CHECK(hipEventRecord(e0));
+    masked_kernel<LANES><<<grid, block>>>(out, cyc, rt);
+    CHECK(hipEventRecord(e1)); CHECK(hipDeviceSynchronize());
+    float ms = 0; CHECK(hipEventElapsedTime(&ms, e0, e1));
+    const double insts = 2.0 * UNROLL * ITERS;
+    printf("%-34s waves/SIMD %d: kernel %.3f ms => %.3f ns per wave-instr per SIMD\n", name, wavesPerSimd, ms, ms * 1e6 / (insts * wavesPerSimd));
+    CHECK(hipFree(out)); CHECK(hipFree(cyc)); CHECK(hipFree(rt));
+}
+
 int main()
 {
     hipDeviceProp_t p; CHECK(hipGetDeviceProperties(&p, 0));
@@ -132,6 +173,7 @@ int main()
         run<44>("v_lshl_or_b32", w); run<45>("v_bfe_u32", w); run<46>("v_dot2_f32_f16", w); run<48>("v_min_f32 3-operand", w); run<49>("v_max_f32_e64", w);
         run<16>("s_and_b64", w); run<17>("v_fma_f32 + s_and_b64 (2)", w); run<5>("v_add_u32", w); run<6>("v_fma_f32 dependent", w);
     }
+    for (int w : {1, 4}) { run_masked<64>("fma+max, all 64 lanes", w); run_masked<32>("fma+max, low 32 lanes", w); run_masked<16>("fma+max, low 16 lanes", w); run_masked<4>("fma+max, every 4th lane", w); }
     printf("ns per wave-instr per SIMD x shader clock (GHz) = cycles; at 2.4 GHz: 2 cycles = 0.833 ns, 4 cycles = 1.667 ns\n");
     return 0;
 }

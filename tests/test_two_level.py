@@ -307,7 +307,6 @@ def test_gpu_built_two_level_structures_equal_the_host_build(gpu_tb, gpu_builder
         many += ["AttributeBegin", "  Translate %g %g %g" % ((i * 37 % 17) - 8.0, (i % 5) * 0.3, (i * 11 % 13) - 6.0), "  Rotate %d 0 1 0" % (i * 23 % 360), '  ObjectInstance "t"', "AttributeEnd"]
     many += ["WorldEnd"]
     p_many = tmp_path / "many.pbrt"; p_many.write_text("\n".join(many) + "\n")
-    single = [ln for ln in many if True]
     p_one = tmp_path / "one.pbrt"; p_one.write_text("\n".join(many[:9] + ["AttributeBegin", "  Translate 1 0 0", '  ObjectInstance "t"', "AttributeEnd", "WorldEnd"]) + "\n")
     for path, instances in ((SCENE, 9), (str(p_many), 300), (str(p_one), 1)):
         host = api.HostScene(path, bvh_builder=host_builder, flatten_instances=False)
