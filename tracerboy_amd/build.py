@@ -57,7 +57,7 @@ def kernel_digest():
                 if f.endswith((".h", ".hpp", ".inc", ".hip")):
                     with open(os.path.join(dp, f), "rb") as fh:
                         h.update(f.encode()); h.update(fh.read())
-    h.update(" ".join(COMMON + DEVICE).encode())
+    h.update(" ".join([f for f in COMMON + DEVICE if not f.startswith("-I")]).encode())   # not the include path: the checkout sits elsewhere on the GPU box
     return h.hexdigest()[:16]
 
 
