@@ -127,6 +127,13 @@ def main():
     jpeg("grey_q85.jpg", smooth(30, 41, 6)[..., 1], quality=85)
     jpeg("tiny_1x1.jpg", smooth(1, 1, 7), quality=90, subsampling=2)
     jpeg("q100_420_8x8.jpg", smooth(8, 8, 8), quality=100, subsampling=2)
+    # progressive (SOF2): spectral selection + successive approximation, DC and AC refinement scans, one-component AC scans over the
+    # component's own block grid (odd sizes make that grid smaller than the MCU grid)
+    jpeg("prog_q85_420.jpg", smooth(45, 67, 11), quality=85, subsampling=2, progressive=True)
+    jpeg("prog_q60_444_odd.jpg", smooth(33, 31, 12), quality=60, subsampling=0, progressive=True)
+    jpeg("prog_q92_422_restart.jpg", smooth(52, 70, 13), quality=92, subsampling=1, progressive=True, restart_marker_blocks=2)
+    jpeg("prog_grey_q75.jpg", smooth(30, 41, 14)[..., 1], quality=75, progressive=True)
+    jpeg("prog_q25_420.jpg", smooth(64, 48, 15), quality=25, subsampling=2, progressive=True, optimize=True)
 
     def bmp(name, pil, expect):
         pil.save(os.path.join(OUT, name), "BMP"); cases[name] = expect

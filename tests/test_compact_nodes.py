@@ -116,3 +116,41 @@ def test_compact_nodes_full_size_configs(gpu_tb, settings, cfg):
     finally:
         gpu_tb.SetOption("bvh_builder", 0)
     _compare(gpu_tb, W, H, F, s, cfg)
+
+
+def test_compact_nodes_option_falls_back_where_the_kernel_has_no_layout_c(gpu_tb, settings):
+    """node_layout = 1 is a request, honoured by the frame-group kernels of the higher-occupancy copies for scenes fetched from
+    memory.  Everywhere else -- a scene that lives in LDS (cornell-box), a one-frame call, a feature set without such a copy (Teapot:
+    `surf`), the counting launch -- the bit-exact layout-B path runs, says so (last_node_layout = 0) and gives the oracle's bits."""
+    import os
+    from conftest import CORNELL
+    W, H = 96, 64
+    s = copy.copy(settings); s.MaxBounces = 4
+    gpu_tb.SetOption("node_layout", 1)
+    try:
+        gpu_tb.LoadScene(CORNELL)
+        gpu_tb.Render(W, H, 6, s, 0.0)
+        assert gpu_tb.GetOption("scene_in_lds_active") == 1 and gpu_tb.GetOption("last_node_layout") == 0
+        ref = ol.render(gpu_tb.HostSceneView(), gpu_tb.FrameConstants(W, H, 0, s, 0.0), W, H, 6, threads=8)["output"]
+        assert np.array_equal(bits(gpu_tb.ReadAccumulation()), bits(ref))
+        gpu_tb.LoadProcedural(0, 20000, 3)
+        gpu_tb.InvalidateHistory(); gpu_tb.Render(W, H, 1, s, 0.0)                      # one frame: the one-pixel-per-lane kernel
+        assert gpu_tb.GetOption("last_node_layout") == 0
+        ref = ol.render(gpu_tb.HostSceneView(), gpu_tb.FrameConstants(W, H, 0, s, 0.0), W, H, 1, threads=8)["output"]
+        assert np.array_equal(bits(gpu_tb.ReadAccumulation()), bits(ref))
+        gpu_tb.InvalidateHistory(); gpu_tb.Render(W, H, 6, s, 0.0)                      # six frames: frame groups, layout C
+        assert gpu_tb.GetOption("last_node_layout") == 1
+        gpu_tb.SetOption("count_rays", 1)
+        try:
+            gpu_tb.Render(W, H, 2, s, 0.0)
+            assert gpu_tb.GetOption("last_node_layout") == 0                           # the counters are the reference's: layout B
+            st = gpu_tb.ReadbackStats().rays
+            rs = ol.render(gpu_tb.HostSceneView(), gpu_tb.FrameConstants(W, H, 0, s, 0.0), W, H, 2, threads=8, stats=True)["stats"]
+            assert st.boxesTested == rs.boxesTested and st.trianglesTested == rs.trianglesTested
+        finally:
+            gpu_tb.SetOption("count_rays", 0)
+        gpu_tb.LoadScene(os.path.join(GOLDEN, "scenes", "Teapot", "scene.pbrt"))
+        gpu_tb.InvalidateHistory(); gpu_tb.Render(W, H, 4, s, 0.0)
+        assert gpu_tb.GetOption("last_variant") == 2 and gpu_tb.GetOption("last_node_layout") == 0
+    finally:
+        gpu_tb.SetOption("node_layout", 0)

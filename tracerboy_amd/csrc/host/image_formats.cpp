@@ -3,11 +3,11 @@
  * The reference hands .dds files to DirectXTex::LoadFromDDSFile(DDS_FLAGS_NO_16BPP) and everything that is not .hdr / .tga / .dds to
  * Windows Imaging (LoadFromWICFile): /root/reference/TracerBoy/TracerBoy.cpp:2214-2226.  What reaches the shaders is the typed
  * load of the resulting DXGI format, reproduced here as RGBA32F texels like image_decode.cpp does for PNG / TGA:
- *   JPEG  baseline / extended sequential Huffman, 8-bit, 1 or 3 components (YCbCr or Adobe RGB), any sampling factors, restart
- *         intervals.  Arithmetic as in the IJG library every decoder is measured against: the "slow integer" inverse DCT
+ *   JPEG  sequential (baseline / extended) and progressive Huffman, 8-bit, 1 or 3 components (YCbCr or Adobe RGB), any sampling
+ *         factors, restart intervals, any split into scans.  Arithmetic as in the IJG library every decoder is measured against: the "slow integer" inverse DCT
  *         (jidctint), triangle ("fancy") chroma upsampling for 2:1 horizontally and 2:1 x 2:1 (jdsample), 16-bit fixed-point
  *         YCbCr -> RGB (jdcolor).  WIC's own decoder is not bit-specified; tests pin this one against Pillow (libjpeg-turbo).
- *         Grey -> (g, 0, 0, 1) like 8bppGray -> R8_UNORM; colour -> R8G8B8A8_UNORM, alpha 1.  Progressive files are refused.
+ *         Grey -> (g, 0, 0, 1) like 8bppGray -> R8_UNORM; colour -> R8G8B8A8_UNORM, alpha 1.
  *   BMP   BITMAPINFOHEADER / V4 / V5; 1, 4, 8 bit palettes, 16 (5-5-5 or bit fields), 24, 32 bit, BI_RGB / BI_BITFIELDS, both row orders
  *   DDS   top mip of the first surface: uncompressed 8 / 16 / 24 / 32-bit masks (16-bit formats expanded to 8888: NO_16BPP),
  *         L8 / A8L8 / A8, BC1-BC5 (DXT1-5, ATI1/2; DX10 header incl. _SRGB, which only flags gamma), R16G16B16A16_FLOAT / UNORM,
@@ -123,91 +123,160 @@ void idctIslow(const int* coef /* dequantised, natural order */, uint8_t* out, s
     }
 }
 
-struct JpegComp { int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0, pred = 0; uint32_t bw = 0, bh = 0 /* blocks */, dw = 0, dh = 0 /* downsampled size */; std::vector<uint8_t> plane; size_t stride = 0; };
+struct JpegComp { int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0, pred = 0; uint32_t bw = 0, bh = 0 /* blocks of the padded (MCU) grid */, cw = 0, ch = 0 /* blocks the component itself needs */, dw = 0, dh = 0 /* downsampled size */;
+                  std::vector<int16_t> coef; /* bw * bh * 64, natural order, before dequantisation */ std::vector<uint8_t> plane; size_t stride = 0; };
+
+/* One scan of a sequential or progressive frame into the components' coefficient arrays (ITU T.81 F.2 / G.1).  Sequential scans carry
+ * whole blocks (Ss = 0, Se = 63, Ah = Al = 0); progressive ones a band of coefficients at a bit position, first pass or refinement. */
+void decodeJpegScan(JpegBits& br, std::vector<JpegComp*>& sc, const JpegHuff* dc, const JpegHuff* ac, bool progressive, int Ss, int Se, int Ah, int Al,
+                    uint32_t mcusX, uint32_t mcusY, int restartInterval)
+{
+    const bool interleaved = sc.size() > 1;
+    uint32_t unitsX = mcusX, unitsY = mcusY;
+    if (!interleaved) { unitsX = sc[0]->cw; unitsY = sc[0]->ch; } /* a one-component scan walks that component's own blocks */
+    for (JpegComp* c : sc) c->pred = 0;
+    uint32_t eobrun = 0; int toRestart = restartInterval;
+    const int p1 = 1 << Al, m1 = -(1 << Al);
+    auto block = [&](JpegComp& c, uint32_t bx, uint32_t by) {
+        int16_t* co = c.coef.data() + ((size_t)by * c.bw + bx) * 64;
+        if (!progressive) {
+            const int t = br.decode(dc[c.td]); if (t > 11) throw std::runtime_error("jpeg: bad DC size");
+            c.pred += t ? JpegBits::extend(br.get(t), t) : 0; co[0] = (int16_t)c.pred;
+            for (int k = 1; k < 64;) {
+                const int rs = br.decode(ac[c.ta]), r = rs >> 4, sz = rs & 15;
+                if (!sz) { if (r == 15) { k += 16; continue; } break; }
+                k += r; if (k > 63) throw std::runtime_error("jpeg: AC run past the block");
+                co[kZigzag[k]] = (int16_t)JpegBits::extend(br.get(sz), sz); k++;
+            }
+            return;
+        }
+        if (Ss == 0) { /* DC band */
+            if (Ah == 0) { const int t = br.decode(dc[c.td]); if (t > 11) throw std::runtime_error("jpeg: bad DC size"); c.pred += t ? JpegBits::extend(br.get(t), t) : 0; co[0] = (int16_t)(c.pred * (1 << Al)); }
+            else if (br.get(1)) co[0] = (int16_t)(co[0] | p1);
+            return;
+        }
+        if (Ah == 0) { /* AC band, first pass (G.1.2.2) */
+            if (eobrun) { eobrun--; return; }
+            for (int k = Ss; k <= Se;) {
+                const int rs = br.decode(ac[c.ta]), r = rs >> 4, sz = rs & 15;
+                if (!sz) { if (r == 15) { k += 16; continue; } eobrun = (1u << r) - 1u; if (r) eobrun += (uint32_t)br.get(r); break; }
+                k += r; if (k > Se) throw std::runtime_error("jpeg: AC run past the band");
+                co[kZigzag[k]] = (int16_t)(JpegBits::extend(br.get(sz), sz) * (1 << Al)); k++;
+            }
+            return;
+        }
+        /* AC band, refinement (G.1.2.3): new coefficients of magnitude 1 at this bit, correction bits for the ones already nonzero */
+        int k = Ss;
+        if (!eobrun) {
+            for (; k <= Se; k++) {
+                const int rs = br.decode(ac[c.ta]); int r = rs >> 4; const int sz = rs & 15; int val = 0;
+                if (sz) { if (sz != 1) throw std::runtime_error("jpeg: bad refinement code"); val = br.get(1) ? p1 : m1; }
+                else if (r != 15) { eobrun = 1u << r; if (r) eobrun += (uint32_t)br.get(r); break; }
+                for (; k <= Se; k++) { /* skip r zero-history coefficients, refining the nonzero ones passed on the way */
+                    int16_t& q = co[kZigzag[k]];
+                    if (q) { if (br.get(1) && !(q & p1)) q = (int16_t)(q + (q >= 0 ? p1 : m1)); }
+                    else { if (--r < 0) break; }
+                }
+                if (val && k <= Se) co[kZigzag[k]] = (int16_t)val;
+            }
+        }
+        if (eobrun) { /* the rest of this block: correction bits only */
+            for (; k <= Se; k++) { int16_t& q = co[kZigzag[k]]; if (q && br.get(1) && !(q & p1)) q = (int16_t)(q + (q >= 0 ? p1 : m1)); }
+            eobrun--;
+        }
+    };
+    for (uint32_t uy = 0; uy < unitsY; uy++) for (uint32_t ux = 0; ux < unitsX; ux++) {
+        if (restartInterval && toRestart == 0) { br.restart(); for (JpegComp* c : sc) c->pred = 0; eobrun = 0; toRestart = restartInterval; }
+        if (interleaved) { for (JpegComp* c : sc) for (int by = 0; by < c->v; by++) for (int bx = 0; bx < c->h; bx++) block(*c, ux * (uint32_t)c->h + (uint32_t)bx, uy * (uint32_t)c->v + (uint32_t)by); }
+        else block(*sc[0], ux, uy);
+        if (restartInterval) toRestart--;
+    }
+}
 
 bool decodeJpeg(const std::vector<uint8_t>& d, DecodedImage& img, std::string& err)
 {
     if (d.size() < 4 || d[0] != 0xff || d[1] != 0xd8) { err = "not a JPEG file"; return false; }
     uint16_t qt[4][64]; bool qtSet[4] = {false, false, false, false};
     JpegHuff dc[4], ac[4];
-    std::vector<JpegComp> comps; uint32_t W = 0, H = 0; int hmax = 1, vmax = 1, restartInterval = 0; int adobeTransform = -1; bool sawSof = false;
+    std::vector<JpegComp> comps; uint32_t W = 0, H = 0; int hmax = 1, vmax = 1, restartInterval = 0; int adobeTransform = -1; bool sawSof = false, progressive = false, sawScan = false;
+    uint32_t mcusX = 0, mcusY = 0;
     size_t at = 2;
     auto u16 = [&](size_t o) -> uint32_t { if (o + 1 >= d.size()) throw std::runtime_error("jpeg: truncated"); return ((uint32_t)d[o] << 8) | d[o + 1]; };
-    for (;;) {
+    for (bool done = false; !done;) {
         while (at < d.size() && d[at] != 0xff) at++;
         while (at < d.size() && d[at] == 0xff) at++;
-        if (at >= d.size()) throw std::runtime_error("jpeg: no scan found");
+        if (at >= d.size()) { if (sawScan) break; throw std::runtime_error("jpeg: no scan found"); } /* a missing EOI after complete scans is tolerated, like libjpeg */
         const uint8_t m = d[at++];
-        if (m == 0xd8 || (m >= 0xd0 && m <= 0xd7) || m == 0x01) continue;
-        if (m == 0xd9) throw std::runtime_error("jpeg: end of image before any scan");
+        if (m == 0xd8 || (m >= 0xd0 && m <= 0xd7) || m == 0x01 || m == 0x00) continue;
+        if (m == 0xd9) { if (!sawScan) throw std::runtime_error("jpeg: end of image before any scan"); break; }
         const uint32_t len = u16(at); if (len < 2 || at + len > d.size()) throw std::runtime_error("jpeg: bad segment length");
         const size_t seg = at + 2, end = at + len;
         if (m == 0xdb) { /* DQT */
             size_t p = seg;
             while (p < end) { const int pq = d[p] >> 4, tq = d[p] & 15; p++; if (tq > 3) throw std::runtime_error("jpeg: bad quantisation table id");
-                for (int i = 0; i < 64; i++) { if (p + (pq ? 1 : 0) >= end + 0 && p >= end) throw std::runtime_error("jpeg: truncated DQT"); qt[tq][kZigzag[i]] = pq ? (uint16_t)u16(p) : d[p]; p += pq ? 2 : 1; }
+                for (int i = 0; i < 64; i++) { if (p + (pq ? 2 : 1) > end) throw std::runtime_error("jpeg: truncated DQT"); qt[tq][kZigzag[i]] = pq ? (uint16_t)u16(p) : d[p]; p += pq ? 2 : 1; }
                 qtSet[tq] = true; }
         } else if (m == 0xc4) { /* DHT */
             size_t p = seg;
             while (p < end) { const int tc = d[p] >> 4, th = d[p] & 15; p++; if (tc > 1 || th > 3) throw std::runtime_error("jpeg: bad Huffman table id");
                 JpegHuff& h = tc ? ac[th] : dc[th]; int total = 0;
+                if (p + 16 > end) throw std::runtime_error("jpeg: truncated DHT");
                 for (int l = 1; l <= 16; l++) { h.bits[l] = d[p++]; total += h.bits[l]; }
                 if (total > 256 || p + total > end) throw std::runtime_error("jpeg: bad Huffman table");
                 memcpy(h.vals, &d[p], (size_t)total); p += total; h.build(); h.present = true; }
-        } else if (m == 0xc0 || m == 0xc1) { /* SOF0 / SOF1 */
+        } else if (m == 0xc0 || m == 0xc1 || m == 0xc2) { /* SOF0 / SOF1 sequential, SOF2 progressive; Huffman, 8 bits */
+            if (sawSof) throw std::runtime_error("jpeg: second frame header");
             if (d[seg] != 8) throw std::runtime_error("jpeg: only 8-bit precision is supported");
+            progressive = m == 0xc2;
             H = u16(seg + 1); W = u16(seg + 3); const int nc = d[seg + 5];
             if (!W || !H || (nc != 1 && nc != 3)) throw std::runtime_error("jpeg: unsupported component count (grey and three-component files are decoded)");
             comps.resize((size_t)nc);
             for (int i = 0; i < nc; i++) { JpegComp& c = comps[(size_t)i]; c.id = d[seg + 6 + 3 * i]; c.h = d[seg + 7 + 3 * i] >> 4; c.v = d[seg + 7 + 3 * i] & 15; c.tq = d[seg + 8 + 3 * i];
                 if (c.h < 1 || c.h > 4 || c.v < 1 || c.v > 4 || c.tq > 3) throw std::runtime_error("jpeg: bad sampling factors"); hmax = std::max(hmax, c.h); vmax = std::max(vmax, c.v); }
+            if (nc == 1) { comps[0].h = comps[0].v = 1; hmax = vmax = 1; } /* a single component is never interleaved: its factors only scale the (absent) others */
+            mcusX = (W + 8u * (uint32_t)hmax - 1) / (8u * (uint32_t)hmax); mcusY = (H + 8u * (uint32_t)vmax - 1) / (8u * (uint32_t)vmax);
+            for (JpegComp& c : comps) {
+                c.dw = (W * (uint32_t)c.h + (uint32_t)hmax - 1) / (uint32_t)hmax; c.dh = (H * (uint32_t)c.v + (uint32_t)vmax - 1) / (uint32_t)vmax;
+                c.cw = (c.dw + 7) / 8; c.ch = (c.dh + 7) / 8; c.bw = mcusX * (uint32_t)c.h; c.bh = mcusY * (uint32_t)c.v;
+                if ((uint64_t)c.bw * c.bh > (1u << 24)) throw std::runtime_error("jpeg: image too large");
+                c.coef.assign((size_t)c.bw * c.bh * 64, 0);
+            }
             sawSof = true;
-        } else if (m == 0xc2 || (m >= 0xc3 && m <= 0xcf && m != 0xc4 && m != 0xc8 && m != 0xcc)) {
-            err = "progressive / lossless / arithmetic-coded JPEG is not supported (baseline and extended sequential Huffman are)"; return false;
+        } else if (m >= 0xc3 && m <= 0xcf && m != 0xc4 && m != 0xc8 && m != 0xcc) {
+            err = "lossless / hierarchical / arithmetic-coded JPEG is not supported (sequential and progressive Huffman files are)"; return false;
         } else if (m == 0xdd) restartInterval = (int)u16(seg);
         else if (m == 0xee && len >= 14 && !memcmp(&d[seg], "Adobe", 5)) adobeTransform = d[seg + 11];
-        else if (m == 0xda) { /* SOS: baseline files carry one scan with all components */
+        else if (m == 0xda) { /* SOS */
             if (!sawSof) throw std::runtime_error("jpeg: scan before frame header");
-            const int ns = d[seg]; if (ns != (int)comps.size()) { err = "multi-scan sequential JPEG is not supported"; return false; }
-            for (int i = 0; i < ns; i++) { const int cid = d[seg + 1 + 2 * i]; bool found = false;
-                for (JpegComp& c : comps) if (c.id == cid) { c.td = d[seg + 2 + 2 * i] >> 4; c.ta = d[seg + 2 + 2 * i] & 15; found = true; }
-                if (!found) throw std::runtime_error("jpeg: scan names an unknown component"); }
-            at = end; break;
+            const int ns = d[seg]; if (ns < 1 || ns > (int)comps.size() || seg + 1 + 2 * (size_t)ns + 3 > end) throw std::runtime_error("jpeg: bad scan header");
+            std::vector<JpegComp*> sc;
+            for (int i = 0; i < ns; i++) { const int cid = d[seg + 1 + 2 * i]; JpegComp* found = nullptr;
+                for (JpegComp& c : comps) if (c.id == cid) found = &c;
+                if (!found) throw std::runtime_error("jpeg: scan names an unknown component");
+                found->td = d[seg + 2 + 2 * i] >> 4; found->ta = d[seg + 2 + 2 * i] & 15; if (found->td > 3 || found->ta > 3) throw std::runtime_error("jpeg: bad table selector"); sc.push_back(found); }
+            const int Ss = d[seg + 1 + 2 * ns], Se = d[seg + 2 + 2 * ns], Ah = d[seg + 3 + 2 * ns] >> 4, Al = d[seg + 3 + 2 * ns] & 15;
+            if (progressive) { if (Ss > Se || Se > 63 || (Ss == 0 && Se != 0) || (Ss > 0 && ns != 1) || Al > 13) throw std::runtime_error("jpeg: bad progressive scan parameters"); }
+            else if (Ss != 0 || Se != 63 || Ah != 0 || Al != 0) throw std::runtime_error("jpeg: bad sequential scan parameters");
+            for (JpegComp* c : sc) { if ((!progressive || (Ss == 0 && Ah == 0)) && !dc[c->td].present) throw std::runtime_error("jpeg: scan refers to a DC table that was not defined");
+                                     if ((!progressive || Ss > 0) && !ac[c->ta].present) throw std::runtime_error("jpeg: scan refers to an AC table that was not defined"); }
+            JpegBits br(d.data(), d.size(), end);
+            decodeJpegScan(br, sc, dc, ac, progressive, Ss, Se, Ah, Al, mcusX, mcusY, restartInterval);
+            sawScan = true;
+            at = br.at; continue; /* the next marker is searched from where the entropy decoder stopped */
         }
         at = end;
     }
-    /* geometry */
-    const uint32_t mcuW = (uint32_t)(8 * hmax), mcuH = (uint32_t)(8 * vmax);
-    const bool single = comps.size() == 1;
-    uint32_t mcusX = (W + mcuW - 1) / mcuW, mcusY = (H + mcuH - 1) / mcuH;
-    if (single) { mcusX = (W + 7) / 8; mcusY = (H + 7) / 8; } /* a one-component scan is not interleaved: one block per MCU whatever its sampling factors */
+    /* dequantise + inverse DCT into the component planes */
+    int coefBlock[64];
     for (JpegComp& c : comps) {
-        if (!qtSet[c.tq] || !dc[c.td].present || !ac[c.ta].present) throw std::runtime_error("jpeg: scan refers to a table that was not defined");
-        c.dw = (W * (uint32_t)c.h + (uint32_t)hmax - 1) / (uint32_t)hmax; c.dh = (H * (uint32_t)c.v + (uint32_t)vmax - 1) / (uint32_t)vmax;
-        if (single) { c.h = c.v = 1; c.dw = W; c.dh = H; }
-        c.bw = mcusX * (uint32_t)c.h; c.bh = mcusY * (uint32_t)c.v;
+        if (!qtSet[c.tq]) throw std::runtime_error("jpeg: frame refers to a quantisation table that was not defined");
         c.stride = (size_t)c.bw * 8; c.plane.assign(c.stride * c.bh * 8, 0);
-    }
-    if (single) { hmax = vmax = 1; }
-    JpegBits br(d.data(), d.size(), at);
-    int coef[64];
-    int toRestart = restartInterval;
-    for (uint32_t my = 0; my < mcusY; my++) for (uint32_t mx = 0; mx < mcusX; mx++) {
-        if (restartInterval && toRestart == 0) { br.restart(); for (JpegComp& c : comps) c.pred = 0; toRestart = restartInterval; }
-        for (JpegComp& c : comps) for (int by = 0; by < c.v; by++) for (int bx = 0; bx < c.h; bx++) {
-            memset(coef, 0, sizeof coef);
-            const int t = br.decode(dc[c.td]); if (t > 11) throw std::runtime_error("jpeg: bad DC size");
-            c.pred += t ? JpegBits::extend(br.get(t), t) : 0;
-            coef[0] = c.pred * qt[c.tq][0];
-            for (int k = 1; k < 64;) {
-                const int rs = br.decode(ac[c.ta]), r = rs >> 4, sz = rs & 15;
-                if (!sz) { if (r == 15) { k += 16; continue; } break; }
-                k += r; if (k > 63) throw std::runtime_error("jpeg: AC run past the block");
-                coef[kZigzag[k]] = JpegBits::extend(br.get(sz), sz) * qt[c.tq][kZigzag[k]]; k++;
-            }
-            idctIslow(coef, c.plane.data() + ((size_t)(my * (uint32_t)c.v + (uint32_t)by) * 8) * c.stride + (size_t)(mx * (uint32_t)c.h + (uint32_t)bx) * 8, c.stride);
+        for (uint32_t by = 0; by < c.bh; by++) for (uint32_t bx = 0; bx < c.bw; bx++) {
+            const int16_t* co = c.coef.data() + ((size_t)by * c.bw + bx) * 64;
+            for (int i = 0; i < 64; i++) coefBlock[i] = (int)co[i] * (int)qt[c.tq][i];
+            idctIslow(coefBlock, c.plane.data() + ((size_t)by * 8) * c.stride + (size_t)bx * 8, c.stride);
         }
-        if (restartInterval) toRestart--;
+        c.coef.clear(); c.coef.shrink_to_fit();
     }
     /* upsample every component to W x H (jdsample.c) */
     std::vector<std::vector<uint8_t>> full(comps.size());
