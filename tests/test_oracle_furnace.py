@@ -299,3 +299,38 @@ def test_glass_slab_snell_and_beer_lambert(built, settings):
     assert seen[0.0] >= 8 and seen[45.0] >= 4, seen
     assert np.allclose(rgb[0, 0], Lenv, rtol=1e-5) or np.allclose(rgb[0, W - 1], Lenv, rtol=1e-5)   # past the slabs: the environment itself
     del keep
+
+
+def test_mix_material_is_the_coin_weighted_average(built, settings):
+    """MIX material under a constant environment: one rand() per GetMaterial picks the first material with probability `amount`
+    (RayGenCommon.h:298-341), so the mean is L (amount a0 + (1 - amount) a1)."""
+    h = api.HostScene(os.path.join(FURNACE, "plane_mix.pbrt")); view = h.view()
+    keep = _bind_constant_environment(view, (1.0, 1.0, 1.0))
+    mats = [view.materials[i] for i in range(view.numMaterials)]
+    mix = [m for m in mats if m.Flags & 0x8]
+    assert len(mix) == 1 and abs(mix[0].albedo.z - 0.3) < 1e-6
+    a0, a1 = mats[int(mix[0].albedo.x)], mats[int(mix[0].albedo.y)]
+    expect = np.array([0.3 * getattr(a0.albedo, c) + 0.7 * getattr(a1.albedo, c) for c in "xyz"])
+    s = copy.copy(settings); s.MaxBounces = 2
+    devs = []
+    for time_seed in (0.0, 2.3, 9.0):                      # the coin is one rand() at a fixed call index: see test_reference_rng_resolution
+        rgb = _mean_rgb(view, h.frame_constants(s, 0, time_seed), 8, 8, 4096)
+        devs.append(rgb.mean(axis=0) / expect - 1.0)
+    assert np.all(np.abs(np.mean(devs, axis=0)) < 0.02), devs
+    del keep
+
+
+def test_resampled_importance_sampling_contributes_nothing_as_written(cornell_host, settings):
+    """GetOneLightSample's 16-candidate RIS branch (RayGenCommon.h:180-211; default off, TracerBoy.h:353) never sets LightAttenuation --
+    it stays at the 0 of the initialisation (:172-174) -- so the next-event term `lightAttenuation * ... / lightPDF` (kernel.glsl:1514)
+    is zero and the light is found only by paths that hit it.  A quirk of the reference, kept: with one bounce the floor patch that the
+    plain estimator lights (test_direct_light_on_floor_centre_is_analytic) is black with RIS on, and the rand() stream is still consumed
+    (the second bounce differs from the plain estimator's)."""
+    view = cornell_host.view()
+    W = H = 64
+    patch = []
+    for ris in (0, 1):
+        s = copy.copy(settings); s.MaxBounces = 1; s.EnableSamplingImportanceResampling = ris
+        img = ol.render(view, cornell_host.frame_constants(s, 0, 0.0), W, H, 64, y0=62, y1=64, threads=8)["output"]
+        patch.append((img[62:64, 18:22, :3] / img[62:64, 18:22, 3:]).reshape(-1, 3).mean(axis=0))
+    assert np.all(patch[0] > 0.01) and np.all(patch[1] == 0.0), patch
