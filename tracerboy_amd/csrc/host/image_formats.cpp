@@ -10,7 +10,7 @@
  *         Grey -> (g, 0, 0, 1) like 8bppGray -> R8_UNORM; colour -> R8G8B8A8_UNORM, alpha 1.
  *   BMP   BITMAPINFOHEADER / V4 / V5; 1, 4, 8 bit palettes, 16 (5-5-5 or bit fields), 24, 32 bit, BI_RGB / BI_BITFIELDS, both row orders
  *   DDS   top mip of the first surface: uncompressed 8 / 16 / 24 / 32-bit masks (16-bit formats expanded to 8888: NO_16BPP),
- *         L8 / A8L8 / A8, BC1-BC5 (DXT1-5, ATI1/2; DX10 header incl. _SRGB, which only flags gamma), R16G16B16A16_FLOAT / UNORM,
+ *         L8 / A8L8 / A8, BC1-BC5 and BC7 (DXT1-5, ATI1/2; DX10 header incl. _SRGB, which only flags gamma), R16G16B16A16_FLOAT / UNORM,
  *         R32G32B32A32_FLOAT, R32_FLOAT.  Block formats are decoded the way D3D specifies the sampler's view of them (endpoints
  *         as UNORM, interpolated in floating point).
  * No third-party code. */
@@ -411,6 +411,105 @@ void bcAlpha8(const uint8_t* b, float a[8], bool snorm) /* the interpolated-alph
 }
 uint32_t bcAlphaIndex(const uint8_t* b, int texel) { uint64_t bits = 0; for (int i = 0; i < 6; i++) bits |= (uint64_t)b[2 + i] << (8 * i); return (uint32_t)(bits >> (3 * texel)) & 7u; }
 
+/* BC7 (DXGI 97-99): eight block modes, up to three endpoint subsets chosen by a fixed partition shape, 2-4 bit indices of which the
+ * "anchor" pixel of every subset stores one bit less (D3D11 functional spec 19.5.9; the tables are the format's constants, regenerated by
+ * tests/golden/make_bc7_tables.py from an independent decoder). */
+const uint8_t bc7Part2[1024] = {
+    0,0,1,1,0,0,1,1,0,0,1,1,0,0,1,1,0,0,0,1,0,0,0,1,0,0,0,1,0,0,0,1,0,1,1,1,0,1,1,1,0,1,1,1,0,1,1,1,0,0,0,1,0,0,1,1,0,0,1,1,0,1,1,1,
+    0,0,0,0,0,0,0,1,0,0,0,1,0,0,1,1,0,0,1,1,0,1,1,1,0,1,1,1,1,1,1,1,0,0,0,1,0,0,1,1,0,1,1,1,1,1,1,1,0,0,0,0,0,0,0,1,0,0,1,1,0,1,1,1,
+    0,0,0,0,0,0,0,0,0,0,0,1,0,0,1,1,0,0,1,1,0,1,1,1,1,1,1,1,1,1,1,1,0,0,0,0,0,0,0,1,0,1,1,1,1,1,1,1,0,0,0,0,0,0,0,0,0,0,0,1,0,1,1,1,
+    0,0,0,1,0,1,1,1,1,1,1,1,1,1,1,1,0,0,0,0,0,0,0,0,1,1,1,1,1,1,1,1,0,0,0,0,1,1,1,1,1,1,1,1,1,1,1,1,0,0,0,0,0,0,0,0,0,0,0,0,1,1,1,1,
+    0,0,0,0,1,0,0,0,1,1,1,0,1,1,1,1,0,1,1,1,0,0,0,1,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,1,0,0,0,1,1,1,0,0,1,1,1,0,0,1,1,0,0,0,1,0,0,0,0,
+    0,0,1,1,0,0,0,1,0,0,0,0,0,0,0,0,0,0,0,0,1,0,0,0,1,1,0,0,1,1,1,0,0,0,0,0,0,0,0,0,1,0,0,0,1,1,0,0,0,1,1,1,0,0,1,1,0,0,1,1,0,0,0,1,
+    0,0,1,1,0,0,0,1,0,0,0,1,0,0,0,0,0,0,0,0,1,0,0,0,1,0,0,0,1,1,0,0,0,1,1,0,0,1,1,0,0,1,1,0,0,1,1,0,0,0,1,1,0,1,1,0,0,1,1,0,1,1,0,0,
+    0,0,0,1,0,1,1,1,1,1,1,0,1,0,0,0,0,0,0,0,1,1,1,1,1,1,1,1,0,0,0,0,0,1,1,1,0,0,0,1,1,0,0,0,1,1,1,0,0,0,1,1,1,0,0,1,1,0,0,1,1,1,0,0,
+    0,1,0,1,0,1,0,1,0,1,0,1,0,1,0,1,0,0,0,0,1,1,1,1,0,0,0,0,1,1,1,1,0,1,0,1,1,0,1,0,0,1,0,1,1,0,1,0,0,0,1,1,0,0,1,1,1,1,0,0,1,1,0,0,
+    0,0,1,1,1,1,0,0,0,0,1,1,1,1,0,0,0,1,0,1,0,1,0,1,1,0,1,0,1,0,1,0,0,1,1,0,1,0,0,1,0,1,1,0,1,0,0,1,0,1,0,1,1,0,1,0,1,0,1,0,0,1,0,1,
+    0,1,1,1,0,0,1,1,1,1,0,0,1,1,1,0,0,0,0,1,0,0,1,1,1,1,0,0,1,0,0,0,0,0,1,1,0,0,1,0,0,1,0,0,1,1,0,0,0,0,1,1,1,0,1,1,1,1,0,1,1,1,0,0,
+    0,1,1,0,1,0,0,1,1,0,0,1,0,1,1,0,0,0,1,1,1,1,0,0,1,1,0,0,0,0,1,1,0,1,1,0,0,1,1,0,1,0,0,1,1,0,0,1,0,0,0,0,0,1,1,0,0,1,1,0,0,0,0,0,
+    0,1,0,0,1,1,1,0,0,1,0,0,0,0,0,0,0,0,1,0,0,1,1,1,0,0,1,0,0,0,0,0,0,0,0,0,0,0,1,0,0,1,1,1,0,0,1,0,0,0,0,0,0,1,0,0,1,1,1,0,0,1,0,0,
+    0,1,1,0,1,1,0,0,1,0,0,1,0,0,1,1,0,0,1,1,0,1,1,0,1,1,0,0,1,0,0,1,0,1,1,0,0,0,1,1,1,0,0,1,1,1,0,0,0,0,1,1,1,0,0,1,1,1,0,0,0,1,1,0,
+    0,1,1,0,1,1,0,0,1,1,0,0,1,0,0,1,0,1,1,0,0,0,1,1,0,0,1,1,1,0,0,1,0,1,1,1,1,1,1,0,1,0,0,0,0,0,0,1,0,0,0,1,1,0,0,0,1,1,1,0,0,1,1,1,
+    0,0,0,0,1,1,1,1,0,0,1,1,0,0,1,1,0,0,1,1,0,0,1,1,1,1,1,1,0,0,0,0,0,0,1,0,0,0,1,0,1,1,1,0,1,1,1,0,0,1,0,0,0,1,0,0,0,1,1,1,0,1,1,1,
+};
+const uint8_t bc7Part3[1024] = {
+    0,0,1,1,0,0,1,1,0,2,2,1,2,2,2,2,0,0,0,1,0,0,1,1,2,2,1,1,2,2,2,1,0,0,0,0,2,0,0,1,2,2,1,1,2,2,1,1,0,2,2,2,0,0,2,2,0,0,1,1,0,1,1,1,
+    0,0,0,0,0,0,0,0,1,1,2,2,1,1,2,2,0,0,1,1,0,0,1,1,0,0,2,2,0,0,2,2,0,0,2,2,0,0,2,2,1,1,1,1,1,1,1,1,0,0,1,1,0,0,1,1,2,2,1,1,2,2,1,1,
+    0,0,0,0,0,0,0,0,1,1,1,1,2,2,2,2,0,0,0,0,1,1,1,1,1,1,1,1,2,2,2,2,0,0,0,0,1,1,1,1,2,2,2,2,2,2,2,2,0,0,1,2,0,0,1,2,0,0,1,2,0,0,1,2,
+    0,1,1,2,0,1,1,2,0,1,1,2,0,1,1,2,0,1,2,2,0,1,2,2,0,1,2,2,0,1,2,2,0,0,1,1,0,1,1,2,1,1,2,2,1,2,2,2,0,0,1,1,2,0,0,1,2,2,0,0,2,2,2,0,
+    0,0,0,1,0,0,1,1,0,1,1,2,1,1,2,2,0,1,1,1,0,0,1,1,2,0,0,1,2,2,0,0,0,0,0,0,1,1,2,2,1,1,2,2,1,1,2,2,0,0,2,2,0,0,2,2,0,0,2,2,1,1,1,1,
+    0,1,1,1,0,1,1,1,0,2,2,2,0,2,2,2,0,0,0,1,0,0,0,1,2,2,2,1,2,2,2,1,0,0,0,0,0,0,1,1,0,1,2,2,0,1,2,2,0,0,0,0,1,1,0,0,2,2,1,0,2,2,1,0,
+    0,1,2,2,0,1,2,2,0,0,1,1,0,0,0,0,0,0,1,2,0,0,1,2,1,1,2,2,2,2,2,2,0,1,1,0,1,2,2,1,1,2,2,1,0,1,1,0,0,0,0,0,0,1,1,0,1,2,2,1,1,2,2,1,
+    0,0,2,2,1,1,0,2,1,1,0,2,0,0,2,2,0,1,1,0,0,1,1,0,2,0,0,2,2,2,2,2,0,0,1,1,0,1,2,2,0,1,2,2,0,0,1,1,0,0,0,0,2,0,0,0,2,2,1,1,2,2,2,1,
+    0,0,0,0,0,0,0,2,1,1,2,2,1,2,2,2,0,2,2,2,0,0,2,2,0,0,1,2,0,0,1,1,0,0,1,1,0,0,1,2,0,0,2,2,0,2,2,2,0,1,2,0,0,1,2,0,0,1,2,0,0,1,2,0,
+    0,0,0,0,1,1,1,1,2,2,2,2,0,0,0,0,0,1,2,0,1,2,0,1,2,0,1,2,0,1,2,0,0,1,2,0,2,0,1,2,1,2,0,1,0,1,2,0,0,0,1,1,2,2,0,0,1,1,2,2,0,0,1,1,
+    0,0,1,1,1,1,2,2,2,2,0,0,0,0,1,1,0,1,0,1,0,1,0,1,2,2,2,2,2,2,2,2,0,0,0,0,0,0,0,0,2,1,2,1,2,1,2,1,0,0,2,2,1,1,2,2,0,0,2,2,1,1,2,2,
+    0,0,2,2,0,0,1,1,0,0,2,2,0,0,1,1,0,2,2,0,1,2,2,1,0,2,2,0,1,2,2,1,0,1,0,1,2,2,2,2,2,2,2,2,0,1,0,1,0,0,0,0,2,1,2,1,2,1,2,1,2,1,2,1,
+    0,1,0,1,0,1,0,1,0,1,0,1,2,2,2,2,0,2,2,2,0,1,1,1,0,2,2,2,0,1,1,1,0,0,0,2,1,1,1,2,0,0,0,2,1,1,1,2,0,0,0,0,2,1,1,2,2,1,1,2,2,1,1,2,
+    0,2,2,2,0,1,1,1,0,1,1,1,0,2,2,2,0,0,0,2,1,1,1,2,1,1,1,2,0,0,0,2,0,1,1,0,0,1,1,0,0,1,1,0,2,2,2,2,0,0,0,0,0,0,0,0,2,1,1,2,2,1,1,2,
+    0,1,1,0,0,1,1,0,2,2,2,2,2,2,2,2,0,0,2,2,0,0,1,1,0,0,1,1,0,0,2,2,0,0,2,2,1,1,2,2,1,1,2,2,0,0,2,2,0,0,0,0,0,0,0,0,0,0,0,0,2,1,1,2,
+    0,0,0,2,0,0,0,1,0,0,0,2,0,0,0,1,0,2,2,2,1,2,2,2,0,2,2,2,1,2,2,2,0,1,0,1,2,2,2,2,2,2,2,2,2,2,2,2,0,1,1,1,2,0,1,1,2,2,0,1,2,2,2,0,
+};
+const uint8_t bc7Anchor2[64] = {
+    15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,2,8,2,2,8,8,15,2,8,2,2,8,8,2,2,
+    15,15,6,8,2,8,15,15,2,8,2,2,2,15,15,6,6,2,6,8,15,15,2,2,15,15,15,15,15,2,2,15,
+};
+const uint8_t bc7Anchor3a[64] = {
+    3,3,15,15,8,3,15,15,8,8,6,6,6,5,3,3,3,3,8,15,3,3,6,10,5,8,8,6,8,5,15,15,
+    8,15,3,5,6,10,8,15,15,3,15,5,15,15,15,15,3,15,5,5,5,8,5,10,5,10,8,13,15,12,3,3,
+};
+const uint8_t bc7Anchor3b[64] = {
+    15,8,8,3,15,15,3,8,15,15,15,15,15,15,15,8,15,8,15,3,15,8,15,8,3,15,6,10,15,15,10,8,
+    15,3,15,10,10,8,9,10,6,15,8,15,3,6,6,8,15,3,15,15,15,15,15,15,15,15,15,15,3,15,15,8,
+};
+
+struct Bc7Mode { uint8_t subsets, partBits, rotBits, idxSelBit, colourBits, alphaBits, endpointP, sharedP, idxBits, idx2Bits; };
+const Bc7Mode bc7Modes[8] = {{3, 4, 0, 0, 4, 0, 1, 0, 3, 0}, {2, 6, 0, 0, 6, 0, 0, 1, 3, 0}, {3, 6, 0, 0, 5, 0, 0, 0, 2, 0}, {2, 6, 0, 0, 7, 0, 1, 0, 2, 0},
+                             {1, 0, 2, 1, 5, 6, 0, 0, 2, 3}, {1, 0, 2, 0, 7, 8, 0, 0, 2, 2}, {1, 0, 0, 0, 7, 7, 1, 0, 4, 0}, {2, 6, 0, 0, 5, 5, 1, 0, 2, 0}};
+const uint8_t bc7Weights2[4] = {0, 21, 43, 64}, bc7Weights3[8] = {0, 9, 18, 27, 37, 46, 55, 64}, bc7Weights4[16] = {0, 4, 9, 13, 17, 21, 26, 30, 34, 38, 43, 47, 51, 55, 60, 64};
+
+void bc7Block(const uint8_t* b, TbFloat4 texel[16])
+{
+    uint32_t pos = 0;
+    auto get = [&](uint32_t n) { uint32_t v = 0; for (uint32_t i = 0; i < n; i++, pos++) v |= (uint32_t)((b[pos >> 3] >> (pos & 7)) & 1u) << i; return v; };
+    uint32_t mode = 0; while (mode < 8 && !get(1)) mode++;
+    if (mode == 8) { for (int t = 0; t < 16; t++) texel[t] = px(0, 0, 0, 0); return; }      /* reserved: the hardware returns zeros */
+    const Bc7Mode& m = bc7Modes[mode];
+    const uint32_t partition = get(m.partBits), rotation = get(m.rotBits), idxSel = get(m.idxSelBit), numEp = 2u * m.subsets;
+    uint32_t ep[6][4];
+    for (int c = 0; c < 3; c++) for (uint32_t e = 0; e < numEp; e++) ep[e][c] = get(m.colourBits);
+    for (uint32_t e = 0; e < numEp; e++) ep[e][3] = m.alphaBits ? get(m.alphaBits) : 255u;
+    uint32_t cb = m.colourBits, ab = m.alphaBits;
+    if (m.endpointP || m.sharedP) {
+        uint32_t pb[6]; if (m.endpointP) for (uint32_t e = 0; e < numEp; e++) pb[e] = get(1); else for (uint32_t k = 0; k < m.subsets; k++) pb[2 * k] = pb[2 * k + 1] = get(1);
+        for (uint32_t e = 0; e < numEp; e++) { for (int c = 0; c < 3; c++) ep[e][c] = (ep[e][c] << 1) | pb[e]; if (ab) ep[e][3] = (ep[e][3] << 1) | pb[e]; }
+        cb++; if (ab) ab++;
+    }
+    for (uint32_t e = 0; e < numEp; e++) {   /* to 8 bits: left-align, replicate the top bits below */
+        for (int c = 0; c < 3; c++) { const uint32_t v = ep[e][c] << (8 - cb); ep[e][c] = v | (v >> cb); }
+        if (ab) { const uint32_t v = ep[e][3] << (8 - ab); ep[e][3] = v | (v >> ab); }
+    }
+    uint8_t subset[16]; uint32_t anchor[3] = {0, 0, 0};
+    for (int t = 0; t < 16; t++) subset[t] = m.subsets == 1 ? 0 : (m.subsets == 2 ? bc7Part2[partition * 16 + t] : bc7Part3[partition * 16 + t]);
+    if (m.subsets == 2) anchor[1] = bc7Anchor2[partition]; else if (m.subsets == 3) { anchor[1] = bc7Anchor3a[partition]; anchor[2] = bc7Anchor3b[partition]; }
+    uint32_t idx[16], idx2[16];
+    for (uint32_t t = 0; t < 16; t++) idx[t] = get(t == anchor[subset[t]] ? m.idxBits - 1u : m.idxBits);
+    for (uint32_t t = 0; t < 16; t++) idx2[t] = m.idx2Bits ? get(t == 0 ? m.idx2Bits - 1u : m.idx2Bits) : 0;
+    auto weight = [](uint32_t bits, uint32_t i) { return (uint32_t)(bits == 2 ? bc7Weights2[i] : (bits == 3 ? bc7Weights3[i] : bc7Weights4[i])); };
+    for (uint32_t t = 0; t < 16; t++) {
+        const uint32_t* e0 = ep[2 * subset[t]]; const uint32_t* e1 = ep[2 * subset[t] + 1];
+        uint32_t wc, wa;
+        if (!m.idx2Bits) wc = wa = weight(m.idxBits, idx[t]);
+        else if (idxSel) { wc = weight(m.idx2Bits, idx2[t]); wa = weight(m.idxBits, idx[t]); }
+        else { wc = weight(m.idxBits, idx[t]); wa = weight(m.idx2Bits, idx2[t]); }
+        uint32_t v[4];
+        for (int c = 0; c < 3; c++) v[c] = ((64u - wc) * e0[c] + wc * e1[c] + 32u) >> 6;
+        v[3] = m.alphaBits ? ((64u - wa) * e0[3] + wa * e1[3] + 32u) >> 6 : 255u;
+        if (rotation) { const uint32_t k = rotation - 1u, tmp = v[k]; v[k] = v[3]; v[3] = tmp; }
+        texel[t] = px((float)v[0] / 255.0f, (float)v[1] / 255.0f, (float)v[2] / 255.0f, (float)v[3] / 255.0f);
+    }
+}
+
 bool decodeDds(const std::vector<uint8_t>& d, DecodedImage& img, std::string& err)
 {
     if (d.size() < 128 || memcmp(d.data(), "DDS ", 4) || rd32(d, 4) != 124) { err = "not a DDS file"; return false; }
@@ -419,7 +518,7 @@ bool decodeDds(const std::vector<uint8_t>& d, DecodedImage& img, std::string& er
     if (!W || !H || W > 65536 || H > 65536) { err = "DDS: bad dimensions"; return false; }
     size_t off = 128; uint32_t dxgi = 0;
     auto cc = [](const char* s) { return (uint32_t)(uint8_t)s[0] | ((uint32_t)(uint8_t)s[1] << 8) | ((uint32_t)(uint8_t)s[2] << 16) | ((uint32_t)(uint8_t)s[3] << 24); };
-    enum { RAW, BC1, BC2, BC3, BC4, BC5, BC4S, BC5S, F16, F32, F32R, U16 } kind = RAW;
+    enum { RAW, BC1, BC2, BC3, BC4, BC5, BC4S, BC5S, BC7, F16, F32, F32R, U16 } kind = RAW;
     if (pfFlags & 4u) {
         if (fourcc == cc("DX10")) { if (d.size() < 148) { err = "DDS: truncated DX10 header"; return false; } dxgi = rd32(d, 128); off = 148; }
         else if (fourcc == cc("DXT1")) kind = BC1; else if (fourcc == cc("DXT2") || fourcc == cc("DXT3")) kind = BC2; else if (fourcc == cc("DXT4") || fourcc == cc("DXT5")) kind = BC3;
@@ -431,7 +530,7 @@ bool decodeDds(const std::vector<uint8_t>& d, DecodedImage& img, std::string& er
     if (dxgi) {
         switch (dxgi) {
         case 71: case 72: kind = BC1; break; case 74: case 75: kind = BC2; break; case 77: case 78: kind = BC3; break; case 80: kind = BC4; break; case 81: kind = BC4S; break;
-        case 83: kind = BC5; break; case 84: kind = BC5S; break; case 10: kind = F16; break; case 2: kind = F32; break; case 41: kind = F32R; break; case 11: kind = U16; break;
+        case 83: kind = BC5; break; case 84: kind = BC5S; break; case 97: case 98: case 99: kind = BC7; break; case 10: kind = F16; break; case 2: kind = F32; break; case 41: kind = F32R; break; case 11: kind = U16; break;
         case 28: case 29: kind = RAW; rawBits = 32; m[0] = 0xff; m[1] = 0xff00; m[2] = 0xff0000; m[3] = 0xff000000u; break;          /* R8G8B8A8_UNORM(_SRGB) */
         case 87: case 91: kind = RAW; rawBits = 32; m[0] = 0xff0000; m[1] = 0xff00; m[2] = 0xff; m[3] = 0xff000000u; break;          /* B8G8R8A8 */
         case 88: case 93: kind = RAW; rawBits = 32; m[0] = 0xff0000; m[1] = 0xff00; m[2] = 0xff; m[3] = 0; break;                    /* B8G8R8X8 */
@@ -475,7 +574,8 @@ bool decodeDds(const std::vector<uint8_t>& d, DecodedImage& img, std::string& er
                 float a8[8]; if (kind == BC3) bcAlpha8(b, a8, false);
                 for (int t = 0; t < 16; t++) { texel[t] = c[(idx >> (2 * t)) & 3u];
                     if (kind == BC2) texel[t].w = (float)((b[t / 2] >> (4 * (t & 1))) & 15) / 15.0f; else if (kind == BC3) texel[t].w = a8[bcAlphaIndex(b, t)]; }
-            } else {
+            } else if (kind == BC7) bc7Block(b, texel);
+            else {
                 const bool sn = kind == BC4S || kind == BC5S; float r8[8], g8[8]; bcAlpha8(b, r8, sn); if (kind == BC5 || kind == BC5S) bcAlpha8(b + 8, g8, sn);
                 for (int t = 0; t < 16; t++) texel[t] = px(r8[bcAlphaIndex(b, t)], (kind == BC5 || kind == BC5S) ? g8[bcAlphaIndex(b + 8, t)] : 0.0f, 0.0f, 1.0f);
             }
