@@ -157,6 +157,7 @@ struct FlatShape { PbrtMeshSP mesh; Affine xfm; bool baked; };
 void Flatten(const PbrtObject& obj, const Affine& xfm, bool isWorldLevel, bool allShapes, std::vector<FlatShape>& out, int depth)
 {
     if (depth > 16) throw std::runtime_error("instance nesting too deep");
+    if (out.size() > 0x00ffffffu) throw std::runtime_error("more than 2^24-1 instanced shapes (nested instancing multiplies)");
     if (!isWorldLevel) {
         size_t n = allShapes ? obj.shapes.size() : (obj.shapes.empty() ? 0 : 1);
         for (size_t i = 0; i < n; i++) { FlatShape f; f.mesh = obj.shapes[i]; f.xfm = xfm; f.baked = false; out.push_back(f); }
@@ -164,7 +165,17 @@ void Flatten(const PbrtObject& obj, const Affine& xfm, bool isWorldLevel, bool a
     for (const PbrtInstance& inst : obj.instances) if (inst.object) Flatten(*inst.object, xfm * inst.xfm, false, allShapes, out, depth + 1);
 }
 
-inline bool usable(const PbrtMesh& mesh) { return !(mesh.index.empty() || mesh.vertex.empty()); }
+/* every path into the conversion asks this first, so it is also where a mesh whose arrays do not fit together is refused (the
+ * reference would read past its vertex buffer): an index beyond the vertices, per-vertex normals / texture coordinates that are fewer */
+inline bool usable(const PbrtMesh& mesh)
+{
+    if (mesh.index.empty() || mesh.vertex.empty()) return false;
+    const size_t nv = mesh.vertex.size();
+    for (uint32_t i : mesh.index) if (i >= nv) throw std::runtime_error("mesh index " + std::to_string(i) + " is beyond its " + std::to_string(nv) + " vertices");
+    if (!mesh.normal.empty() && mesh.normal.size() < nv) throw std::runtime_error("mesh has fewer normals than vertices");
+    if (!mesh.texcoord.empty() && mesh.texcoord.size() < nv) throw std::runtime_error("mesh has fewer texture coordinates than vertices");
+    return true;
+}
 
 /* area lights, one per triangle (TracerBoy.cpp:1526-1576); instanced emitters get their world positions */
 void AppendAreaLights(HostScene& out, const PbrtMesh& mesh, const Affine& xf)
@@ -358,7 +369,7 @@ void ConvertScene(const PbrtScene& in, HostScene& out, const ConvertOptions& opt
           if (!world.meshes.empty()) { defs.push_back(world); insts.push_back(InstDef{0, Affine()}); } }
         std::unordered_map<const PbrtObject*, uint32_t> blasOf;
         struct Walker {
-            std::vector<BlasDef>& defs; std::vector<InstDef>& insts; std::unordered_map<const PbrtObject*, uint32_t>& blasOf;
+            std::vector<BlasDef>& defs; std::vector<InstDef>& insts; std::unordered_map<const PbrtObject*, uint32_t>& blasOf; uint32_t visited = 0;
             void visit(const PbrtObject& obj, const Affine& xfm, int depth)
             {
                 if (depth > 16) throw std::runtime_error("instance nesting too deep");
@@ -374,6 +385,7 @@ void ConvertScene(const PbrtScene& in, HostScene& out, const ConvertOptions& opt
                         it = blasOf.emplace(o, idx).first;
                     }
                     if (it->second != 0xffffffffu) insts.push_back(InstDef{it->second, X});
+                    if (insts.size() > 0x00ffffffu || ++visited > 0x04000000u) throw std::runtime_error("more than 2^24-1 instances (nested instancing multiplies)");
                     visit(*o, X, depth + 1);
                 }
             }

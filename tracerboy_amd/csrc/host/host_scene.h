@@ -77,6 +77,8 @@ bool WritePfmRGB(const std::string& file, uint32_t W, uint32_t H, const float* r
 bool WriteExrRGBA(const std::string& file, uint32_t W, uint32_t H, const float* rgba, std::string& err);
 bool LoadImageRGBA32F(const std::string& file, std::vector<TbFloat4>& texels, uint32_t& w, uint32_t& h, bool& normalizedFormat, std::string& err, bool* hasAlpha = nullptr);
 /* PNG / TGA (image_decode.cpp): texels as the DXGI typed load of what DirectXTex produces, top row first */
+/* D3D12_REQ_TEXTURE2D_U_OR_V_DIMENSION: what the reference could create a texture for; every reader refuses more before it allocates */
+inline bool ImageDimensionsOk(uint32_t w, uint32_t h) { return w >= 1 && h >= 1 && w <= 16384 && h <= 16384; }
 struct DecodedImage { std::vector<TbFloat4> texels; uint32_t width = 0, height = 0; bool normalized = false, hasAlpha = false; };
 bool DecodeImageFile(const std::string& file, DecodedImage& img, std::string& err);
 

@@ -14,6 +14,8 @@
 #include <cstring>
 #include <stdexcept>
 
+#include <sys/stat.h>
+
 namespace tbhost {
 namespace {
 
@@ -21,6 +23,8 @@ bool readFile(const std::string& file, std::vector<uint8_t>& out, std::string& e
 {
     FILE* f = fopen(file.c_str(), "rb");
     if (!f) { err = "cannot open image '" + file + "'"; return false; }
+    struct stat st;
+    if (fstat(fileno(f), &st) != 0 || !S_ISREG(st.st_mode)) { fclose(f); err = "'" + file + "' is not a regular file"; return false; }   /* fopen succeeds on a directory and ftell then reports LONG_MAX */
     fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET);
     out.resize(n > 0 ? (size_t)n : 0);
     bool ok = out.empty() || fread(out.data(), 1, out.size(), f) == out.size();
@@ -179,7 +183,7 @@ bool decodePng(const std::vector<uint8_t>& d, DecodedImage& img, std::string& er
         const uint32_t n = be32(&d[at]); const uint8_t* type = &d[at + 4];
         if (at + 12 + n > d.size()) throw std::runtime_error("png: truncated chunk");
         const uint8_t* body = &d[at + 8];
-        if (!memcmp(type, "IHDR", 4)) { W = be32(body); H = be32(body + 4); depth = body[8]; ctype = body[9]; interlace = body[12]; if (body[10] || body[11]) throw std::runtime_error("png: unknown compression / filter method"); }
+        if (!memcmp(type, "IHDR", 4)) { if (n < 13) throw std::runtime_error("png: short IHDR"); W = be32(body); H = be32(body + 4); depth = body[8]; ctype = body[9]; interlace = body[12]; if (body[10] || body[11]) throw std::runtime_error("png: unknown compression / filter method"); }
         else if (!memcmp(type, "PLTE", 4)) palette.assign(body, body + n);
         else if (!memcmp(type, "tRNS", 4)) trns.assign(body, body + n);
         else if (!memcmp(type, "IDAT", 4)) idat.insert(idat.end(), body, body + n);
@@ -189,13 +193,23 @@ bool decodePng(const std::vector<uint8_t>& d, DecodedImage& img, std::string& er
     const int channels = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
     if (!W || !H || !channels || !(depth == 1 || depth == 2 || depth == 4 || depth == 8 || depth == 16) || interlace > 1) throw std::runtime_error("png: unsupported header");
     if (ctype == 3 && palette.empty()) throw std::runtime_error("png: palette image without PLTE");
+    if (!ImageDimensionsOk(W, H)) throw std::runtime_error("png: dimensions beyond the 16384 a 2-D texture can have");
+    if ((ctype == 2 || ctype == 4 || ctype == 6) && depth < 8) throw std::runtime_error("png: bit depth not allowed for this colour type");
+    if (ctype == 3 && depth == 16) throw std::runtime_error("png: 16-bit palette indices");
     std::vector<uint8_t> raw; zlibInflate(idat, raw);
     const size_t bitsPerPixel = (size_t)channels * depth, bpp = (bitsPerPixel + 7) / 8;
+    {   /* the scanlines the header promises must all be there before anything of that size is allocated */
+        static const uint32_t xs0[7] = {0, 4, 0, 2, 0, 1, 0}, ys0[7] = {0, 0, 4, 0, 2, 0, 1}, dxs0[7] = {8, 8, 4, 4, 2, 2, 1}, dys0[7] = {8, 8, 8, 4, 4, 2, 2};
+        size_t want = 0;
+        if (!interlace) want = (size_t)H * (((size_t)W * bitsPerPixel + 7) / 8 + 1);
+        else for (int p = 0; p < 7; p++) { const size_t pw = (W + dxs0[p] - 1 - xs0[p]) / dxs0[p], ph = (H + dys0[p] - 1 - ys0[p]) / dys0[p]; if (pw && ph) want += ph * ((pw * bitsPerPixel + 7) / 8 + 1); }
+        if (raw.size() < want) throw std::runtime_error("png: image data too short");
+    }
     /* samples[y][x][c] as 16-bit values at the file's bit depth */
     std::vector<uint16_t> samples((size_t)W * H * channels, 0);
     auto unpackPass = [&](const uint8_t* src, uint32_t pw, uint32_t ph, uint32_t x0, uint32_t y0, uint32_t dx, uint32_t dy) -> size_t {
         if (!pw || !ph) return 0;
-        const size_t rowBytes = (pw * bitsPerPixel + 7) / 8;
+        const size_t rowBytes = ((size_t)pw * bitsPerPixel + 7) / 8;
         std::vector<uint8_t> px; unfilter(src, ph, rowBytes, bpp, px);
         for (uint32_t y = 0; y < ph; y++) for (uint32_t x = 0; x < pw; x++) for (int c = 0; c < channels; c++) {
             const uint8_t* row = px.data() + (size_t)y * rowBytes; uint16_t v;
@@ -260,9 +274,13 @@ bool decodeTga(const std::vector<uint8_t>& d, DecodedImage& img, std::string& er
     if ((base == 2 && !(bits == 16 || bits == 24 || bits == 32)) || (base == 3 && bits != 8) || (base == 1 && (bits != 8 || cmapType != 1))) { err = "TGA: unsupported pixel depth"; return false; }
     size_t at = 18 + (size_t)idLen;
     const size_t cmapEntry = (size_t)(cmapBits + 7) / 8;
+    if (base == 1 && !(cmapBits == 15 || cmapBits == 16 || cmapBits == 24 || cmapBits == 32)) { err = "TGA: unsupported colour-map entry size"; return false; }
     const uint8_t* cmap = cmapType ? d.data() + at : nullptr;
     at += cmapType ? (size_t)cmapLen * cmapEntry : 0;
+    if (at > d.size()) throw std::runtime_error("TGA: truncated colour map");
+    if (!ImageDimensionsOk(W, H)) throw std::runtime_error("TGA: dimensions beyond the 16384 a 2-D texture can have");
     const size_t px = (size_t)bits / 8;
+    if ((size_t)W * H * px > (rle ? 128 : 1) * (d.size() - at)) throw std::runtime_error("TGA: truncated");   /* a run packet holds at most 128 pixels */
     std::vector<uint8_t> pix((size_t)W * H * px);
     if (!rle) { if (at + pix.size() > d.size()) throw std::runtime_error("TGA: truncated"); memcpy(pix.data(), d.data() + at, pix.size()); }
     else {

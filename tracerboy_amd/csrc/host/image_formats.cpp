@@ -86,11 +86,11 @@ void idctIslow(const int* coef /* dequantised, natural order */, uint8_t* out, s
     int ws[64];
     for (int c = 0; c < 8; c++) {
         const int* in = coef + c; int* w = ws + c;
-        if (!in[8] && !in[16] && !in[24] && !in[32] && !in[40] && !in[48] && !in[56]) { const int dc = in[0] << PASS1_BITS; for (int r = 0; r < 8; r++) w[8 * r] = dc; continue; }
+        if (!in[8] && !in[16] && !in[24] && !in[32] && !in[40] && !in[48] && !in[56]) { const int dc = in[0] * (1 << PASS1_BITS); for (int r = 0; r < 8; r++) w[8 * r] = dc; continue; }
         long z2 = in[16], z3 = in[48];
         long z1 = (z2 + z3) * F_0_541, tmp2 = z1 + z3 * (-F_1_847), tmp3 = z1 + z2 * F_0_765;
         z2 = in[0]; z3 = in[32];
-        long tmp0 = (z2 + z3) << CONST_BITS, tmp1 = (z2 - z3) << CONST_BITS;
+        long tmp0 = (z2 + z3) * (1L << CONST_BITS), tmp1 = (z2 - z3) * (1L << CONST_BITS);
         const long tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
         tmp0 = in[56]; tmp1 = in[40]; tmp2 = in[24]; tmp3 = in[8];
         z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2; long z4 = tmp1 + tmp3, z5 = (z3 + z4) * F_1_175;
@@ -107,7 +107,7 @@ void idctIslow(const int* coef /* dequantised, natural order */, uint8_t* out, s
         const int* w = ws + 8 * r; uint8_t* o = out + stride * r;
         long z2 = w[2], z3 = w[6];
         long z1 = (z2 + z3) * F_0_541, tmp2 = z1 + z3 * (-F_1_847), tmp3 = z1 + z2 * F_0_765;
-        long tmp0 = ((long)w[0] + w[4]) << CONST_BITS, tmp1 = ((long)w[0] - w[4]) << CONST_BITS;
+        long tmp0 = ((long)w[0] + w[4]) * (1L << CONST_BITS), tmp1 = ((long)w[0] - w[4]) * (1L << CONST_BITS);
         const long tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
         tmp0 = w[7]; tmp1 = w[5]; tmp2 = w[3]; tmp3 = w[1];
         z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2; long z4 = tmp1 + tmp3, z5 = (z3 + z4) * F_1_175;
@@ -226,10 +226,13 @@ bool decodeJpeg(const std::vector<uint8_t>& d, DecodedImage& img, std::string& e
                 memcpy(h.vals, &d[p], (size_t)total); p += total; h.build(); h.present = true; }
         } else if (m == 0xc0 || m == 0xc1 || m == 0xc2) { /* SOF0 / SOF1 sequential, SOF2 progressive; Huffman, 8 bits */
             if (sawSof) throw std::runtime_error("jpeg: second frame header");
+            if (len < 8) throw std::runtime_error("jpeg: short frame header");
             if (d[seg] != 8) throw std::runtime_error("jpeg: only 8-bit precision is supported");
             progressive = m == 0xc2;
             H = u16(seg + 1); W = u16(seg + 3); const int nc = d[seg + 5];
             if (!W || !H || (nc != 1 && nc != 3)) throw std::runtime_error("jpeg: unsupported component count (grey and three-component files are decoded)");
+            if (seg + 6 + 3 * (size_t)nc > end) throw std::runtime_error("jpeg: short frame header");
+            if (!ImageDimensionsOk(W, H)) throw std::runtime_error("jpeg: dimensions beyond the 16384 a 2-D texture can have");
             comps.resize((size_t)nc);
             for (int i = 0; i < nc; i++) { JpegComp& c = comps[(size_t)i]; c.id = d[seg + 6 + 3 * i]; c.h = d[seg + 7 + 3 * i] >> 4; c.v = d[seg + 7 + 3 * i] & 15; c.tq = d[seg + 8 + 3 * i];
                 if (c.h < 1 || c.h > 4 || c.v < 1 || c.v > 4 || c.tq > 3) throw std::runtime_error("jpeg: bad sampling factors"); hmax = std::max(hmax, c.h); vmax = std::max(vmax, c.v); }
@@ -239,12 +242,13 @@ bool decodeJpeg(const std::vector<uint8_t>& d, DecodedImage& img, std::string& e
                 c.dw = (W * (uint32_t)c.h + (uint32_t)hmax - 1) / (uint32_t)hmax; c.dh = (H * (uint32_t)c.v + (uint32_t)vmax - 1) / (uint32_t)vmax;
                 c.cw = (c.dw + 7) / 8; c.ch = (c.dh + 7) / 8; c.bw = mcusX * (uint32_t)c.h; c.bh = mcusY * (uint32_t)c.v;
                 if ((uint64_t)c.bw * c.bh > (1u << 24)) throw std::runtime_error("jpeg: image too large");
+                if ((uint64_t)c.bw * c.bh > 64ull * d.size() + 4096) throw std::runtime_error("jpeg: the file is too short for the frame its header describes");   /* a block costs at least a bit of DC */
                 c.coef.assign((size_t)c.bw * c.bh * 64, 0);
             }
             sawSof = true;
         } else if (m >= 0xc3 && m <= 0xcf && m != 0xc4 && m != 0xc8 && m != 0xcc) {
             err = "lossless / hierarchical / arithmetic-coded JPEG is not supported (sequential and progressive Huffman files are)"; return false;
-        } else if (m == 0xdd) restartInterval = (int)u16(seg);
+        } else if (m == 0xdd) { if (len < 4) throw std::runtime_error("jpeg: short DRI"); restartInterval = (int)u16(seg); }
         else if (m == 0xee && len >= 14 && !memcmp(&d[seg], "Adobe", 5)) adobeTransform = d[seg + 11];
         else if (m == 0xda) { /* SOS */
             if (!sawSof) throw std::runtime_error("jpeg: scan before frame header");
@@ -284,7 +288,7 @@ bool decodeJpeg(const std::vector<uint8_t>& d, DecodedImage& img, std::string& e
         const JpegComp& c = comps[ci]; std::vector<uint8_t>& o = full[ci]; o.assign((size_t)W * H, 0);
         const int hx = hmax / c.h, vx = vmax / c.v; const bool exact = hmax % c.h == 0 && vmax % c.v == 0;
         auto in = [&](uint32_t x, uint32_t y) -> int { return c.plane[(size_t)y * c.stride + x]; };
-        if (hx == 1 && vx == 1) { for (uint32_t y = 0; y < H; y++) memcpy(&o[(size_t)y * W], &c.plane[(size_t)y * c.stride], W); }
+        if (exact && hx == 1 && vx == 1) { for (uint32_t y = 0; y < H; y++) memcpy(&o[(size_t)y * W], &c.plane[(size_t)y * c.stride], W); }
         else if (exact && hx == 2 && vx == 1 && c.dw > 2) { /* h2v1_fancy_upsample: 3/4 nearer + 1/4 further, rounding 1 / 2 alternately */
             for (uint32_t y = 0; y < H; y++) for (uint32_t x = 0; x < W; x++) {
                 const uint32_t i = x >> 1; int v;
@@ -346,8 +350,8 @@ bool decodeBmp(const std::vector<uint8_t>& d, DecodedImage& img, std::string& er
     if (hdr < 40) { err = "BMP: OS/2 core headers are not supported"; return false; }
     const int32_t w = (int32_t)rd32(d, 18), hs = (int32_t)rd32(d, 22);
     const uint32_t bpp = rd16(d, 28), comp = rd32(d, 30); uint32_t colours = rd32(d, 46);
-    if (w <= 0 || hs == 0 || w > 65536 || std::abs(hs) > 65536) { err = "BMP: bad dimensions"; return false; }
-    const uint32_t W = (uint32_t)w, H = (uint32_t)std::abs(hs); const bool topDown = hs < 0;
+    if (w <= 0 || hs == 0 || w > 16384 || hs > 16384 || hs < -16384) { err = "BMP: bad dimensions (a 2-D texture has at most 16384 texels a side)"; return false; }
+    const uint32_t W = (uint32_t)w, H = (uint32_t)(hs < 0 ? -hs : hs); const bool topDown = hs < 0;
     if (comp != 0 && comp != 3) { err = "BMP: RLE / embedded JPEG / PNG compression is not supported"; return false; }
     uint32_t rm = 0, gm = 0, bm = 0, am = 0;
     if (comp == 3) { const size_t mo = hdr >= 52 ? 54 : 14 + 40; rm = rd32(d, mo); gm = rd32(d, mo + 4); bm = rd32(d, mo + 8); if (hdr >= 56) am = rd32(d, mo + 12); }
@@ -356,6 +360,7 @@ bool decodeBmp(const std::vector<uint8_t>& d, DecodedImage& img, std::string& er
     std::vector<TbFloat4> pal;
     if (bpp <= 8) {
         if (!colours) colours = 1u << bpp;
+        if (colours > 256) throw std::runtime_error("BMP: bad palette size");
         const size_t po = 14 + (size_t)hdr + (comp == 3 && hdr == 40 ? 12 : 0);
         for (uint32_t i = 0; i < colours; i++) { if (po + 4 * i + 3 >= d.size()) throw std::runtime_error("BMP: truncated palette"); pal.push_back(px(d[po + 4 * i + 2] / 255.0f, d[po + 4 * i + 1] / 255.0f, d[po + 4 * i] / 255.0f, 1.0f)); }
     }
@@ -515,7 +520,7 @@ bool decodeDds(const std::vector<uint8_t>& d, DecodedImage& img, std::string& er
     if (d.size() < 128 || memcmp(d.data(), "DDS ", 4) || rd32(d, 4) != 124) { err = "not a DDS file"; return false; }
     const uint32_t H = rd32(d, 12), W = rd32(d, 16), pfFlags = rd32(d, 80), fourcc = rd32(d, 84), bits = rd32(d, 88);
     const uint32_t rm = rd32(d, 92), gm = rd32(d, 96), bm = rd32(d, 100), am = rd32(d, 104);
-    if (!W || !H || W > 65536 || H > 65536) { err = "DDS: bad dimensions"; return false; }
+    if (!ImageDimensionsOk(W, H)) { err = "DDS: bad dimensions (a 2-D texture has at most 16384 texels a side)"; return false; }
     size_t off = 128; uint32_t dxgi = 0;
     auto cc = [](const char* s) { return (uint32_t)(uint8_t)s[0] | ((uint32_t)(uint8_t)s[1] << 8) | ((uint32_t)(uint8_t)s[2] << 16) | ((uint32_t)(uint8_t)s[3] << 24); };
     enum { RAW, BC1, BC2, BC3, BC4, BC5, BC4S, BC5S, BC7, F16, F32, F32R, U16 } kind = RAW;
@@ -540,8 +545,10 @@ bool decodeDds(const std::vector<uint8_t>& d, DecodedImage& img, std::string& er
         default: err = "DDS: unsupported DXGI format " + std::to_string(dxgi); return false;
         }
     }
-    img.width = W; img.height = H; img.texels.assign((size_t)W * H, px(0, 0, 0, 1)); img.normalized = !(kind == F16 || kind == F32 || kind == F32R);
-    auto need = [&](size_t bytes) { if (off + bytes > d.size()) throw std::runtime_error("DDS: truncated surface"); };
+    bool sized = false;
+    auto need = [&](size_t bytes) { if (off + bytes > d.size()) throw std::runtime_error("DDS: truncated surface");
+                                    if (!sized) { img.texels.assign((size_t)W * H, px(0, 0, 0, 1)); sized = true; } };   /* nothing of the header's size is allocated before the surface is known to be there */
+    img.width = W; img.height = H; img.normalized = !(kind == F16 || kind == F32 || kind == F32R);
     if (kind == RAW) {
         if (rawBits != 8 && rawBits != 16 && rawBits != 24 && rawBits != 32) { err = "DDS: unsupported bit count"; return false; }
         const size_t bpp = rawBits / 8; need((size_t)W * H * bpp);

@@ -43,6 +43,11 @@ bool loadHdr(const std::string& file, std::vector<TbFloat4>& texels, uint32_t& W
     int h = 0, w = 0; char sy = 0, sx = 0, ay = 0, ax = 0;
     if (sscanf(line.c_str(), "%c%c %d %c%c %d", &sy, &ay, &h, &sx, &ax, &w) != 6 || ay != 'Y' || ax != 'X' || w <= 0 || h <= 0) { err = file + ": unsupported HDR resolution line '" + line + "'"; return false; }
     W = (uint32_t)w; H = (uint32_t)h;
+    if (!ImageDimensionsOk(W, H)) { err = file + ": HDR dimensions beyond the 16384 a 2-D texture can have"; return false; }
+    {   /* a run-length packet holds at most 127 values of one channel in 2 bytes: refuse a header the rest of the file cannot fill */
+        const std::streampos here = in.tellg(); in.seekg(0, std::ios::end); const uint64_t left = (uint64_t)(in.tellg() - here); in.seekg(here);
+        if ((uint64_t)W * H * 4 > 64 * left) { err = file + ": truncated HDR data"; return false; }
+    }
     texels.assign((size_t)W * H, TbFloat4{0, 0, 0, 1});
     std::vector<unsigned char> scan((size_t)W * 4);
     for (uint32_t y = 0; y < H; y++) {
@@ -86,6 +91,11 @@ bool loadPfm(const std::string& file, std::vector<TbFloat4>& texels, uint32_t& W
     int ch = magic == "PF" ? 3 : (magic == "Pf" ? 1 : 0);
     if (!ch || w <= 0 || h <= 0) { err = file + ": not a PFM file"; return false; }
     W = (uint32_t)w; H = (uint32_t)h;
+    if (!ImageDimensionsOk(W, H)) { err = file + ": PFM dimensions beyond the 16384 a 2-D texture can have"; return false; }
+    {
+        const std::streampos here = in.tellg(); in.seekg(0, std::ios::end); const uint64_t left = here < 0 ? 0 : (uint64_t)(in.tellg() - here); in.seekg(here);
+        if ((uint64_t)W * H * (uint64_t)ch * 4 > left) { err = file + ": truncated PFM data"; return false; }
+    }
     std::vector<float> raw((size_t)W * H * ch);
     in.read((char*)raw.data(), (std::streamsize)(raw.size() * 4));
     if (!in) { err = file + ": truncated PFM data"; return false; }

@@ -19,6 +19,8 @@
 #include <cstring>
 #include <stdexcept>
 
+#include <sys/stat.h>
+
 namespace tbhost {
 namespace {
 
@@ -191,6 +193,7 @@ std::shared_ptr<PbrtScene> importPBF(const std::string& fileName)
     FILE* f = fopen(fileName.c_str(), "rb");
     if (!f) throw std::runtime_error("could not open '" + fileName + "'");
     std::vector<uint8_t> data;
+    { struct stat st; if (fstat(fileno(f), &st) != 0 || !S_ISREG(st.st_mode)) { fclose(f); throw std::runtime_error("'" + fileName + "' is not a regular file"); } }
     { fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET); data.resize(n > 0 ? (size_t)n : 0); if (!data.empty() && fread(data.data(), 1, data.size(), f) != data.size()) { fclose(f); throw std::runtime_error("short read from '" + fileName + "'"); } }
     fclose(f);
     if (data.size() < 4) throw std::runtime_error("pbf: file too short");

@@ -357,6 +357,7 @@ private:
             else if (d == "ObjectInstance") {
                 Token n = next(); auto it = objects.find(n.text);
                 if (it == objects.end()) throw std::runtime_error("ObjectInstance of unknown object '" + n.text + "'");
+                for (const std::shared_ptr<PbrtObject>& open : objectStack) if (open == it->second) throw std::runtime_error("object '" + n.text + "' is instanced inside its own definition");   /* the only way to a cycle: objects exist from their ObjectBegin on */
                 PbrtInstance inst; inst.xfm = ctm; inst.object = it->second; currentObject().instances.push_back(inst);
             }
             else if (d == "ActiveTransform" || d == "TransformTimes") { next(); if (d == "TransformTimes") next(); }
@@ -399,6 +400,12 @@ void readPly(const std::string& fileName, std::vector<Vec3>& pos, std::vector<Ve
         } else if (w == "end_header") break;
     }
     if (fmt == BE) throw std::runtime_error(fileName + ": big-endian PLY not supported");
+    {   /* an element costs at least a byte: a count the rest of the file cannot hold is a damaged header, not something to allocate */
+        const std::streampos here = in.tellg(); in.seekg(0, std::ios::end); const uint64_t left = here < 0 ? 0 : (uint64_t)(in.tellg() - here); in.seekg(here);
+        for (const Elem& e : elems) if (!e.props.empty() && e.count > left) throw std::runtime_error(fileName + ": PLY element count beyond the size of the file");
+    }
+    auto listLength = [&](double v) -> size_t { if (!(v >= 0.0 && v <= 1e6)) throw std::runtime_error(fileName + ": bad PLY list length"); return (size_t)v; };
+    auto vertexIndex = [&](double v) -> uint32_t { if (!(v >= 0.0 && v <= 4294967295.0)) throw std::runtime_error(fileName + ": bad PLY vertex index"); return (uint32_t)v; };
     auto sizeOf = [](const std::string& t) -> int {
         if (t == "char" || t == "uchar" || t == "int8" || t == "uint8") return 1;
         if (t == "short" || t == "ushort" || t == "int16" || t == "uint16") return 2;
@@ -407,7 +414,7 @@ void readPly(const std::string& fileName, std::vector<Vec3>& pos, std::vector<Ve
         return 0;
     };
     auto readNum = [&](const std::string& t) -> double {
-        if (fmt == Ascii) { double d; in >> d; return d; }
+        if (fmt == Ascii) { double d = 0; in >> d; if (!in) throw std::runtime_error(fileName + ": unable to read the contents of PLY file"); return d; }
         char b[8]; int n = sizeOf(t); if (n == 0) throw std::runtime_error(fileName + ": unknown PLY type " + t);
         in.read(b, n); if (!in) throw std::runtime_error(fileName + ": unable to read the contents of PLY file");
         if (t == "float" || t == "float32") { float f; memcpy(&f, b, 4); return f; }
@@ -422,11 +429,11 @@ void readPly(const std::string& fileName, std::vector<Vec3>& pos, std::vector<Ve
     for (const Elem& e : elems) {
         if (e.name == "vertex") {
             bool hasN = false, hasUV = false;
-            for (const Prop& p : e.props) { if (p.name == "nx") hasN = true; if (p.name == "u" || p.name == "s") hasUV = true; }
+            for (const Prop& p : e.props) { if (p.name == "nx" || p.name == "ny" || p.name == "nz") hasN = true; if (p.name == "u" || p.name == "s" || p.name == "v" || p.name == "t") hasUV = true; }
             pos.resize(e.count); if (hasN) nor.resize(e.count); if (hasUV) uv.resize(e.count);
             for (size_t i = 0; i < e.count; i++)
                 for (const Prop& p : e.props) {
-                    if (p.isList) { size_t n = (size_t)readNum(p.listCount); for (size_t k = 0; k < n; k++) readNum(p.listItem); continue; }
+                    if (p.isList) { size_t n = listLength(readNum(p.listCount)); for (size_t k = 0; k < n; k++) readNum(p.listItem); continue; }
                     float v = (float)readNum(p.type);
                     if (p.name == "x") pos[i].x = v; else if (p.name == "y") pos[i].y = v; else if (p.name == "z") pos[i].z = v;
                     else if (p.name == "nx") nor[i].x = v; else if (p.name == "ny") nor[i].y = v; else if (p.name == "nz") nor[i].z = v;
@@ -437,15 +444,15 @@ void readPly(const std::string& fileName, std::vector<Vec3>& pos, std::vector<Ve
             for (size_t i = 0; i < e.count; i++)
                 for (const Prop& p : e.props) {
                     if (!p.isList) { readNum(p.type); continue; }
-                    size_t n = (size_t)readNum(p.listCount);
+                    size_t n = listLength(readNum(p.listCount));
                     bool isIdx = p.name == "vertex_indices" || p.name == "vertex_index";
                     if (isIdx && n != 3) throw std::runtime_error(fileName + ": PLY face with " + std::to_string(n) + " vertices (only triangles are supported)");
-                    for (size_t k = 0; k < n; k++) { double v = readNum(p.listItem); if (isIdx) idx.push_back((uint32_t)(int64_t)v); }
+                    for (size_t k = 0; k < n; k++) { double v = readNum(p.listItem); if (isIdx) idx.push_back(vertexIndex(v)); }
                 }
         } else {
             for (size_t i = 0; i < e.count; i++)
                 for (const Prop& p : e.props) {
-                    if (p.isList) { size_t n = (size_t)readNum(p.listCount); for (size_t k = 0; k < n; k++) readNum(p.listItem); }
+                    if (p.isList) { size_t n = listLength(readNum(p.listCount)); for (size_t k = 0; k < n; k++) readNum(p.listItem); }
                     else readNum(p.type);
                 }
         }
