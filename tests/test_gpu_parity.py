@@ -957,3 +957,50 @@ def test_headless_cli_writes_the_library_result(gpu_tb, settings, tmp_path):
     for c, plane in ((0, 3), (1, 2), (2, 1)):
         assert np.array_equal(bits(px[:, plane, :]), bits(acc[..., c] * inv))
     assert np.array_equal(px[:, 0, :], (acc[..., 3] > 0).astype(np.float32))
+
+
+@pytest.mark.parametrize("size", [(1, 1), (7, 5), (13, 9), (65, 33), (257, 1), (1, 129), (72, 40)])
+def test_ragged_frame_sizes_bit_exact(gpu_tb, settings, size):
+    """Frames that are not multiples of the 8 x 8 thread group (the reference's dispatch rounds up and its shader returns for pixels
+    outside, SoftwareRayTraceCS.hlsl:33-37), down to a single pixel and single rows / columns: the persistent megakernel with and
+    without frame groups and the wavefront pipeline against the oracle, the jittered surface and the sample weights included."""
+    W, H = size
+    gpu_tb.LoadScene(CORNELL)
+    for frames in (1, 9):
+        ref = _oracle(gpu_tb, W, H, frames, settings, jittered=True)
+        for pipeline, groups in ((0, 0), (0, -1), (0, 4), (2, 0)):      # frame_group 0: by itself from 8 frames on; -1: one pixel per lane; 4: groups of four
+            try:
+                gpu_tb.SetOption("pipeline", pipeline); gpu_tb.SetOption("frame_group", groups)
+                gpu_tb.InvalidateHistory(); gpu_tb.Render(W, H, frames, settings, 0.0)
+                out, jit = gpu_tb.ReadAccumulation(jittered=True)
+            finally:
+                gpu_tb.SetOption("pipeline", 0); gpu_tb.SetOption("frame_group", 0)
+            assert out.shape == (H, W, 4)
+            assert np.array_equal(bits(out), bits(ref["output"])), (size, frames, pipeline, groups)
+            assert np.array_equal(bits(jit), bits(ref["jittered"])), (size, frames, pipeline, groups)
+
+
+def test_empty_and_degenerate_inputs_are_refused_or_rendered(gpu_tb, settings, tmp_path):
+    """A world without a triangle is refused at load (the reference builds nothing to trace and asserts); zero frames is a no-op;
+    a mesh of only zero-area triangles and a non-finite vertex still render what the oracle renders (no hang, no fault)."""
+    from tracerboy_amd import api
+    head = 'LookAt 0 1 5  0 1 0  0 1 0\nCamera "perspective" "float fov" [45]\nWorldBegin\n'
+    p = tmp_path / "empty.pbrt"; p.write_text(head + "WorldEnd\n")
+    with pytest.raises(api.TracerBoyError):
+        gpu_tb.LoadScene(str(p))
+    gpu_tb.LoadScene(CORNELL)
+    gpu_tb.InvalidateHistory(); gpu_tb.Render(32, 16, 0, settings, 0.0)
+    assert gpu_tb.GetNumberOfSamplesSinceLastInvalidate() == 0
+    gpu_tb.Render(32, 16, 2, settings, 0.0)
+    assert np.array_equal(bits(gpu_tb.ReadAccumulation()), bits(_oracle(gpu_tb, 32, 16, 2, settings)["output"]))
+    flat = head + 'Shape "trianglemesh" "integer indices" [0 1 2 0 2 1] "point P" [1 1 0  1 1 0  1 1 0]\nWorldEnd\n'
+    p = tmp_path / "flat.pbrt"; p.write_text(flat)
+    gpu_tb.LoadScene(str(p)); gpu_tb.Render(40, 24, 2, settings, 0.0)
+    assert np.array_equal(bits(gpu_tb.ReadAccumulation()), bits(_oracle(gpu_tb, 40, 24, 2, settings)["output"]))
+    nonfinite = head + ('MakeNamedMaterial "M" "string type" ["matte"] "rgb Kd" [0.6 0.5 0.4]\nNamedMaterial "M"\n'
+                        'Shape "trianglemesh" "integer indices" [0 1 2 3 4 5] "point P" [-3 0 2  3 0 2  0 0 -4   0 1 0  1e39 1 0  0 2 0]\nWorldEnd\n')
+    p = tmp_path / "nonfinite.pbrt"; p.write_text(nonfinite)
+    gpu_tb.LoadScene(str(p)); gpu_tb.Render(40, 24, 2, settings, 0.0)
+    out = gpu_tb.ReadAccumulation(); ref = _oracle(gpu_tb, 40, 24, 2, settings)["output"]
+    assert np.array_equal(bits(out), bits(ref))
+    gpu_tb.LoadScene(CORNELL)
