@@ -1004,3 +1004,41 @@ def test_empty_and_degenerate_inputs_are_refused_or_rendered(gpu_tb, settings, t
     out = gpu_tb.ReadAccumulation(); ref = _oracle(gpu_tb, 40, 24, 2, settings)["output"]
     assert np.array_equal(bits(out), bits(ref))
     gpu_tb.LoadScene(CORNELL)
+
+
+def test_c_abi_misuse_returns_error_codes(gpu_tb, settings):
+    """The boundary never aborts (the reference asserts; the C ABI returns a negative code and keeps a message): null
+    handles and buffers, calls in the wrong order, unknown options, absurd sizes -- through raw ctypes, not the Python wrapper."""
+    import ctypes as C
+    from tracerboy_amd import api
+    L = gpu_tb._L
+    null = C.c_void_p(None)
+    assert L.tb_render(null, 8, 8, 1, None, C.c_float(0)) < 0
+    assert L.tb_read_accum(null, None, None) < 0
+    assert L.tb_load_scene(null, b"x.pbrt") < 0
+    assert L.tb_set_option(null, b"aov", 1) < 0
+    assert L.tb_group_size(null) == 0
+    L.tb_destroy(null); L.tb_invalidate_history(null)                   # no-ops
+    fresh = api.TracerBoy()                                              # a second context on the same device, no scene yet
+    try:
+        h = fresh._ctx
+        assert L.tb_render(h, 8, 8, 1, None, C.c_float(0)) < 0 and b"no scene" in L.tb_last_error(h)
+        buf = (C.c_float * (8 * 8 * 4))()
+        assert L.tb_read_accum(h, buf, None) < 0
+        assert L.tb_get_camera(h, None) < 0
+        assert L.tb_load_scene(h, None) < 0
+        assert L.tb_load_scene(h, b"/nonexistent/dir/scene.pbrt") < 0 and len(L.tb_last_error(h)) > 0
+        fresh.LoadScene(CORNELL)
+        assert L.tb_render(h, 0, 8, 1, None, C.c_float(0)) < 0
+        assert L.tb_render(h, 1 << 20, 1 << 20, 1, None, C.c_float(0)) < 0      # refused, not attempted
+        assert L.tb_read_aov(h, 3, buf) < 0                                       # AOVs were not enabled
+        assert L.tb_read_aov(h, 99, buf) < 0
+        assert L.tb_get_material(h, -1, None) < 0 and L.tb_set_material(h, 10 ** 6, None) < 0
+        assert L.tb_set_tile_assignment(h, 3, 2, 64, 64) < 0                     # rank beyond the world
+        assert L.tb_set_tile_assignment(h, 0, 1, 0, 64) < 0                      # zero-sized tiles
+        # the context is still usable after all of that
+        fresh.Render(24, 16, 2, settings, 0.0)
+        gpu_tb.LoadScene(CORNELL); gpu_tb.InvalidateHistory(); gpu_tb.Render(24, 16, 2, settings, 0.0)
+        assert np.array_equal(bits(fresh.ReadAccumulation()), bits(gpu_tb.ReadAccumulation()))
+    finally:
+        fresh.close()

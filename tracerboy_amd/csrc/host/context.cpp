@@ -624,6 +624,7 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
 {
     if (!c->hasScene) return fail(c, TB_E_NO_SCENE, "tb_render: no scene loaded");
     if (W == 0 || H == 0) return fail(c, TB_E_INVALID, "tb_render: zero-sized target");
+    if (W > 16384 || H > 16384) return fail(c, TB_E_INVALID, "tb_render: a target has at most 16384 pixels a side (D3D12_REQ_TEXTURE2D_U_OR_V_DIMENSION; pixel indices are 32-bit)");
     tb_output_settings s; if (settings) s = *settings; else DefaultOutputSettings(s);
     if (W != c->width || H != c->height) {
         size_t bytes = (size_t)W * H * sizeof(TbFloat4);
