@@ -131,6 +131,9 @@ def pmc_summary(key):
     from tracerboy_amd import build as tb_build
     stamp = doc.pop("_kernel_digest", None)
     stale = stamp != tb_build.kernel_digest()       # counters of other device code (or unstamped, pre-round-3 files)
+    # the primary-visibility pre-pass (pt_primary) runs once before every lock-step launch it feeds: a "launch" of the roofline block is
+    # the pair, its counters are the two kernels' sums (GRBM_GUI_ACTIVE too: the kernels run one after the other)
+    primary = [v for k, v in doc.items() if k.startswith("pt_primary<") or "::pt_primary<" in k]
     for name, passes in doc.items():
         passes["_stale"] = stale
         # pt_persistent<F, LDS, COUNT, GROUPS[, HYBRID]>: not the counters-on launch (COUNT = true), not the sample fold; the frame-group
@@ -139,6 +142,12 @@ def pmc_summary(key):
         if not m or m.group(2) == "true":
             continue
         if m.group(3) == "true":
+            if primary:
+                passes["_with_prepass"] = True
+                for tag, counters in primary[0].items():
+                    if isinstance(counters, dict) and isinstance(passes.get(tag), dict):
+                        for c, val in counters.items():
+                            if c != "dispatches" and isinstance(val, (int, float)): passes[tag][c] = passes[tag].get(c, 0) + val
             return passes, os.path.relpath(files[-1], ROOT)
         best = passes if best is None else best
     return best, (os.path.relpath(files[-1], ROOT) if best else None)
@@ -161,10 +170,13 @@ def derived_busy(key, passes):
             out["valu_lane_utilisation"] = round(passes["util"]["SQ_THREAD_CYCLES_VALU"] / (64.0 * passes["util"]["SQ_ACTIVE_INST_VALU"]), 3)
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", key + "_mem_counters.json")), key=lambda f: int(re.search(r"profiles/r(\d+)", f).group(1)))
     if files:
+        busy = cyc = 0.0
         for name, c in json.load(open(files[-1])).items():
             m = re.search(r"pt_persistent<\d+u, (true|false), (true|false), (true|false)", name)
-            if m and m.group(2) == "false" and m.group(3) == "true" and c.get("TA_TA_BUSY_sum") and c.get("GRBM_GUI_ACTIVE"):
-                out["ta_busy"] = round(c["TA_TA_BUSY_sum"] / (256.0 * c["GRBM_GUI_ACTIVE"] / 8.0), 3)
+            timed = (m and m.group(2) == "false" and m.group(3) == "true") or (passes and passes.get("_with_prepass") and "pt_primary<" in name)
+            if timed and isinstance(c, dict) and c.get("TA_TA_BUSY_sum") and c.get("GRBM_GUI_ACTIVE"):
+                busy += c["TA_TA_BUSY_sum"]; cyc += c["GRBM_GUI_ACTIVE"]
+        if cyc: out["ta_busy"] = round(busy / (256.0 * cyc / 8.0), 3)
     return out
 
 
@@ -489,6 +501,7 @@ def main():
                 tb.InvalidateHistory(); tb.Render(W3, H3, SPP3, s3, 0.0, sync=False)
             torch.cuda.synchronize(); dt3 = time.perf_counter() - t3
             variant3 = ["matte", "env", "surf", "vol", "full", "sss"][tb.GetOption("last_variant")]
+            prepass3 = bool(tb.GetOption("last_primary_prepass"))   # of the timed renders above (measure_kernel ends with a counting launch, which never has it)
             avg3, frames3, st3 = measure_kernel(tb, api, np, W3, H3, SPP3, s3, 3)
             passes3, src3 = pmc_summary("c3")
             r3 = hbm_roofline(avg3, frames3, W3 * H3, st3, passes3, src3)
@@ -496,6 +509,11 @@ def main():
                        "unit_value": "Msamples/s", "ms_per_step": round(dt3 / 3 * 1e3, 3), "steps": 3, "scene_load_s": round(load3, 2),
                        "kernel_variant": variant3,
                        "note": "launches of 128 frames are batched by the sample-buffer budget: avg_launch_ms / frames_per_launch are per batch launch"})
+            r3["primary_prepass"] = prepass3
+            if r3["primary_prepass"]:
+                r3["kernel"] = "pt_primary + pt_persistent"
+                r3["note"] += ("; a launch is the pair primary-visibility pre-pass (pt_primary: every camera ray of the batch, one 8x8 pixel tile per wave) + lock-step kernel "
+                               "(takes the first hits from the sample slots): avg_launch_ms spans both, the committed counters are their sums")
             r3["pipes"] = derived_busy("c3", passes3)
             r3["pmc_stale"] = bool(passes3 and passes3.get("_stale"))   # true: the committed counters were taken of other kernel code
             # What the committed counters say limits it is not the fabric (traffic_frac_of_peak) but the issue of vector-memory and vector-ALU

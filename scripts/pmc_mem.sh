@@ -25,7 +25,7 @@ out, tag = sys.argv[1], sys.argv[2]
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); disp = collections.defaultdict(set)
 for f in glob.glob(out + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        m = re.search(r"(pt_persistent<[^>]*>|accumulate_samples_kernel)", r["Kernel_Name"])
+        m = re.search(r"(pt_persistent<[^>]*>|pt_primary<[^>]*>|accumulate_samples_kernel)", r["Kernel_Name"])
         if not m or "63u" in m.group(1): continue
         agg[m.group(1)][r["Counter_Name"]] += float(r["Counter_Value"]); disp[(m.group(1), r["Counter_Name"])].add(r["Dispatch_Id"])
 res = {k: {c: v / max(1, len(disp[(k, c)])) for c, v in d.items()} for k, d in agg.items()}

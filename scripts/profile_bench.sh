@@ -32,7 +32,7 @@ for tag in ("fetch", "write", "sq", "lds", "tcc", "util"):
         agg = collections.defaultdict(lambda: collections.defaultdict(float)); seen = set()
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
-            if "pt_persistent" not in k and "accumulate_samples" not in k: continue
+            if "pt_persistent" not in k and "accumulate_samples" not in k and "pt_primary" not in k: continue
             agg[k[:80]][r["Counter_Name"]] += float(r["Counter_Value"])
             seen.add((k, r.get("Dispatch_Id")))
         for k, v in agg.items():

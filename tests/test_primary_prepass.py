@@ -1,0 +1,181 @@
+"""-m gpu: the primary-visibility pre-pass (pt_persistent.inc pt_primary, TbDeviceTargets::primaryGeom, option primary_prepass).
+
+pt_primary walks every camera ray of a frame-group launch, one 8 x 8 pixel tile per wave, and leaves the closest hit in the sample's
+own slot; the lock-step kernel's lanes take it from there, shade the first bounce at once and walk only rays the pre-pass could not
+have walked for them.  Same camera ray (path_begin), same walk (traverse), same hit: the contract is BIT EQUALITY with the path without
+it and with the oracle."""
+import copy
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from conftest import CORNELL, GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def _render(tb, pre, W, H, F, s, calls=1):
+    tb.SetOption("primary_prepass", pre)
+    tb.InvalidateHistory()
+    per = F // calls
+    for k in range(calls):
+        tb.Render(W, H, per if k < calls - 1 else F - per * (calls - 1), s, 0.0)
+    used = tb.GetOption("last_primary_prepass")
+    out, jit = tb.ReadAccumulation(jittered=True)
+    return out, jit, used
+
+
+@pytest.mark.parametrize("scene", ["proc0_env", "proc1_sss", "proc2_sss_depth16", "cornell_from_memory"])
+def test_prepass_is_bit_identical(gpu_tb, settings, scene):
+    s = copy.copy(settings)
+    try:
+        if scene == "proc0_env": gpu_tb.LoadProcedural(0, 30000, 5); s.MaxBounces = 6; want_variant = 1
+        elif scene == "proc1_sss": gpu_tb.LoadProcedural(1, 30000, 7); s.MaxBounces = 6; want_variant = 5
+        elif scene == "proc2_sss_depth16": gpu_tb.LoadProcedural(2, 40000, 9); s.MaxBounces = 16; want_variant = 5
+        else: gpu_tb.SetOption("scene_in_lds", 0); gpu_tb.LoadScene(CORNELL); s.MaxBounces = 8; want_variant = 0
+        W, H, F = 200, 120, 9                                            # not multiples of 16; 9 frames: groups of 8 + 1
+        a, aj, used_a = _render(gpu_tb, 0, W, H, F, s)
+        b, bj, used_b = _render(gpu_tb, 2, W, H, F, s)
+        assert used_a == 0 and used_b == 1 and gpu_tb.GetOption("last_variant") == want_variant
+        ref = ol.render(gpu_tb.HostSceneView(), gpu_tb.FrameConstants(W, H, 0, s, 0.0), W, H, F, threads=8, jittered=True)
+        wrong = lambda x: int((bits(x) != bits(ref["output"])).any(-1).sum())                        # noqa: E731
+        assert np.array_equal(bits(a), bits(b)) and np.array_equal(bits(aj), bits(bj)), ("pixels off the oracle: without %d, with %d" % (wrong(a), wrong(b)))
+        assert np.array_equal(bits(b), bits(ref["output"])) and np.array_equal(bits(bj), bits(ref["jittered"]))
+        c, cj, _ = _render(gpu_tb, 2, W, H, F, s, calls=3)             # progressive: three calls of three frames
+        assert np.array_equal(bits(c), bits(b)) and np.array_equal(bits(cj), bits(bj))
+    finally:
+        gpu_tb.SetOption("primary_prepass", 1); gpu_tb.SetOption("scene_in_lds", 1)
+
+
+def test_prepass_with_sky_split_stack_tiles_and_depth_limits(gpu_tb, settings):
+    """A camera that sees mostly sky (camera rays that leave the scene), the split traversal stack, a rank's share of a tile split,
+    MaxBounces 1 (the path ends with the hit the pre-pass found) and 0 (nothing is traced: the pre-pass stays off)."""
+    from tracerboy_amd import api
+    s = copy.copy(settings); s.MaxBounces = 5
+    gpu_tb.LoadProcedural(0, 30000, 5)
+    W, H, F = 176, 100, 8
+    cam = gpu_tb.GetCamera(); home = copy.copy(cam)
+    try:
+        up = copy.copy(cam)
+        for k in range(3): up.LookAt[k] = cam.LookAt[k] + 0.6 * cam.Up[k]          # tilt the view up
+        gpu_tb.SetCamera(up)
+        a, aj, _ = _render(gpu_tb, 0, W, H, F, s); b, bj, used = _render(gpu_tb, 2, W, H, F, s)
+        assert used == 1 and np.array_equal(bits(a), bits(b)) and np.array_equal(bits(aj), bits(bj))
+        assert (a[..., :3].sum(-1) > 0).mean() > 0.2
+        gpu_tb.SetCamera(home)
+        gpu_tb.SetOption("stack_lds_cap", 4); gpu_tb.SetOption("stack_overflow_max", 64)
+        a, _, _ = _render(gpu_tb, 0, W, H, F, s); b, _, used = _render(gpu_tb, 2, W, H, F, s)
+        assert used == 1 and np.array_equal(bits(a), bits(b))
+        gpu_tb.SetOption("stack_lds_cap", 0); gpu_tb.SetOption("stack_overflow_max", 16)
+        full, _, _ = _render(gpu_tb, 0, W, H, F, s)
+        gpu_tb.SetTileAssignment(1, 2, 32, 16)
+        a, _, _ = _render(gpu_tb, 0, W, H, F, s); b, _, used = _render(gpu_tb, 2, W, H, F, s)
+        assert used == 1 and np.array_equal(bits(a), bits(b))
+        gpu_tb.SetTileAssignment(0, 1)
+        for depth, want in ((1, 1), (0, 0)):
+            s2 = copy.copy(s); s2.MaxBounces = depth
+            a, _, _ = _render(gpu_tb, 0, W, H, F, s2); b, _, used = _render(gpu_tb, 2, W, H, F, s2)
+            assert used == want and np.array_equal(bits(a), bits(b))
+    finally:
+        gpu_tb.SetTileAssignment(0, 1); gpu_tb.SetCamera(home)
+        gpu_tb.SetOption("stack_lds_cap", 0); gpu_tb.SetOption("stack_overflow_max", 16); gpu_tb.SetOption("primary_prepass", 1)
+
+
+def test_prepass_policy_and_where_it_does_not_apply(gpu_tb, settings):
+    """Default (primary_prepass = 1): calls of 2^24 samples or more.  Never: a scene that lives in LDS, a feature set without a
+    higher-occupancy copy (Teapot: surf), the counting launch, AOVs, a selected pixel, the one-pixel-per-lane kernel."""
+    s = copy.copy(settings); s.MaxBounces = 4
+    gpu_tb.SetOption("primary_prepass", 1)
+    gpu_tb.LoadProcedural(0, 30000, 5)
+    gpu_tb.InvalidateHistory(); gpu_tb.Render(256, 128, 8, s, 0.0); assert gpu_tb.GetOption("last_primary_prepass") == 0
+    gpu_tb.InvalidateHistory(); gpu_tb.Render(2048, 1024, 8, s, 0.0); assert gpu_tb.GetOption("last_primary_prepass") == 1
+    big = gpu_tb.ReadAccumulation()
+    gpu_tb.SetOption("primary_prepass", 0)
+    gpu_tb.InvalidateHistory(); gpu_tb.Render(2048, 1024, 8, s, 0.0); assert gpu_tb.GetOption("last_primary_prepass") == 0
+    assert np.array_equal(bits(big), bits(gpu_tb.ReadAccumulation()))
+    gpu_tb.SetOption("primary_prepass", 2)
+    try:
+        gpu_tb.SetOption("frame_group", -1); gpu_tb.InvalidateHistory(); gpu_tb.Render(96, 64, 8, s, 0.0); assert gpu_tb.GetOption("last_primary_prepass") == 0
+        gpu_tb.SetOption("frame_group", 0)
+        gpu_tb.SetOption("count_rays", 1); gpu_tb.Render(96, 64, 8, s, 0.0); assert gpu_tb.GetOption("last_primary_prepass") == 0; gpu_tb.SetOption("count_rays", 0)
+        gpu_tb.SetOption("aov", 1); gpu_tb.Render(96, 64, 8, s, 0.0); assert gpu_tb.GetOption("last_primary_prepass") == 0; gpu_tb.SetOption("aov", 0)
+        gpu_tb.LoadScene(CORNELL); gpu_tb.InvalidateHistory(); gpu_tb.Render(96, 64, 8, s, 0.0)
+        assert gpu_tb.GetOption("scene_in_lds_active") == 1 and gpu_tb.GetOption("last_primary_prepass") == 0
+        gpu_tb.LoadScene(os.path.join(GOLDEN, "scenes", "Teapot", "scene.pbrt")); gpu_tb.InvalidateHistory(); gpu_tb.Render(96, 64, 8, s, 0.0)
+        assert gpu_tb.GetOption("last_variant") == 2 and gpu_tb.GetOption("last_primary_prepass") == 0
+    finally:
+        gpu_tb.SetOption("primary_prepass", 1); gpu_tb.SetOption("frame_group", 0); gpu_tb.SetOption("count_rays", 0); gpu_tb.SetOption("aov", 0)
+
+
+@pytest.mark.parametrize("cfg", ["c3_870k_128spp", "c4_van_class", "c5_bistro_class"])
+def test_prepass_full_size_configs(gpu_tb, settings, cfg):
+    """BASELINE.json configs[2] at its full 1920x1080x128 and the C4- / C5-class 4K scenes (8 spp): with the pre-pass (the default at
+    these sizes) against without, every bit of the accumulation and jittered surfaces."""
+    s = copy.copy(settings)
+    gpu_tb.SetOption("bvh_builder", 4)
+    try:
+        if cfg == "c3_870k_128spp": gpu_tb.LoadProcedural(0, 870000, 1234); s.MaxBounces = 6; W, H, F = 1920, 1080, 128
+        elif cfg == "c4_van_class": gpu_tb.LoadProcedural(1, 700000, 1234); s.MaxBounces = 6; W, H, F = 3840, 2160, 8
+        else: gpu_tb.LoadProcedural(2, 2980000, 1234); s.MaxBounces = 16; W, H, F = 3840, 2160, 8
+    finally:
+        gpu_tb.SetOption("bvh_builder", 0)
+    try:
+        a, aj, used_a = _render(gpu_tb, 0, W, H, F, s)
+        b, bj, used_b = _render(gpu_tb, 1, W, H, F, s)
+        assert used_a == 0 and used_b == 1
+        assert np.array_equal(bits(a), bits(b)) and np.array_equal(bits(aj), bits(bj))
+    finally:
+        gpu_tb.SetOption("primary_prepass", 1)
+
+
+def test_prepass_hand_off_is_not_stale_on_small_frames(gpu_tb, settings):
+    """The hits travel from pt_primary to the lock-step kernel through the sample slots -- slots the previous launch on the same
+    buffer read AND wrote, in a buffer small enough (3 MB here) to stay resident in the XCDs' L2s between launches.  With plain
+    loads / stores about 3 % of such renders shaded one 16x16 region x frame from stale slots (per-XCD L2s are not coherent with each
+    other).  The hits now have records of their own, written and read at system scope, stamped with the launch's epoch and a check
+    word; a lane that finds anything else walks its camera ray itself.  300 small renders of the glass scenes, each against the oracle."""
+    s = copy.copy(settings); s.MaxBounces = 16
+    W, H, F = 200, 120, 9
+    try:
+        for kind, tris, seed in ((1, 30000, 7), (2, 40000, 9)):
+            gpu_tb.LoadProcedural(kind, tris, seed)
+            refs = [ol.render(gpu_tb.HostSceneView(), gpu_tb.FrameConstants(W, H, 0, s, float(t)), W, H, F, threads=8)["output"] for t in range(3)]
+            bad = 0
+            for rep in range(150):          # three random streams against two alternating buffers: what a buffer held before always differs
+                gpu_tb.SetOption("primary_prepass", 0 if rep % 5 == 4 else 2)
+                gpu_tb.InvalidateHistory(); gpu_tb.Render(W, H, F, s, float(rep % 3))
+                bad += int(not np.array_equal(bits(gpu_tb.ReadAccumulation()), bits(refs[rep % 3])))
+            assert bad == 0, "%d of 150 renders differ from the oracle" % bad
+    finally:
+        gpu_tb.SetOption("primary_prepass", 1)
+
+
+@pytest.mark.parametrize("copies", ["higher_occupancy_copies", "base_copies"])
+def test_no_work_item_is_bound_and_left_unrendered(gpu_tb, settings, copies):
+    """Frame-group launches of a 200 x 120 frame whose sample buffers alternate while the random stream cycles through three seeds, so
+    that a slot nobody wrote shows against the oracle.  This is the regression test of a race the round-2 kernels had: two binders of
+    one workgroup under way at once (a workgroup at the frame's edge draws its second slot's trigger sample while thread 0 is still
+    claiming) could leave slot 1 with "nothing left" and slot 2 with the last item of the launch, which no lane ever reached -- part
+    of a 16x16 region of the final frame group unrendered, once in ~1 000 such renders with the base copies (scripts/lost_item_stress.py).
+    Slots are now numbered in the order the claims succeed; "nothing left" is a state of the workgroup, not an entry."""
+    s = copy.copy(settings); s.MaxBounces = 16
+    W, H, F = 200, 120, 9
+    gpu_tb.SetOption("high_occupancy", 1 if copies == "higher_occupancy_copies" else 0)
+    try:
+        for kind, tris, seed in ((1, 30000, 7), (0, 30000, 5)):
+            gpu_tb.LoadProcedural(kind, tris, seed)
+            refs = [ol.render(gpu_tb.HostSceneView(), gpu_tb.FrameConstants(W, H, 0, s, float(t)), W, H, F, threads=8)["output"] for t in range(3)]
+            bad = 0
+            for rep in range(120):
+                gpu_tb.SetOption("primary_prepass", 2 if rep % 2 else 0)
+                gpu_tb.InvalidateHistory(); gpu_tb.Render(W, H, F, s, float(rep % 3))
+                bad += int(not np.array_equal(bits(gpu_tb.ReadAccumulation()), bits(refs[rep % 3])))
+            assert bad == 0, "%d of 120 renders differ from the oracle" % bad
+    finally:
+        gpu_tb.SetOption("high_occupancy", 1); gpu_tb.SetOption("primary_prepass", 1)

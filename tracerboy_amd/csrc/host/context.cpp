@@ -92,6 +92,9 @@ struct tb_context {
     hipStream_t side[2] = {nullptr, nullptr};
     hipEvent_t evPt[2] = {nullptr, nullptr}, evFold[2] = {nullptr, nullptr}, evMain = nullptr;
     DevBuf fgSamples[2];
+    uint32_t launchEpoch = 0; /* TbDeviceTargets::launchEpoch of the last frame-group launch */
+    DevBuf fgSlotLog[2]; /* frame-group mode: the workgroups' logs of bound slots (TbDeviceTargets::slotLog) */
+    DevBuf fgHits[2];   /* primary-visibility pre-pass: 32-B record of every sample's first hit (TbDeviceTargets::primaryHits) */
     DevBuf stackOverflow; /* split traversal stack of the higher-occupancy kernel copies on deep trees (pt_scene.h) */
     std::vector<const void*> warmedLaunchers; /* frame-group kernels that have run once on both side streams (renderImpl) */
     uint32_t fgLaunch = 0; bool sideOrdered = false; /* sideOrdered: the side streams have been ordered after everything else on `stream` */
@@ -123,6 +126,9 @@ struct tb_context {
     float lastMs = 0.0f;
     std::string lastVariant;
     int lastNodeLayout = 0; /* 1: the last render walked the compact layout-C nodes */
+    int lastSlotLogCap = 0;
+    int lastFgPar = 0;          /* which of the two sample buffers the last frame-group launch wrote (debug query) */
+    int lastPrimaryPrepass = 0; /* 1: the last render took its first hits from the primary-visibility pre-pass */
     /* Multi-device group (tb_create_multi): this context is device 0 of the group and owns the assembled frame; `peers` are the
      * contexts of the other devices.  A render splits the frame into 64x64 tiles dealt round-robin over the devices (DESIGN.md
      * section 7), every device renders its own, the peers' packed tiles come over with hipMemcpyPeerAsync (xGMI) and are un-permuted
@@ -669,6 +675,7 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
      * entry (+ the scene image); where the tree is too deep for that, a frame-group launch may still use the copy with a split
      * stack -- as many entries in LDS as fit, the deepest few (option "stack_overflow_max", default 16) in global memory. */
     pt_variant_fn launch = v->fn;
+    size_t overflowHalf = 0;
     TbDeviceScene dsLaunch = c->ds; dsLaunch.stackOverflow = nullptr; dsLaunch.stackOverflowLanes = 0;
     if (v->fnHi && opt("pipeline", 0) == 0 && !count && opt("high_occupancy", 1) != 0) {
         const size_t share = (160 * 1024 / v->wavesHi) / 512 * 512, fixed = (c->sceneInLds ? c->ds.ldsBlobBytes : 0) + 128;
@@ -682,7 +689,8 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
             if (over > 0 && over <= (uint32_t)opt("stack_overflow_max", 16)) {
                 int numCUs = 0; HIP_TRY(hipDeviceGetAttribute(&numCUs, hipDeviceAttributeMultiprocessorCount, c->device));
                 const uint32_t lanes = 2u * 8u * (uint32_t)numCUs * 256u; /* the resident grid is at most 2 x 8 workgroups per CU */
-                ensure(c->stackOverflow, (size_t)over * lanes * 4);
+                ensure(c->stackOverflow, (size_t)over * lanes * 4 * 2); /* two halves: consecutive batches of a call overlap on the two side streams */
+                overflowHalf = (size_t)over * lanes;
                 dsLaunch.stackDepth = cap; dsLaunch.stackOverflow = (uint32_t*)c->stackOverflow.p; dsLaunch.stackOverflowLanes = lanes;
                 launch = v->fnHi;
             }
@@ -698,6 +706,13 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
     const bool compactNodes = opt("node_layout", 0) == 1 && c->ds.nodesC && v->fnHi && launch == v->fnHi && groups && !c->sceneInLds;
     if (!compactNodes) dsLaunch.nodesC = nullptr;
     c->lastNodeLayout = compactNodes ? 1 : 0;
+    /* Primary-visibility pre-pass (pt_scene.h TbDeviceTargets::primaryHits; option "primary_prepass": 0 never, 1 = default: calls of
+     * 2^24 samples or more -- a second launch and its tail cost a small render ~50 us, measured -4 % at 640 x 360 x 16 -- 2 whenever
+     * the kernels have it): frame-group kernels of the higher-occupancy copies, one-level scenes fetched from memory.  Bit-identical
+     * by construction (same camera ray, same walk); +7 % on the 870 k scene, +5 % / +4 % on the 4K scenes (scripts/prepass_ab.py) */
+    const int64_t prepassOpt = opt("primary_prepass", 1);
+    const bool prepass = prepassOpt != 0 && (prepassOpt == 2 || (uint64_t)W * H * n >= (1ull << 24)) && v->fnHi && launch == v->fnHi && groups && !c->sceneInLds && !twoLevel && !(v->features & PT_FEAT_EXT) && s.MaxBounces > 0;
+    c->lastPrimaryPrepass = prepass ? 1 : 0;
     /* launches of the kernels without the EXT features (no selected pixel, no AOVs: nothing but the sample buffer is written)
      * may overlap the drain of the launch before them */
     const bool overlap = groups && v->features != PT_FEAT_ALL && opt("overlap_launches", 1) != 0;
@@ -734,6 +749,7 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
             while (tg.frameGroup & (tg.frameGroup - 1)) tg.frameGroup &= tg.frameGroup - 1; /* a power of two (rounded down): samples find their frame with shifts */
             while ((frames + tg.frameGroup - 1) / tg.frameGroup > 4095u) tg.frameGroup *= 2;   /* a claimed item is group << 20 | region (claim_work_item) */
             if (regions > 0xfffffu) throw std::runtime_error("frame too large for the frame-group launch (more than 2^20 16x16 regions)");
+            while (tg.frameGroup < frames && regions * ((frames + tg.frameGroup - 1) / tg.frameGroup) > (1ull << 21)) tg.frameGroup *= 2; /* at most 2^21 items a launch: slot logs hold 65 534 slots a workgroup */
             if (overlap && !c->sideOrdered) { /* first overlapped launch after other work on the main stream: order the side streams behind it once */
                 HIP_TRY(hipEventRecord(c->evMain, c->stream));
                 for (int i = 0; i < 2; i++) HIP_TRY(hipStreamWaitEvent(c->side[i], c->evMain, 0));
@@ -759,14 +775,52 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
                     ensure(c->fgSamples[par], pixels * batch * 16);
                     HIP_TRY(hipMemsetAsync(c->fgSamples[par].p, 0, pixels * batch * 16, overlap ? c->side[par] : c->stream));
                 }
+            if (prepass) {
+                /* the hit records: sized and touched once like the sample buffers; and the kernels that take their first hits from them
+                 * keep more registers in scratch than the twin the warm-up above runs (sss: 464 against 416 B per lane), so they are
+                 * run once themselves, with no frames, down both side streams -- a queue whose scratch has to grow under a dispatch
+                 * that follows another kernel closely gave one wrong 16x16 region in the first render of 1 process in ~3 000 */
+                for (uint32_t par = 0; par < 2u; par++)
+                    if (c->fgHits[par].bytes < pixels * batch * 32) {
+                        HIP_TRY(hipStreamSynchronize(c->side[par])); HIP_TRY(hipStreamSynchronize(c->stream));
+                        ensure(c->fgHits[par], pixels * batch * 32);
+                        HIP_TRY(hipMemsetAsync(c->fgHits[par].p, 0, pixels * batch * 32, overlap ? c->side[par] : c->stream));
+                    }
+                const void* key = (const void*)((uintptr_t)launch ^ (1u | (dsLaunch.stackOverflow ? 2u : 0u) | (dsLaunch.nodesC ? 4u : 0u))); /* one kernel per (split stack, node layout) */
+                if (std::find(c->warmedLaunchers.begin(), c->warmedLaunchers.end(), key) == c->warmedLaunchers.end()) {
+                    for (uint32_t par = 0; par < 2u; par++) {
+                        TbDeviceTargets warm = tg; warm.samples = (TbFloat4*)c->fgSamples[par].p; warm.workCounter = (uint32_t*)c->workCounter.p + par * 128u;
+                        int numCUs = 0; HIP_TRY(hipDeviceGetAttribute(&numCUs, hipDeviceAttributeMultiprocessorCount, c->device));
+                        if (c->fgSlotLog[par].bytes < 16ull * numCUs * 16 * 8) ensure(c->fgSlotLog[par], 16ull * numCUs * 16 * 8);
+                        warm.slotLog = (unsigned long long*)c->fgSlotLog[par].p; warm.slotLogCap = 16; warm.launchEpoch = ++c->launchEpoch; warm.primaryHits = (unsigned long long*)c->fgHits[par].p;
+                        TbDeviceScene dsPar = dsLaunch; if (dsPar.stackOverflow) dsPar.stackOverflow += par * overflowHalf;
+                        hipStream_t st = overlap ? c->side[par] : c->stream;
+                        HIP_TRY(launch(st, &dsPar, &pf, &warm, W, H, c->samplesRendered, 0, &c->tiles, 0, 0, 0));
+                        HIP_TRY(hipStreamSynchronize(st));
+                    }
+                    c->warmedLaunchers.push_back(key);
+                }
+            }
             for (uint32_t f0 = 0; f0 < n; f0 += batch) {
                 const uint32_t nf = std::min(batch, n - f0), par = c->fgLaunch++ & 1u;
                 hipStream_t ptStream = overlap ? c->side[par] : c->stream;
                 if (c->fgSamples[par].bytes < pixels * batch * 16) ensure(c->fgSamples[par], pixels * batch * 16); /* grow-only */
-                tg.samples = (TbFloat4*)c->fgSamples[par].p; tg.workCounter = (uint32_t*)c->workCounter.p + par * 128u;
+                tg.samples = (TbFloat4*)c->fgSamples[par].p; tg.workCounter = (uint32_t*)c->workCounter.p + par * 128u; c->lastFgPar = (int)par;
+                {   /* slot logs: 16 workgroups per CU at most (2 x residency of 8); a row has room for 8x a workgroup's fair share of the launch's
+                     * items at the SMALLEST resident grid the launcher may choose (2 per CU), so that the rows of any grid hold the whole list
+                     * several times over and a workgroup whose row is full (it retires) never strands work */
+                    int numCUs = 0; HIP_TRY(hipDeviceGetAttribute(&numCUs, hipDeviceAttributeMultiprocessorCount, c->device));
+                    const uint64_t items = regions * (((uint64_t)nf + tg.frameGroup - 1) / tg.frameGroup), wgs = 16ull * (uint64_t)numCUs, fewest = 2ull * (uint64_t)numCUs;
+                    tg.slotLogCap = (uint32_t)std::min<uint64_t>(65534, 8 * ((items + fewest - 1) / fewest) + 16); /* 16 bits of an entry's tag */
+                    tg.launchEpoch = ++c->launchEpoch; c->lastSlotLogCap = (int)tg.slotLogCap;
+                    if (c->fgSlotLog[par].bytes < wgs * tg.slotLogCap * 8) { HIP_TRY(hipStreamSynchronize(c->side[par])); HIP_TRY(hipStreamSynchronize(c->stream)); ensure(c->fgSlotLog[par], wgs * tg.slotLogCap * 8); }
+                    tg.slotLog = (unsigned long long*)c->fgSlotLog[par].p;
+                }
+                if (prepass) tg.primaryHits = (unsigned long long*)c->fgHits[par].p;
                 if (overlap) HIP_TRY(hipStreamWaitEvent(ptStream, c->evFold[par], 0)); /* the fold that last read this sample buffer */
                 if (f0 == 0) { if (clearStats && overlap) HIP_TRY(hipMemsetAsync(c->stats.p, 0, 16, ptStream)); HIP_TRY(hipEventRecord(c->evKernelStart, ptStream)); }
-                HIP_TRY(launch(ptStream, &dsLaunch, &pf, &tg, W, H, c->samplesRendered + f0, nf, &c->tiles, c->sceneInLds ? 1 : 0, 0, 0));
+                TbDeviceScene dsPar = dsLaunch; if (dsPar.stackOverflow) dsPar.stackOverflow += par * overflowHalf; /* the launch before may still be draining on the other stream */
+                HIP_TRY(launch(ptStream, &dsPar, &pf, &tg, W, H, c->samplesRendered + f0, nf, &c->tiles, c->sceneInLds ? 1 : 0, 0, 0));
                 if (f0 == 0) { HIP_TRY(hipEventRecord(c->evKernel, ptStream)); c->lastKernelFrames = nf; }
                 if (overlap) { HIP_TRY(hipEventRecord(c->evPt[par], ptStream)); HIP_TRY(hipStreamWaitEvent(c->stream, c->evPt[par], 0)); }
                 HIP_TRY(pt_launch_accumulate_samples(c->stream, tg.samples, W, H, c->samplesRendered + f0, nf, &c->tiles, tg.output, tg.jittered));
@@ -853,7 +907,7 @@ void tb_destroy(tb_context* c)
     c->output.release(); c->jittered.release(); c->stats.release(); c->rayStats.release(); c->packed.release();
     for (int q = 0; q < 2; q++) for (DevBuf& b : c->wfCols[q]) b.release();
     for (DevBuf& b : c->wfShadowCols) b.release();
-    c->wfHitA.release(); c->wfHitG.release(); c->wfSamples.release(); c->wfCounts.release(); c->workCounter.release(); c->fgSamples[0].release(); c->fgSamples[1].release(); c->stackOverflow.release();
+    c->wfHitA.release(); c->wfHitG.release(); c->wfSamples.release(); c->wfCounts.release(); c->workCounter.release(); c->fgSamples[0].release(); c->fgSamples[1].release(); c->fgHits[0].release(); c->fgHits[1].release(); c->fgSlotLog[0].release(); c->fgSlotLog[1].release(); c->stackOverflow.release();
     c->postOut.release(); c->postRgba8.release(); c->postHistogram.release(); c->postAverage.release();
     for (int i = 0; i < 2; i++) { c->rtIndirect[i].release(); c->rtMoment[i].release(); c->rtFinal[i].release(); c->rtDenoise[i].release(); }
     c->rtComposited.release();
@@ -1294,7 +1348,7 @@ int tb_unpack_gathered_host(uint32_t W, uint32_t H, uint32_t world, uint32_t tw,
 int tb_set_option(tb_context* c, const char* name, int64_t v)
 {
     if (!c || !name) return TB_E_INVALID;
-    static const char* known[] = {"pipeline", "count_rays", "bvh_builder", "flatten_instances", "aov", "scene_in_lds", "lds_scene_budget", "force_full_variant", "wavefront_paths", "wavefront_grid", "wavefront_segment", "pooled_paths", "pooled_samples", "pooled_profile", "park_min", "alpha_test", "node_order", "node_order_top_levels", "frame_group", "overlap_launches", "high_occupancy", "stack_lds_cap", "stack_overflow_max", "flip_texture_uvs", "wavefront_sort", "banded_items", "node_layout", "wavefront_refill"};
+    static const char* known[] = {"primary_prepass", "pipeline", "count_rays", "bvh_builder", "flatten_instances", "aov", "scene_in_lds", "lds_scene_budget", "force_full_variant", "wavefront_paths", "wavefront_grid", "wavefront_segment", "pooled_paths", "pooled_samples", "pooled_profile", "park_min", "alpha_test", "node_order", "node_order_top_levels", "frame_group", "overlap_launches", "high_occupancy", "stack_lds_cap", "stack_overflow_max", "flip_texture_uvs", "wavefront_sort", "banded_items", "node_layout", "wavefront_refill"};
     for (const char* k : known) if (!strcmp(k, name)) { c->options[name] = v; if (!strcmp(name, "count_rays") || !strcmp(name, "aov")) c->samplesRendered = 0; return TB_OK; }
     return fail(c, TB_E_INVALID, std::string("unknown option '") + name + "'");
 }
@@ -1305,6 +1359,10 @@ int64_t tb_get_option(tb_context* c, const char* name)
     if (!strcmp(name, "scene_features")) return c->sceneFeatures;
     if (!strcmp(name, "last_kernel_us")) return (int64_t)(c->lastKernelMs * 1000.0f + 0.5f); /* first path-tracing launch of the last synchronous render */
     if (!strcmp(name, "last_kernel_frames")) return c->lastKernelFrames;
+    if (!strcmp(name, "last_primary_prepass")) return c->lastPrimaryPrepass;
+    if (!strcmp(name, "debug_slot_log_ptr")) return (int64_t)(uintptr_t)c->fgSlotLog[c->lastFgPar].p;
+    if (!strcmp(name, "debug_slot_log_cap")) return c->lastSlotLogCap;
+    if (!strcmp(name, "debug_fg_samples_ptr")) return (int64_t)(uintptr_t)c->fgSamples[c->lastFgPar].p; /* device address of the sample buffer of the last frame-group launch (scripts/lost_item_stress.py) */
     if (!strcmp(name, "last_node_layout")) return c->lastNodeLayout; /* 0: layout B (64-B nodes), 1: layout C (32-B nodes on the 16-bit grid) */
     if (!strcmp(name, "last_pipeline")) return c->lastPipeline; /* the pipeline the last render actually ran (2 / 3 fall back to 0 for feature sets they lack) */
     if (!strcmp(name, "last_variant")) { for (const Variant& k : kVariants) if (c->lastVariant == k.name) return k.id; return -1; } /* 0 matte 1 env 2 surf 3 vol 4 full 5 sss */

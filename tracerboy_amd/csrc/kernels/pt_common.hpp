@@ -44,7 +44,9 @@ __device__ __forceinline__ bool block_region(const TbTileMap& tiles, uint32_t W,
 __device__ __noinline__ uint32_t claim_work_item(uint32_t* counters, uint32_t regions, uint32_t numGroups, uint32_t banded)
 {
     for (uint32_t t = 0; t < 8; t++) {
-        const uint32_t q = (blockIdx.x + t) & 7u, c = atomicAdd(counters + q * 16u, 1u);
+        /* system scope: list q is counted mostly by the workgroups of XCD q, but a workgroup whose own list is empty takes from the
+         * others', and the per-XCD L2s are not coherent with each other (see bind_slot in pt_persistent.inc for what was measured) */
+        const uint32_t q = (blockIdx.x + t) & 7u, c = __hip_atomic_fetch_add(counters + q * 16u, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if (banded) {
             const uint32_t b0 = (uint32_t)(((unsigned long long)regions * q) >> 3), n = (uint32_t)(((unsigned long long)regions * (q + 1u)) >> 3) - b0;
             if (n && c < n * numGroups) { const uint32_t group = c / n; return group << 20 | (b0 + (c - group * n)); }

@@ -726,6 +726,7 @@ enum : uint32_t {
     ST_SSS = 3,       /* pending ray is a step of the interior random walk */
     ST_SCATTER = 4,   /* no pending ray: path_scatter() must run next */
     ST_WAIT = 5,      /* frame-group mode: the lane holds a sample number whose work item is not published yet */
+    ST_PRIMARY = 6,   /* frame-group mode with the primary-visibility pre-pass: a path just begun, its closest hit waits in the sample's slot */
 };
 enum : uint32_t {
     F_SPECULAR = 1u << 0, F_PERFECT = 1u << 1, F_PREV_PERFECT = 1u << 2, F_EXITING = 1u << 3, F_NOSCATTER = 1u << 4,

@@ -74,7 +74,16 @@ struct TbDeviceTargets {
      * accumulate_samples_kernel then sums them in frame order, which keeps the fp32 accumulation of RayGenCommon.h:704-727
      * bit for bit while no lane waits for its neighbours' longer paths. */
     TbFloat4* samples; uint32_t frameGroup; uint32_t* workCounter;
+    unsigned long long* slotLog; uint32_t slotLogCap; /* frame-group mode: slotLogCap entries per workgroup of the launch (at most 16 per CU), zeroed by the launcher; every slot a workgroup binds is recorded here (pt_persistent.inc) */
     uint32_t bandedItems;  /* claim_work_item (pt_common.hpp): every XCD's list covers a contiguous eighth of the regions instead of every eighth region */
+    /* Primary-visibility pre-pass (frame-group mode, nullable).  The camera ray of a sample depends on (x, y, frame) alone, and the
+     * rays of an 8x8 pixel tile at one frame walk almost the same nodes, whereas inside the lock-step kernel a lane's primary ray is
+     * walked together with its neighbours' incoherent bounce rays.  With primaryHits set, pt_primary (pt_persistent.inc) has walked
+     * every camera ray of the launch, one tile per wave, and left the closest hit in record i = (frame - firstFrame) * W * H + pixel --
+     * four 8-byte words: (t or -1, u), (v, primitive), (hit-group index, launchEpoch), the XOR of the three -- where the lane that draws the sample picks it
+     * up instead of walking.  Same camera ray, same walk, same hit, same bits; one lock-step trip less per path. */
+    unsigned long long* primaryHits;
+    uint32_t launchEpoch; /* frame-group mode: a number no other launch on these buffers has had (host counter); stamps the slot-log entries (low byte) and the hit records */
 };
 
 struct TbTileMap { /* multi-GPU tile ownership: tile t is rendered iff t % world == rank; tileW, tileH multiples of 16 */
