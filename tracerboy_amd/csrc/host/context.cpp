@@ -92,6 +92,7 @@ struct tb_context {
     hipStream_t side[2] = {nullptr, nullptr};
     hipEvent_t evPt[2] = {nullptr, nullptr}, evFold[2] = {nullptr, nullptr}, evMain = nullptr;
     DevBuf fgSamples[2];
+    int numCUs = 0;           /* of `device` (deviceCUs) */
     uint32_t launchEpoch = 0; /* TbDeviceTargets::launchEpoch of the last frame-group launch */
     DevBuf fgSlotLog[2]; /* frame-group mode: the workgroups' logs of bound slots (TbDeviceTargets::slotLog) */
     DevBuf fgHits[2];   /* primary-visibility pre-pass: 32-B record of every sample's first hit (TbDeviceTargets::primaryHits) */
@@ -626,6 +627,13 @@ void renderPooled(tb_context* c, int variant, uint32_t W, uint32_t H, uint32_t f
     }
 }
 
+/* compute units of the context's device, asked once */
+int deviceCUs(tb_context* c)
+{
+    if (!c->numCUs && hipDeviceGetAttribute(&c->numCUs, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess) throw std::runtime_error("hipDeviceGetAttribute(multiprocessor count) failed");
+    return c->numCUs;
+}
+
 int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_output_settings* settings, float timeSeed, bool sync)
 {
     if (!c->hasScene) return fail(c, TB_E_NO_SCENE, "tb_render: no scene loaded");
@@ -687,7 +695,7 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
             if (forcedCap > 0) cap = std::min<uint32_t>(cap, (uint32_t)forcedCap);
             const uint32_t over = c->ds.stackDepth > cap ? c->ds.stackDepth - cap : 0;
             if (over > 0 && over <= (uint32_t)opt("stack_overflow_max", 16)) {
-                int numCUs = 0; HIP_TRY(hipDeviceGetAttribute(&numCUs, hipDeviceAttributeMultiprocessorCount, c->device));
+                const int numCUs = deviceCUs(c);
                 const uint32_t lanes = 2u * 8u * (uint32_t)numCUs * 256u; /* the resident grid is at most 2 x 8 workgroups per CU */
                 ensure(c->stackOverflow, (size_t)over * lanes * 4 * 2); /* two halves: consecutive batches of a call overlap on the two side streams */
                 overflowHalf = (size_t)over * lanes;
@@ -790,7 +798,7 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
                 if (std::find(c->warmedLaunchers.begin(), c->warmedLaunchers.end(), key) == c->warmedLaunchers.end()) {
                     for (uint32_t par = 0; par < 2u; par++) {
                         TbDeviceTargets warm = tg; warm.samples = (TbFloat4*)c->fgSamples[par].p; warm.workCounter = (uint32_t*)c->workCounter.p + par * 128u;
-                        int numCUs = 0; HIP_TRY(hipDeviceGetAttribute(&numCUs, hipDeviceAttributeMultiprocessorCount, c->device));
+                        const int numCUs = deviceCUs(c);
                         if (c->fgSlotLog[par].bytes < 16ull * numCUs * 16 * 8) ensure(c->fgSlotLog[par], 16ull * numCUs * 16 * 8);
                         warm.slotLog = (unsigned long long*)c->fgSlotLog[par].p; warm.slotLogCap = 16; warm.launchEpoch = ++c->launchEpoch; warm.primaryHits = (unsigned long long*)c->fgHits[par].p;
                         TbDeviceScene dsPar = dsLaunch; if (dsPar.stackOverflow) dsPar.stackOverflow += par * overflowHalf;
@@ -809,7 +817,7 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
                 {   /* slot logs: 16 workgroups per CU at most (2 x residency of 8); a row has room for 8x a workgroup's fair share of the launch's
                      * items at the SMALLEST resident grid the launcher may choose (2 per CU), so that the rows of any grid hold the whole list
                      * several times over and a workgroup whose row is full (it retires) never strands work */
-                    int numCUs = 0; HIP_TRY(hipDeviceGetAttribute(&numCUs, hipDeviceAttributeMultiprocessorCount, c->device));
+                    const int numCUs = deviceCUs(c);
                     const uint64_t items = regions * (((uint64_t)nf + tg.frameGroup - 1) / tg.frameGroup), wgs = 16ull * (uint64_t)numCUs, fewest = 2ull * (uint64_t)numCUs;
                     tg.slotLogCap = (uint32_t)std::min<uint64_t>(65534, 8 * ((items + fewest - 1) / fewest) + 16); /* 16 bits of an entry's tag */
                     tg.launchEpoch = ++c->launchEpoch; c->lastSlotLogCap = (int)tg.slotLogCap;
