@@ -45,7 +45,9 @@ __device__ __noinline__ uint32_t claim_work_item(uint32_t* counters, uint32_t re
 {
     for (uint32_t t = 0; t < 8; t++) {
         /* system scope: list q is counted mostly by the workgroups of XCD q, but a workgroup whose own list is empty takes from the
-         * others', and the per-XCD L2s are not coherent with each other (see bind_slot in pt_persistent.inc for what was measured) */
+         * others'.  (Agent-scope counters were suspected when work items went missing and were not the cause -- the ray counters of
+         * the counting launches are agent-scope adds from every XCD and equal the oracle's; the cause was the order in which slots
+         * were bound, pt_persistent.inc bind_next.  The wider scope stays: a claim is made once per thousand samples.) */
         const uint32_t q = (blockIdx.x + t) & 7u, c = __hip_atomic_fetch_add(counters + q * 16u, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if (banded) {
             const uint32_t b0 = (uint32_t)(((unsigned long long)regions * q) >> 3), n = (uint32_t)(((unsigned long long)regions * (q + 1u)) >> 3) - b0;
