@@ -156,7 +156,7 @@ def test_prepass_hand_off_is_not_stale_on_small_frames(gpu_tb, settings):
         gpu_tb.SetOption("primary_prepass", 1)
 
 
-@pytest.mark.parametrize("copies", ["higher_occupancy_copies", "base_copies"])
+@pytest.mark.parametrize("copies", ["higher_occupancy_copies", "base_copies", "overlapping_batches_split_stack"])
 def test_no_work_item_is_bound_and_left_unrendered(gpu_tb, settings, copies):
     """Frame-group launches of a 200 x 120 frame whose sample buffers alternate while the random stream cycles through three seeds, so
     that a slot nobody wrote shows against the oracle.  This is the regression test of a race the round-2 kernels had: two binders of
@@ -166,7 +166,9 @@ def test_no_work_item_is_bound_and_left_unrendered(gpu_tb, settings, copies):
     Slots are now numbered in the order the claims succeed; "nothing left" is a state of the workgroup, not an entry."""
     s = copy.copy(settings); s.MaxBounces = 16
     W, H, F = 200, 120, 9
-    gpu_tb.SetOption("high_occupancy", 1 if copies == "higher_occupancy_copies" else 0)
+    gpu_tb.SetOption("high_occupancy", 0 if copies == "base_copies" else 1)
+    if copies == "overlapping_batches_split_stack":   # three launches a render, alternating between the two side streams; deep stack entries in global memory
+        gpu_tb.SetOption("pooled_samples", W * H * 3); gpu_tb.SetOption("stack_lds_cap", 6); gpu_tb.SetOption("stack_overflow_max", 64)
     try:
         for kind, tris, seed in ((1, 30000, 7), (0, 30000, 5)):
             gpu_tb.LoadProcedural(kind, tris, seed)
@@ -179,3 +181,4 @@ def test_no_work_item_is_bound_and_left_unrendered(gpu_tb, settings, copies):
             assert bad == 0, "%d of 120 renders differ from the oracle" % bad
     finally:
         gpu_tb.SetOption("high_occupancy", 1); gpu_tb.SetOption("primary_prepass", 1)
+        gpu_tb.SetOption("pooled_samples", 256 << 20); gpu_tb.SetOption("stack_lds_cap", 0); gpu_tb.SetOption("stack_overflow_max", 16)
