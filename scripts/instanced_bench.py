@@ -60,8 +60,15 @@ for flat in (1, 0):
     for _ in range(3):
         tb.InvalidateHistory(); t = time.perf_counter(); tb.Render(a.width, a.height, a.spp, s, 0.0); ms.append((time.perf_counter() - t) * 1e3)
     variant = ["matte", "env", "surf", "vol", "full", "sss"][tb.GetOption("last_variant")]
+    pre = {}
+    for opt in (0, 2):           # the primary-visibility pre-pass, never / whenever the kernels have it (flattened scenes only)
+        tb.SetOption("primary_prepass", opt); t2 = []
+        for _ in range(3):
+            tb.InvalidateHistory(); t = time.perf_counter(); tb.Render(a.width, a.height, a.spp, s, 0.0); t2.append((time.perf_counter() - t) * 1e3)
+        pre["off" if opt == 0 else "forced"] = {"Msamples_per_s": round(a.width * a.height * a.spp / min(t2) / 1e3, 1), "used": bool(tb.GetOption("last_primary_prepass"))}
+    tb.SetOption("primary_prepass", 1)
     tb.SetOption("count_rays", 1); tb.Render(a.width, a.height, 1, s, 0.0); st = tb.ReadbackStats().rays; tb.SetOption("count_rays", 0)
-    res["flattened" if flat else "two_level"] = {"Msamples_per_s": round(a.width * a.height * a.spp / min(ms) / 1e3, 1), "ms": round(min(ms), 3), "kernel_variant": variant,
+    res["flattened" if flat else "two_level"] = {"Msamples_per_s": round(a.width * a.height * a.spp / min(ms) / 1e3, 1), "ms": round(min(ms), 3), "primary_prepass": pre, "kernel_variant": variant,
                                                  "boxes_per_sample": round(st.boxesTested / st.samples, 2), "tris_per_sample": round(st.trianglesTested / st.samples, 2), "rays_per_sample": round(st.rays / st.samples, 3),
                                                  "triangles_in_bvh": int(info.numTriangles), "bvh_bytes_layout_a": int(info.bvhBytesA), "bvh_depth": int(info.bvhMaxDepth), "load_s": round(load, 2)}
 tb.SetOption("flatten_instances", 1)

@@ -88,7 +88,7 @@ def test_prepass_with_sky_split_stack_tiles_and_depth_limits(gpu_tb, settings):
 
 
 def test_prepass_policy_and_where_it_does_not_apply(gpu_tb, settings):
-    """Default (primary_prepass = 1): calls of 2^24 samples or more.  Never: a scene that lives in LDS, a feature set without a
+    """Default (primary_prepass = 1): calls of 2^24 samples or more of a feature set without interior walks.  Never: a scene that lives in LDS, a feature set without a
     higher-occupancy copy (Teapot: surf), the counting launch, AOVs, a selected pixel, the one-pixel-per-lane kernel."""
     s = copy.copy(settings); s.MaxBounces = 4
     gpu_tb.SetOption("primary_prepass", 1)
@@ -99,6 +99,10 @@ def test_prepass_policy_and_where_it_does_not_apply(gpu_tb, settings):
     gpu_tb.SetOption("primary_prepass", 0)
     gpu_tb.InvalidateHistory(); gpu_tb.Render(2048, 1024, 8, s, 0.0); assert gpu_tb.GetOption("last_primary_prepass") == 0
     assert np.array_equal(bits(big), bits(gpu_tb.ReadAccumulation()))
+    gpu_tb.SetOption("primary_prepass", 1)
+    gpu_tb.LoadProcedural(1, 30000, 7)                                   # glass: interior walks -- only when asked for
+    gpu_tb.InvalidateHistory(); gpu_tb.Render(2048, 1024, 8, s, 0.0); assert gpu_tb.GetOption("last_variant") == 5 and gpu_tb.GetOption("last_primary_prepass") == 0
+    gpu_tb.LoadProcedural(0, 30000, 5)
     gpu_tb.SetOption("primary_prepass", 2)
     try:
         gpu_tb.SetOption("frame_group", -1); gpu_tb.InvalidateHistory(); gpu_tb.Render(96, 64, 8, s, 0.0); assert gpu_tb.GetOption("last_primary_prepass") == 0
@@ -116,7 +120,7 @@ def test_prepass_policy_and_where_it_does_not_apply(gpu_tb, settings):
 @pytest.mark.parametrize("cfg", ["c3_870k_128spp", "c4_van_class", "c5_bistro_class"])
 def test_prepass_full_size_configs(gpu_tb, settings, cfg):
     """BASELINE.json configs[2] at its full 1920x1080x128 and the C4- / C5-class 4K scenes (8 spp): with the pre-pass (the default at
-    these sizes) against without, every bit of the accumulation and jittered surfaces."""
+    this size for configs[2]; asked for on the glass scenes) against without, every bit of the accumulation and jittered surfaces."""
     s = copy.copy(settings)
     gpu_tb.SetOption("bvh_builder", 4)
     try:
@@ -127,8 +131,10 @@ def test_prepass_full_size_configs(gpu_tb, settings, cfg):
         gpu_tb.SetOption("bvh_builder", 0)
     try:
         a, aj, used_a = _render(gpu_tb, 0, W, H, F, s)
-        b, bj, used_b = _render(gpu_tb, 1, W, H, F, s)
-        assert used_a == 0 and used_b == 1
+        b, bj, used_b = _render(gpu_tb, 1, W, H, F, s)          # by itself: the feature sets without interior walks
+        assert used_a == 0 and used_b == (1 if cfg == "c3_870k_128spp" else 0)
+        if not used_b: b, bj, used_b = _render(gpu_tb, 2, W, H, F, s)
+        assert used_b == 1
         assert np.array_equal(bits(a), bits(b)) and np.array_equal(bits(aj), bits(bj))
     finally:
         gpu_tb.SetOption("primary_prepass", 1)

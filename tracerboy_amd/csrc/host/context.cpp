@@ -718,8 +718,13 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
      * 2^24 samples or more -- a second launch and its tail cost a small render ~50 us, measured -4 % at 640 x 360 x 16 -- 2 whenever
      * the kernels have it): frame-group kernels of the higher-occupancy copies, one-level scenes fetched from memory.  Bit-identical
      * by construction (same camera ray, same walk); +7 % on the 870 k scene, +5 % / +4 % on the 4K scenes (scripts/prepass_ab.py) */
+    /* ... and by itself only where camera rays are a large part of all rays: no interior walks and no lights to send a feeler to from
+     * every hit (an environment-lit scene: configs[2], +8.8 %).  Where paths are long the camera ray was riding along under the longer
+     * rays anyway and the pre-pass is all cost: 516 k triangles of glass blobs under an area light lose 5.6 % with it, the same scene
+     * in matte 1.2 %, while the van- and bistro-class scenes gain 3-4 % (scripts/instanced_bench.py, scripts/prepass_ab.py) -- not
+     * told apart before rendering, so those ask for it (option = 2) */
     const int64_t prepassOpt = opt("primary_prepass", 1);
-    const bool prepass = prepassOpt != 0 && (prepassOpt == 2 || (uint64_t)W * H * n >= (1ull << 24)) && v->fnHi && launch == v->fnHi && groups && !c->sceneInLds && !twoLevel && !(v->features & PT_FEAT_EXT) && s.MaxBounces > 0;
+    const bool prepass = prepassOpt != 0 && (prepassOpt == 2 || ((uint64_t)W * H * n >= (1ull << 24) && !(v->features & PT_FEAT_SSS) && c->scene.lights.empty())) && v->fnHi && launch == v->fnHi && groups && !c->sceneInLds && !twoLevel && !(v->features & PT_FEAT_EXT) && s.MaxBounces > 0;
     c->lastPrimaryPrepass = prepass ? 1 : 0;
     /* launches of the kernels without the EXT features (no selected pixel, no AOVs: nothing but the sample buffer is written)
      * may overlap the drain of the launch before them */
