@@ -60,6 +60,56 @@ __device__ __noinline__ uint32_t claim_work_item(uint32_t* counters, uint32_t re
     return 0xffffffffu;
 }
 
+/* Frame-group bookkeeping of pt_persistent (the comments there say what and why): the RARE parts, out of line like claim_work_item and fed
+ * with values rather than with the kernel's argument structs.  Inlined, this code -- run once per few thousand samples -- kept its
+ * pointers, the log's capacity and the epoch alive through the path loop and cost every frame-group kernel 16-48 B of scratch per lane
+ * and 3 % of its speed.  (Moving the per-path part out of line as well -- the ring lookup of every drawn sample -- was measured too: its
+ * LDS reads become flat loads through the texture addresser and the 870 k scene lost 2.7 %.)
+ * groupConst: regions, log2(frames per group), frame groups per region, "a claim has found nothing", tag base ((launch epoch & 0xff) << 16);
+ * bindState: binders under way, slots bound so far; both and the 8-entry ring live in the workgroup's LDS. */
+__device__ __noinline__ void fg_bind_next(uint32_t* groupConst, uint32_t* bindState, unsigned long long* slotTable, uint32_t* workCounter, unsigned long long* logRow,
+                                          uint32_t logCap, uint32_t banded, TbTileMap tiles, uint32_t W, uint32_t H)
+{
+    atomicAdd(&bindState[0], 1u);
+    if (!((volatile uint32_t*)groupConst)[3]) {
+        const uint32_t regions = ((volatile uint32_t*)groupConst)[0], lg = ((volatile uint32_t*)groupConst)[1], numGroups = ((volatile uint32_t*)groupConst)[2];
+        uint32_t item = 0xffffffffu;
+        /* room in the log for every binder under way (the host sizes a row for 8x the workgroup's fair share; a full row retires the workgroup) */
+        if (((volatile uint32_t*)bindState)[1] + ((volatile uint32_t*)bindState)[0] <= logCap) item = claim_work_item(workCounter, regions, numGroups, banded);
+        if (item == 0xffffffffu) ((volatile uint32_t*)groupConst)[3] = 1u;
+        else {
+            const uint32_t slot = atomicAdd(&bindState[1], 1u), group = item >> 20, region = item & 0xfffffu;
+            uint32_t rx, ry;
+            block_region(tiles, W, H, region, rx, ry);
+            const unsigned long long e = (unsigned long long)(((volatile uint32_t*)groupConst)[4] | ((slot + 1u) & 0xffffu)) << 40 | ((unsigned long long)(group << lg) << 24) | (unsigned long long)(ry << 12) | rx;
+            ((volatile unsigned long long*)slotTable)[slot & 7u] = e;
+            __hip_atomic_store(logRow + slot, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    __threadfence_block();
+    atomicSub(&bindState[0], 1u);
+}
+
+/* a slot whose ring entry is not (or no longer) its own: the slot's entry, or 0 = ask again later, 1 = nothing left for this workgroup
+ * (an entry has its tag in the top bits: never 0 or 1; by value -- an out-parameter would put the caller's copy on the stack) */
+__device__ __noinline__ unsigned long long fg_resolve_slow(uint32_t s, uint32_t tag, const uint32_t* groupConst, const uint32_t* bindState, const unsigned long long* logRow)
+{
+    if (s < ((volatile const uint32_t*)bindState)[1]) {
+        /* bound, but the ring has gone round since (or the binder is between taking the number and writing the entry): the log knows.
+         * System scope, both sides: an agent-scope load is served by the XCD's L2, which may still hold the row as an earlier launch
+         * left it (the launcher's memset went through another XCD's L2) */
+        const unsigned long long v = __hip_atomic_load(logRow + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return (uint32_t)(v >> 40) != tag ? 0ull : v;
+    }
+    /* not bound: for good once a claim has failed, no binder is under way and the count still says so -- read in this order (a binder
+     * announces itself before it looks at the flag) */
+    if (!((volatile const uint32_t*)groupConst)[3]) return 0ull;
+    __threadfence_block();
+    if (((volatile const uint32_t*)bindState)[0] != 0) return 0ull;
+    __threadfence_block();
+    return s < ((volatile const uint32_t*)bindState)[1] ? 0ull : 1ull;
+}
+
 __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v)
 {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
