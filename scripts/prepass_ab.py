@@ -28,7 +28,7 @@ def main():
         imgs = {}
         for layout in (0, 1):
             for pre in (0, 1):
-                tb.SetOption("node_layout", layout); tb.SetOption("primary_prepass", pre)
+                tb.SetOption("node_layout", layout); tb.SetOption("primary_prepass", 2 * pre)   # never / asked for (1 would be the try-and-keep default)
                 ts = []
                 for r in range(a.reps + 1):
                     tb.InvalidateHistory(); t = time.perf_counter(); tb.Render(W, H, F, s, 0.0); ts.append(time.perf_counter() - t)

@@ -88,7 +88,8 @@ def test_prepass_with_sky_split_stack_tiles_and_depth_limits(gpu_tb, settings):
 
 
 def test_prepass_policy_and_where_it_does_not_apply(gpu_tb, settings):
-    """Default (primary_prepass = 1): calls of 2^24 samples or more of a feature set without interior walks.  Never: a scene that lives in LDS, a feature set without a
+    """Default (primary_prepass = 1): calls of 2^24 samples or more -- at once where camera rays are a large part of all rays (no interior
+    walks, no lights), by trial elsewhere (the first calls of a kind run without / with / without, the faster way is kept).  Never: a scene that lives in LDS, a feature set without a
     higher-occupancy copy (Teapot: surf), the counting launch, AOVs, a selected pixel, the one-pixel-per-lane kernel."""
     s = copy.copy(settings); s.MaxBounces = 4
     gpu_tb.SetOption("primary_prepass", 1)
@@ -100,8 +101,15 @@ def test_prepass_policy_and_where_it_does_not_apply(gpu_tb, settings):
     gpu_tb.InvalidateHistory(); gpu_tb.Render(2048, 1024, 8, s, 0.0); assert gpu_tb.GetOption("last_primary_prepass") == 0
     assert np.array_equal(bits(big), bits(gpu_tb.ReadAccumulation()))
     gpu_tb.SetOption("primary_prepass", 1)
-    gpu_tb.LoadProcedural(1, 30000, 7)                                   # glass: interior walks -- only when asked for
-    gpu_tb.InvalidateHistory(); gpu_tb.Render(2048, 1024, 8, s, 0.0); assert gpu_tb.GetOption("last_variant") == 5 and gpu_tb.GetOption("last_primary_prepass") == 0
+    gpu_tb.LoadProcedural(1, 30000, 7)                                   # glass: interior walks -- tried: without, with, without, then whichever was faster
+    used, pictures = [], []
+    for call in range(5):
+        gpu_tb.InvalidateHistory(); gpu_tb.Render(2048, 1024, 8, s, 0.0)
+        assert gpu_tb.GetOption("last_variant") == 5
+        used.append(gpu_tb.GetOption("last_primary_prepass")); pictures.append(gpu_tb.ReadAccumulation())
+    assert used[:3] == [0, 1, 0] and used[3] == used[4]
+    assert all(np.array_equal(bits(pictures[0]), bits(q)) for q in pictures[1:])
+    gpu_tb.InvalidateHistory(); gpu_tb.Render(2048, 1024, 9, s, 0.0); assert gpu_tb.GetOption("last_primary_prepass") == 0   # another kind of call: tried afresh
     gpu_tb.LoadProcedural(0, 30000, 5)
     gpu_tb.SetOption("primary_prepass", 2)
     try:
@@ -131,9 +139,7 @@ def test_prepass_full_size_configs(gpu_tb, settings, cfg):
         gpu_tb.SetOption("bvh_builder", 0)
     try:
         a, aj, used_a = _render(gpu_tb, 0, W, H, F, s)
-        b, bj, used_b = _render(gpu_tb, 1, W, H, F, s)          # by itself: the feature sets without interior walks
-        assert used_a == 0 and used_b == (1 if cfg == "c3_870k_128spp" else 0)
-        if not used_b: b, bj, used_b = _render(gpu_tb, 2, W, H, F, s)
+        b, bj, used_b = _render(gpu_tb, 1 if cfg == "c3_870k_128spp" else 2, W, H, F, s)   # by itself on configs[2]; the glass scenes would try it over their first calls
         assert used_b == 1
         assert np.array_equal(bits(a), bits(b)) and np.array_equal(bits(aj), bits(bj))
     finally:

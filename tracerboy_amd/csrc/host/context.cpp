@@ -128,6 +128,8 @@ struct tb_context {
     std::string lastVariant;
     int lastNodeLayout = 0; /* 1: the last render walked the compact layout-C nodes */
     int lastSlotLogCap = 0;
+    struct PrepassTrial { uint64_t key = 0; int calls = 0, pending = 0; float msWith = 0, msWithout = 0; bool keep = false; } prepassTrial; /* renderImpl */
+    uint32_t sceneGeneration = 0; /* counts finalizeScene calls */
     int lastFgPar = 0;          /* which of the two sample buffers the last frame-group launch wrote (debug query) */
     int lastPrimaryPrepass = 0; /* 1: the last render took its first hits from the primary-visibility pre-pass */
     /* Multi-device group (tb_create_multi): this context is device 0 of the group and owns the assembled frame; `peers` are the
@@ -393,6 +395,7 @@ void BuildTlasGpu(tb_context* c, HostScene& s, const std::vector<float>& blasBox
 void finalizeScene(tb_context* c, bool build = true) /* build = false: c->scene already holds a built, reordered tree (a peer of a multi-device group) */
 {
     HostScene& s = c->scene;
+    c->sceneGeneration++;
     auto opt = [&](const char* k, int64_t d) { auto it = c->options.find(k); return it == c->options.end() ? d : it->second; };
     const int64_t builder = opt("bvh_builder", 0);
     const bool twoLevel = !s.instances.empty();
@@ -718,13 +721,36 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
      * 2^24 samples or more -- a second launch and its tail cost a small render ~50 us, measured -4 % at 640 x 360 x 16 -- 2 whenever
      * the kernels have it): frame-group kernels of the higher-occupancy copies, one-level scenes fetched from memory.  Bit-identical
      * by construction (same camera ray, same walk); +7 % on the 870 k scene, +5 % / +4 % on the 4K scenes (scripts/prepass_ab.py) */
-    /* ... and by itself only where camera rays are a large part of all rays: no interior walks and no lights to send a feeler to from
-     * every hit (an environment-lit scene: configs[2], +8.8 %).  Where paths are long the camera ray was riding along under the longer
-     * rays anyway and the pre-pass is all cost: 516 k triangles of glass blobs under an area light lose 5.6 % with it, the same scene
-     * in matte 1.2 %, while the van- and bistro-class scenes gain 3-4 % (scripts/instanced_bench.py, scripts/prepass_ab.py) -- not
-     * told apart before rendering, so those ask for it (option = 2) */
+    /* ... and by itself (option = 1, the default) where it is known or FOUND to pay.  Known: camera rays are a large part of all rays --
+     * no interior walks and no lights to send a feeler to from every hit (an environment-lit scene: configs[2], +8.8 %).  Elsewhere
+     * paths are long, the camera ray was riding along under the longer rays anyway and the pre-pass may be all cost: 516 k triangles of
+     * glass blobs under an area light lose 5.6 % with it, the same scene in matte 1.2 %, while the van- and bistro-class scenes gain
+     * 3-4 % (scripts/instanced_bench.py, scripts/prepass_ab.py) -- not told apart before rendering, so such a scene is TRIED: of the
+     * first calls of one kind (same scene, frame, frames per call, depth) the first runs without (it also pays for buffers and scratch),
+     * the second with, the third without again; their first launches are timed with the events the context records anyway and the
+     * faster way is kept from the fourth call on (the pictures are the same bits either way). */
     const int64_t prepassOpt = opt("primary_prepass", 1);
-    const bool prepass = prepassOpt != 0 && (prepassOpt == 2 || ((uint64_t)W * H * n >= (1ull << 24) && !(v->features & PT_FEAT_SSS) && c->scene.lights.empty())) && v->fnHi && launch == v->fnHi && groups && !c->sceneInLds && !twoLevel && !(v->features & PT_FEAT_EXT) && s.MaxBounces > 0;
+    const bool prepassKernels = v->fnHi && launch == v->fnHi && groups && !c->sceneInLds && !twoLevel && !(v->features & PT_FEAT_EXT) && s.MaxBounces > 0;
+    bool prepass = prepassKernels && prepassOpt == 2;
+    if (prepassKernels && prepassOpt == 1 && (uint64_t)W * H * n >= (1ull << 24)) {
+        if (!(v->features & PT_FEAT_SSS) && c->scene.lights.empty()) prepass = true;
+        else {
+            tb_context::PrepassTrial& t = c->prepassTrial;
+            const uint64_t key = ((uint64_t)W << 48) ^ ((uint64_t)H << 32) ^ ((uint64_t)n << 12) ^ ((uint64_t)s.MaxBounces << 4) ^ ((uint64_t)c->sceneGeneration << 24) ^ (uint64_t)(uintptr_t)launch;
+            if (t.key != key) { t = tb_context::PrepassTrial(); t.key = key; }
+            if (t.pending) { /* the first launch of the call before this one: finished long ago unless the caller renders asynchronously */
+                float ms = 0; HIP_TRY(hipEventSynchronize(c->evKernel));
+                if (hipEventElapsedTime(&ms, c->evKernelStart, c->evKernel) == hipSuccess) { if (t.pending == 1) t.msWith = ms; else t.msWithout = ms; }
+                if (t.pending == 2) t.keep = t.msWith > 0 && t.msWithout > 0 && t.msWith < 0.99f * t.msWithout;
+                t.pending = 0;
+            }
+            if (t.calls == 0) prepass = false;
+            else if (t.calls == 1) { prepass = true; t.pending = 1; }
+            else if (t.calls == 2) { prepass = false; t.pending = 2; }
+            else prepass = t.keep;
+            if (t.calls < 3) t.calls++;
+        }
+    }
     c->lastPrimaryPrepass = prepass ? 1 : 0;
     /* launches of the kernels without the EXT features (no selected pixel, no AOVs: nothing but the sample buffer is written)
      * may overlap the drain of the launch before them */
