@@ -31,13 +31,14 @@ def _render(tb, pre, W, H, F, s, calls=1):
     return out, jit, used
 
 
-@pytest.mark.parametrize("scene", ["proc0_env", "proc1_sss", "proc2_sss_depth16", "cornell_from_memory"])
+@pytest.mark.parametrize("scene", ["proc0_env", "proc1_sss", "proc2_sss_depth16", "cornell_from_memory", "teapot_surf"])
 def test_prepass_is_bit_identical(gpu_tb, settings, scene):
     s = copy.copy(settings)
     try:
         if scene == "proc0_env": gpu_tb.LoadProcedural(0, 30000, 5); s.MaxBounces = 6; want_variant = 1
         elif scene == "proc1_sss": gpu_tb.LoadProcedural(1, 30000, 7); s.MaxBounces = 6; want_variant = 5
         elif scene == "proc2_sss_depth16": gpu_tb.LoadProcedural(2, 40000, 9); s.MaxBounces = 16; want_variant = 5
+        elif scene == "teapot_surf": gpu_tb.LoadScene(os.path.join(GOLDEN, "scenes", "Teapot", "scene.pbrt")); s.MaxBounces = 6; want_variant = 2   # textures, GGX, environment map
         else: gpu_tb.SetOption("scene_in_lds", 0); gpu_tb.LoadScene(CORNELL); s.MaxBounces = 8; want_variant = 0
         W, H, F = 200, 120, 9                                            # not multiples of 16; 9 frames: groups of 8 + 1
         a, aj, used_a = _render(gpu_tb, 0, W, H, F, s)
@@ -89,8 +90,7 @@ def test_prepass_with_sky_split_stack_tiles_and_depth_limits(gpu_tb, settings):
 
 def test_prepass_policy_and_where_it_does_not_apply(gpu_tb, settings):
     """Default (primary_prepass = 1): calls of 2^24 samples or more -- at once where camera rays are a large part of all rays (no interior
-    walks, no lights), by trial elsewhere (the first calls of a kind run without / with / without, the faster way is kept).  Never: a scene that lives in LDS, a feature set without a
-    higher-occupancy copy (Teapot: surf), the counting launch, AOVs, a selected pixel, the one-pixel-per-lane kernel."""
+    walks, no lights), by trial elsewhere (the first calls of a kind run without / with / without, the faster way is kept).  Never: a scene that lives in LDS, the full feature set, the counting launch, AOVs, a selected pixel, the one-pixel-per-lane kernel."""
     s = copy.copy(settings); s.MaxBounces = 4
     gpu_tb.SetOption("primary_prepass", 1)
     gpu_tb.LoadProcedural(0, 30000, 5)
@@ -120,9 +120,12 @@ def test_prepass_policy_and_where_it_does_not_apply(gpu_tb, settings):
         gpu_tb.LoadScene(CORNELL); gpu_tb.InvalidateHistory(); gpu_tb.Render(96, 64, 8, s, 0.0)
         assert gpu_tb.GetOption("scene_in_lds_active") == 1 and gpu_tb.GetOption("last_primary_prepass") == 0
         gpu_tb.LoadScene(os.path.join(GOLDEN, "scenes", "Teapot", "scene.pbrt")); gpu_tb.InvalidateHistory(); gpu_tb.Render(96, 64, 8, s, 0.0)
-        assert gpu_tb.GetOption("last_variant") == 2 and gpu_tb.GetOption("last_primary_prepass") == 0
+        assert gpu_tb.GetOption("last_variant") == 2 and gpu_tb.GetOption("last_primary_prepass") == 1     # surf: compiled into its only copy
+        gpu_tb.SetOption("force_full_variant", 1); gpu_tb.InvalidateHistory(); gpu_tb.Render(96, 64, 8, s, 0.0)
+        assert gpu_tb.GetOption("last_variant") == 4 and gpu_tb.GetOption("last_primary_prepass") == 0     # the full feature set has none
+        gpu_tb.SetOption("force_full_variant", 0)
     finally:
-        gpu_tb.SetOption("primary_prepass", 1); gpu_tb.SetOption("frame_group", 0); gpu_tb.SetOption("count_rays", 0); gpu_tb.SetOption("aov", 0)
+        gpu_tb.SetOption("primary_prepass", 1); gpu_tb.SetOption("frame_group", 0); gpu_tb.SetOption("count_rays", 0); gpu_tb.SetOption("aov", 0); gpu_tb.SetOption("force_full_variant", 0)
 
 
 @pytest.mark.parametrize("cfg", ["c3_870k_128spp", "c4_van_class", "c5_bistro_class"])

@@ -730,7 +730,7 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
      * the second with, the third without again; their first launches are timed with the events the context records anyway and the
      * faster way is kept from the fourth call on (the pictures are the same bits either way). */
     const int64_t prepassOpt = opt("primary_prepass", 1);
-    const bool prepassKernels = v->fnHi && launch == v->fnHi && groups && !c->sceneInLds && !twoLevel && !(v->features & PT_FEAT_EXT) && s.MaxBounces > 0;
+    const bool prepassKernels = ((v->fnHi && launch == v->fnHi) || (!v->fnHi && v->id == 2 /* surf: compiled into its only copy */ && launch == v->fn && !dsLaunch.stackOverflow)) && groups && !c->sceneInLds && !twoLevel && !(v->features & PT_FEAT_EXT) && s.MaxBounces > 0;
     bool prepass = prepassKernels && prepassOpt == 2;
     if (prepassKernels && prepassOpt == 1 && (uint64_t)W * H * n >= (1ull << 24)) {
         if (!(v->features & PT_FEAT_SSS) && c->scene.lights.empty()) prepass = true;
