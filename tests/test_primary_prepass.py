@@ -31,13 +31,14 @@ def _render(tb, pre, W, H, F, s, calls=1):
     return out, jit, used
 
 
-@pytest.mark.parametrize("scene", ["proc0_env", "proc1_sss", "proc2_sss_depth16", "cornell_from_memory", "teapot_surf"])
+@pytest.mark.parametrize("scene", ["proc0_env", "proc1_sss", "proc2_sss_depth16", "cornell_from_memory", "teapot_surf", "mix_glass_vol"])
 def test_prepass_is_bit_identical(gpu_tb, settings, scene):
     s = copy.copy(settings)
     try:
         if scene == "proc0_env": gpu_tb.LoadProcedural(0, 30000, 5); s.MaxBounces = 6; want_variant = 1
         elif scene == "proc1_sss": gpu_tb.LoadProcedural(1, 30000, 7); s.MaxBounces = 6; want_variant = 5
         elif scene == "proc2_sss_depth16": gpu_tb.LoadProcedural(2, 40000, 9); s.MaxBounces = 16; want_variant = 5
+        elif scene == "mix_glass_vol": gpu_tb.SetOption("scene_in_lds", 0); gpu_tb.LoadScene(os.path.join(GOLDEN, "scenes", "mix-glass", "scene.pbrt")); s.MaxBounces = 6; want_variant = 3   # mix materials: the feeler is judged before the scatter
         elif scene == "teapot_surf": gpu_tb.LoadScene(os.path.join(GOLDEN, "scenes", "Teapot", "scene.pbrt")); s.MaxBounces = 6; want_variant = 2   # textures, GGX, environment map
         else: gpu_tb.SetOption("scene_in_lds", 0); gpu_tb.LoadScene(CORNELL); s.MaxBounces = 8; want_variant = 0
         W, H, F = 200, 120, 9                                            # not multiples of 16; 9 frames: groups of 8 + 1
