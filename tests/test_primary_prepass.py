@@ -71,6 +71,11 @@ def test_prepass_with_sky_split_stack_tiles_and_depth_limits(gpu_tb, settings):
         assert used == 1 and np.array_equal(bits(a), bits(b)) and np.array_equal(bits(aj), bits(bj))
         assert (a[..., :3].sum(-1) > 0).mean() > 0.2
         gpu_tb.SetCamera(home)
+        sb = copy.copy(s); sb.EnableBlueNoise = 1                      # the reference's default sampler: two blue-noise texels + Halton instead of rand() for the film jitter
+        a, aj, _ = _render(gpu_tb, 0, W, H, F, sb); b, bj, used = _render(gpu_tb, 2, W, H, F, sb)
+        assert used == 1 and np.array_equal(bits(a), bits(b)) and np.array_equal(bits(aj), bits(bj))
+        ref = ol.render(gpu_tb.HostSceneView(), gpu_tb.FrameConstants(W, H, 0, sb, 0.0), W, H, F, threads=8)["output"]
+        assert np.array_equal(bits(b), bits(ref))
         gpu_tb.SetOption("stack_lds_cap", 4); gpu_tb.SetOption("stack_overflow_max", 64)
         a, _, _ = _render(gpu_tb, 0, W, H, F, s); b, _, used = _render(gpu_tb, 2, W, H, F, s)
         assert used == 1 and np.array_equal(bits(a), bits(b))
