@@ -785,7 +785,11 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
              * was measured on launches of 16 frames; at 128 it chose 32): 870 k scene 1080p x 128, synchronous renders, G = 2 / 4 / 8 / 16 /
              * 32: 4 440 / 4 513 / 4 495 / 4 401 / 4 167 Msamples/s with the pre-pass, 4 354 / 4 356 / 4 270 / 4 118 / 3 876 without;
              * x 32 frames 3 966 / 4 003 / 3 768 / 3 479 / 2 846; van-class 4K x 8: 1 615 / 1 656 / 1 668 (scripts/fg_sweep.py) */
-            const uint32_t autoG = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(frames, c->sceneInLds ? 64 : 4), std::max<uint64_t>(1, ((uint64_t)frames * regions + 24575) / 24576));
+            /* the feature sets with interior walks keep up to 16 (their trips are long, a lane parked at a slot's end loses more): van- /
+             * bistro-class 4K x 32 with the pre-pass, G = 2 / 4 / 8 / 16: 1 646 / 1 692 / 1 721 / 1 727 and 1 323 / 1 363 / 1 407 / 1 430
+             * (scripts/fg_sweep_4k.py) */
+            const uint64_t capG = c->sceneInLds ? 64 : ((v->features & PT_FEAT_SSS) ? 16 : 4);
+            const uint32_t autoG = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(frames, capG), std::max<uint64_t>(1, ((uint64_t)frames * regions + 24575) / 24576));
             ensure(c->workCounter, 1024);
             tg.bandedItems = (uint32_t)opt("banded_items", 0);
             tg.frameGroup = fg > 0 ? (uint32_t)fg : autoG;
