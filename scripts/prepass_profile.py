@@ -9,7 +9,7 @@ proc, W, H, F, depth = {"c3": ((0, 870000, 1234), 1920, 1080, 32, 6), "c4": ((1,
 tb = api.TracerBoy()
 s = api.GetDefaultOutputSettings(); s.EnableBlueNoise = 0; s.MaxBounces = depth
 tb.SetOption("bvh_builder", 4); tb.LoadProcedural(*proc)
-tb.SetOption("primary_prepass", pre)
+tb.SetOption("primary_prepass", 2 if pre else 0)
 if len(sys.argv) > 3: tb.SetOption("stack_lds_cap", int(sys.argv[3])); tb.SetOption("stack_overflow_max", 64)
 for r in range(4):
     tb.InvalidateHistory(); tb.Render(W, H, F, s, 0.0)
