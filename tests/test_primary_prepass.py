@@ -94,9 +94,10 @@ def test_prepass_with_sky_split_stack_tiles_and_depth_limits(gpu_tb, settings):
         gpu_tb.SetOption("stack_lds_cap", 0); gpu_tb.SetOption("stack_overflow_max", 16); gpu_tb.SetOption("primary_prepass", 1)
 
 
-def test_prepass_policy_and_where_it_does_not_apply(gpu_tb, settings):
+def test_prepass_policy_and_where_it_does_not_apply(gpu_tb, settings, tmp_path):
     """Default (primary_prepass = 1): calls of 2^24 samples or more -- at once where camera rays are a large part of all rays (no interior
-    walks, no lights), by trial elsewhere (the first calls of a kind run without / with / without, the faster way is kept).  Never: a scene that lives in LDS, the full feature set, the counting launch, AOVs, a selected pixel, the one-pixel-per-lane kernel."""
+    walks, no lights; or glass on fewer than half of the triangles), by trial elsewhere (the first calls of a kind run without / with /
+    without, the faster way is kept).  Never: a scene that lives in LDS, the full feature set, the counting launch, AOVs, a selected pixel, the one-pixel-per-lane kernel."""
     s = copy.copy(settings); s.MaxBounces = 4
     gpu_tb.SetOption("primary_prepass", 1)
     gpu_tb.LoadProcedural(0, 30000, 5)
@@ -107,7 +108,19 @@ def test_prepass_policy_and_where_it_does_not_apply(gpu_tb, settings):
     gpu_tb.InvalidateHistory(); gpu_tb.Render(2048, 1024, 8, s, 0.0); assert gpu_tb.GetOption("last_primary_prepass") == 0
     assert np.array_equal(bits(big), bits(gpu_tb.ReadAccumulation()))
     gpu_tb.SetOption("primary_prepass", 1)
-    gpu_tb.LoadProcedural(1, 30000, 7)                                   # glass: interior walks -- tried: without, with, without, then whichever was faster
+    gpu_tb.LoadProcedural(1, 30000, 7)                                   # glass among other things (a fifth of the triangles): at once
+    gpu_tb.InvalidateHistory(); gpu_tb.Render(2048, 1024, 8, s, 0.0); assert gpu_tb.GetOption("last_variant") == 5 and gpu_tb.GetOption("last_primary_prepass") == 1
+    # a glass ball over a matte floor under an area light (all but four of ~1 000 triangles are glass): tried -- without, with, without, then whichever was faster
+    nu, nv = 32, 16
+    P = [(0.8 * np.sin(np.pi * j / nv) * np.cos(2 * np.pi * i / nu), 1.0 + 0.8 * np.cos(np.pi * j / nv), 0.8 * np.sin(np.pi * j / nv) * np.sin(2 * np.pi * i / nu)) for j in range(nv + 1) for i in range(nu)]
+    I = [k for j in range(nv) for i in range(nu) for k in (j * nu + i, (j + 1) * nu + i, (j + 1) * nu + (i + 1) % nu, j * nu + i, (j + 1) * nu + (i + 1) % nu, j * nu + (i + 1) % nu)]
+    text = ('LookAt 0 1.2 4  0 1 0  0 1 0\nCamera "perspective" "float fov" [40]\nWorldBegin\n'
+            'MakeNamedMaterial "Floor" "string type" ["matte"] "rgb Kd" [0.6 0.6 0.6]\nMakeNamedMaterial "Glass" "string type" ["glass"] "float index" [1.5]\n'
+            'AttributeBegin\n  AreaLightSource "diffuse" "rgb L" [12 12 12]\n  Shape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-1 3.5 -1  1 3.5 -1  1 3.5 1  -1 3.5 1]\nAttributeEnd\n'
+            'NamedMaterial "Floor"\nShape "trianglemesh" "integer indices" [0 1 2 0 2 3] "point P" [-6 0 6  6 0 6  6 0 -6  -6 0 -6]\n'
+            'NamedMaterial "Glass"\nShape "trianglemesh" "integer indices" [%s] "point P" [%s]\nWorldEnd\n' % (" ".join(map(str, I)), " ".join("%.6f %.6f %.6f" % p for p in P)))
+    path = tmp_path / "glass.pbrt"; path.write_text(text)
+    gpu_tb.SetOption("scene_in_lds", 0); gpu_tb.LoadScene(str(path)); gpu_tb.SetOption("scene_in_lds", 1)
     used, pictures = [], []
     for call in range(5):
         gpu_tb.InvalidateHistory(); gpu_tb.Render(2048, 1024, 8, s, 0.0)

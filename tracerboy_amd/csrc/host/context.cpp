@@ -130,6 +130,7 @@ struct tb_context {
     int lastSlotLogCap = 0;
     struct PrepassTrial { uint64_t key = 0; int calls = 0, pending = 0; float msWith = 0, msWithout = 0; bool keep = false; } prepassTrial; /* renderImpl */
     uint32_t sceneGeneration = 0; /* counts finalizeScene calls */
+    float interiorWalkTriangleShare = 0; /* finalizeScene */
     int lastFgPar = 0;          /* which of the two sample buffers the last frame-group launch wrote (debug query) */
     int lastPrimaryPrepass = 0; /* 1: the last render took its first hits from the primary-visibility pre-pass */
     /* Multi-device group (tb_create_multi): this context is device 0 of the group and owns the assembled frame; `peers` are the
@@ -396,6 +397,12 @@ void finalizeScene(tb_context* c, bool build = true) /* build = false: c->scene 
 {
     HostScene& s = c->scene;
     c->sceneGeneration++;
+    {   /* share of the triangles whose material sends a path on an interior walk (the pre-pass policy in renderImpl) */
+        uint64_t walks = 0;
+        if (s.instances.empty())
+            for (uint32_t g : s.triGeometry) { if (g < s.hitGroups.size()) { const uint32_t m = s.hitGroups[g].MaterialIndex; if (m < s.materials.size() && (s.materials[m].Flags & TB_MAT_SUBSURFACE_SCATTER)) walks++; } }
+        c->interiorWalkTriangleShare = s.triGeometry.empty() ? 0.0f : (float)((double)walks / (double)s.triGeometry.size());
+    }
     auto opt = [&](const char* k, int64_t d) { auto it = c->options.find(k); return it == c->options.end() ? d : it->second; };
     const int64_t builder = opt("bvh_builder", 0);
     const bool twoLevel = !s.instances.empty();
@@ -722,7 +729,8 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
      * the kernels have it): frame-group kernels of the higher-occupancy copies, one-level scenes fetched from memory.  Bit-identical
      * by construction (same camera ray, same walk); +7 % on the 870 k scene, +5 % / +4 % on the 4K scenes (scripts/prepass_ab.py) */
     /* ... and by itself (option = 1, the default) where it is known or FOUND to pay.  Known: camera rays are a large part of all rays --
-     * no interior walks and no lights to send a feeler to from every hit (an environment-lit scene: configs[2], +8.8 %).  Elsewhere
+     * no interior walks and no lights to send a feeler to from every hit (an environment-lit scene: configs[2], +8.8 %) -- or the feature
+     * set with interior walks runs a scene in which few triangles are glass (measured below).  Elsewhere
      * paths are long, the camera ray was riding along under the longer rays anyway and the pre-pass may be all cost: 516 k triangles of
      * glass blobs under an area light lose 5.6 % with it, the same scene in matte 1.2 %, while the van- and bistro-class scenes gain
      * 3-4 % (scripts/instanced_bench.py, scripts/prepass_ab.py) -- not told apart before rendering, so such a scene is TRIED: of the
@@ -734,6 +742,7 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
     bool prepass = prepassKernels && prepassOpt == 2;
     if (prepassKernels && prepassOpt == 1 && (uint64_t)W * H * n >= (1ull << 24)) {
         if (!(v->features & PT_FEAT_SSS) && c->scene.lights.empty()) prepass = true;
+        else if ((v->features & PT_FEAT_SSS) && c->interiorWalkTriangleShare < 0.5f) prepass = true; /* glass among other things (van- / bistro-class: 20 % / 10 % of the triangles, +9 % / +8 %): most camera rays start ordinary paths.  A scene that is mostly glass (the blobs: every triangle but two, -5 %) is tried like the rest */
         else {
             tb_context::PrepassTrial& t = c->prepassTrial;
             const uint64_t key = ((uint64_t)W << 48) ^ ((uint64_t)H << 32) ^ ((uint64_t)n << 12) ^ ((uint64_t)s.MaxBounces << 4) ^ ((uint64_t)c->sceneGeneration << 24) ^ (uint64_t)(uintptr_t)launch;
