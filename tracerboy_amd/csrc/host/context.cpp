@@ -798,7 +798,10 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
              * bistro-class 4K x 32 with the pre-pass, G = 2 / 4 / 8 / 16: 1 646 / 1 692 / 1 721 / 1 727 and 1 323 / 1 363 / 1 407 / 1 430
              * (scripts/fg_sweep_4k.py) */
             const uint64_t capG = c->sceneInLds ? 64 : ((v->features & PT_FEAT_SSS) ? 16 : 4);
-            const uint32_t autoG = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(frames, capG), std::max<uint64_t>(1, ((uint64_t)frames * regions + 24575) / 24576));
+            /* a scene in LDS: half as many items (cornell-box x 64 frames, launches back to back, G = 8 / 16 / 32 / 64: 6 940 / 7 091 / 7 145 /
+             * 7 117 Msamples/s, scripts/fg_sweep_c2.py; the 24 576 rule gave 16) */
+            const uint64_t itemsWanted = c->sceneInLds ? 12288 : 24576;
+            const uint32_t autoG = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(frames, capG), std::max<uint64_t>(1, ((uint64_t)frames * regions + itemsWanted - 1) / itemsWanted));
             ensure(c->workCounter, 1024);
             tg.bandedItems = (uint32_t)opt("banded_items", 0);
             tg.frameGroup = fg > 0 ? (uint32_t)fg : autoG;
