@@ -32,7 +32,8 @@ DEVICE = ["--offload-arch=" + ARCH, "-fno-slp-vectorize", "-mllvm", "-amdgpu-sch
 HOST_SRCS = ["host/pbrt_loader.cpp", "host/pbf_loader.cpp", "host/host_scene.cpp", "host/images.cpp", "host/image_decode.cpp", "host/image_formats.cpp", "host/bvh_build.cpp", "host/procedural.cpp", "host/context.cpp", "host/pbrt_dump.cpp"]
 KERNEL_SRCS = ["kernels/pt_kernels.hip", "kernels/post_kernels.hip", "kernels/bvh_kernels.hip", "kernels/rt_kernels.hip", "kernels/pt_variant_matte.hip", "kernels/pt_variant_matte5.hip", "kernels/pt_variant_env.hip", "kernels/pt_variant_env5.hip", "kernels/pt_variant_surf.hip",
                "kernels/pt_variant_sss.hip", "kernels/pt_variant_sss4.hip",
-               "kernels/pt_variant_vol.hip", "kernels/pt_variant_vol4.hip", "kernels/pt_variant_full.hip"]
+               "kernels/pt_variant_vol.hip", "kernels/pt_variant_vol4.hip", "kernels/pt_variant_full.hip",
+               "kernels/pt_split_matte.hip", "kernels/pt_split_env.hip", "kernels/pt_split_surf.hip", "kernels/pt_split_sss.hip"]
 
 
 def _deps_digest():

@@ -33,6 +33,13 @@ hipError_t pt_launch_persistent_sss4(hipStream_t, const TbDeviceScene*, const Tb
 hipError_t pt_launch_persistent_vol4(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, uint32_t, uint32_t, uint32_t, uint32_t, const TbTileMap*, int, int, int);
 hipError_t pt_launch_persistent_vol(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, uint32_t, uint32_t, uint32_t, uint32_t, const TbTileMap*, int, int, int);
 hipError_t pt_launch_persistent_full(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, uint32_t, uint32_t, uint32_t, uint32_t, const TbTileMap*, int, int, int);
+/* pipeline 4, the split-role kernel (pt_split.inc): shading waves + traversal waves over an LDS ray queue */
+typedef hipError_t (*pt_split_fn)(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, const TbSplitParams*, uint32_t, uint32_t, uint32_t, uint32_t,
+                                  const TbTileMap*, int, int*);
+hipError_t pt_launch_split_matte(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, const TbSplitParams*, uint32_t, uint32_t, uint32_t, uint32_t, const TbTileMap*, int, int*);
+hipError_t pt_launch_split_env(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, const TbSplitParams*, uint32_t, uint32_t, uint32_t, uint32_t, const TbTileMap*, int, int*);
+hipError_t pt_launch_split_surf(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, const TbSplitParams*, uint32_t, uint32_t, uint32_t, uint32_t, const TbTileMap*, int, int*);
+hipError_t pt_launch_split_sss(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, const TbSplitParams*, uint32_t, uint32_t, uint32_t, uint32_t, const TbTileMap*, int, int*);
 }
 
 #include "../kernels/wf_types.h"
@@ -65,14 +72,14 @@ std::string g_createError;
 #ifndef TB_VOL_WAVES
 #define TB_VOL_WAVES 5
 #endif
-struct Variant { uint32_t features; pt_variant_fn fn; const char* name; pt_variant_fn fnHi; uint32_t wavesHi; int id; wf_variant_fn wf; bool pooled; };
+struct Variant { uint32_t features; pt_variant_fn fn; const char* name; pt_variant_fn fnHi; uint32_t wavesHi; int id; wf_variant_fn wf; bool pooled; pt_split_fn split; };
 const Variant kVariants[] = {
-    {0u, pt_launch_persistent_matte, "matte", pt_launch_persistent_matte5, TB_MATTE_WAVES, 0, wf_launch_matte, true},
-        {PT_FEAT_ENV, pt_launch_persistent_env, "env", pt_launch_persistent_env5, TB_ENV_WAVES, 1, wf_launch_env, true},
-    {PT_FEAT_ENV | PT_FEAT_SPECULAR | PT_FEAT_TEXTURES, pt_launch_persistent_surf, "surf", nullptr, 0, 2, wf_launch_surf, true},
-        {PT_FEAT_ENV | PT_FEAT_SPECULAR | PT_FEAT_TEXTURES | PT_FEAT_SSS, pt_launch_persistent_sss, "sss", pt_launch_persistent_sss4, TB_SSS_WAVES, 5, wf_launch_sss, false},
-    {PT_FEAT_ENV | PT_FEAT_SPECULAR | PT_FEAT_TEXTURES | PT_FEAT_SSS | PT_FEAT_MIX, pt_launch_persistent_vol, "vol", pt_launch_persistent_vol4, TB_VOL_WAVES, 3, wf_launch_vol, false},
-        {PT_FEAT_ALL, pt_launch_persistent_full, "full", nullptr, 0, 4, nullptr, false},
+    {0u, pt_launch_persistent_matte, "matte", pt_launch_persistent_matte5, TB_MATTE_WAVES, 0, wf_launch_matte, true, pt_launch_split_matte},
+        {PT_FEAT_ENV, pt_launch_persistent_env, "env", pt_launch_persistent_env5, TB_ENV_WAVES, 1, wf_launch_env, true, pt_launch_split_env},
+    {PT_FEAT_ENV | PT_FEAT_SPECULAR | PT_FEAT_TEXTURES, pt_launch_persistent_surf, "surf", nullptr, 0, 2, wf_launch_surf, true, pt_launch_split_surf},
+        {PT_FEAT_ENV | PT_FEAT_SPECULAR | PT_FEAT_TEXTURES | PT_FEAT_SSS, pt_launch_persistent_sss, "sss", pt_launch_persistent_sss4, TB_SSS_WAVES, 5, wf_launch_sss, false, pt_launch_split_sss},
+    {PT_FEAT_ENV | PT_FEAT_SPECULAR | PT_FEAT_TEXTURES | PT_FEAT_SSS | PT_FEAT_MIX, pt_launch_persistent_vol, "vol", pt_launch_persistent_vol4, TB_VOL_WAVES, 3, wf_launch_vol, false, nullptr},
+        {PT_FEAT_ALL, pt_launch_persistent_full, "full", nullptr, 0, 4, nullptr, false, nullptr},
 };
 constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 
@@ -131,6 +138,7 @@ struct tb_context {
     struct PrepassTrial { uint64_t key = 0; int calls = 0, pending = 0; float msWith = 0, msWithout = 0; bool keep = false; } prepassTrial; /* renderImpl */
     uint32_t sceneGeneration = 0; /* counts finalizeScene calls */
     float interiorWalkTriangleShare = 0; /* finalizeScene */
+    uint32_t* splitAbort = nullptr; int lastSplitWaves = 0; /* pipeline 4: host-mapped abort word of the split-role kernel (renderSplit); travWaves * 100 + shadeWaves of the last launch */
     int lastFgPar = 0;          /* which of the two sample buffers the last frame-group launch wrote (debug query) */
     int lastPrimaryPrepass = 0; /* 1: the last render took its first hits from the primary-visibility pre-pass */
     /* Multi-device group (tb_create_multi): this context is device 0 of the group and owns the assembled frame; `peers` are the
@@ -644,6 +652,89 @@ int deviceCUs(tb_context* c)
     return c->numCUs;
 }
 
+/* Split-role pipeline (option "pipeline" = 4, pt_split.inc): workgroups of traversal waves + shading waves over an LDS ray queue.
+ * The host side is frame-group mode's: batches of frames into one of two ordered sample buffers, launches alternating between the two
+ * side streams so that a launch starts while the one before drains, accumulate_samples_kernel folding each batch in frame order on
+ * the main stream.  Options: split_trav / split_shade (waves of either role per workgroup), split_ready, split_refill, split_wi /
+ * split_wl (TbSplitParams), split_frame_group (frames of a wave's work item), split_stack_cap (stack entries kept in LDS; the rest
+ * of a deeper tree's stack lives in global memory, pt_scene.h). */
+void renderSplit(tb_context* c, const Variant* v, uint32_t W, uint32_t H, uint32_t n, const TbPerFrameConstants& pf, TbDeviceTargets tg)
+{
+    auto opt = [&](const char* k, int64_t d) { auto it = c->options.find(k); return it == c->options.end() ? d : it->second; };
+    const uint64_t pixels = (uint64_t)W * H, budget = (uint64_t)opt("pooled_samples", 256ll << 20);
+    uint32_t batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(n, 32768), budget / pixels));
+    batch = (n + (n + batch - 1) / batch - 1) / ((n + batch - 1) / batch); /* equal batches */
+    const int numCUs = deviceCUs(c);
+    const bool lds = c->sceneInLds;
+    TbSplitParams sp; memset(&sp, 0, sizeof sp);
+    sp.travWaves = (uint32_t)std::max<int64_t>(1, opt("split_trav", 4)); sp.shadeWaves = (uint32_t)opt("split_shade", 0);
+    if (!sp.shadeWaves) sp.shadeWaves = lds ? 4 : 6; /* 0 = the default for the kind of scene */
+    sp.readyMin = (uint32_t)opt("split_ready", 32); sp.refillMin = (uint32_t)std::max<int64_t>(1, opt("split_refill", 16));
+    sp.innerWeight = (uint32_t)std::max<int64_t>(1, opt("split_wi", 85)); sp.leafWeight = (uint32_t)std::max<int64_t>(1, opt("split_wl", 160));
+    sp.ringCap = 256; while (sp.ringCap < 256u * sp.shadeWaves) sp.ringCap *= 2;
+    sp.spinLimit = (uint32_t)opt("split_spin_limit", 1 << 21);
+    if (!c->splitAbort) { HIP_TRY(hipHostMalloc((void**)&c->splitAbort, 64, hipHostMallocMapped)); *c->splitAbort = 0; }
+    HIP_TRY(hipHostGetDevicePointer((void**)&sp.abortFlag, c->splitAbort, 0));
+    TbDeviceScene dsL = c->ds; dsL.nodesC = nullptr; dsL.stackOverflow = nullptr; dsL.stackOverflowLanes = 0;
+    const pt_split_fn fn = v->split;
+    size_t overflowHalf = 0;
+    const int64_t cap = opt("split_stack_cap", 0);
+    if (cap > 0 && (uint32_t)cap < c->ds.stackDepth && !lds) {
+        dsL.stackDepth = (uint32_t)cap;
+        TbDeviceTargets probe = tg; probe.samples = (TbFloat4*)16; probe.workCounter = (uint32_t*)16; probe.frameGroup = 1;
+        TbDeviceScene dsProbe = dsL; dsProbe.stackOverflow = (uint32_t*)16; dsProbe.stackOverflowLanes = 0xffffffffu; /* which kernel: the split-stack one */
+        int perCU = 0;
+        HIP_TRY(fn(c->stream, &dsProbe, &pf, &probe, &sp, W, H, 0, 1, &c->tiles, 0, &perCU));
+        const uint32_t over = c->ds.stackDepth - (uint32_t)cap, lanes = (uint32_t)std::max(perCU, 1) * (uint32_t)numCUs * sp.travWaves * 64u;
+        ensure(c->stackOverflow, (size_t)over * lanes * 4 * 2); /* two halves: consecutive launches overlap on the two side streams */
+        overflowHalf = (size_t)over * lanes;
+        dsL.stackOverflow = (uint32_t*)c->stackOverflow.p; dsL.stackOverflowLanes = lanes;
+    }
+    const int64_t fgOpt = opt("split_frame_group", 8);
+    tg.frameGroup = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(fgOpt, std::min(batch, n)));
+    while ((std::min(batch, n) + tg.frameGroup - 1) / tg.frameGroup > 4095u) tg.frameGroup *= 2; /* a claimed item is group << 20 | tile */
+    tg.bandedItems = (uint32_t)opt("banded_items", 0);
+    ensure(c->workCounter, 1024);
+    const bool overlap = opt("overlap_launches", 1) != 0;
+    if (!overlap) c->sideOrdered = false;
+    if (overlap && !c->sideOrdered) {
+        HIP_TRY(hipEventRecord(c->evMain, c->stream));
+        for (int i = 0; i < 2; i++) HIP_TRY(hipStreamWaitEvent(c->side[i], c->evMain, 0));
+        c->sideOrdered = true;
+    }
+    for (uint32_t par = 0; par < 2u; par++)
+        if (c->fgSamples[par].bytes < pixels * batch * 16) {
+            HIP_TRY(hipStreamSynchronize(c->side[par])); HIP_TRY(hipStreamSynchronize(c->stream));
+            ensure(c->fgSamples[par], pixels * batch * 16);
+            HIP_TRY(hipMemsetAsync(c->fgSamples[par].p, 0, pixels * batch * 16, overlap ? c->side[par] : c->stream));
+        }
+    /* the first render with a kernel: a zero-frame launch down both side streams, so that whatever the runtime sets up at a queue's first
+     * dispatch of it (scratch) falls into this call (renderImpl's frame-group path does the same) */
+    const void* key = (const void*)((uintptr_t)fn ^ (dsL.stackOverflow ? 2u : 0u) ^ (lds ? 4u : 0u));
+    if (overlap && std::find(c->warmedLaunchers.begin(), c->warmedLaunchers.end(), key) == c->warmedLaunchers.end()) {
+        for (uint32_t par = 0; par < 2u; par++) {
+            TbDeviceTargets warm = tg; warm.samples = (TbFloat4*)c->fgSamples[par].p; warm.workCounter = (uint32_t*)c->workCounter.p + par * 128u;
+            TbDeviceScene dsPar = dsL; if (dsPar.stackOverflow) dsPar.stackOverflow += par * overflowHalf;
+            HIP_TRY(fn(c->side[par], &dsPar, &pf, &warm, &sp, W, H, c->samplesRendered, 0, &c->tiles, lds ? 1 : 0, nullptr));
+        }
+        c->warmedLaunchers.push_back(key);
+    }
+    for (uint32_t f0 = 0; f0 < n; f0 += batch) {
+        const uint32_t nf = std::min(batch, n - f0), par = c->fgLaunch++ & 1u;
+        hipStream_t ptStream = overlap ? c->side[par] : c->stream;
+        tg.samples = (TbFloat4*)c->fgSamples[par].p; tg.workCounter = (uint32_t*)c->workCounter.p + par * 128u; c->lastFgPar = (int)par;
+        if (overlap) HIP_TRY(hipStreamWaitEvent(ptStream, c->evFold[par], 0)); /* the fold that last read this sample buffer */
+        if (f0 == 0) HIP_TRY(hipEventRecord(c->evKernelStart, ptStream)); /* (the stats words were cleared on the main stream, which the side streams have just been ordered behind) */
+        TbDeviceScene dsPar = dsL; if (dsPar.stackOverflow) dsPar.stackOverflow += par * overflowHalf;
+        HIP_TRY(fn(ptStream, &dsPar, &pf, &tg, &sp, W, H, c->samplesRendered + f0, nf, &c->tiles, lds ? 1 : 0, nullptr));
+        if (f0 == 0) { HIP_TRY(hipEventRecord(c->evKernel, ptStream)); c->lastKernelFrames = nf; }
+        if (overlap) { HIP_TRY(hipEventRecord(c->evPt[par], ptStream)); HIP_TRY(hipStreamWaitEvent(c->stream, c->evPt[par], 0)); }
+        HIP_TRY(pt_launch_accumulate_samples(c->stream, tg.samples, W, H, c->samplesRendered + f0, nf, &c->tiles, tg.output, tg.jittered));
+        if (overlap) HIP_TRY(hipEventRecord(c->evFold[par], c->stream));
+    }
+    c->lastSplitWaves = (int)(sp.travWaves * 100 + sp.shadeWaves);
+}
+
 int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_output_settings* settings, float timeSeed, bool sync)
 {
     if (!c->hasScene) return fail(c, TB_E_NO_SCENE, "tb_render: no scene loaded");
@@ -662,6 +753,7 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
     if (n == 0) return TB_OK;
     auto opt = [&](const char* k, int64_t d) { auto it = c->options.find(k); return it == c->options.end() ? d : it->second; };
     const bool aov = opt("aov", 0) != 0, count = opt("count_rays", 0) != 0;
+    const int64_t pipeAsked = opt("pipeline", 0), pipe = pipeAsked == 4 ? 0 : pipeAsked; /* 4 = the split-role kernel where it exists, the lock-step kernel (0) elsewhere */
     c->ds.alphaTest = opt("alpha_test", 0) ? 1u : 0u;
     ensure(c->stats, 16);
     const bool clearStats = c->samplesRendered == 0; /* enqueued below, on the stream of the first path-tracing launch */
@@ -684,18 +776,20 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
     c->lastVariant = v->name;
     const int variantIndex = (int)(v - kVariants);
     const bool twoLevel = c->ds.numInstances != 0; /* instanced scene (flatten_instances = 0): pipeline 0 only */
-    if (twoLevel && opt("pipeline", 0) != 0) return fail(c, TB_E_UNSUPPORTED, "tb_render: two-level (instanced) scenes are not supported by pipelines 1-3; use pipeline 0 or flatten_instances = 1");
-    const bool wavefront = opt("pipeline", 0) == 2 && v->wf && !count && !aov;
-    const bool pooled = opt("pipeline", 0) == 3 && v->pooled && !count && !aov;
+    if (twoLevel && pipe != 0) return fail(c, TB_E_UNSUPPORTED, "tb_render: two-level (instanced) scenes are not supported by pipelines 1-3; use pipeline 0 or flatten_instances = 1");
+    const bool wavefront = pipe == 2 && v->wf && !count && !aov;
+    const bool pooled = pipe == 3 && v->pooled && !count && !aov;
+    /* pipeline 4 (pt_split.inc) where the feature set has it and the call writes nothing but samples; otherwise the lock-step kernel */
+    const bool split = pipeAsked == 4 && v->split && !count && !aov && !twoLevel && !s.RenderModeRealTime && c->selX == 0xffffffffu && s.MaxBounces >= 0;
     const int64_t fg = opt("frame_group", 0);
-    const bool groups = !wavefront && !pooled && opt("pipeline", 0) == 0 && !count && !aov && !s.RenderModeRealTime && c->selX == 0xffffffffu && fg >= 0 && (fg > 0 || n >= (c->sceneInLds ? 1u : 2u)); /* measured: frame groups win from 2 frames per call on (cornell-box 4 spp +23 %, 870 k scene 4 spp 2x); one frame per call: +17 % with the scene in LDS, -9 % on the 870 k scene */
+    const bool groups = !split && !wavefront && !pooled && pipe == 0 && !count && !aov && !s.RenderModeRealTime && c->selX == 0xffffffffu && fg >= 0 && (fg > 0 || n >= (c->sceneInLds ? 1u : 2u)); /* measured: frame groups win from 2 frames per call on (cornell-box 4 spp +23 %, 870 k scene 4 spp 2x); one frame per call: +17 % with the scene in LDS, -9 % on the 870 k scene */
     /* Which copy of the feature set: the higher-occupancy one when its workgroups fit in LDS.  LDS per workgroup = 1 KB per stack
      * entry (+ the scene image); where the tree is too deep for that, a frame-group launch may still use the copy with a split
      * stack -- as many entries in LDS as fit, the deepest few (option "stack_overflow_max", default 16) in global memory. */
     pt_variant_fn launch = v->fn;
     size_t overflowHalf = 0;
     TbDeviceScene dsLaunch = c->ds; dsLaunch.stackOverflow = nullptr; dsLaunch.stackOverflowLanes = 0;
-    if (v->fnHi && opt("pipeline", 0) == 0 && !count && opt("high_occupancy", 1) != 0) {
+    if (v->fnHi && pipe == 0 && !count && opt("high_occupancy", 1) != 0) {
         const size_t share = (160 * 1024 / v->wavesHi) / 512 * 512, fixed = (c->sceneInLds ? c->ds.ldsBlobBytes : 0) + 128;
         const size_t ldsPerGroup = ((size_t)c->ds.stackDepth * 1024 + fixed + 511) / 512 * 512; /* + static LDS, 512-B granules */
         const int64_t forcedCap = opt("stack_lds_cap", 0); /* tests: split the stack although it would fit */
@@ -769,8 +863,9 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
     if (clearStats && !overlap) HIP_TRY(hipMemsetAsync(c->stats.p, 0, 16, c->stream));
     if (!groups) HIP_TRY(hipEventRecord(c->evKernelStart, c->stream));
     c->lastKernelFrames = 0;
-    c->lastPipeline = wavefront ? 2 : (pooled ? 3 : (int)(opt("pipeline", 0) == 1 ? 1 : 0));
-    if (wavefront) renderWavefront(c, variantIndex, W, H, c->samplesRendered, n, pf);
+    c->lastPipeline = split ? 4 : (wavefront ? 2 : (pooled ? 3 : (int)(pipe == 1 ? 1 : 0)));
+    if (split) renderSplit(c, v, W, H, n, pf, tg);
+    else if (wavefront) renderWavefront(c, variantIndex, W, H, c->samplesRendered, n, pf);
     else if (pooled) renderPooled(c, variantIndex, W, H, c->samplesRendered, n, pf);
     else {
         /* frame-group mode (TbDeviceTargets::samples, pt_scene.h): the frames of a batch are cut into groups, workgroup
@@ -778,7 +873,7 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
          * to an ordered sample buffer and accumulate_samples_kernel folds them in frame order (bit-identical sums).  Keeps all
          * lanes of a workgroup busy to its end and gives a rank of a tile split enough workgroups; on whenever a call renders
          * enough frames to form groups.  Option "frame_group" = G > 0 forces the group size, < 0 forbids the mode. */
-        if (!groups) HIP_TRY(launch(c->stream, &dsLaunch, &pf, &tg, W, H, c->samplesRendered, n, &c->tiles, c->sceneInLds ? 1 : 0, count ? 1 : 0, (int)opt("pipeline", 0)));
+        if (!groups) HIP_TRY(launch(c->stream, &dsLaunch, &pf, &tg, W, H, c->samplesRendered, n, &c->tiles, c->sceneInLds ? 1 : 0, count ? 1 : 0, (int)pipe));
         else {
             const uint64_t pixels = (uint64_t)W * H, budget = (uint64_t)opt("pooled_samples", 256ll << 20);
             uint32_t batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(n, 32768), budget / pixels)); /* a slot entry holds 15 bits of relative frame */
@@ -893,6 +988,7 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
     if (sync) {
         HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipEventElapsedTime(&c->lastMs, c->ev0, c->ev1));
         HIP_TRY(hipEventElapsedTime(&c->lastKernelMs, c->evKernelStart, c->evKernel));
+        if (c->splitAbort && *c->splitAbort) { *c->splitAbort = 0; return fail(c, TB_E_DEVICE, "tb_render: the split-role kernel gave up waiting (a wave slept spin_limit times without progress); the frame is incomplete"); }
     }
     return TB_OK;
 }
@@ -971,6 +1067,7 @@ void tb_destroy(tb_context* c)
     for (int i = 0; i < 2; i++) { c->rtIndirect[i].release(); c->rtMoment[i].release(); c->rtFinal[i].release(); c->rtDenoise[i].release(); }
     c->rtComposited.release();
     for (DevBuf& b : c->aov) b.release();
+    if (c->splitAbort) (void)hipHostFree(c->splitAbort);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->evKernel) (void)hipEventDestroy(c->evKernel);
@@ -1138,6 +1235,7 @@ int tb_sync(tb_context* c)
     return guarded(c, [&]() {
         HIP_TRY(hipStreamSynchronize(c->stream)); (void)hipEventElapsedTime(&c->lastMs, c->ev0, c->ev1);
         if (hipEventElapsedTime(&c->lastKernelMs, c->evKernelStart, c->evKernel) != hipSuccess) c->lastKernelMs = c->lastMs;
+        if (c->splitAbort && *c->splitAbort) { *c->splitAbort = 0; return fail(c, TB_E_DEVICE, "tb_sync: the split-role kernel gave up waiting (a wave slept spin_limit times without progress); the frame is incomplete"); }
         return TB_OK;
     });
 }
@@ -1407,7 +1505,8 @@ int tb_unpack_gathered_host(uint32_t W, uint32_t H, uint32_t world, uint32_t tw,
 int tb_set_option(tb_context* c, const char* name, int64_t v)
 {
     if (!c || !name) return TB_E_INVALID;
-    static const char* known[] = {"primary_prepass", "pipeline", "count_rays", "bvh_builder", "flatten_instances", "aov", "scene_in_lds", "lds_scene_budget", "force_full_variant", "wavefront_paths", "wavefront_grid", "wavefront_segment", "pooled_paths", "pooled_samples", "pooled_profile", "park_min", "alpha_test", "node_order", "node_order_top_levels", "frame_group", "overlap_launches", "high_occupancy", "stack_lds_cap", "stack_overflow_max", "flip_texture_uvs", "wavefront_sort", "banded_items", "node_layout", "wavefront_refill"};
+    static const char* known[] = {"primary_prepass", "pipeline", "count_rays", "bvh_builder", "flatten_instances", "aov", "scene_in_lds", "lds_scene_budget", "force_full_variant", "wavefront_paths", "wavefront_grid", "wavefront_segment", "pooled_paths", "pooled_samples", "pooled_profile", "park_min", "alpha_test", "node_order", "node_order_top_levels", "frame_group", "overlap_launches", "high_occupancy", "stack_lds_cap", "stack_overflow_max", "flip_texture_uvs", "wavefront_sort", "banded_items", "node_layout", "wavefront_refill",
+                                  "split_trav", "split_shade", "split_ready", "split_refill", "split_wi", "split_wl", "split_frame_group", "split_stack_cap", "split_spin_limit"};
     for (const char* k : known) if (!strcmp(k, name)) { c->options[name] = v; if (!strcmp(name, "count_rays") || !strcmp(name, "aov")) c->samplesRendered = 0; return TB_OK; }
     return fail(c, TB_E_INVALID, std::string("unknown option '") + name + "'");
 }
@@ -1423,6 +1522,7 @@ int64_t tb_get_option(tb_context* c, const char* name)
     if (!strcmp(name, "debug_slot_log_cap")) return c->lastSlotLogCap;
     if (!strcmp(name, "debug_fg_samples_ptr")) return (int64_t)(uintptr_t)c->fgSamples[c->lastFgPar].p; /* device address of the sample buffer of the last frame-group launch (scripts/lost_item_stress.py) */
     if (!strcmp(name, "last_node_layout")) return c->lastNodeLayout; /* 0: layout B (64-B nodes), 1: layout C (32-B nodes on the 16-bit grid) */
+    if (!strcmp(name, "last_split_waves")) return c->lastSplitWaves; /* traversal waves * 100 + shading waves per workgroup of the last pipeline-4 launch */
     if (!strcmp(name, "last_pipeline")) return c->lastPipeline; /* the pipeline the last render actually ran (2 / 3 fall back to 0 for feature sets they lack) */
     if (!strcmp(name, "last_variant")) { for (const Variant& k : kVariants) if (c->lastVariant == k.name) return k.id; return -1; } /* 0 matte 1 env 2 surf 3 vol 4 full 5 sss */
     auto it = c->options.find(name); return it == c->options.end() ? 0 : it->second;

@@ -94,26 +94,52 @@ struct RayPre { tb3 inv, ainv, oinv, shear; int kx, ky, kz; tb3 o, operm; uint32
 #define TB_DEGEN_INV 1.2089258196146292e24f       /* 2^80 */
 #define TB_DEGEN_AINV 1.2101064112353466e24f      /* 2^80 (1 + 2^-10) */
 
-TBD RayPre ray_prepare(tb3 o, tb3 d) /* GetRayData, TraverseFunction.hlsli:473-495 */
+/* GetRayData in two halves: the five quotients (1 / d per axis, the two shear terms) and everything else.  The split-role kernel
+ * (pt_split.inc) has the lane that SHADES a path divide, with the wave's other paths, and hands the quotients to the lane that walks
+ * the ray, which assembles the rest from compares, products and selects; ray_prepare() is the two halves back to back. */
+struct RayDiv { tb3 inv0; float sx, sy; };
+
+TBD void ray_axes(tb3 d, int& kx, int& ky, int& kz, float& dz)
+{
+    tb3 a = tb3_abs(d);
+    int z = (a.x > a.y && a.x > a.z) ? 0 : (a.y > a.z ? 1 : 2);
+    kx = z == 2 ? 0 : z + 1; ky = kx == 2 ? 0 : kx + 1;
+    dz = tb3_get(d, z);
+    if (dz < 0.0f) { int t = kx; kx = ky; ky = t; }
+    kz = z;
+}
+
+TBD RayDiv ray_divide(tb3 d)
+{
+    RayDiv q;
+    q.inv0 = tb3_make(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    int kx, ky, kz; float dz;
+    ray_axes(d, kx, ky, kz, dz);
+    q.sx = tb3_get(d, kx) / dz; q.sy = tb3_get(d, ky) / dz;
+    return q;
+}
+
+TBD RayPre ray_assemble(tb3 o, tb3 d, const RayDiv& q)
 {
     RayPre r;
-    r.inv = tb3_make(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    const tb3 inv0 = r.inv; /* before the degenerate-axis substitution: 1 / d[kz] below is one of these three quotients */
+    r.inv = q.inv0; /* inv0: before the degenerate-axis substitution: 1 / d[kz] below is one of these three quotients */
     r.oinv = o * r.inv; r.ainv = tb3_abs(r.inv);
     if (d.x == 0.0f) { r.inv.x = TB_DEGEN_INV; r.ainv.x = TB_DEGEN_AINV; r.oinv.x = o.x * TB_DEGEN_INV; }
     if (d.y == 0.0f) { r.inv.y = TB_DEGEN_INV; r.ainv.y = TB_DEGEN_AINV; r.oinv.y = o.y * TB_DEGEN_INV; }
     if (d.z == 0.0f) { r.inv.z = TB_DEGEN_INV; r.ainv.z = TB_DEGEN_AINV; r.oinv.z = o.z * TB_DEGEN_INV; }
-    tb3 a = tb3_abs(d);
-    int z = (a.x > a.y && a.x > a.z) ? 0 : (a.y > a.z ? 1 : 2);
-    int kx = z == 2 ? 0 : z + 1, ky = kx == 2 ? 0 : kx + 1;
-    float dz = tb3_get(d, z);
-    if (dz < 0.0f) { int t = kx; kx = ky; ky = t; }
+    int kx, ky, z; float dz;
+    ray_axes(d, kx, ky, z, dz);
     r.kx = kx; r.ky = ky; r.kz = z;
     r.operm = tb3_make(tb3_get(o, kx), tb3_get(o, ky), tb3_get(o, z)); /* for the axis-permuted triangle copies */
     r.permUnits = (uint32_t)(z * 2 + (dz < 0.0f ? 1 : 0)) * 3u;        /* copy index * 48 B / 16 */
     r.o = o;
-    r.shear = tb3_make(tb3_get(d, kx) / dz, tb3_get(d, ky) / dz, tb3_get(inv0, z)); /* Shear.z = 1 / d[kz]: the same division as inv0[kz], not repeated */
+    r.shear = tb3_make(q.sx, q.sy, tb3_get(q.inv0, z)); /* Shear.z = 1 / d[kz]: the same division as inv0[kz], not repeated */
     return r;
+}
+
+TBD RayPre ray_prepare(tb3 o, tb3 d) /* GetRayData, TraverseFunction.hlsli:473-495 */
+{
+    return ray_assemble(o, d, ray_divide(d));
 }
 
 TBD bool box_test(float& tEntry, float closest, const RayPre& r, tb3 c, tb3 h) /* RayBoxTest :204-221 */

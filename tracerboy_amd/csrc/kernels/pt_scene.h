@@ -86,6 +86,20 @@ struct TbDeviceTargets {
     uint32_t launchEpoch; /* frame-group mode: a number no other launch on these buffers has had (host counter); stamps the slot-log entries (low byte) and the hit records */
 };
 
+/* Split-role kernel (pipeline 4, pt_split.inc): a workgroup is `travWaves` traversal waves followed by `shadeWaves` shading waves.
+ * Shading waves own the paths (state in registers), write each pending ray -- origin, direction and the five quotients of
+ * GetRayData -- into the lane's slot in LDS and queue the slot's number; traversal waves draw rays from that queue whenever lanes
+ * fall idle, walk them (resumable per-lane walk, one body per step chosen by majority) and leave the closest hit in the slot. */
+struct TbSplitParams {
+    uint32_t travWaves, shadeWaves;
+    uint32_t readyMin;      /* a shading wave goes on when this many of its lanes have all their rays back (or every lane that waits) */
+    uint32_t refillMin;     /* a traversal wave asks the queue for rays when this many of its lanes are idle */
+    uint32_t innerWeight, leafWeight; /* a step runs the inner-node body when lanesAtInnerNodes * leafWeight >= lanesAtLeaves * innerWeight */
+    uint32_t ringCap;       /* entries of the ray queue: a power of two >= 2 x 128 x shadeWaves */
+    uint32_t spinLimit;     /* every wait is bounded: a wave that has slept this often raises *abortFlag and the launch winds down */
+    uint32_t* abortFlag;    /* host-visible word, 0 while all is well */
+};
+
 struct TbTileMap { /* multi-GPU tile ownership: tile t is rendered iff t % world == rank; tileW, tileH multiples of 16 */
     uint32_t rank, world, tileW, tileH;
 };
