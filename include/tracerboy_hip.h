@@ -180,6 +180,11 @@ int tb_read_stats(tb_context* ctx, tb_readback_stats* out);
  * wave trips) for: BVH inner-node step, leaf step, closest-hit shading, shadow-ray slot, scatter, regeneration,
  * main-loop iteration.  occupancy of a phase = active / (64 * trips). */
 int tb_read_wave_profile(tb_context* ctx, uint64_t* out14);
+/* Counters of the split-role kernel (option "pipeline" = 4 rendered with option "split_profile" = 1; no reference counterpart, an
+ * instrument like the one above).  Traversal waves: [0] inner-node steps, [1] lanes in them, [2] triangle steps, [3] lanes in them,
+ * [4] ticket draws, [5] rays taken, [6] sleeps with nothing to walk, [7] wave cycles.  Shading waves: [8] rounds, [9] lanes in them,
+ * [10] sleeps waiting for hits, [11] wave cycles, [12] rays queued, [13] samples finished.  [14] / [15] traversal / shading waves. */
+int tb_read_split_profile(tb_context* ctx, uint64_t* out16);
 /* <-> InvalidateHistory (TracerBoy.cpp:3569-3575) / GetNumberOfSamplesSinceLastInvalidate */
 void tb_invalidate_history(tb_context* ctx);
 uint32_t tb_samples_rendered(tb_context* ctx);

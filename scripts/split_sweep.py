@@ -16,6 +16,7 @@ def main():
     ap.add_argument("--scene", default="cornell-box"); ap.add_argument("--width", type=int, default=1920); ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=64); ap.add_argument("--depth", type=int, default=8); ap.add_argument("--builder", type=int, default=1)
     ap.add_argument("--configs", default="4x4"); ap.add_argument("--reps", type=int, default=3); ap.add_argument("--out", default="")
+    ap.add_argument("--profile", action="store_true", help="one more render per config with the counting copy: occupancies, sleeps, cycles per step")
     ap.add_argument("--async-steps", type=int, default=0, help="also time N back-to-back async renders (overlapped launches)")
     a = ap.parse_args()
     tb = api.TracerBoy(0)
@@ -53,6 +54,10 @@ def main():
         try:
             r = timed(cfg)
             r["bit_exact_vs_pipeline0"] = bool(np.array_equal(tb.ReadAccumulation().view(np.uint32), ref.view(np.uint32)))
+            if a.profile:
+                tb.SetOption("split_profile", 1); tb.InvalidateHistory(); tb.Render(W, H, SPP, s, 0.0)
+                p = tb.SplitProfile(); tb.SetOption("split_profile", 0)
+                r["profile"] = {k: (round(v, 3) if isinstance(v, float) else v) for k, v in p.items()}
         except Exception as e:
             r = {"label": cfg, "error": str(e)[:300]}
         res.append(r); print(json.dumps(r), flush=True)

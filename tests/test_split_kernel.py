@@ -33,6 +33,7 @@ def _oracle(tb, W, H, frames, s, **kw):
 
 
 def _check(tb, W, H, F, s, jittered=True):
+    tb.InvalidateHistory()
     tb.Render(W, H, F, s, 0.0)
     assert tb.GetOption("last_pipeline") == 4
     out, jit = tb.ReadAccumulation(jittered=True)

@@ -73,6 +73,7 @@ def lib():
         "tb_accum_device_ptr": (C.c_int, [vp, P(vp), P(vp)]),
         "tb_read_stats": (C.c_int, [vp, P(abi.tb_readback_stats)]),
         "tb_read_wave_profile": (C.c_int, [vp, P(C.c_uint64)]),
+        "tb_read_split_profile": (C.c_int, [vp, P(C.c_uint64)]),
         "tb_invalidate_history": (None, [vp]),
         "tb_samples_rendered": (C.c_uint32, [vp]),
         "tb_select_pixel": (C.c_int, [vp, C.c_uint32, C.c_uint32]),
@@ -322,6 +323,19 @@ class TracerBoy:
         self._check(self._L.tb_read_wave_profile(self._ctx, raw))
         names = ["bvh_inner", "bvh_leaf", "closest_shade", "shadow_slot", "scatter", "regenerate", "iteration"]
         return {n: (int(raw[2 * i]), int(raw[2 * i + 1]), (raw[2 * i] / (64.0 * raw[2 * i + 1])) if raw[2 * i + 1] else 0.0) for i, n in enumerate(names)}
+
+    def SplitProfile(self):
+        """Counters of the split-role kernel (pipeline 4 rendered with option split_profile = 1), with the ratios that matter."""
+        raw = (C.c_uint64 * 16)()
+        self._check(self._L.tb_read_split_profile(self._ctx, raw))
+        v = [int(x) for x in raw]
+        d = dict(t_inner_steps=v[0], t_inner_lanes=v[1], t_leaf_steps=v[2], t_leaf_lanes=v[3], t_ticket_draws=v[4], t_rays=v[5], t_sleeps=v[6], t_cycles=v[7],
+                 s_rounds=v[8], s_lanes=v[9], s_sleeps=v[10], s_cycles=v[11], s_rays=v[12], s_samples=v[13], t_waves=v[14], s_waves=v[15])
+        d["inner_occupancy"] = v[1] / (64.0 * v[0]) if v[0] else 0.0
+        d["leaf_occupancy"] = v[3] / (64.0 * v[2]) if v[2] else 0.0
+        d["shade_occupancy"] = v[9] / (64.0 * v[8]) if v[8] else 0.0
+        d["cycles_per_walk_step"] = v[7] / float(v[0] + v[2]) if v[0] + v[2] else 0.0
+        return d
 
     # -- surfaces -------------------------------------------------------------------------------
     def ReadAccumulation(self, jittered=False):

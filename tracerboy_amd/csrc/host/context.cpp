@@ -138,7 +138,7 @@ struct tb_context {
     struct PrepassTrial { uint64_t key = 0; int calls = 0, pending = 0; float msWith = 0, msWithout = 0; bool keep = false; } prepassTrial; /* renderImpl */
     uint32_t sceneGeneration = 0; /* counts finalizeScene calls */
     float interiorWalkTriangleShare = 0; /* finalizeScene */
-    uint32_t* splitAbort = nullptr; int lastSplitWaves = 0; /* pipeline 4: host-mapped abort word of the split-role kernel (renderSplit); travWaves * 100 + shadeWaves of the last launch */
+    DevBuf splitProf; uint32_t* splitAbort = nullptr; int lastSplitWaves = 0; /* pipeline 4: host-mapped abort word of the split-role kernel (renderSplit); travWaves * 100 + shadeWaves of the last launch */
     int lastFgPar = 0;          /* which of the two sample buffers the last frame-group launch wrote (debug query) */
     int lastPrimaryPrepass = 0; /* 1: the last render took its first hits from the primary-visibility pre-pass */
     /* Multi-device group (tb_create_multi): this context is device 0 of the group and owns the assembled frame; `peers` are the
@@ -675,6 +675,11 @@ void renderSplit(tb_context* c, const Variant* v, uint32_t W, uint32_t H, uint32
     sp.spinLimit = (uint32_t)opt("split_spin_limit", 1 << 21);
     if (!c->splitAbort) { HIP_TRY(hipHostMalloc((void**)&c->splitAbort, 64, hipHostMallocMapped)); *c->splitAbort = 0; }
     HIP_TRY(hipHostGetDevicePointer((void**)&sp.abortFlag, c->splitAbort, 0));
+    if (opt("split_profile", 0)) { /* counting copy: 16 counters, cleared with the history, read back with tb_read_split_profile */
+        ensure(c->splitProf, 16 * 8);
+        if (c->samplesRendered == 0) HIP_TRY(hipMemsetAsync(c->splitProf.p, 0, 16 * 8, c->stream));
+        sp.prof = (unsigned long long*)c->splitProf.p;
+    }
     TbDeviceScene dsL = c->ds; dsL.nodesC = nullptr; dsL.stackOverflow = nullptr; dsL.stackOverflowLanes = 0;
     const pt_split_fn fn = v->split;
     size_t overflowHalf = 0;
@@ -1068,6 +1073,7 @@ void tb_destroy(tb_context* c)
     c->rtComposited.release();
     for (DevBuf& b : c->aov) b.release();
     if (c->splitAbort) (void)hipHostFree(c->splitAbort);
+    c->splitProf.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->evKernel) (void)hipEventDestroy(c->evKernel);
@@ -1440,6 +1446,16 @@ int tb_read_wave_profile(tb_context* c, uint64_t* out14)
     });
 }
 
+int tb_read_split_profile(tb_context* c, uint64_t* out16)
+{
+    return guarded(c, [&]() {
+        if (!out16 || !c->splitProf.p) return fail(c, TB_E_INVALID, "tb_read_split_profile: render with options \"pipeline\" = 4 and \"split_profile\" = 1 first");
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipMemcpy(out16, c->splitProf.p, 16 * 8, hipMemcpyDeviceToHost));
+        return TB_OK;
+    });
+}
+
 void tb_invalidate_history(tb_context* c) { if (c) { c->samplesRendered = 0; for (tb_context* p : c->peers) p->samplesRendered = 0; } }
 uint32_t tb_samples_rendered(tb_context* c) { return c ? c->samplesRendered : 0; }
 int tb_select_pixel(tb_context* c, uint32_t x, uint32_t y) { if (!c) return TB_E_INVALID; c->selX = x; c->selY = y; return TB_OK; } /* (a group renders the selection on the device that owns the pixel's tile; ReadbackStats reads the owner's buffer) */
@@ -1506,7 +1522,7 @@ int tb_set_option(tb_context* c, const char* name, int64_t v)
 {
     if (!c || !name) return TB_E_INVALID;
     static const char* known[] = {"primary_prepass", "pipeline", "count_rays", "bvh_builder", "flatten_instances", "aov", "scene_in_lds", "lds_scene_budget", "force_full_variant", "wavefront_paths", "wavefront_grid", "wavefront_segment", "pooled_paths", "pooled_samples", "pooled_profile", "park_min", "alpha_test", "node_order", "node_order_top_levels", "frame_group", "overlap_launches", "high_occupancy", "stack_lds_cap", "stack_overflow_max", "flip_texture_uvs", "wavefront_sort", "banded_items", "node_layout", "wavefront_refill",
-                                  "split_trav", "split_shade", "split_ready", "split_refill", "split_wi", "split_wl", "split_frame_group", "split_stack_cap", "split_spin_limit"};
+                                  "split_trav", "split_shade", "split_ready", "split_refill", "split_wi", "split_wl", "split_frame_group", "split_stack_cap", "split_spin_limit", "split_profile"};
     for (const char* k : known) if (!strcmp(k, name)) { c->options[name] = v; if (!strcmp(name, "count_rays") || !strcmp(name, "aov")) c->samplesRendered = 0; return TB_OK; }
     return fail(c, TB_E_INVALID, std::string("unknown option '") + name + "'");
 }

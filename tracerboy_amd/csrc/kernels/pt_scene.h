@@ -98,6 +98,7 @@ struct TbSplitParams {
     uint32_t ringCap;       /* entries of the ray queue: a power of two >= 2 x 128 x shadeWaves */
     uint32_t spinLimit;     /* every wait is bounded: a wave that has slept this often raises *abortFlag and the launch winds down */
     uint32_t* abortFlag;    /* host-visible word, 0 while all is well */
+    unsigned long long* prof; /* option split_profile: 16 counters (pt_split.inc SP_*), filled by the profiling copy of the kernel; else null */
 };
 
 struct TbTileMap { /* multi-GPU tile ownership: tile t is rendered iff t % world == rank; tileW, tileH multiples of 16 */
