@@ -658,6 +658,18 @@ int deviceCUs(tb_context* c)
  * the main stream.  Options: split_trav / split_shade (waves of either role per workgroup), split_ready, split_refill, split_wi /
  * split_wl (TbSplitParams), split_frame_group (frames of a wave's work item), split_stack_cap (stack entries kept in LDS; the rest
  * of a deeper tree's stack lives in global memory, pt_scene.h). */
+/* the split-role kernel's abort word and the state the wave that raised it left behind (pt_split.inc give_up); clears the word */
+std::string splitAbortMessage(tb_context* c)
+{
+    volatile uint32_t* w = c->splitAbort;
+    char buf[512];
+    static const char* why[] = {"?", "a traversal wave found nothing to walk", "a shading wave waited for hits", "a queue position stayed full"};
+    snprintf(buf, sizeof buf, "the split-role kernel gave up (%s for spin_limit sleeps; workgroup %u wave %u; state %u %u 0x%x 0x%x; tickets %u, positions %u, shading waves done %u); the frame is incomplete",
+             why[w[0] < 4 ? w[0] : 0], w[1] >> 8, w[1] & 255u, w[2], w[3], w[4], w[5], w[6], w[7], w[8]);
+    for (int i = 0; i < 9; i++) w[i] = 0;
+    return buf;
+}
+
 void renderSplit(tb_context* c, const Variant* v, uint32_t W, uint32_t H, uint32_t n, const TbPerFrameConstants& pf, TbDeviceTargets tg)
 {
     auto opt = [&](const char* k, int64_t d) { auto it = c->options.find(k); return it == c->options.end() ? d : it->second; };
@@ -673,7 +685,7 @@ void renderSplit(tb_context* c, const Variant* v, uint32_t W, uint32_t H, uint32
     sp.innerWeight = (uint32_t)std::max<int64_t>(1, opt("split_wi", 85)); sp.leafWeight = (uint32_t)std::max<int64_t>(1, opt("split_wl", 160));
     sp.ringCap = 256; while (sp.ringCap < 256u * sp.shadeWaves) sp.ringCap *= 2;
     sp.spinLimit = (uint32_t)opt("split_spin_limit", 1 << 21);
-    if (!c->splitAbort) { HIP_TRY(hipHostMalloc((void**)&c->splitAbort, 64, hipHostMallocMapped)); *c->splitAbort = 0; }
+    if (!c->splitAbort) { HIP_TRY(hipHostMalloc((void**)&c->splitAbort, 64, hipHostMallocMapped)); memset(c->splitAbort, 0, 64); }
     HIP_TRY(hipHostGetDevicePointer((void**)&sp.abortFlag, c->splitAbort, 0));
     if (opt("split_profile", 0)) { /* counting copy: 16 counters, cleared with the history, read back with tb_read_split_profile */
         ensure(c->splitProf, 16 * 8);
@@ -993,7 +1005,7 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
     if (sync) {
         HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipEventElapsedTime(&c->lastMs, c->ev0, c->ev1));
         HIP_TRY(hipEventElapsedTime(&c->lastKernelMs, c->evKernelStart, c->evKernel));
-        if (c->splitAbort && *c->splitAbort) { *c->splitAbort = 0; return fail(c, TB_E_DEVICE, "tb_render: the split-role kernel gave up waiting (a wave slept spin_limit times without progress); the frame is incomplete"); }
+        if (c->splitAbort && *c->splitAbort) return fail(c, TB_E_DEVICE, splitAbortMessage(c));
     }
     return TB_OK;
 }
@@ -1241,7 +1253,7 @@ int tb_sync(tb_context* c)
     return guarded(c, [&]() {
         HIP_TRY(hipStreamSynchronize(c->stream)); (void)hipEventElapsedTime(&c->lastMs, c->ev0, c->ev1);
         if (hipEventElapsedTime(&c->lastKernelMs, c->evKernelStart, c->evKernel) != hipSuccess) c->lastKernelMs = c->lastMs;
-        if (c->splitAbort && *c->splitAbort) { *c->splitAbort = 0; return fail(c, TB_E_DEVICE, "tb_sync: the split-role kernel gave up waiting (a wave slept spin_limit times without progress); the frame is incomplete"); }
+        if (c->splitAbort && *c->splitAbort) return fail(c, TB_E_DEVICE, splitAbortMessage(c));
         return TB_OK;
     });
 }
