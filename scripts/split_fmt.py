@@ -5,7 +5,7 @@ for line in sys.stdin:
     line = line.strip()
     if not line.startswith("{"): continue
     r = json.loads(line)
-    if "error" in r: print("%-22s ERROR %s" % (r["label"], r["error"][:120])); continue
+    if "error" in r: print("%-22s ERROR %s" % (r["label"], r["error"][:400])); continue
     s = "%-22s %8.1f Msamples/s %8.2f ms" % (r["label"], r["msamples_s"], r["ms"])
     if "async_msamples_s" in r: s += "  async %8.1f" % r["async_msamples_s"]
     if "bit_exact_vs_pipeline0" in r: s += "  exact=%d" % r["bit_exact_vs_pipeline0"]

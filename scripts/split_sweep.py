@@ -59,7 +59,7 @@ def main():
                 p = tb.SplitProfile(); tb.SetOption("split_profile", 0)
                 r["profile"] = {k: (round(v, 3) if isinstance(v, float) else v) for k, v in p.items()}
         except Exception as e:
-            r = {"label": cfg, "error": str(e)[:300]}
+            r = {"label": cfg, "error": str(e)[:500]}
         res.append(r); print(json.dumps(r), flush=True)
     if a.out:
         json.dump({"scene": a.scene, "W": W, "H": H, "spp": SPP, "depth": a.depth, "results": res}, open(a.out, "w"), indent=1)
