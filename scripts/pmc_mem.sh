@@ -20,17 +20,15 @@ pass d SQ_INST_LEVEL_VMEM SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR 
 pass e TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum
 pass e2 TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum
 python3 - "$OUT" "$TAG" <<'PY'
-import csv, glob, collections, sys, json, re
-out, tag = sys.argv[1], sys.argv[2]
-agg = collections.defaultdict(lambda: collections.defaultdict(float)); disp = collections.defaultdict(set)
-for f in glob.glob(out + "/**/*counter_collection.csv", recursive=True):
-    for r in csv.DictReader(open(f)):
-        m = re.search(r"(pt_persistent<[^>]*>|pt_primary<[^>]*>|accumulate_samples_kernel)", r["Kernel_Name"])
-        if not m or "63u" in m.group(1): continue
-        agg[m.group(1)][r["Counter_Name"]] += float(r["Counter_Value"]); disp[(m.group(1), r["Counter_Name"])].add(r["Dispatch_Id"])
-res = {k: {c: v / max(1, len(disp[(k, c)])) for c, v in d.items()} for k, d in agg.items()}
-sys.path.insert(0, ".")
+import sys, json, re
+sys.path.insert(0, "scripts"); sys.path.insert(0, ".")
+from pmc_aggregate import aggregate
 from tracerboy_amd import build as tb_build
+out, tag = sys.argv[1], sys.argv[2]
+def key(k):
+    m = re.search(r"(pt_persistent<[^>]*>|pt_primary<[^>]*>|pt_split<[^>]*>|accumulate_samples_kernel)", k)
+    return m.group(1) if m else None
+res = aggregate(out + "/**/*counter_collection.csv", lambda k: key(k) is not None and "63u" not in key(k), key)   # real launches only (pmc_aggregate.py)
 res["_kernel_digest"] = {"digest": tb_build.kernel_digest()}
 json.dump(res, open("gpurun_out/pmcmem_%s.json" % tag, "w"), indent=1)
 del res["_kernel_digest"]

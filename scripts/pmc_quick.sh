@@ -9,20 +9,16 @@ ARGS="--steps 2 --warmup 1 --no-cpu-baseline $*"
 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES --output-format csv -d $OUT/a -o a -- python3 bench.py $ARGS > /dev/null 2> $OUT/a.err
 rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM GRBM_GUI_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_SMEM --output-format csv -d $OUT/b -o b -- python3 bench.py $ARGS > /dev/null 2> $OUT/b.err
 python3 - "$OUT" "$TAG" <<'PY'
-import csv, glob, collections, sys, json, re
+import sys, json
+sys.path.insert(0, "scripts"); sys.path.insert(0, ".")
+from pmc_aggregate import aggregate, pt_key
+from tracerboy_amd import build as tb_build
 out, tag = sys.argv[1], sys.argv[2]
-agg = collections.defaultdict(lambda: collections.defaultdict(float)); disp = collections.defaultdict(set)
-for f in glob.glob(out + "/**/*counter_collection.csv", recursive=True):
-    for r in csv.DictReader(open(f)):
-        m = re.search(r"(pt_\w+|wf_\w+)<?([^>(]*)", r["Kernel_Name"])
-        if not m: continue
-        k = m.group(1) + "<" + m.group(2) + ">"
-        if "true>" in k and k.startswith("pt_persistent<63"): continue
-        agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); disp[(k, r["Counter_Name"])].add(r["Dispatch_Id"])
-res = {k: {c: v / max(1, len(disp[(k, c)])) for c, v in d.items()} for k, d in agg.items()}
+res = aggregate(out + "/**/*counter_collection.csv", lambda k: ("pt_" in k or "wf_" in k) and "63u" not in k, pt_key)   # real launches only (pmc_aggregate.py)
 for k, d in res.items():
-    if "SQ_INSTS_VALU" in d:
-        d["lane_util"] = d["SQ_THREAD_CYCLES_VALU"] / (d["SQ_ACTIVE_INST_VALU"] * 64)
+    if d.get("SQ_ACTIVE_INST_VALU"): d["lane_util"] = d["SQ_THREAD_CYCLES_VALU"] / (d["SQ_ACTIVE_INST_VALU"] * 64)
+res["_kernel_digest"] = {"digest": tb_build.kernel_digest()}
 json.dump(res, open("gpurun_out/pmc_%s.json" % tag, "w"), indent=1)
-for k, d in res.items(): print(k, {c: (round(v / 1e6, 1) if v > 1000 else round(v, 3)) for c, v in sorted(d.items())})
+for k, d in res.items():
+    if not k.startswith("_"): print(k, {c: (round(v / 1e6, 1) if v > 1000 else round(v, 3)) for c, v in sorted(d.items())})
 PY

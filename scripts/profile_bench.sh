@@ -24,27 +24,22 @@ pass tcc TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum
 pass util SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_SCA
 for f in $(find $OUT/trace -name "*kernel_stats.csv"); do cp "$f" $OUT/kernel_stats.csv; head -6 "$f"; done
 python3 - "$OUT" <<'PY'
-import csv, glob, collections, sys, json
+import sys, json
+sys.path.insert(0, "scripts"); sys.path.insert(0, ".")
+from pmc_aggregate import aggregate
+from tracerboy_amd import build as tb_build
 out = sys.argv[1]
 summary = {}
+keep = lambda k: "pt_persistent" in k or "accumulate_samples" in k or "pt_primary" in k or "pt_split" in k
 for tag in ("fetch", "write", "sq", "lds", "tcc", "util"):
-    for f in glob.glob("%s/pmc_%s/**/*counter_collection.csv" % (out, tag), recursive=True):
-        agg = collections.defaultdict(lambda: collections.defaultdict(float)); seen = set()
-        for r in csv.DictReader(open(f)):
-            k = r["Kernel_Name"]
-            if "pt_persistent" not in k and "accumulate_samples" not in k and "pt_primary" not in k: continue
-            agg[k[:80]][r["Counter_Name"]] += float(r["Counter_Value"])
-            seen.add((k, r.get("Dispatch_Id")))
-        for k, v in agg.items():
-            d = len({s for s in seen if s[0][:80] == k})
-            summary.setdefault(k, {})[tag] = {"dispatches": d, **{c: val / max(d, 1) for c, val in v.items()}}
-sys.path.insert(0, ".")
-from tracerboy_amd import build as tb_build
+    # real launches only: the zero-frame dispatches the host warms its streams with are dropped before averaging (pmc_aggregate.py)
+    for k, v in aggregate("%s/pmc_%s/**/*counter_collection.csv" % (out, tag), keep).items():
+        summary.setdefault(k, {})[tag] = v
 summary["_kernel_digest"] = tb_build.kernel_digest()   # bench.py compares it with the code it runs
 open(out + "/pmc_summary.json", "w").write(json.dumps(summary, indent=1))
 for k, v in summary.items():
     if k.startswith("_"): continue
-    print(k, {t: {c: round(x / 1e6, 2) for c, x in d.items() if c != "dispatches"} for t, d in v.items()})
+    print(k, {t: {c: round(x / 1e6, 2) for c, x in d.items() if c not in ("dispatches", "warm_dispatches_dropped")} for t, d in v.items()})
 PY
 cat $OUT/bench.json
 tail -2 $OUT/*.err | grep -v "^$" | head -30

@@ -13,6 +13,8 @@
 
 #include <algorithm>
 #include <cstring>
+#include <limits>
+#include <cmath>
 #include <map>
 #include <stdexcept>
 #include <string>
@@ -135,7 +137,8 @@ struct tb_context {
     std::string lastVariant;
     int lastNodeLayout = 0; /* 1: the last render walked the compact layout-C nodes */
     int lastSlotLogCap = 0;
-    struct PrepassTrial { uint64_t key = 0; int calls = 0, pending = 0; float msWith = 0, msWithout = 0; bool keep = false; } prepassTrial; /* renderImpl */
+    struct PrepassTrial { uint64_t key = 0; int calls = 0, pending = 0, nWith = 0, nWithout = 0; float msWith = 0, msWithout = 0; bool keep = false; uint64_t stamp = 0; } prepassTrial; /* renderImpl */
+    uint64_t kernelEventStamp = 0; /* counts the renders that have recorded evKernelStart / evKernel: a trial's sample belongs to the render it was asked of */
     uint32_t sceneGeneration = 0; /* counts finalizeScene calls */
     float interiorWalkTriangleShare = 0; /* finalizeScene */
     DevBuf splitProf; uint32_t* splitAbort = nullptr; int lastSplitWaves = 0; /* pipeline 4: host-mapped abort word of the split-role kernel (renderSplit); travWaves * 100 + shadeWaves of the last launch */
@@ -148,7 +151,8 @@ struct tb_context {
     std::vector<tb_context*> peers;
     tb_context* groupOwner = nullptr;          /* set on a peer: API calls on a peer handle are refused */
     DevBuf groupPacked[2], groupGathered[2];   /* [0] output, [1] jittered: this device's packed tiles; (owner) world x capacity gathered tiles */
-    hipEvent_t evGroup = nullptr;
+    hipEvent_t evGroup = nullptr, evGroupDone = nullptr; /* evGroupDone (owner): the un-permute of the last group render has read groupGathered */
+    bool compactTried = false; /* layout C was asked for and built -- or could not be built -- for the loaded scene (ensureCompactNodes) */
 };
 
 namespace {
@@ -157,10 +161,19 @@ namespace {
 
 int fail(tb_context* c, int code, const std::string& msg) { if (c) c->err = msg; else g_createError = msg; return code; }
 
+/* Every entry point runs on its context's device and hands the calling thread back the device it came with: a host that shares the
+ * thread (torch in bench.py, an application's own hipMalloc) would otherwise go on allocating and launching on the last peer of a
+ * device group. */
+struct DeviceScope {
+    int saved = -1;
+    explicit DeviceScope(int dev) { if (hipGetDevice(&saved) != hipSuccess) saved = -1; (void)hipSetDevice(dev); }
+    ~DeviceScope() { if (saved >= 0) (void)hipSetDevice(saved); }
+};
+
 template <class F> int guarded(tb_context* c, F f)
 {
     if (!c) return TB_E_INVALID;
-    try { (void)hipSetDevice(c->device); return f(); }
+    try { DeviceScope scope(c->device); return f(); }
     catch (const std::bad_alloc&) { return fail(c, TB_E_DEVICE, "out of host memory"); }
     catch (const std::exception& e) {
         std::string m = e.what();
@@ -353,8 +366,12 @@ void buildCompactNodes(const HostScene& s, std::vector<TbNodeC>& out, TbQuantFra
     if (!(ext > 0)) ext = 1.0;
     for (int a = 0; a < 3; a++) {
         const double e = std::max(hi[a] - lo[a], ext * 1e-6); /* flat scenes: keep the cell finite */
-        q.origin[a] = (float)(lo[a] - 0.002 * e); q.cell[a] = (float)(e * 1.004 / 65535.0);
-        if (!((double)q.origin[a] + 2.0 * q.cell[a] <= lo[a])) q.origin[a] = (float)(lo[a] - 0.004 * e - 4.0 * q.cell[a]); /* fp32 rounding of the origin itself */
+        q.cell[a] = (float)(e * 1.004 / 65535.0);
+        q.origin[a] = (float)(lo[a] - 0.002 * e);
+        /* the origin is an fp32 number: step it DOWN until two cells of margin are really there (a scene far from the coordinate origin has
+         * ulps larger than the margin; if they are larger than the grid can absorb, the box test below refuses the layout and the render
+         * stays with layout B) */
+        for (int guard = 0; guard < 64 && !((double)q.origin[a] + 2.0 * (double)q.cell[a] <= lo[a]); guard++) q.origin[a] = std::nextafter(q.origin[a], -std::numeric_limits<float>::infinity());
     }
     out.assign(s.nodesB.size(), TbNodeC{});
     auto ref = [nodeUnits](uint32_t r) { return (r & TB_BVH_LEAF_FLAG) ? (TB_BVH_LEAF_FLAG | ((r & ~TB_BVH_LEAF_FLAG) * 3u)) : r * nodeUnits; };
@@ -371,6 +388,22 @@ void buildCompactNodes(const HostScene& s, std::vector<TbNodeC>& out, TbQuantFra
             o.c[a][k] = (uint16_t)cq; o.h[a][k] = (uint16_t)hq;
         }
     }
+}
+
+/* Layout C for the loaded scene, on first demand (option "node_layout" = 1 at a render or a trace): +32 B per node of device memory and a
+ * host pass, paid only by who asks.  A scene the 16-bit grid cannot hold (coordinates far from the origin relative to the extent, boxes
+ * with NaN or infinite bounds) keeps layout B: the failure is remembered, not thrown (it used to abort tb_load_scene). */
+void ensureCompactNodes(tb_context* c)
+{
+    if (c->compactTried || c->ds.nodesC) return;
+    c->compactTried = true;
+    const HostScene& s = c->scene;
+    if (!s.instances.empty() || (s.rootRefB & TB_BVH_LEAF_FLAG)) return;
+    try {
+        std::vector<TbNodeC> compact;
+        buildCompactNodes(s, compact, c->ds.quant, 2u);
+        c->ds.nodesC = upload(c, compact);
+    } catch (const std::exception&) { c->ds.nodesC = nullptr; }
 }
 
 /* the top level of a two-level scene on the GPU (bvh_gpu_build_tlas): same bytes as bvh_build.cpp BuildTlas / the oracle's tbo_build_tlas */
@@ -441,12 +474,7 @@ void finalizeScene(tb_context* c, bool build = true) /* build = false: c->scene 
         d.nodes = upload(c, dev);
     }
     d.tris = upload(c, s.trisB);
-    d.nodesC = nullptr;
-    if (!twoLevel && !(s.rootRefB & TB_BVH_LEAF_FLAG)) { /* layout C beside layout B (32 B per node more); option "node_layout" = 1 selects it at render time */
-        std::vector<TbNodeC> compact;
-        buildCompactNodes(s, compact, d.quant, 2u);
-        d.nodesC = upload(c, compact);
-    }
+    d.nodesC = nullptr; c->compactTried = false; /* layout C is built when a render or trace first asks for it (ensureCompactNodes) */
     d.rootRef = twoLevel ? ((s.rootRefB & TB_BVH_LEAF_FLAG) ? (TB_BVH_LEAF_FLAG | ((s.rootRefB & ~TB_BVH_LEAF_FLAG) * 4u)) : s.rootRefB * 4u) : deviceRef(s.rootRefB, 4); /* 0 or LEAF|0: the same in both images */ d.numNodes = (uint32_t)s.nodesB.size(); d.numTris = (uint32_t)s.trisB.size();
     { const TbAabbNode* root = (const TbAabbNode*)((twoLevel ? s.tlasA.data() : s.bvhA.data()) + 16); memcpy(d.rootCenter, root->center, 12); memcpy(d.rootHalf, root->halfDim, 12); }
     {   /* instances in their device form: the bottom-level root as a device child ref */
@@ -832,6 +860,7 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
         dsLaunch = c->ds; dsLaunch.stackOverflow = nullptr; dsLaunch.stackOverflowLanes = 0;
     }
     /* Compact nodes (option "node_layout" = 1): in the frame-group kernels of the higher-occupancy copies, scenes fetched from memory */
+    if (opt("node_layout", 0) == 1 && !twoLevel && !c->sceneInLds) { ensureCompactNodes(c); dsLaunch.nodesC = c->ds.nodesC; dsLaunch.quant = c->ds.quant; }
     const bool compactNodes = opt("node_layout", 0) == 1 && c->ds.nodesC && v->fnHi && launch == v->fnHi && groups && !c->sceneInLds;
     if (!compactNodes) dsLaunch.nodesC = nullptr;
     c->lastNodeLayout = compactNodes ? 1 : 0;
@@ -858,17 +887,23 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
             tb_context::PrepassTrial& t = c->prepassTrial;
             const uint64_t key = ((uint64_t)W << 48) ^ ((uint64_t)H << 32) ^ ((uint64_t)n << 12) ^ ((uint64_t)s.MaxBounces << 4) ^ ((uint64_t)c->sceneGeneration << 24) ^ (uint64_t)(uintptr_t)launch;
             if (t.key != key) { t = tb_context::PrepassTrial(); t.key = key; }
-            if (t.pending) { /* the first launch of the call before this one: finished long ago unless the caller renders asynchronously */
-                float ms = 0; HIP_TRY(hipEventSynchronize(c->evKernel));
-                if (hipEventElapsedTime(&ms, c->evKernelStart, c->evKernel) == hipSuccess) { if (t.pending == 1) t.msWith = ms; else t.msWithout = ms; }
-                if (t.pending == 2) t.keep = t.msWith > 0 && t.msWithout > 0 && t.msWith < 0.99f * t.msWithout;
+            if (t.pending) {
+                /* the first launch of the call before this one: finished long ago unless the caller renders asynchronously -- then the
+                 * sample is skipped and that step of the trial repeated (tb_render_async enqueues, it never waits: no hipEventSynchronize
+                 * here); and only if no other render has recorded the two events since (t.stamp, below) */
+                float ms = 0;
+                const bool mine = t.stamp == c->kernelEventStamp && hipEventQuery(c->evKernel) == hipSuccess && hipEventElapsedTime(&ms, c->evKernelStart, c->evKernel) == hipSuccess && ms > 0;
+                if (mine) { float& best = t.pending == 1 ? t.msWith : t.msWithout; best = best > 0 ? std::min(best, ms) : ms; (t.pending == 1 ? t.nWith : t.nWithout)++; }
+                else t.calls = t.pending == 1 ? 1 : 2; /* repeat the step whose sample was lost */
+                if (t.nWith >= 2 && t.nWithout >= 2) t.keep = t.msWith < 0.99f * t.msWithout; /* the faster of two samples per side */
                 t.pending = 0;
             }
-            if (t.calls == 0) prepass = false;
-            else if (t.calls == 1) { prepass = true; t.pending = 1; }
-            else if (t.calls == 2) { prepass = false; t.pending = 2; }
-            else prepass = t.keep;
-            if (t.calls < 3) t.calls++;
+            /* call 0 without (it also pays for buffers and scratch, not timed), then with / without alternately until each side has two
+             * samples; from then on the faster way */
+            if (t.calls == 0) { prepass = false; t.calls = 1; }
+            else if (t.nWith >= 2 && t.nWithout >= 2) prepass = t.keep;
+            else if (t.calls == 1) { prepass = true; t.pending = 1; t.stamp = c->kernelEventStamp + 1; t.calls = 2; }
+            else { prepass = false; t.pending = 2; t.stamp = c->kernelEventStamp + 1; t.calls = 1; }
         }
     }
     c->lastPrimaryPrepass = prepass ? 1 : 0;
@@ -876,6 +911,7 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
      * may overlap the drain of the launch before them */
     const bool overlap = groups && v->features != PT_FEAT_ALL && opt("overlap_launches", 1) != 0;
     if (!overlap) c->sideOrdered = false;
+    c->kernelEventStamp++; /* this render records evKernelStart / evKernel */
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
     if (clearStats && !overlap) HIP_TRY(hipMemsetAsync(c->stats.p, 0, 16, c->stream));
     if (!groups) HIP_TRY(hipEventRecord(c->evKernelStart, c->stream));
@@ -926,18 +962,6 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
                 for (int i = 0; i < 2; i++) HIP_TRY(hipStreamWaitEvent(c->side[i], c->evMain, 0));
                 c->sideOrdered = true;
             }
-            /* The kernel copies held to an occupancy keep a few registers in scratch, and the runtime sizes a queue's scratch at the
-             * first dispatch on that queue that needs it (milliseconds, once per stream).  The first render with a given kernel
-             * therefore sends a zero-frame launch of its one-pixel-per-lane form (same feature set, at least as much scratch, a
-             * full grid of workgroups that exit at once) down BOTH side streams, so that the one-off cost falls into that first
-             * call and not into whichever later call happens to reach the second stream. */
-            if (overlap && std::find(c->warmedLaunchers.begin(), c->warmedLaunchers.end(), (const void*)launch) == c->warmedLaunchers.end()) {
-                TbDeviceTargets none = tg; none.samples = nullptr;
-                TbDeviceScene dsWarm = c->ds; dsWarm.nodesC = nullptr; /* the one-pixel-per-lane twin fetches layout B */
-                for (uint32_t par = 0; par < 2; par++)
-                    HIP_TRY(launch(c->side[par], &dsWarm, &pf, &none, W, H, c->samplesRendered, 0, &c->tiles, c->sceneInLds ? 1 : 0, 0, 0));
-                c->warmedLaunchers.push_back((const void*)launch);
-            }
             /* both sample buffers are sized -- and touched once, a fresh allocation is mapped lazily -- by the first call that needs
              * them, not by the call that first reaches the second one */
             for (uint32_t par = 0; par < 2u; par++)
@@ -946,6 +970,36 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
                     ensure(c->fgSamples[par], pixels * batch * 16);
                     HIP_TRY(hipMemsetAsync(c->fgSamples[par].p, 0, pixels * batch * 16, overlap ? c->side[par] : c->stream));
                 }
+            /* a zero-frame launch of the frame-group form of `launch` itself down one side stream (resident grid of workgroups that find the
+             * list empty), with or without the hit records of the pre-pass */
+            auto warmFrameGroupForm = [&](uint32_t par, bool withHits) {
+                TbDeviceTargets warm = tg; warm.samples = (TbFloat4*)c->fgSamples[par].p; warm.workCounter = (uint32_t*)c->workCounter.p + par * 128u;
+                const int numCUs = deviceCUs(c);
+                if (c->fgSlotLog[par].bytes < 16ull * numCUs * 16 * 8) ensure(c->fgSlotLog[par], 16ull * numCUs * 16 * 8);
+                warm.slotLog = (unsigned long long*)c->fgSlotLog[par].p; warm.slotLogCap = 16; warm.launchEpoch = ++c->launchEpoch;
+                warm.primaryHits = withHits ? (unsigned long long*)c->fgHits[par].p : nullptr;
+                TbDeviceScene dsPar = dsLaunch; if (dsPar.stackOverflow) dsPar.stackOverflow += par * overflowHalf;
+                hipStream_t st = overlap ? c->side[par] : c->stream;
+                HIP_TRY(launch(st, &dsPar, &pf, &warm, W, H, c->samplesRendered, 0, &c->tiles, withHits ? 0 : (c->sceneInLds ? 1 : 0), 0, 0));
+                HIP_TRY(hipStreamSynchronize(st));
+            };
+            /* The kernel copies held to an occupancy keep a few registers in scratch, and the runtime sizes a queue's scratch at the
+             * first dispatch on that queue that needs it (milliseconds, once per stream).  The first render with a given kernel
+             * therefore sends a zero-frame launch of its one-pixel-per-lane form (same feature set, at least as much scratch, a
+             * full grid of workgroups that exit at once) down BOTH side streams, so that the one-off cost falls into that first
+             * call and not into whichever later call happens to reach the second stream.  Two-level scenes in the tuned copies have no
+             * one-pixel-per-lane form (pt_variant.inc refuses it: the first render of an instanced scene in a fresh context used to fail
+             * here and then for good): they are warmed with the frame-group form itself. */
+            if (overlap && std::find(c->warmedLaunchers.begin(), c->warmedLaunchers.end(), (const void*)launch) == c->warmedLaunchers.end()) {
+                if (twoLevel) { for (uint32_t par = 0; par < 2; par++) warmFrameGroupForm(par, false); }
+                else {
+                    TbDeviceTargets none = tg; none.samples = nullptr;
+                    TbDeviceScene dsWarm = c->ds; dsWarm.nodesC = nullptr; /* the one-pixel-per-lane twin fetches layout B */
+                    for (uint32_t par = 0; par < 2; par++)
+                        HIP_TRY(launch(c->side[par], &dsWarm, &pf, &none, W, H, c->samplesRendered, 0, &c->tiles, c->sceneInLds ? 1 : 0, 0, 0));
+                }
+                c->warmedLaunchers.push_back((const void*)launch);
+            }
             if (prepass) {
                 /* the hit records: sized and touched once like the sample buffers; and the kernels that take their first hits from them
                  * keep more registers in scratch than the twin the warm-up above runs (sss: 464 against 416 B per lane), so they are
@@ -959,16 +1013,7 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
                     }
                 const void* key = (const void*)((uintptr_t)launch ^ (1u | (dsLaunch.stackOverflow ? 2u : 0u) | (dsLaunch.nodesC ? 4u : 0u))); /* one kernel per (split stack, node layout) */
                 if (std::find(c->warmedLaunchers.begin(), c->warmedLaunchers.end(), key) == c->warmedLaunchers.end()) {
-                    for (uint32_t par = 0; par < 2u; par++) {
-                        TbDeviceTargets warm = tg; warm.samples = (TbFloat4*)c->fgSamples[par].p; warm.workCounter = (uint32_t*)c->workCounter.p + par * 128u;
-                        const int numCUs = deviceCUs(c);
-                        if (c->fgSlotLog[par].bytes < 16ull * numCUs * 16 * 8) ensure(c->fgSlotLog[par], 16ull * numCUs * 16 * 8);
-                        warm.slotLog = (unsigned long long*)c->fgSlotLog[par].p; warm.slotLogCap = 16; warm.launchEpoch = ++c->launchEpoch; warm.primaryHits = (unsigned long long*)c->fgHits[par].p;
-                        TbDeviceScene dsPar = dsLaunch; if (dsPar.stackOverflow) dsPar.stackOverflow += par * overflowHalf;
-                        hipStream_t st = overlap ? c->side[par] : c->stream;
-                        HIP_TRY(launch(st, &dsPar, &pf, &warm, W, H, c->samplesRendered, 0, &c->tiles, 0, 0, 0));
-                        HIP_TRY(hipStreamSynchronize(st));
-                    }
+                    for (uint32_t par = 0; par < 2u; par++) warmFrameGroupForm(par, true);
                     c->warmedLaunchers.push_back(key);
                 }
             }
@@ -1073,6 +1118,7 @@ void tb_destroy(tb_context* c)
     (void)hipSetDevice(c->device);
     for (int k = 0; k < 2; k++) { c->groupPacked[k].release(); c->groupGathered[k].release(); }
     if (c->evGroup) (void)hipEventDestroy(c->evGroup);
+    if (c->evGroupDone) (void)hipEventDestroy(c->evGroupDone);
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     releaseScene(c);
@@ -1214,6 +1260,9 @@ static int renderGroup(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const 
         for (uint32_t i = 1; i < world; i++) {
             tb_context* p = all[i];
             HIP_TRY(hipSetDevice(p->device));
+            /* the owner's un-permute of the call BEFORE this one reads groupGathered: the copies below must not overtake it (back-to-back
+             * tb_render_async calls; a wait on an event never recorded is a no-op) */
+            if (c->evGroupDone) HIP_TRY(hipStreamWaitEvent(p->stream, c->evGroupDone, 0));
             for (int k = 0; k < 2; k++) {
                 ensure(p->groupPacked[k], bytes);
                 const TbFloat4* surface = (const TbFloat4*)(k ? p->jittered.p : p->output.p);
@@ -1231,6 +1280,8 @@ static int renderGroup(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const 
             HIP_TRY(pt_launch_unpack_gathered(c->stream, (const TbFloat4*)c->groupGathered[k].p, (size_t)capacity, surface, W, H, world, 64, 64));
         }
         HIP_TRY(hipEventRecord(c->ev1, c->stream)); /* tb_last_render_ms of a group: render + gather + un-permute on the owner's stream */
+        if (!c->evGroupDone) HIP_TRY(hipEventCreateWithFlags(&c->evGroupDone, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(c->evGroupDone, c->stream));
         return TB_OK;
     });
 }
@@ -1589,6 +1640,7 @@ int tb_trace_closest(tb_context* c, uint32_t n, const float* origins, const floa
         in(dO, origins, (size_t)n * 12); in(dD, dirs, (size_t)n * 12);
         ensure(dT.b, (size_t)n * 4); ensure(dM.b, (size_t)n * 4); ensure(dB.b, (size_t)n * 8); ensure(dP.b, (size_t)n * 4); ensure(dG.b, (size_t)n * 4);
         ensure(dN.b, (size_t)n * 12); ensure(dU.b, (size_t)n * 8); ensure(dBx.b, (size_t)n * 4); ensure(dTr.b, (size_t)n * 4);
+        { auto it = c->options.find("node_layout"); if (it != c->options.end() && it->second == 1) ensureCompactNodes(c); }
         TbDeviceScene dsTrace = c->ds; /* option "node_layout" = 1: the batch walks the compact nodes too (one-level scenes) */
         { auto it = c->options.find("node_layout"); if (it == c->options.end() || it->second != 1 || dsTrace.numInstances) dsTrace.nodesC = nullptr; }
         HIP_TRY(pt_launch_trace_closest(c->stream, &dsTrace, n, (const float*)dO.b.p, (const float*)dD.b.p, (float*)dT.b.p, (int*)dM.b.p, (float*)dB.b.p, (uint32_t*)dP.b.p,
