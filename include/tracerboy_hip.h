@@ -219,6 +219,48 @@ int tb_unpack_gathered_host(uint32_t width, uint32_t height, uint32_t world, uin
 int tb_set_option(tb_context* ctx, const char* name, int64_t value);
 int64_t tb_get_option(tb_context* ctx, const char* name);
 
+/* The launch policy of tb_render as a pure function (no device, no context): which pipeline, which copy of the feature set (and how
+ * much of the traversal stack stays in LDS), compact nodes, the primary-visibility pre-pass (off / on / tried both ways), whether
+ * consecutive launches overlap, and the batch and frame-group sizes -- from statistics of the scene, the size of the call and the
+ * options.  tb_render fills the input from its context and executes the plan; tests walk every branch on the CPU
+ * (tests/test_launch_plan.py).  No reference counterpart: TracerBoy::Render has one shader and one dispatch shape (TracerBoy.cpp:2677-2946). */
+enum { TB_PLAN_FEAT_SSS = 8, TB_PLAN_FEAT_EXT = 32 }; /* bits of variant_features the policy looks at (PT_FEAT_SSS / PT_FEAT_EXT) */
+enum { TB_PLAN_PREPASS_OFF = 0, TB_PLAN_PREPASS_ON = 1, TB_PLAN_PREPASS_TRIAL = 2 };
+enum { TB_PLAN_RULE_ONE_PIXEL_PER_LANE = 1, TB_PLAN_RULE_FRAME_GROUPS, TB_PLAN_RULE_WAVEFRONT, TB_PLAN_RULE_POOLED, TB_PLAN_RULE_SPLIT,                 /* rule_pipeline */
+       TB_PLAN_RULE_COPY_NONE = 10, TB_PLAN_RULE_COPY_FITS, TB_PLAN_RULE_COPY_SPLIT_STACK, TB_PLAN_RULE_COPY_TOO_DEEP, TB_PLAN_RULE_COPY_NO_ROOM, TB_PLAN_RULE_COPY_FULL_FOR_INSTANCES, /* rule_copy */
+       TB_PLAN_RULE_PREPASS_NO_KERNEL = 20, TB_PLAN_RULE_PREPASS_OPTION_OFF, TB_PLAN_RULE_PREPASS_FORCED, TB_PLAN_RULE_PREPASS_SMALL_CALL, TB_PLAN_RULE_PREPASS_ENV_LIT,
+       TB_PLAN_RULE_PREPASS_GLASS_AMONG_OTHERS, TB_PLAN_RULE_PREPASS_TRIAL };                                                                              /* rule_prepass */
+typedef struct tb_plan_input {
+    /* the feature set the scene and the settings select (context.cpp kVariants) */
+    uint32_t variant_features;        /* PT_FEAT_* mask of the set */
+    uint32_t variant_waves_hi;        /* waves per SIMD of its higher-occupancy copy, 0 = it has none */
+    uint32_t variant_prepass_in_base; /* its only copy carries the pre-pass (surf) */
+    uint32_t variant_has_wavefront, variant_has_pooled, variant_has_split; /* pipelines 2 / 3 / 4 exist for it */
+    /* the loaded scene */
+    uint32_t scene_in_lds, lds_blob_bytes, stack_depth, two_level, has_lights, has_compact_nodes;
+    float interior_walk_triangle_share; /* share of the triangles whose material starts an interior walk */
+    /* the call */
+    uint32_t width, height, frames; int32_t max_bounces;
+    uint64_t owned_regions;           /* 16x16 regions this context renders (the whole frame, or its tiles of a split) */
+    uint32_t count_rays, aov, realtime, selected_pixel;
+    /* options (tb_set_option), with their defaults where 0 is not one */
+    int64_t pipeline, frame_group, high_occupancy /* 1 */, stack_lds_cap, stack_overflow_max /* 16 */, node_layout, primary_prepass /* 1 */,
+            overlap_launches /* 1 */, pooled_samples /* 2^28 */;
+} tb_plan_input;
+typedef struct tb_launch_plan {
+    int32_t pipeline;                 /* 0 lock-step, 1 streaming, 2 wavefront, 3 pooled, 4 split-role: what will run */
+    uint32_t groups;                  /* frame-group mode (resident grid, ordered sample buffer) */
+    uint32_t high_occupancy_copy, full_variant;
+    uint32_t stack_lds_entries, stack_overflow_entries; /* split stack when the second is not 0 */
+    uint32_t compact_nodes;
+    uint32_t prepass;                 /* TB_PLAN_PREPASS_* */
+    uint32_t overlap_launches;
+    uint32_t batch_frames, frame_group; /* frame-group mode only */
+    uint32_t rule_pipeline, rule_copy, rule_prepass; /* TB_PLAN_RULE_*: which branch decided */
+} tb_launch_plan;
+void tb_plan_defaults(tb_plan_input* in);  /* zeroes, then the option defaults */
+int tb_plan_launch(const tb_plan_input* in, tb_launch_plan* out);
+
 /* The kernel seam, exported so the checker can run on exactly the arrays the kernels read:
  * fills `view` with HOST pointers owned by the context (valid until the next load/destroy). */
 int tb_host_scene_view(tb_context* ctx, TbSceneView* view);

@@ -160,6 +160,25 @@ class tb_scene_info(C.Structure):
                 ("sceneMin", C.c_float * 3), ("sceneMax", C.c_float * 3)]
 
 
+class tb_plan_input(C.Structure):
+    """include/tracerboy_hip.h tb_plan_input: what the launch policy is told (scene statistics, the call, the options)."""
+    _fields_ = [("variant_features", C.c_uint32), ("variant_waves_hi", C.c_uint32), ("variant_prepass_in_base", C.c_uint32),
+                ("variant_has_wavefront", C.c_uint32), ("variant_has_pooled", C.c_uint32), ("variant_has_split", C.c_uint32),
+                ("scene_in_lds", C.c_uint32), ("lds_blob_bytes", C.c_uint32), ("stack_depth", C.c_uint32), ("two_level", C.c_uint32), ("has_lights", C.c_uint32),
+                ("has_compact_nodes", C.c_uint32), ("interior_walk_triangle_share", C.c_float),
+                ("width", C.c_uint32), ("height", C.c_uint32), ("frames", C.c_uint32), ("max_bounces", C.c_int32), ("owned_regions", C.c_uint64),
+                ("count_rays", C.c_uint32), ("aov", C.c_uint32), ("realtime", C.c_uint32), ("selected_pixel", C.c_uint32),
+                ("pipeline", C.c_int64), ("frame_group", C.c_int64), ("high_occupancy", C.c_int64), ("stack_lds_cap", C.c_int64), ("stack_overflow_max", C.c_int64),
+                ("node_layout", C.c_int64), ("primary_prepass", C.c_int64), ("overlap_launches", C.c_int64), ("pooled_samples", C.c_int64)]
+
+
+class tb_launch_plan(C.Structure):
+    _fields_ = [("pipeline", C.c_int32), ("groups", C.c_uint32), ("high_occupancy_copy", C.c_uint32), ("full_variant", C.c_uint32),
+                ("stack_lds_entries", C.c_uint32), ("stack_overflow_entries", C.c_uint32), ("compact_nodes", C.c_uint32), ("prepass", C.c_uint32),
+                ("overlap_launches", C.c_uint32), ("batch_frames", C.c_uint32), ("frame_group", C.c_uint32),
+                ("rule_pipeline", C.c_uint32), ("rule_copy", C.c_uint32), ("rule_prepass", C.c_uint32)]
+
+
 assert C.sizeof(TbPostConstants) == 36
 assert C.sizeof(TbTemporalConstants) == 144
 assert C.sizeof(TbDenoiserConstants) == 28

@@ -74,6 +74,8 @@ def lib():
         "tb_read_stats": (C.c_int, [vp, P(abi.tb_readback_stats)]),
         "tb_read_wave_profile": (C.c_int, [vp, P(C.c_uint64)]),
         "tb_read_split_profile": (C.c_int, [vp, P(C.c_uint64)]),
+        "tb_plan_defaults": (None, [P(abi.tb_plan_input)]),
+        "tb_plan_launch": (C.c_int, [P(abi.tb_plan_input), P(abi.tb_launch_plan)]),
         "tb_invalidate_history": (None, [vp]),
         "tb_samples_rendered": (C.c_uint32, [vp]),
         "tb_select_pixel": (C.c_int, [vp, C.c_uint32, C.c_uint32]),
@@ -130,6 +132,19 @@ def GetDefaultPostProcessSettings():
     s = abi.tb_post_settings()
     lib().tb_default_post_settings(C.byref(s))
     return s
+
+
+def PlanLaunch(**kw):
+    """The launch policy of tb_render as a pure function (include/tracerboy_hip.h tb_plan_launch; no device): keyword arguments are
+    fields of tb_plan_input over the option defaults; returns the tb_launch_plan."""
+    pin = abi.tb_plan_input(); lib().tb_plan_defaults(C.byref(pin))
+    for k, v in kw.items():
+        if not hasattr(pin, k): raise KeyError(k)
+        setattr(pin, k, v)
+    plan = abi.tb_launch_plan()
+    rc = lib().tb_plan_launch(C.byref(pin), C.byref(plan))
+    if rc != 0: raise TracerBoyError(rc, "tb_plan_launch")
+    return plan
 
 
 def WriteImage(path, image):

@@ -8,6 +8,7 @@
 #include "host_scene.h"
 #include "../kernels/pt_launch.h"
 #include "../kernels/pt_device_features.h"
+#include "launch_plan.h"
 
 #include <hip/hip_runtime.h>
 
@@ -780,6 +781,22 @@ void renderSplit(tb_context* c, const Variant* v, uint32_t W, uint32_t H, uint32
     c->lastSplitWaves = (int)(sp.travWaves * 100 + sp.shadeWaves);
 }
 
+/* what PlanLaunch (launch_plan.h) is told about this context's scene, the call and the options */
+void fillPlanInput(tb_context* c, const Variant* v, uint32_t W, uint32_t H, uint32_t n, const tb_output_settings& s, bool aov, bool count, tb_plan_input& in)
+{
+    auto opt = [&](const char* k, int64_t d) { auto it = c->options.find(k); return it == c->options.end() ? d : it->second; };
+    memset(&in, 0, sizeof in);
+    in.variant_features = v->features; in.variant_waves_hi = v->fnHi ? v->wavesHi : 0u; in.variant_prepass_in_base = (!v->fnHi && v->id == 2) ? 1u : 0u; /* surf: compiled into its only copy */
+    in.variant_has_wavefront = v->wf ? 1u : 0u; in.variant_has_pooled = v->pooled ? 1u : 0u; in.variant_has_split = v->split ? 1u : 0u;
+    in.scene_in_lds = c->sceneInLds ? 1u : 0u; in.lds_blob_bytes = c->ds.ldsBlobBytes; in.stack_depth = c->ds.stackDepth; in.two_level = c->ds.numInstances ? 1u : 0u;
+    in.has_lights = c->scene.lights.empty() ? 0u : 1u; in.has_compact_nodes = c->ds.nodesC ? 1u : 0u; in.interior_walk_triangle_share = c->interiorWalkTriangleShare;
+    in.width = W; in.height = H; in.frames = n; in.max_bounces = s.MaxBounces; in.owned_regions = tb_persistent_grid(W, H, c->tiles);
+    in.count_rays = count ? 1u : 0u; in.aov = aov ? 1u : 0u; in.realtime = s.RenderModeRealTime ? 1u : 0u; in.selected_pixel = c->selX != 0xffffffffu ? 1u : 0u;
+    in.pipeline = opt("pipeline", 0); in.frame_group = opt("frame_group", 0); in.high_occupancy = opt("high_occupancy", 1); in.stack_lds_cap = opt("stack_lds_cap", 0);
+    in.stack_overflow_max = opt("stack_overflow_max", 16); in.node_layout = opt("node_layout", 0); in.primary_prepass = opt("primary_prepass", 1);
+    in.overlap_launches = opt("overlap_launches", 1); in.pooled_samples = opt("pooled_samples", 256ll << 20);
+}
+
 int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_output_settings* settings, float timeSeed, bool sync)
 {
     if (!c->hasScene) return fail(c, TB_E_NO_SCENE, "tb_render: no scene loaded");
@@ -822,94 +839,58 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
     const int variantIndex = (int)(v - kVariants);
     const bool twoLevel = c->ds.numInstances != 0; /* instanced scene (flatten_instances = 0): pipeline 0 only */
     if (twoLevel && pipe != 0) return fail(c, TB_E_UNSUPPORTED, "tb_render: two-level (instanced) scenes are not supported by pipelines 1-3; use pipeline 0 or flatten_instances = 1");
-    const bool wavefront = pipe == 2 && v->wf && !count && !aov;
-    const bool pooled = pipe == 3 && v->pooled && !count && !aov;
-    /* pipeline 4 (pt_split.inc) where the feature set has it and the call writes nothing but samples; otherwise the lock-step kernel */
-    const bool split = pipeAsked == 4 && v->split && !count && !aov && !twoLevel && !s.RenderModeRealTime && c->selX == 0xffffffffu && s.MaxBounces >= 0;
+    /* WHAT to launch is decided by a pure function of scene statistics, call size and options (launch_plan.h; tests/test_launch_plan.py
+     * walks its branches on the CPU); what follows executes the plan. */
+    tb_plan_input pin; fillPlanInput(c, v, W, H, n, s, aov, count, pin);
+    tb_launch_plan plan; PlanLaunch(pin, plan);
+    const bool wavefront = plan.pipeline == 2, pooled = plan.pipeline == 3, split = plan.pipeline == 4, groups = plan.groups != 0;
     const int64_t fg = opt("frame_group", 0);
-    const bool groups = !split && !wavefront && !pooled && pipe == 0 && !count && !aov && !s.RenderModeRealTime && c->selX == 0xffffffffu && fg >= 0 && (fg > 0 || n >= (c->sceneInLds ? 1u : 2u)); /* measured: frame groups win from 2 frames per call on (cornell-box 4 spp +23 %, 870 k scene 4 spp 2x); one frame per call: +17 % with the scene in LDS, -9 % on the 870 k scene */
-    /* Which copy of the feature set: the higher-occupancy one when its workgroups fit in LDS.  LDS per workgroup = 1 KB per stack
-     * entry (+ the scene image); where the tree is too deep for that, a frame-group launch may still use the copy with a split
-     * stack -- as many entries in LDS as fit, the deepest few (option "stack_overflow_max", default 16) in global memory. */
-    pt_variant_fn launch = v->fn;
+    pt_variant_fn launch = plan.high_occupancy_copy ? v->fnHi : v->fn;
     size_t overflowHalf = 0;
     TbDeviceScene dsLaunch = c->ds; dsLaunch.stackOverflow = nullptr; dsLaunch.stackOverflowLanes = 0;
-    if (v->fnHi && pipe == 0 && !count && opt("high_occupancy", 1) != 0) {
-        const size_t share = (160 * 1024 / v->wavesHi) / 512 * 512, fixed = (c->sceneInLds ? c->ds.ldsBlobBytes : 0) + 128;
-        const size_t ldsPerGroup = ((size_t)c->ds.stackDepth * 1024 + fixed + 511) / 512 * 512; /* + static LDS, 512-B granules */
-        const int64_t forcedCap = opt("stack_lds_cap", 0); /* tests: split the stack although it would fit */
-        if (ldsPerGroup <= share && !(forcedCap > 0 && groups && (uint32_t)forcedCap < c->ds.stackDepth)) launch = v->fnHi;
-        else if (groups && share > fixed + 4 * 1024) {
-            uint32_t cap = (uint32_t)((share - fixed) / 1024);
-            if (forcedCap > 0) cap = std::min<uint32_t>(cap, (uint32_t)forcedCap);
-            const uint32_t over = c->ds.stackDepth > cap ? c->ds.stackDepth - cap : 0;
-            if (over > 0 && over <= (uint32_t)opt("stack_overflow_max", 16)) {
-                const int numCUs = deviceCUs(c);
-                const uint32_t lanes = 2u * 8u * (uint32_t)numCUs * 256u; /* the resident grid is at most 2 x 8 workgroups per CU */
-                ensure(c->stackOverflow, (size_t)over * lanes * 4 * 2); /* two halves: consecutive batches of a call overlap on the two side streams */
-                overflowHalf = (size_t)over * lanes;
-                dsLaunch.stackDepth = cap; dsLaunch.stackOverflow = (uint32_t*)c->stackOverflow.p; dsLaunch.stackOverflowLanes = lanes;
-                launch = v->fnHi;
-            }
-        }
+    if (plan.stack_overflow_entries) { /* split stack: the deepest entries in global memory, one column per lane of the resident grid (at most 2 x 8 workgroups per CU) */
+        const int numCUs = deviceCUs(c);
+        const uint32_t lanes = 2u * 8u * (uint32_t)numCUs * 256u;
+        ensure(c->stackOverflow, (size_t)plan.stack_overflow_entries * lanes * 4 * 2); /* two halves: consecutive batches of a call overlap on the two side streams */
+        overflowHalf = (size_t)plan.stack_overflow_entries * lanes;
+        dsLaunch.stackDepth = plan.stack_lds_entries; dsLaunch.stackOverflow = (uint32_t*)c->stackOverflow.p; dsLaunch.stackOverflowLanes = lanes;
     }
-    /* Two-level scenes: the tuned walk (while-while, split stack) is compiled into the frame-group kernels of the higher-occupancy
-     * copies; every other launch of an instanced scene goes to the full feature set, whose kernels carry the walk in all their forms */
-    if (twoLevel && !(v->fnHi && launch == v->fnHi && groups)) {
-        v = &kVariants[kNumVariants - 1]; launch = v->fn; c->lastVariant = v->name;
-        dsLaunch = c->ds; dsLaunch.stackOverflow = nullptr; dsLaunch.stackOverflowLanes = 0;
+    if (plan.full_variant && v != &kVariants[kNumVariants - 1]) { v = &kVariants[kNumVariants - 1]; launch = v->fn; c->lastVariant = v->name; }
+    if (opt("node_layout", 0) == 1 && !twoLevel && !c->sceneInLds && !c->ds.nodesC && !c->compactTried) { /* layout C on first demand; the plan is made again with what came of it */
+        ensureCompactNodes(c); dsLaunch.nodesC = c->ds.nodesC; dsLaunch.quant = c->ds.quant;
+        pin.has_compact_nodes = c->ds.nodesC ? 1u : 0u; PlanLaunch(pin, plan);
     }
-    /* Compact nodes (option "node_layout" = 1): in the frame-group kernels of the higher-occupancy copies, scenes fetched from memory */
-    if (opt("node_layout", 0) == 1 && !twoLevel && !c->sceneInLds) { ensureCompactNodes(c); dsLaunch.nodesC = c->ds.nodesC; dsLaunch.quant = c->ds.quant; }
-    const bool compactNodes = opt("node_layout", 0) == 1 && c->ds.nodesC && v->fnHi && launch == v->fnHi && groups && !c->sceneInLds;
+    const bool compactNodes = plan.compact_nodes != 0;
     if (!compactNodes) dsLaunch.nodesC = nullptr;
     c->lastNodeLayout = compactNodes ? 1 : 0;
-    /* Primary-visibility pre-pass (pt_scene.h TbDeviceTargets::primaryHits; option "primary_prepass": 0 never, 1 = default: calls of
-     * 2^24 samples or more -- a second launch and its tail cost a small render ~50 us, measured -4 % at 640 x 360 x 16 -- 2 whenever
-     * the kernels have it): frame-group kernels of the higher-occupancy copies, one-level scenes fetched from memory.  Bit-identical
-     * by construction (same camera ray, same walk); +7 % on the 870 k scene, +5 % / +4 % on the 4K scenes (scripts/prepass_ab.py) */
-    /* ... and by itself (option = 1, the default) where it is known or FOUND to pay.  Known: camera rays are a large part of all rays --
-     * no interior walks and no lights to send a feeler to from every hit (an environment-lit scene: configs[2], +8.8 %) -- or the feature
-     * set with interior walks runs a scene in which few triangles are glass (measured below).  Elsewhere
-     * paths are long, the camera ray was riding along under the longer rays anyway and the pre-pass may be all cost: 516 k triangles of
-     * glass blobs under an area light lose 5.6 % with it, the same scene in matte 1.2 %, while the van- and bistro-class scenes gain
-     * 3-4 % (scripts/instanced_bench.py, scripts/prepass_ab.py) -- not told apart before rendering, so such a scene is TRIED: of the
-     * first calls of one kind (same scene, frame, frames per call, depth) the first runs without (it also pays for buffers and scratch),
-     * the second with, the third without again; their first launches are timed with the events the context records anyway and the
-     * faster way is kept from the fourth call on (the pictures are the same bits either way). */
-    const int64_t prepassOpt = opt("primary_prepass", 1);
-    const bool prepassKernels = ((v->fnHi && launch == v->fnHi) || (!v->fnHi && v->id == 2 /* surf: compiled into its only copy */ && launch == v->fn && !dsLaunch.stackOverflow)) && groups && !c->sceneInLds && !twoLevel && !(v->features & PT_FEAT_EXT) && s.MaxBounces > 0;
-    bool prepass = prepassKernels && prepassOpt == 2;
-    if (prepassKernels && prepassOpt == 1 && (uint64_t)W * H * n >= (1ull << 24)) {
-        if (!(v->features & PT_FEAT_SSS) && c->scene.lights.empty()) prepass = true;
-        else if ((v->features & PT_FEAT_SSS) && c->interiorWalkTriangleShare < 0.5f) prepass = true; /* glass among other things (van- / bistro-class: 20 % / 10 % of the triangles, +9 % / +8 %): most camera rays start ordinary paths.  A scene that is mostly glass (the blobs: every triangle but two, -5 %) is tried like the rest */
-        else {
-            tb_context::PrepassTrial& t = c->prepassTrial;
-            const uint64_t key = ((uint64_t)W << 48) ^ ((uint64_t)H << 32) ^ ((uint64_t)n << 12) ^ ((uint64_t)s.MaxBounces << 4) ^ ((uint64_t)c->sceneGeneration << 24) ^ (uint64_t)(uintptr_t)launch;
-            if (t.key != key) { t = tb_context::PrepassTrial(); t.key = key; }
-            if (t.pending) {
-                /* the first launch of the call before this one: finished long ago unless the caller renders asynchronously -- then the
-                 * sample is skipped and that step of the trial repeated (tb_render_async enqueues, it never waits: no hipEventSynchronize
-                 * here); and only if no other render has recorded the two events since (t.stamp, below) */
-                float ms = 0;
-                const bool mine = t.stamp == c->kernelEventStamp && hipEventQuery(c->evKernel) == hipSuccess && hipEventElapsedTime(&ms, c->evKernelStart, c->evKernel) == hipSuccess && ms > 0;
-                if (mine) { float& best = t.pending == 1 ? t.msWith : t.msWithout; best = best > 0 ? std::min(best, ms) : ms; (t.pending == 1 ? t.nWith : t.nWithout)++; }
-                else t.calls = t.pending == 1 ? 1 : 2; /* repeat the step whose sample was lost */
-                if (t.nWith >= 2 && t.nWithout >= 2) t.keep = t.msWith < 0.99f * t.msWithout; /* the faster of two samples per side */
-                t.pending = 0;
-            }
-            /* call 0 without (it also pays for buffers and scratch, not timed), then with / without alternately until each side has two
-             * samples; from then on the faster way */
-            if (t.calls == 0) { prepass = false; t.calls = 1; }
-            else if (t.nWith >= 2 && t.nWithout >= 2) prepass = t.keep;
-            else if (t.calls == 1) { prepass = true; t.pending = 1; t.stamp = c->kernelEventStamp + 1; t.calls = 2; }
-            else { prepass = false; t.pending = 2; t.stamp = c->kernelEventStamp + 1; t.calls = 1; }
+    bool prepass = plan.prepass == TB_PLAN_PREPASS_ON;
+    if (plan.prepass == TB_PLAN_PREPASS_TRIAL) {
+        /* the scenes the policy cannot tell apart: of the first calls of one kind (same scene, frame, frames per call, depth) the first runs
+         * without (it also pays for buffers and scratch, untimed), then with / without alternately until each side has two timed samples
+         * -- the first launch of a call, with the events the context records anyway -- and the faster way is kept from then on */
+        tb_context::PrepassTrial& t = c->prepassTrial;
+        const uint64_t key = ((uint64_t)W << 48) ^ ((uint64_t)H << 32) ^ ((uint64_t)n << 12) ^ ((uint64_t)s.MaxBounces << 4) ^ ((uint64_t)c->sceneGeneration << 24) ^ (uint64_t)(uintptr_t)launch;
+        if (t.key != key) { t = tb_context::PrepassTrial(); t.key = key; }
+        if (t.pending) {
+            /* the first launch of the call before this one: finished long ago unless the caller renders asynchronously -- then the
+             * sample is skipped and that step of the trial repeated (tb_render_async enqueues, it never waits: no hipEventSynchronize
+             * here); and only if no other render has recorded the two events since (t.stamp, below) */
+            float ms = 0;
+            const bool mine = t.stamp == c->kernelEventStamp && hipEventQuery(c->evKernel) == hipSuccess && hipEventElapsedTime(&ms, c->evKernelStart, c->evKernel) == hipSuccess && ms > 0;
+            if (mine) { float& best = t.pending == 1 ? t.msWith : t.msWithout; best = best > 0 ? std::min(best, ms) : ms; (t.pending == 1 ? t.nWith : t.nWithout)++; }
+            else t.calls = t.pending == 1 ? 1 : 2; /* repeat the step whose sample was lost */
+            if (t.nWith >= 2 && t.nWithout >= 2) t.keep = t.msWith < 0.99f * t.msWithout; /* the faster of two samples per side */
+            t.pending = 0;
         }
+        if (t.calls == 0) { prepass = false; t.calls = 1; }
+        else if (t.nWith >= 2 && t.nWithout >= 2) prepass = t.keep;
+        else if (t.calls == 1) { prepass = true; t.pending = 1; t.stamp = c->kernelEventStamp + 1; t.calls = 2; }
+        else { prepass = false; t.pending = 2; t.stamp = c->kernelEventStamp + 1; t.calls = 1; }
     }
     c->lastPrimaryPrepass = prepass ? 1 : 0;
     /* launches of the kernels without the EXT features (no selected pixel, no AOVs: nothing but the sample buffer is written)
      * may overlap the drain of the launch before them */
-    const bool overlap = groups && v->features != PT_FEAT_ALL && opt("overlap_launches", 1) != 0;
+    const bool overlap = plan.overlap_launches != 0;
     if (!overlap) c->sideOrdered = false;
     c->kernelEventStamp++; /* this render records evKernelStart / evKernel */
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
@@ -928,35 +909,14 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
          * enough frames to form groups.  Option "frame_group" = G > 0 forces the group size, < 0 forbids the mode. */
         if (!groups) HIP_TRY(launch(c->stream, &dsLaunch, &pf, &tg, W, H, c->samplesRendered, n, &c->tiles, c->sceneInLds ? 1 : 0, count ? 1 : 0, (int)pipe));
         else {
-            const uint64_t pixels = (uint64_t)W * H, budget = (uint64_t)opt("pooled_samples", 256ll << 20);
-            uint32_t batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(n, 32768), budget / pixels)); /* a slot entry holds 15 bits of relative frame */
-            batch = (n + (n + batch - 1) / batch - 1) / ((n + batch - 1) / batch); /* equal batches: 128 frames under a 123-frame budget run as 64 + 64, not 123 + 5 */
-            /* automatic group size: about 24 576 work items per launch, rounded down to a power of two -- fine enough that the last
-             * items end together, coarse enough that claiming them does not show.  Measured on 1080p with launches enqueued back
-             * to back (bench.py): Cornell x 64 frames 6 370 / 6 730 / 6 870 / 6 910 / 6 850 Msamples/s at G = 4 / 8 / 16 / 32 / 64 (the
-             * rule gives 16), 870 k triangles x 16 frames 4 010 / 4 000 / 3 910 / 3 740 at G = 2 / 4 / 8 / 16 (the rule gives 4); an
-             * eighth of the frame (one rank of eight) is best at 2-4 */
+            /* batch and group sizes: launch_plan.h (with the measurements they come from) */
+            const uint64_t pixels = (uint64_t)W * H;
+            const uint32_t batch = plan.batch_frames;
             const uint64_t regions = std::max<uint64_t>(1, tb_persistent_grid(W, H, c->tiles));
-            const uint32_t frames = std::min(batch, n);
-            /* ... and for scenes fetched from memory at most 4 frames a group, however many frames the launch has (the 24 576-item rule
-             * was measured on launches of 16 frames; at 128 it chose 32): 870 k scene 1080p x 128, synchronous renders, G = 2 / 4 / 8 / 16 /
-             * 32: 4 440 / 4 513 / 4 495 / 4 401 / 4 167 Msamples/s with the pre-pass, 4 354 / 4 356 / 4 270 / 4 118 / 3 876 without;
-             * x 32 frames 3 966 / 4 003 / 3 768 / 3 479 / 2 846; van-class 4K x 8: 1 615 / 1 656 / 1 668 (scripts/fg_sweep.py) */
-            /* the feature sets with interior walks keep up to 16 (their trips are long, a lane parked at a slot's end loses more): van- /
-             * bistro-class 4K x 32 with the pre-pass, G = 2 / 4 / 8 / 16: 1 646 / 1 692 / 1 721 / 1 727 and 1 323 / 1 363 / 1 407 / 1 430
-             * (scripts/fg_sweep_4k.py) */
-            const uint64_t capG = c->sceneInLds ? 64 : ((v->features & PT_FEAT_SSS) ? 16 : 4);
-            /* a scene in LDS: half as many items (cornell-box x 64 frames, launches back to back, G = 8 / 16 / 32 / 64: 6 940 / 7 091 / 7 145 /
-             * 7 117 Msamples/s, scripts/fg_sweep_c2.py; the 24 576 rule gave 16) */
-            const uint64_t itemsWanted = c->sceneInLds ? 12288 : 24576;
-            const uint32_t autoG = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(frames, capG), std::max<uint64_t>(1, ((uint64_t)frames * regions + itemsWanted - 1) / itemsWanted));
+            if (regions > 0xfffffu) throw std::runtime_error("frame too large for the frame-group launch (more than 2^20 16x16 regions)");
             ensure(c->workCounter, 1024);
             tg.bandedItems = (uint32_t)opt("banded_items", 0);
-            tg.frameGroup = fg > 0 ? (uint32_t)fg : autoG;
-            while (tg.frameGroup & (tg.frameGroup - 1)) tg.frameGroup &= tg.frameGroup - 1; /* a power of two (rounded down): samples find their frame with shifts */
-            while ((frames + tg.frameGroup - 1) / tg.frameGroup > 4095u) tg.frameGroup *= 2;   /* a claimed item is group << 20 | region (claim_work_item) */
-            if (regions > 0xfffffu) throw std::runtime_error("frame too large for the frame-group launch (more than 2^20 16x16 regions)");
-            while (tg.frameGroup < frames && regions * ((frames + tg.frameGroup - 1) / tg.frameGroup) > (1ull << 21)) tg.frameGroup *= 2; /* at most 2^21 items a launch: slot logs hold 65 534 slots a workgroup */
+            tg.frameGroup = plan.frame_group;
             if (overlap && !c->sideOrdered) { /* first overlapped launch after other work on the main stream: order the side streams behind it once */
                 HIP_TRY(hipEventRecord(c->evMain, c->stream));
                 for (int i = 0; i < 2; i++) HIP_TRY(hipStreamWaitEvent(c->side[i], c->evMain, 0));
@@ -1507,6 +1467,19 @@ int tb_read_wave_profile(tb_context* c, uint64_t* out14)
         HIP_TRY(hipMemcpy(out14, (const char*)c->rayStats.p + 56, 14 * 8, hipMemcpyDeviceToHost));
         return TB_OK;
     });
+}
+
+void tb_plan_defaults(tb_plan_input* in)
+{
+    if (!in) return;
+    memset(in, 0, sizeof *in);
+    in->high_occupancy = 1; in->stack_overflow_max = 16; in->primary_prepass = 1; in->overlap_launches = 1; in->pooled_samples = 256ll << 20;
+}
+int tb_plan_launch(const tb_plan_input* in, tb_launch_plan* out)
+{
+    if (!in || !out || !in->width || !in->height) return TB_E_INVALID;
+    PlanLaunch(*in, *out);
+    return TB_OK;
 }
 
 int tb_read_split_profile(tb_context* c, uint64_t* out16)

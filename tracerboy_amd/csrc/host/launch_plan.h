@@ -1,0 +1,96 @@
+/* launch_plan.h -- WHICH kernels a render call launches and how, as a pure function of what is known before anything is enqueued:
+ * statistics of the loaded scene, the size of the call, the options.  renderImpl (context.cpp) executes the plan; tests/test_launch_plan.py
+ * walks every branch on the CPU through tb_plan_launch (include/tracerboy_hip.h).  The thresholds are measurements; each carries the
+ * numbers it came from (DESIGN.md section 6 has the tables). */
+#pragma once
+#include <stdint.h>
+#include <algorithm>
+#include "../../../include/tracerboy_hip.h"
+
+namespace tbhost {
+
+inline void PlanLaunch(const tb_plan_input& in, tb_launch_plan& p)
+{
+    p = tb_launch_plan{};
+    const bool plain = !in.count_rays && !in.aov && !in.realtime && !in.selected_pixel; /* the call writes nothing but radiance */
+    const int64_t pipe = in.pipeline == 4 ? 0 : in.pipeline; /* 4 = the split-role kernel where it exists, the lock-step kernel (0) elsewhere */
+    p.pipeline = (int32_t)pipe;
+    if (in.pipeline == 4 && in.variant_has_split && plain && !in.two_level) { p.pipeline = 4; p.rule_pipeline = TB_PLAN_RULE_SPLIT; return; }
+    if (pipe == 2 && in.variant_has_wavefront && !in.count_rays && !in.aov) { p.rule_pipeline = TB_PLAN_RULE_WAVEFRONT; return; }
+    if (pipe == 3 && in.variant_has_pooled && !in.count_rays && !in.aov) { p.rule_pipeline = TB_PLAN_RULE_POOLED; return; }
+    if (pipe == 2 || pipe == 3) p.pipeline = 0; /* feature sets these pipelines lack fall back to the lock-step kernel */
+    /* Frame-group mode: measured to win from 2 frames per call on (cornell-box 4 spp +23 %, 870 k scene 4 spp 2x); one frame per call:
+     * +17 % with the scene in LDS, -9 % on the 870 k scene.  Option frame_group > 0 forces it (and the group size), < 0 forbids it. */
+    p.groups = pipe == 0 && plain && in.frame_group >= 0 && (in.frame_group > 0 || in.frames >= (in.scene_in_lds ? 1u : 2u));
+    p.rule_pipeline = p.groups ? TB_PLAN_RULE_FRAME_GROUPS : TB_PLAN_RULE_ONE_PIXEL_PER_LANE;
+    /* Which copy of the feature set: the higher-occupancy one when its workgroups fit in LDS.  LDS per workgroup = 1 KB per stack entry
+     * (+ the scene image); where the tree is too deep for that, a frame-group launch may still use the copy with a split stack -- as
+     * many entries in LDS as fit, the deepest few (option stack_overflow_max, default 16) in global memory. */
+    p.stack_lds_entries = in.stack_depth;
+    if (in.variant_waves_hi && pipe == 0 && !in.count_rays && in.high_occupancy != 0) {
+        const uint64_t share = (160u * 1024u / in.variant_waves_hi) / 512u * 512u, fixed = (in.scene_in_lds ? in.lds_blob_bytes : 0u) + 128u;
+        const uint64_t ldsPerGroup = ((uint64_t)in.stack_depth * 1024u + fixed + 511u) / 512u * 512u; /* + static LDS, 512-B granules */
+        const int64_t forcedCap = in.stack_lds_cap; /* tests: split the stack although it would fit */
+        if (ldsPerGroup <= share && !(forcedCap > 0 && p.groups && (uint64_t)forcedCap < in.stack_depth)) { p.high_occupancy_copy = 1; p.rule_copy = TB_PLAN_RULE_COPY_FITS; }
+        else if (p.groups && share > fixed + 4u * 1024u) {
+            uint32_t cap = (uint32_t)((share - fixed) / 1024u);
+            if (forcedCap > 0) cap = std::min<uint32_t>(cap, (uint32_t)forcedCap);
+            const uint32_t over = in.stack_depth > cap ? in.stack_depth - cap : 0u;
+            if (over > 0 && over <= (uint32_t)in.stack_overflow_max) { p.high_occupancy_copy = 1; p.stack_lds_entries = cap; p.stack_overflow_entries = over; p.rule_copy = TB_PLAN_RULE_COPY_SPLIT_STACK; }
+            else p.rule_copy = TB_PLAN_RULE_COPY_TOO_DEEP;
+        } else p.rule_copy = TB_PLAN_RULE_COPY_NO_ROOM;
+    } else p.rule_copy = TB_PLAN_RULE_COPY_NONE;
+    /* Two-level scenes: the tuned walk lives in the frame-group kernels of the higher-occupancy copies; every other launch of an
+     * instanced scene goes to the full feature set, whose kernels carry the walk in all their forms */
+    if (in.two_level && !(p.high_occupancy_copy && p.groups)) { p.full_variant = 1; p.high_occupancy_copy = 0; p.stack_lds_entries = in.stack_depth; p.stack_overflow_entries = 0; p.rule_copy = TB_PLAN_RULE_COPY_FULL_FOR_INSTANCES; }
+    const bool ext = p.full_variant || (in.variant_features & TB_PLAN_FEAT_EXT) != 0, sss = !p.full_variant && (in.variant_features & TB_PLAN_FEAT_SSS) != 0;
+    /* Compact nodes (option node_layout = 1): frame-group kernels of the higher-occupancy copies, scenes fetched from memory */
+    p.compact_nodes = in.node_layout == 1 && in.has_compact_nodes && p.high_occupancy_copy && p.groups && !in.scene_in_lds && !in.two_level;
+    /* Primary-visibility pre-pass (option primary_prepass: 0 never, 2 wherever the kernels have it, 1 = the default policy):
+     * the kernels that have it -- frame-group launches of the higher-occupancy copies, and of `surf`, whose only copy carries it --
+     * on one-level scenes fetched from memory.  Default policy: calls of 2^24 samples or more (a second launch and its tail cost a
+     * small render ~50 us: -4 % at 640 x 360 x 16); AT ONCE where camera rays are a large part of all rays -- no interior walks and no
+     * lights to send a feeler to from every hit (configs[2] +8.8 %, Teapot +11 %) -- or where the feature set with interior walks runs a
+     * scene in which glass is one material among others (fewer than half of the triangles: van- / bistro-class 20 % / 10 %, +9 % / +8 %);
+     * BY TRIAL elsewhere (516 k triangles of glass blobs lose 5.6 % with it, the same scene in matte 1.2 %): renderImpl times the first
+     * calls of a kind both ways and keeps the faster (the pictures are the same bits either way). */
+    const bool prepassKernels = ((in.variant_waves_hi && p.high_occupancy_copy) || (!in.variant_waves_hi && in.variant_prepass_in_base && !p.full_variant && !p.stack_overflow_entries))
+                                && p.groups && !in.scene_in_lds && !in.two_level && !ext && in.max_bounces > 0;
+    p.prepass = TB_PLAN_PREPASS_OFF; p.rule_prepass = TB_PLAN_RULE_PREPASS_NO_KERNEL;
+    if (prepassKernels) {
+        p.rule_prepass = TB_PLAN_RULE_PREPASS_OPTION_OFF;
+        if (in.primary_prepass == 2) { p.prepass = TB_PLAN_PREPASS_ON; p.rule_prepass = TB_PLAN_RULE_PREPASS_FORCED; }
+        else if (in.primary_prepass == 1) {
+            if ((uint64_t)in.width * in.height * in.frames < (1ull << 24)) p.rule_prepass = TB_PLAN_RULE_PREPASS_SMALL_CALL;
+            else if (!sss && !in.has_lights) { p.prepass = TB_PLAN_PREPASS_ON; p.rule_prepass = TB_PLAN_RULE_PREPASS_ENV_LIT; }
+            else if (sss && in.interior_walk_triangle_share < 0.5f) { p.prepass = TB_PLAN_PREPASS_ON; p.rule_prepass = TB_PLAN_RULE_PREPASS_GLASS_AMONG_OTHERS; }
+            else { p.prepass = TB_PLAN_PREPASS_TRIAL; p.rule_prepass = TB_PLAN_RULE_PREPASS_TRIAL; }
+        }
+    }
+    /* launches of the kernels without the EXT features (no selected pixel, no AOVs: nothing but the sample buffer is written) may
+     * overlap the drain of the launch before them */
+    p.overlap_launches = p.groups && !ext && in.overlap_launches != 0;
+    if (!p.groups) return;
+    /* batches: the sample buffer holds option pooled_samples entries (16 B each, default 2^28); a slot entry holds 15 bits of relative
+     * frame; equal batches (128 frames under a 123-frame budget run as 64 + 64, not 123 + 5) */
+    const uint64_t pixels = (uint64_t)in.width * in.height, budget = (uint64_t)std::max<int64_t>(1, in.pooled_samples);
+    uint32_t batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(in.frames, 32768), budget / std::max<uint64_t>(pixels, 1)));
+    batch = (in.frames + (in.frames + batch - 1) / batch - 1) / ((in.frames + batch - 1) / batch);
+    p.batch_frames = batch;
+    /* Group size: about 24 576 work items per launch (half as many for a scene in LDS: cornell-box x 64 frames, G = 8 / 16 / 32 / 64:
+     * 6 940 / 7 091 / 7 145 / 7 117 Msamples/s), at most 4 frames a group for scenes fetched from memory (870 k scene x 128, G = 2 / 4 / 8 /
+     * 16 / 32: 4 440 / 4 513 / 4 495 / 4 401 / 4 167 with the pre-pass), 16 for the feature sets with interior walks (van- / bistro-class
+     * 4K x 32, G = 2 / 4 / 8 / 16: 1 646 / 1 692 / 1 721 / 1 727 and 1 323 / 1 363 / 1 407 / 1 430), 64 for scenes in LDS; a power of two
+     * (samples find their frame with shifts); at most 4 095 groups a region and 2^21 items a launch (slot logs, claim_work_item) */
+    const uint64_t regions = std::max<uint64_t>(1, in.owned_regions);
+    const uint32_t frames = std::min(batch, in.frames);
+    const uint64_t capG = in.scene_in_lds ? 64 : (sss ? 16 : 4), itemsWanted = in.scene_in_lds ? 12288 : 24576;
+    const uint32_t autoG = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(frames, capG), std::max<uint64_t>(1, ((uint64_t)frames * regions + itemsWanted - 1) / itemsWanted));
+    uint32_t G = in.frame_group > 0 ? (uint32_t)in.frame_group : autoG;
+    while (G & (G - 1)) G &= G - 1;
+    while ((frames + G - 1) / G > 4095u) G *= 2;
+    while (G < frames && regions * ((frames + G - 1) / G) > (1ull << 21)) G *= 2;
+    p.frame_group = G;
+}
+
+} // namespace tbhost

@@ -291,9 +291,12 @@ TBD void prof_hit(WaveProf* p, int slot)
     if ((int)(threadIdx.x & 63u) == __ffsll((long long)m) - 1) p->v[slot + 1] += 1; /* wave trips */
 }
 
-/* COUNT: box / triangle counters and the wave-occupancy profile; ALPHA: the IsValidHit filter on non-opaque candidates is compiled in
- * (it still needs ds.alphaTest at run time); HYBRID: split stack; NODEC: fetch layout-C nodes (ds.nodesC) instead of layout B. */
-template <bool COUNT, bool ALPHA, bool HYBRID = false, bool NODEC = false>
+/* RAY_COUNTERS: the ray's BoxesTested / TrianglesTested (TraverseFunction.hlsli:662,751) are kept -- counting launches, and the full
+ * feature set, whose heatmap output reads them (RayGenCommon.h:537-543); ALPHA: the IsValidHit filter on non-opaque candidates is
+ * compiled in (it still needs ds.alphaTest at run time); HYBRID: split stack; NODEC: fetch layout-C nodes (ds.nodesC) instead of layout B;
+ * PROFILE: the wave-occupancy profile (counting launches only).  One flag per thing a kernel pays for: the first parameter used to stand
+ * for "counters or the full feature set", one refactor away from changing who pays for what. */
+template <bool RAY_COUNTERS, bool ALPHA, bool HYBRID = false, bool NODEC = false, bool PROFILE = false>
 TBD bool traverse(const SceneRefs& sc, const TbDeviceScene& ds, tb3 o, tb3 d, Hit& best, uint32_t* stack, uint32_t stride,
                   uint32_t& boxes, uint32_t& tris, WaveProf* prof = nullptr, uint32_t* overflow = nullptr)
 {
@@ -318,11 +321,11 @@ TBD bool traverse(const SceneRefs& sc, const TbDeviceScene& ds, tb3 o, tb3 d, Hi
     };
     while (ref != DONE) {
         while (!(ref & TB_BVH_LEAF_FLAG)) {
-            if (COUNT) prof_hit(prof, PROF_INNER);
+            if (PROFILE) prof_hit(prof, PROF_INNER);
             float lt, rt; bool lh, rh; uint32_t nl, nr;
             if (NODEC) { const NodeC16 n = load_node_c(ds, ref); box_test2_c(lh, rh, lt, rt, best.t, r, n); nl = n.left; nr = n.right; }
             else { const TbNodeB n = load_node(sc, ref); box_test2(lh, rh, lt, rt, best.t, r, n); nl = n.left; nr = n.right; }
-            if (COUNT) boxes += 2;
+            if (RAY_COUNTERS) boxes += 2;
             if (lh && rh) {
                 bool rightFirst = rt < lt;
                 const uint32_t far = rightFirst ? nl : nr;
@@ -339,9 +342,9 @@ TBD bool traverse(const SceneRefs& sc, const TbDeviceScene& ds, tb3 o, tb3 d, Hi
             if (__popcll(__ballot(!(ref & TB_BVH_LEAF_FLAG))) < PARK_MIN) break;
         }
         if ((ref & TB_BVH_LEAF_FLAG) && ref != DONE) {
-            if (COUNT) prof_hit(prof, PROF_LEAF);
+            if (PROFILE) prof_hit(prof, PROF_LEAF);
             const TbTriB tri = load_tri(sc, sc.trisPermuted ? ref + r.permUnits : ref);
-            if (COUNT) tris++;
+            if (RAY_COUNTERS) tris++;
             tri_test<ALPHA>(best, MIN_T, o, r, tri, sc.trisPermuted != 0, sc, ds);
             ref = pop();
         }
@@ -369,7 +372,7 @@ TBD tb3 xfm_vector34(const float* m, tb3 v)
     return tb3_make(tb_fma(m[2], v.z, tb_fma(m[1], v.y, m[0] * v.x)), tb_fma(m[6], v.z, tb_fma(m[5], v.y, m[4] * v.x)), tb_fma(m[10], v.z, tb_fma(m[9], v.y, m[8] * v.x)));
 }
 
-template <bool COUNT, bool ALPHA, bool HYBRID = false>
+template <bool RAY_COUNTERS, bool ALPHA, bool HYBRID = false>
 TBD bool traverse_instanced(const SceneRefs& sc, const TbDeviceScene& ds, tb3 o, tb3 d, Hit& best, uint32_t* stack, uint32_t stride, uint32_t& boxes, uint32_t& tris,
                             uint32_t* overflow = nullptr)
 {
@@ -400,7 +403,7 @@ TBD bool traverse_instanced(const SceneRefs& sc, const TbDeviceScene& ds, tb3 o,
             const TbNodeB n = load_node(sc, ref);
             float lt, rt; bool lh, rh;
             box_test2(lh, rh, lt, rt, best.t, r, n);
-            if (COUNT) boxes += 2;
+            if (RAY_COUNTERS) boxes += 2;
             if (lh && rh) {
                 const bool rightFirst = rt < lt;
                 const uint32_t far = rightFirst ? n.left : n.right;
@@ -421,7 +424,7 @@ TBD bool traverse_instanced(const SceneRefs& sc, const TbDeviceScene& ds, tb3 o,
                 ref = in.blasRootRef;
             } else {
                 const TbTriB tri = load_tri(sc, ref);
-                if (COUNT) tris++;
+                if (RAY_COUNTERS) tris++;
                 /* committed record: InstanceContributionToHitGroupIndex + GeometryContributionToHitGroupIndex; the IsValidHit filter sees the
                  * same index (RayGenCommon.h:427: CandidateInstanceIndex() + CandidateGeometryIndex()) */
                 tri_test<ALPHA>(best, MIN_T, ro, r, tri, false, sc, ds, hitBase);
@@ -449,15 +452,15 @@ TBD bool trav_begin(Trav& t, const TbDeviceScene& ds, tb3 o, tb3 d) /* returns f
 }
 
 /* One while-while round for the lanes with `busy` set; clears `busy` when a lane's walk is complete. */
-template <bool COUNT, bool ALPHA, int PARK_MIN>
+template <bool RAY_COUNTERS, bool ALPHA, int PARK_MIN, bool PROFILE = false>
 TBD void trav_round(Trav& t, bool& busy, const SceneRefs& sc, const TbDeviceScene& ds, uint32_t* stack, uint32_t stride, WaveProf* prof)
 {
     while (busy && !(t.ref & TB_BVH_LEAF_FLAG)) {
-        if (COUNT) prof_hit(prof, PROF_INNER);
+        if (PROFILE) prof_hit(prof, PROF_INNER);
         const TbNodeB n = load_node(sc, t.ref);
         float lt, rt; bool lh, rh;
         box_test2(lh, rh, lt, rt, t.best.t, t.r, n);
-        if (COUNT) t.boxes += 2;
+        if (RAY_COUNTERS) t.boxes += 2;
         if (lh && rh) {
             bool rightFirst = rt < lt;
             stack[(t.top++) * stride] = rightFirst ? n.left : n.right;
@@ -471,9 +474,9 @@ TBD void trav_round(Trav& t, bool& busy, const SceneRefs& sc, const TbDeviceScen
     }
     if (busy && (t.ref & TB_BVH_LEAF_FLAG)) {
         if (t.ref != TRAV_DONE) {
-            if (COUNT) prof_hit(prof, PROF_LEAF);
+            if (PROFILE) prof_hit(prof, PROF_LEAF);
             const TbTriB tri = load_tri(sc, sc.trisPermuted ? t.ref + t.r.permUnits : t.ref);
-            if (COUNT) t.tris++;
+            if (RAY_COUNTERS) t.tris++;
             tri_test<ALPHA>(t.best, MIN_T, t.r.o, t.r, tri, sc.trisPermuted != 0, sc, ds);
             t.ref = t.top ? stack[(--t.top) * stride] : TRAV_DONE;
         }
