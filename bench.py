@@ -49,17 +49,21 @@ def parse_args(argv=None):
     ap.add_argument("--spp", type=int, default=64)
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--scene", default="cornell-box")  # or proc0:<tris> / proc1:<tris> / proc2:<tris> / path.pbrt
-    ap.add_argument("--builder", type=int, default=1)  # 0 LBVH, 1 binned SAH + reinsertion, 2 LBVH on the GPU, 3 LBVH + treelet passes (the reference's tree), 4 the same on the GPU
+    ap.add_argument("--builder", type=int, default=None)  # default: 1 -- except at --gpus > 1 on procedural scenes, where it is 4 (eight ranks each running the 58-s SAH build on a 16-CPU quota would dominate the run's wall clock; the timed region never sees the build) -- 0 LBVH, 1 binned SAH + reinsertion, 2 LBVH on the GPU, 3 LBVH + treelet passes (the reference's tree), 4 the same on the GPU
     ap.add_argument("--pipeline", type=int, default=0)  # 0 = lock-step bounce (fastest measured), 1 = streaming, 2 = wavefront queues, 3 = pooled
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=INT")  # extra tb_set_option()s, applied before the scene is loaded
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-readback", action="store_true")   # skip the PCIe-inclusive side measurement
-    ap.add_argument("--no-c3", action="store_true")         # skip the second roofline object (configs[2] at 128 spp)
+    ap.add_argument("--no-c3", action="store_true")         # skip the further roofline objects (configs[2] at 128 spp, the 4K scenes, Teapot)
+    ap.add_argument("--legs", default="c3,c4,c5,teapot")     # which of them the default run renders after its timed region (N = 1, cornell-box, pipeline 0)
     ap.add_argument("--async-steps", action="store_true")  # run the N > 1 step pipeline (async render + pack + stream-ordered consumer) on one GPU
     ap.add_argument("--sync-steps", action="store_true")   # N = 1: wait for every render before enqueuing the next (default: enqueue the K steps, wait once)
     ap.add_argument("--cpu-baseline-seconds", type=float, default=10.0)
     ap.add_argument("--selftest-cpu", action="store_true")  # plumbing test without a GPU: spawn -> gloo rendezvous -> tile gather -> assemble -> one JSON line (tests/)
-    return ap.parse_args(argv)
+    a = ap.parse_args(argv)
+    if a.builder is None:
+        a.builder = 4 if (a.gpus > 1 and a.scene.startswith("proc")) else 1
+    return a
 
 
 # --------------------------------------------------------------------------------------------- self-spawn
@@ -253,6 +257,61 @@ def hbm_roofline(avg_ms, frames, pixels, st, passes, src):
     return r
 
 
+def expected_speedup(scene, W, H, spp, depth, world):
+    """What the tile split should give at this N, from the one-GPU stand-in measurement of a rank's own-tiles render, pack and un-permute
+    (scripts/gather_standin.py -> profiles/rN/gather_standin.json) plus one xGMI hop of its packed tiles; render k + 1 overlaps gather k, so a
+    step is the render and a fraction of a millisecond of exposed tail.  The driver computes the measured efficiency from its own per-N runs."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "gather_standin.json")), key=lambda f: int(re.search(r"profiles/r(\d+)", f).group(1)))
+    if not files or (scene, W, H, spp, depth) != ("cornell-box", 1920, 1080, 64, 8): return None
+    d = json.load(open(files[-1]))
+    one, mine, hop = d.get("c2_rank0_of_1"), d.get("c2_rank0_of_%d" % world), d.get("1080p_world%d" % world)
+    if not one or not mine: return None
+    step = mine["render_ms"] + 0.1       # exposed tail of the pipelined step (pack + un-permute + what the gather does not hide)
+    return {"vs_1gpu": round(one["render_ms"] / step, 2), "render_ms_per_rank": mine["render_ms"], "gather_hop_us": hop["xgmi_hop_estimate_us"] if hop else None,
+            "source": os.path.relpath(files[-1], ROOT), "note": "one GPU emulating rank 0 of N; no multi-GPU hardware was available to the build"}
+
+
+TEAPOT = os.path.join(ROOT, "tests", "golden", "scenes", "Teapot", "scene.pbrt")
+EXTRA_LEGS = {   # key -> (scene, builder, W, H, spp, depth): the configurations the 8 GPUs divide, and the reference's own textured scene
+    "c4": ("proc1:700000", 4, 3840, 2160, 8, 6),      # BASELINE configs[3] class: 0.7 M triangles with glass, 4K (8 of its 256 spp per step)
+    "c5": ("proc2:2980000", 4, 3840, 2160, 8, 16),    # BASELINE configs[4] class: 2.98 M triangles, 40 materials, depth 16 (8 of its 1024 spp per step)
+    "teapot": (TEAPOT, 1, 1920, 1080, 16, 8),         # /root/reference/Scenes/Teapot as committed under tests/golden: 126 k triangles, textures + env + GGX
+}
+
+
+def extra_leg(tb, api, np, torch, load, key, steps=3):
+    """One more workload under the driver's clock: loaded, warmed, `steps` renders enqueued back to back and waited for once (like the
+    timed region), then launches run one at a time for the roofline figures; counters from profiles/rN/<key>_{pmc_summary,mem_counters}.json."""
+    scene, builder, W, H, SPP, D = EXTRA_LEGS[key]
+    s = api.GetDefaultOutputSettings(); s.EnableBlueNoise = 0; s.MaxBounces = D
+    tb.SetOption("bvh_builder", builder)
+    load_s = load(scene)
+    info = tb.SceneInfo()
+    tb.InvalidateHistory(); tb.Render(W, H, SPP, s, 0.0)      # warm-up (first launch of this kernel copy, buffers)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(steps):
+        tb.InvalidateHistory(); tb.Render(W, H, SPP, s, 0.0, sync=False)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    variant = ["matte", "env", "surf", "vol", "full", "sss"][tb.GetOption("last_variant")]
+    prepass = bool(tb.GetOption("last_primary_prepass"))
+    avg, frames, st = measure_kernel(tb, api, np, W, H, SPP, s, steps)
+    passes, src = pmc_summary(key)
+    r = hbm_roofline(avg, frames, W * H, st, passes, src)
+    r.update({"workload": "%s %dx%d %dspp depth%d" % (os.path.basename(os.path.dirname(scene)) if scene.endswith(".pbrt") else scene, W, H, SPP, D), "triangles": int(info.numTriangles),
+              "value": round(W * H * SPP * steps / dt / 1e6, 1), "unit_value": "Msamples/s", "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps, "scene_load_s": round(load_s, 2),
+              "bvh_builder": ("lbvh", "sah", "lbvh-gpu", "lbvh+treelets", "lbvh+treelets-gpu")[builder], "kernel_variant": variant, "primary_prepass": prepass,
+              "kernel": "pt_primary + pt_persistent" if prepass else "pt_persistent", "pipes": derived_busy(key, passes), "pmc_stale": bool(passes and passes.get("_stale")),
+              "algorithmic": {"achieved": None, "unit": "GB/s", "peak": HBM_PEAK_GBS, "note": "SURVEY 8d byte model x samples / launch time; served mostly by L2 / Infinity Cache (traffic_GBs is what the fabric carries)"}})
+    r["algorithmic"]["achieved"] = r["achieved"]; r["algorithmic"]["frac"] = r["frac"]
+    pipes = r["pipes"]
+    if pipes.get("ta_busy") is not None:   # like roofline_c3: the busier of the two issue pipes the counters show
+        busiest = max(("vmem_issue", pipes["ta_busy"]), ("valu", pipes.get("valu_busy", 0.0)), key=lambda kv: kv[1])
+        r.update({"bound": busiest[0], "frac": busiest[1], "achieved": busiest[1], "peak": 1.0, "unit": "busy fraction of the launch (TA_TA_BUSY / 256 TAs, or 4 x SQ_ACTIVE_INST_VALU / 1024 SIMDs)"})
+    return r
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -399,12 +458,14 @@ def main():
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s %dx%d %dspp depth%d" % (args.scene, W, H, SPP, args.depth), "triangles": int(info.numTriangles),
-                   "bvh_builder": ("lbvh", "sah", "lbvh-gpu", "lbvh+treelets", "lbvh+treelets-gpu")[args.builder], "pipeline": ("lockstep", "stream", "wavefront", "pooled")[args.pipeline], "tile": TILE if world > 1 else None,
+                   "bvh_builder": ("lbvh", "sah", "lbvh-gpu", "lbvh+treelets", "lbvh+treelets-gpu")[args.builder], "pipeline": ("lockstep", "stream", "wavefront", "pooled", "split")[tb.GetOption("last_pipeline")], "tile": TILE if world > 1 else None,
                    "parallelism": "tiles%d" % world, "scene_in_lds": bool(tb.GetOption("scene_in_lds_active")),
                    "kernel_variant": ["matte", "env", "surf", "vol", "full", "sss"][tb.GetOption("last_variant")], "scene_load_s": round(load_s, 3)},
     }
 
     if world > 1:
+        tl = torch.tensor([load_s], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64); dist.all_reduce(tl, op=dist.ReduceOp.MAX)
+        result["config"]["scene_load_s"] = round(float(tl.item()), 3); result["config"]["scene_load_s_note"] = "max over ranks (every rank loads and builds the scene itself)"
         # ---- where a step's time goes, per rank (after the timed region, stages run one at a time with a device sync between them, so
         #      the figures are each stage's own cost, not its share of the overlapped pipeline): this rank's own-tiles render, the
         #      device-side pack of its tiles, the gather to rank 0 (RCCL over xGMI; every rank's buffer is `capacity` pixels) and rank 0's
@@ -434,6 +495,8 @@ def main():
         result["scale_breakdown"].update({"mean_over_ranks": {k: round(float(sm[i]) / world, 3) for i, k in enumerate(stages)},
                                           "gather_bytes_per_rank": int(capacity) * 16, "owned_pixels_rank0": int(owned),
                                           "note": "stages run one at a time after the timed region (best of 3, max over ranks); in the timed steps render k+1 overlaps gather k"})
+        exp = expected_speedup(args.scene, W, H, SPP, args.depth, world)
+        if exp: result["expected_speedup"] = exp
         result["rccl_ranks"] = int(dist.get_world_size())
         result["collective_backend"] = backend
         # after the timed region: the frame rank 0 assembled from the gathered tiles equals a single-GPU render of the whole frame
@@ -459,10 +522,15 @@ def main():
             avg_ms = float(np.mean(kernel_ms)); launch_frames = tb.GetOption("last_kernel_frames")
             tb.SetOption("count_rays", 1); tb.Render(W, H, 1, s, 0.0); st = tb.ReadbackStats().rays; tb.SetOption("count_rays", 0)
         key = {("cornell-box", 1920, 1080, 64, 8): "c2", ("proc0:870000", 1920, 1080, 128, 6): "c3", ("proc0:870000", 1920, 1080, 16, 6): "c3_16spp"}.get((args.scene, W, H, SPP, args.depth))
-        passes, src = pmc_summary(key) if (key and world == 1 and args.pipeline == 0) else (None, None)
+        # N > 1: the committed counters are of the single-GPU launch of the same workload (a rank's own-tiles launch runs the same kernel on
+        # 1/N of the regions); they stay in the line, marked, so that the N = 1 and N > 1 records carry the same fields
+        passes, src = pmc_summary(key) if (key and args.pipeline == 0) else (None, None)
         pixels = W * H if world == 1 else owned
         hbm = hbm_roofline(avg_ms, launch_frames, pixels, st, passes, src)
         hbm["launch_timing"] = launch_timing
+        if world > 1:
+            hbm["per_rank"] = {"owned_pixels_rank0": int(owned), "avg_launch_ms_rank0": round(avg_ms, 3), "note": "rank 0's own-tiles launch; counters (traffic, pipes) are per launch of the SINGLE-GPU workload, from " + str(src)}
+            if hbm.get("traffic"): hbm["traffic"] = None; hbm.pop("traffic_GBs", None); hbm.pop("traffic_frac_of_peak", None)   # a per-launch byte count of another launch shape is not this launch's traffic
         insts = passes.get("lds", {}).get("SQ_INSTS_VALU") if passes else None
         pmc_stale = bool(passes and passes.get("_stale"))
         if pmc_stale: insts = None      # an instruction count of other code says nothing about this build's issue rate
@@ -490,7 +558,7 @@ def main():
             result["roofline"] = hbm
 
         # ---- second object: configs[2] at its full 128 spp, the workload whose roofline IS HBM ---------
-        if world == 1 and not args.no_c3 and args.scene == "cornell-box" and args.pipeline == 0:
+        if world == 1 and not args.no_c3 and args.scene == "cornell-box" and args.pipeline == 0 and "c3" in args.legs.split(","):
             W3, H3, SPP3, D3 = 1920, 1080, 128, 6
             s3 = api.GetDefaultOutputSettings(); s3.EnableBlueNoise = 0; s3.MaxBounces = D3
             load3 = load("proc0:870000")
@@ -544,7 +612,12 @@ def main():
                                        "contract": "relative L2 <= 1e-4 against the bit-exact layout-B path (tests/test_compact_nodes.py), not bit equality"}
             tb.SetOption("node_layout", 0)
             result["roofline_c3"] = r3
-            load(args.scene)   # back to the timed workload for the CPU baseline below
+            tb.SetOption("bvh_builder", args.builder); load(args.scene)   # back to the timed workload for the CPU baseline below
+        # ---- the configurations the 8 GPUs divide (4K glass scenes) and the reference's own Teapot, each a few steps under the driver's clock
+        if world == 1 and not args.no_c3 and args.scene == "cornell-box" and args.pipeline == 0:
+            for leg in [x for x in args.legs.split(",") if x in EXTRA_LEGS]:
+                result["roofline_" + leg] = extra_leg(tb, api, np, torch, load, leg)
+            tb.SetOption("bvh_builder", args.builder); load(args.scene)
 
         # ---- CPU baseline: the scalar oracle on a bounded sample of the same workload ------------------
         # ---- the same render with the frame handed to the host (tb_read_accum: one D2H copy of the RGBA32F sums into a host
@@ -561,7 +634,7 @@ def main():
             result["pcie_inclusive"] = {"value": round(samples_per_step / t_rb / 1e6, 3), "unit": "Msamples/s", "ms_per_step": round(t_rb * 1e3, 3),
                                         "readback_bytes": int(host.nbytes), "note": "render + tb_read_accum into pageable host memory, synchronous, %d steps" % n_rb}
 
-        if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only
+        if not args.no_cpu_baseline:   # rank 0 (the other ranks wait at the closing barrier): the same leg at every N, so that the records carry the same fields
             import oracle_lib as ol
             allowance = cpu_allowance()
             cores = len(os.sched_getaffinity(0))      # the CPUs this process may run on, not the machine's ...

@@ -816,7 +816,7 @@ def test_bench_multi_rank_step_on_one_gpu(tmp_path):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(TB_BENCH_SHARE_DEVICE="1", TB_BENCH_BACKEND="gloo")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--width", "712", "--height", "400", "--spp", "6",
-                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env)
+                        "--cpu-baseline-seconds", "1"], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout
@@ -829,6 +829,10 @@ def test_bench_multi_rank_step_on_one_gpu(tmp_path):
     assert out["rccl_ranks"] == 2 and out["collective_backend"] == "gloo"
     assert all(sb[k] > 0 for k in ("render_ms", "pack_ms", "gather_ms", "unpack_ms")) and sb["gather_bytes_per_rank"] > 0
     assert set(sb["mean_over_ranks"]) == {"render_ms", "pack_ms", "gather_ms", "unpack_ms"}
+    # the N > 1 line carries the fields of the N = 1 line: a roofline block (rank 0's launch) and the CPU baseline leg (rank 0), plus the
+    # slowest rank's scene load
+    assert out["roofline"]["avg_launch_ms"] > 0 and out["roofline"]["per_rank"]["owned_pixels_rank0"] > 0
+    assert out["cpu_baseline"]["value"] > 0 and out["cpu_baseline"]["kind"] == "port" and out["config"]["scene_load_s"] > 0
 
 
 def test_headless_cli_native_rccl_gather_plumbing(tmp_path):
