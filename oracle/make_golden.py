@@ -44,6 +44,14 @@ def digest_records(path):
     return out
 
 
+def write_digest(scene_path, out_json):
+    """The REFERENCE parser's reading of scene_path (oracle/_ref/pbrt_dump) as per-record sha256 digests."""
+    tmp = "/tmp/tb_ref_dump_%d.txt" % os.getpid()
+    subprocess.run([DUMP, scene_path, tmp], check=True, stdout=subprocess.DEVNULL)
+    json.dump(digest_records(tmp), open(out_json, "w"), indent=0)
+    os.remove(tmp)
+
+
 def write_rgbe(path, img):
     """Radiance .hdr, flat (non-RLE) scanlines, -Y H +X W."""
     h, w, _ = img.shape

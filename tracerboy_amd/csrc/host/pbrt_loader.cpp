@@ -194,8 +194,10 @@ private:
             if (has(ps, "uroughness") && !isTexture(ps, "uroughness")) m->uRoughness = get1f(ps, "uroughness", 0.f);
             if (has(ps, "vroughness") && !isTexture(ps, "vroughness")) m->vRoughness = get1f(ps, "vroughness", 0.f);
             if (has3f(ps, "eta")) get3f(ps, "eta", m->eta3);
-        } else if (type == "glass") { /* :671-688 */
-            m->kr = Vec3(1.f); m->kt = Vec3(1.f); m->index = get1f(ps, "index", 1.5f);
+        } else if (type == "glass") { /* :671-688; createMaterial_glass (impl/semantic/Materials.cpp:411-420) ASSIGNS getParam1f("index"), whose fall-back is 0: a glass
+                                       * without an "index" parameter has index 0 in the reference, not the struct's 1.5 (found by the reference's own vw-van scene, whose
+                                       * three glass materials name no index; tests/golden/vw-van.parser.digest.json) */
+            m->kr = Vec3(1.f); m->kt = Vec3(1.f); m->index = get1f(ps, "index", 0.f);
             get3f(ps, "Kr", m->kr); get3f(ps, "Kt", m->kt);
         } else if (type == "disney") { /* :425-452 + createMaterial_disney defaults */
             m->color = Vec3(.5f); get3f(ps, "color", m->color);
