@@ -326,3 +326,33 @@ def test_gpu_built_two_level_structures_equal_the_host_build(gpu_tb, gpu_builder
         rng = np.random.default_rng(4); d = rng.normal(size=(2000, 3)).astype(np.float32); d[:, 1] -= 0.5; d[:, 2] -= 1.0; d /= np.linalg.norm(d, axis=1, keepdims=True)
         g = gpu_tb.TraceClosest(o, d); c = ol.trace_closest(gv, o, d)
         assert np.array_equal(bits(g["t"]), bits(c["t"])) and np.array_equal(g["geom"], c["geom"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["matte", "glass"])
+def test_instanced_scene_as_the_first_render_of_a_fresh_context(settings, kind, tmp_path):
+    """the first frame-group render of a two-level scene in a FRESH context used to fail -- the stream warm-up launched
+    the one-pixel-per-lane form of the tuned copy, which that copy does not have for instanced scenes -- and every later call with it.
+    The session-wide context of the other tests had always warmed the launcher with another scene first."""
+    from tracerboy_amd import api
+    text = open(SCENE).read()
+    if kind == "matte":
+        text = text.replace('"string type" ["plastic"] "rgb Kd" [0.1 0.3 0.7] "rgb Ks" [0.4 0.4 0.4] "float roughness" [0.1]', '"string type" ["matte"] "rgb Kd" [0.1 0.3 0.7]')
+        text = text.replace('"string type" ["metal"] "float uroughness" [0.15] "float vroughness" [0.15] "rgb eta" [0.9 0.9 0.9]', '"string type" ["matte"] "rgb Kd" [0.6 0.6 0.65]')
+    else:
+        text = text.replace('"string type" ["plastic"] "rgb Kd" [0.1 0.3 0.7] "rgb Ks" [0.4 0.4 0.4] "float roughness" [0.1]', '"string type" ["glass"] "float index" [1.45]')
+    p = tmp_path / "scene.pbrt"; p.write_text(text)
+    for f in os.listdir(os.path.dirname(SCENE)):
+        if f != "scene.pbrt":
+            src = os.path.join(os.path.dirname(SCENE), f)
+            if os.path.isfile(src): (tmp_path / f).write_bytes(open(src, "rb").read())
+    s = copy.copy(settings); s.MaxBounces = 5
+    with api.TracerBoy(0) as tb:
+        tb.SetOption("flatten_instances", 0)
+        tb.LoadScene(str(p))
+        tb.Render(W, H, 9, s, 0.0)                                   # 9 frames: a frame-group launch, overlapped, the context's very first render
+        out = tb.ReadAccumulation()
+        ref = ol.render(tb.HostSceneView(), tb.FrameConstants(W, H, 0, s, 0.0), W, H, 9, threads=8)
+        assert np.array_equal(bits(out), bits(ref["output"]))
+        tb.InvalidateHistory(); tb.Render(W, H, 9, s, 0.0)           # and again
+        assert np.array_equal(bits(tb.ReadAccumulation()), bits(ref["output"]))

@@ -139,6 +139,7 @@ struct tb_context {
     int lastNodeLayout = 0; /* 1: the last render walked the compact layout-C nodes */
     int lastSlotLogCap = 0;
     struct PrepassTrial { uint64_t key = 0; int calls = 0, pending = 0, nWith = 0, nWithout = 0; float msWith = 0, msWithout = 0; bool keep = false; uint64_t stamp = 0; } prepassTrial; /* renderImpl */
+    tb_launch_plan lastPlan{}; /* what PlanLaunch decided for the last render (options last_plan_rule_*) */
     uint64_t kernelEventStamp = 0; /* counts the renders that have recorded evKernelStart / evKernel: a trial's sample belongs to the render it was asked of */
     uint32_t sceneGeneration = 0; /* counts finalizeScene calls */
     float interiorWalkTriangleShare = 0; /* finalizeScene */
@@ -887,7 +888,7 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
         else if (t.calls == 1) { prepass = true; t.pending = 1; t.stamp = c->kernelEventStamp + 1; t.calls = 2; }
         else { prepass = false; t.pending = 2; t.stamp = c->kernelEventStamp + 1; t.calls = 1; }
     }
-    c->lastPrimaryPrepass = prepass ? 1 : 0;
+    c->lastPrimaryPrepass = prepass ? 1 : 0; c->lastPlan = plan;
     /* launches of the kernels without the EXT features (no selected pixel, no AOVs: nothing but the sample buffer is written)
      * may overlap the drain of the launch before them */
     const bool overlap = plan.overlap_launches != 0;
@@ -1574,6 +1575,11 @@ int64_t tb_get_option(tb_context* c, const char* name)
     if (!strcmp(name, "debug_slot_log_cap")) return c->lastSlotLogCap;
     if (!strcmp(name, "debug_fg_samples_ptr")) return (int64_t)(uintptr_t)c->fgSamples[c->lastFgPar].p; /* device address of the sample buffer of the last frame-group launch (scripts/lost_item_stress.py) */
     if (!strcmp(name, "last_node_layout")) return c->lastNodeLayout; /* 0: layout B (64-B nodes), 1: layout C (32-B nodes on the 16-bit grid) */
+    if (!strcmp(name, "last_plan_rule_pipeline")) return c->lastPlan.rule_pipeline; /* TB_PLAN_RULE_* of the last render (tracerboy_hip.h) */
+    if (!strcmp(name, "last_plan_rule_copy")) return c->lastPlan.rule_copy;
+    if (!strcmp(name, "last_plan_rule_prepass")) return c->lastPlan.rule_prepass;
+    if (!strcmp(name, "last_plan_frame_group")) return c->lastPlan.frame_group;
+    if (!strcmp(name, "last_plan_stack_overflow")) return c->lastPlan.stack_overflow_entries;
     if (!strcmp(name, "last_split_waves")) return c->lastSplitWaves; /* traversal waves * 100 + shading waves per workgroup of the last pipeline-4 launch */
     if (!strcmp(name, "last_pipeline")) return c->lastPipeline; /* the pipeline the last render actually ran (2 / 3 fall back to 0 for feature sets they lack) */
     if (!strcmp(name, "last_variant")) { for (const Variant& k : kVariants) if (c->lastVariant == k.name) return k.id; return -1; } /* 0 matte 1 env 2 surf 3 vol 4 full 5 sss */
