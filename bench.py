@@ -548,6 +548,7 @@ def main():
                 roof.update({"achieved": None, "frac": None, "note": ("the committed PMC passes (%s) were taken of other kernel code (kernel digest differs): re-run scripts/profile_bench.sh" % src) if pmc_stale
                              else "no committed PMC pass for this workload: instruction count unknown"})
             roof["pipes"] = derived_busy(key, passes) if key else {}
+            if world > 1: roof["per_rank"] = hbm["per_rank"]
             roof["pmc_stale"] = pmc_stale
             roof["algorithmic"] = {k: hbm[k] for k in ("achieved", "unit", "algorithmic_bytes_per_sample", "boxes_per_sample", "tris_per_sample", "rays_per_sample")}
             roof["algorithmic"]["note"] = "SURVEY 8d byte model; served by the LDS scene image, not HBM (achieved / 8 TB/s = %.2f says nothing about HBM)" % (hbm["achieved"] / HBM_PEAK_GBS)

@@ -16,6 +16,7 @@ def main():
     ap.add_argument("--scene", default="cornell-box"); ap.add_argument("--width", type=int, default=1920); ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=64); ap.add_argument("--depth", type=int, default=8); ap.add_argument("--builder", type=int, default=1)
     ap.add_argument("--configs", default="4x4"); ap.add_argument("--reps", type=int, default=3); ap.add_argument("--out", default="")
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=INT", help="extra options for every split config")
     ap.add_argument("--profile", action="store_true", help="one more render per config with the counting copy: occupancies, sleeps, cycles per step")
     ap.add_argument("--async-steps", type=int, default=0, help="also time N back-to-back async renders (overlapped launches)")
     a = ap.parse_args()
@@ -45,6 +46,8 @@ def main():
     tb.SetOption("pipeline", 0)
     r = timed("pipeline0"); ref = tb.ReadAccumulation().copy(); res.append(r); print(json.dumps(r), flush=True)
     tb.SetOption("pipeline", 4)
+    for kv in a.opt:
+        k, v = kv.split("="); tb.SetOption(k, int(v))
     for cfg in a.configs.split(","):
         parts = cfg.split(":"); t, sh = parts[0].split("x")
         vals = [int(x) for x in parts[1:]] + [None] * 4

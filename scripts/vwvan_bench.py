@@ -13,6 +13,7 @@ RULES = {10: "no tuned copy", 11: "tuned copy fits", 12: "tuned copy, split stac
 tb = api.TracerBoy(0)
 s = api.GetDefaultOutputSettings(); s.EnableBlueNoise = 0; s.MaxBounces = 6
 W, H, F = 3840, 2160, 8
+if len(sys.argv) > 2: W, H, F = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
 out = {"scene": "vw-van (reference Scenes/vw-van minus mesh_00125.ply, synthetic sky) %dx%dx%d depth %d" % (W, H, F, s.MaxBounces), "rows": []}
 for flatten in (1, 0):
     tb.SetOption("flatten_instances", flatten); tb.SetOption("bvh_builder", 4)
@@ -20,15 +21,16 @@ for flatten in (1, 0):
     info = tb.SceneInfo(); pictures = []
     for pre, name in ((0, "never"), (2, "forced"), (1, "default")):
         tb.SetOption("primary_prepass", pre); ts = []
-        for r in range(8 if pre == 1 else 4):          # the default policy may try both ways over its first calls
+        for r in range((8 if pre == 1 else 4) if flatten else 2):          # the default policy may try both ways over its first calls
             tb.InvalidateHistory(); t = time.perf_counter(); tb.Render(W, H, F, s, 0.0); ts.append(time.perf_counter() - t)
         pictures.append(tb.ReadAccumulation())
-        row = {"instances": "flattened" if flatten else "two-level (240 instances)", "prepass_option": name, "Msamples_per_s": round(W * H * F / float(np.median(ts[-3:])) / 1e6, 1),
+        row = {"instances": "flattened" if flatten else "two-level (240 instances)", "prepass_option": name, "Msamples_per_s": round(W * H * F / float(np.median(ts[-3:] if flatten else ts[-1:])) / 1e6, 2),
                "prepass_used": bool(tb.GetOption("last_primary_prepass")), "variant": ["matte", "env", "surf", "vol", "full", "sss"][tb.GetOption("last_variant")],
                "copy_rule": RULES.get(tb.GetOption("last_plan_rule_copy")), "prepass_rule": RULES.get(tb.GetOption("last_plan_rule_prepass")),
                "frame_group": tb.GetOption("last_plan_frame_group"), "stack_overflow_entries": tb.GetOption("last_plan_stack_overflow"),
                "triangles": int(info.numTriangles), "bvh_nodes": int(info.bvhNodesB), "bvh_depth": int(info.bvhMaxDepth), "load_s": round(load_s, 2)}
         out["rows"].append(row); print(json.dumps(row), flush=True)
+        if len(sys.argv) > 1: json.dump(out, open(sys.argv[1], "w"), indent=1)
     out.setdefault("bit_identical_across_prepass", []).append(bool(all(np.array_equal(pictures[0].view(np.uint32), p.view(np.uint32)) for p in pictures[1:])))
 tb.SetOption("primary_prepass", 1); tb.SetOption("flatten_instances", 1); tb.SetOption("bvh_builder", 0)
 # the split-role kernel has no feature set with mix materials: pipeline 4 falls back to the lock-step kernel here

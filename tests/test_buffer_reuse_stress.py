@@ -1,0 +1,56 @@
+"""-m gpu: short form of scripts/lost_item_stress.py in the suite.  Frame-group renders cycle through THREE random
+streams (time seed 0 / 1 / 2) over the TWO alternating sample / hit-record buffers, so that a buffer's previous content always differs
+from what the next launch must write: a work item bound and never rendered, a hit record or a slot-log row served as an earlier launch
+left it, shows as a wrong picture -- the same picture rendered twice could never show it.  Three frame sizes: 200 x 120 (buffers stay
+L2-resident: where round 3 saw stale records), 1920 x 1080, 3840 x 2160.  Reference pictures: the one-pixel-per-lane kernel (no sample
+buffer, no records), itself held to the oracle on a strip."""
+import copy
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+@pytest.mark.parametrize("W,H,F,reps,tris", [(200, 120, 9, 45, 30000), (1920, 1080, 8, 9, 60000), (3840, 2160, 4, 6, 60000)])
+@pytest.mark.parametrize("mode", ["prepass_forced", "default", "split_kernel"])
+def test_three_streams_over_two_buffers(gpu_tb, settings, W, H, F, reps, tris, mode):
+    s = copy.copy(settings); s.MaxBounces = 6
+    gpu_tb.SetOption("bvh_builder", 4)
+    try:
+        gpu_tb.LoadProcedural(1 if mode != "split_kernel" else 0, tris, 7)      # glass among other things (feature set sss) / matte + environment for the split-role kernel
+    finally:
+        gpu_tb.SetOption("bvh_builder", 0)
+    refs = []
+    gpu_tb.SetOption("frame_group", -1)                                          # one pixel per lane: the reference pictures
+    try:
+        for t in (0.0, 1.0, 2.0):
+            gpu_tb.InvalidateHistory(); gpu_tb.Render(W, H, F, s, t); refs.append(gpu_tb.ReadAccumulation())
+    finally:
+        gpu_tb.SetOption("frame_group", 0)
+    y0 = (H // 2) & ~7
+    strip = ol.render(gpu_tb.HostSceneView(), gpu_tb.FrameConstants(W, H, 0, s, 1.0), W, H, F, y0=y0, y1=y0 + 8, threads=8)["output"]
+    assert np.array_equal(bits(refs[1][y0:y0 + 8]), bits(strip[y0:y0 + 8]))
+    assert not np.array_equal(bits(refs[0]), bits(refs[1])) and not np.array_equal(bits(refs[1]), bits(refs[2]))
+    gpu_tb.SetOption("primary_prepass", 2 if mode == "prepass_forced" else 1)
+    gpu_tb.SetOption("pipeline", 4 if mode == "split_kernel" else 0)
+    try:
+        for rep in range(reps):
+            t = rep % 3
+            gpu_tb.InvalidateHistory()
+            if rep % 4 == 3:                                                     # some calls asynchronous and back to back: launches of consecutive calls overlap on the side streams
+                gpu_tb.Render(W, H, F, s, float(t), sync=False); gpu_tb.InvalidateHistory(); gpu_tb.Render(W, H, F, s, float(t), sync=False); gpu_tb.Sync()
+            else:
+                gpu_tb.Render(W, H, F, s, float(t))
+            if mode == "split_kernel": assert gpu_tb.GetOption("last_pipeline") == 4
+            out = gpu_tb.ReadAccumulation()
+            wrong = (bits(out) != bits(refs[t])).any(-1)
+            assert not wrong.any(), (mode, rep, int(wrong.sum()), "equal to the other stream's picture there: %s" % bool(np.array_equal(bits(out)[wrong], bits(refs[(t + 1) % 3])[wrong])))
+    finally:
+        gpu_tb.SetOption("primary_prepass", 1); gpu_tb.SetOption("pipeline", 0)

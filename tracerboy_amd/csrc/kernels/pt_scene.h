@@ -95,6 +95,7 @@ struct TbSplitParams {
     uint32_t readyMin;      /* a shading wave goes on when this many of its lanes have all their rays back (or every lane that waits) */
     uint32_t refillMin;     /* a traversal wave asks the queue for rays when this many of its lanes are idle */
     uint32_t innerWeight, leafWeight; /* a step runs the inner-node body when lanesAtInnerNodes * leafWeight >= lanesAtLeaves * innerWeight */
+    uint32_t travLast, shadePrio; /* the traversal waves are the LAST waves of the workgroup (younger: they yield issue slots to the shading waves); s_setprio 3 for the shading waves */
     uint32_t ringCap;       /* entries of the ray queue: a power of two >= 2 x 128 x shadeWaves */
     uint32_t spinLimit;     /* every wait is bounded: a wave that has slept this often raises *abortFlag and the launch winds down */
     uint32_t* abortFlag;    /* host-visible word, 0 while all is well */
