@@ -142,6 +142,13 @@ TBD RayPre ray_prepare(tb3 o, tb3 d) /* GetRayData, TraverseFunction.hlsli:473-4
     return ray_assemble(o, d, ray_divide(d));
 }
 
+/* A ray with a NaN in its origin or direction hits nothing: the NaN reaches U, V and W of the watertight test together and every one of
+ * its comparisons fails.  The slab test's min / max DROP NaN operands, though, so the literal walk visits most or all of the tree before it
+ * has hit nothing -- 1.39 million steps for one ray in 12 000 of the reference's vw-van scene, 86 % of the render's steps and, in a lock-step
+ * wave, three orders of magnitude of its time (1.5 Msamples/s).  Such a ray is a miss at once, in the kernels and in the checker alike
+ * (oracle/tb_oracle.cpp RayCannotHit; TB_LITERAL_BOX_TEST=1 walks it literally: tests/test_vw_van.py shows the same bits either way). */
+TBD bool ray_cannot_hit(tb3 o, tb3 d) { return tb_isnan(o.x) || tb_isnan(o.y) || tb_isnan(o.z) || tb_isnan(d.x) || tb_isnan(d.y) || tb_isnan(d.z); }
+
 TBD bool box_test(float& tEntry, float closest, const RayPre& r, tb3 c, tb3 h) /* RayBoxTest :204-221 */
 {
     /* (not `precise` in the reference: contraction allowed, pinned here as explicit fmas) */
@@ -301,6 +308,7 @@ TBD bool traverse(const SceneRefs& sc, const TbDeviceScene& ds, tb3 o, tb3 d, Hi
                   uint32_t& boxes, uint32_t& tris, WaveProf* prof = nullptr, uint32_t* overflow = nullptr)
 {
     best.t = MAX_T; best.u = best.v = 0.0f; best.prim = best.geom = 0u;
+    if (ray_cannot_hit(o, d)) return false;
     RayPre r = ray_prepare(o, d);
     float unusedT;
     if (!box_test(unusedT, best.t, r, ld3(ds.rootCenter), ld3(ds.rootHalf))) return false; /* :566-580 */
@@ -377,6 +385,7 @@ TBD bool traverse_instanced(const SceneRefs& sc, const TbDeviceScene& ds, tb3 o,
                             uint32_t* overflow = nullptr)
 {
     best.t = MAX_T; best.u = best.v = 0.0f; best.prim = best.geom = 0u;
+    if (ray_cannot_hit(o, d)) return false;
     RayPre r = ray_prepare(o, d);
     float unusedT;
     if (!box_test(unusedT, best.t, r, ld3(ds.rootCenter), ld3(ds.rootHalf))) return false; /* :566-580, the top level's root box */
@@ -446,7 +455,7 @@ TBD bool trav_begin(Trav& t, const TbDeviceScene& ds, tb3 o, tb3 d) /* returns f
     t.boxes = t.tris = 0; t.top = 0;
     t.r = ray_prepare(o, d);
     float unusedT;
-    bool in = box_test(unusedT, t.best.t, t.r, ld3(ds.rootCenter), ld3(ds.rootHalf));
+    bool in = !ray_cannot_hit(o, d) && box_test(unusedT, t.best.t, t.r, ld3(ds.rootCenter), ld3(ds.rootHalf));
     t.ref = in ? ds.rootRef : TRAV_DONE;
     return in;
 }
