@@ -64,9 +64,11 @@ def test_vw_van_4k_strips_bit_exact(gpu_tb, settings, flatten):
     finally:
         gpu_tb.SetOption("flatten_instances", 1); gpu_tb.SetOption("bvh_builder", 0)
     gpu_tb.InvalidateHistory(); gpu_tb.Render(W, H, F, s, 0.0)
-    assert gpu_tb.GetOption("last_variant") == 3                       # "vol": interior walks AND a mix material
+    # "vol": interior walks AND a mix material; the two-level tree is 53 levels deep, more than the tuned copy's LDS share + 16 overflow entries: full feature set
+    assert gpu_tb.GetOption("last_variant") == (3 if flatten else 4)
     out, jit = gpu_tb.ReadAccumulation(jittered=True)
-    assert np.all(out[..., 3] == float(F)) and (out[..., :3][~np.isnan(out[..., :3])] >= 0).all() and out[..., :3].max() > 0
+    # a sample that comes back NaN is dropped WITH its weight (RayGenCommon.h:704-727; this scene's index-0 glass makes some): weights count at most the frames
+    assert not np.isnan(out).any() and (out[..., 3] <= float(F)).all() and (out[..., 3] == float(F)).mean() > 0.98 and (out[..., :3] >= 0).all() and out[..., :3].max() > 0
     view, pf = gpu_tb.HostSceneView(), gpu_tb.FrameConstants(W, H, 0, s, 0.0)
     for y0 in (700, 1100, 1500):
         ref = ol.render(view, pf, W, H, F, y0=y0, y1=y0 + 8, threads=8, jittered=True)
