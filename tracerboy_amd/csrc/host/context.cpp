@@ -143,6 +143,7 @@ struct tb_context {
     uint64_t kernelEventStamp = 0; /* counts the renders that have recorded evKernelStart / evKernel: a trial's sample belongs to the render it was asked of */
     uint32_t sceneGeneration = 0; /* counts finalizeScene calls */
     float interiorWalkTriangleShare = 0; /* finalizeScene */
+    DevBuf debugCounters; /* TbDeviceTargets::debugCounters (16 words, zeroed once) */
     DevBuf splitProf; uint32_t* splitAbort = nullptr; int lastSplitWaves = 0; /* pipeline 4: host-mapped abort word of the split-role kernel (renderSplit); travWaves * 100 + shadeWaves of the last launch */
     int lastFgPar = 0;          /* which of the two sample buffers the last frame-group launch wrote (debug query) */
     int lastPrimaryPrepass = 0; /* 1: the last render took its first hits from the primary-visibility pre-pass */
@@ -823,6 +824,8 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
     const bool clearStats = c->samplesRendered == 0; /* enqueued below, on the stream of the first path-tracing launch */
     TbDeviceTargets tg; memset(&tg, 0, sizeof tg);
     tg.output = (TbFloat4*)c->output.p; tg.jittered = (TbFloat4*)c->jittered.p; tg.stats = (uint32_t*)c->stats.p;
+    if (!c->debugCounters.p) { ensure(c->debugCounters, 64); HIP_TRY(hipMemsetAsync(c->debugCounters.p, 0, 64, c->stream)); }
+    tg.debugCounters = (uint32_t*)c->debugCounters.p;
     if (aov) {
         size_t px = (size_t)W * H;
         for (int i = 2; i <= 7; i++) { size_t bytes = px * (i == TB_AOV_DEPTH ? 4 : 16); if (c->aov[i].bytes != bytes) { ensure(c->aov[i], bytes); HIP_TRY(hipMemsetAsync(c->aov[i].p, 0, bytes, c->stream)); } }
@@ -1093,7 +1096,7 @@ void tb_destroy(tb_context* c)
     c->rtComposited.release();
     for (DevBuf& b : c->aov) b.release();
     if (c->splitAbort) (void)hipHostFree(c->splitAbort);
-    c->splitProf.release();
+    c->splitProf.release(); c->debugCounters.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->evKernel) (void)hipEventDestroy(c->evKernel);
@@ -1576,6 +1579,8 @@ int64_t tb_get_option(tb_context* c, const char* name)
     if (!strcmp(name, "debug_slot_log_cap")) return c->lastSlotLogCap;
     if (!strcmp(name, "debug_fg_samples_ptr")) return (int64_t)(uintptr_t)c->fgSamples[c->lastFgPar].p; /* device address of the sample buffer of the last frame-group launch (scripts/lost_item_stress.py) */
     if (!strcmp(name, "last_node_layout")) return c->lastNodeLayout; /* 0: layout B (64-B nodes), 1: layout C (32-B nodes on the 16-bit grid) */
+    if (!strcmp(name, "debug_prepass_rejects")) { /* hit records of the primary-visibility pre-pass that failed validation since the context was made */
+        uint32_t v = 0; if (c->debugCounters.p) { (void)hipStreamSynchronize(c->stream); (void)hipMemcpy(&v, c->debugCounters.p, 4, hipMemcpyDeviceToHost); } return v; }
     if (!strcmp(name, "last_plan_rule_pipeline")) return c->lastPlan.rule_pipeline; /* TB_PLAN_RULE_* of the last render (tracerboy_hip.h) */
     if (!strcmp(name, "last_plan_rule_copy")) return c->lastPlan.rule_copy;
     if (!strcmp(name, "last_plan_rule_prepass")) return c->lastPlan.rule_prepass;

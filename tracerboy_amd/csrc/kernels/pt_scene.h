@@ -83,6 +83,7 @@ struct TbDeviceTargets {
      * four 8-byte words: (t or -1, u), (v, primitive), (hit-group index, launchEpoch), the XOR of the three -- where the lane that draws the sample picks it
      * up instead of walking.  Same camera ray, same walk, same hit, same bits; one lock-step trip less per path. */
     unsigned long long* primaryHits;
+    uint32_t* debugCounters; /* nullable; [0] = hit records of the pre-pass that failed their epoch / check word and were walked again (pt_persistent.inc) */
     uint32_t launchEpoch; /* frame-group mode: a number no other launch on these buffers has had (host counter); stamps the slot-log entries (low byte) and the hit records */
 };
 
