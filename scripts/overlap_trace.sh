@@ -15,7 +15,7 @@ for f in glob.glob(out + "/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
         if "pt_persistent" in n or "accumulate_samples" in n or "pt_split" in n:
-            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Queue_Id"], "fold" if "accumulate" in n else ("launch" if int(r["Grid_Size"]) > int(r["Workgroup_Size"]) else "warm"), n[n.find("pt_"):][:60] if "pt_" in n else "accumulate_samples_kernel"))
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "queue %s stream %s" % (r["Queue_Id"], r.get("Stream_Id", "?")), "fold" if "accumulate" in n else ("launch" if int(r["Grid_Size_X"]) > int(r["Workgroup_Size_X"]) else "warm"), n[n.find("pt_"):][:60] if "pt_" in n else "accumulate_samples_kernel"))
 rows.sort()
 t0 = rows[0][0]
 with open("gpurun_out/c2_overlap_trace.csv", "w") as g:
