@@ -147,7 +147,7 @@ TBD RayPre ray_prepare(tb3 o, tb3 d) /* GetRayData, TraverseFunction.hlsli:473-4
  * has hit nothing -- 1.39 million steps for one ray in 12 000 of the reference's vw-van scene, 86 % of the render's steps and, in a lock-step
  * wave, three orders of magnitude of its time (1.5 Msamples/s).  Such a ray is a miss at once, in the kernels and in the checker alike
  * (oracle/tb_oracle.cpp RayCannotHit; TB_LITERAL_BOX_TEST=1 walks it literally: tests/test_vw_van.py shows the same bits either way). */
-TBD bool ray_cannot_hit(tb3 o, tb3 d) { return tb_isnan(o.x) || tb_isnan(o.y) || tb_isnan(o.z) || tb_isnan(d.x) || tb_isnan(d.y) || tb_isnan(d.z); }
+TBD bool ray_cannot_hit(tb3 o, tb3 d) { return __builtin_isunordered(o.x, o.y) || __builtin_isunordered(o.z, d.x) || __builtin_isunordered(d.y, d.z); } /* three v_cmp_u_f32: unordered = either operand is a NaN */
 
 TBD bool box_test(float& tEntry, float closest, const RayPre& r, tb3 c, tb3 h) /* RayBoxTest :204-221 */
 {
