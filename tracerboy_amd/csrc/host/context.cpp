@@ -139,6 +139,12 @@ struct tb_context {
     int lastNodeLayout = 0; /* 1: the last render walked the compact layout-C nodes */
     int lastSlotLogCap = 0;
     struct PrepassTrial { uint64_t key = 0; int calls = 0, pending = 0, nWith = 0, nWithout = 0; float msWith = 0, msWithout = 0; bool keep = false; uint64_t stamp = 0; } prepassTrial; /* renderImpl */
+    /* Do back-to-back calls gain from running on the two side streams at once?  Found by measurement where it is in doubt (renderImpl):
+     * the end of every render is marked by an event of a ring; the interval between two consecutive ends, when the later call was enqueued
+     * before the earlier one had finished (the device was never idle between them), is what a call costs in that mode. */
+    struct OverlapTrial { uint64_t key = 0; int phase = 0 /* 0 measuring overlapped, 1 measuring one at a time, 2 decided */; int n[2] = {0, 0}; float best[2] = {0, 0}; bool keep = true; } overlapTrial;
+    struct CallRec { uint64_t key = 0; int mode = -1; bool deviceBound = false, settled = false, used = true; } callRec[4];
+    hipEvent_t evCallEnd[4] = {nullptr, nullptr, nullptr, nullptr}; uint64_t callCount = 0; int lastOverlap = 0;
     tb_launch_plan lastPlan{}; /* what PlanLaunch decided for the last render (options last_plan_rule_*) */
     uint64_t kernelEventStamp = 0; /* counts the renders that have recorded evKernelStart / evKernel: a trial's sample belongs to the render it was asked of */
     uint32_t sceneGeneration = 0; /* counts finalizeScene calls */
@@ -895,7 +901,41 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
     c->lastPrimaryPrepass = prepass ? 1 : 0; c->lastPlan = plan;
     /* launches of the kernels without the EXT features (no selected pixel, no AOVs: nothing but the sample buffer is written)
      * may overlap the drain of the launch before them */
-    const bool overlap = plan.overlap_launches != 0;
+    bool overlap = plan.overlap_launches != 0;
+    /* ... which pays for the feature sets whose kernels fit their registers (matte / env: cornell-box +9 %, the 870 k scene +4 ... +9 %, at
+     * every frame size measured) and is in doubt for the others: the 4K glass scenes LOSE 6-7 % with two launches in flight, the same scenes
+     * at 1080p gain 4-13 %, Teapot (surf) gains 9-17 % on calls below ~10 M samples and loses 6 % above, the reference's vw-van (vol) gains 21 %
+     * at 4K (scripts/overlap_ab.py, profiles/r4/overlap_ab*.json) -- no rule in scene statistics fits that.  Like the pre-pass it is therefore
+     * TRIED where it is in doubt (option overlap_launches = 1, the default; 2 = always, 0 = never): calls of one kind run overlapped until two
+     * device-bound intervals between their ends are known, then one at a time until two more are, then the faster way.  A caller that waits for
+     * every call never produces a device-bound interval and stays overlapped (for it the two ways are the same). */
+    const int64_t overlapOpt = opt("overlap_launches", 1);
+    const uint64_t callKey = ((uint64_t)W << 48) ^ ((uint64_t)H << 32) ^ ((uint64_t)n << 12) ^ ((uint64_t)s.MaxBounces << 4) ^ ((uint64_t)c->sceneGeneration << 24) ^ (uint64_t)(uintptr_t)launch ^ (prepass ? 1u : 0u);
+    const bool trialOverlap = overlap && overlapOpt == 1 && (v->features & (PT_FEAT_SPECULAR | PT_FEAT_TEXTURES | PT_FEAT_SSS | PT_FEAT_MIX)) != 0;
+    if (trialOverlap) {
+        tb_context::OverlapTrial& t = c->overlapTrial;
+        if (t.key != callKey) { t = tb_context::OverlapTrial(); t.key = callKey; }
+        for (uint64_t i = c->callCount >= 3 ? c->callCount - 3 : 1; i < c->callCount; i++) { /* intervals that have become known */
+            tb_context::CallRec& r = c->callRec[i & 3u];
+            if (r.used || r.key != callKey || !c->evCallEnd[i & 3u] || !c->evCallEnd[(i - 1) & 3u]) continue;
+            if (hipEventQuery(c->evCallEnd[i & 3u]) != hipSuccess) continue;
+            r.used = true;
+            float ms = 0;
+            if (r.deviceBound && r.settled && (r.mode == 0 || r.mode == 1) && hipEventElapsedTime(&ms, c->evCallEnd[(i - 1) & 3u], c->evCallEnd[i & 3u]) == hipSuccess && ms > 0) {
+                t.best[r.mode] = t.n[r.mode] ? std::min(t.best[r.mode], ms) : ms; t.n[r.mode]++;
+            }
+        }
+        if (t.phase == 0 && t.n[0] >= 2) t.phase = 1;
+        if (t.phase == 1 && t.n[1] >= 2) { t.phase = 2; t.keep = t.best[0] < 0.99f * t.best[1]; }
+        overlap = t.phase == 0 ? true : (t.phase == 1 ? false : t.keep);
+    }
+    c->lastOverlap = overlap ? 1 : 0;
+    {   /* this call's record: was the device still busy with the call before it, and is that call of the same kind and mode (a settled pipeline)? */
+        tb_context::CallRec& r = c->callRec[c->callCount & 3u]; const tb_context::CallRec& prev = c->callRec[(c->callCount - 1) & 3u];
+        r.key = callKey; r.mode = trialOverlap ? (overlap ? 0 : 1) : -1; r.used = !trialOverlap;
+        r.deviceBound = c->callCount > 0 && c->evCallEnd[(c->callCount - 1) & 3u] && hipEventQuery(c->evCallEnd[(c->callCount - 1) & 3u]) == hipErrorNotReady;
+        r.settled = c->callCount > 0 && prev.key == callKey && prev.mode == r.mode;
+    }
     if (!overlap) c->sideOrdered = false;
     c->kernelEventStamp++; /* this render records evKernelStart / evKernel */
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
@@ -1011,6 +1051,8 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
     }
     if (!c->lastKernelFrames) { HIP_TRY(hipEventRecord(c->evKernel, c->stream)); c->lastKernelFrames = n; } /* one launch (or one pipeline) for the whole call */
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    if (!c->evCallEnd[c->callCount & 3u]) HIP_TRY(hipEventCreate(&c->evCallEnd[c->callCount & 3u]));
+    HIP_TRY(hipEventRecord(c->evCallEnd[c->callCount & 3u], c->stream)); c->callCount++; /* the end of this render, for the overlap trial above */
     c->samplesRendered += n;
     if (sync) {
         HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipEventElapsedTime(&c->lastMs, c->ev0, c->ev1));
@@ -1095,6 +1137,7 @@ void tb_destroy(tb_context* c)
     for (int i = 0; i < 2; i++) { c->rtIndirect[i].release(); c->rtMoment[i].release(); c->rtFinal[i].release(); c->rtDenoise[i].release(); }
     c->rtComposited.release();
     for (DevBuf& b : c->aov) b.release();
+    for (hipEvent_t& e : c->evCallEnd) if (e) (void)hipEventDestroy(e);
     if (c->splitAbort) (void)hipHostFree(c->splitAbort);
     c->splitProf.release(); c->debugCounters.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -1581,6 +1624,8 @@ int64_t tb_get_option(tb_context* c, const char* name)
     if (!strcmp(name, "last_node_layout")) return c->lastNodeLayout; /* 0: layout B (64-B nodes), 1: layout C (32-B nodes on the 16-bit grid) */
     if (!strcmp(name, "debug_prepass_rejects")) { /* hit records of the primary-visibility pre-pass that failed validation since the context was made */
         uint32_t v = 0; if (c->debugCounters.p) { (void)hipStreamSynchronize(c->stream); (void)hipMemcpy(&v, c->debugCounters.p, 4, hipMemcpyDeviceToHost); } return v; }
+    if (!strcmp(name, "last_overlap")) return c->lastOverlap; /* the last frame-group render used the two side streams */
+    if (!strcmp(name, "overlap_trial_phase")) return c->overlapTrial.phase; /* 0 measuring overlapped, 1 measuring one at a time, 2 decided */
     if (!strcmp(name, "last_plan_rule_pipeline")) return c->lastPlan.rule_pipeline; /* TB_PLAN_RULE_* of the last render (tracerboy_hip.h) */
     if (!strcmp(name, "last_plan_rule_copy")) return c->lastPlan.rule_copy;
     if (!strcmp(name, "last_plan_rule_prepass")) return c->lastPlan.rule_prepass;
