@@ -295,7 +295,7 @@ def extra_leg(tb, api, np, torch, load, key, steps=3):
     # turns -- it needs a few rounds of asynchronous calls to see device-bound intervals both ways (renderImpl, overlap trial)
     for _ in range(4):
         if tb.GetOption("overlap_trial_phase") == 2: break
-        for _ in range(3):
+        for _ in range(5):
             tb.InvalidateHistory(); tb.Render(W, H, SPP, s, 0.0, sync=False)
         tb.Sync()
         if tb.GetOption("last_variant") in (0, 1): break      # matte / env: overlapped launches always pay, nothing is tried

@@ -33,7 +33,7 @@ for key, scene, builder, W, H, F, D in SETS[which]:
         row.setdefault("overlap" if ov else "one at a time", []).append(round(W * H * F / dt / 1e6, 1))
     tb.SetOption("overlap_launches", 1)      # the default: tried where it is in doubt
     for _ in range(4):
-        for _ in range(3): tb.InvalidateHistory(); tb.Render(W, H, F, s, 0.0, sync=False)
+        for _ in range(5): tb.InvalidateHistory(); tb.Render(W, H, F, s, 0.0, sync=False)
         tb.Sync()
     t = time.perf_counter()
     for _ in range(6): tb.InvalidateHistory(); tb.Render(W, H, F, s, 0.0, sync=False)

@@ -143,8 +143,8 @@ struct tb_context {
      * the end of every render is marked by an event of a ring; the interval between two consecutive ends, when the later call was enqueued
      * before the earlier one had finished (the device was never idle between them), is what a call costs in that mode. */
     struct OverlapTrial { uint64_t key = 0; int phase = 0 /* 0 measuring overlapped, 1 measuring one at a time, 2 decided */; int n[2] = {0, 0}; float best[2] = {0, 0}; bool keep = true; } overlapTrial;
-    struct CallRec { uint64_t key = 0; int mode = -1; bool deviceBound = false, settled = false, used = true; } callRec[4];
-    hipEvent_t evCallEnd[4] = {nullptr, nullptr, nullptr, nullptr}; uint64_t callCount = 0; int lastOverlap = 0;
+    struct CallRec { uint64_t key = 0; int mode = -1; bool deviceBound = false, settled = false, used = true; } callRec[8];
+    hipEvent_t evCallEnd[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; uint64_t callCount = 0; int lastOverlap = 0;
     tb_launch_plan lastPlan{}; /* what PlanLaunch decided for the last render (options last_plan_rule_*) */
     uint64_t kernelEventStamp = 0; /* counts the renders that have recorded evKernelStart / evKernel: a trial's sample belongs to the render it was asked of */
     uint32_t sceneGeneration = 0; /* counts finalizeScene calls */
@@ -907,7 +907,7 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
      * at 1080p gain 4-13 %, Teapot (surf) gains 9-17 % on calls below ~10 M samples and loses 6 % above, the reference's vw-van (vol) gains 21 %
      * at 4K (scripts/overlap_ab.py, profiles/r4/overlap_ab*.json) -- no rule in scene statistics fits that.  Like the pre-pass it is therefore
      * TRIED where it is in doubt (option overlap_launches = 1, the default; 2 = always, 0 = never): calls of one kind run overlapped until two
-     * device-bound intervals between their ends are known, then one at a time until two more are, then the faster way.  A caller that waits for
+     * device-bound two-call spans between their ends are known, then one at a time until two more are, then the faster way.  A caller that waits for
      * every call never produces a device-bound interval and stays overlapped (for it the two ways are the same). */
     const int64_t overlapOpt = opt("overlap_launches", 1);
     const uint64_t callKey = ((uint64_t)W << 48) ^ ((uint64_t)H << 32) ^ ((uint64_t)n << 12) ^ ((uint64_t)s.MaxBounces << 4) ^ ((uint64_t)c->sceneGeneration << 24) ^ (uint64_t)(uintptr_t)launch ^ (prepass ? 1u : 0u);
@@ -915,25 +915,29 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
     if (trialOverlap) {
         tb_context::OverlapTrial& t = c->overlapTrial;
         if (t.key != callKey) { t = tb_context::OverlapTrial(); t.key = callKey; }
-        for (uint64_t i = c->callCount >= 3 ? c->callCount - 3 : 1; i < c->callCount; i++) { /* intervals that have become known */
-            tb_context::CallRec& r = c->callRec[i & 3u];
-            if (r.used || r.key != callKey || !c->evCallEnd[i & 3u] || !c->evCallEnd[(i - 1) & 3u]) continue;
-            if (hipEventQuery(c->evCallEnd[i & 3u]) != hipSuccess) continue;
+        /* spans that have become known.  A span is TWO calls long -- (end of call i) - (end of call i - 2), halved: overlapped launches finish in
+         * pairs (two are in flight at once: the ends of consecutive calls are alternately 2 ms and 86 ms apart on the van-class 4K scene) */
+        for (uint64_t i = c->callCount >= 5 ? c->callCount - 5 : 2; i + 1 < c->callCount; i++) {
+            tb_context::CallRec& r = c->callRec[i & 7u]; const tb_context::CallRec& q = c->callRec[(i - 1) & 7u]; const tb_context::CallRec& nx = c->callRec[(i + 1) & 7u];
+            if (r.used || r.key != callKey || !c->evCallEnd[i & 7u] || !c->evCallEnd[(i - 2) & 7u]) continue;
+            if (hipEventQuery(c->evCallEnd[i & 7u]) != hipSuccess) continue;
             r.used = true;
             float ms = 0;
-            if (r.deviceBound && r.settled && (r.mode == 0 || r.mode == 1) && hipEventElapsedTime(&ms, c->evCallEnd[(i - 1) & 3u], c->evCallEnd[i & 3u]) == hipSuccess && ms > 0) {
-                t.best[r.mode] = t.n[r.mode] ? std::min(t.best[r.mode], ms) : ms; t.n[r.mode]++;
+            /* ... and call i must not be the last of a burst (the call after it was enqueued while it ran): the last launch has the chip to itself */
+            if (r.deviceBound && r.settled && q.deviceBound && q.settled && q.key == callKey && q.mode == r.mode && (r.mode == 0 || r.mode == 1) && nx.deviceBound && nx.key == callKey && nx.mode == r.mode
+                && hipEventElapsedTime(&ms, c->evCallEnd[(i - 2) & 7u], c->evCallEnd[i & 7u]) == hipSuccess && ms > 0) {
+                ms *= 0.5f; t.best[r.mode] = t.n[r.mode] ? std::min(t.best[r.mode], ms) : ms; t.n[r.mode]++;
             }
         }
         if (t.phase == 0 && t.n[0] >= 2) t.phase = 1;
-        if (t.phase == 1 && t.n[1] >= 2) { t.phase = 2; t.keep = t.best[0] < 0.99f * t.best[1]; }
+        if (t.phase == 1 && t.n[1] >= 2) { t.phase = 2; t.keep = t.best[0] < 1.02f * t.best[1]; } /* taking turns has to win by 2 %: short bursts flatter it (their last launch runs alone) */
         overlap = t.phase == 0 ? true : (t.phase == 1 ? false : t.keep);
     }
     c->lastOverlap = overlap ? 1 : 0;
     {   /* this call's record: was the device still busy with the call before it, and is that call of the same kind and mode (a settled pipeline)? */
-        tb_context::CallRec& r = c->callRec[c->callCount & 3u]; const tb_context::CallRec& prev = c->callRec[(c->callCount - 1) & 3u];
+        tb_context::CallRec& r = c->callRec[c->callCount & 7u]; const tb_context::CallRec& prev = c->callRec[(c->callCount - 1) & 7u];
         r.key = callKey; r.mode = trialOverlap ? (overlap ? 0 : 1) : -1; r.used = !trialOverlap;
-        r.deviceBound = c->callCount > 0 && c->evCallEnd[(c->callCount - 1) & 3u] && hipEventQuery(c->evCallEnd[(c->callCount - 1) & 3u]) == hipErrorNotReady;
+        r.deviceBound = c->callCount > 0 && c->evCallEnd[(c->callCount - 1) & 7u] && hipEventQuery(c->evCallEnd[(c->callCount - 1) & 7u]) == hipErrorNotReady;
         r.settled = c->callCount > 0 && prev.key == callKey && prev.mode == r.mode;
     }
     if (!overlap) c->sideOrdered = false;
@@ -1051,8 +1055,8 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
     }
     if (!c->lastKernelFrames) { HIP_TRY(hipEventRecord(c->evKernel, c->stream)); c->lastKernelFrames = n; } /* one launch (or one pipeline) for the whole call */
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
-    if (!c->evCallEnd[c->callCount & 3u]) HIP_TRY(hipEventCreate(&c->evCallEnd[c->callCount & 3u]));
-    HIP_TRY(hipEventRecord(c->evCallEnd[c->callCount & 3u], c->stream)); c->callCount++; /* the end of this render, for the overlap trial above */
+    if (!c->evCallEnd[c->callCount & 7u]) HIP_TRY(hipEventCreate(&c->evCallEnd[c->callCount & 7u]));
+    HIP_TRY(hipEventRecord(c->evCallEnd[c->callCount & 7u], c->stream)); c->callCount++; /* the end of this render, for the overlap trial above */
     c->samplesRendered += n;
     if (sync) {
         HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipEventElapsedTime(&c->lastMs, c->ev0, c->ev1));
@@ -1625,6 +1629,8 @@ int64_t tb_get_option(tb_context* c, const char* name)
     if (!strcmp(name, "debug_prepass_rejects")) { /* hit records of the primary-visibility pre-pass that failed validation since the context was made */
         uint32_t v = 0; if (c->debugCounters.p) { (void)hipStreamSynchronize(c->stream); (void)hipMemcpy(&v, c->debugCounters.p, 4, hipMemcpyDeviceToHost); } return v; }
     if (!strcmp(name, "last_overlap")) return c->lastOverlap; /* the last frame-group render used the two side streams */
+    if (!strcmp(name, "overlap_trial_us_overlapped")) return (int64_t)(c->overlapTrial.best[0] * 1000.0f); /* best device-bound interval between call ends, overlapped / one at a time */
+    if (!strcmp(name, "overlap_trial_us_one_at_a_time")) return (int64_t)(c->overlapTrial.best[1] * 1000.0f);
     if (!strcmp(name, "overlap_trial_phase")) return c->overlapTrial.phase; /* 0 measuring overlapped, 1 measuring one at a time, 2 decided */
     if (!strcmp(name, "last_plan_rule_pipeline")) return c->lastPlan.rule_pipeline; /* TB_PLAN_RULE_* of the last render (tracerboy_hip.h) */
     if (!strcmp(name, "last_plan_rule_copy")) return c->lastPlan.rule_copy;
