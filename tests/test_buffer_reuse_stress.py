@@ -54,3 +54,33 @@ def test_three_streams_over_two_buffers(gpu_tb, settings, W, H, F, reps, tris, m
             assert not wrong.any(), (mode, rep, int(wrong.sum()), "equal to the other stream's picture there: %s" % bool(np.array_equal(bits(out)[wrong], bits(refs[(t + 1) % 3])[wrong])))
     finally:
         gpu_tb.SetOption("primary_prepass", 1); gpu_tb.SetOption("pipeline", 0)
+
+
+def test_overlap_trial_decides_without_changing_a_bit(gpu_tb, settings):
+    """Whether back-to-back calls share the chip (two launches in flight on the side streams) or take turns is found by measurement for the
+    feature sets where it is in doubt (surf / sss / vol; renderImpl, overlap trial): bursts of asynchronous calls walk the trial through
+    its phases -- overlapped, one at a time, decided -- and every picture on the way is the same bits."""
+    s = copy.copy(settings); s.MaxBounces = 6
+    W, H, F = 640, 360, 4
+    gpu_tb.SetOption("bvh_builder", 4)
+    try:
+        gpu_tb.LoadProcedural(1, 40000, 11)                     # glass among other things: feature set sss
+    finally:
+        gpu_tb.SetOption("bvh_builder", 0)
+    gpu_tb.SetOption("frame_group", -1); gpu_tb.InvalidateHistory(); gpu_tb.Render(W, H, F, s, 0.0); ref = gpu_tb.ReadAccumulation(); gpu_tb.SetOption("frame_group", 0)
+    assert gpu_tb.GetOption("last_variant") == 5
+    phases, modes = [], set()
+    for burst in range(6):
+        for k in range(6):
+            gpu_tb.InvalidateHistory(); gpu_tb.Render(W, H, F, s, 0.0, sync=False); modes.add(gpu_tb.GetOption("last_overlap"))
+        gpu_tb.Sync()
+        phases.append(gpu_tb.GetOption("overlap_trial_phase"))
+        assert np.array_equal(bits(gpu_tb.ReadAccumulation()), bits(ref)), burst
+    assert phases[-1] == 2 and phases == sorted(phases) and modes == {0, 1}, (phases, modes)   # both ways were tried, then one was kept
+    for opt_value, expect in ((0, 0), (2, 1)):                  # 0 = never, 2 = always
+        gpu_tb.SetOption("overlap_launches", opt_value)
+        try:
+            gpu_tb.InvalidateHistory(); gpu_tb.Render(W, H, F, s, 0.0); assert gpu_tb.GetOption("last_overlap") == expect
+            assert np.array_equal(bits(gpu_tb.ReadAccumulation()), bits(ref))
+        finally:
+            gpu_tb.SetOption("overlap_launches", 1)
