@@ -244,7 +244,7 @@ typedef struct tb_plan_input {
     uint64_t owned_regions;           /* 16x16 regions this context renders (the whole frame, or its tiles of a split) */
     uint32_t count_rays, aov, realtime, selected_pixel;
     /* options (tb_set_option), with their defaults where 0 is not one */
-    int64_t pipeline, frame_group, high_occupancy /* 1 */, stack_lds_cap, stack_overflow_max /* 16 */, node_layout, primary_prepass /* 1 */,
+    int64_t pipeline, frame_group, high_occupancy /* 1 */, stack_lds_cap, stack_overflow_max /* 24 */, node_layout, primary_prepass /* 1 */,
             overlap_launches /* 1 */, pooled_samples /* 2^28 */;
 } tb_plan_input;
 typedef struct tb_launch_plan {

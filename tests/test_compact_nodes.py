@@ -95,11 +95,11 @@ def test_compact_nodes_small_scene_and_split_stack(gpu_tb, settings):
         ref = ol.render(gpu_tb.HostSceneView(), gpu_tb.FrameConstants(W, H, 0, s, 0.0), W, H, F, threads=8)["output"]
         for cap in (0, 3):
             try:
-                gpu_tb.SetOption("stack_lds_cap", cap); gpu_tb.SetOption("stack_overflow_max", 64 if cap else 16)
+                gpu_tb.SetOption("stack_lds_cap", cap); gpu_tb.SetOption("stack_overflow_max", 64 if cap else 24)
                 b, c = _compare(gpu_tb, W, H, F, s, "proc%d cap %d" % (kind, cap))
                 assert gpu_tb.GetOption("last_variant") == variant
             finally:
-                gpu_tb.SetOption("stack_lds_cap", 0); gpu_tb.SetOption("stack_overflow_max", 16)
+                gpu_tb.SetOption("stack_lds_cap", 0); gpu_tb.SetOption("stack_overflow_max", 24)
             assert np.array_equal(bits(b), bits(ref))
             assert rel_l2(c[..., :3], ref[..., :3]) <= TOL
 

@@ -317,7 +317,7 @@ def test_split_traversal_stack_bit_exact(gpu_tb, settings, scene):
         ref = _oracle(gpu_tb, W, H, F, s)["output"]
         assert np.array_equal(bits(out), bits(ref))
     finally:
-        gpu_tb.SetOption("stack_lds_cap", 0); gpu_tb.SetOption("stack_overflow_max", 16)
+        gpu_tb.SetOption("stack_lds_cap", 0); gpu_tb.SetOption("stack_overflow_max", 24)
 
 
 @pytest.mark.parametrize("sort", [0, 1])

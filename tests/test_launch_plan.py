@@ -55,10 +55,13 @@ def test_dragon_class_c3_plan():
     # the same tree built by the GPU (36 levels): the 6-wave copy's share of LDS holds 26 entries, the other 10 go to global memory
     p = plan(ENVV, HD, frames=128, stack_depth=36, max_bounces=6)
     assert (p.high_occupancy_copy, p.rule_copy, p.stack_lds_entries, p.stack_overflow_entries) == (1, COPY_SPLIT_STACK, 26, 10)
-    # deeper than the overflow allows (16): the base copy, whole stack in LDS, and with it no pre-pass kernel
-    p = plan(ENVV, HD, frames=128, stack_depth=43, max_bounces=6)
-    assert (p.high_occupancy_copy, p.rule_copy, p.stack_lds_entries, p.prepass, p.rule_prepass) == (0, COPY_TOO_DEEP, 43, OFF, PRE_NO_KERNEL)
-    assert plan(ENVV, HD, frames=128, stack_depth=43, stack_overflow_max=20).rule_copy == COPY_SPLIT_STACK
+    # deeper than the overflow allows (24 entries in global memory): the base copy, whole stack in LDS, and with it no pre-pass kernel
+    p = plan(ENVV, HD, frames=128, stack_depth=51, max_bounces=6)
+    assert (p.high_occupancy_copy, p.rule_copy, p.stack_lds_entries, p.prepass, p.rule_prepass) == (0, COPY_TOO_DEEP, 51, OFF, PRE_NO_KERNEL)
+    assert plan(ENVV, HD, frames=128, stack_depth=51, stack_overflow_max=30).rule_copy == COPY_SPLIT_STACK
+    assert plan(ENVV, HD, frames=128, stack_depth=43, stack_overflow_max=16).rule_copy == COPY_TOO_DEEP     # round 3's limit
+    p = plan(dict(variant_features=31, variant_waves_hi=5), UHD, frames=8, stack_depth=53, two_level=1)         # the reference's vw-van as a two-level scene: vol copy, 31 + 22
+    assert (p.high_occupancy_copy, p.full_variant, p.stack_lds_entries, p.stack_overflow_entries) == (1, 0, 31, 22)
     assert plan(ENVV, HD, frames=128, stack_depth=26, high_occupancy=0).rule_copy == COPY_NONE
     # a forced cap splits a stack that would fit (tests); one-frame calls have no split stack
     p = plan(ENVV, HD, frames=8, stack_depth=20, stack_lds_cap=12); assert (p.rule_copy, p.stack_lds_entries, p.stack_overflow_entries) == (COPY_SPLIT_STACK, 12, 8)

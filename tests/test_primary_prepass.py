@@ -79,7 +79,7 @@ def test_prepass_with_sky_split_stack_tiles_and_depth_limits(gpu_tb, settings):
         gpu_tb.SetOption("stack_lds_cap", 4); gpu_tb.SetOption("stack_overflow_max", 64)
         a, _, _ = _render(gpu_tb, 0, W, H, F, s); b, _, used = _render(gpu_tb, 2, W, H, F, s)
         assert used == 1 and np.array_equal(bits(a), bits(b))
-        gpu_tb.SetOption("stack_lds_cap", 0); gpu_tb.SetOption("stack_overflow_max", 16)
+        gpu_tb.SetOption("stack_lds_cap", 0); gpu_tb.SetOption("stack_overflow_max", 24)
         full, _, _ = _render(gpu_tb, 0, W, H, F, s)
         gpu_tb.SetTileAssignment(1, 2, 32, 16)
         a, _, _ = _render(gpu_tb, 0, W, H, F, s); b, _, used = _render(gpu_tb, 2, W, H, F, s)
@@ -91,7 +91,7 @@ def test_prepass_with_sky_split_stack_tiles_and_depth_limits(gpu_tb, settings):
             assert used == want and np.array_equal(bits(a), bits(b))
     finally:
         gpu_tb.SetTileAssignment(0, 1); gpu_tb.SetCamera(home)
-        gpu_tb.SetOption("stack_lds_cap", 0); gpu_tb.SetOption("stack_overflow_max", 16); gpu_tb.SetOption("primary_prepass", 1)
+        gpu_tb.SetOption("stack_lds_cap", 0); gpu_tb.SetOption("stack_overflow_max", 24); gpu_tb.SetOption("primary_prepass", 1)
 
 
 def test_prepass_policy_and_where_it_does_not_apply(gpu_tb, settings, tmp_path):
@@ -215,4 +215,4 @@ def test_no_work_item_is_bound_and_left_unrendered(gpu_tb, settings, copies):
             assert bad == 0, "%d of 120 renders differ from the oracle" % bad
     finally:
         gpu_tb.SetOption("high_occupancy", 1); gpu_tb.SetOption("primary_prepass", 1)
-        gpu_tb.SetOption("pooled_samples", 256 << 20); gpu_tb.SetOption("stack_lds_cap", 0); gpu_tb.SetOption("stack_overflow_max", 16)
+        gpu_tb.SetOption("pooled_samples", 256 << 20); gpu_tb.SetOption("stack_lds_cap", 0); gpu_tb.SetOption("stack_overflow_max", 24)

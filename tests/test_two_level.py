@@ -272,13 +272,13 @@ def test_two_level_tuned_kernel_copies_bit_exact(gpu_tb, settings, kind, tmp_pat
     ref = ol.render(view, gpu_tb.FrameConstants(W, H, 0, s, 0.0), W, H, 9, threads=8, jittered=True)
     try:
         for cap in (0, 3):
-            gpu_tb.SetOption("stack_lds_cap", cap); gpu_tb.SetOption("stack_overflow_max", 64 if cap else 16)
+            gpu_tb.SetOption("stack_lds_cap", cap); gpu_tb.SetOption("stack_overflow_max", 64 if cap else 24)
             gpu_tb.InvalidateHistory(); gpu_tb.Render(W, H, 9, s, 0.0)
             assert gpu_tb.GetOption("last_variant") == variant, (kind, cap)          # not the full feature set: the tuned copy ran
             out, jit = gpu_tb.ReadAccumulation(jittered=True)
             assert np.array_equal(bits(out), bits(ref["output"])) and np.array_equal(bits(jit), bits(ref["jittered"])), (kind, cap)
     finally:
-        gpu_tb.SetOption("stack_lds_cap", 0); gpu_tb.SetOption("stack_overflow_max", 16)
+        gpu_tb.SetOption("stack_lds_cap", 0); gpu_tb.SetOption("stack_overflow_max", 24)
     gpu_tb.InvalidateHistory(); gpu_tb.Render(W, H, 1, s, 0.0)
     assert gpu_tb.GetOption("last_variant") == 4
     one = ol.render(view, gpu_tb.FrameConstants(W, H, 0, s, 0.0), W, H, 1, threads=8)["output"]

@@ -802,7 +802,7 @@ void fillPlanInput(tb_context* c, const Variant* v, uint32_t W, uint32_t H, uint
     in.width = W; in.height = H; in.frames = n; in.max_bounces = s.MaxBounces; in.owned_regions = tb_persistent_grid(W, H, c->tiles);
     in.count_rays = count ? 1u : 0u; in.aov = aov ? 1u : 0u; in.realtime = s.RenderModeRealTime ? 1u : 0u; in.selected_pixel = c->selX != 0xffffffffu ? 1u : 0u;
     in.pipeline = opt("pipeline", 0); in.frame_group = opt("frame_group", 0); in.high_occupancy = opt("high_occupancy", 1); in.stack_lds_cap = opt("stack_lds_cap", 0);
-    in.stack_overflow_max = opt("stack_overflow_max", 16); in.node_layout = opt("node_layout", 0); in.primary_prepass = opt("primary_prepass", 1);
+    in.stack_overflow_max = opt("stack_overflow_max", 24); in.node_layout = opt("node_layout", 0); in.primary_prepass = opt("primary_prepass", 1);
     in.overlap_launches = opt("overlap_launches", 1); in.pooled_samples = opt("pooled_samples", 256ll << 20);
 }
 
@@ -1525,7 +1525,7 @@ void tb_plan_defaults(tb_plan_input* in)
 {
     if (!in) return;
     memset(in, 0, sizeof *in);
-    in->high_occupancy = 1; in->stack_overflow_max = 16; in->primary_prepass = 1; in->overlap_launches = 1; in->pooled_samples = 256ll << 20;
+    in->high_occupancy = 1; in->stack_overflow_max = 24; in->primary_prepass = 1; in->overlap_launches = 1; in->pooled_samples = 256ll << 20;
 }
 int tb_plan_launch(const tb_plan_input* in, tb_launch_plan* out)
 {

@@ -25,7 +25,9 @@ inline void PlanLaunch(const tb_plan_input& in, tb_launch_plan& p)
     p.rule_pipeline = p.groups ? TB_PLAN_RULE_FRAME_GROUPS : TB_PLAN_RULE_ONE_PIXEL_PER_LANE;
     /* Which copy of the feature set: the higher-occupancy one when its workgroups fit in LDS.  LDS per workgroup = 1 KB per stack entry
      * (+ the scene image); where the tree is too deep for that, a frame-group launch may still use the copy with a split stack -- as
-     * many entries in LDS as fit, the deepest few (option stack_overflow_max, default 16) in global memory. */
+     * many entries in LDS as fit, the deepest few (option stack_overflow_max) in global memory.  Default 24 since round 4 (16 before): the
+     * reference's vw-van as a two-level scene builds a 53-level tree, 22 beyond the vol copy's 31 -- with 16 it fell to the full feature set (1 052
+     * Msamples/s at 4K), with 24 it runs in the tuned two-level walk (1 266; 1 544 with launches overlapping, more than the flattened scene's 1 395). */
     p.stack_lds_entries = in.stack_depth;
     if (in.variant_waves_hi && pipe == 0 && !in.count_rays && in.high_occupancy != 0) {
         const uint64_t share = (160u * 1024u / in.variant_waves_hi) / 512u * 512u, fixed = (in.scene_in_lds ? in.lds_blob_bytes : 0u) + 128u;
