@@ -29,7 +29,7 @@ COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "
 # 1 171 -> 1 213 Msamples/s; neither changes a result bit (-ffp-contract=off pins the arithmetic, tests/ -m gpu).
 DEVICE = ["--offload-arch=" + ARCH, "-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]
 
-HOST_SRCS = ["host/pbrt_loader.cpp", "host/pbf_loader.cpp", "host/host_scene.cpp", "host/images.cpp", "host/image_decode.cpp", "host/image_formats.cpp", "host/bvh_build.cpp", "host/procedural.cpp", "host/context.cpp", "host/pbrt_dump.cpp"]
+HOST_SRCS = ["host/pbrt_loader.cpp", "host/pbf_loader.cpp", "host/host_scene.cpp", "host/images.cpp", "host/image_decode.cpp", "host/image_formats.cpp", "host/bvh_build.cpp", "host/procedural.cpp", "host/context.cpp", "host/context_scene.cpp", "host/context_render.cpp", "host/pbrt_dump.cpp"]
 KERNEL_SRCS = ["kernels/pt_kernels.hip", "kernels/post_kernels.hip", "kernels/bvh_kernels.hip", "kernels/rt_kernels.hip", "kernels/pt_variant_matte.hip", "kernels/pt_variant_matte5.hip", "kernels/pt_variant_env.hip", "kernels/pt_variant_env5.hip", "kernels/pt_variant_surf.hip",
                "kernels/pt_variant_sss.hip", "kernels/pt_variant_sss4.hip",
                "kernels/pt_variant_vol.hip", "kernels/pt_variant_vol4.hip", "kernels/pt_variant_full.hip",

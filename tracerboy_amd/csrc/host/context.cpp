@@ -5,77 +5,15 @@
  * There is no CPU rendering path in this library: every entry point that produces pixels or hits
  * launches a HIP kernel, and tb_create fails when no HIP device is usable.
  */
-#include "host_scene.h"
-#include "../kernels/pt_launch.h"
-#include "../kernels/pt_device_features.h"
-#include "launch_plan.h"
-
-#include <hip/hip_runtime.h>
-
-#include <algorithm>
-#include <cstring>
-#include <limits>
-#include <cmath>
-#include <map>
-#include <stdexcept>
-#include <string>
-#include <vector>
+#include "context_internal.h"
 
 using namespace tbhost;
+using namespace tbctx;
 
-extern "C" {
-typedef hipError_t (*pt_variant_fn)(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, uint32_t, uint32_t, uint32_t, uint32_t,
-                                    const TbTileMap*, int, int, int);
-hipError_t pt_launch_persistent_matte(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, uint32_t, uint32_t, uint32_t, uint32_t, const TbTileMap*, int, int, int);
-hipError_t pt_launch_persistent_env(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, uint32_t, uint32_t, uint32_t, uint32_t, const TbTileMap*, int, int, int);
-hipError_t pt_launch_persistent_surf(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, uint32_t, uint32_t, uint32_t, uint32_t, const TbTileMap*, int, int, int);
-hipError_t pt_launch_persistent_matte5(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, uint32_t, uint32_t, uint32_t, uint32_t, const TbTileMap*, int, int, int);
-hipError_t pt_launch_persistent_env5(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, uint32_t, uint32_t, uint32_t, uint32_t, const TbTileMap*, int, int, int);
-hipError_t pt_launch_persistent_sss(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, uint32_t, uint32_t, uint32_t, uint32_t, const TbTileMap*, int, int, int);
-hipError_t pt_launch_persistent_sss4(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, uint32_t, uint32_t, uint32_t, uint32_t, const TbTileMap*, int, int, int);
-hipError_t pt_launch_persistent_vol4(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, uint32_t, uint32_t, uint32_t, uint32_t, const TbTileMap*, int, int, int);
-hipError_t pt_launch_persistent_vol(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, uint32_t, uint32_t, uint32_t, uint32_t, const TbTileMap*, int, int, int);
-hipError_t pt_launch_persistent_full(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, uint32_t, uint32_t, uint32_t, uint32_t, const TbTileMap*, int, int, int);
-/* pipeline 4, the split-role kernel (pt_split.inc): shading waves + traversal waves over an LDS ray queue */
-typedef hipError_t (*pt_split_fn)(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, const TbSplitParams*, uint32_t, uint32_t, uint32_t, uint32_t,
-                                  const TbTileMap*, int, int*);
-hipError_t pt_launch_split_matte(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, const TbSplitParams*, uint32_t, uint32_t, uint32_t, uint32_t, const TbTileMap*, int, int*);
-hipError_t pt_launch_split_env(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, const TbSplitParams*, uint32_t, uint32_t, uint32_t, uint32_t, const TbTileMap*, int, int*);
-hipError_t pt_launch_split_surf(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, const TbSplitParams*, uint32_t, uint32_t, uint32_t, uint32_t, const TbTileMap*, int, int*);
-hipError_t pt_launch_split_sss(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, const TbSplitParams*, uint32_t, uint32_t, uint32_t, uint32_t, const TbTileMap*, int, int*);
-}
-
-#include "../kernels/wf_types.h"
-extern "C" {
-typedef hipError_t (*wf_variant_fn)(hipStream_t, int, const TbDeviceScene*, const TbPerFrameConstants*, const WfParams*, const WfQueue*, const WfQueue*, const WfQueue*,
-                                    const WfHits*, int, TbFloat4*, TbFloat4*, uint32_t);
-hipError_t wf_launch_matte(hipStream_t, int, const TbDeviceScene*, const TbPerFrameConstants*, const WfParams*, const WfQueue*, const WfQueue*, const WfQueue*, const WfHits*, int, TbFloat4*, TbFloat4*, uint32_t);
-hipError_t wf_launch_env(hipStream_t, int, const TbDeviceScene*, const TbPerFrameConstants*, const WfParams*, const WfQueue*, const WfQueue*, const WfQueue*, const WfHits*, int, TbFloat4*, TbFloat4*, uint32_t);
-hipError_t wf_launch_surf(hipStream_t, int, const TbDeviceScene*, const TbPerFrameConstants*, const WfParams*, const WfQueue*, const WfQueue*, const WfQueue*, const WfHits*, int, TbFloat4*, TbFloat4*, uint32_t);
-hipError_t wf_launch_sss(hipStream_t, int, const TbDeviceScene*, const TbPerFrameConstants*, const WfParams*, const WfQueue*, const WfQueue*, const WfQueue*, const WfHits*, int, TbFloat4*, TbFloat4*, uint32_t);
-hipError_t wf_launch_vol(hipStream_t, int, const TbDeviceScene*, const TbPerFrameConstants*, const WfParams*, const WfQueue*, const WfQueue*, const WfQueue*, const WfHits*, int, TbFloat4*, TbFloat4*, uint32_t);
-}
-
-namespace {
+namespace tbctx {
 
 std::string g_createError;
-/* fnHi: the same feature set compiled to `wavesHi` waves per SIMD (fewer VGPRs, more scratch; pipeline 0 only), used when LDS
- * has room for that many workgroups per CU -- otherwise its spills would buy no residency.  Searched in order: the first feature
- * set that covers what scene + settings need.  id: what option "last_variant" reports (stable across insertions).
- * wf: the wavefront pipeline's launcher of the feature set (pipeline 2; none for the full set); pooled: pipeline 3 exists. */
-#ifndef TB_MATTE_WAVES
-#define TB_MATTE_WAVES 5
-#endif
-#ifndef TB_ENV_WAVES
-#define TB_ENV_WAVES 6
-#endif
-#ifndef TB_SSS_WAVES
-#define TB_SSS_WAVES 5
-#endif
-#ifndef TB_VOL_WAVES
-#define TB_VOL_WAVES 5
-#endif
-struct Variant { uint32_t features; pt_variant_fn fn; const char* name; pt_variant_fn fnHi; uint32_t wavesHi; int id; wf_variant_fn wf; bool pooled; pt_split_fn split; };
+#ifndef __HIP_DEVICE_COMPILE__ /* host data: the file goes through hipcc's device pass too, which has no use for a table of host functions */
 const Variant kVariants[] = {
     {0u, pt_launch_persistent_matte, "matte", pt_launch_persistent_matte5, TB_MATTE_WAVES, 0, wf_launch_matte, true, pt_launch_split_matte},
         {PT_FEAT_ENV, pt_launch_persistent_env, "env", pt_launch_persistent_env5, TB_ENV_WAVES, 1, wf_launch_env, true, pt_launch_split_env},
@@ -84,126 +22,10 @@ const Variant kVariants[] = {
     {PT_FEAT_ENV | PT_FEAT_SPECULAR | PT_FEAT_TEXTURES | PT_FEAT_SSS | PT_FEAT_MIX, pt_launch_persistent_vol, "vol", pt_launch_persistent_vol4, TB_VOL_WAVES, 3, wf_launch_vol, false, nullptr},
         {PT_FEAT_ALL, pt_launch_persistent_full, "full", nullptr, 0, 4, nullptr, false, nullptr},
 };
-constexpr int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
-
-struct DevBuf {
-    void* p = nullptr; size_t bytes = 0;
-    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
-};
-
-} // namespace
-
-struct tb_context {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, evKernelStart = nullptr, evKernel = nullptr; /* evKernelStart..evKernel: the render's first path-tracing launch */
-    /* frame-group launches alternate between two side streams and two sample buffers: launch k+1 starts while the last paths
-     * of launch k drain; the folds stay on `stream`, in order (renderImpl) */
-    hipStream_t side[2] = {nullptr, nullptr};
-    hipEvent_t evPt[2] = {nullptr, nullptr}, evFold[2] = {nullptr, nullptr}, evMain = nullptr;
-    DevBuf fgSamples[2];
-    int numCUs = 0;           /* of `device` (deviceCUs) */
-    uint32_t launchEpoch = 0; /* TbDeviceTargets::launchEpoch of the last frame-group launch */
-    DevBuf fgSlotLog[2]; /* frame-group mode: the workgroups' logs of bound slots (TbDeviceTargets::slotLog) */
-    DevBuf fgHits[2];   /* primary-visibility pre-pass: 32-B record of every sample's first hit (TbDeviceTargets::primaryHits) */
-    DevBuf stackOverflow; /* split traversal stack of the higher-occupancy kernel copies on deep trees (pt_scene.h) */
-    std::vector<const void*> warmedLaunchers; /* frame-group kernels that have run once on both side streams (renderImpl) */
-    uint32_t fgLaunch = 0; bool sideOrdered = false; /* sideOrdered: the side streams have been ordered after everything else on `stream` */
-    uint32_t lastKernelFrames = 0; float lastKernelMs = 0.0f;
-    std::string err;
-    HostScene scene; bool hasScene = false;
-    tb_camera camera{};
-    std::vector<DevBuf> sceneBufs;
-    TbDeviceScene ds{};
-    uint32_t sceneFeatures = 0; bool sceneInLds = false;
-    /* surfaces */
-    uint32_t width = 0, height = 0;
-    DevBuf output, jittered, aov[8], stats, rayStats, packed;
-    DevBuf postOut, postRgba8, postHistogram, postAverage; /* output stage (post_kernels.hip) */
-    /* real-time chain (rt_kernels.hip): ping-pong histories like TracerBoy.h:513-518,747-749 */
-    DevBuf rtIndirect[2], rtMoment[2], rtFinal[2], rtDenoise[2], rtComposited;
-    uint32_t rtActive = 0, rtWidth = 0, rtHeight = 0; int rtLast[5] = {-1, -1, -1, -1, -1}; /* which buffer holds each stage's last output */
-    bool lastRenderRealtime = false; tb_camera prevCamera{};
-    /* wavefront pipeline: two ping-pong extend queues (4 columns), one shadow queue (11 columns), hits, samples, counters */
-    DevBuf wfCols[2][6], wfShadowCols[12], wfHitA, wfHitG, wfSamples, wfCounts, workCounter;
-    uint64_t wfCapacity = 0, wfSampleCapacity = 0;
-    int lastPipeline = 0;
-    uint32_t samplesRendered = 0;
-    tb_output_settings lastSettings{}; bool haveLastSettings = false;
-    float lastTime = 0.0f;
-    uint32_t selX = 0xffffffffu, selY = 0xffffffffu;
-    TbTileMap tiles{0, 1, 64, 64};
-    std::map<std::string, int64_t> options;
-    float lastMs = 0.0f;
-    std::string lastVariant;
-    int lastNodeLayout = 0; /* 1: the last render walked the compact layout-C nodes */
-    int lastSlotLogCap = 0;
-    struct PrepassTrial { uint64_t key = 0; int calls = 0, pending = 0, nWith = 0, nWithout = 0; float msWith = 0, msWithout = 0; bool keep = false; uint64_t stamp = 0; } prepassTrial; /* renderImpl */
-    /* Do back-to-back calls gain from running on the two side streams at once?  Found by measurement where it is in doubt (renderImpl):
-     * the end of every render is marked by an event of a ring; the interval between two consecutive ends, when the later call was enqueued
-     * before the earlier one had finished (the device was never idle between them), is what a call costs in that mode. */
-    struct OverlapTrial { uint64_t key = 0; int phase = 0 /* 0 measuring overlapped, 1 measuring one at a time, 2 decided */; int n[2] = {0, 0}; float best[2] = {0, 0}; bool keep = true; } overlapTrial;
-    struct CallRec { uint64_t key = 0; int mode = -1; bool deviceBound = false, settled = false, used = true; } callRec[8];
-    hipEvent_t evCallEnd[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; uint64_t callCount = 0; int lastOverlap = 0;
-    tb_launch_plan lastPlan{}; /* what PlanLaunch decided for the last render (options last_plan_rule_*) */
-    uint64_t kernelEventStamp = 0; /* counts the renders that have recorded evKernelStart / evKernel: a trial's sample belongs to the render it was asked of */
-    uint32_t sceneGeneration = 0; /* counts finalizeScene calls */
-    float interiorWalkTriangleShare = 0; /* finalizeScene */
-    DevBuf debugCounters; /* TbDeviceTargets::debugCounters (16 words, zeroed once) */
-    DevBuf splitProf; uint32_t* splitAbort = nullptr; int lastSplitWaves = 0; /* pipeline 4: host-mapped abort word of the split-role kernel (renderSplit); travWaves * 100 + shadeWaves of the last launch */
-    int lastFgPar = 0;          /* which of the two sample buffers the last frame-group launch wrote (debug query) */
-    int lastPrimaryPrepass = 0; /* 1: the last render took its first hits from the primary-visibility pre-pass */
-    /* Multi-device group (tb_create_multi): this context is device 0 of the group and owns the assembled frame; `peers` are the
-     * contexts of the other devices.  A render splits the frame into 64x64 tiles dealt round-robin over the devices (DESIGN.md
-     * section 7), every device renders its own, the peers' packed tiles come over with hipMemcpyPeerAsync (xGMI) and are un-permuted
-     * into this context's accumulation surfaces.  One host thread drives all devices; nothing blocks until the final wait. */
-    std::vector<tb_context*> peers;
-    tb_context* groupOwner = nullptr;          /* set on a peer: API calls on a peer handle are refused */
-    DevBuf groupPacked[2], groupGathered[2];   /* [0] output, [1] jittered: this device's packed tiles; (owner) world x capacity gathered tiles */
-    hipEvent_t evGroup = nullptr, evGroupDone = nullptr; /* evGroupDone (owner): the un-permute of the last group render has read groupGathered */
-    bool compactTried = false; /* layout C was asked for and built -- or could not be built -- for the loaded scene (ensureCompactNodes) */
-};
-
-namespace {
-
-#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
+const int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
+#endif
 
 int fail(tb_context* c, int code, const std::string& msg) { if (c) c->err = msg; else g_createError = msg; return code; }
-
-/* Every entry point runs on its context's device and hands the calling thread back the device it came with: a host that shares the
- * thread (torch in bench.py, an application's own hipMalloc) would otherwise go on allocating and launching on the last peer of a
- * device group. */
-struct DeviceScope {
-    int saved = -1;
-    explicit DeviceScope(int dev) { if (hipGetDevice(&saved) != hipSuccess) saved = -1; (void)hipSetDevice(dev); }
-    ~DeviceScope() { if (saved >= 0) (void)hipSetDevice(saved); }
-};
-
-template <class F> int guarded(tb_context* c, F f)
-{
-    if (!c) return TB_E_INVALID;
-    try { DeviceScope scope(c->device); return f(); }
-    catch (const std::bad_alloc&) { return fail(c, TB_E_DEVICE, "out of host memory"); }
-    catch (const std::exception& e) {
-        std::string m = e.what();
-        int code = TB_E_PARSE;
-        if (m.find("hip") == 0 || m.find("HIP") != std::string::npos) code = TB_E_DEVICE;
-        else if (m.find("open") != std::string::npos || m.find("Couldn't") != std::string::npos) code = TB_E_IO;
-        else if (m.find("not supported") != std::string::npos || m.find("unsupported") != std::string::npos) code = TB_E_UNSUPPORTED;
-        return fail(c, code, m);
-    }
-}
-
-template <class T> const T* upload(tb_context* c, const std::vector<T>& v)
-{
-    DevBuf b;
-    b.bytes = v.size() * sizeof(T);
-    if (b.bytes == 0) return nullptr;
-    HIP_TRY(hipMalloc(&b.p, b.bytes));
-    c->sceneBufs.push_back(b);
-    HIP_TRY(hipMemcpyAsync(b.p, v.data(), b.bytes, hipMemcpyHostToDevice, c->stream));
-    return (const T*)b.p;
-}
 
 void ensure(DevBuf& b, size_t bytes)
 {
@@ -213,860 +35,7 @@ void ensure(DevBuf& b, size_t bytes)
     HIP_TRY(hipMalloc(&b.p, bytes));
     b.bytes = bytes;
 }
-
-void releaseScene(tb_context* c)
-{
-    for (DevBuf& b : c->sceneBufs) b.release();
-    c->sceneBufs.clear();
-    memset(&c->ds, 0, sizeof c->ds);
-}
-
-uint32_t sceneFeatureMask(const HostScene& s)
-{
-    uint32_t f = 0;
-    if (!s.envMap.empty()) f |= PT_FEAT_ENV;
-    for (const TbMaterial& m : s.materials) {
-        if ((m.Flags & TB_MAT_NO_SPECULAR) == 0 && (m.Flags & TB_MAT_MIX) == 0) f |= PT_FEAT_SPECULAR;
-        if (m.albedoIndex != TB_INVALID_TEXTURE || m.emissiveIndex != TB_INVALID_TEXTURE || m.specularMapIndex != TB_INVALID_TEXTURE || m.normalMapIndex != TB_INVALID_TEXTURE) f |= PT_FEAT_TEXTURES | PT_FEAT_SPECULAR;
-        if (m.Flags & TB_MAT_SUBSURFACE_SCATTER) f |= PT_FEAT_SSS;
-        if (m.Flags & TB_MAT_MIX) f |= PT_FEAT_MIX;
-    }
-    for (const TbLight& l : s.lights) if (l.LightType != TB_LIGHT_TYPE_AREA) f |= PT_FEAT_EXT;
-    /* two-level scenes: renderImpl picks a kernel copy that walks instances (the frame-group kernels of the higher-occupancy copies,
-     * else the full feature set) */
-    return f;
-}
-
-uint32_t settingsFeatureMask(const tb_context* c, const tb_output_settings& s, bool aov)
-{
-    bool ext = s.EnableSamplingImportanceResampling || s.DOFFocalDistance > 0.0f || s.FilterType != TB_FILTER_TYPE_BOX ||
-               s.FireflyClampValue != 0.0f || s.RenderModeRealTime || s.OutputType == TB_OUTPUT_TYPE_HEATMAP || aov ||
-               (c->selX != 0xffffffffu) || c->ds.alphaTest != 0;
-    return ext ? PT_FEAT_EXT : 0u;
-}
-
-/* Storage order of the layout-B nodes (results do not depend on it).  order 0: breadth-first, the top of the tree is one
- * contiguous prefix; order 1: depth-first pre-order, a node's left child follows it (same 128-B line every other step of
- * a descent); order 2: breadth-first for the top `topLevels` levels, depth-first below (cached top + local subtrees);
- * order 3: blocks of `topLevels` levels stored breadth-first, the blocks themselves depth-first (van Emde Boas style: a
- * descent of `topLevels` steps stays inside one contiguous block); order 4: depth-first by SIBLING PAIRS -- the two inner children
- * of a node lie side by side in one aligned 128-B line (a dummy node pads where needed), so fetching the near child brings the
- * far child's record along for when it is popped; order 5: order 4 below a breadth-first top of `topLevels` levels. */
-void reorderNodes(HostScene& s, int order_, uint32_t topLevels)
-{
-    const uint32_t n = (uint32_t)s.nodesB.size();
-    if (s.rootRefB & TB_BVH_LEAF_FLAG) return;
-    constexpr uint32_t PAD = 0xffffffffu;
-    std::vector<uint32_t> order; order.reserve(n + n / 4);
-    std::vector<uint32_t> newIndex(n, 0);
-    auto inner = [](uint32_t ref) { return !(ref & TB_BVH_LEAF_FLAG); };
-    auto pairDfs = [&](uint32_t root) { /* `root` itself is already placed */
-        std::vector<uint32_t> st; st.push_back(root);
-        while (!st.empty()) {
-            const uint32_t x = st.back(); st.pop_back();
-            const TbNodeB& nd = s.nodesB[x];
-            const bool li = inner(nd.left), ri = inner(nd.right);
-            if (li && ri && (order.size() & 1u)) order.push_back(PAD);
-            if (li) order.push_back(nd.left);
-            if (ri) order.push_back(nd.right);
-            if (ri) st.push_back(nd.right);
-            if (li) st.push_back(nd.left);
-        }
-    };
-    auto dfs = [&](uint32_t root) {
-        std::vector<uint32_t> st; st.push_back(root);
-        while (!st.empty()) {
-            uint32_t x = st.back(); st.pop_back(); order.push_back(x);
-            const TbNodeB& nd = s.nodesB[x];
-            if (inner(nd.right)) st.push_back(nd.right);
-            if (inner(nd.left)) st.push_back(nd.left);
-        }
-    };
-    if (order_ == 1) dfs(s.rootRefB);
-    else if (order_ == 4) { order.push_back(s.rootRefB); pairDfs(s.rootRefB); }
-    else if (order_ == 3) {
-        const uint32_t h = topLevels ? topLevels : 2;
-        std::vector<uint32_t> blocks; blocks.push_back(s.rootRefB);
-        std::vector<uint32_t> level, next, below;
-        while (!blocks.empty()) {
-            level.assign(1, blocks.back()); blocks.pop_back(); below.clear();
-            for (uint32_t d = 0; d < h && !level.empty(); d++) {
-                next.clear();
-                for (uint32_t x : level) { order.push_back(x); const TbNodeB& nd = s.nodesB[x]; if (inner(nd.left)) next.push_back(nd.left); if (inner(nd.right)) next.push_back(nd.right); }
-                level.swap(next);
-            }
-            for (size_t i = level.size(); i-- > 0;) blocks.push_back(level[i]); /* leftmost block below comes next */
-        }
-    } else {
-        std::vector<uint32_t> level; level.push_back(s.rootRefB);
-        uint32_t depth = 0;
-        while (!level.empty() && (order_ == 0 || depth < topLevels)) { /* orders 0, 2, 5 */
-            std::vector<uint32_t> next;
-            for (uint32_t x : level) { order.push_back(x); const TbNodeB& nd = s.nodesB[x]; if (inner(nd.left)) next.push_back(nd.left); if (inner(nd.right)) next.push_back(nd.right); }
-            level.swap(next); depth++;
-        }
-        if (order_ == 5) { if ((order.size() & 1u) && !level.empty()) order.push_back(PAD); for (uint32_t x : level) order.push_back(x); for (uint32_t x : level) pairDfs(x); }
-        else for (uint32_t x : level) dfs(x); /* order 2: the subtrees hanging below the breadth-first top */
-    }
-    for (uint32_t i = 0; i < (uint32_t)order.size(); i++) if (order[i] != PAD) newIndex[order[i]] = i;
-    std::vector<TbNodeB> out(order.size());
-    for (uint32_t i = 0; i < (uint32_t)order.size(); i++) {
-        if (order[i] == PAD) { memset(&out[i], 0, sizeof(TbNodeB)); out[i].left = out[i].right = TB_BVH_LEAF_FLAG; continue; }
-        TbNodeB nd = s.nodesB[order[i]];
-        if (inner(nd.left)) nd.left = newIndex[nd.left];
-        if (inner(nd.right)) nd.right = newIndex[nd.right];
-        out[i] = nd;
-    }
-    s.nodesB.swap(out);
-    s.rootRefB = 0;
-}
-
-/* option "bvh_builder" = 2 / 4: the LBVH of builder 0 / the LBVH + treelet passes of builder 3 constructed on the GPU
- * (bvh_kernels.hip); the host copies are filled
- * from the device result so that every host-side consumer (oracle view, layout queries) sees the same tree */
-void BuildBvhGpu(tb_context* c, HostScene& s, uint32_t treeletPasses)
-{
-    const uint64_t N64 = s.triGeometry.size();
-    if (N64 == 0) throw std::runtime_error("BuildBvh: no triangles");
-    if (N64 > 0x00ffffffull) throw std::runtime_error("BuildBvh: more than 2^24-1 triangles does not fit the 24-bit node indices of the reference layout");
-    if (s.blueNoise0.empty()) LoadBlueNoiseTiles(s);
-    const uint32_t N = (uint32_t)N64;
-    const uint64_t nodes = 2ull * N - 1, total = 16 + 32 * nodes + 52ull * N;
-    if (total > 0xffffffffull) throw std::runtime_error("BuildBvh: BVH image exceeds 4 GiB");
-    DevBuf dPos, dIdx, dGeo, dPrim, dFlag, dA, dNodes, dTris, dScratch, dHeight;
-    auto up = [&](DevBuf& b, const void* p, size_t bytes) { ensure(b, bytes); HIP_TRY(hipMemcpyAsync(b.p, p, bytes, hipMemcpyHostToDevice, c->stream)); };
-    try {
-        up(dPos, s.positions.data(), s.positions.size() * 4); up(dIdx, s.triVertexIndex.data(), s.triVertexIndex.size() * 4);
-        up(dGeo, s.triGeometry.data(), 4ull * N); up(dPrim, s.triPrimitive.data(), 4ull * N); up(dFlag, s.triFlags.data(), 4ull * N);
-        const size_t nB = N > 1 ? N - 1 : 1, scratchBytes = bvh_gpu_scratch_bytes(N);
-        ensure(dA, total); ensure(dNodes, nB * sizeof(TbNodeB)); ensure(dTris, (size_t)N * sizeof(TbTriB)); ensure(dScratch, scratchBytes); ensure(dHeight, 4);
-        HIP_TRY(hipMemsetAsync(dNodes.p, 0, nB * sizeof(TbNodeB), c->stream));
-        HIP_TRY(bvh_gpu_build(c->stream, (const float*)dPos.p, (const uint32_t*)dIdx.p, (const uint32_t*)dGeo.p, (const uint32_t*)dPrim.p, (const uint32_t*)dFlag.p, N,
-                              treeletPasses, (uint8_t*)dScratch.p, scratchBytes, (uint8_t*)dA.p, (TbNodeB*)dNodes.p, (TbTriB*)dTris.p, (uint32_t*)dHeight.p));
-        s.bvhA.resize((size_t)total); s.nodesB.resize(nB); s.trisB.resize(N);
-        HIP_TRY(hipMemcpy(s.bvhA.data(), dA.p, total, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(s.nodesB.data(), dNodes.p, nB * sizeof(TbNodeB), hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(s.trisB.data(), dTris.p, (size_t)N * sizeof(TbTriB), hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(&s.bvhMaxDepth, dHeight.p, 4, hipMemcpyDeviceToHost));
-        s.rootRefB = N == 1 ? TB_BVH_LEAF_FLAG : 0u;
-    } catch (...) {
-        for (DevBuf* b : {&dPos, &dIdx, &dGeo, &dPrim, &dFlag, &dA, &dNodes, &dTris, &dScratch, &dHeight}) b->release();
-        throw;
-    }
-    for (DevBuf* b : {&dPos, &dIdx, &dGeo, &dPrim, &dFlag, &dA, &dNodes, &dTris, &dScratch, &dHeight}) b->release();
-}
-
-/* Layout C (tb_abi.h TbNodeC): the layout-B nodes, same order, boxes rounded outward onto a 16-bit grid over the root box.
- * A quantised box [c - h, c + h] contains its layout-B box with at least an eighth of a cell to spare on every side, which is
- * what covers the different rounding of the two slab computations (the kernel evaluates q * (cell * inv) - (o - origin) * inv
- * where layout B evaluates c * inv - o * inv: errors of a few ulp of |c * inv| + |o * inv|, i.e. below 2^-6 cells while ray origin
- * and box lie within a few scene extents of each other). */
-void buildCompactNodes(const HostScene& s, std::vector<TbNodeC>& out, TbQuantFrame& q, uint32_t nodeUnits)
-{
-    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-    auto grow = [&](const float* cc, const float* hh, int k) { for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], (double)cc[a * 2 + k] - hh[a * 2 + k]); hi[a] = std::max(hi[a], (double)cc[a * 2 + k] + hh[a * 2 + k]); } };
-    auto boxOf = [](const TbNodeB& n, float* cc, float* hh) { /* [axis * 2 + child] */
-        cc[0] = n.cx[0]; cc[1] = n.cx[1]; cc[2] = n.cy[0]; cc[3] = n.cy[1]; cc[4] = n.cz[0]; cc[5] = n.cz[1];
-        hh[0] = n.hx[0]; hh[1] = n.hx[1]; hh[2] = n.hy[0]; hh[3] = n.hy[1]; hh[4] = n.hz[0]; hh[5] = n.hz[1];
-    };
-    auto isPad = [](const TbNodeB& n) { return n.left == TB_BVH_LEAF_FLAG && n.right == TB_BVH_LEAF_FLAG && n.hx[0] == 0.0f && n.hx[1] == 0.0f && n.cx[0] == 0.0f && n.cx[1] == 0.0f; };
-    for (const TbNodeB& n : s.nodesB) { if (isPad(n)) continue; float cc[6], hh[6]; boxOf(n, cc, hh); grow(cc, hh, 0); grow(cc, hh, 1); }
-    double ext = 0; for (int a = 0; a < 3; a++) ext = std::max(ext, hi[a] - lo[a]);
-    if (!(ext > 0)) ext = 1.0;
-    for (int a = 0; a < 3; a++) {
-        const double e = std::max(hi[a] - lo[a], ext * 1e-6); /* flat scenes: keep the cell finite */
-        q.cell[a] = (float)(e * 1.004 / 65535.0);
-        q.origin[a] = (float)(lo[a] - 0.002 * e);
-        /* the origin is an fp32 number: step it DOWN until two cells of margin are really there (a scene far from the coordinate origin has
-         * ulps larger than the margin; if they are larger than the grid can absorb, the box test below refuses the layout and the render
-         * stays with layout B) */
-        for (int guard = 0; guard < 64 && !((double)q.origin[a] + 2.0 * (double)q.cell[a] <= lo[a]); guard++) q.origin[a] = std::nextafter(q.origin[a], -std::numeric_limits<float>::infinity());
-    }
-    out.assign(s.nodesB.size(), TbNodeC{});
-    auto ref = [nodeUnits](uint32_t r) { return (r & TB_BVH_LEAF_FLAG) ? (TB_BVH_LEAF_FLAG | ((r & ~TB_BVH_LEAF_FLAG) * 3u)) : r * nodeUnits; };
-    for (size_t i = 0; i < s.nodesB.size(); i++) {
-        const TbNodeB& n = s.nodesB[i]; TbNodeC& o = out[i];
-        o.left = ref(n.left); o.right = ref(n.right);
-        if (isPad(n)) continue;
-        float cc[6], hh[6]; boxOf(n, cc, hh);
-        for (int a = 0; a < 3; a++) for (int k = 0; k < 2; k++) {
-            const double bl = ((double)cc[a * 2 + k] - hh[a * 2 + k] - q.origin[a]) / q.cell[a], bh = ((double)cc[a * 2 + k] + hh[a * 2 + k] - q.origin[a]) / q.cell[a];
-            long ql = (long)std::floor(bl - 0.125), qh = (long)std::ceil(bh + 0.125);
-            if (ql < 0 || qh > 65535 || !(bl == bl) || !(bh == bh)) throw std::runtime_error("compact nodes: a box lies outside the quantisation grid");
-            const long cq = (ql + qh) >> 1, hq = qh - cq; /* cq - hq <= ql and cq + hq == qh */
-            o.c[a][k] = (uint16_t)cq; o.h[a][k] = (uint16_t)hq;
-        }
-    }
-}
-
-/* Layout C for the loaded scene, on first demand (option "node_layout" = 1 at a render or a trace): +32 B per node of device memory and a
- * host pass, paid only by who asks.  A scene the 16-bit grid cannot hold (coordinates far from the origin relative to the extent, boxes
- * with NaN or infinite bounds) keeps layout B: the failure is remembered, not thrown (it used to abort tb_load_scene). */
-void ensureCompactNodes(tb_context* c)
-{
-    if (c->compactTried || c->ds.nodesC) return;
-    c->compactTried = true;
-    const HostScene& s = c->scene;
-    if (!s.instances.empty() || (s.rootRefB & TB_BVH_LEAF_FLAG)) return;
-    try {
-        std::vector<TbNodeC> compact;
-        buildCompactNodes(s, compact, c->ds.quant, 2u);
-        c->ds.nodesC = upload(c, compact);
-    } catch (const std::exception&) { c->ds.nodesC = nullptr; }
-}
-
-/* the top level of a two-level scene on the GPU (bvh_gpu_build_tlas): same bytes as bvh_build.cpp BuildTlas / the oracle's tbo_build_tlas */
-void BuildTlasGpu(tb_context* c, HostScene& s, const std::vector<float>& blasBoxes, std::vector<TbNodeB>& top, uint32_t& rootRef, uint32_t& depth)
-{
-    const uint32_t M = (uint32_t)s.instances.size();
-    std::vector<float> o2w(12ull * M), w2o(12ull * M); std::vector<uint32_t> blas(M), base(M);
-    for (uint32_t i = 0; i < M; i++) { memcpy(&o2w[12ull * i], s.instances[i].objectToWorld, 48); memcpy(&w2o[12ull * i], s.instances[i].worldToObject, 48); blas[i] = s.instances[i].blas; base[i] = s.instances[i].hitGroupBase; }
-    const size_t total = 16 + 32 * (2ull * M - 1) + 116ull * M, scratchBytes = bvh_gpu_tlas_scratch_bytes(M);
-    DevBuf dO, dW, dB, dH, dBox, dScratch, dA, dTop, dWords;
-    auto up = [&](DevBuf& b, const void* p, size_t bytes) { ensure(b, bytes); HIP_TRY(hipMemcpyAsync(b.p, p, bytes, hipMemcpyHostToDevice, c->stream)); };
-    try {
-        up(dO, o2w.data(), o2w.size() * 4); up(dW, w2o.data(), w2o.size() * 4); up(dB, blas.data(), 4ull * M); up(dH, base.data(), 4ull * M); up(dBox, blasBoxes.data(), blasBoxes.size() * 4);
-        ensure(dScratch, scratchBytes); ensure(dA, total); ensure(dTop, std::max<size_t>(1, M - 1) * sizeof(TbNodeB)); ensure(dWords, 8);
-        HIP_TRY(hipMemsetAsync(dA.p, 0, total, c->stream));
-        HIP_TRY(bvh_gpu_build_tlas(c->stream, M, (const float*)dO.p, (const float*)dW.p, (const uint32_t*)dB.p, (const uint32_t*)dH.p, (const float*)dBox.p, (uint8_t*)dScratch.p, scratchBytes,
-                                   (uint8_t*)dA.p, (TbNodeB*)dTop.p, (uint32_t*)dWords.p, (uint32_t*)dWords.p + 1));
-        s.tlasA.resize(total); top.assign(M > 1 ? M - 1 : 0, TbNodeB{});
-        uint32_t words[2];
-        HIP_TRY(hipMemcpy(s.tlasA.data(), dA.p, total, hipMemcpyDeviceToHost));
-        if (M > 1) HIP_TRY(hipMemcpy(top.data(), dTop.p, (size_t)(M - 1) * sizeof(TbNodeB), hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(words, dWords.p, 8, hipMemcpyDeviceToHost));
-        rootRef = words[0]; depth = words[1];
-    } catch (...) {
-        for (DevBuf* b : {&dO, &dW, &dB, &dH, &dBox, &dScratch, &dA, &dTop, &dWords}) b->release();
-        throw;
-    }
-    for (DevBuf* b : {&dO, &dW, &dB, &dH, &dBox, &dScratch, &dA, &dTop, &dWords}) b->release();
-}
-
-void finalizeScene(tb_context* c, bool build = true) /* build = false: c->scene already holds a built, reordered tree (a peer of a multi-device group) */
-{
-    HostScene& s = c->scene;
-    c->sceneGeneration++;
-    {   /* share of the triangles whose material sends a path on an interior walk (the pre-pass policy in renderImpl) */
-        uint64_t walks = 0;
-        if (s.instances.empty())
-            for (uint32_t g : s.triGeometry) { if (g < s.hitGroups.size()) { const uint32_t m = s.hitGroups[g].MaterialIndex; if (m < s.materials.size() && (s.materials[m].Flags & TB_MAT_SUBSURFACE_SCATTER)) walks++; } }
-        c->interiorWalkTriangleShare = s.triGeometry.empty() ? 0.0f : (float)((double)walks / (double)s.triGeometry.size());
-    }
-    auto opt = [&](const char* k, int64_t d) { auto it = c->options.find(k); return it == c->options.end() ? d : it->second; };
-    const int64_t builder = opt("bvh_builder", 0);
-    const bool twoLevel = !s.instances.empty();
-    if (build) {
-    if (twoLevel && (builder == 2 || builder == 4)) /* every bottom-level structure and the top level on the GPU (GpuBVH2Builder.cpp:498-501: the same passes, no treelets at the top) */
-        BuildBvhWith(s, [&](HostScene& one) { BuildBvhGpu(c, one, builder == 4 ? 3u : 0u); },
-                     [&](HostScene& all, const std::vector<float>& boxes, std::vector<TbNodeB>& top, uint32_t& rootRef, uint32_t& depth) { BuildTlasGpu(c, all, boxes, top, rootRef, depth); });
-    else if (twoLevel) BuildBvh(s, (int)builder);
-    else if (builder == 2 || builder == 4) BuildBvhGpu(c, s, builder == 4 ? 3u : 0u);
-    else BuildBvh(s, (int)builder);
-    if (!twoLevel) reorderNodes(s, (int)opt("node_order", 2), (uint32_t)opt("node_order_top_levels", 10)); /* measured on the 870 k scene: 0 -> 2258, 1 -> 2283, 2 (10 levels) -> 2300 Msamples/s */
-    }
-    c->camera = s.camera;
-    releaseScene(c);
-    TbDeviceScene& d = c->ds;
-    if (s.nodesB.size() > 0x7fffffffull / 5 || s.trisB.size() > 0x7fffffffull / 3) throw std::runtime_error("scene too large for 31-bit device child refs");
-    /* device child refs: offsets in 16-B units (pt_scene.h) */
-    auto deviceRef = [](uint32_t ref, uint32_t nodeUnits) { return (ref & TB_BVH_LEAF_FLAG) ? (TB_BVH_LEAF_FLAG | ((ref & ~TB_BVH_LEAF_FLAG) * 3u)) : ref * nodeUnits; };
-    {
-        std::vector<TbNodeB> dev(s.nodesB);
-        /* two-level scenes: the first M - 1 nodes are the top level, whose leaf refs address 64-B instance records (4 units) */
-        const size_t topNodes = s.instances.size() > 1 ? s.instances.size() - 1 : 0;
-        auto topRef = [](uint32_t ref) { return (ref & TB_BVH_LEAF_FLAG) ? (TB_BVH_LEAF_FLAG | ((ref & ~TB_BVH_LEAF_FLAG) * 4u)) : ref * 4u; };
-        for (size_t i = 0; i < dev.size(); i++) {
-            TbNodeB& nd = dev[i];
-            if (i < topNodes) { nd.left = topRef(nd.left); nd.right = topRef(nd.right); } else { nd.left = deviceRef(nd.left, 4); nd.right = deviceRef(nd.right, 4); }
-        }
-        d.nodes = upload(c, dev);
-    }
-    d.tris = upload(c, s.trisB);
-    d.nodesC = nullptr; c->compactTried = false; /* layout C is built when a render or trace first asks for it (ensureCompactNodes) */
-    d.rootRef = twoLevel ? ((s.rootRefB & TB_BVH_LEAF_FLAG) ? (TB_BVH_LEAF_FLAG | ((s.rootRefB & ~TB_BVH_LEAF_FLAG) * 4u)) : s.rootRefB * 4u) : deviceRef(s.rootRefB, 4); /* 0 or LEAF|0: the same in both images */ d.numNodes = (uint32_t)s.nodesB.size(); d.numTris = (uint32_t)s.trisB.size();
-    { const TbAabbNode* root = (const TbAabbNode*)((twoLevel ? s.tlasA.data() : s.bvhA.data()) + 16); memcpy(d.rootCenter, root->center, 12); memcpy(d.rootHalf, root->halfDim, 12); }
-    {   /* instances in their device form: the bottom-level root as a device child ref */
-        std::vector<TbInstanceB> devInst(s.instancesB);
-        for (TbInstanceB& ib : devInst) ib.blasRootRef = deviceRef(ib.blasRootRef, 4);
-        d.instances = upload(c, devInst); d.numInstances = (uint32_t)devInst.size();
-    }
-    /* shading records in their 16-B aligned device form (pt_scene.h) */
-    std::vector<TbDevHitGroup> devHit(s.hitGroups.size());
-    for (size_t i = 0; i < devHit.size(); i++) {
-        if (s.hitGroups[i].VertexBufferOffset % 32 || s.hitGroups[i].IndexBufferOffset % 4) throw std::runtime_error("hit group buffer offsets must be vertex-/index-aligned");
-        devHit[i] = TbDevHitGroup{s.hitGroups[i].MaterialIndex, s.hitGroups[i].VertexBufferOffset / 4, s.hitGroups[i].IndexBufferOffset / 4, 0};
-    }
-    std::vector<TbDevMaterial> devMat(s.materials.size());
-    for (size_t i = 0; i < devMat.size(); i++) { memset(&devMat[i], 0, sizeof(TbDevMaterial)); devMat[i].m = s.materials[i]; }
-    std::vector<TbDevLight> devLight(s.lights.size());
-    for (size_t i = 0; i < devLight.size(); i++) { memset(&devLight[i], 0, sizeof(TbDevLight)); devLight[i].l = s.lights[i]; }
-    d.hitGroups = upload(c, devHit); d.numHitGroups = (uint32_t)s.hitGroups.size();
-    d.indexBuffer = upload(c, s.indexBuffer); d.numIndices = (uint32_t)s.indexBuffer.size();
-    d.vertexBuffer = upload(c, s.vertexBuffer); d.numVertexFloats = (uint32_t)s.vertexBuffer.size();
-    d.materials = upload(c, devMat); d.numMaterials = (uint32_t)s.materials.size();
-    d.textureData = upload(c, s.textureData); d.numTextureData = (uint32_t)s.textureData.size();
-    d.lights = upload(c, devLight); d.numLights = (uint32_t)s.lights.size();
-    d.images = upload(c, s.images); d.numImages = (uint32_t)s.images.size();
-    d.texelPool = upload(c, s.texelPool);
-    d.envMap = upload(c, s.envMap); d.envWidth = s.envWidth; d.envHeight = s.envHeight;
-    d.blueNoise0 = upload(c, s.blueNoise0); d.blueNoise1 = upload(c, s.blueNoise1);
-    d.config = s.config;
-    /* a root-to-leaf path of bvhMaxDepth nodes has bvhMaxDepth - 1 inner nodes, each of which parks at most one far child: the
-     * walk never holds more than bvhMaxDepth - 1 entries (one spare) */
-    d.stackDepth = s.bvhMaxDepth < 2 ? 2 : s.bvhMaxDepth;
-    d.alphaTest = opt("alpha_test", 0) ? 1u : 0u;
-    /* whole-scene LDS image */
-    {
-        std::vector<uint8_t> blob;
-        auto put = [&](const void* p, size_t bytes) { while (blob.size() % 16) blob.push_back(0); uint32_t off = (uint32_t)blob.size(); const uint8_t* b = (const uint8_t*)p; blob.insert(blob.end(), b, b + bytes); return off; };
-        auto ldsRef = [](uint32_t ref) { return (ref & TB_BVH_LEAF_FLAG) ? (TB_BVH_LEAF_FLAG | ((ref & ~TB_BVH_LEAF_FLAG) * 3u * TB_LDS_TRI_COPIES)) : ref * (TB_LDS_NODE_STRIDE / 16); };
-        {   /* nodes TB_LDS_NODE_STRIDE apart (pt_scene.h) */
-            std::vector<uint8_t> padded(s.nodesB.size() * TB_LDS_NODE_STRIDE, 0);
-            for (size_t i = 0; i < s.nodesB.size(); i++) {
-                TbNodeB nd = s.nodesB[i]; nd.left = ldsRef(nd.left); nd.right = ldsRef(nd.right);
-                memcpy(padded.data() + i * TB_LDS_NODE_STRIDE, &nd, sizeof nd);
-            }
-            d.offNodes = put(padded.data(), padded.size());
-        }
-        {   /* six axis-permuted copies per triangle (pt_scene.h): copy = kz * 2 + swapped, (kx, ky) = the two axes after kz, swapped when d[kz] < 0 */
-            std::vector<TbTriB> perm(s.trisB.size() * TB_LDS_TRI_COPIES);
-            for (size_t i = 0; i < s.trisB.size(); i++)
-                for (int kz = 0; kz < 3; kz++)
-                    for (int sw = 0; sw < 2; sw++) {
-                        int kx = kz == 2 ? 0 : kz + 1, ky = kx == 2 ? 0 : kx + 1;
-                        if (sw) std::swap(kx, ky);
-                        const TbTriB& t = s.trisB[i]; TbTriB q = t;
-                        const float* src[3] = {t.v0, t.v1, t.v2}; float* dst[3] = {q.v0, q.v1, q.v2};
-                        for (int v = 0; v < 3; v++) { dst[v][0] = src[v][kx]; dst[v][1] = src[v][ky]; dst[v][2] = src[v][kz]; }
-                        perm[i * TB_LDS_TRI_COPIES + (size_t)(kz * 2 + sw)] = q;
-                    }
-            d.offTris = put(perm.data(), perm.size() * sizeof(TbTriB));
-        }
-        d.offHitGroups = put(devHit.data(), devHit.size() * sizeof(TbDevHitGroup));
-        d.offIndices = put(s.indexBuffer.data(), s.indexBuffer.size() * 4);
-        d.offVertices = put(s.vertexBuffer.data(), s.vertexBuffer.size() * 4);
-        d.offMaterials = put(devMat.data(), devMat.size() * sizeof(TbDevMaterial));
-        d.offLights = put(devLight.data(), devLight.size() * sizeof(TbDevLight));
-        while (blob.size() % 16) blob.push_back(0);
-        size_t budget = (size_t)opt("lds_scene_budget", 40 * 1024);
-        c->sceneInLds = blob.size() + (size_t)d.stackDepth * 256 * 4 <= budget && opt("scene_in_lds", 1) != 0 && !twoLevel;
-        if (c->sceneInLds) { d.ldsBlob = upload(c, blob); d.ldsBlobBytes = (uint32_t)blob.size(); }
-        else { d.ldsBlob = nullptr; d.ldsBlobBytes = 0; }
-        /* measured on MI355X: LDS-resident scenes are nearly insensitive (at five waves per SIMD 1-2 is best: 6 745 / 6 730 against
-         * 6 680 at 4, 6 230 at 12), scenes fetched through the caches gain ~5 % from a late switch to the leaf phase (16-24) */
-        d.parkMin = (uint32_t)std::max<int64_t>(1, opt("park_min", c->sceneInLds ? 2 : 24));
-    }
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    c->sceneFeatures = sceneFeatureMask(s);
-    c->hasScene = true;
-    c->samplesRendered = 0;
-}
-
-bool historyRelevantChange(const tb_output_settings& a, const tb_output_settings& b) /* TracerBoy.cpp:2163-2185 */
-{
-    return a.OutputType != b.OutputType || a.EnableNormalMaps != b.EnableNormalMaps || a.RenderModeRealTime != b.RenderModeRealTime ||
-           a.DOFFocalDistance != b.DOFFocalDistance || a.ApertureWidth != b.ApertureWidth || a.FilterType != b.FilterType || a.FilterWidth != b.FilterWidth ||
-           a.FireflyClampValue != b.FireflyClampValue || a.EnableNextEventEstimation != b.EnableNextEventEstimation ||
-           a.EnableSamplingImportanceResampling != b.EnableSamplingImportanceResampling || a.EnableBlueNoise != b.EnableBlueNoise || a.MaxBounces != b.MaxBounces ||
-           a.DebugValue != b.DebugValue || a.DebugValue2 != b.DebugValue2;
-}
-
-/* Wavefront pipeline (option "pipeline" = 2): frames are processed in batches of as many frames as fit the path
- * budget; per batch: generate+extend, then MaxBounces x (shade, connect, extend), then the ordered accumulation.
- * Every launch is a fixed-size grid-stride kernel reading its queue length from device memory: no host sync inside. */
-void renderWavefront(tb_context* c, int variant, uint32_t W, uint32_t H, uint32_t firstFrame, uint32_t n, TbPerFrameConstants pf)
-{
-    auto opt = [&](const char* k, int64_t d) { auto it = c->options.find(k); return it == c->options.end() ? d : it->second; };
-    const uint64_t pixels = (uint64_t)W * H;
-    const uint64_t perFrame = (uint64_t)((W + 7) / 8) * ((H + 7) / 8) * 64; /* sample ids walk whole 8x8 tiles (wf_sample_pixel) */
-    const uint64_t budget = (uint64_t)opt("wavefront_paths", 16ll << 20);
-    const uint32_t segCap = (uint32_t)std::max<int64_t>(256, opt("wavefront_segment", 4096));
-    uint32_t batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n, budget / perFrame));
-    const uint64_t maxSegments = (perFrame * batch + segCap - 1) / segCap;
-    const uint64_t capacity = maxSegments * segCap;
-    if (capacity > 0xffffff00ull) throw std::runtime_error("wavefront batch exceeds 2^32 paths");
-    {   /* the LDS a stage asks for, checked here so that a large segment fails with a sentence instead of a launch error */
-        const size_t blobBytes = c->sceneInLds ? c->ds.ldsBlobBytes : 0, ldsLimit = 160 * 1024;
-        if (opt("wavefront_sort", 0)) {
-            if (segCap > 65536u) throw std::runtime_error("wavefront_sort: wavefront_segment must not exceed 65536 (the index permutation is 16-bit); unsupported");
-            const size_t sortBytes = 64 * 4 + ((size_t)segCap * 3 + 15) / 16 * 16;
-            if (16 + blobBytes + sortBytes > ldsLimit) throw std::runtime_error("wavefront_sort: a segment of " + std::to_string(segCap) + " entries needs " + std::to_string(16 + blobBytes + sortBytes) + " B of LDS (limit 163840): lower wavefront_segment; unsupported");
-        }
-        if (16 + (size_t)c->ds.stackDepth * 1024 + blobBytes > ldsLimit) throw std::runtime_error("wavefront pipeline: traversal stack of depth " + std::to_string(c->ds.stackDepth) + " does not fit LDS; unsupported");
-    }
-    const bool sss = (kVariants[variant].features & PT_FEAT_SSS) != 0; /* entries may be steps of the interior walk: two more columns per queue */
-    {
-        for (int q = 0; q < 2; q++) for (int k = 0; k < (sss ? 6 : 4); k++) ensure(c->wfCols[q][k], capacity * 16);
-        for (int k = 0; k < (sss ? 12 : 11); k++) if (sss || k != 8) ensure(c->wfShadowCols[k], capacity * 16); /* column i (8) and l (11): FEAT_SSS only */
-        ensure(c->wfHitA, capacity * 16); ensure(c->wfHitG, capacity * 4);
-        ensure(c->wfSamples, pixels * batch * 16);
-        ensure(c->wfCounts, maxSegments * 3 * 4);
-        c->wfCapacity = capacity;
-    }
-    WfQueue E[2], S; memset(E, 0, sizeof E); memset(&S, 0, sizeof S);
-    for (int q = 0; q < 2; q++) {
-        E[q].a = (float4*)c->wfCols[q][0].p; E[q].b = (float4*)c->wfCols[q][1].p; E[q].c = (float4*)c->wfCols[q][2].p; E[q].d = (float4*)c->wfCols[q][3].p;
-        E[q].e = (float4*)c->wfCols[q][4].p; E[q].f = (float4*)c->wfCols[q][5].p;
-    }
-    float4** sc[12] = {&S.a, &S.b, &S.c, &S.d, &S.e, &S.f, &S.g, &S.h, &S.i, &S.j, &S.k, &S.l};
-    for (int k = 0; k < 12; k++) *sc[k] = (float4*)c->wfShadowCols[k].p;
-    /* per-segment fill counts; every stage writes the counts of all segments of its output queues, so no clearing */
-    E[0].segCount = (uint32_t*)c->wfCounts.p; E[1].segCount = E[0].segCount + maxSegments; S.segCount = E[1].segCount + maxSegments;
-    WfHits hits; hits.tuv_prim = (float4*)c->wfHitA.p; hits.geom = (uint32_t*)c->wfHitG.p;
-    const wf_variant_fn fn = kVariants[variant].wf;
-    const uint32_t gridOpt = (uint32_t)opt("wavefront_grid", 256 * 8);
-    const uint32_t depth = pf.MaxBounces;
-    std::vector<uint32_t> counts;
-    for (uint32_t f0 = 0; f0 < n; f0 += batch) {
-        const uint32_t nf = std::min(batch, n - f0);
-        WfParams wp; memset(&wp, 0, sizeof wp);
-        wp.W = W; wp.H = H; wp.firstFrame = firstFrame + f0; wp.numFrames = nf; wp.tiles = c->tiles;
-        wp.samples = (float4*)c->wfSamples.p;
-        wp.segCapacity = segCap; wp.numSegments = (uint32_t)((perFrame * nf + segCap - 1) / segCap);
-        wp.sortByMaterial = opt("wavefront_sort", 0) ? 1u : 0u;
-        wp.refillBelow = (uint32_t)std::min<int64_t>(64, std::max<int64_t>(0, opt("wavefront_refill", 0)));
-        const uint32_t grid = std::min(gridOpt, wp.numSegments);
-        const int lds = c->sceneInLds ? 1 : 0;
-        HIP_TRY(fn(c->stream, WF_STAGE_GENERATE_EXTEND, &c->ds, &pf, &wp, nullptr, nullptr, &E[0], &hits, lds, nullptr, nullptr, grid));
-        /* One round = one ray per live path.  Without SSS a path casts one extension ray per bounce, so MaxBounces rounds empty the
-         * queues.  With SSS every step of an interior walk is a round of its own (up to 100 per bounce, kernel.glsl:1565): past the
-         * first MaxBounces rounds the host reads the segment counts back before each round and stops when nothing is left. */
-        for (uint32_t b = 0; depth > 0; b++) {
-            const WfQueue& in = E[b & 1]; const WfQueue& next = E[(b + 1) & 1];
-            HIP_TRY(fn(c->stream, WF_STAGE_SHADE, &c->ds, &pf, &wp, &in, &S, &next, &hits, lds, nullptr, nullptr, grid));
-            HIP_TRY(fn(c->stream, WF_STAGE_CONNECT, &c->ds, &pf, &wp, nullptr, &S, &next, &hits, lds, nullptr, nullptr, grid));
-            if (!sss && b + 1 >= depth) break;
-            /* SSS: past the first MaxBounces rounds the queues are looked at every FOURTH round only (a round over empty queues is a
-             * few no-op launches; a look is a copy + a wait of the host, which used to serialise host and device once per round) */
-            if (sss && b + 1 >= depth && ((b + 1 - depth) & 3u) == 0u) {
-                counts.resize(wp.numSegments);
-                HIP_TRY(hipMemcpyAsync(counts.data(), next.segCount, (size_t)wp.numSegments * 4, hipMemcpyDeviceToHost, c->stream));
-                HIP_TRY(hipStreamSynchronize(c->stream));
-                uint64_t live = 0; for (uint32_t v : counts) live += v;
-                if (live == 0) break;
-                if (b > depth * 101u + 8u) throw std::runtime_error("wavefront pipeline: paths still alive after MaxBounces x 101 rounds");
-            }
-            HIP_TRY(fn(c->stream, WF_STAGE_EXTEND, &c->ds, &pf, &wp, nullptr, nullptr, &next, &hits, lds, nullptr, nullptr, grid));
-        }
-        HIP_TRY(fn(c->stream, WF_STAGE_ACCUMULATE, &c->ds, &pf, &wp, nullptr, nullptr, nullptr, &hits, lds, (TbFloat4*)c->output.p, (TbFloat4*)c->jittered.p, gridOpt));
-    }
-}
-
-/* Pooled pipeline (option "pipeline" = 3, pt_pooled.inc): one persistent launch per batch of frames, then the ordered
- * accumulation of the batch's sample buffer. */
-void renderPooled(tb_context* c, int variant, uint32_t W, uint32_t H, uint32_t firstFrame, uint32_t n, TbPerFrameConstants pf)
-{
-    auto opt = [&](const char* k, int64_t d) { auto it = c->options.find(k); return it == c->options.end() ? d : it->second; };
-    const uint64_t pixels = (uint64_t)W * H;
-    const uint64_t budget = (uint64_t)opt("pooled_samples", 256ll << 20); /* sample buffer entries (16 B each) */
-    const uint32_t batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n, budget / pixels));
-    if (pixels * batch > 0xffffff00ull) throw std::runtime_error("pooled batch exceeds 2^32 samples");
-    ensure(c->wfSamples, pixels * batch * 16);
-    const wf_variant_fn fn = kVariants[variant].wf;
-    const uint32_t blocks = tb_persistent_grid(W, H, c->tiles);
-    if (blocks == 0) return; /* this rank owns no tile */
-    for (uint32_t f0 = 0; f0 < n; f0 += batch) {
-        WfParams wp; memset(&wp, 0, sizeof wp);
-        wp.W = W; wp.H = H; wp.firstFrame = firstFrame + f0; wp.numFrames = std::min(batch, n - f0); wp.tiles = c->tiles;
-        wp.samples = (float4*)c->wfSamples.p;
-        wp.pathsPerLane = (uint32_t)opt("pooled_paths", 2);
-        if (opt("pooled_profile", 0)) { /* counting variant: wave-occupancy slots, read back with tb_read_wave_profile */
-            ensure(c->rayStats, 21 * 8);
-            if (firstFrame + f0 == 0) HIP_TRY(hipMemsetAsync(c->rayStats.p, 0, 21 * 8, c->stream));
-            wp.prof = (unsigned long long*)c->rayStats.p + 7;
-        }
-        const int lds = c->sceneInLds ? 1 : 0;
-        HIP_TRY(fn(c->stream, WF_STAGE_POOLED, &c->ds, &pf, &wp, nullptr, nullptr, nullptr, nullptr, lds, nullptr, nullptr, blocks));
-        HIP_TRY(fn(c->stream, WF_STAGE_ACCUMULATE, &c->ds, &pf, &wp, nullptr, nullptr, nullptr, nullptr, lds, (TbFloat4*)c->output.p, (TbFloat4*)c->jittered.p, 2048));
-    }
-}
-
-/* compute units of the context's device, asked once */
-int deviceCUs(tb_context* c)
-{
-    if (!c->numCUs && hipDeviceGetAttribute(&c->numCUs, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess) throw std::runtime_error("hipDeviceGetAttribute(multiprocessor count) failed");
-    return c->numCUs;
-}
-
-/* Split-role pipeline (option "pipeline" = 4, pt_split.inc): workgroups of traversal waves + shading waves over an LDS ray queue.
- * The host side is frame-group mode's: batches of frames into one of two ordered sample buffers, launches alternating between the two
- * side streams so that a launch starts while the one before drains, accumulate_samples_kernel folding each batch in frame order on
- * the main stream.  Options: split_trav / split_shade (waves of either role per workgroup), split_ready, split_refill, split_wi /
- * split_wl (TbSplitParams), split_frame_group (frames of a wave's work item), split_stack_cap (stack entries kept in LDS; the rest
- * of a deeper tree's stack lives in global memory, pt_scene.h). */
-/* the split-role kernel's abort word and the state the wave that raised it left behind (pt_split.inc give_up); clears the word */
-std::string splitAbortMessage(tb_context* c)
-{
-    volatile uint32_t* w = c->splitAbort;
-    char buf[512];
-    static const char* why[] = {"?", "a traversal wave found nothing to walk", "a shading wave waited for hits", "a queue position stayed full"};
-    snprintf(buf, sizeof buf, "the split-role kernel gave up (%s for spin_limit sleeps; workgroup %u wave %u; state %u %u 0x%x 0x%x; tickets %u, positions %u, shading waves done %u); the frame is incomplete",
-             why[w[0] < 4 ? w[0] : 0], w[1] >> 8, w[1] & 255u, w[2], w[3], w[4], w[5], w[6], w[7], w[8]);
-    for (int i = 0; i < 9; i++) w[i] = 0;
-    return buf;
-}
-
-void renderSplit(tb_context* c, const Variant* v, uint32_t W, uint32_t H, uint32_t n, const TbPerFrameConstants& pf, TbDeviceTargets tg)
-{
-    auto opt = [&](const char* k, int64_t d) { auto it = c->options.find(k); return it == c->options.end() ? d : it->second; };
-    const uint64_t pixels = (uint64_t)W * H, budget = (uint64_t)opt("pooled_samples", 256ll << 20);
-    uint32_t batch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(n, 32768), budget / pixels));
-    batch = (n + (n + batch - 1) / batch - 1) / ((n + batch - 1) / batch); /* equal batches */
-    const int numCUs = deviceCUs(c);
-    const bool lds = c->sceneInLds;
-    TbSplitParams sp; memset(&sp, 0, sizeof sp);
-    sp.travWaves = (uint32_t)std::max<int64_t>(1, opt("split_trav", 4)); sp.shadeWaves = (uint32_t)opt("split_shade", 0);
-    if (!sp.shadeWaves) sp.shadeWaves = lds ? 4 : 6; /* 0 = the default for the kind of scene */
-    sp.readyMin = (uint32_t)opt("split_ready", 32); sp.refillMin = (uint32_t)std::max<int64_t>(1, opt("split_refill", 16));
-    sp.innerWeight = (uint32_t)std::max<int64_t>(1, opt("split_wi", 85)); sp.leafWeight = (uint32_t)std::max<int64_t>(1, opt("split_wl", 160));
-    sp.travLast = opt("split_trav_last", 0) ? 1u : 0u; sp.shadePrio = opt("split_shade_prio", 0) ? 1u : 0u;
-    sp.ringCap = 256; while (sp.ringCap < 256u * sp.shadeWaves) sp.ringCap *= 2;
-    sp.spinLimit = (uint32_t)opt("split_spin_limit", 1 << 21);
-    if (!c->splitAbort) { HIP_TRY(hipHostMalloc((void**)&c->splitAbort, 64, hipHostMallocMapped)); memset(c->splitAbort, 0, 64); }
-    HIP_TRY(hipHostGetDevicePointer((void**)&sp.abortFlag, c->splitAbort, 0));
-    if (opt("split_profile", 0)) { /* counting copy: 16 counters, cleared with the history, read back with tb_read_split_profile */
-        ensure(c->splitProf, 16 * 8);
-        if (c->samplesRendered == 0) HIP_TRY(hipMemsetAsync(c->splitProf.p, 0, 16 * 8, c->stream));
-        sp.prof = (unsigned long long*)c->splitProf.p;
-    }
-    TbDeviceScene dsL = c->ds; dsL.nodesC = nullptr; dsL.stackOverflow = nullptr; dsL.stackOverflowLanes = 0;
-    const pt_split_fn fn = v->split;
-    size_t overflowHalf = 0;
-    const int64_t cap = opt("split_stack_cap", 0);
-    if (cap > 0 && (uint32_t)cap < c->ds.stackDepth && !lds) {
-        dsL.stackDepth = (uint32_t)cap;
-        TbDeviceTargets probe = tg; probe.samples = (TbFloat4*)16; probe.workCounter = (uint32_t*)16; probe.frameGroup = 1;
-        TbDeviceScene dsProbe = dsL; dsProbe.stackOverflow = (uint32_t*)16; dsProbe.stackOverflowLanes = 0xffffffffu; /* which kernel: the split-stack one */
-        int perCU = 0;
-        HIP_TRY(fn(c->stream, &dsProbe, &pf, &probe, &sp, W, H, 0, 1, &c->tiles, 0, &perCU));
-        const uint32_t over = c->ds.stackDepth - (uint32_t)cap, lanes = (uint32_t)std::max(perCU, 1) * (uint32_t)numCUs * sp.travWaves * 64u;
-        ensure(c->stackOverflow, (size_t)over * lanes * 4 * 2); /* two halves: consecutive launches overlap on the two side streams */
-        overflowHalf = (size_t)over * lanes;
-        dsL.stackOverflow = (uint32_t*)c->stackOverflow.p; dsL.stackOverflowLanes = lanes;
-    }
-    const int64_t fgOpt = opt("split_frame_group", 8);
-    tg.frameGroup = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(fgOpt, std::min(batch, n)));
-    while ((std::min(batch, n) + tg.frameGroup - 1) / tg.frameGroup > 4095u) tg.frameGroup *= 2; /* a claimed item is group << 20 | tile */
-    tg.bandedItems = (uint32_t)opt("banded_items", 0);
-    ensure(c->workCounter, 1024);
-    const bool overlap = opt("overlap_launches", 1) != 0;
-    if (!overlap) c->sideOrdered = false;
-    if (overlap && !c->sideOrdered) {
-        HIP_TRY(hipEventRecord(c->evMain, c->stream));
-        for (int i = 0; i < 2; i++) HIP_TRY(hipStreamWaitEvent(c->side[i], c->evMain, 0));
-        c->sideOrdered = true;
-    }
-    for (uint32_t par = 0; par < 2u; par++)
-        if (c->fgSamples[par].bytes < pixels * batch * 16) {
-            HIP_TRY(hipStreamSynchronize(c->side[par])); HIP_TRY(hipStreamSynchronize(c->stream));
-            ensure(c->fgSamples[par], pixels * batch * 16);
-            HIP_TRY(hipMemsetAsync(c->fgSamples[par].p, 0, pixels * batch * 16, overlap ? c->side[par] : c->stream));
-        }
-    /* the first render with a kernel: a zero-frame launch down both side streams, so that whatever the runtime sets up at a queue's first
-     * dispatch of it (scratch) falls into this call (renderImpl's frame-group path does the same) */
-    const void* key = (const void*)((uintptr_t)fn ^ (dsL.stackOverflow ? 2u : 0u) ^ (lds ? 4u : 0u));
-    if (overlap && std::find(c->warmedLaunchers.begin(), c->warmedLaunchers.end(), key) == c->warmedLaunchers.end()) {
-        for (uint32_t par = 0; par < 2u; par++) {
-            TbDeviceTargets warm = tg; warm.samples = (TbFloat4*)c->fgSamples[par].p; warm.workCounter = (uint32_t*)c->workCounter.p + par * 128u;
-            TbDeviceScene dsPar = dsL; if (dsPar.stackOverflow) dsPar.stackOverflow += par * overflowHalf;
-            HIP_TRY(fn(c->side[par], &dsPar, &pf, &warm, &sp, W, H, c->samplesRendered, 0, &c->tiles, lds ? 1 : 0, nullptr));
-        }
-        c->warmedLaunchers.push_back(key);
-    }
-    for (uint32_t f0 = 0; f0 < n; f0 += batch) {
-        const uint32_t nf = std::min(batch, n - f0), par = c->fgLaunch++ & 1u;
-        hipStream_t ptStream = overlap ? c->side[par] : c->stream;
-        tg.samples = (TbFloat4*)c->fgSamples[par].p; tg.workCounter = (uint32_t*)c->workCounter.p + par * 128u; c->lastFgPar = (int)par;
-        if (overlap) HIP_TRY(hipStreamWaitEvent(ptStream, c->evFold[par], 0)); /* the fold that last read this sample buffer */
-        if (f0 == 0) HIP_TRY(hipEventRecord(c->evKernelStart, ptStream)); /* (the stats words were cleared on the main stream, which the side streams have just been ordered behind) */
-        TbDeviceScene dsPar = dsL; if (dsPar.stackOverflow) dsPar.stackOverflow += par * overflowHalf;
-        HIP_TRY(fn(ptStream, &dsPar, &pf, &tg, &sp, W, H, c->samplesRendered + f0, nf, &c->tiles, lds ? 1 : 0, nullptr));
-        if (f0 == 0) { HIP_TRY(hipEventRecord(c->evKernel, ptStream)); c->lastKernelFrames = nf; }
-        if (overlap) { HIP_TRY(hipEventRecord(c->evPt[par], ptStream)); HIP_TRY(hipStreamWaitEvent(c->stream, c->evPt[par], 0)); }
-        HIP_TRY(pt_launch_accumulate_samples(c->stream, tg.samples, W, H, c->samplesRendered + f0, nf, &c->tiles, tg.output, tg.jittered));
-        if (overlap) HIP_TRY(hipEventRecord(c->evFold[par], c->stream));
-    }
-    c->lastSplitWaves = (int)(sp.travWaves * 100 + sp.shadeWaves);
-}
-
-/* what PlanLaunch (launch_plan.h) is told about this context's scene, the call and the options */
-void fillPlanInput(tb_context* c, const Variant* v, uint32_t W, uint32_t H, uint32_t n, const tb_output_settings& s, bool aov, bool count, tb_plan_input& in)
-{
-    auto opt = [&](const char* k, int64_t d) { auto it = c->options.find(k); return it == c->options.end() ? d : it->second; };
-    memset(&in, 0, sizeof in);
-    in.variant_features = v->features; in.variant_waves_hi = v->fnHi ? v->wavesHi : 0u; in.variant_prepass_in_base = (!v->fnHi && v->id == 2) ? 1u : 0u; /* surf: compiled into its only copy */
-    in.variant_has_wavefront = v->wf ? 1u : 0u; in.variant_has_pooled = v->pooled ? 1u : 0u; in.variant_has_split = v->split ? 1u : 0u;
-    in.scene_in_lds = c->sceneInLds ? 1u : 0u; in.lds_blob_bytes = c->ds.ldsBlobBytes; in.stack_depth = c->ds.stackDepth; in.two_level = c->ds.numInstances ? 1u : 0u;
-    in.has_lights = c->scene.lights.empty() ? 0u : 1u; in.has_compact_nodes = c->ds.nodesC ? 1u : 0u; in.interior_walk_triangle_share = c->interiorWalkTriangleShare;
-    in.width = W; in.height = H; in.frames = n; in.max_bounces = s.MaxBounces; in.owned_regions = tb_persistent_grid(W, H, c->tiles);
-    in.count_rays = count ? 1u : 0u; in.aov = aov ? 1u : 0u; in.realtime = s.RenderModeRealTime ? 1u : 0u; in.selected_pixel = c->selX != 0xffffffffu ? 1u : 0u;
-    in.pipeline = opt("pipeline", 0); in.frame_group = opt("frame_group", 0); in.high_occupancy = opt("high_occupancy", 1); in.stack_lds_cap = opt("stack_lds_cap", 0);
-    in.stack_overflow_max = opt("stack_overflow_max", 24); in.node_layout = opt("node_layout", 0); in.primary_prepass = opt("primary_prepass", 1);
-    in.overlap_launches = opt("overlap_launches", 1); in.pooled_samples = opt("pooled_samples", 256ll << 20);
-}
-
-int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_output_settings* settings, float timeSeed, bool sync)
-{
-    if (!c->hasScene) return fail(c, TB_E_NO_SCENE, "tb_render: no scene loaded");
-    if (W == 0 || H == 0) return fail(c, TB_E_INVALID, "tb_render: zero-sized target");
-    if (W > 16384 || H > 16384) return fail(c, TB_E_INVALID, "tb_render: a target has at most 16384 pixels a side (D3D12_REQ_TEXTURE2D_U_OR_V_DIMENSION; pixel indices are 32-bit)");
-    tb_output_settings s; if (settings) s = *settings; else DefaultOutputSettings(s);
-    if (W != c->width || H != c->height) {
-        size_t bytes = (size_t)W * H * sizeof(TbFloat4);
-        ensure(c->output, bytes); ensure(c->jittered, bytes);
-        HIP_TRY(hipMemsetAsync(c->output.p, 0, bytes, c->stream)); HIP_TRY(hipMemsetAsync(c->jittered.p, 0, bytes, c->stream));
-        for (DevBuf& b : c->aov) b.release();
-        c->width = W; c->height = H; c->samplesRendered = 0;
-    }
-    if (c->haveLastSettings && (historyRelevantChange(s, c->lastSettings) || timeSeed != c->lastTime)) c->samplesRendered = 0;
-    c->lastSettings = s; c->haveLastSettings = true; c->lastTime = timeSeed;
-    if (n == 0) return TB_OK;
-    auto opt = [&](const char* k, int64_t d) { auto it = c->options.find(k); return it == c->options.end() ? d : it->second; };
-    const bool aov = opt("aov", 0) != 0, count = opt("count_rays", 0) != 0;
-    const int64_t pipeAsked = opt("pipeline", 0), pipe = pipeAsked == 4 ? 0 : pipeAsked; /* 4 = the split-role kernel where it exists, the lock-step kernel (0) elsewhere */
-    c->ds.alphaTest = opt("alpha_test", 0) ? 1u : 0u;
-    ensure(c->stats, 16);
-    const bool clearStats = c->samplesRendered == 0; /* enqueued below, on the stream of the first path-tracing launch */
-    TbDeviceTargets tg; memset(&tg, 0, sizeof tg);
-    tg.output = (TbFloat4*)c->output.p; tg.jittered = (TbFloat4*)c->jittered.p; tg.stats = (uint32_t*)c->stats.p;
-    if (!c->debugCounters.p) { ensure(c->debugCounters, 64); HIP_TRY(hipMemsetAsync(c->debugCounters.p, 0, 64, c->stream)); }
-    tg.debugCounters = (uint32_t*)c->debugCounters.p;
-    if (aov) {
-        size_t px = (size_t)W * H;
-        for (int i = 2; i <= 7; i++) { size_t bytes = px * (i == TB_AOV_DEPTH ? 4 : 16); if (c->aov[i].bytes != bytes) { ensure(c->aov[i], bytes); HIP_TRY(hipMemsetAsync(c->aov[i].p, 0, bytes, c->stream)); } }
-        tg.aovNormals = (TbFloat4*)c->aov[2].p; tg.aovWorldPos0 = (TbFloat4*)c->aov[3].p; tg.aovWorldPos1 = (TbFloat4*)c->aov[4].p;
-        tg.aovCustom = (TbFloat4*)c->aov[5].p; tg.aovDepth = (float*)c->aov[6].p; tg.aovEmissive = (TbFloat4*)c->aov[7].p;
-    }
-    if (count) { ensure(c->rayStats, 21 * 8); if (c->samplesRendered == 0) HIP_TRY(hipMemsetAsync(c->rayStats.p, 0, 21 * 8, c->stream)); tg.rayStats = (unsigned long long*)c->rayStats.p; }
-    TbPerFrameConstants pf;
-    MakeFrameConstants(c->scene, c->camera, s, c->samplesRendered, timeSeed, c->selX, c->selY, pf);
-    uint32_t need = c->sceneFeatures | settingsFeatureMask(c, s, aov);
-    if (count || opt("force_full_variant", 0)) need = PT_FEAT_ALL;
-    const Variant* v = nullptr;
-    for (const Variant& k : kVariants) if ((need & ~k.features) == 0) { v = &k; break; }
-    if (!v) v = &kVariants[kNumVariants - 1];
-    c->lastVariant = v->name;
-    const int variantIndex = (int)(v - kVariants);
-    const bool twoLevel = c->ds.numInstances != 0; /* instanced scene (flatten_instances = 0): pipeline 0 only */
-    if (twoLevel && pipe != 0) return fail(c, TB_E_UNSUPPORTED, "tb_render: two-level (instanced) scenes are not supported by pipelines 1-3; use pipeline 0 or flatten_instances = 1");
-    /* WHAT to launch is decided by a pure function of scene statistics, call size and options (launch_plan.h; tests/test_launch_plan.py
-     * walks its branches on the CPU); what follows executes the plan. */
-    tb_plan_input pin; fillPlanInput(c, v, W, H, n, s, aov, count, pin);
-    tb_launch_plan plan; PlanLaunch(pin, plan);
-    const bool wavefront = plan.pipeline == 2, pooled = plan.pipeline == 3, split = plan.pipeline == 4, groups = plan.groups != 0;
-    const int64_t fg = opt("frame_group", 0);
-    pt_variant_fn launch = plan.high_occupancy_copy ? v->fnHi : v->fn;
-    size_t overflowHalf = 0;
-    TbDeviceScene dsLaunch = c->ds; dsLaunch.stackOverflow = nullptr; dsLaunch.stackOverflowLanes = 0;
-    if (plan.stack_overflow_entries) { /* split stack: the deepest entries in global memory, one column per lane of the resident grid (at most 2 x 8 workgroups per CU) */
-        const int numCUs = deviceCUs(c);
-        const uint32_t lanes = 2u * 8u * (uint32_t)numCUs * 256u;
-        ensure(c->stackOverflow, (size_t)plan.stack_overflow_entries * lanes * 4 * 2); /* two halves: consecutive batches of a call overlap on the two side streams */
-        overflowHalf = (size_t)plan.stack_overflow_entries * lanes;
-        dsLaunch.stackDepth = plan.stack_lds_entries; dsLaunch.stackOverflow = (uint32_t*)c->stackOverflow.p; dsLaunch.stackOverflowLanes = lanes;
-    }
-    if (plan.full_variant && v != &kVariants[kNumVariants - 1]) { v = &kVariants[kNumVariants - 1]; launch = v->fn; c->lastVariant = v->name; }
-    if (opt("node_layout", 0) == 1 && !twoLevel && !c->sceneInLds && !c->ds.nodesC && !c->compactTried) { /* layout C on first demand; the plan is made again with what came of it */
-        ensureCompactNodes(c); dsLaunch.nodesC = c->ds.nodesC; dsLaunch.quant = c->ds.quant;
-        pin.has_compact_nodes = c->ds.nodesC ? 1u : 0u; PlanLaunch(pin, plan);
-    }
-    const bool compactNodes = plan.compact_nodes != 0;
-    if (!compactNodes) dsLaunch.nodesC = nullptr;
-    c->lastNodeLayout = compactNodes ? 1 : 0;
-    bool prepass = plan.prepass == TB_PLAN_PREPASS_ON;
-    if (plan.prepass == TB_PLAN_PREPASS_TRIAL) {
-        /* the scenes the policy cannot tell apart: of the first calls of one kind (same scene, frame, frames per call, depth) the first runs
-         * without (it also pays for buffers and scratch, untimed), then with / without alternately until each side has two timed samples
-         * -- the first launch of a call, with the events the context records anyway -- and the faster way is kept from then on */
-        tb_context::PrepassTrial& t = c->prepassTrial;
-        const uint64_t key = ((uint64_t)W << 48) ^ ((uint64_t)H << 32) ^ ((uint64_t)n << 12) ^ ((uint64_t)s.MaxBounces << 4) ^ ((uint64_t)c->sceneGeneration << 24) ^ (uint64_t)(uintptr_t)launch;
-        if (t.key != key) { t = tb_context::PrepassTrial(); t.key = key; }
-        if (t.pending) {
-            /* the first launch of the call before this one: finished long ago unless the caller renders asynchronously -- then the
-             * sample is skipped and that step of the trial repeated (tb_render_async enqueues, it never waits: no hipEventSynchronize
-             * here); and only if no other render has recorded the two events since (t.stamp, below) */
-            float ms = 0;
-            const bool mine = t.stamp == c->kernelEventStamp && hipEventQuery(c->evKernel) == hipSuccess && hipEventElapsedTime(&ms, c->evKernelStart, c->evKernel) == hipSuccess && ms > 0;
-            if (mine) { float& best = t.pending == 1 ? t.msWith : t.msWithout; best = best > 0 ? std::min(best, ms) : ms; (t.pending == 1 ? t.nWith : t.nWithout)++; }
-            else t.calls = t.pending == 1 ? 1 : 2; /* repeat the step whose sample was lost */
-            if (t.nWith >= 2 && t.nWithout >= 2) t.keep = t.msWith < 0.99f * t.msWithout; /* the faster of two samples per side */
-            t.pending = 0;
-        }
-        if (t.calls == 0) { prepass = false; t.calls = 1; }
-        else if (t.nWith >= 2 && t.nWithout >= 2) prepass = t.keep;
-        else if (t.calls == 1) { prepass = true; t.pending = 1; t.stamp = c->kernelEventStamp + 1; t.calls = 2; }
-        else { prepass = false; t.pending = 2; t.stamp = c->kernelEventStamp + 1; t.calls = 1; }
-    }
-    c->lastPrimaryPrepass = prepass ? 1 : 0; c->lastPlan = plan;
-    /* launches of the kernels without the EXT features (no selected pixel, no AOVs: nothing but the sample buffer is written)
-     * may overlap the drain of the launch before them */
-    bool overlap = plan.overlap_launches != 0;
-    /* ... which pays for the feature sets whose kernels fit their registers (matte / env: cornell-box +9 %, the 870 k scene +4 ... +9 %, at
-     * every frame size measured) and is in doubt for the others: the 4K glass scenes LOSE 6-7 % with two launches in flight, the same scenes
-     * at 1080p gain 4-13 %, Teapot (surf) gains 9-17 % on calls below ~10 M samples and loses 6 % above, the reference's vw-van (vol) gains 21 %
-     * at 4K (scripts/overlap_ab.py, profiles/r4/overlap_ab*.json) -- no rule in scene statistics fits that.  Like the pre-pass it is therefore
-     * TRIED where it is in doubt (option overlap_launches = 1, the default; 2 = always, 0 = never): calls of one kind run overlapped until two
-     * device-bound two-call spans between their ends are known, then one at a time until two more are, then the faster way.  A caller that waits for
-     * every call never produces a device-bound interval and stays overlapped (for it the two ways are the same). */
-    const int64_t overlapOpt = opt("overlap_launches", 1);
-    const uint64_t callKey = ((uint64_t)W << 48) ^ ((uint64_t)H << 32) ^ ((uint64_t)n << 12) ^ ((uint64_t)s.MaxBounces << 4) ^ ((uint64_t)c->sceneGeneration << 24) ^ (uint64_t)(uintptr_t)launch ^ (prepass ? 1u : 0u);
-    const bool trialOverlap = overlap && overlapOpt == 1 && (v->features & (PT_FEAT_SPECULAR | PT_FEAT_TEXTURES | PT_FEAT_SSS | PT_FEAT_MIX)) != 0;
-    if (trialOverlap) {
-        tb_context::OverlapTrial& t = c->overlapTrial;
-        if (t.key != callKey) { t = tb_context::OverlapTrial(); t.key = callKey; }
-        /* spans that have become known.  A span is TWO calls long -- (end of call i) - (end of call i - 2), halved: overlapped launches finish in
-         * pairs (two are in flight at once: the ends of consecutive calls are alternately 2 ms and 86 ms apart on the van-class 4K scene) */
-        for (uint64_t i = c->callCount >= 5 ? c->callCount - 5 : 2; i + 1 < c->callCount; i++) {
-            tb_context::CallRec& r = c->callRec[i & 7u]; const tb_context::CallRec& q = c->callRec[(i - 1) & 7u]; const tb_context::CallRec& nx = c->callRec[(i + 1) & 7u];
-            if (r.used || r.key != callKey || !c->evCallEnd[i & 7u] || !c->evCallEnd[(i - 2) & 7u]) continue;
-            if (hipEventQuery(c->evCallEnd[i & 7u]) != hipSuccess) continue;
-            r.used = true;
-            float ms = 0;
-            /* ... and call i must not be the last of a burst (the call after it was enqueued while it ran): the last launch has the chip to itself */
-            if (r.deviceBound && r.settled && q.deviceBound && q.settled && q.key == callKey && q.mode == r.mode && (r.mode == 0 || r.mode == 1) && nx.deviceBound && nx.key == callKey && nx.mode == r.mode
-                && hipEventElapsedTime(&ms, c->evCallEnd[(i - 2) & 7u], c->evCallEnd[i & 7u]) == hipSuccess && ms > 0) {
-                ms *= 0.5f; t.best[r.mode] = t.n[r.mode] ? std::min(t.best[r.mode], ms) : ms; t.n[r.mode]++;
-            }
-        }
-        if (t.phase == 0 && t.n[0] >= 2) t.phase = 1;
-        if (t.phase == 1 && t.n[1] >= 2) { t.phase = 2; t.keep = t.best[0] < 1.02f * t.best[1]; } /* taking turns has to win by 2 %: short bursts flatter it (their last launch runs alone) */
-        overlap = t.phase == 0 ? true : (t.phase == 1 ? false : t.keep);
-    }
-    c->lastOverlap = overlap ? 1 : 0;
-    {   /* this call's record: was the device still busy with the call before it, and is that call of the same kind and mode (a settled pipeline)? */
-        tb_context::CallRec& r = c->callRec[c->callCount & 7u]; const tb_context::CallRec& prev = c->callRec[(c->callCount - 1) & 7u];
-        r.key = callKey; r.mode = trialOverlap ? (overlap ? 0 : 1) : -1; r.used = !trialOverlap;
-        r.deviceBound = c->callCount > 0 && c->evCallEnd[(c->callCount - 1) & 7u] && hipEventQuery(c->evCallEnd[(c->callCount - 1) & 7u]) == hipErrorNotReady;
-        r.settled = c->callCount > 0 && prev.key == callKey && prev.mode == r.mode;
-    }
-    if (!overlap) c->sideOrdered = false;
-    c->kernelEventStamp++; /* this render records evKernelStart / evKernel */
-    HIP_TRY(hipEventRecord(c->ev0, c->stream));
-    if (clearStats && !overlap) HIP_TRY(hipMemsetAsync(c->stats.p, 0, 16, c->stream));
-    if (!groups) HIP_TRY(hipEventRecord(c->evKernelStart, c->stream));
-    c->lastKernelFrames = 0;
-    c->lastPipeline = split ? 4 : (wavefront ? 2 : (pooled ? 3 : (int)(pipe == 1 ? 1 : 0)));
-    if (split) renderSplit(c, v, W, H, n, pf, tg);
-    else if (wavefront) renderWavefront(c, variantIndex, W, H, c->samplesRendered, n, pf);
-    else if (pooled) renderPooled(c, variantIndex, W, H, c->samplesRendered, n, pf);
-    else {
-        /* frame-group mode (TbDeviceTargets::samples, pt_scene.h): the frames of a batch are cut into groups, workgroup
-         * (group, region) renders its 256 pixels x G frames drawing (pixel, frame) pairs from a counter in LDS, every sample goes
-         * to an ordered sample buffer and accumulate_samples_kernel folds them in frame order (bit-identical sums).  Keeps all
-         * lanes of a workgroup busy to its end and gives a rank of a tile split enough workgroups; on whenever a call renders
-         * enough frames to form groups.  Option "frame_group" = G > 0 forces the group size, < 0 forbids the mode. */
-        if (!groups) HIP_TRY(launch(c->stream, &dsLaunch, &pf, &tg, W, H, c->samplesRendered, n, &c->tiles, c->sceneInLds ? 1 : 0, count ? 1 : 0, (int)pipe));
-        else {
-            /* batch and group sizes: launch_plan.h (with the measurements they come from) */
-            const uint64_t pixels = (uint64_t)W * H;
-            const uint32_t batch = plan.batch_frames;
-            const uint64_t regions = std::max<uint64_t>(1, tb_persistent_grid(W, H, c->tiles));
-            if (regions > 0xfffffu) throw std::runtime_error("frame too large for the frame-group launch (more than 2^20 16x16 regions)");
-            ensure(c->workCounter, 1024);
-            tg.bandedItems = (uint32_t)opt("banded_items", 0);
-            tg.frameGroup = plan.frame_group;
-            if (overlap && !c->sideOrdered) { /* first overlapped launch after other work on the main stream: order the side streams behind it once */
-                HIP_TRY(hipEventRecord(c->evMain, c->stream));
-                for (int i = 0; i < 2; i++) HIP_TRY(hipStreamWaitEvent(c->side[i], c->evMain, 0));
-                c->sideOrdered = true;
-            }
-            /* both sample buffers are sized -- and touched once, a fresh allocation is mapped lazily -- by the first call that needs
-             * them, not by the call that first reaches the second one */
-            for (uint32_t par = 0; par < 2u; par++)
-                if (c->fgSamples[par].bytes < pixels * batch * 16) {
-                    HIP_TRY(hipStreamSynchronize(c->side[par])); HIP_TRY(hipStreamSynchronize(c->stream)); /* nobody reads the old one any more */
-                    ensure(c->fgSamples[par], pixels * batch * 16);
-                    HIP_TRY(hipMemsetAsync(c->fgSamples[par].p, 0, pixels * batch * 16, overlap ? c->side[par] : c->stream));
-                }
-            /* a zero-frame launch of the frame-group form of `launch` itself down one side stream (resident grid of workgroups that find the
-             * list empty), with or without the hit records of the pre-pass */
-            auto warmFrameGroupForm = [&](uint32_t par, bool withHits) {
-                TbDeviceTargets warm = tg; warm.samples = (TbFloat4*)c->fgSamples[par].p; warm.workCounter = (uint32_t*)c->workCounter.p + par * 128u;
-                const int numCUs = deviceCUs(c);
-                if (c->fgSlotLog[par].bytes < 16ull * numCUs * 16 * 8) ensure(c->fgSlotLog[par], 16ull * numCUs * 16 * 8);
-                warm.slotLog = (unsigned long long*)c->fgSlotLog[par].p; warm.slotLogCap = 16; warm.launchEpoch = ++c->launchEpoch;
-                warm.primaryHits = withHits ? (unsigned long long*)c->fgHits[par].p : nullptr;
-                TbDeviceScene dsPar = dsLaunch; if (dsPar.stackOverflow) dsPar.stackOverflow += par * overflowHalf;
-                hipStream_t st = overlap ? c->side[par] : c->stream;
-                HIP_TRY(launch(st, &dsPar, &pf, &warm, W, H, c->samplesRendered, 0, &c->tiles, withHits ? 0 : (c->sceneInLds ? 1 : 0), 0, 0));
-                HIP_TRY(hipStreamSynchronize(st));
-            };
-            /* The kernel copies held to an occupancy keep a few registers in scratch, and the runtime sizes a queue's scratch at the
-             * first dispatch on that queue that needs it (milliseconds, once per stream).  The first render with a given kernel
-             * therefore sends a zero-frame launch of its one-pixel-per-lane form (same feature set, at least as much scratch, a
-             * full grid of workgroups that exit at once) down BOTH side streams, so that the one-off cost falls into that first
-             * call and not into whichever later call happens to reach the second stream.  Two-level scenes in the tuned copies have no
-             * one-pixel-per-lane form (pt_variant.inc refuses it: the first render of an instanced scene in a fresh context used to fail
-             * here and then for good): they are warmed with the frame-group form itself. */
-            if (overlap && std::find(c->warmedLaunchers.begin(), c->warmedLaunchers.end(), (const void*)launch) == c->warmedLaunchers.end()) {
-                if (twoLevel) { for (uint32_t par = 0; par < 2; par++) warmFrameGroupForm(par, false); }
-                else {
-                    TbDeviceTargets none = tg; none.samples = nullptr;
-                    TbDeviceScene dsWarm = c->ds; dsWarm.nodesC = nullptr; /* the one-pixel-per-lane twin fetches layout B */
-                    for (uint32_t par = 0; par < 2; par++)
-                        HIP_TRY(launch(c->side[par], &dsWarm, &pf, &none, W, H, c->samplesRendered, 0, &c->tiles, c->sceneInLds ? 1 : 0, 0, 0));
-                }
-                c->warmedLaunchers.push_back((const void*)launch);
-            }
-            if (prepass) {
-                /* the hit records: sized and touched once like the sample buffers; and the kernels that take their first hits from them
-                 * keep more registers in scratch than the twin the warm-up above runs (sss: 464 against 416 B per lane), so they are
-                 * run once themselves, with no frames, down both side streams -- a queue whose scratch has to grow under a dispatch
-                 * that follows another kernel closely gave one wrong 16x16 region in the first render of 1 process in ~3 000 */
-                for (uint32_t par = 0; par < 2u; par++)
-                    if (c->fgHits[par].bytes < pixels * batch * 32) {
-                        HIP_TRY(hipStreamSynchronize(c->side[par])); HIP_TRY(hipStreamSynchronize(c->stream));
-                        ensure(c->fgHits[par], pixels * batch * 32);
-                        HIP_TRY(hipMemsetAsync(c->fgHits[par].p, 0, pixels * batch * 32, overlap ? c->side[par] : c->stream));
-                    }
-                const void* key = (const void*)((uintptr_t)launch ^ (1u | (dsLaunch.stackOverflow ? 2u : 0u) | (dsLaunch.nodesC ? 4u : 0u))); /* one kernel per (split stack, node layout) */
-                if (std::find(c->warmedLaunchers.begin(), c->warmedLaunchers.end(), key) == c->warmedLaunchers.end()) {
-                    for (uint32_t par = 0; par < 2u; par++) warmFrameGroupForm(par, true);
-                    c->warmedLaunchers.push_back(key);
-                }
-            }
-            for (uint32_t f0 = 0; f0 < n; f0 += batch) {
-                const uint32_t nf = std::min(batch, n - f0), par = c->fgLaunch++ & 1u;
-                hipStream_t ptStream = overlap ? c->side[par] : c->stream;
-                if (c->fgSamples[par].bytes < pixels * batch * 16) ensure(c->fgSamples[par], pixels * batch * 16); /* grow-only */
-                tg.samples = (TbFloat4*)c->fgSamples[par].p; tg.workCounter = (uint32_t*)c->workCounter.p + par * 128u; c->lastFgPar = (int)par;
-                {   /* slot logs: 16 workgroups per CU at most (2 x residency of 8); a row has room for 8x a workgroup's fair share of the launch's
-                     * items at the SMALLEST resident grid the launcher may choose (2 per CU), so that the rows of any grid hold the whole list
-                     * several times over and a workgroup whose row is full (it retires) never strands work */
-                    const int numCUs = deviceCUs(c);
-                    const uint64_t items = regions * (((uint64_t)nf + tg.frameGroup - 1) / tg.frameGroup), wgs = 16ull * (uint64_t)numCUs, fewest = 2ull * (uint64_t)numCUs;
-                    tg.slotLogCap = (uint32_t)std::min<uint64_t>(65534, 8 * ((items + fewest - 1) / fewest) + 16); /* 16 bits of an entry's tag */
-                    tg.launchEpoch = ++c->launchEpoch; c->lastSlotLogCap = (int)tg.slotLogCap;
-                    if (c->fgSlotLog[par].bytes < wgs * tg.slotLogCap * 8) { HIP_TRY(hipStreamSynchronize(c->side[par])); HIP_TRY(hipStreamSynchronize(c->stream)); ensure(c->fgSlotLog[par], wgs * tg.slotLogCap * 8); }
-                    tg.slotLog = (unsigned long long*)c->fgSlotLog[par].p;
-                }
-                if (prepass) tg.primaryHits = (unsigned long long*)c->fgHits[par].p;
-                if (overlap) HIP_TRY(hipStreamWaitEvent(ptStream, c->evFold[par], 0)); /* the fold that last read this sample buffer */
-                if (f0 == 0) { if (clearStats && overlap) HIP_TRY(hipMemsetAsync(c->stats.p, 0, 16, ptStream)); HIP_TRY(hipEventRecord(c->evKernelStart, ptStream)); }
-                TbDeviceScene dsPar = dsLaunch; if (dsPar.stackOverflow) dsPar.stackOverflow += par * overflowHalf; /* the launch before may still be draining on the other stream */
-                HIP_TRY(launch(ptStream, &dsPar, &pf, &tg, W, H, c->samplesRendered + f0, nf, &c->tiles, c->sceneInLds ? 1 : 0, 0, 0));
-                if (f0 == 0) { HIP_TRY(hipEventRecord(c->evKernel, ptStream)); c->lastKernelFrames = nf; }
-                if (overlap) { HIP_TRY(hipEventRecord(c->evPt[par], ptStream)); HIP_TRY(hipStreamWaitEvent(c->stream, c->evPt[par], 0)); }
-                HIP_TRY(pt_launch_accumulate_samples(c->stream, tg.samples, W, H, c->samplesRendered + f0, nf, &c->tiles, tg.output, tg.jittered));
-                if (overlap) HIP_TRY(hipEventRecord(c->evFold[par], c->stream));
-            }
-        }
-    }
-    if (!c->lastKernelFrames) { HIP_TRY(hipEventRecord(c->evKernel, c->stream)); c->lastKernelFrames = n; } /* one launch (or one pipeline) for the whole call */
-    HIP_TRY(hipEventRecord(c->ev1, c->stream));
-    if (!c->evCallEnd[c->callCount & 7u]) HIP_TRY(hipEventCreate(&c->evCallEnd[c->callCount & 7u]));
-    HIP_TRY(hipEventRecord(c->evCallEnd[c->callCount & 7u], c->stream)); c->callCount++; /* the end of this render, for the overlap trial above */
-    c->samplesRendered += n;
-    if (sync) {
-        HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipEventElapsedTime(&c->lastMs, c->ev0, c->ev1));
-        HIP_TRY(hipEventElapsedTime(&c->lastKernelMs, c->evKernelStart, c->evKernel));
-        if (c->splitAbort && *c->splitAbort) return fail(c, TB_E_DEVICE, splitAbortMessage(c));
-    }
-    return TB_OK;
-}
-
-} // namespace
+} // namespace tbctx
 
 extern "C" {
 
@@ -1639,7 +608,7 @@ int64_t tb_get_option(tb_context* c, const char* name)
     if (!strcmp(name, "last_plan_stack_overflow")) return c->lastPlan.stack_overflow_entries;
     if (!strcmp(name, "last_split_waves")) return c->lastSplitWaves; /* traversal waves * 100 + shading waves per workgroup of the last pipeline-4 launch */
     if (!strcmp(name, "last_pipeline")) return c->lastPipeline; /* the pipeline the last render actually ran (2 / 3 fall back to 0 for feature sets they lack) */
-    if (!strcmp(name, "last_variant")) { for (const Variant& k : kVariants) if (c->lastVariant == k.name) return k.id; return -1; } /* 0 matte 1 env 2 surf 3 vol 4 full 5 sss */
+    if (!strcmp(name, "last_variant")) { for (int i = 0; i < kNumVariants; i++) if (c->lastVariant == kVariants[i].name) return kVariants[i].id; return -1; } /* 0 matte 1 env 2 surf 3 vol 4 full 5 sss */
     auto it = c->options.find(name); return it == c->options.end() ? 0 : it->second;
 }
 
@@ -1804,3 +773,4 @@ int tb_host_scene_triangles(tb_host_scene* h, const float** pos, uint32_t* nv, c
 }
 
 } // extern "C"
+
