@@ -269,8 +269,17 @@ def expected_speedup(scene, W, H, spp, depth, world):
     one, mine, hop = d.get("c2_rank0_of_1"), d.get("c2_rank0_of_%d" % world), d.get("1080p_world%d" % world)
     if not one or not mine: return None
     step = mine["render_ms"] + 0.1       # exposed tail of the pipelined step (pack + un-permute + what the gather does not hide)
-    return {"vs_1gpu": round(one["render_ms"] / step, 2), "render_ms_per_rank": mine["render_ms"], "gather_hop_us": hop["xgmi_hop_estimate_us"] if hop else None,
-            "source": os.path.relpath(files[-1], ROOT), "note": "one GPU emulating rank 0 of N; no multi-GPU hardware was available to the build"}
+    out = {"vs_1gpu": round(one["render_ms"] / step, 2), "render_ms_per_rank": mine["render_ms"], "gather_hop_us": hop["xgmi_hop_estimate_us"] if hop else None,
+           "source": os.path.relpath(files[-1], ROOT), "note": "one GPU emulating rank 0 of N; no multi-GPU hardware was available to the build"}
+    # the same step as the timed region runs it (launches overlapping, pack and a stream-ordered consumer behind each render), K steps back to
+    # back on one GPU as rank 0 of N (scripts/rank_share_async.py): what is left per step when the links keep up
+    piped = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "rank_share_async.json")), key=lambda f: int(re.search(r"profiles/r(\d+)", f).group(1)))
+    if piped:
+        a = json.load(open(piped[-1]))
+        if a.get("world1") and a.get("world%d" % world):
+            out["pipelined"] = {"vs_1gpu": round(a["world1"]["ms_per_step"] / a["world%d" % world]["ms_per_step"], 2), "ms_per_step_per_rank": a["world%d" % world]["ms_per_step"],
+                                "source": os.path.relpath(piped[-1], ROOT)}
+    return out
 
 
 TEAPOT = os.path.join(ROOT, "tests", "golden", "scenes", "Teapot", "scene.pbrt")
