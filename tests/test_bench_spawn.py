@@ -57,3 +57,18 @@ def test_cli_ranks_return_the_failing_ranks_status_and_leave_nothing_behind(buil
     env = dict(os.environ, TB_CLI_RANK="1")
     r = subprocess.run([exe, CORNELL], capture_output=True, text=True, timeout=60, env=env)
     assert r.returncode == 2 and "TB_CLI_WORLD" in r.stderr
+
+
+def test_expected_speedup_reads_the_committed_stand_in_measurements():
+    """bench.py's N > 1 line quotes what the tile split should give from the one-GPU stand-in runs under profiles/ (the driver computes the
+    measured ratio itself): both forms are there for configs[1] at 2 / 4 / 8 ranks, grow with N, stay below N; other workloads get none."""
+    sys.path.insert(0, ROOT)
+    import bench
+    last = 1.0
+    for world in (2, 4, 8):
+        e = bench.expected_speedup("cornell-box", 1920, 1080, 64, 8, world)
+        assert e and e["source"].startswith("profiles/") and e["pipelined"]["source"].startswith("profiles/")
+        for v in (e["vs_1gpu"], e["pipelined"]["vs_1gpu"]):
+            assert 0.7 * world < v < world
+        assert e["pipelined"]["vs_1gpu"] > last; last = e["pipelined"]["vs_1gpu"]
+    assert bench.expected_speedup("proc0:870000", 1920, 1080, 128, 6, 8) is None
