@@ -298,6 +298,13 @@ TBD void prof_hit(WaveProf* p, int slot)
     if ((int)(threadIdx.x & 63u) == __ffsll((long long)m) - 1) p->v[slot + 1] += 1; /* wave trips */
 }
 
+/* The values a walk reads at every step are made ITS OWN at its entry: passed through an empty asm they become new values as far as the
+ * register allocator can tell, live from here to the end of the walk.  Without that the ray origin is the same value as Path::ro, which
+ * lives from the start of the bounce to the end of shading; the kernels held to 96 registers spill that whole range and reload the origin
+ * from scratch at every use -- at every triangle test, 2-3 scratch loads per leaf step in a loop whose texture addresser is the
+ * bottleneck (scripts/isa_spill_map.py lists them).  Round 4: van- / bistro-class 4K +7 %, vw-van +15 %; no instruction added. */
+TBD void walk_owns(tb3& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z)); }
+
 /* RAY_COUNTERS: the ray's BoxesTested / TrianglesTested (TraverseFunction.hlsli:662,751) are kept -- counting launches, and the full
  * feature set, whose heatmap output reads them (RayGenCommon.h:537-543); ALPHA: the IsValidHit filter on non-opaque candidates is
  * compiled in (it still needs ds.alphaTest at run time); HYBRID: split stack; NODEC: fetch layout-C nodes (ds.nodesC) instead of layout B;
@@ -309,6 +316,7 @@ TBD bool traverse(const SceneRefs& sc, const TbDeviceScene& ds, tb3 o, tb3 d, Hi
 {
     best.t = MAX_T; best.u = best.v = 0.0f; best.prim = best.geom = 0u;
     if (ray_cannot_hit(o, d)) return false;
+    walk_owns(o);
     RayPre r = ray_prepare(o, d);
     float unusedT;
     if (!box_test(unusedT, best.t, r, ld3(ds.rootCenter), ld3(ds.rootHalf))) return false; /* :566-580 */
@@ -386,6 +394,7 @@ TBD bool traverse_instanced(const SceneRefs& sc, const TbDeviceScene& ds, tb3 o,
 {
     best.t = MAX_T; best.u = best.v = 0.0f; best.prim = best.geom = 0u;
     if (ray_cannot_hit(o, d)) return false;
+    walk_owns(o); walk_owns(d); /* both are read again at every instance entered */
     RayPre r = ray_prepare(o, d);
     float unusedT;
     if (!box_test(unusedT, best.t, r, ld3(ds.rootCenter), ld3(ds.rootHalf))) return false; /* :566-580, the top level's root box */
