@@ -11,7 +11,7 @@ b.build(verbose=False)
 out_dir = os.path.join(b.ROOT, "_sweep"); os.makedirs(out_dir, exist_ok=True)
 srcs = b.HOST_SRCS + b.KERNEL_SRCS
 objs = {s: os.path.join(b.OBJ, s.replace("/", "_") + ".o") for s in srcs}
-for w in (3, 4, 5, 6):
+for w in ([int(x) for x in sys.argv[1:]] or [3, 4, 5, 6]):
     mine = dict(objs)
     for s in ("kernels/pt_variant_sss4.hip", "host/context.cpp"):
         o = os.path.join(out_dir, "w%d_%s.o" % (w, s.replace("/", "_")))

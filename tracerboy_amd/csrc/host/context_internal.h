@@ -71,10 +71,10 @@ extern std::string g_createError;
 #define TB_ENV_WAVES 6
 #endif
 #ifndef TB_SSS_WAVES
-#define TB_SSS_WAVES 5
+#define TB_SSS_WAVES 6
 #endif
 #ifndef TB_VOL_WAVES
-#define TB_VOL_WAVES 5
+#define TB_VOL_WAVES 4
 #endif
 struct Variant { uint32_t features; pt_variant_fn fn; const char* name; pt_variant_fn fnHi; uint32_t wavesHi; int id; wf_variant_fn wf; bool pooled; pt_split_fn split; };
 extern const Variant kVariants[];

@@ -1,4 +1,4 @@
-/* pt_variant_sss4.hip -- feature set "sss" held to a higher occupancy (TB_SSS_WAVES = 5 waves per SIMD, 96 VGPRs + scratch; the
+/* pt_variant_sss4.hip -- feature set "sss" held to a higher occupancy (TB_SSS_WAVES = 6 waves per SIMD, 80 VGPRs + scratch; the
  * file name dates from the 4-wave copy), pipeline 0 only; chosen when that many workgroups per CU fit in LDS, deeper trees with the
  * last stack entries in global memory (split stack). */
 #include "pt_device_features.h"
@@ -7,7 +7,7 @@
 #define PT_COUNT 0
 #define PT_ONLY_PERSISTENT 1
 #ifndef TB_SSS_WAVES
-#define TB_SSS_WAVES 5 /* measured 3 / 4 / 5 / 6 waves per SIMD on the 4K scenes: 1 102 / 1 211 / 1 316 / 1 263 (bistro-class), - / 1 495 / 1 564 / 1 501 (van-class) Msamples/s; experiments: -DTB_SSS_WAVES=n (scripts/ab_flags.sh); context.cpp reads the same macro */
+#define TB_SSS_WAVES 6 /* waves per SIMD (80 VGPRs + scratch).  Round 3, when the walk loop still reloaded spilled values at every step: 3 / 4 / 5 / 6 waves = 1 102 / 1 211 / 1 316 / 1 263 (bistro-class), - / 1 495 / 1 564 / 1 501 (van-class) Msamples/s.  Round 4, walk loops free of scratch (walk_owns, pt_device.hpp): 4 / 5 / 6 / 7 / 8 waves = 1 332 / 1 374 / 1 410 / 819 / 1 255 (bistro-class), 1 688 / 1 657 / 1 706 / 969 / 1 517 (van-class; 7 workgroups per CU do not divide the work lists). Experiments: -DTB_SSS_WAVES=n (scripts/build_sss_sweep.py, scripts/sss_waves_timing.sh); context_internal.h reads the same macro */
 #endif
 #define PT_PERSISTENT_ATTR __attribute__((amdgpu_waves_per_eu(TB_SSS_WAVES))) /* keep in step with kVariants[].wavesHi, context.cpp */
 #include "pt_variant.inc"

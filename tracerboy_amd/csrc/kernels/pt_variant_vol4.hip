@@ -1,4 +1,4 @@
-/* pt_variant_vol4.hip -- feature set "vol" held to a higher occupancy (TB_VOL_WAVES = 5 waves per SIMD; the file name dates from the
+/* pt_variant_vol4.hip -- feature set "vol" held to a higher occupancy (TB_VOL_WAVES = 4 waves per SIMD; the file name dates from the
  * 4-wave copy): chosen over pt_variant_vol.hip when that many workgroups per CU fit in LDS (split stack for deeper trees). */
 #include "pt_device_features.h"
 #define PT_FEATURES (PT_FEAT_ENV | PT_FEAT_SPECULAR | PT_FEAT_TEXTURES | PT_FEAT_SSS | PT_FEAT_MIX)
@@ -6,7 +6,7 @@
 #define PT_COUNT 0
 #define PT_ONLY_PERSISTENT 1
 #ifndef TB_VOL_WAVES
-#define TB_VOL_WAVES 5 /* same choice as the sss copy (pt_variant_sss4.hip: measured there); experiments: -DTB_VOL_WAVES=n (scripts/ab_flags.sh); context.cpp reads the same macro */
+#define TB_VOL_WAVES 4 /* waves per SIMD (128 VGPRs + scratch).  Round 4, walk loops free of scratch (walk_owns, pt_device.hpp), the reference's vw-van at 4K x 8: 4 / 5 / 6 waves = 1 824 / 1 617 / 1 582 Msamples/s flattened, 1 608 / 1 601 / 1 028 as a two-level scene (at 6 its 53-level tree leaves the tuned copy); 1080p 1 379 / 1 266 / 1 243.  Experiments: -DTB_VOL_WAVES=n (scripts/ab_device_flags.sh); context_internal.h reads the same macro */
 #endif
 #define PT_PERSISTENT_ATTR __attribute__((amdgpu_waves_per_eu(TB_VOL_WAVES))) /* keep in step with kVariants[].wavesHi, context.cpp */
 #include "pt_variant.inc"
