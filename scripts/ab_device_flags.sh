@@ -13,6 +13,7 @@ out = {"flags": sys.argv[1]}
 SETS = {"sss": (("c4 lbvh", "proc1:700000", 4, 3840, 2160, 8, 6), ("c4 sah", "proc1:700000", 1, 3840, 2160, 8, 6), ("c5 lbvh", "proc2:2980000", 4, 3840, 2160, 8, 16), ("c4 200k sah", "proc1:200000", 1, 3840, 2160, 8, 6)),
         "rest": (("c2", "cornell-box/scene.pbrt", 1, 1920, 1080, 64, 8), ("c3", "proc0:870000", 4, 1920, 1080, 128, 6), ("teapot", "Teapot/scene.pbrt", 1, 1920, 1080, 16, 8), ("vw-van", "vw-van/vw-van.pbrt", 4, 3840, 2160, 8, 6),
                  ("c3 4K", "proc0:870000", 4, 3840, 2160, 8, 6)),
+        "teapot": (("teapot x16", "Teapot/scene.pbrt", 1, 1920, 1080, 16, 8), ("teapot x64", "Teapot/scene.pbrt", 1, 1920, 1080, 64, 8), ("teapot 4K x4", "Teapot/scene.pbrt", 1, 3840, 2160, 4, 8), ("teapot 640x360 x16", "Teapot/scene.pbrt", 1, 640, 360, 16, 8)),
         "van": (("vw-van", "vw-van/vw-van.pbrt", 4, 3840, 2160, 8, 6), ("vw-van two-level", "vw-van/vw-van.pbrt", 4, 3840, 2160, 8, 6), ("vw-van 1080p", "vw-van/vw-van.pbrt", 4, 1920, 1080, 8, 6),
                 ("c4 lbvh", "proc1:700000", 4, 3840, 2160, 8, 6), ("c5 lbvh", "proc2:2980000", 4, 3840, 2160, 8, 16))}
 for key, scene, builder, W, H, F, D in SETS[os.environ.get("AB_SET", "sss")]:
