@@ -345,9 +345,10 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
      * may overlap the drain of the launch before them */
     bool overlap = plan.overlap_launches != 0;
     /* ... which pays for the feature sets whose kernels fit their registers (matte / env: cornell-box +9 %, the 870 k scene +4 ... +9 %, at
-     * every frame size measured) and is in doubt for the others: the 4K glass scenes LOSE 6-7 % with two launches in flight, the same scenes
-     * at 1080p gain 4-13 %, Teapot (surf) gains 9-17 % on calls below ~10 M samples and loses 6 % above, the reference's vw-van (vol) gains 21 %
-     * at 4K (scripts/overlap_ab.py, profiles/r4/overlap_ab*.json) -- no rule in scene statistics fits that.  Like the pre-pass it is therefore
+     * every frame size measured) and is in doubt for the others: Teapot (surf) gains 9-17 % on calls below ~10 M samples and loses 6 % above; the 4K
+     * glass scenes LOST 6-7 % with the round-3 kernels (whose leaf steps waited for scratch) and gain 4-5 % with the present ones, the same scenes at
+     * 1080p gain 8-16 %, the reference's vw-van (vol) 18-39 % (scripts/overlap_ab.py, profiles/r4/overlap_ab*.json) -- no rule in scene statistics
+     * fits that, and it moves with the kernels.  Like the pre-pass it is therefore
      * TRIED where it is in doubt (option overlap_launches = 1, the default; 2 = always, 0 = never): calls of one kind run overlapped until two
      * device-bound two-call spans between their ends are known, then one at a time until two more are, then the faster way.  A caller that waits for
      * every call never produces a device-bound interval and stays overlapped (for it the two ways are the same). */
