@@ -1,34 +1,42 @@
 #!/usr/bin/env python3
-"""Where a kernel's register spills sit: static scratch loads / stores of every pt_persistent kernel of an assembly listing, and how many of
-them are inside the walk loops (loops that fetch nodes with four global_load_dwordx4) -- those run once per step, the rest once per bounce.
-   hipcc ... -S -o k.s pt_variant_sss4.hip;  python scripts/isa_spill_map.py k.s [substring of the demangled kernel name]"""
+"""Where a kernel's register spills sit: static scratch loads / stores of every pt_persistent / pt_primary kernel of an assembly listing, and how
+many of them are inside the walk loops (loops that fetch nodes with four global_load_dwordx4) -- those run once per step, the rest once per bounce.
+   hipcc ... -S -o k.s pt_variant_sss4.hip;  python scripts/isa_spill_map.py k.s [substring of the demangled kernel name]
+tests/test_isa_walk_loops.py uses spill_map() to keep the walk loops of the kernels held to an occupancy free of scratch."""
 import re, subprocess, sys
 
-text = open(sys.argv[1]).read()
-want = sys.argv[2] if len(sys.argv) > 2 else ""
-for m in re.finditer(r"^(_ZN\S*pt_(?:persistent|primary)\S*):.*$", text, re.M):
-    name = subprocess.run(["c++filt", m.group(1)], capture_output=True, text=True).stdout.strip()
-    name = re.sub(r"\(anonymous namespace\)::", "", name); name = re.sub(r"\(.*", "", name).replace("void ", "")
-    if want not in name: continue
-    body = text[m.start():text.index(".end_amdhsa_kernel", m.start())]
-    blocks, cur = [], {"label": "entry", "ins": []}
-    for line in body.split("\n"):
-        lab = re.match(r"^(\.LBB\d+_\d+):", line)
-        if lab: blocks.append(cur); cur = {"label": lab.group(1), "ins": []}
-        else:
-            s = line.strip()
-            if s and re.match(r"^[a-z]", s): cur["ins"].append(s)
-    blocks.append(cur)
-    index = {b["label"]: k for k, b in enumerate(blocks)}
-    loops = set()
-    for k, b in enumerate(blocks):
-        for ins in b["ins"]:
-            br = re.match(r"s_c?branch\S*\s+(\.LBB\d+_\d+)", ins)
-            if br and br.group(1) in index and index[br.group(1)] <= k: loops.add((index[br.group(1)], k))
-    count = lambda prefix, a=0, b=None: sum(sum(1 for i in blocks[k]["ins"] if i.startswith(prefix)) for k in range(a, len(blocks) if b is None else b + 1))
-    walk = [(a, b) for a, b in loops if count("global_load_dwordx4", a, b) >= 4 and sum(len(blocks[k]["ins"]) for k in range(a, b + 1)) < 600]
-    # outermost walk loops only (a walk = inner-node loop nested in the while-while loop)
-    outer = [l for l in walk if not any(o != l and o[0] <= l[0] and l[1] <= o[1] for o in walk)]
-    inwalk = [(blocks[a]["label"], sum(len(blocks[k]["ins"]) for k in range(a, b + 1)), count("scratch_load", a, b), count("scratch_store", a, b)) for a, b in sorted(outer)]
-    meta = text[text.index(m.group(1), text.index("amdhsa.kernels:")):] if "amdhsa.kernels:" in text else ""
-    print("%-70s instr %5d  scratch ld %3d st %3d  walk loops (label, instr, ld, st): %s" % (name, sum(len(b["ins"]) for b in blocks), count("scratch_load"), count("scratch_store"), inwalk))
+
+def spill_map(text, want=""):
+    """[{name, instr, scratch_ld, scratch_st, walk_loops: [(label, instr, ld, st), ...]}] for the kernels whose demangled name contains `want`"""
+    out = []
+    for m in re.finditer(r"^(_ZN\S*pt_(?:persistent|primary)\S*):.*$", text, re.M):
+        name = subprocess.run(["c++filt", m.group(1)], capture_output=True, text=True).stdout.strip()
+        name = re.sub(r"\(anonymous namespace\)::", "", name); name = re.sub(r"\(.*", "", name).replace("void ", "")
+        if want not in name: continue
+        body = text[m.start():text.index(".end_amdhsa_kernel", m.start())]
+        blocks, cur = [], {"label": "entry", "ins": []}
+        for line in body.split("\n"):
+            lab = re.match(r"^(\.LBB\d+_\d+):", line)
+            if lab: blocks.append(cur); cur = {"label": lab.group(1), "ins": []}
+            else:
+                s = line.strip()
+                if s and re.match(r"^[a-z]", s): cur["ins"].append(s)
+        blocks.append(cur)
+        index = {b["label"]: k for k, b in enumerate(blocks)}
+        loops = set()
+        for k, b in enumerate(blocks):
+            for ins in b["ins"]:
+                br = re.match(r"s_c?branch\S*\s+(\.LBB\d+_\d+)", ins)
+                if br and br.group(1) in index and index[br.group(1)] <= k: loops.add((index[br.group(1)], k))
+        count = lambda prefix, a=0, b=None: sum(sum(1 for i in blocks[k]["ins"] if i.startswith(prefix)) for k in range(a, len(blocks) if b is None else b + 1))
+        size = lambda a, b: sum(len(blocks[k]["ins"]) for k in range(a, b + 1))
+        walk = [(a, b) for a, b in loops if count("global_load_dwordx4", a, b) >= 4 and size(a, b) < 600]
+        outer = [l for l in walk if not any(o != l and o[0] <= l[0] and l[1] <= o[1] for o in walk)]   # a walk = the inner-node loop nested in the while-while loop
+        out.append({"name": name, "instr": size(0, len(blocks) - 1), "scratch_ld": count("scratch_load"), "scratch_st": count("scratch_store"),
+                    "walk_loops": [(blocks[a]["label"], size(a, b), count("scratch_load", a, b), count("scratch_store", a, b)) for a, b in sorted(outer)]})
+    return out
+
+
+if __name__ == "__main__":
+    for k in spill_map(open(sys.argv[1]).read(), sys.argv[2] if len(sys.argv) > 2 else ""):
+        print("%-70s instr %5d  scratch ld %3d st %3d  walk loops (label, instr, ld, st): %s" % (k["name"], k["instr"], k["scratch_ld"], k["scratch_st"], k["walk_loops"]))
