@@ -21,7 +21,7 @@ def _listing(tmp_path, unit):
     return open(out).read()
 
 
-# <F, COUNT, SCENE_LDS, GROUPS, HYBRID, NODEC, TWOLEVEL, PRIMARY>.  Every one-level kernel is held to the rule; the two-level walks keep the world ray's slab
+# <F, SCENE_LDS, COUNT, GROUPS, HYBRID, NODEC, TWOLEVEL, PRIMARY>.  Every one-level kernel is held to the rule; the two-level walks keep the world ray's slab
 # constants for the way back out of an instance and may reload them there (once per instance left, not per step)
 @pytest.mark.parametrize("unit", ["sss4", "vol4"])
 def test_walk_loops_of_the_occupancy_copies_touch_no_scratch(tmp_path, unit):
