@@ -63,7 +63,10 @@ inline void PlanLaunch(const tb_plan_input& in, tb_launch_plan& p)
         p.rule_prepass = TB_PLAN_RULE_PREPASS_OPTION_OFF;
         if (in.primary_prepass == 2) { p.prepass = TB_PLAN_PREPASS_ON; p.rule_prepass = TB_PLAN_RULE_PREPASS_FORCED; }
         else if (in.primary_prepass == 1) {
-            if ((uint64_t)in.width * in.height * in.frames < (1ull << 24)) p.rule_prepass = TB_PLAN_RULE_PREPASS_SMALL_CALL;
+            /* the call's OWN samples: a rank of a tile split renders its tiles only (round 5: rank 0 of 8 on a 4K frame x 8 is an
+             * 8.3 M-sample call, where the pre-pass between two launches of a stream costs what it saves: 6.53 / 6.45 ms with / without) */
+            const uint64_t callSamples = std::min<uint64_t>((uint64_t)in.width * in.height, (uint64_t)std::max<uint64_t>(1, in.owned_regions) * 256u) * in.frames;
+            if (callSamples < (1ull << 24)) p.rule_prepass = TB_PLAN_RULE_PREPASS_SMALL_CALL;
             else if (!sss && !in.has_lights) { p.prepass = TB_PLAN_PREPASS_ON; p.rule_prepass = TB_PLAN_RULE_PREPASS_ENV_LIT; }
             else if (sss && in.interior_walk_triangle_share < 0.5f) { p.prepass = TB_PLAN_PREPASS_ON; p.rule_prepass = TB_PLAN_RULE_PREPASS_GLASS_AMONG_OTHERS; }
             else { p.prepass = TB_PLAN_PREPASS_TRIAL; p.rule_prepass = TB_PLAN_RULE_PREPASS_TRIAL; }
