@@ -118,24 +118,29 @@ TB_HD float tb_cos_poly(float r)
     return tb_fma(p * z, z, tb_fma(-0.5f, z, 1.0f));
 }
 
+/* inf, nan and absurdly large arguments give NaN -- by a select on the way in (the reduction then sees 0) and one on the way out, not
+ * by a branch: a branch costs the device an exec-mask save / restore per call and keeps two consecutive rand() calls from being
+ * scheduled together; the value of every in-range argument is computed by the same operations as before */
 TB_HD float tb_sin(float x)
 {
-    if (!(tb_abs(x) < 1.0e9f)) return tb_u2f(0x7fc00000u); /* inf, nan, absurdly large */
+    const bool ok = tb_abs(x) < 1.0e9f;
     float r; int q;
-    tb_sincos_reduce(x, &r, &q);
+    tb_sincos_reduce(ok ? x : 0.0f, &r, &q);
     const float sp = tb_sin_poly(r), cp = tb_cos_poly(r); /* both, then a select: the quadrant differs from lane to lane */
     float s = (q & 1) ? cp : sp;
-    return (q & 2) ? -s : s;
+    s = (q & 2) ? -s : s;
+    return ok ? s : tb_u2f(0x7fc00000u);
 }
 
 TB_HD float tb_cos(float x)
 {
-    if (!(tb_abs(x) < 1.0e9f)) return tb_u2f(0x7fc00000u);
+    const bool ok = tb_abs(x) < 1.0e9f;
     float r; int q;
-    tb_sincos_reduce(x, &r, &q);
+    tb_sincos_reduce(ok ? x : 0.0f, &r, &q);
     const float sp = tb_sin_poly(r), cp = tb_cos_poly(r);
     float c = (q & 1) ? sp : cp;
-    return ((q + 1) & 2) ? -c : c;
+    c = ((q + 1) & 2) ? -c : c;
+    return ok ? c : tb_u2f(0x7fc00000u);
 }
 
 /* ---- asin / acos (Cephes asinf/acosf) ---------------------------------------------------- */

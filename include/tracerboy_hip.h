@@ -226,7 +226,7 @@ int64_t tb_get_option(tb_context* ctx, const char* name);
  * (tests/test_launch_plan.py).  No reference counterpart: TracerBoy::Render has one shader and one dispatch shape (TracerBoy.cpp:2677-2946). */
 enum { TB_PLAN_FEAT_SSS = 8, TB_PLAN_FEAT_EXT = 32 }; /* bits of variant_features the policy looks at (PT_FEAT_SSS / PT_FEAT_EXT) */
 enum { TB_PLAN_PREPASS_OFF = 0, TB_PLAN_PREPASS_ON = 1, TB_PLAN_PREPASS_TRIAL = 2 };
-enum { TB_PLAN_RULE_ONE_PIXEL_PER_LANE = 1, TB_PLAN_RULE_FRAME_GROUPS, TB_PLAN_RULE_WAVEFRONT, TB_PLAN_RULE_POOLED, TB_PLAN_RULE_SPLIT,                 /* rule_pipeline */
+enum { TB_PLAN_RULE_ONE_PIXEL_PER_LANE = 1, TB_PLAN_RULE_FRAME_GROUPS, TB_PLAN_RULE_WAVEFRONT, TB_PLAN_RULE_POOLED, TB_PLAN_RULE_SPLIT, TB_PLAN_RULE_SPLIT_NO_ROOM,                 /* rule_pipeline */
        TB_PLAN_RULE_COPY_NONE = 10, TB_PLAN_RULE_COPY_FITS, TB_PLAN_RULE_COPY_SPLIT_STACK, TB_PLAN_RULE_COPY_TOO_DEEP, TB_PLAN_RULE_COPY_NO_ROOM, TB_PLAN_RULE_COPY_FULL_FOR_INSTANCES, /* rule_copy */
        TB_PLAN_RULE_PREPASS_NO_KERNEL = 20, TB_PLAN_RULE_PREPASS_OPTION_OFF, TB_PLAN_RULE_PREPASS_FORCED, TB_PLAN_RULE_PREPASS_SMALL_CALL, TB_PLAN_RULE_PREPASS_ENV_LIT,
        TB_PLAN_RULE_PREPASS_GLASS_AMONG_OTHERS, TB_PLAN_RULE_PREPASS_TRIAL };                                                                              /* rule_prepass */
@@ -246,6 +246,9 @@ typedef struct tb_plan_input {
     /* options (tb_set_option), with their defaults where 0 is not one */
     int64_t pipeline, frame_group, high_occupancy /* 1 */, stack_lds_cap, stack_overflow_max /* 24 */, node_layout, primary_prepass /* 1 */,
             overlap_launches /* 1 */, pooled_samples /* 2^28 */;
+    /* pipeline 4 (split-role kernel): its workgroup shape, so that the plan knows whether a workgroup's LDS and the frame's work items fit
+     * and says "the lock-step kernel" itself where they do not (rule TB_PLAN_RULE_SPLIT_NO_ROOM) instead of leaving the launcher to refuse */
+    int64_t split_trav /* 4 */, split_shade /* 0 = 4 with the scene in LDS, 6 otherwise */, split_stack_cap /* 0 = the whole stack in LDS */;
 } tb_plan_input;
 typedef struct tb_launch_plan {
     int32_t pipeline;                 /* 0 lock-step, 1 streaming, 2 wavefront, 3 pooled, 4 split-role: what will run */
@@ -259,6 +262,9 @@ typedef struct tb_launch_plan {
     uint32_t rule_pipeline, rule_copy, rule_prepass; /* TB_PLAN_RULE_*: which branch decided */
 } tb_launch_plan;
 void tb_plan_defaults(tb_plan_input* in);  /* zeroes, then the option defaults */
+/* waves per SIMD the higher-occupancy copy of a feature set ("matte", "env", "surf", "vol", "full", "sss") is compiled for -- what
+ * renderImpl puts into tb_plan_input::variant_waves_hi; 0 = the set has no such copy, -1 = no such set.  Needs no context. */
+int tb_variant_waves_hi(const char* variant_name);
 int tb_plan_launch(const tb_plan_input* in, tb_launch_plan* out);
 
 /* The kernel seam, exported so the checker can run on exactly the arrays the kernels read:

@@ -19,6 +19,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("tag")
 ap.add_argument("--flags", default="")
 ap.add_argument("--tus", nargs="+", required=True)
+ap.add_argument("--default-scheduler", action="store_true")   # drop the build's -amdgpu-sched-strategy (LLVM's own default)
 a = ap.parse_args()
 
 b.build(verbose=False)
@@ -35,7 +36,10 @@ if not want:
 
 def compile_one(s):
     o = os.path.join(out_dir, "%s_%s.o" % (a.tag, s.replace("/", "_")))
-    dev = b.DEVICE if s.endswith(".hip") else ["-x", "hip", "--offload-arch=" + b.ARCH]
+    dev = list(b.device_flags(s)) if s.endswith(".hip") else ["-x", "hip", "--offload-arch=" + b.ARCH]
+    if "-amdgpu-sched-strategy=" in a.flags or a.default_scheduler:   # an -mllvm option may occur once: the variant's scheduler replaces the build's
+        dev = [f for i, f in enumerate(dev) if not f.startswith("-amdgpu-sched-strategy=") and not
+               (f == "-mllvm" and i + 1 < len(dev) and dev[i + 1].startswith("-amdgpu-sched-strategy="))]
     cmd = [b.HIPCC] + b.COMMON + a.flags.split() + dev + ["-c", os.path.join(b.CSRC, s), "-o", o]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:

@@ -302,7 +302,7 @@ def main():
     lockstep_regen(samples, 1, park_min=2)
     for cap in (1000, 16, 8, 6, 4, 3, 2, 1):
         lockstep_sliced(samples, cap, park_min=2)
-    return
+    # every scheduler DESIGN.md / docs/experiments quote (an early return used to hide the rows below)
     report("lock-step + hoisted bounce ray, own lane", lockstep_hoisted(samples), n)
     report("lock-step + hoisted, wave-local pool", lockstep_hoisted(samples, share_wave=True), n)
     for R in (1, 2, 4):

@@ -7,6 +7,7 @@ set -u
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
 OUT=gpurun_out/sss_sweep; rm -rf $OUT; mkdir -p $OUT
 cp tracerboy_amd/libtracerboy_hip.so $OUT/lib_default.so
+trap 'cp $OUT/lib_default.so tracerboy_amd/libtracerboy_hip.so' EXIT   # an interrupted run must not leave a sweep build in the tree
 for W in 3 4 5 6; do
   cp tracerboy_amd/_sweep/libtracerboy_hip_sss$W.so tracerboy_amd/libtracerboy_hip.so
   for CFG in c4 c5; do

@@ -1,5 +1,6 @@
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
 cp tracerboy_amd/libtracerboy_hip.so /tmp/lib_default.so
+trap 'cp /tmp/lib_default.so tracerboy_amd/libtracerboy_hip.so' EXIT   # an interrupted run must not leave a sweep build in the tree
 for W in 6 7; do
   cp tracerboy_amd/_sweep/libtracerboy_hip_sss$W.so tracerboy_amd/libtracerboy_hip.so
   rm -rf gpurun_out/w$W

@@ -3,6 +3,7 @@
 set -u
 cd "$GRAFT_REPO_ROOT"
 cp tracerboy_amd/libtracerboy_hip.so /tmp/lib_default.so
+trap 'cp /tmp/lib_default.so tracerboy_amd/libtracerboy_hip.so' EXIT   # an interrupted run must not leave a sweep build in the tree
 for W in "$@"; do
   cp tracerboy_amd/_sweep/libtracerboy_hip_sss$W.so tracerboy_amd/libtracerboy_hip.so
   python3 - "$W" <<'PY'

@@ -6,10 +6,20 @@ import pytest
 from tracerboy_amd import api
 
 ENV, SPEC, TEX, SSS, MIX, EXT = 1, 2, 4, 8, 16, 32
-MATTE = dict(variant_features=0, variant_waves_hi=5, variant_has_wavefront=1, variant_has_pooled=1, variant_has_split=1)
-ENVV = dict(variant_features=ENV, variant_waves_hi=6, variant_has_wavefront=1, variant_has_pooled=1, variant_has_split=1)
+# the occupancies the shipped kernel copies are compiled for come from the library (tb_variant_waves_hi), so that the plans tested
+# here are the plans that run (the file used to pin a 5-wave sss copy after the copy had moved to 6)
+W_MATTE, W_ENV, W_SSS, W_VOL = (api.VariantWavesHi(n) for n in ("matte", "env", "sss", "vol"))
+
+
+def lds_entries(waves):
+    """Stack entries a copy held to `waves` per SIMD keeps in LDS: its workgroups' share of 160 KB in 512-B granules, less 128 B of statics."""
+    return ((160 * 1024 // waves) // 512 * 512 - 128) // 1024
+
+
+MATTE = dict(variant_features=0, variant_waves_hi=W_MATTE, variant_has_wavefront=1, variant_has_pooled=1, variant_has_split=1)
+ENVV = dict(variant_features=ENV, variant_waves_hi=W_ENV, variant_has_wavefront=1, variant_has_pooled=1, variant_has_split=1)
 SURF = dict(variant_features=ENV | SPEC | TEX, variant_waves_hi=0, variant_prepass_in_base=1, variant_has_wavefront=1, variant_has_pooled=1, variant_has_split=1)
-SSSV = dict(variant_features=ENV | SPEC | TEX | SSS, variant_waves_hi=5, variant_has_wavefront=1, variant_has_split=1)
+SSSV = dict(variant_features=ENV | SPEC | TEX | SSS, variant_waves_hi=W_SSS, variant_has_wavefront=1, variant_has_split=1)
 FULL = dict(variant_features=63, variant_waves_hi=0)
 HD = dict(width=1920, height=1080, owned_regions=120 * 68, max_bounces=8)
 UHD = dict(width=3840, height=2160, owned_regions=240 * 135, max_bounces=6)
@@ -60,8 +70,10 @@ def test_dragon_class_c3_plan():
     assert (p.high_occupancy_copy, p.rule_copy, p.stack_lds_entries, p.prepass, p.rule_prepass) == (0, COPY_TOO_DEEP, 51, OFF, PRE_NO_KERNEL)
     assert plan(ENVV, HD, frames=128, stack_depth=51, stack_overflow_max=30).rule_copy == COPY_SPLIT_STACK
     assert plan(ENVV, HD, frames=128, stack_depth=43, stack_overflow_max=16).rule_copy == COPY_TOO_DEEP     # round 3's limit
-    p = plan(dict(variant_features=31, variant_waves_hi=5), UHD, frames=8, stack_depth=53, two_level=1)         # the reference's vw-van as a two-level scene: vol copy, 31 + 22
-    assert (p.high_occupancy_copy, p.full_variant, p.stack_lds_entries, p.stack_overflow_entries) == (1, 0, 31, 22)
+    # the reference's vw-van as a two-level scene (53 levels) in the vol copy (4 waves per SIMD: 39 entries in LDS + 14 in global memory)
+    p = plan(dict(variant_features=31, variant_waves_hi=W_VOL), UHD, frames=8, stack_depth=53, two_level=1)
+    assert (W_VOL, lds_entries(W_VOL)) == (4, 39)
+    assert (p.high_occupancy_copy, p.full_variant, p.stack_lds_entries, p.stack_overflow_entries) == (1, 0, 39, 14)
     assert plan(ENVV, HD, frames=128, stack_depth=26, high_occupancy=0).rule_copy == COPY_NONE
     # a forced cap splits a stack that would fit (tests); one-frame calls have no split stack
     p = plan(ENVV, HD, frames=8, stack_depth=20, stack_lds_cap=12); assert (p.rule_copy, p.stack_lds_entries, p.stack_overflow_entries) == (COPY_SPLIT_STACK, 12, 8)
@@ -87,11 +99,12 @@ def test_prepass_policy_branches():
 
 
 def test_4k_glass_scenes_c4_c5_plans():
-    p = plan(SSSV, UHD, frames=256, stack_depth=36, has_lights=1, interior_walk_triangle_share=0.2)   # van-class: 5-wave copy with a split stack, groups of 16
-    assert (p.groups, p.high_occupancy_copy, p.rule_copy, p.stack_lds_entries, p.stack_overflow_entries) == (1, 1, COPY_SPLIT_STACK, 31, 5)
+    assert (W_SSS, lds_entries(W_SSS)) == (6, 26)                                                   # the sss copy as shipped: 6 waves per SIMD, 26 entries in LDS
+    p = plan(SSSV, UHD, frames=256, stack_depth=36, has_lights=1, interior_walk_triangle_share=0.2)   # van-class: split stack 26 + 10, groups of 16
+    assert (p.groups, p.high_occupancy_copy, p.rule_copy, p.stack_lds_entries, p.stack_overflow_entries) == (1, 1, COPY_SPLIT_STACK, 26, 10)
     assert (p.batch_frames, p.frame_group) == (32, 16)                                             # 2^28 samples / 8.3 M pixels = 32 frames a batch
-    p = plan(SSSV, UHD, frames=1024, stack_depth=41, has_lights=1, interior_walk_triangle_share=0.1, max_bounces=16)
-    assert (p.stack_lds_entries, p.stack_overflow_entries, p.batch_frames, p.frame_group) == (31, 10, 32, 16)
+    p = plan(SSSV, UHD, frames=1024, stack_depth=41, has_lights=1, interior_walk_triangle_share=0.1, max_bounces=16)   # bistro-class: 26 + 15
+    assert (p.stack_lds_entries, p.stack_overflow_entries, p.batch_frames, p.frame_group) == (26, 15, 32, 16)
 
 
 def test_group_size_rules():
@@ -125,3 +138,26 @@ def test_pipelines_and_instances():
     for kw in (dict(has_compact_nodes=0), dict(high_occupancy=0), dict(frame_group=-1), dict(two_level=1), dict(scene_in_lds=1, lds_blob_bytes=100)):
         assert plan(ENVV, HD, frames=8, stack_depth=20, node_layout=1, **{**dict(has_compact_nodes=1), **kw}).compact_nodes == 0, kw
     assert plan(ENVV, HD, frames=8, stack_depth=20, overlap_launches=0).overlap_launches == 0
+
+
+def test_split_kernel_falls_back_where_its_launcher_would_refuse():
+    """pipeline 4 used to be chosen from variant_has_split alone and pt_launch_split_* refused three cases with a generic HIP
+    error; the plan now knows the workgroup's LDS need and the item count and says "lock-step kernel" with a rule of its own."""
+    SPLIT_NO_ROOM = 6
+    ok = plan(ENVV, HD, frames=16, stack_depth=26, pipeline=4)
+    assert (ok.pipeline, ok.rule_pipeline) == (4, SPLIT)
+    deep = plan(ENVV, HD, frames=16, stack_depth=60, pipeline=4, split_trav=8)              # 60 x 8 x 256 B of stacks alone > 160 KB
+    assert (deep.pipeline, deep.rule_pipeline, deep.groups) == (0, SPLIT_NO_ROOM, 1)
+    capped = plan(ENVV, HD, frames=16, stack_depth=60, pipeline=4, split_trav=8, split_stack_cap=20)   # ... unless most of the stack lives in global memory
+    assert capped.pipeline == 4
+    huge = plan(ENVV, dict(width=16384, height=16384, owned_regions=1 << 20, max_bounces=4), frames=4, stack_depth=20, pipeline=4, pooled_samples=1 << 40)
+    assert (huge.pipeline, huge.rule_pipeline) == (0, SPLIT_NO_ROOM)                        # 4 x 2^20 tiles do not fit a claimed item's 20 bits
+    assert plan(ENVV, HD, frames=16, stack_depth=26, pipeline=4, split_trav=12, split_shade=6).pipeline == 0   # 18 waves > 1024 threads
+
+
+def test_prepass_small_call_rule_counts_the_calls_own_samples():
+    """A rank of a tile split renders its tiles only: rank 0 of 8 on a 4K frame x 8 is an 8.3 M-sample call (round 5)."""
+    whole = plan(SSSV, UHD, frames=8, stack_depth=30, has_lights=1, interior_walk_triangle_share=0.2)
+    eighth = plan(SSSV, dict(UHD, owned_regions=240 * 135 // 8), frames=8, stack_depth=30, has_lights=1, interior_walk_triangle_share=0.2)
+    assert (whole.prepass, whole.rule_prepass) == (ON, PRE_GLASS_AMONG_OTHERS) and (eighth.prepass, eighth.rule_prepass) == (OFF, PRE_SMALL_CALL)
+    assert plan(SSSV, dict(UHD, owned_regions=240 * 135 // 8), frames=32, stack_depth=30, has_lights=1, interior_walk_triangle_share=0.2).prepass == ON

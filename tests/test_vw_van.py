@@ -138,3 +138,41 @@ def test_nan_rays_are_misses_either_way(built, tmp_path):
     assert res["0"]["arr_1"][0] < 0.5 * res["1"]["arr_1"][0]                                       # boxes: the literal walk tests several times as many
     assert np.array_equal(res["0"]["arr_2"], res["1"]["arr_2"]) and (res["0"]["arr_2"][[0, 1, 2, 4]] == -1).all()   # NaN rays miss either way
     assert (res["0"]["arr_3"][[0, 1, 2, 4]] == 0).all() and res["1"]["arr_3"][[0, 1, 2]].sum() > 1000              # at once / after walking the tree
+
+
+@pytest.mark.gpu
+def test_ray_stats_of_nan_rays_follow_the_checker_not_the_literal_walk(gpu_tb, settings, tmp_path):
+    """a ray with a NaN is a miss before the walk (ray_cannot_hit, pt_device.hpp), so the counting kernels and the heatmap
+    report 0 BoxesTested / TrianglesTested for it where the reference's literal walk would count the whole tree (INTEGRATION.md,
+    "Known stat divergence").  The GPU's counters equal the checker's -- rays, hits, boxes, triangles -- and the literal walk
+    (TB_LITERAL_BOX_TEST=1, in a child process: the switch is read once) casts the same rays, shades the same hits and tests MORE boxes."""
+    import subprocess, sys, textwrap
+    W, H = 96, 60
+    s = copy.copy(settings); s.MaxBounces = 6
+    gpu_tb.SetOption("bvh_builder", 3)
+    try:
+        gpu_tb.LoadScene(VW)
+    finally:
+        gpu_tb.SetOption("bvh_builder", 0)
+    gpu_tb.SetOption("count_rays", 1)
+    try:
+        gpu_tb.InvalidateHistory(); gpu_tb.Render(W, H, 1, s, 0.0)
+        g = gpu_tb.ReadbackStats().rays
+    finally:
+        gpu_tb.SetOption("count_rays", 0)
+    c = ol.render(gpu_tb.HostSceneView(), gpu_tb.FrameConstants(W, H, 0, s, 0.0), W, H, 1, threads=4, stats=True)["stats"]
+    assert (g.rays, g.hitsShaded, g.boxesTested, g.trianglesTested) == (c.rays, c.hitsShaded, c.boxesTested, c.trianglesTested)
+    root = os.path.dirname(os.path.dirname(GOLDEN))
+    code = textwrap.dedent('''
+        import sys
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        from tracerboy_amd import api
+        import oracle_lib as ol
+        s = api.GetDefaultOutputSettings(); s.EnableBlueNoise = 0; s.MaxBounces = 6
+        hs = api.HostScene(%r, bvh_builder=3)
+        st = ol.render(hs.view(), hs.frame_constants(s, 0, 0.0), %d, %d, 1, threads=4, stats=True)["stats"]
+        print(st.rays, st.hitsShaded, st.boxesTested, st.trianglesTested)
+    ''') % (root, os.path.join(root, "tests"), VW, W, H)
+    r = subprocess.run([sys.executable, "-c", code], check=True, capture_output=True, text=True, env=dict(os.environ, TB_LITERAL_BOX_TEST="1"))
+    rays, hits, boxes, tris = (int(x) for x in r.stdout.split()[-4:])
+    assert (rays, hits) == (g.rays, g.hitsShaded) and boxes > g.boxesTested and tris >= g.trianglesTested

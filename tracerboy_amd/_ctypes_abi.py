@@ -169,7 +169,8 @@ class tb_plan_input(C.Structure):
                 ("width", C.c_uint32), ("height", C.c_uint32), ("frames", C.c_uint32), ("max_bounces", C.c_int32), ("owned_regions", C.c_uint64),
                 ("count_rays", C.c_uint32), ("aov", C.c_uint32), ("realtime", C.c_uint32), ("selected_pixel", C.c_uint32),
                 ("pipeline", C.c_int64), ("frame_group", C.c_int64), ("high_occupancy", C.c_int64), ("stack_lds_cap", C.c_int64), ("stack_overflow_max", C.c_int64),
-                ("node_layout", C.c_int64), ("primary_prepass", C.c_int64), ("overlap_launches", C.c_int64), ("pooled_samples", C.c_int64)]
+                ("node_layout", C.c_int64), ("primary_prepass", C.c_int64), ("overlap_launches", C.c_int64), ("pooled_samples", C.c_int64),
+                ("split_trav", C.c_int64), ("split_shade", C.c_int64), ("split_stack_cap", C.c_int64)]
 
 
 class tb_launch_plan(C.Structure):

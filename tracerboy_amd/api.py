@@ -76,6 +76,7 @@ def lib():
         "tb_read_split_profile": (C.c_int, [vp, P(C.c_uint64)]),
         "tb_plan_defaults": (None, [P(abi.tb_plan_input)]),
         "tb_plan_launch": (C.c_int, [P(abi.tb_plan_input), P(abi.tb_launch_plan)]),
+        "tb_variant_waves_hi": (C.c_int, [C.c_char_p]),
         "tb_invalidate_history": (None, [vp]),
         "tb_samples_rendered": (C.c_uint32, [vp]),
         "tb_select_pixel": (C.c_int, [vp, C.c_uint32, C.c_uint32]),
@@ -132,6 +133,11 @@ def GetDefaultPostProcessSettings():
     s = abi.tb_post_settings()
     lib().tb_default_post_settings(C.byref(s))
     return s
+
+
+def VariantWavesHi(name):
+    """Waves per SIMD the higher-occupancy copy of feature set `name` is compiled for (0: no such copy; tb_variant_waves_hi)."""
+    return int(lib().tb_variant_waves_hi(name.encode()))
 
 
 def PlanLaunch(**kw):

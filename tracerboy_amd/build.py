@@ -28,6 +28,24 @@ COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "
 # machine scheduler.  Measured on MI355X (scripts/ab_flags.sh): cornell-box 6 894 -> 7 054, 870 k scene 4 106 -> 4 247, bistro-class 4K
 # 1 171 -> 1 213 Msamples/s; neither changes a result bit (-ffp-contract=off pins the arithmetic, tests/ -m gpu).
 DEVICE = ["--offload-arch=" + ARCH, "-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]
+# The machine scheduler is chosen PER TRANSLATION UNIT where a same-box A/B says so (round 5, scripts/ab_variants.sh,
+# profiles/r5/ab_sched*.json; bit-identical pictures either way -- the scheduler only orders instructions).  max-memory-clause groups a
+# block's loads instead of spreading them for ILP: fewer values live at once, so the copies held to an occupancy spill less --
+#   vol4 (vw-van, 4 waves per SIMD): spill stores per launch 89 M -> 61 M, 4K flattened 1 845 -> 1 958 Msamples/s (+6 %), two-level +3.7 %;
+#   surf (Teapot): +1.6 % at 3 waves per SIMD, and with it 4 waves beat 3 for the first time (2 913 -> 3 116, +7 %: pt_variant_surf.hip);
+# and where it loses it stays off: sss4 (van- / bistro-class 4K) -3 % / -4 % although its spill stores fall 17 %, env5 (870 k scene) -12 %,
+# matte5 (cornell-box) +-0.  iterative-minreg: spill stores -10 % ... -34 %, every scene 10-13 % slower.
+SCHED_MEMORY_CLAUSE = ["-mllvm", "-amdgpu-sched-strategy=max-memory-clause"]
+TU_SCHEDULER = {"kernels/pt_variant_vol4.hip": SCHED_MEMORY_CLAUSE, "kernels/pt_variant_surf.hip": SCHED_MEMORY_CLAUSE}
+
+
+def device_flags(src):
+    """DEVICE with the translation unit's own scheduler in place of the default one (an -mllvm option may occur once)."""
+    if src not in TU_SCHEDULER:
+        return DEVICE
+    base = [f for i, f in enumerate(DEVICE) if not f.startswith("-amdgpu-sched-strategy=")
+            and not (f == "-mllvm" and i + 1 < len(DEVICE) and DEVICE[i + 1].startswith("-amdgpu-sched-strategy="))]
+    return base + TU_SCHEDULER[src]
 
 HOST_SRCS = ["host/pbrt_loader.cpp", "host/pbf_loader.cpp", "host/host_scene.cpp", "host/images.cpp", "host/image_decode.cpp", "host/image_formats.cpp", "host/bvh_build.cpp", "host/procedural.cpp", "host/context.cpp", "host/context_scene.cpp", "host/context_render.cpp", "host/pbrt_dump.cpp"]
 KERNEL_SRCS = ["kernels/pt_kernels.hip", "kernels/post_kernels.hip", "kernels/bvh_kernels.hip", "kernels/rt_kernels.hip", "kernels/pt_variant_matte.hip", "kernels/pt_variant_matte5.hip", "kernels/pt_variant_env.hip", "kernels/pt_variant_env5.hip", "kernels/pt_variant_surf.hip",
@@ -44,7 +62,7 @@ def _deps_digest():
                 if f.endswith((".h", ".hpp", ".inc", ".cpp", ".hip")):
                     with open(os.path.join(dp, f), "rb") as fh:
                         h.update(f.encode()); h.update(fh.read())
-    h.update(" ".join(COMMON + DEVICE).encode())
+    h.update(" ".join(COMMON + DEVICE + [k + " ".join(v) for k, v in sorted(TU_SCHEDULER.items())]).encode())
     return h.hexdigest()
 
 
@@ -58,13 +76,14 @@ def kernel_digest():
                 if f.endswith((".h", ".hpp", ".inc", ".hip")):
                     with open(os.path.join(dp, f), "rb") as fh:
                         h.update(f.encode()); h.update(fh.read())
-    h.update(" ".join([f for f in COMMON + DEVICE if not f.startswith("-I")]).encode())   # not the include path: the checkout sits elsewhere on the GPU box
+    flags = COMMON + DEVICE + [k + " ".join(v) for k, v in sorted(TU_SCHEDULER.items())]
+    h.update(" ".join([f for f in flags if not f.startswith("-I")]).encode())   # not the include path: the checkout sits elsewhere on the GPU box
     return h.hexdigest()[:16]
 
 
 def _compile(src):
     obj = os.path.join(OBJ, src.replace("/", "_") + ".o")
-    cmd = [HIPCC] + COMMON + (DEVICE if src.endswith(".hip") else ["-x", "hip", "--offload-arch=" + ARCH]) + ["-c", os.path.join(CSRC, src), "-o", obj]
+    cmd = [HIPCC] + COMMON + (device_flags(src) if src.endswith(".hip") else ["-x", "hip", "--offload-arch=" + ARCH]) + ["-c", os.path.join(CSRC, src), "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("compile failed: %s\n%s\n%s" % (" ".join(cmd), r.stdout, r.stderr))

@@ -295,6 +295,8 @@ int tb_read_accum(tb_context* c, float* rgba, float* jit)
     return guarded(c, [&]() {
         if (!c->output.p) return fail(c, TB_E_INVALID, "tb_read_accum: nothing rendered yet");
         HIP_TRY(hipStreamSynchronize(c->stream));
+        /* an asynchronous render of the split-role kernel that gave up leaves an incomplete frame: say so here too, not only in tb_sync */
+        if (c->splitAbort && *c->splitAbort) return fail(c, TB_E_DEVICE, splitAbortMessage(c));
         if (rgba) HIP_TRY(hipMemcpy(rgba, c->output.p, c->output.bytes, hipMemcpyDeviceToHost));
         if (jit) HIP_TRY(hipMemcpy(jit, c->jittered.p, c->jittered.bytes, hipMemcpyDeviceToHost));
         return TB_OK;
@@ -311,7 +313,15 @@ int tb_read_aov(tb_context* c, int which, void* dst)
     });
 }
 
-int tb_accum_device_ptr(tb_context* c, void** o, void** j) { if (!c) return TB_E_INVALID; if (o) *o = c->output.p; if (j) *j = c->jittered.p; return c->output.p ? TB_OK : TB_E_INVALID; }
+int tb_accum_device_ptr(tb_context* c, void** o, void** j)
+{
+    if (!c) return TB_E_INVALID;
+    if (o) *o = c->output.p;
+    if (j) *j = c->jittered.p;
+    /* the abort word of the split-role kernel is host-mapped: a launch that has already given up is reported without waiting for anything */
+    if (c->splitAbort && *c->splitAbort) return fail(c, TB_E_DEVICE, splitAbortMessage(c));
+    return c->output.p ? TB_OK : TB_E_INVALID;
+}
 
 void tb_default_denoiser_settings(tb_denoiser_settings* o) /* TracerBoy.h:338-344 */
 {
@@ -495,6 +505,13 @@ void tb_plan_defaults(tb_plan_input* in)
     if (!in) return;
     memset(in, 0, sizeof *in);
     in->high_occupancy = 1; in->stack_overflow_max = 24; in->primary_prepass = 1; in->overlap_launches = 1; in->pooled_samples = 256ll << 20;
+    in->split_trav = 4;
+}
+int tb_variant_waves_hi(const char* name)
+{
+    if (!name) return -1;
+    for (int i = 0; i < tbctx::kNumVariants; i++) if (!strcmp(tbctx::kVariants[i].name, name)) return tbctx::kVariants[i].fnHi ? (int)tbctx::kVariants[i].wavesHi : 0;
+    return -1;
 }
 int tb_plan_launch(const tb_plan_input* in, tb_launch_plan* out)
 {

@@ -149,6 +149,35 @@ std::string splitAbortMessage(tb_context* c)
     return buf;
 }
 
+/* the split-role kernel's workgroup shape and thresholds from the options (everything but the abort word and the profile pointer) */
+static void splitParamsFromOptions(tb_context* c, TbSplitParams& sp)
+{
+    auto opt = [&](const char* k, int64_t d) { auto it = c->options.find(k); return it == c->options.end() ? d : it->second; };
+    memset(&sp, 0, sizeof sp);
+    sp.travWaves = (uint32_t)std::max<int64_t>(1, opt("split_trav", 4)); sp.shadeWaves = (uint32_t)opt("split_shade", 0);
+    if (!sp.shadeWaves) sp.shadeWaves = c->sceneInLds ? 4 : 6; /* 0 = the default for the kind of scene */
+    sp.readyMin = (uint32_t)opt("split_ready", 32); sp.refillMin = (uint32_t)std::max<int64_t>(1, opt("split_refill", 16));
+    sp.innerWeight = (uint32_t)std::max<int64_t>(1, opt("split_wi", 85)); sp.leafWeight = (uint32_t)std::max<int64_t>(1, opt("split_wl", 160));
+    sp.travLast = opt("split_trav_last", 0) ? 1u : 0u; sp.shadePrio = opt("split_shade_prio", 0) ? 1u : 0u;
+    sp.ringCap = 256; while (sp.ringCap < 256u * sp.shadeWaves) sp.ringCap *= 2;
+    sp.spinLimit = (uint32_t)opt("split_spin_limit", 1 << 21);
+}
+
+/* Would pt_launch_split_* take this call?  Asked of the launcher itself (its query form launches nothing): besides what PlanLaunch can
+ * see -- LDS per workgroup, the number of 8x8 tiles -- it refuses a workgroup shape of which not one fits a CU by registers. */
+bool splitLaunchable(tb_context* c, const Variant* v, uint32_t W, uint32_t H, const TbPerFrameConstants& pf)
+{
+    auto opt = [&](const char* k, int64_t d) { auto it = c->options.find(k); return it == c->options.end() ? d : it->second; };
+    if (!v->split) return false;
+    TbSplitParams sp; splitParamsFromOptions(c, sp);
+    TbDeviceScene dsProbe = c->ds; dsProbe.nodesC = nullptr; dsProbe.stackOverflow = nullptr; dsProbe.stackOverflowLanes = 0;
+    const int64_t cap = opt("split_stack_cap", 0);
+    if (cap > 0 && (uint32_t)cap < c->ds.stackDepth && !c->sceneInLds) { dsProbe.stackDepth = (uint32_t)cap; dsProbe.stackOverflow = (uint32_t*)16; dsProbe.stackOverflowLanes = 0xffffffffu; }
+    TbDeviceTargets probe; memset(&probe, 0, sizeof probe); probe.samples = (TbFloat4*)16; probe.workCounter = (uint32_t*)16; probe.frameGroup = 1;
+    int perCU = 0;
+    return v->split(c->stream, &dsProbe, &pf, &probe, &sp, W, H, 0, 1, &c->tiles, c->sceneInLds ? 1 : 0, &perCU) == hipSuccess;
+}
+
 void renderSplit(tb_context* c, const Variant* v, uint32_t W, uint32_t H, uint32_t n, const TbPerFrameConstants& pf, TbDeviceTargets tg)
 {
     auto opt = [&](const char* k, int64_t d) { auto it = c->options.find(k); return it == c->options.end() ? d : it->second; };
@@ -157,14 +186,7 @@ void renderSplit(tb_context* c, const Variant* v, uint32_t W, uint32_t H, uint32
     batch = (n + (n + batch - 1) / batch - 1) / ((n + batch - 1) / batch); /* equal batches */
     const int numCUs = deviceCUs(c);
     const bool lds = c->sceneInLds;
-    TbSplitParams sp; memset(&sp, 0, sizeof sp);
-    sp.travWaves = (uint32_t)std::max<int64_t>(1, opt("split_trav", 4)); sp.shadeWaves = (uint32_t)opt("split_shade", 0);
-    if (!sp.shadeWaves) sp.shadeWaves = lds ? 4 : 6; /* 0 = the default for the kind of scene */
-    sp.readyMin = (uint32_t)opt("split_ready", 32); sp.refillMin = (uint32_t)std::max<int64_t>(1, opt("split_refill", 16));
-    sp.innerWeight = (uint32_t)std::max<int64_t>(1, opt("split_wi", 85)); sp.leafWeight = (uint32_t)std::max<int64_t>(1, opt("split_wl", 160));
-    sp.travLast = opt("split_trav_last", 0) ? 1u : 0u; sp.shadePrio = opt("split_shade_prio", 0) ? 1u : 0u;
-    sp.ringCap = 256; while (sp.ringCap < 256u * sp.shadeWaves) sp.ringCap *= 2;
-    sp.spinLimit = (uint32_t)opt("split_spin_limit", 1 << 21);
+    TbSplitParams sp; splitParamsFromOptions(c, sp);
     if (!c->splitAbort) { HIP_TRY(hipHostMalloc((void**)&c->splitAbort, 64, hipHostMallocMapped)); memset(c->splitAbort, 0, 64); }
     HIP_TRY(hipHostGetDevicePointer((void**)&sp.abortFlag, c->splitAbort, 0));
     if (opt("split_profile", 0)) { /* counting copy: 16 counters, cleared with the history, read back with tb_read_split_profile */
@@ -246,6 +268,7 @@ void fillPlanInput(tb_context* c, const Variant* v, uint32_t W, uint32_t H, uint
     in.pipeline = opt("pipeline", 0); in.frame_group = opt("frame_group", 0); in.high_occupancy = opt("high_occupancy", 1); in.stack_lds_cap = opt("stack_lds_cap", 0);
     in.stack_overflow_max = opt("stack_overflow_max", 24); in.node_layout = opt("node_layout", 0); in.primary_prepass = opt("primary_prepass", 1);
     in.overlap_launches = opt("overlap_launches", 1); in.pooled_samples = opt("pooled_samples", 256ll << 20);
+    in.split_trav = opt("split_trav", 4); in.split_shade = opt("split_shade", 0); in.split_stack_cap = opt("split_stack_cap", 0);
 }
 
 int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_output_settings* settings, float timeSeed, bool sync)
@@ -296,6 +319,9 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
      * walks its branches on the CPU); what follows executes the plan. */
     tb_plan_input pin; fillPlanInput(c, v, W, H, n, s, aov, count, pin);
     tb_launch_plan plan; PlanLaunch(pin, plan);
+    if (plan.pipeline == 4 && !splitLaunchable(c, v, W, H, pf)) { /* the launcher's own refusal: the lock-step kernel, by the plan's rules for it */
+        pin.pipeline = 0; PlanLaunch(pin, plan); plan.rule_pipeline = TB_PLAN_RULE_SPLIT_NO_ROOM;
+    }
     const bool wavefront = plan.pipeline == 2, pooled = plan.pipeline == 3, split = plan.pipeline == 4, groups = plan.groups != 0;
     const int64_t fg = opt("frame_group", 0);
     pt_variant_fn launch = plan.high_occupancy_copy ? v->fnHi : v->fn;

@@ -15,14 +15,26 @@ inline void PlanLaunch(const tb_plan_input& in, tb_launch_plan& p)
     const bool plain = !in.count_rays && !in.aov && !in.realtime && !in.selected_pixel; /* the call writes nothing but radiance */
     const int64_t pipe = in.pipeline == 4 ? 0 : in.pipeline; /* 4 = the split-role kernel where it exists, the lock-step kernel (0) elsewhere */
     p.pipeline = (int32_t)pipe;
-    if (in.pipeline == 4 && in.variant_has_split && plain && !in.two_level) { p.pipeline = 4; p.rule_pipeline = TB_PLAN_RULE_SPLIT; return; }
+    if (in.pipeline == 4 && in.variant_has_split && plain && !in.two_level) {
+        /* what pt_launch_split_* would refuse (pt_split_variant.inc): a workgroup's LDS -- traversal stacks (as many entries as the tree is
+         * deep, or option split_stack_cap of them with the rest in global memory), the scene image, 48-B ray slots, the queue -- beyond
+         * 160 KB, or more 8x8 tiles than a claimed item has bits for (frames above ~8192 x 8192).  Such a call runs the lock-step kernel,
+         * with a rule of its own (it used to throw a generic HIP error out of renderSplit). */
+        const uint64_t trav = (uint64_t)std::max<int64_t>(1, in.split_trav), shade = in.split_shade > 0 ? (uint64_t)in.split_shade : (in.scene_in_lds ? 4u : 6u);
+        uint64_t ring = 256; while (ring < 256u * shade) ring *= 2;
+        const uint64_t entries = (in.split_stack_cap > 0 && (uint64_t)in.split_stack_cap < in.stack_depth && !in.scene_in_lds) ? (uint64_t)in.split_stack_cap : in.stack_depth;
+        const uint64_t lds = entries * trav * 256u + (in.scene_in_lds ? ((uint64_t)in.lds_blob_bytes + 15u) / 16u * 16u : 0u) + shade * 128u * 48u + ring * 4u + 16u;
+        const bool fits = lds <= 160u * 1024u && 4ull * std::max<uint64_t>(1, in.owned_regions) <= 0xfffffull && (trav + shade) * 64u <= 1024u;
+        if (fits) { p.pipeline = 4; p.rule_pipeline = TB_PLAN_RULE_SPLIT; return; }
+        p.rule_pipeline = TB_PLAN_RULE_SPLIT_NO_ROOM; /* and on with the lock-step kernel's plan; the rule stays */
+    }
     if (pipe == 2 && in.variant_has_wavefront && !in.count_rays && !in.aov) { p.rule_pipeline = TB_PLAN_RULE_WAVEFRONT; return; }
     if (pipe == 3 && in.variant_has_pooled && !in.count_rays && !in.aov) { p.rule_pipeline = TB_PLAN_RULE_POOLED; return; }
     if (pipe == 2 || pipe == 3) p.pipeline = 0; /* feature sets these pipelines lack fall back to the lock-step kernel */
     /* Frame-group mode: measured to win from 2 frames per call on (cornell-box 4 spp +23 %, 870 k scene 4 spp 2x); one frame per call:
      * +17 % with the scene in LDS, -9 % on the 870 k scene.  Option frame_group > 0 forces it (and the group size), < 0 forbids it. */
     p.groups = pipe == 0 && plain && in.frame_group >= 0 && (in.frame_group > 0 || in.frames >= (in.scene_in_lds ? 1u : 2u));
-    p.rule_pipeline = p.groups ? TB_PLAN_RULE_FRAME_GROUPS : TB_PLAN_RULE_ONE_PIXEL_PER_LANE;
+    if (p.rule_pipeline != TB_PLAN_RULE_SPLIT_NO_ROOM) p.rule_pipeline = p.groups ? TB_PLAN_RULE_FRAME_GROUPS : TB_PLAN_RULE_ONE_PIXEL_PER_LANE;
     /* Which copy of the feature set: the higher-occupancy one when its workgroups fit in LDS.  LDS per workgroup = 1 KB per stack entry
      * (+ the scene image); where the tree is too deep for that, a frame-group launch may still use the copy with a split stack -- as
      * many entries in LDS as fit, the deepest few (option stack_overflow_max) in global memory.  Default 24 since round 4 (16 before): the
