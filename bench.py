@@ -386,7 +386,16 @@ def expected_speedup_leg(key, world):
     if not d or "world1" not in d or ("world%d" % world) not in d:
         return None
     one, w = d["world1"], d["world%d" % world]
-    return {"vs_1gpu": round(one["max_ms"] / w["max_ms"], 2), "max_over_mean_rank_ms": w["max_over_mean"],
+    longer = None
+    f32 = _newest("rank_imbalance_32spp.json")
+    if f32:
+        d32 = json.load(open(f32)).get(key) or {}
+        if "world1" in d32 and ("world%d" % world) in d32:
+            longer = {"spp": 32, "vs_1gpu": round(d32["world1"]["max_ms"] / d32["world%d" % world]["max_ms"], 2),
+                      "max_over_mean_rank_ms": d32["world%d" % world]["max_over_mean"], "source": os.path.relpath(f32, ROOT),
+                      "note": "the same sweep at 32 spp per step: a launch costs ~1.5 ms more than its samples whatever its size "
+                              "(its tail), which weighs a quarter of a rank's 8-spp step and little of a longer one"}
+    return {"vs_1gpu": round(one["max_ms"] / w["max_ms"], 2), "max_over_mean_rank_ms": w["max_over_mean"], "at_longer_steps": longer,
             "slowest_rank": w.get("slowest_rank"), "ms_per_step_slowest_rank": w["max_ms"], "tile": d.get("tile", TILE),
             "deal": d.get("deal", "round-robin"), "source": os.path.relpath(f, ROOT),
             "note": "one GPU emulating each rank of N in turn (async step: render + pack + stream-ordered consumer); "

@@ -118,29 +118,27 @@ TB_HD float tb_cos_poly(float r)
     return tb_fma(p * z, z, tb_fma(-0.5f, z, 1.0f));
 }
 
-/* inf, nan and absurdly large arguments give NaN -- by a select on the way in (the reduction then sees 0) and one on the way out, not
- * by a branch: a branch costs the device an exec-mask save / restore per call and keeps two consecutive rand() calls from being
- * scheduled together; the value of every in-range argument is computed by the same operations as before */
+/* The guard against inf, nan and absurdly large arguments stays a BRANCH here, unlike the selects of exp2 / log2 / asin / acos / atan below:
+ * every rand() goes through tb_sin, the cornell-box kernel is VALU-bound, and the select form's two extra vector instructions per call
+ * cost it 0.6 % where the branch's exec-mask bookkeeping is scalar work that kernel has to spare (same-box A/B, profiles/r5/ab_rounds.json). */
 TB_HD float tb_sin(float x)
 {
-    const bool ok = tb_abs(x) < 1.0e9f;
+    if (!(tb_abs(x) < 1.0e9f)) return tb_u2f(0x7fc00000u); /* inf, nan, absurdly large */
     float r; int q;
-    tb_sincos_reduce(ok ? x : 0.0f, &r, &q);
+    tb_sincos_reduce(x, &r, &q);
     const float sp = tb_sin_poly(r), cp = tb_cos_poly(r); /* both, then a select: the quadrant differs from lane to lane */
     float s = (q & 1) ? cp : sp;
-    s = (q & 2) ? -s : s;
-    return ok ? s : tb_u2f(0x7fc00000u);
+    return (q & 2) ? -s : s;
 }
 
 TB_HD float tb_cos(float x)
 {
-    const bool ok = tb_abs(x) < 1.0e9f;
+    if (!(tb_abs(x) < 1.0e9f)) return tb_u2f(0x7fc00000u);
     float r; int q;
-    tb_sincos_reduce(ok ? x : 0.0f, &r, &q);
+    tb_sincos_reduce(x, &r, &q);
     const float sp = tb_sin_poly(r), cp = tb_cos_poly(r);
     float c = (q & 1) ? sp : cp;
-    c = ((q + 1) & 2) ? -c : c;
-    return ok ? c : tb_u2f(0x7fc00000u);
+    return ((q + 1) & 2) ? -c : c;
 }
 
 /* ---- asin / acos (Cephes asinf/acosf) ---------------------------------------------------- */
@@ -154,37 +152,39 @@ TB_HD float tb_asin_core(float a) /* 0 <= a <= 0.5 */
     return tb_fma(p * z, a, a);
 }
 
+/* select form (see tb_exp2): one evaluation of the core polynomial on the argument the case asks for, the case's affine map chosen
+ * afterwards; each case's operations are those of the branching form */
 TB_HD float tb_asin(float x)
 {
-    float a = tb_abs(x);
-    if (!(a <= 1.0f)) return tb_u2f(0x7fc00000u);
-    float r;
-    if (a > 0.5f) {
-        float z = 0.5f * (1.0f - a);
-        float s = tb_sqrt(z);
-        r = 1.5707963267948966f - 2.0f * tb_asin_core(s);
-    } else {
-        r = tb_asin_core(a);
-    }
-    return (x < 0.0f) ? -r : r;
+    const float a = tb_abs(x);
+    const bool ok = a <= 1.0f, hi = a > 0.5f;
+    const float s = tb_sqrt(0.5f * (1.0f - a));
+    const float c = tb_asin_core(hi ? s : a);
+    float r = hi ? 1.5707963267948966f - 2.0f * c : c;
+    r = (x < 0.0f) ? -r : r;
+    return ok ? r : tb_u2f(0x7fc00000u);
 }
 
 TB_HD float tb_acos(float x)
 {
-    if (!(tb_abs(x) <= 1.0f)) return tb_u2f(0x7fc00000u);
-    if (x > 0.5f) return 2.0f * tb_asin_core(tb_sqrt(0.5f * (1.0f - x)));
-    if (x < -0.5f) return 3.14159265358979323846f - 2.0f * tb_asin_core(tb_sqrt(0.5f * (1.0f + x)));
-    return 1.5707963267948966f - tb_asin(x);
+    const float a = tb_abs(x);
+    const bool ok = a <= 1.0f, hi = a > 0.5f;
+    const float s = tb_sqrt(0.5f * (1.0f - a)); /* 1 - x for x > 0.5, 1 + x for x < -0.5: the same number */
+    const float c = tb_asin_core(hi ? s : a);
+    const float mid = 1.5707963267948966f - ((x < 0.0f) ? -c : c);                 /* |x| <= 0.5: pi/2 - asin(x) */
+    const float out = (x > 0.5f) ? 2.0f * c : 3.14159265358979323846f - 2.0f * c;  /* x > 0.5 | x < -0.5 */
+    const float r = hi ? out : mid;
+    return ok ? r : tb_u2f(0x7fc00000u);
 }
 
 /* ---- atan / atan2 (Cephes atanf) --------------------------------------------------------- */
 TB_HD float tb_atan(float xx)
 {
     float x = tb_abs(xx);
-    float y;
-    if (x > 2.414213562373095f) { y = 1.5707963267948966f; x = -(1.0f / x); }
-    else if (x > 0.4142135623730950f) { y = 0.7853981633974483f; x = (x - 1.0f) / (x + 1.0f); }
-    else { y = 0.0f; }
+    /* the three ranges as selects of ONE division's operands: -(1 / x) = (-1) / x and x = x / 1 exactly */
+    const bool big = x > 2.414213562373095f, mid = x > 0.4142135623730950f;
+    float y = big ? 1.5707963267948966f : (mid ? 0.7853981633974483f : 0.0f);
+    x = (big ? -1.0f : (mid ? x - 1.0f : x)) / (big ? x : (mid ? x + 1.0f : 1.0f));
     float z = x * x;
     float p = tb_fma(8.05374449538e-2f, z, -1.38776856032e-1f);
     p = tb_fma(p, z, 1.99777106478e-1f);
@@ -208,13 +208,15 @@ TB_HD float tb_atan2(float y, float x)
 }
 
 /* ---- exp2 / log2 (Cephes exp2f / log2f) and the HLSL-style derived forms ------------------ */
+/* Special arguments are handled by selects on the way in (the main path then sees a harmless value) and on the way out, not by
+ * early returns: on the device every early return is an exec-mask save / restore and a branch around code that a neighbouring lane
+ * needs anyway (pow = exp2(y * log2(x)) alone had eight of them).  Every argument's value is that of the branching form. */
 TB_HD float tb_exp2(float x)
 {
-    if (x != x) return x;
-    if (x >= 128.0f) return tb_u2f(0x7f800000u);
-    if (x < -150.0f) return 0.0f;
-    float n = __builtin_rintf(x);
-    float r = x - n; /* exact, |r| <= 0.5 */
+    const bool isNan = x != x, big = x >= 128.0f, tiny = x < -150.0f;
+    const float xm = (isNan || big || tiny) ? 0.0f : x;
+    float n = __builtin_rintf(xm);
+    float r = xm - n; /* exact, |r| <= 0.5 */
     float p = tb_fma(1.535336188319500e-4f, r, 1.339887440266574e-3f);
     p = tb_fma(p, r, 9.618437357674640e-3f);
     p = tb_fma(p, r, 5.550332471162809e-2f);
@@ -227,26 +229,26 @@ TB_HD float tb_exp2(float x)
     int n1 = ni / 2, n2 = ni - n1;
     float s1 = tb_u2f((uint32_t)(n1 + 127) << 23);
     float s2 = tb_u2f((uint32_t)(n2 + 127) << 23);
-    return (p * s1) * s2;
+    float v = (p * s1) * s2;
+    v = tiny ? 0.0f : v;
+    v = big ? tb_u2f(0x7f800000u) : v;
+    return isNan ? x : v;
 }
 
 TB_HD float tb_log2(float x)
 {
-    if (x != x) return x;
-    if (x < 0.0f) return tb_u2f(0x7fc00000u);
-    if (x == 0.0f) return tb_u2f(0xff800000u);
-    if (x == tb_u2f(0x7f800000u)) return x;
-    uint32_t u = tb_f2u(x);
-    int e = 0;
-    if ((u & 0x7f800000u) == 0) { /* denormal: renormalise exactly */
-        x = x * 8388608.0f;
-        u = tb_f2u(x);
-        e = -23;
-    }
+    const bool isNan = x != x, neg = x < 0.0f, zero = x == 0.0f, inf = x == tb_u2f(0x7f800000u);
+    float xm = (isNan || neg || zero || inf) ? 1.0f : x;
+    uint32_t u = tb_f2u(xm);
+    const bool den = (u & 0x7f800000u) == 0; /* denormal: renormalise exactly */
+    xm = den ? xm * 8388608.0f : xm;
+    u = tb_f2u(xm);
+    int e = den ? -23 : 0;
     e += (int)((u >> 23) & 0xff) - 126;
     float m = tb_u2f((u & 0x007fffffu) | 0x3f000000u); /* [0.5, 1) */
-    if (m < 0.70710678118654752440f) { e -= 1; m = m + m - 1.0f; }
-    else { m = m - 1.0f; }
+    const bool low = m < 0.70710678118654752440f;
+    e = low ? e - 1 : e;
+    m = low ? m + m - 1.0f : m - 1.0f;
     float z = m * m;
     float p = tb_fma(7.0376836292e-2f, m, -1.1514610310e-1f);
     p = tb_fma(p, m, 1.1676998740e-1f);
@@ -263,7 +265,11 @@ TB_HD float tb_log2(float x)
     r = tb_fma(m, log2ea, r);
     r = r + y;
     r = r + m;
-    return r + (float)e;
+    float v = r + (float)e;
+    v = inf ? x : v;
+    v = zero ? tb_u2f(0xff800000u) : v;
+    v = neg ? tb_u2f(0x7fc00000u) : v;
+    return isNan ? x : v;
 }
 
 TB_HD float tb_exp(float x) { return tb_exp2(x * 1.4426950408889634f); }

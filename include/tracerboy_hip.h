@@ -171,7 +171,8 @@ int tb_decode_image(const char* path, uint32_t* width, uint32_t* height, int* no
  * buffers and the previous camera live in the context.  tb_post_process(LIT) afterwards tonemaps the chain's output.
  * tb_read_realtime stages: 0 first TAA output (rgb, variance), 1 moments, 2 denoised, 3 composited, 4 final TAA output. */
 void tb_default_denoiser_settings(tb_denoiser_settings* out);
-int tb_render_realtime(tb_context* ctx, uint32_t width, uint32_t height, const tb_output_settings* settings, const tb_denoiser_settings* denoiser, float time_seed);
+int tb_render_realtime(tb_context* ctx, uint32_t width, uint32_t height, const tb_output_settings* settings, const tb_denoiser_settings* denoiser,
+    float time_seed);
 int tb_read_realtime(tb_context* ctx, int stage, float* rgba);
 
 /* <-> ReadbackStats copy (TracerBoy.cpp:2946, D3D12App.cpp:195-201) */
@@ -226,10 +227,16 @@ int64_t tb_get_option(tb_context* ctx, const char* name);
  * (tests/test_launch_plan.py).  No reference counterpart: TracerBoy::Render has one shader and one dispatch shape (TracerBoy.cpp:2677-2946). */
 enum { TB_PLAN_FEAT_SSS = 8, TB_PLAN_FEAT_EXT = 32 }; /* bits of variant_features the policy looks at (PT_FEAT_SSS / PT_FEAT_EXT) */
 enum { TB_PLAN_PREPASS_OFF = 0, TB_PLAN_PREPASS_ON = 1, TB_PLAN_PREPASS_TRIAL = 2 };
-enum { TB_PLAN_RULE_ONE_PIXEL_PER_LANE = 1, TB_PLAN_RULE_FRAME_GROUPS, TB_PLAN_RULE_WAVEFRONT, TB_PLAN_RULE_POOLED, TB_PLAN_RULE_SPLIT, TB_PLAN_RULE_SPLIT_NO_ROOM,                 /* rule_pipeline */
-       TB_PLAN_RULE_COPY_NONE = 10, TB_PLAN_RULE_COPY_FITS, TB_PLAN_RULE_COPY_SPLIT_STACK, TB_PLAN_RULE_COPY_TOO_DEEP, TB_PLAN_RULE_COPY_NO_ROOM, TB_PLAN_RULE_COPY_FULL_FOR_INSTANCES, /* rule_copy */
-       TB_PLAN_RULE_PREPASS_NO_KERNEL = 20, TB_PLAN_RULE_PREPASS_OPTION_OFF, TB_PLAN_RULE_PREPASS_FORCED, TB_PLAN_RULE_PREPASS_SMALL_CALL, TB_PLAN_RULE_PREPASS_ENV_LIT,
-       TB_PLAN_RULE_PREPASS_GLASS_AMONG_OTHERS, TB_PLAN_RULE_PREPASS_TRIAL };                                                                              /* rule_prepass */
+/* rule_pipeline */
+enum { TB_PLAN_RULE_ONE_PIXEL_PER_LANE = 1, TB_PLAN_RULE_FRAME_GROUPS, TB_PLAN_RULE_WAVEFRONT, TB_PLAN_RULE_POOLED, TB_PLAN_RULE_SPLIT,
+    TB_PLAN_RULE_SPLIT_NO_ROOM,
+       /* rule_copy */
+       TB_PLAN_RULE_COPY_NONE = 10, TB_PLAN_RULE_COPY_FITS, TB_PLAN_RULE_COPY_SPLIT_STACK, TB_PLAN_RULE_COPY_TOO_DEEP, TB_PLAN_RULE_COPY_NO_ROOM,
+           TB_PLAN_RULE_COPY_FULL_FOR_INSTANCES,
+       TB_PLAN_RULE_PREPASS_NO_KERNEL = 20, TB_PLAN_RULE_PREPASS_OPTION_OFF, TB_PLAN_RULE_PREPASS_FORCED, TB_PLAN_RULE_PREPASS_SMALL_CALL,
+           TB_PLAN_RULE_PREPASS_ENV_LIT,
+       /* rule_prepass */
+       TB_PLAN_RULE_PREPASS_GLASS_AMONG_OTHERS, TB_PLAN_RULE_PREPASS_TRIAL };
 typedef struct tb_plan_input {
     /* the feature set the scene and the settings select (context.cpp kVariants) */
     uint32_t variant_features;        /* PT_FEAT_* mask of the set */

@@ -77,7 +77,8 @@ inline Box AABBtoBox(tb3 mn, tb3 mx)
 namespace {
 
 struct AABB { tb3 mn, mx; };
-inline AABB CombineAABB(const AABB& a, const AABB& b) { AABB r; r.mn = tb3_min(a.mn, b.mn); r.mx = tb3_max(a.mx, b.mx); return r; } /* TreeletReorderBindings.h:104-110 */
+/* TreeletReorderBindings.h:104-110 */
+inline AABB CombineAABB(const AABB& a, const AABB& b) { AABB r; r.mn = tb3_min(a.mn, b.mn); r.mx = tb3_max(a.mx, b.mx); return r; }
 inline float ComputeBoxSurfaceArea(const AABB& a) /* TreeletReorderBindings.h:98-102 */
 {
     tb3 dim = a.mx - a.mn;
@@ -108,7 +109,8 @@ struct Treelets {
                 uint32_t treeletNodeIndex = treeletToReorder[i];
                 if (!isLeaf(treeletNodeIndex)) {
                     float surfaceArea = ComputeBoxSurfaceArea(aabb[treeletNodeIndex]);
-                    if (surfaceArea > largestSurfaceArea) { largestSurfaceArea = surfaceArea; nodeIndexToTraverse = treeletNodeIndex; indexOfNodeIndexToTraverse = i; }
+                    if (surfaceArea > largestSurfaceArea) { largestSurfaceArea = surfaceArea; nodeIndexToTraverse = treeletNodeIndex;
+                        indexOfNodeIndexToTraverse = i; }
                 }
             }
             internalNodes[treeletSize - 1] = nodeIndexToTraverse;
@@ -148,10 +150,12 @@ struct Treelets {
         while (partitionStackSize > 0) {
             PartitionEntry partition = partitionStack[--partitionStackSize];
             PartitionEntry leftEntry; leftEntry.Mask = optimalPartition[partition.Mask];
-            if (__builtin_popcount(leftEntry.Mask) > 1) { leftEntry.NodeIndex = internalNodes[nodesAllocated++]; partitionStack[partitionStackSize++] = leftEntry; }
+            if (__builtin_popcount(leftEntry.Mask) > 1) { leftEntry.NodeIndex = internalNodes[nodesAllocated++];
+                partitionStack[partitionStackSize++] = leftEntry; }
             else leftEntry.NodeIndex = treeletToReorder[__builtin_ctz(leftEntry.Mask)];
             PartitionEntry rightEntry; rightEntry.Mask = partition.Mask ^ leftEntry.Mask;
-            if (__builtin_popcount(rightEntry.Mask) > 1) { rightEntry.NodeIndex = internalNodes[nodesAllocated++]; partitionStack[partitionStackSize++] = rightEntry; }
+            if (__builtin_popcount(rightEntry.Mask) > 1) { rightEntry.NodeIndex = internalNodes[nodesAllocated++];
+                partitionStack[partitionStackSize++] = rightEntry; }
             else rightEntry.NodeIndex = treeletToReorder[__builtin_ctz(rightEntry.Mask)];
             L(partition.NodeIndex) = leftEntry.NodeIndex; R(partition.NodeIndex) = rightEntry.NodeIndex;
             parent[leftEntry.NodeIndex] = partition.NodeIndex; parent[rightEntry.NodeIndex] = partition.NodeIndex;
@@ -347,24 +351,37 @@ namespace {
 float Determinant34(const float* t) /* RayTracingHelper.hlsli:287-295 */
 {
 #define M(r, c) t[(r) * 4 + (c)]
-    return M(0, 0) * M(1, 1) * M(2, 2) - M(0, 0) * M(2, 1) * M(1, 2) - M(1, 0) * M(0, 1) * M(2, 2) + M(1, 0) * M(2, 1) * M(0, 2) + M(2, 0) * M(0, 1) * M(1, 2) - M(2, 0) * M(1, 1) * M(0, 2);
+    return M(0, 0) * M(1, 1) * M(2, 2) - M(0, 0) * M(2, 1) * M(1, 2) - M(1, 0) * M(0, 1) * M(2, 2) + M(1, 0) * M(2, 1) * M(0, 2) + M(2, 0) * M(0, 1) * M(1,
+        2) - M(2, 0) * M(1, 1) * M(0, 2);
 }
 void InverseAffine34(const float* t, float* o) /* RayTracingHelper.hlsli:297-316, term by term */
 {
     const float invDet = 1.0f / Determinant34(t);
 #define O(r, c) o[(r) * 4 + (c)]
-    O(0, 0) = invDet * (M(1, 1) * (M(2, 2) * 1.0f - 0.0f * M(2, 3)) + M(2, 1) * (0.0f * M(1, 3) - M(1, 2) * 1.0f) + 0.0f * (M(1, 2) * M(2, 3) - M(2, 2) * M(1, 3)));
-    O(1, 0) = invDet * (M(1, 2) * (M(2, 0) * 1.0f - 0.0f * M(2, 3)) + M(2, 2) * (0.0f * M(1, 3) - M(1, 0) * 1.0f) + 0.0f * (M(1, 0) * M(2, 3) - M(2, 0) * M(1, 3)));
-    O(2, 0) = invDet * (M(1, 3) * (M(2, 0) * 0.0f - 0.0f * M(2, 1)) + M(2, 3) * (0.0f * M(1, 1) - M(1, 0) * 0.0f) + 1.0f * (M(1, 0) * M(2, 1) - M(2, 0) * M(1, 1)));
-    O(0, 1) = invDet * (M(2, 1) * (M(0, 2) * 1.0f - 0.0f * M(0, 3)) + 0.0f * (M(2, 2) * M(0, 3) - M(0, 2) * M(2, 3)) + M(0, 1) * (0.0f * M(2, 3) - M(2, 2) * 1.0f));
-    O(1, 1) = invDet * (M(2, 2) * (M(0, 0) * 1.0f - 0.0f * M(0, 3)) + 0.0f * (M(2, 0) * M(0, 3) - M(0, 0) * M(2, 3)) + M(0, 2) * (0.0f * M(2, 3) - M(2, 0) * 1.0f));
-    O(2, 1) = invDet * (M(2, 3) * (M(0, 0) * 0.0f - 0.0f * M(0, 1)) + 1.0f * (M(2, 0) * M(0, 1) - M(0, 0) * M(2, 1)) + M(0, 3) * (0.0f * M(2, 1) - M(2, 0) * 0.0f));
-    O(0, 2) = invDet * (0.0f * (M(0, 2) * M(1, 3) - M(1, 2) * M(0, 3)) + M(0, 1) * (M(1, 2) * 1.0f - 0.0f * M(1, 3)) + M(1, 1) * (0.0f * M(0, 3) - M(0, 2) * 1.0f));
-    O(1, 2) = invDet * (0.0f * (M(0, 0) * M(1, 3) - M(1, 0) * M(0, 3)) + M(0, 2) * (M(1, 0) * 1.0f - 0.0f * M(1, 3)) + M(1, 2) * (0.0f * M(0, 3) - M(0, 0) * 1.0f));
-    O(2, 2) = invDet * (1.0f * (M(0, 0) * M(1, 1) - M(1, 0) * M(0, 1)) + M(0, 3) * (M(1, 0) * 0.0f - 0.0f * M(1, 1)) + M(1, 3) * (0.0f * M(0, 1) - M(0, 0) * 0.0f));
-    O(0, 3) = invDet * (M(0, 1) * (M(2, 2) * M(1, 3) - M(1, 2) * M(2, 3)) + M(1, 1) * (M(0, 2) * M(2, 3) - M(2, 2) * M(0, 3)) + M(2, 1) * (M(1, 2) * M(0, 3) - M(0, 2) * M(1, 3)));
-    O(1, 3) = invDet * (M(0, 2) * (M(2, 0) * M(1, 3) - M(1, 0) * M(2, 3)) + M(1, 2) * (M(0, 0) * M(2, 3) - M(2, 0) * M(0, 3)) + M(2, 2) * (M(1, 0) * M(0, 3) - M(0, 0) * M(1, 3)));
-    O(2, 3) = invDet * (M(0, 3) * (M(2, 0) * M(1, 1) - M(1, 0) * M(2, 1)) + M(1, 3) * (M(0, 0) * M(2, 1) - M(2, 0) * M(0, 1)) + M(2, 3) * (M(1, 0) * M(0, 1) - M(0, 0) * M(1, 1)));
+    O(0, 0) = invDet * (M(1, 1) * (M(2, 2) * 1.0f - 0.0f * M(2, 3)) + M(2, 1) * (0.0f * M(1, 3) - M(1, 2) * 1.0f) + 0.0f * (M(1, 2) * M(2, 3) - M(2, 2) * M(1,
+        3)));
+    O(1, 0) = invDet * (M(1, 2) * (M(2, 0) * 1.0f - 0.0f * M(2, 3)) + M(2, 2) * (0.0f * M(1, 3) - M(1, 0) * 1.0f) + 0.0f * (M(1, 0) * M(2, 3) - M(2, 0) * M(1,
+        3)));
+    O(2, 0) = invDet * (M(1, 3) * (M(2, 0) * 0.0f - 0.0f * M(2, 1)) + M(2, 3) * (0.0f * M(1, 1) - M(1, 0) * 0.0f) + 1.0f * (M(1, 0) * M(2, 1) - M(2, 0) * M(1,
+        1)));
+    O(0, 1) = invDet * (M(2, 1) * (M(0, 2) * 1.0f - 0.0f * M(0, 3)) + 0.0f * (M(2, 2) * M(0, 3) - M(0, 2) * M(2, 3)) + M(0, 1) * (0.0f * M(2, 3) - M(2,
+        2) * 1.0f));
+    O(1, 1) = invDet * (M(2, 2) * (M(0, 0) * 1.0f - 0.0f * M(0, 3)) + 0.0f * (M(2, 0) * M(0, 3) - M(0, 0) * M(2, 3)) + M(0, 2) * (0.0f * M(2, 3) - M(2,
+        0) * 1.0f));
+    O(2, 1) = invDet * (M(2, 3) * (M(0, 0) * 0.0f - 0.0f * M(0, 1)) + 1.0f * (M(2, 0) * M(0, 1) - M(0, 0) * M(2, 1)) + M(0, 3) * (0.0f * M(2, 1) - M(2,
+        0) * 0.0f));
+    O(0, 2) = invDet * (0.0f * (M(0, 2) * M(1, 3) - M(1, 2) * M(0, 3)) + M(0, 1) * (M(1, 2) * 1.0f - 0.0f * M(1, 3)) + M(1, 1) * (0.0f * M(0, 3) - M(0,
+        2) * 1.0f));
+    O(1, 2) = invDet * (0.0f * (M(0, 0) * M(1, 3) - M(1, 0) * M(0, 3)) + M(0, 2) * (M(1, 0) * 1.0f - 0.0f * M(1, 3)) + M(1, 2) * (0.0f * M(0, 3) - M(0,
+        0) * 1.0f));
+    O(2, 2) = invDet * (1.0f * (M(0, 0) * M(1, 1) - M(1, 0) * M(0, 1)) + M(0, 3) * (M(1, 0) * 0.0f - 0.0f * M(1, 1)) + M(1, 3) * (0.0f * M(0, 1) - M(0,
+        0) * 0.0f));
+    O(0, 3) = invDet * (M(0, 1) * (M(2, 2) * M(1, 3) - M(1, 2) * M(2, 3)) + M(1, 1) * (M(0, 2) * M(2, 3) - M(2, 2) * M(0, 3)) + M(2, 1) * (M(1, 2) * M(0,
+        3) - M(0, 2) * M(1, 3)));
+    O(1, 3) = invDet * (M(0, 2) * (M(2, 0) * M(1, 3) - M(1, 0) * M(2, 3)) + M(1, 2) * (M(0, 0) * M(2, 3) - M(2, 0) * M(0, 3)) + M(2, 2) * (M(1, 0) * M(0,
+        3) - M(0, 0) * M(1, 3)));
+    O(2, 3) = invDet * (M(0, 3) * (M(2, 0) * M(1, 1) - M(1, 0) * M(2, 1)) + M(1, 3) * (M(0, 0) * M(2, 1) - M(2, 0) * M(0, 1)) + M(2, 3) * (M(1, 0) * M(0,
+        1) - M(0, 0) * M(1, 1)));
 #undef O
 #undef M
 }
@@ -386,7 +403,8 @@ extern "C" int64_t tbo_build_tlas(const float* objectToWorld, const float* rootB
     for (uint32_t i = 0; i < M; i++) {
         const float* o2w = objectToWorld + 12ull * i;
         InverseAffine34(o2w, &w2o[12ull * i]);
-        const tb3 mn = tb3_make(rootBoxes[6 * i], rootBoxes[6 * i + 1], rootBoxes[6 * i + 2]), mx = tb3_make(rootBoxes[6 * i + 3], rootBoxes[6 * i + 4], rootBoxes[6 * i + 5]);
+        const tb3 mn = tb3_make(rootBoxes[6 * i], rootBoxes[6 * i + 1], rootBoxes[6 * i + 2]), mx = tb3_make(rootBoxes[6 * i + 3], rootBoxes[6 * i + 4],
+            rootBoxes[6 * i + 5]);
         /* TransformAABB :318-344: the eight corners in the order of the listing (the min / max of a set does not depend on it) */
         const tb3 corner[8] = {mn, tb3_make(mn.x, mn.y, mx.z), tb3_make(mn.x, mx.y, mx.z), tb3_make(mn.x, mx.y, mn.z), tb3_make(mx.x, mn.y, mn.z),
                                tb3_make(mx.x, mx.y, mn.z), tb3_make(mx.x, mn.y, mx.z), mx};
@@ -432,7 +450,8 @@ extern "C" int64_t tbo_build_tlas(const float* objectToWorld, const float* rootB
     }
     std::vector<uint32_t> count((size_t)numNodes, 0), order; order.reserve((size_t)numNodes);
     { std::vector<uint32_t> st; st.push_back(0);
-      while (!st.empty()) { uint32_t x = st.back(); st.pop_back(); order.push_back(x); if (M > 1 && x < M - 1) { st.push_back(left[x]); st.push_back(right[x]); } }
+      while (!st.empty()) { uint32_t x = st.back(); st.pop_back(); order.push_back(x); if (M > 1 && x < M - 1) { st.push_back(left[x]); st.push_back(right[x]);
+          } }
       std::reverse(order.begin(), order.end()); }
     auto writeNode = [&](uint32_t idx, const Box& bx, uint32_t fx, uint32_t fy) {
         TbAabbNode nd; nd.center[0] = bx.center.x; nd.center[1] = bx.center.y; nd.center[2] = bx.center.z; nd.flags = fx;
@@ -441,12 +460,14 @@ extern "C" int64_t tbo_build_tlas(const float* objectToWorld, const float* rootB
     auto readBox = [&](uint32_t idx) { Box bx; bx.center = tb3_make(nodes[idx].center[0], nodes[idx].center[1], nodes[idx].center[2]);
                                         bx.halfDim = tb3_make(nodes[idx].halfDim[0], nodes[idx].halfDim[1], nodes[idx].halfDim[2]); return bx; };
     for (uint32_t x : order) {
-        if (x >= M - 1) { const uint32_t k = x - (M - 1); writeNode(x, leaf[keyed[k].second], k | TB_BVH_LEAF_FLAG, 1); count[x] = 1; } /* TopLevelComputeAABBs.hlsl:16-33 */
+        /* TopLevelComputeAABBs.hlsl:16-33 */
+        if (x >= M - 1) { const uint32_t k = x - (M - 1); writeNode(x, leaf[keyed[k].second], k | TB_BVH_LEAF_FLAG, 1); count[x] = 1; }
         else {
             uint32_t l = left[x], r = right[x];
             if (count[l] > count[r]) { uint32_t t = l; l = r; r = t; }
             const Box lb = readBox(l), rb = readBox(r);
-            writeNode(x, AABBtoBox(tb3_min(lb.center - lb.halfDim, rb.center - rb.halfDim), tb3_max(lb.center + lb.halfDim, rb.center + rb.halfDim)), l & TB_BVH_INDEX_MASK, r);
+            writeNode(x, AABBtoBox(tb3_min(lb.center - lb.halfDim, rb.center - rb.halfDim), tb3_max(lb.center + lb.halfDim, rb.center + rb.halfDim)),
+                l & TB_BVH_INDEX_MASK, r);
             count[x] = count[l] + count[r];
         }
     }
@@ -485,7 +506,8 @@ extern "C" int tbo_validate_bvh(const uint8_t* bvh, uint32_t bvhBytes, const flo
     std::vector<Item> st; st.push_back({0, 1});
     uint32_t maxDepth = 0; uint64_t visited = 0;
     std::unordered_multimap<uint64_t, uint32_t> want; /* hash of 9 floats -> input triangle */
-    auto hash9 = [](const float* f) { uint64_t hsh = 1469598103934665603ull; for (int i = 0; i < 9; i++) { uint32_t u; memcpy(&u, f + i, 4); hsh = (hsh ^ u) * 1099511628211ull; } return hsh; };
+    auto hash9 = [](const float* f) { uint64_t hsh = 1469598103934665603ull; for (int i = 0; i < 9; i++) { uint32_t u; memcpy(&u, f + i, 4);
+        hsh = (hsh ^ u) * 1099511628211ull; } return hsh; };
     std::vector<uint8_t> triMatched(N, 0);
     for (uint32_t t = 0; t < N; t++) {
         float f[9];

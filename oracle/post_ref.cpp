@@ -157,7 +157,8 @@ uint32_t LuminanceToHistogramIndex(float luminance, float minLogLuminance, float
 
 } // namespace
 
-extern "C" void tbo_post_process(const TbPostConstants* pc, const float* in, int inIsR32, float* outRgba, uint8_t* outRgba8, float* averagedOut, uint32_t* histogramOut)
+extern "C" void tbo_post_process(const TbPostConstants* pc, const float* in, int inIsR32, float* outRgba, uint8_t* outRgba8, float* averagedOut,
+    uint32_t* histogramOut)
 {
     const uint32_t W = pc->W, H = pc->H;
     const size_t n = (size_t)W * H;

@@ -57,18 +57,25 @@ static void dumpMaterial(FILE* f, const Material::SP& m)
     fprintf(f, "material_type 1 %s\n", materialType(m));
     if (!m) return;
     fprintf(f, "material_ptr 1 %p\n", (void*)m.get());
-    if (auto p = std::dynamic_pointer_cast<MatteMaterial>(m)) { putf(f, "kd", &p->kd.x, 3); putf(f, "sigma", &p->sigma, 1); fprintf(f, "map_kd 1 %d\n", p->map_kd ? 1 : 0); }
-    if (auto p = std::dynamic_pointer_cast<SubstrateMaterial>(m)) { putf(f, "kd", &p->kd.x, 3); putf(f, "ks", &p->ks.x, 3); putf(f, "uroughness", &p->uRoughness, 1); putf(f, "vroughness", &p->vRoughness, 1); }
-    if (auto p = std::dynamic_pointer_cast<PlasticMaterial>(m)) { putf(f, "kd", &p->kd.x, 3); putf(f, "ks", &p->ks.x, 3); putf(f, "roughness", &p->roughness, 1); }
-    if (auto p = std::dynamic_pointer_cast<UberMaterial>(m)) { putf(f, "kd", &p->kd.x, 3); putf(f, "ks", &p->ks.x, 3); putf(f, "kt", &p->kt.x, 3); putf(f, "opacity", &p->opacity.x, 3); putf(f, "index", &p->index, 1); putf(f, "roughness", &p->roughness, 1); putf(f, "uroughness", &p->uRoughness, 1); }
+    if (auto p = std::dynamic_pointer_cast<MatteMaterial>(m)) { putf(f, "kd", &p->kd.x, 3); putf(f, "sigma", &p->sigma, 1);
+        fprintf(f, "map_kd 1 %d\n", p->map_kd ? 1 : 0); }
+    if (auto p = std::dynamic_pointer_cast<SubstrateMaterial>(m)) { putf(f, "kd", &p->kd.x, 3); putf(f, "ks", &p->ks.x, 3);
+        putf(f, "uroughness", &p->uRoughness, 1); putf(f, "vroughness", &p->vRoughness, 1); }
+    if (auto p = std::dynamic_pointer_cast<PlasticMaterial>(m)) { putf(f, "kd", &p->kd.x, 3); putf(f, "ks", &p->ks.x, 3);
+        putf(f, "roughness", &p->roughness, 1); }
+    if (auto p = std::dynamic_pointer_cast<UberMaterial>(m)) { putf(f, "kd", &p->kd.x, 3); putf(f, "ks", &p->ks.x, 3); putf(f, "kt", &p->kt.x, 3);
+        putf(f, "opacity", &p->opacity.x, 3); putf(f, "index", &p->index, 1); putf(f, "roughness", &p->roughness, 1); putf(f, "uroughness", &p->uRoughness, 1);
+        }
     if (auto p = std::dynamic_pointer_cast<MirrorMaterial>(m)) { putf(f, "kr", &p->kr.x, 3); }
-    if (auto p = std::dynamic_pointer_cast<MetalMaterial>(m)) { putf(f, "eta", &p->eta.x, 3); putf(f, "roughness", &p->roughness, 1); putf(f, "uroughness", &p->uRoughness, 1); }
+    if (auto p = std::dynamic_pointer_cast<MetalMaterial>(m)) { putf(f, "eta", &p->eta.x, 3); putf(f, "roughness", &p->roughness, 1);
+        putf(f, "uroughness", &p->uRoughness, 1); }
     if (auto p = std::dynamic_pointer_cast<GlassMaterial>(m)) { putf(f, "index", &p->index, 1); }
 }
 
 int main(int argc, char** argv)
 {
-    if (argc < 3) { fprintf(stderr, "usage: pbrt_dump scene.pbrt out.txt | pbrt_dump --save-pbf scene.pbrt out.pbf | pbrt_dump scene.pbf out.txt\n"); return 2; }
+    if (argc < 3) { fprintf(stderr, "usage: pbrt_dump scene.pbrt out.txt | pbrt_dump --save-pbf scene.pbrt out.pbf | pbrt_dump scene.pbf out.txt\n"); return 2;
+        }
     if (!strcmp(argv[1], "--save-pbf")) { /* the reference parser's own binary writer (pbrt::Scene::saveTo), for the .pbf reader's fixture */
         if (argc < 4) return 2;
         try { Scene::SP s = importPBRT(argv[2]); s->saveTo(argv[3]); }

@@ -43,7 +43,8 @@ void sampleBilinearClamp(const float* t, uint32_t W, uint32_t H, float u, float 
 } // namespace
 
 extern "C" void tbo_temporal(const TbTemporalConstants* C, const float* TemporalHistory, const float* CurrentFrame, const float* WorldPositionTexture,
-                             const float* PreviousFrameWorldPositionTexture, const float* MomentHistory, const float* WorldNormalTexture, float* OutputTexture, float* OutputMoment)
+                             const float* PreviousFrameWorldPositionTexture, const float* MomentHistory, const float* WorldNormalTexture, float* OutputTexture,
+                                 float* OutputMoment)
 {
     const uint32_t W = C->ResolutionX, H = C->ResolutionY;
     for (uint32_t py = 0; py < H; py++) for (uint32_t px = 0; px < W; px++) {
@@ -75,7 +76,8 @@ extern "C" void tbo_temporal(const TbTemporalConstants* C, const float* Temporal
 
         V3 PrevFrameColor = v3(0, 0, 0), PrevMomentData = v3(0, 0, 0);
         float t = -1.0f; /* PlaneIntersection(PrevFrameFocalPoint, PrevFrameRayDirection, PrevFrameCameraPosition, PrevFrameCameraDir) :78-88 */
-        { float denom = dot(PrevFrameCameraDir, PrevFrameRayDirection); if (tb_abs(denom) > 0.0f) t = dot(sub(PrevPos, PrevFrameFocalPoint), PrevFrameCameraDir) / denom; }
+        { float denom = dot(PrevFrameCameraDir, PrevFrameRayDirection);
+            if (tb_abs(denom) > 0.0f) t = dot(sub(PrevPos, PrevFrameFocalPoint), PrevFrameCameraDir) / denom; }
         bool bValidHistory = false;
         if (!C->IgnoreHistory && t >= 0 && bHitValid) {
             V3 LensPosition = add(PrevFrameFocalPoint, mul(PrevFrameRayDirection, t));
@@ -101,7 +103,8 @@ extern "C" void tbo_temporal(const TbTemporalConstants* C, const float* Temporal
                 }
                 bValidHistory = SummedWeight > 0.0f;
                 if (bValidHistory) { PrevFrameColor = divs(PrevFrameColor, SummedWeight); PrevMomentData = divs(PrevMomentData, SummedWeight); }
-                if (C->OutputMomentInformation) { float m[4]; sampleBilinearClamp(MomentHistory, W, H, UVx, UVy, m); PrevMomentData = v3(m[0], m[1], m[2]); } /* :204 */
+                /* :204 */
+                if (C->OutputMomentInformation) { float m[4]; sampleBilinearClamp(MomentHistory, W, H, UVx, UVy, m); PrevMomentData = v3(m[0], m[1], m[2]); }
             }
         }
         float outputAlpha = 1.0f;
@@ -121,7 +124,8 @@ extern "C" void tbo_temporal(const TbTemporalConstants* C, const float* Temporal
     }
 }
 
-extern "C" void tbo_denoise(const TbDenoiserConstants* C, const float* InputTexture, const float* AOVNormals, const float* AOVIntersectPosition, const float* UndenoisedTexture,
+extern "C" void tbo_denoise(const TbDenoiserConstants* C, const float* InputTexture, const float* AOVNormals, const float* AOVIntersectPosition,
+    const float* UndenoisedTexture,
                             float* OutputTexture)
 {
     const uint32_t W = C->ResolutionX, H = C->ResolutionY;
@@ -138,7 +142,8 @@ extern "C" void tbo_denoise(const TbDenoiserConstants* C, const float* InputText
         V3 accumulatedColor = v3(0, 0, 0);
         if (normal.x != 0.0f || normal.y != 0.0f || normal.z != 0.0f) { /* ValidNormal */
             const int mult = (int)C->OffsetMultiplier;
-            for (int xOffset = -KERNEL_WIDTH / 2; xOffset <= KERNEL_WIDTH / 2; xOffset++) for (int yOffset = -KERNEL_WIDTH / 2; yOffset <= KERNEL_WIDTH / 2; yOffset++) {
+            for (int xOffset = -KERNEL_WIDTH / 2; xOffset <= KERNEL_WIDTH / 2; xOffset++) for (int yOffset =
+                -KERNEL_WIDTH / 2; yOffset <= KERNEL_WIDTH / 2; yOffset++) {
                 int ox = xOffset * mult, oy = yOffset * mult;
                 int cx = (int)px + ox, cy = (int)py + oy;
                 if (cx < 0 || cy < 0 || cx >= (int)W || cy >= (int)H) continue;
@@ -149,7 +154,8 @@ extern "C" void tbo_denoise(const TbDenoiserConstants* C, const float* InputText
                 float lumaWeight = tb_exp(-tb_abs(l - luma) / tb_max(C->LumaWeightingMultiplier * centerVarianceSqrt, EPSILON));
                 float normalWeight = tb_pow(tb_max(0.0f, dot(normal, ld(AOVNormals, c))), C->NormalWeightingExponential);
                 float distance = length(sub(ld(AOVIntersectPosition, c), intersectedPosition));
-                float positionWeight = tb_exp(-distance / (C->IntersectionPositionWeightingMultiplier * tb_abs((float)ox * distanceToNeighborPixel + (float)oy * distanceToNeighborPixel) + EPSILON));
+                float positionWeight = tb_exp(-distance / (C->IntersectionPositionWeightingMultiplier * tb_abs((float)ox * distanceToNeighborPixel +
+                    (float)oy * distanceToNeighborPixel) + EPSILON));
                 const float weights[3] = {3.0f / 8.0f, 1.0f / 4.0f, 1.0f / 16.0f};
                 int ax = ox / mult; if (ax < 0) ax = -ax;
                 int ay = oy / mult; if (ay < 0) ay = -ay;
@@ -162,12 +168,14 @@ extern "C" void tbo_denoise(const TbDenoiserConstants* C, const float* InputText
         } else {
             accumulatedVariance = InputTexture[4 * i + 3]; accumulatedColor = ld(InputTexture, i); weightedSum = 1.0f;
         }
-        OutputTexture[4 * i] = accumulatedColor.x / weightedSum; OutputTexture[4 * i + 1] = accumulatedColor.y / weightedSum; OutputTexture[4 * i + 2] = accumulatedColor.z / weightedSum;
+        OutputTexture[4 * i] = accumulatedColor.x / weightedSum; OutputTexture[4 * i + 1] = accumulatedColor.y / weightedSum;
+            OutputTexture[4 * i + 2] = accumulatedColor.z / weightedSum;
         OutputTexture[4 * i + 3] = accumulatedVariance / (weightedSum * weightedSum);
     }
 }
 
-extern "C" void tbo_composite(uint32_t W, uint32_t H, const float* AlbedoTexture, const float* IndirectLightingTexture, const float* EmissiveTexture, float* OutputTexture)
+extern "C" void tbo_composite(uint32_t W, uint32_t H, const float* AlbedoTexture, const float* IndirectLightingTexture, const float* EmissiveTexture,
+    float* OutputTexture)
 {
     for (size_t i = 0; i < (size_t)W * H; i++) {
         V3 albedo = ld(AlbedoTexture, i); float diffuseContribution = AlbedoTexture[4 * i + 3], specularContribution = 1.0f - diffuseContribution;

@@ -197,7 +197,8 @@ static int g_alphaTest = 0;
 bool IsValidHit(const TbSceneView* sc, uint32_t geometryIndex, uint32_t primitiveIndex, float b0, float b1);
 
 /* TraverseFunction.hlsli:537-779 */
-bool TraverseTwoLevel(const TbSceneView* sc, tb3 origin, tb3 direction, float TMin, float TMax, Committed& hit, uint32_t& trianglesTested, uint32_t& boxesTested);
+bool TraverseTwoLevel(const TbSceneView* sc, tb3 origin, tb3 direction, float TMin, float TMax, Committed& hit, uint32_t& trianglesTested,
+    uint32_t& boxesTested);
 bool Traverse(const TbSceneView* sc, tb3 origin, tb3 direction, float TMin, float TMax, Committed& hit,
               uint32_t& trianglesTested, uint32_t& boxesTested)
 {
@@ -276,7 +277,8 @@ inline tb3 MulPoint34(const float* m, tb3 v) /* mul(float3x4, float4(v, 1)): the
 }
 inline tb3 MulVector34(const float* m, tb3 v) /* mul(float3x4, float4(v, 0)) */
 {
-    return tb3_make(tb_fma(m[2], v.z, tb_fma(m[1], v.y, m[0] * v.x)), tb_fma(m[6], v.z, tb_fma(m[5], v.y, m[4] * v.x)), tb_fma(m[10], v.z, tb_fma(m[9], v.y, m[8] * v.x)));
+    return tb3_make(tb_fma(m[2], v.z, tb_fma(m[1], v.y, m[0] * v.x)), tb_fma(m[6], v.z, tb_fma(m[5], v.y, m[4] * v.x)), tb_fma(m[10], v.z, tb_fma(m[9], v.y,
+        m[8] * v.x)));
 }
 
 bool TraverseTwoLevel(const TbSceneView* sc, tb3 origin, tb3 direction, float TMin, float TMax, Committed& hit,
@@ -331,11 +333,13 @@ bool TraverseTwoLevel(const TbSceneView* sc, tb3 origin, tb3 direction, float TM
                     const uint32_t geomContribution = ld32(m), primIdx = ld32(m + 4);
                     trianglesTested++;
                     const uint8_t* p = current + offPrims + 40u * (flagsX & TB_BVH_INDEX_MASK) + 4;
-                    const tb3 v0 = tb3_make(ldf(p), ldf(p + 4), ldf(p + 8)), v1 = tb3_make(ldf(p + 12), ldf(p + 16), ldf(p + 20)), v2 = tb3_make(ldf(p + 24), ldf(p + 28), ldf(p + 32));
+                    const tb3 v0 = tb3_make(ldf(p), ldf(p + 4), ldf(p + 8)), v1 = tb3_make(ldf(p + 12), ldf(p + 16), ldf(p + 20)), v2 = tb3_make(ldf(p + 24),
+                        ldf(p + 28), ldf(p + 32));
                     float t0 = hit.t, b[2] = {0, 0};
                     RayTriangleIntersect(t0, b, objectOrigin, rd, v0, v1, v2); /* ObjectRayOrigin / ObjectRayDirection, :667-668 */
                     bool valid = true; /* the any-hit filter sees CandidateInstanceIndex() + CandidateGeometryIndex(), RayGenCommon.h:427 */
-                    if (g_alphaTest && t0 < hit.t && t0 > TMin && !(ld32(m + 8) & 1u)) valid = IsValidHit(sc, instanceOffset + geomContribution, primIdx, b[0], b[1]);
+                    if (g_alphaTest && t0 < hit.t && t0 > TMin && !(ld32(m + 8) & 1u)) valid = IsValidHit(sc, instanceOffset + geomContribution, primIdx, b[0],
+                        b[1]);
                     if (valid && t0 < hit.t && t0 > TMin) {
                         hit.t = t0; hit.bary[0] = b[0]; hit.bary[1] = b[1];
                         hit.primitiveIndex = primIdx; hit.geometryIndex = instanceOffset + geomContribution;
@@ -350,7 +354,8 @@ bool TraverseTwoLevel(const TbSceneView* sc, tb3 origin, tb3 direction, float TM
                 const bool rh = RayBoxTest(rt, hit.t, rd, to3((const float*)rn), to3((const float*)(rn + 16)));
                 boxesTested += 2;
                 if (top + 2 > ORACLE_STACK) return false;
-                if (lh && rh) { const bool rightFirst = rt < lt; stack[top++] = rightFirst ? l : r; stack[top++] = rightFirst ? r : l; nodesToProcess[processingBottom ? BOTTOM : TOP] += 2; }
+                if (lh && rh) { const bool rightFirst = rt < lt; stack[top++] = rightFirst ? l : r; stack[top++] = rightFirst ? r : l;
+                    nodesToProcess[processingBottom ? BOTTOM : TOP] += 2; }
                 else if (lh || rh) { stack[top++] = rh ? r : l; nodesToProcess[processingBottom ? BOTTOM : TOP] += 1; }
             }
         } while (nodesToProcess[processingBottom ? BOTTOM : TOP] != 0);
@@ -434,7 +439,8 @@ inline F4 SampleBilinearWrap(const TbFloat4* tex, uint32_t w, uint32_t h, float 
     float fx = u * (float)w - 0.5f, fy = v * (float)h - 0.5f;
     float x0f = tb_floor(fx), y0f = tb_floor(fy);
     float tx = fx - x0f, ty = fy - y0f;
-    auto wrap = [](float f, uint32_t n) { float m = f - tb_floor(f / (float)n) * (float)n; int i = (int)m; if (i < 0) i = 0; if (i >= (int)n) i = (int)n - 1; return (uint32_t)i; };
+    auto wrap = [](float f, uint32_t n) { float m = f - tb_floor(f / (float)n) * (float)n; int i = (int)m; if (i < 0) i = 0; if (i >= (int)n) i = (int)n - 1;
+        return (uint32_t)i; };
     uint32_t x0 = wrap(x0f, w), x1 = wrap(x0f + 1.0f, w), y0 = wrap(y0f, h), y1 = wrap(y0f + 1.0f, h);
     const TbFloat4 &a = tex[y0 * w + x0], &b = tex[y0 * w + x1], &c = tex[y1 * w + x0], &d = tex[y1 * w + x1];
     auto bl = [&](float p, float q, float r, float s) { float top = tb_lerp(p, q, tx), bot = tb_lerp(r, s, tx); return tb_lerp(top, bot, ty); };
@@ -523,7 +529,8 @@ inline TbMaterial GetMaterialInternal(Ctx& c, int MaterialID, float u, float v, 
         else return FetchMaterial(c.scene, (uint32_t)mat.albedo.y);
     }
     if (IsValidTexture(mat.albedoIndex)) { F4 t = GetTextureData(c.scene, mat.albedoIndex, u, v); mat.albedo.x = t.x; mat.albedo.y = t.y; mat.albedo.z = t.z; }
-    if (IsValidTexture(mat.emissiveIndex) && !ShouldIgnoreEmissive) { F4 t = GetTextureData(c.scene, mat.emissiveIndex, u, v); mat.emissive.x = t.x; mat.emissive.y = t.y; mat.emissive.z = t.z; }
+    if (IsValidTexture(mat.emissiveIndex) && !ShouldIgnoreEmissive) { F4 t = GetTextureData(c.scene, mat.emissiveIndex, u, v); mat.emissive.x = t.x;
+        mat.emissive.y = t.y; mat.emissive.z = t.z; }
     if (IsValidTexture(mat.specularMapIndex)) {
         F4 t = GetTextureData(c.scene, mat.specularMapIndex, u, v);
         mat.roughness = t.y;
@@ -836,7 +843,9 @@ tb3 Trace(Ctx& c, Ray ray, Ray neighborRay)
         c.rayKind = 'E';
         IntersectWithMaxDistance(c, ray, 999999.0f, resT, resMat, normal, tangent, uvx, uvy); /* :1312 */
 
-        if (accumulatedIndirectLightMultiplier.x < EPSILON && accumulatedIndirectLightMultiplier.y < EPSILON && accumulatedIndirectLightMultiplier.z < EPSILON) break; /* :1319-1326 */
+        /* :1319-1326 */
+        if (accumulatedIndirectLightMultiplier.x < EPSILON && accumulatedIndirectLightMultiplier.y < EPSILON && accumulatedIndirectLightMultiplier.z < EPSILON)
+            break;
 
         if (resMat == INVALID_MATERIAL_ID) { /* :1328-1343 */
             accumulatedColor = accumulatedColor + accumulatedIndirectLightMultiplier * SampleEnvironmentMap(c.scene, ray.direction);
@@ -855,7 +864,8 @@ tb3 Trace(Ctx& c, Ray ray, Ray neighborRay)
             c.aovDistanceToNeighbor += tb3_length(NeighborRayPoint - RayPoint);
             c.aovNormal = detailNormal;
             c.aovDepth = tb_saturate(resT / pf.MaxZ); c.aovDepthWritten = true;
-            if (c.x == pf.SelectedPixelX && c.y == pf.SelectedPixelY) { c.selWritten = true; c.selDistance = resT; c.selMaterial = resMat; } /* IsSelectedPixel :593-596; OutputMaterial(int(result.y)) */
+            /* IsSelectedPixel :593-596; OutputMaterial(int(result.y)) */
+            if (c.x == pf.SelectedPixelX && c.y == pf.SelectedPixelY) { c.selWritten = true; c.selDistance = resT; c.selMaterial = resMat; }
             if (pf.OutputMode == TB_OUTPUT_TYPE_HEATMAP) break;
         }
         bool IsInsidePrimitve = IsBacksideOfGeometry;
@@ -891,7 +901,9 @@ tb3 Trace(Ctx& c, Ray ray, Ray neighborRay)
                     if (!IsLight(sMaterial)) ShadowMultiplier = tb3_splat(0.0f); /* :1474-1511 */
                 }
                 float lightMultiplier = lightAttenuation * DiffuseBRDF(lightDirection, detailNormal) * tb_abs(tb3_dot(lightNormal, lightDirection)) / lightPDF;
-                accumulatedColor = accumulatedColor + accumulatedIndirectLightMultiplier * to3(material.albedo) * lightMultiplier * ShadowMultiplier * lightColor; /* :1514-1515 */
+                /* :1514-1515 */
+                accumulatedColor = accumulatedColor + accumulatedIndirectLightMultiplier * to3(material.albedo) * lightMultiplier * ShadowMultiplier *
+                    lightColor;
             }
         }
 
@@ -937,7 +949,8 @@ tb3 Trace(Ctx& c, Ray ray, Ray neighborRay)
                     RayPoint = GetRayPoint(ray, resT);
                     ray.origin = RayPoint + normal * EPSILON;
                     tb3 ab = to3(material.absorption);
-                    tb3 beerLambert = tb3_make(tb_exp(-distanceTravelledBeforeScatter * ab.x), tb_exp(-distanceTravelledBeforeScatter * ab.y), tb_exp(-distanceTravelledBeforeScatter * ab.z));
+                    tb3 beerLambert = tb3_make(tb_exp(-distanceTravelledBeforeScatter * ab.x), tb_exp(-distanceTravelledBeforeScatter * ab.y),
+                        tb_exp(-distanceTravelledBeforeScatter * ab.z));
                     accumulatedIndirectLightMultiplier = accumulatedIndirectLightMultiplier * beerLambert;
                     if (exittingPrimitive) {
                         RayDirectionDotN = tb3_dot(normal, ray.direction);
@@ -995,7 +1008,8 @@ tb3 Trace(Ctx& c, Ray ray, Ray neighborRay)
             tb3 halfVector = tb3_normalize(-previousDirection + ray.direction);
             float roughnessSquared = tb_max(material.roughness * material.roughness, MIN_ROUGHNESS_SQUARED);
             float specular = GGXNormalDistributionFunction(detailNormal, halfVector, roughnessSquared) /
-                (4.0f * tb_abs(tb3_dot(-previousDirection, halfVector)) * tb_max(tb_abs(tb3_dot(-previousDirection, normal)), tb_abs(tb3_dot(ray.direction, normal))));
+                (4.0f * tb_abs(tb3_dot(-previousDirection, halfVector)) * tb_max(tb_abs(tb3_dot(-previousDirection, normal)), tb_abs(tb3_dot(ray.direction,
+                    normal))));
             accumulatedIndirectLightMultiplier = accumulatedIndirectLightMultiplier * (specular * albedo * tb_saturate(tb3_dot(ray.direction, normal)));
         } else if (AllowsSpecular(material)) { /* :1744-1765 */
             tb3 halfVector = GetHalfVectorSafe(-previousDirection, ray.direction, normal);
@@ -1007,7 +1021,8 @@ tb3 Trace(Ctx& c, Ray ray, Ray neighborRay)
             tb3 diffuse = albedo * diffuseMultiplier;
             float roughnessSquared = tb_max(material.roughness * material.roughness, MIN_ROUGHNESS_SQUARED);
             float specular = GGXNormalDistributionFunction(detailNormal, halfVector, roughnessSquared) /
-                (4.0f * tb_abs(tb3_dot(-previousDirection, halfVector)) * tb_max(tb_abs(tb3_dot(-previousDirection, normal)), tb_abs(tb3_dot(ray.direction, normal))));
+                (4.0f * tb_abs(tb3_dot(-previousDirection, halfVector)) * tb_max(tb_abs(tb3_dot(-previousDirection, normal)), tb_abs(tb3_dot(ray.direction,
+                    normal))));
             tb3 IndirectLightMultiplier = (diffuse + tb3_splat(fresnel * specular)) * tb_saturate(tb3_dot(ray.direction, normal));
             accumulatedIndirectLightMultiplier = accumulatedIndirectLightMultiplier * IndirectLightMultiplier;
         } else { /* :1766-1769 */
@@ -1093,7 +1108,8 @@ void sample_pixel(Ctx& c, float out[4])
     float uvx = 0.0f + dux * 1.0f, uvy = 1.0f + duy * -1.0f;                                         /* :697 */
     float pcx = uvx * (float)c.width, pcy = uvy * (float)c.height;                                    /* :703 */
     BlueNoiseData bn = GetBlueNoise(c); /* kernel.glsl:1830 */
-    CameraRays cr = MakeCameraRays(pf, c.scene->config.CameraLensHeight, c.width, c.height, pcx, pcy, bn.PrimaryJitter[0], bn.PrimaryJitter[1], bn.DOFJitter[0], bn.DOFJitter[1]);
+    CameraRays cr = MakeCameraRays(pf, c.scene->config.CameraLensHeight, c.width, c.height, pcx, pcy, bn.PrimaryJitter[0], bn.PrimaryJitter[1],
+        bn.DOFJitter[0], bn.DOFJitter[1]);
     tb3 color = Trace(c, cr.camera, cr.neighbor);
     if (pf.FireflyClampValue >= EPSILON) color = tb3_min(color, tb3_splat(pf.FireflyClampValue)); /* :1910-1913 */
     out[0] = color.x * cr.filterWeight; out[1] = color.y * cr.filterWeight; out[2] = color.z * cr.filterWeight; out[3] = cr.filterWeight;
@@ -1234,12 +1250,14 @@ void tbo_rand_stream(float seed, float time, uint32_t n, float* out)
 }
 
 /* Known-answer probes of the BSDF sampling pieces (tests/test_oracle_furnace.py): the functions themselves, not restatements */
-float tbo_ggx_pdf(const float* normal, const float* incoming, const float* outgoing, float roughness) /* the pdf the throughput update uses, kernel.glsl:1701-1706 */
+/* the pdf the throughput update uses, kernel.glsl:1701-1706 */
+float tbo_ggx_pdf(const float* normal, const float* incoming, const float* outgoing, float roughness)
 {
     const tb3 n = to3(normal), in = to3(incoming), out = to3(outgoing);
     return ImportanceSampleGGXPDF(n, out, GetHalfVectorSafe(-in, out, n), roughness);
 }
-void tbo_sample_directions(int kind, float seed, float time, const float* incoming, const float* normal, float roughness, uint32_t n, float* outDirs, float* outPdf)
+void tbo_sample_directions(int kind, float seed, float time, const float* incoming, const float* normal, float roughness, uint32_t n, float* outDirs,
+    float* outPdf)
 {
     TbPerFrameConstants pf; memset(&pf, 0, sizeof pf); pf.Time = time;
     Ctx c; memset(&c, 0, sizeof c); c.pf = &pf; c.seed = seed;

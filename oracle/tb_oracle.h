@@ -58,7 +58,8 @@ void tbo_rand_stream(float seed, float time, uint32_t n, float* out);
 /* BSDF sampling pieces for the furnace / pdf known-answer tests: ImportanceSampleGGXPDF with the half vector the throughput update
  * forms (kernel.glsl:1084-1094,1701-1706); kind 0 ImportanceSampleGGX (:1066-1082), 1 the refraction lobe (:1048-1064), 2 cosine (:1025-1046) */
 float tbo_ggx_pdf(const float* normal, const float* incoming, const float* outgoing, float roughness);
-void tbo_sample_directions(int kind, float seed, float time, const float* incoming, const float* normal, float roughness, uint32_t n, float* outDirs, float* outPdf);
+void tbo_sample_directions(int kind, float seed, float time, const float* incoming, const float* normal, float roughness, uint32_t n, float* outDirs,
+    float* outPdf);
 /* StatsBuffer +8 / +12 of the selected pixel after the given frames (RayGenCommon.h:632-648); returns 0 if nothing was written */
 int tbo_selected_pixel(const TbSceneView* scene, const TbPerFrameConstants* constants, uint32_t width, uint32_t height, uint32_t firstFrame, uint32_t numFrames,
                        float* distance, int32_t* materialId);

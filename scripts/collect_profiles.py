@@ -3,7 +3,7 @@
    <tag>_kernel_stats.csv, <tag>_pmc_summary.json, <tag>_mem_counters.json, <tag>_bench.json.    python scripts/collect_profiles.py r4 [tags...]"""
 import os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-rnd = sys.argv[1]; tags = sys.argv[2:] or ["c2", "c3", "c4", "c5", "teapot"]
+rnd = sys.argv[1]; tags = sys.argv[2:] or ["c2", "c3", "c4", "c5", "teapot", "vwvan", "vwvan_2level"]
 dst = os.path.join(ROOT, "profiles", rnd); os.makedirs(dst, exist_ok=True)
 for t in tags:
     for src, name in ((os.path.join("gpurun_out", t, "kernel_stats.csv"), t + "_kernel_stats.csv"), (os.path.join("gpurun_out", t, "pmc_summary.json"), t + "_pmc_summary.json"),

@@ -1,0 +1,4 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp; O=gpurun_out/r5; mkdir -p $O
+python3 -m pytest tests/test_gpu_parity.py tests/test_material_branches.py tests/test_vw_van.py tests/test_split_kernel.py -m gpu -x -q 2>&1 | tail -3
+python3 scripts/ab_rounds.py r4 3 $O/ab_rounds.json > $O/ab_rounds.log 2>&1; tail -6 $O/ab_rounds.log | cut -c1-460

@@ -8,8 +8,9 @@ A step of the N-GPU job takes what its slowest rank takes: t(1) / max_r t(r of N
 max / mean over the ranks is the imbalance SURVEY.md 8e names as the expected limiter (a car in the middle of a sky).
 Where max / mean exceeds 1.05 at N = 8 the same is measured with 32x32 tiles.
 
-    python scripts/rank_imbalance.py [out.json] [--steps K] [--legs vwvan,c4,c5] [--worlds 1,2,4,8]
-bench.py's expected_speedup_leg() reads profiles/rN/rank_imbalance.json.
+    python scripts/rank_imbalance.py [out.json] [--steps K] [--legs vwvan,c4,c5] [--worlds 1,2,4,8] [--spp S]
+bench.py's expected_speedup_leg() reads profiles/rN/rank_imbalance.json (the bench's own 8-spp step) and, beside it,
+profiles/rN/rank_imbalance_32spp.json (--spp 32: a step a quarter of the way to the configurations' own 256 / 1024 spp).
 """
 import argparse
 import json
@@ -28,6 +29,7 @@ ap.add_argument("out", nargs="?", default=None)
 ap.add_argument("--steps", type=int, default=4)
 ap.add_argument("--legs", default="vwvan,c4,c5")
 ap.add_argument("--worlds", default="1,2,4,8")
+ap.add_argument("--spp", type=int, default=None)   # samples per pixel of a step (default: the workload's own, 8 for the 4K legs)
 ap.add_argument("--imbalance-threshold", type=float, default=1.05)
 args = ap.parse_args()
 worlds = [int(x) for x in args.worlds.split(",")]
@@ -91,7 +93,7 @@ def sweep(W, H, SPP, s, tile):
 
 for key in args.legs.split(","):
     w = bench.WORKLOADS[key]
-    W, H, SPP = w["W"], w["H"], w["spp"]
+    W, H, SPP = w["W"], w["H"], args.spp or w["spp"]
     s = b.settings(w["depth"])
     t0 = time.time()
     b.load_workload(key)

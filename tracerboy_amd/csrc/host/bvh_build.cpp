@@ -36,7 +36,8 @@ struct Tree {
     std::vector<uint32_t> left, right; /* children of inner node i (node ids; leaf k = N-1+k) */
 };
 
-inline tb3 P(const HostScene& s, uint32_t tri, int k) { const float* p = &s.positions[3ull * s.triVertexIndex[3ull * tri + k]]; return tb3_make(p[0], p[1], p[2]); }
+inline tb3 P(const HostScene& s, uint32_t tri, int k) { const float* p = &s.positions[3ull * s.triVertexIndex[3ull * tri + k]];
+    return tb3_make(p[0], p[1], p[2]); }
 
 template <class F> void parallelFor(size_t n, F f)
 {
@@ -48,13 +49,15 @@ template <class F> void parallelFor(size_t n, F f)
     for (auto& t : th) t.join();
 }
 
-inline uint32_t expand10(uint32_t v) { v &= 0x3ff; v = (v | (v << 16)) & 0x030000FF; v = (v | (v << 8)) & 0x0300F00F; v = (v | (v << 4)) & 0x030C30C3; v = (v | (v << 2)) & 0x09249249; return v; }
+inline uint32_t expand10(uint32_t v) { v &= 0x3ff; v = (v | (v << 16)) & 0x030000FF; v = (v | (v << 8)) & 0x0300F00F; v = (v | (v << 4)) & 0x030C30C3;
+    v = (v | (v << 2)) & 0x09249249; return v; }
 
 /* 30-bit Morton code of a centroid inside the scene box (CalculateMortonCodesBindings.h:116-149): axis 0 <- y, axis 1 <- x, axis 2 <- z */
 inline uint32_t mortonCode(tb3 c, tb3 smin, tb3 dim)
 {
     tb3 u = (c - smin) / dim;
-    float ax = tb_min(tb_max(u.x * 1024.0f, 0.0f), 1023.0f), ay = tb_min(tb_max(u.y * 1024.0f, 0.0f), 1023.0f), az = tb_min(tb_max(u.z * 1024.0f, 0.0f), 1023.0f);
+    float ax = tb_min(tb_max(u.x * 1024.0f, 0.0f), 1023.0f), ay = tb_min(tb_max(u.y * 1024.0f, 0.0f), 1023.0f), az = tb_min(tb_max(u.z * 1024.0f, 0.0f),
+        1023.0f);
     return expand10((uint32_t)ay) | (expand10((uint32_t)ax) << 1) | (expand10((uint32_t)az) << 2);
 }
 
@@ -152,22 +155,27 @@ void buildSah(const HostScene& s, Tree& t)
                     float ea = tb3_get(ext, ax); if (!(ea > 0.0f)) continue;
                     for (int i = 0; i < B; i++) { bb[i] = emptyB(); bc[i] = 0; }
                     float k0 = tb3_get(cb.mn, ax), k1 = (float)B * (1.0f - 1e-6f) / ea;
-                    for (uint32_t i = p.begin; i < p.end; i++) { int b = (int)((tb3_get(cen[ids[i]], ax) - k0) * k1); b = b < 0 ? 0 : (b >= B ? B - 1 : b); grow(bb[b], tb[ids[i]]); bc[b]++; }
+                    for (uint32_t i = p.begin; i < p.end; i++) { int b = (int)((tb3_get(cen[ids[i]], ax) - k0) * k1); b = b < 0 ? 0 : (b >= B ? B - 1 : b);
+                        grow(bb[b], tb[ids[i]]); bc[b]++; }
                     float ra[B]; Bounds acc = emptyB(); uint32_t rc[B]; uint32_t c = 0;
                     for (int i = B - 1; i > 0; i--) { grow(acc, bb[i]); c += bc[i]; ra[i] = area(acc); rc[i] = c; }
                     acc = emptyB(); c = 0;
-                    for (int i = 0; i < B - 1; i++) { grow(acc, bb[i]); c += bc[i]; if (c == 0 || rc[i + 1] == 0) continue; float cost = area(acc) * (float)c + ra[i + 1] * (float)rc[i + 1]; if (cost < bestCost) { bestCost = cost; bestAxis = ax; bestBin = i; } }
+                    for (int i = 0; i < B - 1; i++) { grow(acc, bb[i]); c += bc[i]; if (c == 0 || rc[i + 1] == 0) continue;
+                        float cost = area(acc) * (float)c + ra[i + 1] * (float)rc[i + 1]; if (cost < bestCost) { bestCost = cost; bestAxis = ax; bestBin = i;
+                        } }
                 }
                 if (bestAxis >= 0) {
                     float ea = tb3_get(ext, bestAxis), k0 = tb3_get(cb.mn, bestAxis), k1 = (float)B * (1.0f - 1e-6f) / ea;
-                    auto it = std::stable_partition(ids.begin() + p.begin, ids.begin() + p.end, [&](uint32_t id) { int b = (int)((tb3_get(cen[id], bestAxis) - k0) * k1); b = b < 0 ? 0 : (b >= B ? B - 1 : b); return b <= bestBin; });
+                    auto it = std::stable_partition(ids.begin() + p.begin, ids.begin() + p.end, [&](uint32_t id) { int b = (int)((tb3_get(cen[id],
+                        bestAxis) - k0) * k1); b = b < 0 ? 0 : (b >= B ? B - 1 : b); return b <= bestBin; });
                     mid = (uint32_t)(it - ids.begin());
                     split = mid > p.begin && mid < p.end;
                 }
             }
             if (!split) { /* median along the widest axis (also the fallback for coincident centroids) */
                 mid = p.begin + count / 2;
-                std::stable_sort(ids.begin() + p.begin, ids.begin() + p.end, [&](uint32_t a, uint32_t b) { return tb3_get(cen[a], axis) < tb3_get(cen[b], axis); });
+                std::stable_sort(ids.begin() + p.begin, ids.begin() + p.end, [&](uint32_t a, uint32_t b) { return tb3_get(cen[a], axis) < tb3_get(cen[b],
+                    axis); });
             }
             /* push right first so the left subtree is emitted first */
             todo.push_back({mid, p.end, me, 1});
@@ -195,9 +203,11 @@ void optimizeByReinsertion(const HostScene& s, Tree& t, int maxPasses, double mi
     std::vector<Bounds> box(M); std::vector<float> sa(M); std::vector<uint32_t> parent(M, NONE); std::vector<uint16_t> height(M, 0);
     auto isLeaf = [&](uint32_t x) { return x >= N - 1; };
     auto unite = [&](const Bounds& a, const Bounds& b) { Bounds u = a; grow(u, b); return u; };
-    for (uint32_t k = 0; k < N; k++) { Bounds b = emptyB(); for (int v = 0; v < 3; v++) grow(b, P(s, t.order[k], v)); b.mn = tb3_min(b.mn, b.mx - tb3_splat(0.001f)); box[N - 1 + k] = b; sa[N - 1 + k] = area(b); }
+    for (uint32_t k = 0; k < N; k++) { Bounds b = emptyB(); for (int v = 0; v < 3; v++) grow(b, P(s, t.order[k], v));
+        b.mn = tb3_min(b.mn, b.mx - tb3_splat(0.001f)); box[N - 1 + k] = b; sa[N - 1 + k] = area(b); }
     for (uint32_t i = 0; i + 1 < N; i++) { parent[t.left[i]] = i; parent[t.right[i]] = i; }
-    auto pull = [&](uint32_t x) { const uint32_t l = t.left[x], r = t.right[x]; box[x] = unite(box[l], box[r]); sa[x] = area(box[x]); height[x] = (uint16_t)(1 + std::max(height[l], height[r])); };
+    auto pull = [&](uint32_t x) { const uint32_t l = t.left[x], r = t.right[x]; box[x] = unite(box[l], box[r]); sa[x] = area(box[x]);
+        height[x] = (uint16_t)(1 + std::max(height[l], height[r])); };
     std::vector<uint32_t> st;
     { /* inner boxes and heights bottom-up */
         std::vector<uint32_t> pre; pre.reserve(M); st.push_back(0);
@@ -234,7 +244,8 @@ void optimizeByReinsertion(const HostScene& s, Tree& t, int maxPasses, double mi
                 if (it.induced + ax >= bestInc) continue;
                 const uint32_t y = it.node;
                 const float direct = area(unite(box[y], bx));
-                if (y != 0 && it.induced + direct < bestInc && it.depth + 1u + std::max<uint32_t>(hx, height[y]) <= depthLimit) { bestInc = it.induced + direct; best = y; }
+                if (y != 0 && it.induced + direct < bestInc && it.depth + 1u + std::max<uint32_t>(hx,
+                    height[y]) <= depthLimit) { bestInc = it.induced + direct; best = y; }
                 if (!isLeaf(y)) {
                     const float below = it.induced + direct - sa[y];
                     if (below + ax < bestInc) {
@@ -279,7 +290,8 @@ struct TreeletPass {
         inner[0] = root; leafNode[0] = left[root]; leafNode[1] = right[root];
         for (uint32_t n = 2; n < 7; n++) { /* open the inner node with the largest box */
             float best = 0.0f; uint32_t at = 0, node = 0;
-            for (uint32_t i = 0; i < n; i++) if (!leaf(leafNode[i])) { const float a = sarea(box[leafNode[i]]); if (a > best) { best = a; at = i; node = leafNode[i]; } }
+            for (uint32_t i = 0; i < n; i++) if (!leaf(leafNode[i])) { const float a = sarea(box[leafNode[i]]); if (a > best) { best = a; at = i;
+                node = leafNode[i]; } }
             inner[n - 1] = node; leafNode[at] = left[node]; leafNode[n] = right[node];
         }
         const float rootArea = sarea(box[root]);
@@ -312,7 +324,8 @@ struct TreeletPass {
     void run(uint32_t minTris, const std::vector<Bounds>& leafBox)
     {
         const uint32_t M = 2 * N - 1;
-        std::vector<uint32_t> pre; pre.reserve(M); { std::vector<uint32_t> st(1, 0u); while (!st.empty()) { const uint32_t x = st.back(); st.pop_back(); pre.push_back(x); if (!leaf(x)) { st.push_back(left[x]); st.push_back(right[x]); } } }
+        std::vector<uint32_t> pre; pre.reserve(M); { std::vector<uint32_t> st(1, 0u); while (!st.empty()) { const uint32_t x = st.back(); st.pop_back();
+            pre.push_back(x); if (!leaf(x)) { st.push_back(left[x]); st.push_back(right[x]); } } }
         std::vector<uint32_t> tris(M, 0); std::vector<uint8_t> done(M, 0); /* done: treelets rebuilt by the group standing here, 0 = nobody came */
         for (size_t w = pre.size(); w-- > 0;) {
             const uint32_t x = pre[w];
@@ -321,7 +334,8 @@ struct TreeletPass {
             box[x] = box[l]; grow(box[x], box[r]); tris[x] = tris[l] + tris[r];
             if (tris[x] < minTris) continue;
             uint32_t fewest = 0xffu; bool everyGroupCame = true, anyBig = false;
-            for (uint32_t c : {l, r}) if (tris[c] >= minTris) { anyBig = true; if (!done[c]) everyGroupCame = false; else fewest = std::min<uint32_t>(fewest, done[c]); }
+            for (uint32_t c : {l, r}) if (tris[c] >= minTris) { anyBig = true; if (!done[c]) everyGroupCame = false;
+                else fewest = std::min<uint32_t>(fewest, done[c]); }
             if (!anyBig) done[x] = 1; else if (everyGroupCame && fewest < 33) done[x] = (uint8_t)(fewest + 1);
             if (done[x]) rebuild(x);
         }
@@ -392,7 +406,8 @@ void BuildBvhSingle(HostScene& s, int builder)
     std::vector<uint32_t> depth((size_t)numNodes, 0);
     { std::vector<uint32_t> st; st.push_back(0); depth[0] = 1; uint32_t maxD = 1;
       while (!st.empty()) { uint32_t x = st.back(); st.pop_back(); walk.push_back(x);
-          if (N > 1 && x < N - 1) { uint32_t l = t.left[x], r = t.right[x]; depth[l] = depth[r] = depth[x] + 1; if (depth[l] > maxD) maxD = depth[l]; st.push_back(l); st.push_back(r); } }
+          if (N > 1 && x < N - 1) { uint32_t l = t.left[x], r = t.right[x]; depth[l] = depth[r] = depth[x] + 1; if (depth[l] > maxD) maxD = depth[l];
+              st.push_back(l); st.push_back(r); } }
       s.bvhMaxDepth = maxD; }
     std::vector<uint32_t> count((size_t)numNodes, 0);
     auto center = [&](uint32_t i) { return tb3_make(nodes[i].center[0], nodes[i].center[1], nodes[i].center[2]); };
@@ -492,7 +507,8 @@ void BuildTlas(HostScene& s, const std::vector<Bounds>& blasRoot, std::vector<Tb
     std::vector<uint32_t> depth((size_t)numNodes, 0), count((size_t)numNodes, 0);
     { std::vector<uint32_t> st; st.push_back(0); depth[0] = 1; uint32_t maxD = 1;
       while (!st.empty()) { uint32_t x = st.back(); st.pop_back(); walk.push_back(x);
-          if (M > 1 && x < M - 1) { uint32_t l = t.left[x], r = t.right[x]; depth[l] = depth[r] = depth[x] + 1; if (depth[l] > maxD) maxD = depth[l]; st.push_back(l); st.push_back(r); } }
+          if (M > 1 && x < M - 1) { uint32_t l = t.left[x], r = t.right[x]; depth[l] = depth[r] = depth[x] + 1; if (depth[l] > maxD) maxD = depth[l];
+              st.push_back(l); st.push_back(r); } }
       depthOut = maxD; }
     auto center = [&](uint32_t i) { return tb3_make(nodes[i].center[0], nodes[i].center[1], nodes[i].center[2]); };
     auto half = [&](uint32_t i) { return tb3_make(nodes[i].halfDim[0], nodes[i].halfDim[1], nodes[i].halfDim[2]); };
@@ -580,7 +596,9 @@ void BuildBvhWith(HostScene& s, const std::function<void(HostScene&)>& single, c
     std::vector<TbNodeB> top; uint32_t tlasDepth = 0; float rc[3], rh[3];
     if (tlas) {
         std::vector<float> boxes(6 * blasRoot.size());
-        for (size_t b = 0; b < blasRoot.size(); b++) { boxes[6 * b] = blasRoot[b].mn.x; boxes[6 * b + 1] = blasRoot[b].mn.y; boxes[6 * b + 2] = blasRoot[b].mn.z; boxes[6 * b + 3] = blasRoot[b].mx.x; boxes[6 * b + 4] = blasRoot[b].mx.y; boxes[6 * b + 5] = blasRoot[b].mx.z; }
+        for (size_t b = 0; b < blasRoot.size(); b++) { boxes[6 * b] = blasRoot[b].mn.x; boxes[6 * b + 1] = blasRoot[b].mn.y;
+            boxes[6 * b + 2] = blasRoot[b].mn.z; boxes[6 * b + 3] = blasRoot[b].mx.x; boxes[6 * b + 4] = blasRoot[b].mx.y; boxes[6 * b + 5] = blasRoot[b].mx.z;
+            }
         tlas(s, boxes, top, s.rootRefB, tlasDepth);
     } else BuildTlas(s, blasRoot, top, s.rootRefB, tlasDepth, rc, rh);
     for (uint32_t i = 0; i < tlasNodes; i++) allNodes[i] = top[i];

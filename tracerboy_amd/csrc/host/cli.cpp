@@ -113,7 +113,8 @@ static int spawnRanks(int argc, char** argv, int world)
 
 int main(int argc, char** argv)
 {
-    if (argc < 2) { fprintf(stderr, "usage: tracerboy-hip scene.pbrt [--width W --height H --spp N --depth D --seed-time T --device I --builder lbvh|sah|lbvh-gpu|treelets|treelets-gpu --blue-noise 0|1 --tonemap 0..7 --exposure E|auto --out f.png|f.pfm|f.exr]\n"); return 2; }
+    if (argc < 2) { fprintf(stderr,
+        "usage: tracerboy-hip scene.pbrt [--width W --height H --spp N --depth D --seed-time T --device I --builder lbvh|sah|lbvh-gpu|treelets|treelets-gpu --blue-noise 0|1 --tonemap 0..7 --exposure E|auto --out f.png|f.pfm|f.exr]\n"); return 2; }
     std::string scene = argv[1], out = "frame.png";
     tb_post_settings post; tb_default_post_settings(&post);
     uint32_t W = 0, H = 0, spp = 64; int depth = -1, device = 0, builder = 0, blue = -1, ranks = 1; float t = 0.0f;
@@ -121,9 +122,12 @@ int main(int argc, char** argv)
         std::string k = argv[i]; const char* v = argv[i + 1];
         if (k == "--width") W = (uint32_t)atoi(v); else if (k == "--height") H = (uint32_t)atoi(v); else if (k == "--spp") spp = (uint32_t)atoi(v);
         else if (k == "--depth") depth = atoi(v); else if (k == "--seed-time") t = (float)atof(v); else if (k == "--device") device = atoi(v);
-        else if (k == "--builder") builder = !strcmp(v, "sah") ? 1 : !strcmp(v, "lbvh-gpu") ? 2 : !strcmp(v, "treelets") ? 3 : !strcmp(v, "treelets-gpu") ? 4 : 0; /* tb_set_option "bvh_builder" */ else if (k == "--blue-noise") blue = atoi(v); else if (k == "--out") out = v; else if (k == "--ranks") ranks = atoi(v);
+        else if (k == "--builder") builder = !strcmp(v, "sah") ? 1 : !strcmp(v, "lbvh-gpu") ? 2 : !strcmp(v, "treelets") ? 3 : !strcmp(v,
+            "treelets-gpu") ? 4 : 0; /* tb_set_option "bvh_builder" */ else if (k == "--blue-noise") blue = atoi(v); else if (k == "--out") out = v;
+            else if (k == "--ranks") ranks = atoi(v);
         else if (k == "--tonemap") post.TonemapType = (uint32_t)atoi(v);
-        else if (k == "--exposure") { if (!strcmp(v, "auto")) post.EnableAutoExposure = 1; else { post.EnableAutoExposure = 0; post.ExposureMultiplier = (float)atof(v); } }
+        else if (k == "--exposure") { if (!strcmp(v, "auto")) post.EnableAutoExposure = 1; else { post.EnableAutoExposure = 0;
+            post.ExposureMultiplier = (float)atof(v); } }
         else { fprintf(stderr, "unknown option %s\n", k.c_str()); return 2; }
     }
     /* multi-GPU: the parent only starts the ranks; a rank knows itself from the environment */
@@ -133,7 +137,8 @@ int main(int argc, char** argv)
     if (ranks > 1 && !envRank) return spawnRanks(argc, argv, ranks);
     if (envRank && (!getenv("TB_CLI_WORLD") || atoi(getenv("TB_CLI_WORLD")) < 1 || atoi(envRank) < 0 || atoi(envRank) >= atoi(getenv("TB_CLI_WORLD")) ||
                     (atoi(getenv("TB_CLI_WORLD")) > 1 && !getenv("TB_CLI_ID_FILE")))) {
-        fprintf(stderr, "tracerboy-hip: TB_CLI_RANK needs TB_CLI_WORLD (rank < world) and, for more than one rank, TB_CLI_ID_FILE -- these are set by --ranks, not by hand\n"); return 2;
+        fprintf(stderr,
+            "tracerboy-hip: TB_CLI_RANK needs TB_CLI_WORLD (rank < world) and, for more than one rank, TB_CLI_ID_FILE -- these are set by --ranks, not by hand\n"); return 2;
     }
     const int rank = envRank ? atoi(envRank) : 0, world = envRank ? atoi(getenv("TB_CLI_WORLD")) : 1;
     if (world > 1) device = rank; /* one process per GPU */
@@ -158,8 +163,10 @@ int main(int argc, char** argv)
     if (world > 1 || forceRccl) {
         /* ---- the gather: packed tiles of every rank -> rank 0's accumulation surface ---- */
         Rccl nccl; if (!nccl.load()) { tb_destroy(ctx); return 1; }
-#define NCCL_TRY(x) do { int e_ = (x); if (e_) { fprintf(stderr, "tracerboy-hip: rank %d: %s: %s\n", rank, #x, nccl.GetErrorString(e_)); tb_destroy(ctx); return 1; } } while (0)
-#define HIP_OK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "tracerboy-hip: rank %d: %s: %s\n", rank, #x, hipGetErrorString(e_)); tb_destroy(ctx); return 1; } } while (0)
+#define NCCL_TRY(x) do { int e_ = (x); if (e_) { fprintf(stderr, "tracerboy-hip: rank %d: %s: %s\n", rank, #x, nccl.GetErrorString(e_)); tb_destroy(ctx); \
+    return 1; } } while (0)
+#define HIP_OK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "tracerboy-hip: rank %d: %s: %s\n", rank, #x, hipGetErrorString(e_)); \
+    tb_destroy(ctx); return 1; } } while (0)
         RcclId id; memset(&id, 0, sizeof id);
         const char* idFile = getenv("TB_CLI_ID_FILE");
         if (rank == 0) {
@@ -167,7 +174,8 @@ int main(int argc, char** argv)
             if (world > 1) { /* publish atomically: write beside, rename */
                 if (!idFile) { fprintf(stderr, "tracerboy-hip: TB_CLI_ID_FILE is not set\n"); return 1; }
                 const std::string tmp = std::string(idFile) + ".tmp";
-                const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW | O_CLOEXEC, 0600); /* never through a link, never over an existing file */
+                /* never through a link, never over an existing file */
+                const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW | O_CLOEXEC, 0600);
                 if (fd < 0 || write(fd, &id, sizeof id) != (ssize_t)sizeof id) { perror("tracerboy-hip: unique id file"); if (fd >= 0) close(fd); return 1; }
                 close(fd); if (rename(tmp.c_str(), idFile)) { perror("tracerboy-hip: rename"); return 1; }
             }
@@ -198,13 +206,15 @@ int main(int argc, char** argv)
             HIP_OK(hipMemcpyAsync(gathered, packed, capacity * 16, hipMemcpyDeviceToDevice, stream));
             void *surface = nullptr, *jit = nullptr;
             if ((rc = tb_accum_device_ptr(ctx, &surface, &jit))) return fail(ctx, "tb_accum_device_ptr", rc);
-            if ((rc = tb_unpack_gathered_device(ctx, stream, gathered, capacity, W, H, (uint32_t)world, TILE, TILE, surface))) return fail(ctx, "tb_unpack_gathered_device", rc);
+            if ((rc = tb_unpack_gathered_device(ctx, stream, gathered, capacity, W, H, (uint32_t)world, TILE, TILE, surface))) return fail(ctx,
+                "tb_unpack_gathered_device", rc);
         }
         if ((rc = tb_sync(ctx))) return fail(ctx, "tb_sync", rc);
         NCCL_TRY(nccl.CommDestroy(comm));
         (void)hipFree(packed); if (gathered) (void)hipFree(gathered);
         if (rank != 0) { tb_destroy(ctx); return 0; } /* the picture is rank 0's to write */
-        ms = (float)(std::chrono::duration<double>(std::chrono::steady_clock::now() - r0).count() * 1e3); /* render + gather + un-permute, rank 0's wall clock */
+        /* render + gather + un-permute, rank 0's wall clock */
+        ms = (float)(std::chrono::duration<double>(std::chrono::steady_clock::now() - r0).count() * 1e3);
 #undef NCCL_TRY
 #undef HIP_OK
     }
@@ -216,11 +226,13 @@ int main(int argc, char** argv)
     } else {
         std::vector<float> acc((size_t)W * H * 4);
         if ((rc = tb_read_accum(ctx, acc.data(), nullptr))) return fail(ctx, "tb_read_accum", rc);
-        for (size_t i = 0; i < (size_t)W * H; i++) { float w = acc[4 * i + 3], inv = w > 0 ? 1.0f / w : 0.0f; acc[4 * i] *= inv; acc[4 * i + 1] *= inv; acc[4 * i + 2] *= inv; acc[4 * i + 3] = w > 0 ? 1.0f : 0.0f; }
+        for (size_t i = 0; i < (size_t)W * H; i++) { float w = acc[4 * i + 3], inv = w > 0 ? 1.0f / w : 0.0f; acc[4 * i] *= inv; acc[4 * i + 1] *= inv;
+            acc[4 * i + 2] *= inv; acc[4 * i + 3] = w > 0 ? 1.0f : 0.0f; }
         if ((rc = tb_write_image_f32(out.c_str(), W, H, acc.data()))) return fail(ctx, "tb_write_image_f32 (use .png, .pfm or .exr)", rc);
     }
     printf("%s: %u triangles, %ux%u x %u spp, depth %d, %d GPU%s: %.2f ms (%.1f Msamples/s), scene load + BVH %.2f s -> %s\n",
-           scene.c_str(), info.numTriangles, W, H, spp, s.MaxBounces, world, world > 1 ? "s (tiles gathered over RCCL)" : "", ms, (double)W * H * spp / (ms * 1e3), loadS, out.c_str());
+           scene.c_str(), info.numTriangles, W, H, spp, s.MaxBounces, world, world > 1 ? "s (tiles gathered over RCCL)" : "", ms,
+               (double)W * H * spp / (ms * 1e3), loadS, out.c_str());
     tb_destroy(ctx);
     return 0;
 }

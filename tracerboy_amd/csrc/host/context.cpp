@@ -18,8 +18,10 @@ const Variant kVariants[] = {
     {0u, pt_launch_persistent_matte, "matte", pt_launch_persistent_matte5, TB_MATTE_WAVES, 0, wf_launch_matte, true, pt_launch_split_matte},
         {PT_FEAT_ENV, pt_launch_persistent_env, "env", pt_launch_persistent_env5, TB_ENV_WAVES, 1, wf_launch_env, true, pt_launch_split_env},
     {PT_FEAT_ENV | PT_FEAT_SPECULAR | PT_FEAT_TEXTURES, pt_launch_persistent_surf, "surf", nullptr, 0, 2, wf_launch_surf, true, pt_launch_split_surf},
-        {PT_FEAT_ENV | PT_FEAT_SPECULAR | PT_FEAT_TEXTURES | PT_FEAT_SSS, pt_launch_persistent_sss, "sss", pt_launch_persistent_sss4, TB_SSS_WAVES, 5, wf_launch_sss, false, pt_launch_split_sss},
-    {PT_FEAT_ENV | PT_FEAT_SPECULAR | PT_FEAT_TEXTURES | PT_FEAT_SSS | PT_FEAT_MIX, pt_launch_persistent_vol, "vol", pt_launch_persistent_vol4, TB_VOL_WAVES, 3, wf_launch_vol, false, nullptr},
+        {PT_FEAT_ENV | PT_FEAT_SPECULAR | PT_FEAT_TEXTURES | PT_FEAT_SSS, pt_launch_persistent_sss, "sss", pt_launch_persistent_sss4, TB_SSS_WAVES, 5,
+            wf_launch_sss, false, pt_launch_split_sss},
+    {PT_FEAT_ENV | PT_FEAT_SPECULAR | PT_FEAT_TEXTURES | PT_FEAT_SSS | PT_FEAT_MIX, pt_launch_persistent_vol, "vol", pt_launch_persistent_vol4, TB_VOL_WAVES,
+        3, wf_launch_vol, false, nullptr},
         {PT_FEAT_ALL, pt_launch_persistent_full, "full", nullptr, 0, 4, nullptr, false, nullptr},
 };
 const int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
@@ -45,7 +47,8 @@ int tb_create(tb_context** out, int device_id)
     *out = nullptr;
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
-    if (e != hipSuccess || n <= 0) return fail(nullptr, TB_E_NO_DEVICE, std::string("no HIP device available: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count is 0") + " (libtracerboy_hip has no CPU fallback)");
+    if (e != hipSuccess || n <= 0) return fail(nullptr, TB_E_NO_DEVICE,
+        std::string("no HIP device available: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count is 0") + " (libtracerboy_hip has no CPU fallback)");
     if (device_id < 0 || device_id >= n) return fail(nullptr, TB_E_INVALID, "tb_create: device id out of range");
     tb_context* c = new tb_context();
     c->device = device_id;
@@ -74,13 +77,16 @@ int tb_create_multi(tb_context** out, const int* device_ids, int n_devices)
     for (int i = 1; i < n_devices; i++) {
         tb_context* p = nullptr;
         rc = tb_create(&p, device_ids[i]);
-        if (rc == TB_OK && hipEventCreateWithFlags(&p->evGroup, hipEventDisableTiming) != hipSuccess) { g_createError = "tb_create_multi: hipEventCreate failed"; rc = TB_E_DEVICE; }
+        if (rc == TB_OK && hipEventCreateWithFlags(&p->evGroup,
+            hipEventDisableTiming) != hipSuccess) { g_createError = "tb_create_multi: hipEventCreate failed"; rc = TB_E_DEVICE; }
         if (rc != TB_OK) { if (p) tb_destroy(p); tb_destroy(owner); return rc; }
         p->groupOwner = owner; owner->peers.push_back(p);
         if (device_ids[i] != device_ids[0]) { /* direct peer copies over xGMI where the devices allow it; the copy works (staged) without */
             int can = 0;
-            if (hipDeviceCanAccessPeer(&can, device_ids[0], device_ids[i]) == hipSuccess && can) { (void)hipSetDevice(device_ids[0]); (void)hipDeviceEnablePeerAccess(device_ids[i], 0); (void)hipGetLastError(); }
-            if (hipDeviceCanAccessPeer(&can, device_ids[i], device_ids[0]) == hipSuccess && can) { (void)hipSetDevice(device_ids[i]); (void)hipDeviceEnablePeerAccess(device_ids[0], 0); (void)hipGetLastError(); }
+            if (hipDeviceCanAccessPeer(&can, device_ids[0], device_ids[i]) == hipSuccess && can) { (void)hipSetDevice(device_ids[0]);
+                (void)hipDeviceEnablePeerAccess(device_ids[i], 0); (void)hipGetLastError(); }
+            if (hipDeviceCanAccessPeer(&can, device_ids[i], device_ids[0]) == hipSuccess && can) { (void)hipSetDevice(device_ids[i]);
+                (void)hipDeviceEnablePeerAccess(device_ids[0], 0); (void)hipGetLastError(); }
         }
     }
     (void)hipSetDevice(device_ids[0]);
@@ -105,7 +111,9 @@ void tb_destroy(tb_context* c)
     c->output.release(); c->jittered.release(); c->stats.release(); c->rayStats.release(); c->packed.release();
     for (int q = 0; q < 2; q++) for (DevBuf& b : c->wfCols[q]) b.release();
     for (DevBuf& b : c->wfShadowCols) b.release();
-    c->wfHitA.release(); c->wfHitG.release(); c->wfSamples.release(); c->wfCounts.release(); c->workCounter.release(); c->fgSamples[0].release(); c->fgSamples[1].release(); c->fgHits[0].release(); c->fgHits[1].release(); c->fgSlotLog[0].release(); c->fgSlotLog[1].release(); c->stackOverflow.release();
+    c->wfHitA.release(); c->wfHitG.release(); c->wfSamples.release(); c->wfCounts.release(); c->workCounter.release(); c->fgSamples[0].release();
+        c->fgSamples[1].release(); c->fgHits[0].release(); c->fgHits[1].release(); c->fgSlotLog[0].release(); c->fgSlotLog[1].release();
+        c->stackOverflow.release();
     c->postOut.release(); c->postRgba8.release(); c->postHistogram.release(); c->postAverage.release();
     for (int i = 0; i < 2; i++) { c->rtIndirect[i].release(); c->rtMoment[i].release(); c->rtFinal[i].release(); c->rtDenoise[i].release(); }
     c->rtComposited.release();
@@ -144,7 +152,8 @@ static int shareSceneWithPeers(tb_context* c)
     }
     return TB_OK;
 }
-#define TB_REFUSE_PEER(c) do { if ((c) && (c)->groupOwner) return fail((c), TB_E_INVALID, "this context is a member of a multi-device group: call the group's context"); } while (0)
+#define TB_REFUSE_PEER(c) do { if ((c) && (c)->groupOwner) return fail((c), TB_E_INVALID, \
+    "this context is a member of a multi-device group: call the group's context"); } while (0)
 
 int tb_load_scene(tb_context* c, const char* path)
 {
@@ -188,7 +197,8 @@ int tb_scene_info_get(tb_context* c, tb_scene_info* o)
 
 void tb_default_output_settings(tb_output_settings* o) { if (o) DefaultOutputSettings(*o); }
 
-int tb_get_camera(tb_context* c, tb_camera* o) { if (!c || !o) return TB_E_INVALID; if (!c->hasScene) return fail(c, TB_E_NO_SCENE, "no scene loaded"); *o = c->camera; return TB_OK; }
+int tb_get_camera(tb_context* c, tb_camera* o) { if (!c || !o) return TB_E_INVALID; if (!c->hasScene) return fail(c, TB_E_NO_SCENE, "no scene loaded");
+    *o = c->camera; return TB_OK; }
 int tb_set_camera(tb_context* c, const tb_camera* cam)
 {
     if (!c || !cam) return TB_E_INVALID;
@@ -211,7 +221,8 @@ int tb_set_material(tb_context* c, int id, const TbMaterial* in)
         if (!in || !c->hasScene || id < 0 || id >= (int)c->scene.materials.size()) return fail(c, TB_E_INVALID, "material id out of range");
         c->scene.materials[(size_t)id] = *in;
         HIP_TRY(hipMemcpy((void*)&c->ds.materials[id].m, in, sizeof *in, hipMemcpyHostToDevice));
-        if (c->sceneInLds) HIP_TRY(hipMemcpy((void*)(c->ds.ldsBlob + c->ds.offMaterials + sizeof(TbDevMaterial) * (size_t)id), in, sizeof *in, hipMemcpyHostToDevice));
+        if (c->sceneInLds) HIP_TRY(hipMemcpy((void*)(c->ds.ldsBlob + c->ds.offMaterials + sizeof(TbDevMaterial) * (size_t)id), in, sizeof *in,
+            hipMemcpyHostToDevice));
         c->sceneFeatures = sceneFeatureMask(c->scene);
         c->samplesRendered = 0;
         for (tb_context* p : c->peers) { const int rc = tb_set_material(p, id, in); if (rc != TB_OK) return rc; }
@@ -227,14 +238,17 @@ static int renderGroup(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const 
     const uint32_t world = 1u + (uint32_t)c->peers.size();
     if (c->options.count("aov") && c->options["aov"]) return fail(c, TB_E_UNSUPPORTED, "tb_render: AOV targets are not gathered across the devices of a group");
     std::vector<tb_context*> all; all.push_back(c); for (tb_context* p : c->peers) all.push_back(p);
-    for (uint32_t i = 0; i < world; i++) if (all[i]->tiles.world != world || all[i]->tiles.rank != i) { all[i]->tiles = TbTileMap{i, world, 64, 64}; all[i]->samplesRendered = 0; }
+    for (uint32_t i = 0; i < world; i++) if (all[i]->tiles.world != world || all[i]->tiles.rank != i) { all[i]->tiles = TbTileMap{i, world, 64, 64};
+        all[i]->samplesRendered = 0; }
     for (uint32_t i = world; i-- > 0;) { /* the peers first: their launches are in flight while the owner's are enqueued */
         tb_context* x = all[i];
-        const int rc = guarded(x, [&]() { x->options = c->options; x->selX = c->selX; x->selY = c->selY; x->lastRenderRealtime = false; return renderImpl(x, W, H, n, s, t, false); });
+        const int rc = guarded(x, [&]() { x->options = c->options; x->selX = c->selX; x->selY = c->selY; x->lastRenderRealtime = false; return renderImpl(x, W,
+            H, n, s, t, false); });
         if (rc != TB_OK) return x == c ? rc : fail(c, rc, "peer device " + std::to_string(x->device) + ": " + x->err);
     }
     if (n == 0) return TB_OK;
-    const uint64_t tilesTotal = (uint64_t)((W + 63) / 64) * ((H + 63) / 64), capacity = ((tilesTotal + world - 1) / world) * 64 * 64; /* pixels per device, padded to the largest owner */
+    /* pixels per device, padded to the largest owner */
+    const uint64_t tilesTotal = (uint64_t)((W + 63) / 64) * ((H + 63) / 64), capacity = ((tilesTotal + world - 1) / world) * 64 * 64;
     const size_t bytes = (size_t)capacity * sizeof(TbFloat4);
     return guarded(c, [&]() {
         for (int k = 0; k < 2; k++) ensure(c->groupGathered[k], bytes * world);
@@ -281,7 +295,8 @@ int tb_render_async(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_
 }
 int tb_sync(tb_context* c)
 {
-    if (c) for (tb_context* p : c->peers) { const int rc = tb_sync(p); if (rc != TB_OK) return fail(c, rc, "peer device " + std::to_string(p->device) + ": " + p->err); }
+    if (c) for (tb_context* p : c->peers) { const int rc = tb_sync(p);
+        if (rc != TB_OK) return fail(c, rc, "peer device " + std::to_string(p->device) + ": " + p->err); }
     return guarded(c, [&]() {
         HIP_TRY(hipStreamSynchronize(c->stream)); (void)hipEventElapsedTime(&c->lastMs, c->ev0, c->ev1);
         if (hipEventElapsedTime(&c->lastKernelMs, c->evKernelStart, c->evKernel) != hipSuccess) c->lastKernelMs = c->lastMs;
@@ -306,7 +321,8 @@ int tb_read_accum(tb_context* c, float* rgba, float* jit)
 int tb_read_aov(tb_context* c, int which, void* dst)
 {
     return guarded(c, [&]() {
-        if (which < 2 || which > 7 || !dst || !c->aov[which].p) return fail(c, TB_E_INVALID, "tb_read_aov: AOV not available (set option \"aov\" before rendering)");
+        if (which < 2 || which > 7 || !dst || !c->aov[which].p) return fail(c, TB_E_INVALID,
+            "tb_read_aov: AOV not available (set option \"aov\" before rendering)");
         HIP_TRY(hipStreamSynchronize(c->stream));
         HIP_TRY(hipMemcpy(dst, c->aov[which].p, c->aov[which].bytes, hipMemcpyDeviceToHost));
         return TB_OK;
@@ -326,7 +342,8 @@ int tb_accum_device_ptr(tb_context* c, void** o, void** j)
 void tb_default_denoiser_settings(tb_denoiser_settings* o) /* TracerBoy.h:338-344 */
 {
     if (!o) return;
-    o->Enabled = 1; o->IntersectPositionWeightingMultiplier = 1.0f; o->NormalWeightingExponential = 128.0f; o->LuminanceWeightingMultiplier = 4.0f; o->WaveletIterations = 5;
+    o->Enabled = 1; o->IntersectPositionWeightingMultiplier = 1.0f; o->NormalWeightingExponential = 128.0f; o->LuminanceWeightingMultiplier = 4.0f;
+        o->WaveletIterations = 5;
 }
 
 /* One frame of RenderMode::RealTime: path trace 1 spp (IsRealTime: per-frame output, demodulated albedo, AOVs), then
@@ -343,7 +360,8 @@ int tb_render_realtime(tb_context* c, uint32_t W, uint32_t H, const tb_output_se
         c->options["aov"] = 1;
         const size_t bytes = (size_t)W * H * sizeof(TbFloat4);
         if (c->rtWidth != W || c->rtHeight != H) {
-            for (DevBuf* b : {&c->rtIndirect[0], &c->rtIndirect[1], &c->rtMoment[0], &c->rtMoment[1], &c->rtFinal[0], &c->rtFinal[1], &c->rtDenoise[0], &c->rtDenoise[1], &c->rtComposited}) {
+            for (DevBuf* b : {&c->rtIndirect[0], &c->rtIndirect[1], &c->rtMoment[0], &c->rtMoment[1], &c->rtFinal[0], &c->rtFinal[1], &c->rtDenoise[0],
+                &c->rtDenoise[1], &c->rtComposited}) {
                 ensure(*b, bytes); HIP_TRY(hipMemsetAsync(b->p, 0, bytes, c->stream));
             }
             c->rtWidth = W; c->rtHeight = H; c->rtActive = 0; c->prevCamera = c->camera;
@@ -352,18 +370,22 @@ int tb_render_realtime(tb_context* c, uint32_t W, uint32_t H, const tb_output_se
         c->options["aov"] = savedAov;
         if (rc != TB_OK) return rc;
         const uint32_t cur = c->rtActive, prev = cur ^ 1u;
-        const TbFloat4* wpCur = (const TbFloat4*)c->aov[TB_AOV_WORLD_POSITION0 + cur].p;   /* AOVWorldPosition0SRV + GetPathTracerOutputIndex(), TracerBoy.cpp:3614-3622 */
+        /* AOVWorldPosition0SRV + GetPathTracerOutputIndex(), TracerBoy.cpp:3614-3622 */
+        const TbFloat4* wpCur = (const TbFloat4*)c->aov[TB_AOV_WORLD_POSITION0 + cur].p;
         const TbFloat4* wpPrev = (const TbFloat4*)c->aov[TB_AOV_WORLD_POSITION0 + prev].p;
         const TbFloat4* normals = (const TbFloat4*)c->aov[TB_AOV_NORMALS].p;
         auto temporal = [&](const TbFloat4* current, DevBuf* outBuf, DevBuf* histBuf, DevBuf* momentOut, DevBuf* momentHist) {
             TbTemporalConstants k; memset(&k, 0, sizeof k); /* TemporalAccumulationPass.cpp:95-110 */
             k.ResolutionX = W; k.ResolutionY = H; k.OutputMomentInformation = momentOut ? 1u : 0u;
-            k.IgnoreHistory = c->samplesRendered == 0 ? 1u : 0u; /* evaluated after m_SamplesRendered++ (TracerBoy.cpp:2930,3083), i.e. never set while rendering */
+            /* evaluated after m_SamplesRendered++ (TracerBoy.cpp:2930,3083), i.e. never set while rendering */
+            k.IgnoreHistory = c->samplesRendered == 0 ? 1u : 0u;
             k.HistoryWeight = 0.95f; k.CameraLensHeight = c->camera.LensHeight; k.CameraFocalDistance = c->camera.FocalDistance;
-            memcpy(k.CameraPosition, c->camera.Position, 12); memcpy(k.CameraLookAt, c->camera.LookAt, 12); memcpy(k.CameraRight, c->camera.Right, 12); memcpy(k.CameraUp, c->camera.Up, 12);
+            memcpy(k.CameraPosition, c->camera.Position, 12); memcpy(k.CameraLookAt, c->camera.LookAt, 12); memcpy(k.CameraRight, c->camera.Right, 12);
+                memcpy(k.CameraUp, c->camera.Up, 12);
             memcpy(k.PrevFrameCameraPosition, c->prevCamera.Position, 12); memcpy(k.PrevFrameCameraLookAt, c->prevCamera.LookAt, 12);
             memcpy(k.PrevFrameCameraRight, c->prevCamera.Right, 12); memcpy(k.PrevFrameCameraUp, c->prevCamera.Up, 12);
-            HIP_TRY(rt_launch_temporal(c->stream, &k, (const TbFloat4*)histBuf->p, current, wpCur, wpPrev, momentHist ? (const TbFloat4*)momentHist->p : nullptr, normals,
+            HIP_TRY(rt_launch_temporal(c->stream, &k, (const TbFloat4*)histBuf->p, current, wpCur, wpPrev,
+                momentHist ? (const TbFloat4*)momentHist->p : nullptr, normals,
                                        (TbFloat4*)outBuf->p, momentOut ? (TbFloat4*)momentOut->p : nullptr));
         };
         temporal((const TbFloat4*)c->output.p, &c->rtIndirect[cur], &c->rtIndirect[prev], &c->rtMoment[cur], &c->rtMoment[prev]);
@@ -374,7 +396,8 @@ int tb_render_realtime(tb_context* c, uint32_t W, uint32_t H, const tb_output_se
             uint32_t outIdx = 0, inIdx = 1;
             for (uint32_t i = 0; i < dn.WaveletIterations; i++) {
                 TbDenoiserConstants k; k.ResolutionX = W; k.ResolutionY = H; k.OffsetMultiplier = 1u << i;
-                k.NormalWeightingExponential = dn.NormalWeightingExponential; k.IntersectionPositionWeightingMultiplier = dn.IntersectPositionWeightingMultiplier;
+                k.NormalWeightingExponential = dn.NormalWeightingExponential;
+                    k.IntersectionPositionWeightingMultiplier = dn.IntersectPositionWeightingMultiplier;
                 k.LumaWeightingMultiplier = dn.LuminanceWeightingMultiplier; k.GlobalFrameCount = c->samplesRendered;
                 const TbFloat4* in = i == 0 ? (const TbFloat4*)c->rtIndirect[cur].p : (const TbFloat4*)c->rtDenoise[inIdx].p;
                 HIP_TRY(rt_launch_denoise(c->stream, &k, in, normals, wpCur, (const TbFloat4*)c->rtIndirect[cur].p, (TbFloat4*)c->rtDenoise[outIdx].p));
@@ -382,7 +405,8 @@ int tb_render_realtime(tb_context* c, uint32_t W, uint32_t H, const tb_output_se
             }
             if (dn.WaveletIterations > 0) { lighting = (const TbFloat4*)c->rtDenoise[inIdx].p; c->rtLast[2] = (int)inIdx; }
         }
-        HIP_TRY(rt_launch_composite(c->stream, W, H, (const TbFloat4*)c->aov[TB_AOV_CUSTOM].p, lighting, (const TbFloat4*)c->aov[TB_AOV_EMISSIVE].p, (TbFloat4*)c->rtComposited.p));
+        HIP_TRY(rt_launch_composite(c->stream, W, H, (const TbFloat4*)c->aov[TB_AOV_CUSTOM].p, lighting, (const TbFloat4*)c->aov[TB_AOV_EMISSIVE].p,
+            (TbFloat4*)c->rtComposited.p));
         c->rtLast[3] = 0;
         temporal((const TbFloat4*)c->rtComposited.p, &c->rtFinal[cur], &c->rtFinal[prev], nullptr, nullptr);
         c->rtLast[4] = (int)cur;
@@ -396,8 +420,10 @@ int tb_render_realtime(tb_context* c, uint32_t W, uint32_t H, const tb_output_se
 int tb_read_realtime(tb_context* c, int stage, float* dst)
 {
     return guarded(c, [&]() {
-        if (!dst || stage < 0 || stage > 4 || !c->lastRenderRealtime || c->rtLast[stage] < 0) return fail(c, TB_E_INVALID, "tb_read_realtime: stage not available (render a real-time frame first)");
-        const DevBuf* b = stage == 0 ? &c->rtIndirect[c->rtLast[0]] : stage == 1 ? &c->rtMoment[c->rtLast[1]] : stage == 2 ? &c->rtDenoise[c->rtLast[2]] : stage == 3 ? &c->rtComposited : &c->rtFinal[c->rtLast[4]];
+        if (!dst || stage < 0 || stage > 4 || !c->lastRenderRealtime || c->rtLast[stage] < 0) return fail(c, TB_E_INVALID,
+            "tb_read_realtime: stage not available (render a real-time frame first)");
+        const DevBuf* b = stage == 0 ? &c->rtIndirect[c->rtLast[0]] : stage == 1 ? &c->rtMoment[c->rtLast[1]] : stage == 2 ? &c->rtDenoise[c->rtLast[2]] :
+            stage == 3 ? &c->rtComposited : &c->rtFinal[c->rtLast[4]];
         HIP_TRY(hipStreamSynchronize(c->stream));
         HIP_TRY(hipMemcpy(dst, b->p, (size_t)c->rtWidth * c->rtHeight * sizeof(TbFloat4), hipMemcpyDeviceToHost));
         return TB_OK;
@@ -417,7 +443,8 @@ int tb_post_process(tb_context* c, const tb_post_settings* post, uint32_t output
         tb_post_settings ps; if (post) ps = *post; else tb_default_post_settings(&ps);
         const TbFloat4* in = nullptr; const float* inR32 = nullptr;
         switch (outputType) { /* GetOutputSRV, TracerBoy.cpp:2354-2383 */
-        case TB_OUTPUT_TYPE_LIT: in = (const TbFloat4*)(c->lastRenderRealtime ? c->rtFinal[c->rtLast[4]].p : c->output.p); break; /* PostProcessInput after the real-time chain, TracerBoy.cpp:3144-3160 */
+        /* PostProcessInput after the real-time chain, TracerBoy.cpp:3144-3160 */
+        case TB_OUTPUT_TYPE_LIT: in = (const TbFloat4*)(c->lastRenderRealtime ? c->rtFinal[c->rtLast[4]].p : c->output.p); break;
         case TB_OUTPUT_TYPE_LUMINANCE: in = (const TbFloat4*)c->output.p; break;
         case TB_OUTPUT_TYPE_ALBEDO: case TB_OUTPUT_TYPE_LIVE_PIXELS: case TB_OUTPUT_TYPE_HEATMAP: in = (const TbFloat4*)c->aov[TB_AOV_CUSTOM].p; break;
         case TB_OUTPUT_TYPE_NORMAL: in = (const TbFloat4*)c->aov[TB_AOV_NORMALS].p; break;
@@ -484,8 +511,11 @@ int tb_read_stats(tb_context* c, tb_readback_stats* o)
         if (!o) return TB_E_INVALID;
         memset(o, 0, sizeof *o);
         HIP_TRY(hipStreamSynchronize(c->stream));
-        if (c->stats.p) { uint32_t raw[4]; HIP_TRY(hipMemcpy(raw, c->stats.p, 16, hipMemcpyDeviceToHost)); o->ActiveWaves = raw[0]; o->ActivePixels = raw[1]; memcpy(&o->SelectedPixelDistance, &raw[2], 4); o->SelectedMaterialID = (int32_t)raw[3]; }
-        if (c->rayStats.p) { uint64_t r[7]; HIP_TRY(hipMemcpy(r, c->rayStats.p, 56, hipMemcpyDeviceToHost)); o->rays.boxesTested = r[0]; o->rays.trianglesTested = r[1]; o->rays.hitsShaded = r[2]; o->rays.materialFetches = r[3]; o->rays.lightSamples = r[4]; o->rays.samples = r[5]; o->rays.rays = r[6]; }
+        if (c->stats.p) { uint32_t raw[4]; HIP_TRY(hipMemcpy(raw, c->stats.p, 16, hipMemcpyDeviceToHost)); o->ActiveWaves = raw[0]; o->ActivePixels = raw[1];
+            memcpy(&o->SelectedPixelDistance, &raw[2], 4); o->SelectedMaterialID = (int32_t)raw[3]; }
+        if (c->rayStats.p) { uint64_t r[7]; HIP_TRY(hipMemcpy(r, c->rayStats.p, 56, hipMemcpyDeviceToHost)); o->rays.boxesTested = r[0];
+            o->rays.trianglesTested = r[1]; o->rays.hitsShaded = r[2]; o->rays.materialFetches = r[3]; o->rays.lightSamples = r[4]; o->rays.samples = r[5];
+            o->rays.rays = r[6]; }
         return TB_OK;
     });
 }
@@ -510,7 +540,8 @@ void tb_plan_defaults(tb_plan_input* in)
 int tb_variant_waves_hi(const char* name)
 {
     if (!name) return -1;
-    for (int i = 0; i < tbctx::kNumVariants; i++) if (!strcmp(tbctx::kVariants[i].name, name)) return tbctx::kVariants[i].fnHi ? (int)tbctx::kVariants[i].wavesHi : 0;
+    for (int i = 0; i < tbctx::kNumVariants; i++) if (!strcmp(tbctx::kVariants[i].name,
+        name)) return tbctx::kVariants[i].fnHi ? (int)tbctx::kVariants[i].wavesHi : 0;
     return -1;
 }
 int tb_plan_launch(const tb_plan_input* in, tb_launch_plan* out)
@@ -523,7 +554,8 @@ int tb_plan_launch(const tb_plan_input* in, tb_launch_plan* out)
 int tb_read_split_profile(tb_context* c, uint64_t* out16)
 {
     return guarded(c, [&]() {
-        if (!out16 || !c->splitProf.p) return fail(c, TB_E_INVALID, "tb_read_split_profile: render with options \"pipeline\" = 4 and \"split_profile\" = 1 first");
+        if (!out16 || !c->splitProf.p) return fail(c, TB_E_INVALID,
+            "tb_read_split_profile: render with options \"pipeline\" = 4 and \"split_profile\" = 1 first");
         HIP_TRY(hipStreamSynchronize(c->stream));
         HIP_TRY(hipMemcpy(out16, c->splitProf.p, 16 * 8, hipMemcpyDeviceToHost));
         return TB_OK;
@@ -532,13 +564,15 @@ int tb_read_split_profile(tb_context* c, uint64_t* out16)
 
 void tb_invalidate_history(tb_context* c) { if (c) { c->samplesRendered = 0; for (tb_context* p : c->peers) p->samplesRendered = 0; } }
 uint32_t tb_samples_rendered(tb_context* c) { return c ? c->samplesRendered : 0; }
-int tb_select_pixel(tb_context* c, uint32_t x, uint32_t y) { if (!c) return TB_E_INVALID; c->selX = x; c->selY = y; return TB_OK; } /* (a group renders the selection on the device that owns the pixel's tile; ReadbackStats reads the owner's buffer) */
+/* (a group renders the selection on the device that owns the pixel's tile; ReadbackStats reads the owner's buffer) */
+int tb_select_pixel(tb_context* c, uint32_t x, uint32_t y) { if (!c) return TB_E_INVALID; c->selX = x; c->selY = y; return TB_OK; }
 
 int tb_set_tile_assignment(tb_context* c, uint32_t rank, uint32_t world, uint32_t tw, uint32_t th)
 {
     if (c && (!c->peers.empty() || c->groupOwner)) return fail(c, TB_E_INVALID, "tb_set_tile_assignment: a multi-device group deals its tiles itself");
     if (!c || world == 0 || rank >= world || tw == 0 || th == 0) return c ? fail(c, TB_E_INVALID, "tb_set_tile_assignment: bad arguments") : TB_E_INVALID;
-    if (world > 1 && (tw % 16 || th % 16)) return fail(c, TB_E_INVALID, "tb_set_tile_assignment: tile width and height must be multiples of 16 (a workgroup renders 16x16 pixels)");
+    if (world > 1 && (tw % 16 || th % 16)) return fail(c, TB_E_INVALID,
+        "tb_set_tile_assignment: tile width and height must be multiples of 16 (a workgroup renders 16x16 pixels)");
     c->tiles = TbTileMap{rank, world, tw, th}; c->samplesRendered = 0;
     return TB_OK;
 }
@@ -550,7 +584,8 @@ int tb_pack_owned_device(tb_context* c, void* dst)
 {
     return guarded(c, [&]() {
         if (!dst || !c->output.p) return fail(c, TB_E_INVALID, "tb_pack_owned_device: nothing rendered / null destination");
-        HIP_TRY(pt_launch_pack_owned(c->stream, (const TbFloat4*)c->output.p, (TbFloat4*)dst, c->width, c->height, &c->tiles, ownedTiles(c->width, c->height, c->tiles)));
+        HIP_TRY(pt_launch_pack_owned(c->stream, (const TbFloat4*)c->output.p, (TbFloat4*)dst, c->width, c->height, &c->tiles, ownedTiles(c->width, c->height,
+            c->tiles)));
         HIP_TRY(hipStreamSynchronize(c->stream));
         return TB_OK;
     });
@@ -560,20 +595,24 @@ int tb_pack_owned_device_async(tb_context* c, void* dst)
 {
     return guarded(c, [&]() {
         if (!dst || !c->output.p) return fail(c, TB_E_INVALID, "tb_pack_owned_device_async: nothing rendered / null destination");
-        HIP_TRY(pt_launch_pack_owned(c->stream, (const TbFloat4*)c->output.p, (TbFloat4*)dst, c->width, c->height, &c->tiles, ownedTiles(c->width, c->height, c->tiles)));
+        HIP_TRY(pt_launch_pack_owned(c->stream, (const TbFloat4*)c->output.p, (TbFloat4*)dst, c->width, c->height, &c->tiles, ownedTiles(c->width, c->height,
+            c->tiles)));
         return TB_OK;
     });
 }
 
 void* tb_stream(tb_context* c) { return c ? (void*)c->stream : nullptr; }
 
-int tb_unpack_gathered_device(tb_context* c, void* stream, const void* gathered, uint64_t capacityPixels, uint32_t W, uint32_t H, uint32_t world, uint32_t tw, uint32_t th, void* full)
+int tb_unpack_gathered_device(tb_context* c, void* stream, const void* gathered, uint64_t capacityPixels, uint32_t W, uint32_t H, uint32_t world, uint32_t tw,
+    uint32_t th, void* full)
 {
     return guarded(c, [&]() {
         if (!gathered || !full || world == 0 || tw == 0 || th == 0 || W == 0 || H == 0) return fail(c, TB_E_INVALID, "tb_unpack_gathered_device: bad argument");
         const uint64_t tilesTotal = (uint64_t)((W + tw - 1) / tw) * ((H + th - 1) / th);
-        if (((tilesTotal + world - 1) / world) * tw * th > capacityPixels) return fail(c, TB_E_INVALID, "tb_unpack_gathered_device: per-rank capacity smaller than rank 0's tiles");
-        HIP_TRY(pt_launch_unpack_gathered(stream ? (hipStream_t)stream : c->stream, (const TbFloat4*)gathered, (size_t)capacityPixels, (TbFloat4*)full, W, H, world, tw, th));
+        if (((tilesTotal + world - 1) / world) * tw * th > capacityPixels) return fail(c, TB_E_INVALID,
+            "tb_unpack_gathered_device: per-rank capacity smaller than rank 0's tiles");
+        HIP_TRY(pt_launch_unpack_gathered(stream ? (hipStream_t)stream : c->stream, (const TbFloat4*)gathered, (size_t)capacityPixels, (TbFloat4*)full, W, H,
+            world, tw, th));
         return TB_OK;
     });
 }
@@ -595,9 +634,14 @@ int tb_unpack_gathered_host(uint32_t W, uint32_t H, uint32_t world, uint32_t tw,
 int tb_set_option(tb_context* c, const char* name, int64_t v)
 {
     if (!c || !name) return TB_E_INVALID;
-    static const char* known[] = {"primary_prepass", "pipeline", "count_rays", "bvh_builder", "flatten_instances", "aov", "scene_in_lds", "lds_scene_budget", "force_full_variant", "wavefront_paths", "wavefront_grid", "wavefront_segment", "pooled_paths", "pooled_samples", "pooled_profile", "park_min", "alpha_test", "node_order", "node_order_top_levels", "frame_group", "overlap_launches", "high_occupancy", "stack_lds_cap", "stack_overflow_max", "flip_texture_uvs", "wavefront_sort", "banded_items", "node_layout", "wavefront_refill",
-                                  "split_trav", "split_shade", "split_ready", "split_refill", "split_wi", "split_wl", "split_frame_group", "split_stack_cap", "split_spin_limit", "split_profile", "split_trav_last", "split_shade_prio"};
-    for (const char* k : known) if (!strcmp(k, name)) { c->options[name] = v; if (!strcmp(name, "count_rays") || !strcmp(name, "aov")) c->samplesRendered = 0; return TB_OK; }
+    static const char* known[] = {"primary_prepass", "pipeline", "count_rays", "bvh_builder", "flatten_instances", "aov", "scene_in_lds", "lds_scene_budget",
+        "force_full_variant", "wavefront_paths", "wavefront_grid", "wavefront_segment", "pooled_paths", "pooled_samples", "pooled_profile", "park_min",
+        "alpha_test", "node_order", "node_order_top_levels", "frame_group", "overlap_launches", "high_occupancy", "stack_lds_cap", "stack_overflow_max",
+        "flip_texture_uvs", "wavefront_sort", "banded_items", "node_layout", "wavefront_refill",
+                                  "split_trav", "split_shade", "split_ready", "split_refill", "split_wi", "split_wl", "split_frame_group", "split_stack_cap",
+                                      "split_spin_limit", "split_profile", "split_trav_last", "split_shade_prio"};
+    for (const char* k : known) if (!strcmp(k, name)) { c->options[name] = v; if (!strcmp(name, "count_rays") || !strcmp(name, "aov")) c->samplesRendered = 0;
+        return TB_OK; }
     return fail(c, TB_E_INVALID, std::string("unknown option '") + name + "'");
 }
 int64_t tb_get_option(tb_context* c, const char* name)
@@ -610,12 +654,15 @@ int64_t tb_get_option(tb_context* c, const char* name)
     if (!strcmp(name, "last_primary_prepass")) return c->lastPrimaryPrepass;
     if (!strcmp(name, "debug_slot_log_ptr")) return (int64_t)(uintptr_t)c->fgSlotLog[c->lastFgPar].p;
     if (!strcmp(name, "debug_slot_log_cap")) return c->lastSlotLogCap;
-    if (!strcmp(name, "debug_fg_samples_ptr")) return (int64_t)(uintptr_t)c->fgSamples[c->lastFgPar].p; /* device address of the sample buffer of the last frame-group launch (scripts/lost_item_stress.py) */
+    /* device address of the sample buffer of the last frame-group launch (scripts/lost_item_stress.py) */
+    if (!strcmp(name, "debug_fg_samples_ptr")) return (int64_t)(uintptr_t)c->fgSamples[c->lastFgPar].p;
     if (!strcmp(name, "last_node_layout")) return c->lastNodeLayout; /* 0: layout B (64-B nodes), 1: layout C (32-B nodes on the 16-bit grid) */
     if (!strcmp(name, "debug_prepass_rejects")) { /* hit records of the primary-visibility pre-pass that failed validation since the context was made */
-        uint32_t v = 0; if (c->debugCounters.p) { (void)hipStreamSynchronize(c->stream); (void)hipMemcpy(&v, c->debugCounters.p, 4, hipMemcpyDeviceToHost); } return v; }
+        uint32_t v = 0; if (c->debugCounters.p) { (void)hipStreamSynchronize(c->stream); (void)hipMemcpy(&v, c->debugCounters.p, 4, hipMemcpyDeviceToHost);
+            } return v; }
     if (!strcmp(name, "last_overlap")) return c->lastOverlap; /* the last frame-group render used the two side streams */
-    if (!strcmp(name, "overlap_trial_us_overlapped")) return (int64_t)(c->overlapTrial.best[0] * 1000.0f); /* best device-bound interval between call ends, overlapped / one at a time */
+    /* best device-bound interval between call ends, overlapped / one at a time */
+    if (!strcmp(name, "overlap_trial_us_overlapped")) return (int64_t)(c->overlapTrial.best[0] * 1000.0f);
     if (!strcmp(name, "overlap_trial_us_one_at_a_time")) return (int64_t)(c->overlapTrial.best[1] * 1000.0f);
     if (!strcmp(name, "overlap_trial_phase")) return c->overlapTrial.phase; /* 0 measuring overlapped, 1 measuring one at a time, 2 decided */
     if (!strcmp(name, "last_plan_rule_pipeline")) return c->lastPlan.rule_pipeline; /* TB_PLAN_RULE_* of the last render (tracerboy_hip.h) */
@@ -624,8 +671,10 @@ int64_t tb_get_option(tb_context* c, const char* name)
     if (!strcmp(name, "last_plan_frame_group")) return c->lastPlan.frame_group;
     if (!strcmp(name, "last_plan_stack_overflow")) return c->lastPlan.stack_overflow_entries;
     if (!strcmp(name, "last_split_waves")) return c->lastSplitWaves; /* traversal waves * 100 + shading waves per workgroup of the last pipeline-4 launch */
-    if (!strcmp(name, "last_pipeline")) return c->lastPipeline; /* the pipeline the last render actually ran (2 / 3 fall back to 0 for feature sets they lack) */
-    if (!strcmp(name, "last_variant")) { for (int i = 0; i < kNumVariants; i++) if (c->lastVariant == kVariants[i].name) return kVariants[i].id; return -1; } /* 0 matte 1 env 2 surf 3 vol 4 full 5 sss */
+    /* the pipeline the last render actually ran (2 / 3 fall back to 0 for feature sets they lack) */
+    if (!strcmp(name, "last_pipeline")) return c->lastPipeline;
+    /* 0 matte 1 env 2 surf 3 vol 4 full 5 sss */
+    if (!strcmp(name, "last_variant")) { for (int i = 0; i < kNumVariants; i++) if (c->lastVariant == kVariants[i].name) return kVariants[i].id; return -1; }
     auto it = c->options.find(name); return it == c->options.end() ? 0 : it->second;
 }
 
@@ -665,11 +714,13 @@ int tb_trace_closest(tb_context* c, uint32_t n, const float* origins, const floa
         { auto it = c->options.find("node_layout"); if (it != c->options.end() && it->second == 1) ensureCompactNodes(c); }
         TbDeviceScene dsTrace = c->ds; /* option "node_layout" = 1: the batch walks the compact nodes too (one-level scenes) */
         { auto it = c->options.find("node_layout"); if (it == c->options.end() || it->second != 1 || dsTrace.numInstances) dsTrace.nodesC = nullptr; }
-        HIP_TRY(pt_launch_trace_closest(c->stream, &dsTrace, n, (const float*)dO.b.p, (const float*)dD.b.p, (float*)dT.b.p, (int*)dM.b.p, (float*)dB.b.p, (uint32_t*)dP.b.p,
+        HIP_TRY(pt_launch_trace_closest(c->stream, &dsTrace, n, (const float*)dO.b.p, (const float*)dD.b.p, (float*)dT.b.p, (int*)dM.b.p, (float*)dB.b.p,
+            (uint32_t*)dP.b.p,
                                         (uint32_t*)dG.b.p, (float*)dN.b.p, (float*)dU.b.p, (uint32_t*)dBx.b.p, (uint32_t*)dTr.b.p));
         HIP_TRY(hipStreamSynchronize(c->stream));
         auto outc = [&](void* h, Tmp& t, size_t bytes) { if (h) HIP_TRY(hipMemcpy(h, t.b.p, bytes, hipMemcpyDeviceToHost)); };
-        outc(outT, dT, (size_t)n * 4); outc(outMat, dM, (size_t)n * 4); outc(outBary, dB, (size_t)n * 8); outc(outPrim, dP, (size_t)n * 4); outc(outGeom, dG, (size_t)n * 4);
+        outc(outT, dT, (size_t)n * 4); outc(outMat, dM, (size_t)n * 4); outc(outBary, dB, (size_t)n * 8); outc(outPrim, dP, (size_t)n * 4);
+            outc(outGeom, dG, (size_t)n * 4);
         outc(outNormal, dN, (size_t)n * 12); outc(outUV, dU, (size_t)n * 8); outc(outBoxes, dBx, (size_t)n * 4); outc(outTris, dTr, (size_t)n * 4);
         return TB_OK;
     });
@@ -779,7 +830,8 @@ int tb_host_scene_layout_b(tb_host_scene* h, const TbNodeB** nodes, uint32_t* nn
     if (root) *root = h->scene.rootRefB;
     return TB_OK;
 }
-int tb_host_scene_triangles(tb_host_scene* h, const float** pos, uint32_t* nv, const uint32_t** tvi, const uint32_t** tg, const uint32_t** tp, const uint32_t** tf, uint32_t* nt)
+int tb_host_scene_triangles(tb_host_scene* h, const float** pos, uint32_t* nv, const uint32_t** tvi, const uint32_t** tg, const uint32_t** tp,
+    const uint32_t** tf, uint32_t* nt)
 {
     if (!h) return TB_E_INVALID;
     const HostScene& s = h->scene;

@@ -24,36 +24,58 @@
 using namespace tbhost;
 
 extern "C" {
-typedef hipError_t (*pt_variant_fn)(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, uint32_t, uint32_t, uint32_t, uint32_t,
+typedef hipError_t (*pt_variant_fn)(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, uint32_t, uint32_t, uint32_t,
+    uint32_t,
                                     const TbTileMap*, int, int, int);
-hipError_t pt_launch_persistent_matte(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, uint32_t, uint32_t, uint32_t, uint32_t, const TbTileMap*, int, int, int);
-hipError_t pt_launch_persistent_env(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, uint32_t, uint32_t, uint32_t, uint32_t, const TbTileMap*, int, int, int);
-hipError_t pt_launch_persistent_surf(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, uint32_t, uint32_t, uint32_t, uint32_t, const TbTileMap*, int, int, int);
-hipError_t pt_launch_persistent_matte5(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, uint32_t, uint32_t, uint32_t, uint32_t, const TbTileMap*, int, int, int);
-hipError_t pt_launch_persistent_env5(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, uint32_t, uint32_t, uint32_t, uint32_t, const TbTileMap*, int, int, int);
-hipError_t pt_launch_persistent_sss(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, uint32_t, uint32_t, uint32_t, uint32_t, const TbTileMap*, int, int, int);
-hipError_t pt_launch_persistent_sss4(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, uint32_t, uint32_t, uint32_t, uint32_t, const TbTileMap*, int, int, int);
-hipError_t pt_launch_persistent_vol4(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, uint32_t, uint32_t, uint32_t, uint32_t, const TbTileMap*, int, int, int);
-hipError_t pt_launch_persistent_vol(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, uint32_t, uint32_t, uint32_t, uint32_t, const TbTileMap*, int, int, int);
-hipError_t pt_launch_persistent_full(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, uint32_t, uint32_t, uint32_t, uint32_t, const TbTileMap*, int, int, int);
+hipError_t pt_launch_persistent_matte(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, uint32_t, uint32_t, uint32_t,
+    uint32_t, const TbTileMap*, int, int, int);
+hipError_t pt_launch_persistent_env(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, uint32_t, uint32_t, uint32_t,
+    uint32_t, const TbTileMap*, int, int, int);
+hipError_t pt_launch_persistent_surf(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, uint32_t, uint32_t, uint32_t,
+    uint32_t, const TbTileMap*, int, int, int);
+hipError_t pt_launch_persistent_matte5(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, uint32_t, uint32_t, uint32_t,
+    uint32_t, const TbTileMap*, int, int, int);
+hipError_t pt_launch_persistent_env5(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, uint32_t, uint32_t, uint32_t,
+    uint32_t, const TbTileMap*, int, int, int);
+hipError_t pt_launch_persistent_sss(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, uint32_t, uint32_t, uint32_t,
+    uint32_t, const TbTileMap*, int, int, int);
+hipError_t pt_launch_persistent_sss4(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, uint32_t, uint32_t, uint32_t,
+    uint32_t, const TbTileMap*, int, int, int);
+hipError_t pt_launch_persistent_vol4(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, uint32_t, uint32_t, uint32_t,
+    uint32_t, const TbTileMap*, int, int, int);
+hipError_t pt_launch_persistent_vol(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, uint32_t, uint32_t, uint32_t,
+    uint32_t, const TbTileMap*, int, int, int);
+hipError_t pt_launch_persistent_full(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, uint32_t, uint32_t, uint32_t,
+    uint32_t, const TbTileMap*, int, int, int);
 /* pipeline 4, the split-role kernel (pt_split.inc): shading waves + traversal waves over an LDS ray queue */
-typedef hipError_t (*pt_split_fn)(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, const TbSplitParams*, uint32_t, uint32_t, uint32_t, uint32_t,
+typedef hipError_t (*pt_split_fn)(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, const TbSplitParams*, uint32_t,
+    uint32_t, uint32_t, uint32_t,
                                   const TbTileMap*, int, int*);
-hipError_t pt_launch_split_matte(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, const TbSplitParams*, uint32_t, uint32_t, uint32_t, uint32_t, const TbTileMap*, int, int*);
-hipError_t pt_launch_split_env(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, const TbSplitParams*, uint32_t, uint32_t, uint32_t, uint32_t, const TbTileMap*, int, int*);
-hipError_t pt_launch_split_surf(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, const TbSplitParams*, uint32_t, uint32_t, uint32_t, uint32_t, const TbTileMap*, int, int*);
-hipError_t pt_launch_split_sss(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, const TbSplitParams*, uint32_t, uint32_t, uint32_t, uint32_t, const TbTileMap*, int, int*);
+hipError_t pt_launch_split_matte(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, const TbSplitParams*, uint32_t,
+    uint32_t, uint32_t, uint32_t, const TbTileMap*, int, int*);
+hipError_t pt_launch_split_env(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, const TbSplitParams*, uint32_t, uint32_t,
+    uint32_t, uint32_t, const TbTileMap*, int, int*);
+hipError_t pt_launch_split_surf(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, const TbSplitParams*, uint32_t,
+    uint32_t, uint32_t, uint32_t, const TbTileMap*, int, int*);
+hipError_t pt_launch_split_sss(hipStream_t, const TbDeviceScene*, const TbPerFrameConstants*, const TbDeviceTargets*, const TbSplitParams*, uint32_t, uint32_t,
+    uint32_t, uint32_t, const TbTileMap*, int, int*);
 }
 
 #include "../kernels/wf_types.h"
 extern "C" {
-typedef hipError_t (*wf_variant_fn)(hipStream_t, int, const TbDeviceScene*, const TbPerFrameConstants*, const WfParams*, const WfQueue*, const WfQueue*, const WfQueue*,
+typedef hipError_t (*wf_variant_fn)(hipStream_t, int, const TbDeviceScene*, const TbPerFrameConstants*, const WfParams*, const WfQueue*, const WfQueue*,
+    const WfQueue*,
                                     const WfHits*, int, TbFloat4*, TbFloat4*, uint32_t);
-hipError_t wf_launch_matte(hipStream_t, int, const TbDeviceScene*, const TbPerFrameConstants*, const WfParams*, const WfQueue*, const WfQueue*, const WfQueue*, const WfHits*, int, TbFloat4*, TbFloat4*, uint32_t);
-hipError_t wf_launch_env(hipStream_t, int, const TbDeviceScene*, const TbPerFrameConstants*, const WfParams*, const WfQueue*, const WfQueue*, const WfQueue*, const WfHits*, int, TbFloat4*, TbFloat4*, uint32_t);
-hipError_t wf_launch_surf(hipStream_t, int, const TbDeviceScene*, const TbPerFrameConstants*, const WfParams*, const WfQueue*, const WfQueue*, const WfQueue*, const WfHits*, int, TbFloat4*, TbFloat4*, uint32_t);
-hipError_t wf_launch_sss(hipStream_t, int, const TbDeviceScene*, const TbPerFrameConstants*, const WfParams*, const WfQueue*, const WfQueue*, const WfQueue*, const WfHits*, int, TbFloat4*, TbFloat4*, uint32_t);
-hipError_t wf_launch_vol(hipStream_t, int, const TbDeviceScene*, const TbPerFrameConstants*, const WfParams*, const WfQueue*, const WfQueue*, const WfQueue*, const WfHits*, int, TbFloat4*, TbFloat4*, uint32_t);
+hipError_t wf_launch_matte(hipStream_t, int, const TbDeviceScene*, const TbPerFrameConstants*, const WfParams*, const WfQueue*, const WfQueue*, const WfQueue*,
+    const WfHits*, int, TbFloat4*, TbFloat4*, uint32_t);
+hipError_t wf_launch_env(hipStream_t, int, const TbDeviceScene*, const TbPerFrameConstants*, const WfParams*, const WfQueue*, const WfQueue*, const WfQueue*,
+    const WfHits*, int, TbFloat4*, TbFloat4*, uint32_t);
+hipError_t wf_launch_surf(hipStream_t, int, const TbDeviceScene*, const TbPerFrameConstants*, const WfParams*, const WfQueue*, const WfQueue*, const WfQueue*,
+    const WfHits*, int, TbFloat4*, TbFloat4*, uint32_t);
+hipError_t wf_launch_sss(hipStream_t, int, const TbDeviceScene*, const TbPerFrameConstants*, const WfParams*, const WfQueue*, const WfQueue*, const WfQueue*,
+    const WfHits*, int, TbFloat4*, TbFloat4*, uint32_t);
+hipError_t wf_launch_vol(hipStream_t, int, const TbDeviceScene*, const TbPerFrameConstants*, const WfParams*, const WfQueue*, const WfQueue*, const WfQueue*,
+    const WfHits*, int, TbFloat4*, TbFloat4*, uint32_t);
 }
 
 namespace tbctx {
@@ -76,7 +98,8 @@ extern std::string g_createError;
 #ifndef TB_VOL_WAVES
 #define TB_VOL_WAVES 4
 #endif
-struct Variant { uint32_t features; pt_variant_fn fn; const char* name; pt_variant_fn fnHi; uint32_t wavesHi; int id; wf_variant_fn wf; bool pooled; pt_split_fn split; };
+struct Variant { uint32_t features; pt_variant_fn fn; const char* name; pt_variant_fn fnHi; uint32_t wavesHi; int id; wf_variant_fn wf; bool pooled;
+    pt_split_fn split; };
 extern const Variant kVariants[];
 extern const int kNumVariants;
 
@@ -133,11 +156,14 @@ struct tb_context {
     std::string lastVariant;
     int lastNodeLayout = 0; /* 1: the last render walked the compact layout-C nodes */
     int lastSlotLogCap = 0;
-    struct PrepassTrial { uint64_t key = 0; int calls = 0, pending = 0, nWith = 0, nWithout = 0; float msWith = 0, msWithout = 0; bool keep = false; uint64_t stamp = 0; } prepassTrial; /* renderImpl */
+    /* renderImpl */
+    struct PrepassTrial { uint64_t key = 0; int calls = 0, pending = 0, nWith = 0, nWithout = 0; float msWith = 0, msWithout = 0; bool keep = false;
+        uint64_t stamp = 0; } prepassTrial;
     /* Do back-to-back calls gain from running on the two side streams at once?  Found by measurement where it is in doubt (renderImpl):
      * the end of every render is marked by an event of a ring; the interval between two consecutive ends, when the later call was enqueued
      * before the earlier one had finished (the device was never idle between them), is what a call costs in that mode. */
-    struct OverlapTrial { uint64_t key = 0; int phase = 0 /* 0 measuring overlapped, 1 measuring one at a time, 2 decided */; int n[2] = {0, 0}; float best[2] = {0, 0}; bool keep = true; } overlapTrial;
+    struct OverlapTrial { uint64_t key = 0; int phase = 0 /* 0 measuring overlapped, 1 measuring one at a time, 2 decided */; int n[2] = {0, 0};
+        float best[2] = {0, 0}; bool keep = true; } overlapTrial;
     struct CallRec { uint64_t key = 0; int mode = -1; bool deviceBound = false, settled = false, used = true; } callRec[8];
     hipEvent_t evCallEnd[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; uint64_t callCount = 0; int lastOverlap = 0;
     tb_launch_plan lastPlan{}; /* what PlanLaunch decided for the last render (options last_plan_rule_*) */
@@ -145,7 +171,8 @@ struct tb_context {
     uint32_t sceneGeneration = 0; /* counts finalizeScene calls */
     float interiorWalkTriangleShare = 0; /* finalizeScene */
     DevBuf debugCounters; /* TbDeviceTargets::debugCounters (16 words, zeroed once) */
-    DevBuf splitProf; uint32_t* splitAbort = nullptr; int lastSplitWaves = 0; /* pipeline 4: host-mapped abort word of the split-role kernel (renderSplit); travWaves * 100 + shadeWaves of the last launch */
+    /* pipeline 4: host-mapped abort word of the split-role kernel (renderSplit); travWaves * 100 + shadeWaves of the last launch */
+    DevBuf splitProf; uint32_t* splitAbort = nullptr; int lastSplitWaves = 0;
     int lastFgPar = 0;          /* which of the two sample buffers the last frame-group launch wrote (debug query) */
     int lastPrimaryPrepass = 0; /* 1: the last render took its first hits from the primary-visibility pre-pass */
     /* Multi-device group (tb_create_multi): this context is device 0 of the group and owns the assembled frame; `peers` are the
@@ -161,7 +188,8 @@ struct tb_context {
 
 namespace tbctx {
 
-#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
+#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
 
 int fail(tb_context* c, int code, const std::string& msg);
 

@@ -10,7 +10,8 @@ bool historyRelevantChange(const tb_output_settings& a, const tb_output_settings
     return a.OutputType != b.OutputType || a.EnableNormalMaps != b.EnableNormalMaps || a.RenderModeRealTime != b.RenderModeRealTime ||
            a.DOFFocalDistance != b.DOFFocalDistance || a.ApertureWidth != b.ApertureWidth || a.FilterType != b.FilterType || a.FilterWidth != b.FilterWidth ||
            a.FireflyClampValue != b.FireflyClampValue || a.EnableNextEventEstimation != b.EnableNextEventEstimation ||
-           a.EnableSamplingImportanceResampling != b.EnableSamplingImportanceResampling || a.EnableBlueNoise != b.EnableBlueNoise || a.MaxBounces != b.MaxBounces ||
+           a.EnableSamplingImportanceResampling != b.EnableSamplingImportanceResampling || a.EnableBlueNoise != b.EnableBlueNoise ||
+               a.MaxBounces != b.MaxBounces ||
            a.DebugValue != b.DebugValue || a.DebugValue2 != b.DebugValue2;
 }
 
@@ -31,11 +32,14 @@ void renderWavefront(tb_context* c, int variant, uint32_t W, uint32_t H, uint32_
     {   /* the LDS a stage asks for, checked here so that a large segment fails with a sentence instead of a launch error */
         const size_t blobBytes = c->sceneInLds ? c->ds.ldsBlobBytes : 0, ldsLimit = 160 * 1024;
         if (opt("wavefront_sort", 0)) {
-            if (segCap > 65536u) throw std::runtime_error("wavefront_sort: wavefront_segment must not exceed 65536 (the index permutation is 16-bit); unsupported");
+            if (segCap > 65536u)
+                throw std::runtime_error("wavefront_sort: wavefront_segment must not exceed 65536 (the index permutation is 16-bit); unsupported");
             const size_t sortBytes = 64 * 4 + ((size_t)segCap * 3 + 15) / 16 * 16;
-            if (16 + blobBytes + sortBytes > ldsLimit) throw std::runtime_error("wavefront_sort: a segment of " + std::to_string(segCap) + " entries needs " + std::to_string(16 + blobBytes + sortBytes) + " B of LDS (limit 163840): lower wavefront_segment; unsupported");
+            if (16 + blobBytes + sortBytes > ldsLimit) throw std::runtime_error("wavefront_sort: a segment of " + std::to_string(segCap) + " entries needs " +
+                std::to_string(16 + blobBytes + sortBytes) + " B of LDS (limit 163840): lower wavefront_segment; unsupported");
         }
-        if (16 + (size_t)c->ds.stackDepth * 1024 + blobBytes > ldsLimit) throw std::runtime_error("wavefront pipeline: traversal stack of depth " + std::to_string(c->ds.stackDepth) + " does not fit LDS; unsupported");
+        if (16 + (size_t)c->ds.stackDepth * 1024 + blobBytes > ldsLimit) throw std::runtime_error("wavefront pipeline: traversal stack of depth " +
+            std::to_string(c->ds.stackDepth) + " does not fit LDS; unsupported");
     }
     const bool sss = (kVariants[variant].features & PT_FEAT_SSS) != 0; /* entries may be steps of the interior walk: two more columns per queue */
     {
@@ -91,7 +95,8 @@ void renderWavefront(tb_context* c, int variant, uint32_t W, uint32_t H, uint32_
             }
             HIP_TRY(fn(c->stream, WF_STAGE_EXTEND, &c->ds, &pf, &wp, nullptr, nullptr, &next, &hits, lds, nullptr, nullptr, grid));
         }
-        HIP_TRY(fn(c->stream, WF_STAGE_ACCUMULATE, &c->ds, &pf, &wp, nullptr, nullptr, nullptr, &hits, lds, (TbFloat4*)c->output.p, (TbFloat4*)c->jittered.p, gridOpt));
+        HIP_TRY(fn(c->stream, WF_STAGE_ACCUMULATE, &c->ds, &pf, &wp, nullptr, nullptr, nullptr, &hits, lds, (TbFloat4*)c->output.p, (TbFloat4*)c->jittered.p,
+            gridOpt));
     }
 }
 
@@ -120,14 +125,16 @@ void renderPooled(tb_context* c, int variant, uint32_t W, uint32_t H, uint32_t f
         }
         const int lds = c->sceneInLds ? 1 : 0;
         HIP_TRY(fn(c->stream, WF_STAGE_POOLED, &c->ds, &pf, &wp, nullptr, nullptr, nullptr, nullptr, lds, nullptr, nullptr, blocks));
-        HIP_TRY(fn(c->stream, WF_STAGE_ACCUMULATE, &c->ds, &pf, &wp, nullptr, nullptr, nullptr, nullptr, lds, (TbFloat4*)c->output.p, (TbFloat4*)c->jittered.p, 2048));
+        HIP_TRY(fn(c->stream, WF_STAGE_ACCUMULATE, &c->ds, &pf, &wp, nullptr, nullptr, nullptr, nullptr, lds, (TbFloat4*)c->output.p, (TbFloat4*)c->jittered.p,
+            2048));
     }
 }
 
 /* compute units of the context's device, asked once */
 int deviceCUs(tb_context* c)
 {
-    if (!c->numCUs && hipDeviceGetAttribute(&c->numCUs, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess) throw std::runtime_error("hipDeviceGetAttribute(multiprocessor count) failed");
+    if (!c->numCUs && hipDeviceGetAttribute(&c->numCUs, hipDeviceAttributeMultiprocessorCount,
+        c->device) != hipSuccess) throw std::runtime_error("hipDeviceGetAttribute(multiprocessor count) failed");
     return c->numCUs;
 }
 
@@ -143,7 +150,8 @@ std::string splitAbortMessage(tb_context* c)
     volatile uint32_t* w = c->splitAbort;
     char buf[512];
     static const char* why[] = {"?", "a traversal wave found nothing to walk", "a shading wave waited for hits", "a queue position stayed full"};
-    snprintf(buf, sizeof buf, "the split-role kernel gave up (%s for spin_limit sleeps; workgroup %u wave %u; state %u %u 0x%x 0x%x; tickets %u, positions %u, shading waves done %u); the frame is incomplete",
+    snprintf(buf, sizeof buf,
+        "the split-role kernel gave up (%s for spin_limit sleeps; workgroup %u wave %u; state %u %u 0x%x 0x%x; tickets %u, positions %u, shading waves done %u); the frame is incomplete",
              why[w[0] < 4 ? w[0] : 0], w[1] >> 8, w[1] & 255u, w[2], w[3], w[4], w[5], w[6], w[7], w[8]);
     for (int i = 0; i < 9; i++) w[i] = 0;
     return buf;
@@ -172,7 +180,8 @@ bool splitLaunchable(tb_context* c, const Variant* v, uint32_t W, uint32_t H, co
     TbSplitParams sp; splitParamsFromOptions(c, sp);
     TbDeviceScene dsProbe = c->ds; dsProbe.nodesC = nullptr; dsProbe.stackOverflow = nullptr; dsProbe.stackOverflowLanes = 0;
     const int64_t cap = opt("split_stack_cap", 0);
-    if (cap > 0 && (uint32_t)cap < c->ds.stackDepth && !c->sceneInLds) { dsProbe.stackDepth = (uint32_t)cap; dsProbe.stackOverflow = (uint32_t*)16; dsProbe.stackOverflowLanes = 0xffffffffu; }
+    if (cap > 0 && (uint32_t)cap < c->ds.stackDepth && !c->sceneInLds) { dsProbe.stackDepth = (uint32_t)cap; dsProbe.stackOverflow = (uint32_t*)16;
+        dsProbe.stackOverflowLanes = 0xffffffffu; }
     TbDeviceTargets probe; memset(&probe, 0, sizeof probe); probe.samples = (TbFloat4*)16; probe.workCounter = (uint32_t*)16; probe.frameGroup = 1;
     int perCU = 0;
     return v->split(c->stream, &dsProbe, &pf, &probe, &sp, W, H, 0, 1, &c->tiles, c->sceneInLds ? 1 : 0, &perCU) == hipSuccess;
@@ -243,7 +252,8 @@ void renderSplit(tb_context* c, const Variant* v, uint32_t W, uint32_t H, uint32
         hipStream_t ptStream = overlap ? c->side[par] : c->stream;
         tg.samples = (TbFloat4*)c->fgSamples[par].p; tg.workCounter = (uint32_t*)c->workCounter.p + par * 128u; c->lastFgPar = (int)par;
         if (overlap) HIP_TRY(hipStreamWaitEvent(ptStream, c->evFold[par], 0)); /* the fold that last read this sample buffer */
-        if (f0 == 0) HIP_TRY(hipEventRecord(c->evKernelStart, ptStream)); /* (the stats words were cleared on the main stream, which the side streams have just been ordered behind) */
+        /* (the stats words were cleared on the main stream, which the side streams have just been ordered behind) */
+        if (f0 == 0) HIP_TRY(hipEventRecord(c->evKernelStart, ptStream));
         TbDeviceScene dsPar = dsL; if (dsPar.stackOverflow) dsPar.stackOverflow += par * overflowHalf;
         HIP_TRY(fn(ptStream, &dsPar, &pf, &tg, &sp, W, H, c->samplesRendered + f0, nf, &c->tiles, lds ? 1 : 0, nullptr));
         if (f0 == 0) { HIP_TRY(hipEventRecord(c->evKernel, ptStream)); c->lastKernelFrames = nf; }
@@ -259,13 +269,17 @@ void fillPlanInput(tb_context* c, const Variant* v, uint32_t W, uint32_t H, uint
 {
     auto opt = [&](const char* k, int64_t d) { auto it = c->options.find(k); return it == c->options.end() ? d : it->second; };
     memset(&in, 0, sizeof in);
-    in.variant_features = v->features; in.variant_waves_hi = v->fnHi ? v->wavesHi : 0u; in.variant_prepass_in_base = (!v->fnHi && v->id == 2) ? 1u : 0u; /* surf: compiled into its only copy */
+    /* surf: compiled into its only copy */
+    in.variant_features = v->features; in.variant_waves_hi = v->fnHi ? v->wavesHi : 0u; in.variant_prepass_in_base = (!v->fnHi && v->id == 2) ? 1u : 0u;
     in.variant_has_wavefront = v->wf ? 1u : 0u; in.variant_has_pooled = v->pooled ? 1u : 0u; in.variant_has_split = v->split ? 1u : 0u;
-    in.scene_in_lds = c->sceneInLds ? 1u : 0u; in.lds_blob_bytes = c->ds.ldsBlobBytes; in.stack_depth = c->ds.stackDepth; in.two_level = c->ds.numInstances ? 1u : 0u;
-    in.has_lights = c->scene.lights.empty() ? 0u : 1u; in.has_compact_nodes = c->ds.nodesC ? 1u : 0u; in.interior_walk_triangle_share = c->interiorWalkTriangleShare;
+    in.scene_in_lds = c->sceneInLds ? 1u : 0u; in.lds_blob_bytes = c->ds.ldsBlobBytes; in.stack_depth = c->ds.stackDepth;
+        in.two_level = c->ds.numInstances ? 1u : 0u;
+    in.has_lights = c->scene.lights.empty() ? 0u : 1u; in.has_compact_nodes = c->ds.nodesC ? 1u : 0u;
+        in.interior_walk_triangle_share = c->interiorWalkTriangleShare;
     in.width = W; in.height = H; in.frames = n; in.max_bounces = s.MaxBounces; in.owned_regions = tb_persistent_grid(W, H, c->tiles);
     in.count_rays = count ? 1u : 0u; in.aov = aov ? 1u : 0u; in.realtime = s.RenderModeRealTime ? 1u : 0u; in.selected_pixel = c->selX != 0xffffffffu ? 1u : 0u;
-    in.pipeline = opt("pipeline", 0); in.frame_group = opt("frame_group", 0); in.high_occupancy = opt("high_occupancy", 1); in.stack_lds_cap = opt("stack_lds_cap", 0);
+    in.pipeline = opt("pipeline", 0); in.frame_group = opt("frame_group", 0); in.high_occupancy = opt("high_occupancy", 1);
+        in.stack_lds_cap = opt("stack_lds_cap", 0);
     in.stack_overflow_max = opt("stack_overflow_max", 24); in.node_layout = opt("node_layout", 0); in.primary_prepass = opt("primary_prepass", 1);
     in.overlap_launches = opt("overlap_launches", 1); in.pooled_samples = opt("pooled_samples", 256ll << 20);
     in.split_trav = opt("split_trav", 4); in.split_shade = opt("split_shade", 0); in.split_stack_cap = opt("split_stack_cap", 0);
@@ -275,7 +289,8 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
 {
     if (!c->hasScene) return fail(c, TB_E_NO_SCENE, "tb_render: no scene loaded");
     if (W == 0 || H == 0) return fail(c, TB_E_INVALID, "tb_render: zero-sized target");
-    if (W > 16384 || H > 16384) return fail(c, TB_E_INVALID, "tb_render: a target has at most 16384 pixels a side (D3D12_REQ_TEXTURE2D_U_OR_V_DIMENSION; pixel indices are 32-bit)");
+    if (W > 16384 || H > 16384) return fail(c, TB_E_INVALID,
+        "tb_render: a target has at most 16384 pixels a side (D3D12_REQ_TEXTURE2D_U_OR_V_DIMENSION; pixel indices are 32-bit)");
     tb_output_settings s; if (settings) s = *settings; else DefaultOutputSettings(s);
     if (W != c->width || H != c->height) {
         size_t bytes = (size_t)W * H * sizeof(TbFloat4);
@@ -289,7 +304,8 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
     if (n == 0) return TB_OK;
     auto opt = [&](const char* k, int64_t d) { auto it = c->options.find(k); return it == c->options.end() ? d : it->second; };
     const bool aov = opt("aov", 0) != 0, count = opt("count_rays", 0) != 0;
-    const int64_t pipeAsked = opt("pipeline", 0), pipe = pipeAsked == 4 ? 0 : pipeAsked; /* 4 = the split-role kernel where it exists, the lock-step kernel (0) elsewhere */
+    /* 4 = the split-role kernel where it exists, the lock-step kernel (0) elsewhere */
+    const int64_t pipeAsked = opt("pipeline", 0), pipe = pipeAsked == 4 ? 0 : pipeAsked;
     c->ds.alphaTest = opt("alpha_test", 0) ? 1u : 0u;
     ensure(c->stats, 16);
     const bool clearStats = c->samplesRendered == 0; /* enqueued below, on the stream of the first path-tracing launch */
@@ -299,11 +315,13 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
     tg.debugCounters = (uint32_t*)c->debugCounters.p;
     if (aov) {
         size_t px = (size_t)W * H;
-        for (int i = 2; i <= 7; i++) { size_t bytes = px * (i == TB_AOV_DEPTH ? 4 : 16); if (c->aov[i].bytes != bytes) { ensure(c->aov[i], bytes); HIP_TRY(hipMemsetAsync(c->aov[i].p, 0, bytes, c->stream)); } }
+        for (int i = 2; i <= 7; i++) { size_t bytes = px * (i == TB_AOV_DEPTH ? 4 : 16); if (c->aov[i].bytes != bytes) { ensure(c->aov[i], bytes);
+            HIP_TRY(hipMemsetAsync(c->aov[i].p, 0, bytes, c->stream)); } }
         tg.aovNormals = (TbFloat4*)c->aov[2].p; tg.aovWorldPos0 = (TbFloat4*)c->aov[3].p; tg.aovWorldPos1 = (TbFloat4*)c->aov[4].p;
         tg.aovCustom = (TbFloat4*)c->aov[5].p; tg.aovDepth = (float*)c->aov[6].p; tg.aovEmissive = (TbFloat4*)c->aov[7].p;
     }
-    if (count) { ensure(c->rayStats, 21 * 8); if (c->samplesRendered == 0) HIP_TRY(hipMemsetAsync(c->rayStats.p, 0, 21 * 8, c->stream)); tg.rayStats = (unsigned long long*)c->rayStats.p; }
+    if (count) { ensure(c->rayStats, 21 * 8); if (c->samplesRendered == 0) HIP_TRY(hipMemsetAsync(c->rayStats.p, 0, 21 * 8, c->stream));
+        tg.rayStats = (unsigned long long*)c->rayStats.p; }
     TbPerFrameConstants pf;
     MakeFrameConstants(c->scene, c->camera, s, c->samplesRendered, timeSeed, c->selX, c->selY, pf);
     uint32_t need = c->sceneFeatures | settingsFeatureMask(c, s, aov);
@@ -314,7 +332,8 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
     c->lastVariant = v->name;
     const int variantIndex = (int)(v - kVariants);
     const bool twoLevel = c->ds.numInstances != 0; /* instanced scene (flatten_instances = 0): pipeline 0 only */
-    if (twoLevel && pipe != 0) return fail(c, TB_E_UNSUPPORTED, "tb_render: two-level (instanced) scenes are not supported by pipelines 1-3; use pipeline 0 or flatten_instances = 1");
+    if (twoLevel && pipe != 0) return fail(c, TB_E_UNSUPPORTED,
+        "tb_render: two-level (instanced) scenes are not supported by pipelines 1-3; use pipeline 0 or flatten_instances = 1");
     /* WHAT to launch is decided by a pure function of scene statistics, call size and options (launch_plan.h; tests/test_launch_plan.py
      * walks its branches on the CPU); what follows executes the plan. */
     tb_plan_input pin; fillPlanInput(c, v, W, H, n, s, aov, count, pin);
@@ -327,15 +346,18 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
     pt_variant_fn launch = plan.high_occupancy_copy ? v->fnHi : v->fn;
     size_t overflowHalf = 0;
     TbDeviceScene dsLaunch = c->ds; dsLaunch.stackOverflow = nullptr; dsLaunch.stackOverflowLanes = 0;
-    if (plan.stack_overflow_entries) { /* split stack: the deepest entries in global memory, one column per lane of the resident grid (at most 2 x 8 workgroups per CU) */
+    /* split stack: the deepest entries in global memory, one column per lane of the resident grid (at most 2 x 8 workgroups per CU) */
+    if (plan.stack_overflow_entries) {
         const int numCUs = deviceCUs(c);
         const uint32_t lanes = 2u * 8u * (uint32_t)numCUs * 256u;
-        ensure(c->stackOverflow, (size_t)plan.stack_overflow_entries * lanes * 4 * 2); /* two halves: consecutive batches of a call overlap on the two side streams */
+        /* two halves: consecutive batches of a call overlap on the two side streams */
+        ensure(c->stackOverflow, (size_t)plan.stack_overflow_entries * lanes * 4 * 2);
         overflowHalf = (size_t)plan.stack_overflow_entries * lanes;
         dsLaunch.stackDepth = plan.stack_lds_entries; dsLaunch.stackOverflow = (uint32_t*)c->stackOverflow.p; dsLaunch.stackOverflowLanes = lanes;
     }
     if (plan.full_variant && v != &kVariants[kNumVariants - 1]) { v = &kVariants[kNumVariants - 1]; launch = v->fn; c->lastVariant = v->name; }
-    if (opt("node_layout", 0) == 1 && !twoLevel && !c->sceneInLds && !c->ds.nodesC && !c->compactTried) { /* layout C on first demand; the plan is made again with what came of it */
+    /* layout C on first demand; the plan is made again with what came of it */
+    if (opt("node_layout", 0) == 1 && !twoLevel && !c->sceneInLds && !c->ds.nodesC && !c->compactTried) {
         ensureCompactNodes(c); dsLaunch.nodesC = c->ds.nodesC; dsLaunch.quant = c->ds.quant;
         pin.has_compact_nodes = c->ds.nodesC ? 1u : 0u; PlanLaunch(pin, plan);
     }
@@ -348,15 +370,18 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
          * without (it also pays for buffers and scratch, untimed), then with / without alternately until each side has two timed samples
          * -- the first launch of a call, with the events the context records anyway -- and the faster way is kept from then on */
         tb_context::PrepassTrial& t = c->prepassTrial;
-        const uint64_t key = ((uint64_t)W << 48) ^ ((uint64_t)H << 32) ^ ((uint64_t)n << 12) ^ ((uint64_t)s.MaxBounces << 4) ^ ((uint64_t)c->sceneGeneration << 24) ^ (uint64_t)(uintptr_t)launch;
+        const uint64_t key = ((uint64_t)W << 48) ^ ((uint64_t)H << 32) ^ ((uint64_t)n << 12) ^ ((uint64_t)s.MaxBounces << 4) ^ ((uint64_t)c->sceneGeneration <<
+            24) ^ (uint64_t)(uintptr_t)launch;
         if (t.key != key) { t = tb_context::PrepassTrial(); t.key = key; }
         if (t.pending) {
             /* the first launch of the call before this one: finished long ago unless the caller renders asynchronously -- then the
              * sample is skipped and that step of the trial repeated (tb_render_async enqueues, it never waits: no hipEventSynchronize
              * here); and only if no other render has recorded the two events since (t.stamp, below) */
             float ms = 0;
-            const bool mine = t.stamp == c->kernelEventStamp && hipEventQuery(c->evKernel) == hipSuccess && hipEventElapsedTime(&ms, c->evKernelStart, c->evKernel) == hipSuccess && ms > 0;
-            if (mine) { float& best = t.pending == 1 ? t.msWith : t.msWithout; best = best > 0 ? std::min(best, ms) : ms; (t.pending == 1 ? t.nWith : t.nWithout)++; }
+            const bool mine = t.stamp == c->kernelEventStamp && hipEventQuery(c->evKernel) == hipSuccess && hipEventElapsedTime(&ms, c->evKernelStart,
+                c->evKernel) == hipSuccess && ms > 0;
+            if (mine) { float& best = t.pending == 1 ? t.msWith : t.msWithout; best = best > 0 ? std::min(best, ms) : ms;
+                (t.pending == 1 ? t.nWith : t.nWithout)++; }
             else t.calls = t.pending == 1 ? 1 : 2; /* repeat the step whose sample was lost */
             if (t.nWith >= 2 && t.nWithout >= 2) t.keep = t.msWith < 0.99f * t.msWithout; /* the faster of two samples per side */
             t.pending = 0;
@@ -379,7 +404,8 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
      * device-bound two-call spans between their ends are known, then one at a time until two more are, then the faster way.  A caller that waits for
      * every call never produces a device-bound interval and stays overlapped (for it the two ways are the same). */
     const int64_t overlapOpt = opt("overlap_launches", 1);
-    const uint64_t callKey = ((uint64_t)W << 48) ^ ((uint64_t)H << 32) ^ ((uint64_t)n << 12) ^ ((uint64_t)s.MaxBounces << 4) ^ ((uint64_t)c->sceneGeneration << 24) ^ (uint64_t)(uintptr_t)launch ^ (prepass ? 1u : 0u);
+    const uint64_t callKey = ((uint64_t)W << 48) ^ ((uint64_t)H << 32) ^ ((uint64_t)n << 12) ^ ((uint64_t)s.MaxBounces << 4) ^ ((uint64_t)c->sceneGeneration <<
+        24) ^ (uint64_t)(uintptr_t)launch ^ (prepass ? 1u : 0u);
     const bool trialOverlap = overlap && overlapOpt == 1 && (v->features & (PT_FEAT_SPECULAR | PT_FEAT_TEXTURES | PT_FEAT_SSS | PT_FEAT_MIX)) != 0;
     if (trialOverlap) {
         tb_context::OverlapTrial& t = c->overlapTrial;
@@ -387,19 +413,22 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
         /* spans that have become known.  A span is TWO calls long -- (end of call i) - (end of call i - 2), halved: overlapped launches finish in
          * pairs (two are in flight at once: the ends of consecutive calls are alternately 2 ms and 86 ms apart on the van-class 4K scene) */
         for (uint64_t i = c->callCount >= 5 ? c->callCount - 5 : 2; i + 1 < c->callCount; i++) {
-            tb_context::CallRec& r = c->callRec[i & 7u]; const tb_context::CallRec& q = c->callRec[(i - 1) & 7u]; const tb_context::CallRec& nx = c->callRec[(i + 1) & 7u];
+            tb_context::CallRec& r = c->callRec[i & 7u]; const tb_context::CallRec& q = c->callRec[(i - 1) & 7u];
+                const tb_context::CallRec& nx = c->callRec[(i + 1) & 7u];
             if (r.used || r.key != callKey || !c->evCallEnd[i & 7u] || !c->evCallEnd[(i - 2) & 7u]) continue;
             if (hipEventQuery(c->evCallEnd[i & 7u]) != hipSuccess) continue;
             r.used = true;
             float ms = 0;
             /* ... and call i must not be the last of a burst (the call after it was enqueued while it ran): the last launch has the chip to itself */
-            if (r.deviceBound && r.settled && q.deviceBound && q.settled && q.key == callKey && q.mode == r.mode && (r.mode == 0 || r.mode == 1) && nx.deviceBound && nx.key == callKey && nx.mode == r.mode
+            if (r.deviceBound && r.settled && q.deviceBound && q.settled && q.key == callKey && q.mode == r.mode && (r.mode == 0 || r.mode == 1) &&
+                nx.deviceBound && nx.key == callKey && nx.mode == r.mode
                 && hipEventElapsedTime(&ms, c->evCallEnd[(i - 2) & 7u], c->evCallEnd[i & 7u]) == hipSuccess && ms > 0) {
                 ms *= 0.5f; t.best[r.mode] = t.n[r.mode] ? std::min(t.best[r.mode], ms) : ms; t.n[r.mode]++;
             }
         }
         if (t.phase == 0 && t.n[0] >= 2) t.phase = 1;
-        if (t.phase == 1 && t.n[1] >= 2) { t.phase = 2; t.keep = t.best[0] < 1.02f * t.best[1]; } /* taking turns has to win by 2 %: short bursts flatter it (their last launch runs alone) */
+        /* taking turns has to win by 2 %: short bursts flatter it (their last launch runs alone) */
+        if (t.phase == 1 && t.n[1] >= 2) { t.phase = 2; t.keep = t.best[0] < 1.02f * t.best[1]; }
         overlap = t.phase == 0 ? true : (t.phase == 1 ? false : t.keep);
     }
     c->lastOverlap = overlap ? 1 : 0;
@@ -489,7 +518,8 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
                         ensure(c->fgHits[par], pixels * batch * 32);
                         HIP_TRY(hipMemsetAsync(c->fgHits[par].p, 0, pixels * batch * 32, overlap ? c->side[par] : c->stream));
                     }
-                const void* key = (const void*)((uintptr_t)launch ^ (1u | (dsLaunch.stackOverflow ? 2u : 0u) | (dsLaunch.nodesC ? 4u : 0u))); /* one kernel per (split stack, node layout) */
+                /* one kernel per (split stack, node layout) */
+                const void* key = (const void*)((uintptr_t)launch ^ (1u | (dsLaunch.stackOverflow ? 2u : 0u) | (dsLaunch.nodesC ? 4u : 0u)));
                 if (std::find(c->warmedLaunchers.begin(), c->warmedLaunchers.end(), key) == c->warmedLaunchers.end()) {
                     for (uint32_t par = 0; par < 2u; par++) warmFrameGroupForm(par, true);
                     c->warmedLaunchers.push_back(key);
@@ -504,16 +534,20 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
                      * items at the SMALLEST resident grid the launcher may choose (2 per CU), so that the rows of any grid hold the whole list
                      * several times over and a workgroup whose row is full (it retires) never strands work */
                     const int numCUs = deviceCUs(c);
-                    const uint64_t items = regions * (((uint64_t)nf + tg.frameGroup - 1) / tg.frameGroup), wgs = 16ull * (uint64_t)numCUs, fewest = 2ull * (uint64_t)numCUs;
+                    const uint64_t items = regions * (((uint64_t)nf + tg.frameGroup - 1) / tg.frameGroup), wgs = 16ull * (uint64_t)numCUs,
+                        fewest = 2ull * (uint64_t)numCUs;
                     tg.slotLogCap = (uint32_t)std::min<uint64_t>(65534, 8 * ((items + fewest - 1) / fewest) + 16); /* 16 bits of an entry's tag */
                     tg.launchEpoch = ++c->launchEpoch; c->lastSlotLogCap = (int)tg.slotLogCap;
-                    if (c->fgSlotLog[par].bytes < wgs * tg.slotLogCap * 8) { HIP_TRY(hipStreamSynchronize(c->side[par])); HIP_TRY(hipStreamSynchronize(c->stream)); ensure(c->fgSlotLog[par], wgs * tg.slotLogCap * 8); }
+                    if (c->fgSlotLog[par].bytes < wgs * tg.slotLogCap * 8) { HIP_TRY(hipStreamSynchronize(c->side[par]));
+                        HIP_TRY(hipStreamSynchronize(c->stream)); ensure(c->fgSlotLog[par], wgs * tg.slotLogCap * 8); }
                     tg.slotLog = (unsigned long long*)c->fgSlotLog[par].p;
                 }
                 if (prepass) tg.primaryHits = (unsigned long long*)c->fgHits[par].p;
                 if (overlap) HIP_TRY(hipStreamWaitEvent(ptStream, c->evFold[par], 0)); /* the fold that last read this sample buffer */
-                if (f0 == 0) { if (clearStats && overlap) HIP_TRY(hipMemsetAsync(c->stats.p, 0, 16, ptStream)); HIP_TRY(hipEventRecord(c->evKernelStart, ptStream)); }
-                TbDeviceScene dsPar = dsLaunch; if (dsPar.stackOverflow) dsPar.stackOverflow += par * overflowHalf; /* the launch before may still be draining on the other stream */
+                if (f0 == 0) { if (clearStats && overlap) HIP_TRY(hipMemsetAsync(c->stats.p, 0, 16, ptStream));
+                    HIP_TRY(hipEventRecord(c->evKernelStart, ptStream)); }
+                /* the launch before may still be draining on the other stream */
+                TbDeviceScene dsPar = dsLaunch; if (dsPar.stackOverflow) dsPar.stackOverflow += par * overflowHalf;
                 HIP_TRY(launch(ptStream, &dsPar, &pf, &tg, W, H, c->samplesRendered + f0, nf, &c->tiles, c->sceneInLds ? 1 : 0, 0, 0));
                 if (f0 == 0) { HIP_TRY(hipEventRecord(c->evKernel, ptStream)); c->lastKernelFrames = nf; }
                 if (overlap) { HIP_TRY(hipEventRecord(c->evPt[par], ptStream)); HIP_TRY(hipStreamWaitEvent(c->stream, c->evPt[par], 0)); }
@@ -522,7 +556,8 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
             }
         }
     }
-    if (!c->lastKernelFrames) { HIP_TRY(hipEventRecord(c->evKernel, c->stream)); c->lastKernelFrames = n; } /* one launch (or one pipeline) for the whole call */
+    /* one launch (or one pipeline) for the whole call */
+    if (!c->lastKernelFrames) { HIP_TRY(hipEventRecord(c->evKernel, c->stream)); c->lastKernelFrames = n; }
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
     if (!c->evCallEnd[c->callCount & 7u]) HIP_TRY(hipEventCreate(&c->evCallEnd[c->callCount & 7u]));
     HIP_TRY(hipEventRecord(c->evCallEnd[c->callCount & 7u], c->stream)); c->callCount++; /* the end of this render, for the overlap trial above */

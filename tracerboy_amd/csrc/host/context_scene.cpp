@@ -17,7 +17,8 @@ uint32_t sceneFeatureMask(const HostScene& s)
     if (!s.envMap.empty()) f |= PT_FEAT_ENV;
     for (const TbMaterial& m : s.materials) {
         if ((m.Flags & TB_MAT_NO_SPECULAR) == 0 && (m.Flags & TB_MAT_MIX) == 0) f |= PT_FEAT_SPECULAR;
-        if (m.albedoIndex != TB_INVALID_TEXTURE || m.emissiveIndex != TB_INVALID_TEXTURE || m.specularMapIndex != TB_INVALID_TEXTURE || m.normalMapIndex != TB_INVALID_TEXTURE) f |= PT_FEAT_TEXTURES | PT_FEAT_SPECULAR;
+        if (m.albedoIndex != TB_INVALID_TEXTURE || m.emissiveIndex != TB_INVALID_TEXTURE || m.specularMapIndex != TB_INVALID_TEXTURE ||
+            m.normalMapIndex != TB_INVALID_TEXTURE) f |= PT_FEAT_TEXTURES | PT_FEAT_SPECULAR;
         if (m.Flags & TB_MAT_SUBSURFACE_SCATTER) f |= PT_FEAT_SSS;
         if (m.Flags & TB_MAT_MIX) f |= PT_FEAT_MIX;
     }
@@ -82,7 +83,8 @@ void reorderNodes(HostScene& s, int order_, uint32_t topLevels)
             level.assign(1, blocks.back()); blocks.pop_back(); below.clear();
             for (uint32_t d = 0; d < h && !level.empty(); d++) {
                 next.clear();
-                for (uint32_t x : level) { order.push_back(x); const TbNodeB& nd = s.nodesB[x]; if (inner(nd.left)) next.push_back(nd.left); if (inner(nd.right)) next.push_back(nd.right); }
+                for (uint32_t x : level) { order.push_back(x); const TbNodeB& nd = s.nodesB[x]; if (inner(nd.left)) next.push_back(nd.left);
+                    if (inner(nd.right)) next.push_back(nd.right); }
                 level.swap(next);
             }
             for (size_t i = level.size(); i-- > 0;) blocks.push_back(level[i]); /* leftmost block below comes next */
@@ -92,10 +94,12 @@ void reorderNodes(HostScene& s, int order_, uint32_t topLevels)
         uint32_t depth = 0;
         while (!level.empty() && (order_ == 0 || depth < topLevels)) { /* orders 0, 2, 5 */
             std::vector<uint32_t> next;
-            for (uint32_t x : level) { order.push_back(x); const TbNodeB& nd = s.nodesB[x]; if (inner(nd.left)) next.push_back(nd.left); if (inner(nd.right)) next.push_back(nd.right); }
+            for (uint32_t x : level) { order.push_back(x); const TbNodeB& nd = s.nodesB[x]; if (inner(nd.left)) next.push_back(nd.left);
+                if (inner(nd.right)) next.push_back(nd.right); }
             level.swap(next); depth++;
         }
-        if (order_ == 5) { if ((order.size() & 1u) && !level.empty()) order.push_back(PAD); for (uint32_t x : level) order.push_back(x); for (uint32_t x : level) pairDfs(x); }
+        if (order_ == 5) { if ((order.size() & 1u) && !level.empty()) order.push_back(PAD); for (uint32_t x : level) order.push_back(x);
+            for (uint32_t x : level) pairDfs(x); }
         else for (uint32_t x : level) dfs(x); /* order 2: the subtrees hanging below the breadth-first top */
     }
     for (uint32_t i = 0; i < (uint32_t)order.size(); i++) if (order[i] != PAD) newIndex[order[i]] = i;
@@ -131,7 +135,8 @@ void BuildBvhGpu(tb_context* c, HostScene& s, uint32_t treeletPasses)
         const size_t nB = N > 1 ? N - 1 : 1, scratchBytes = bvh_gpu_scratch_bytes(N);
         ensure(dA, total); ensure(dNodes, nB * sizeof(TbNodeB)); ensure(dTris, (size_t)N * sizeof(TbTriB)); ensure(dScratch, scratchBytes); ensure(dHeight, 4);
         HIP_TRY(hipMemsetAsync(dNodes.p, 0, nB * sizeof(TbNodeB), c->stream));
-        HIP_TRY(bvh_gpu_build(c->stream, (const float*)dPos.p, (const uint32_t*)dIdx.p, (const uint32_t*)dGeo.p, (const uint32_t*)dPrim.p, (const uint32_t*)dFlag.p, N,
+        HIP_TRY(bvh_gpu_build(c->stream, (const float*)dPos.p, (const uint32_t*)dIdx.p, (const uint32_t*)dGeo.p, (const uint32_t*)dPrim.p,
+            (const uint32_t*)dFlag.p, N,
                               treeletPasses, (uint8_t*)dScratch.p, scratchBytes, (uint8_t*)dA.p, (TbNodeB*)dNodes.p, (TbTriB*)dTris.p, (uint32_t*)dHeight.p));
         s.bvhA.resize((size_t)total); s.nodesB.resize(nB); s.trisB.resize(N);
         HIP_TRY(hipMemcpy(s.bvhA.data(), dA.p, total, hipMemcpyDeviceToHost));
@@ -154,12 +159,14 @@ void BuildBvhGpu(tb_context* c, HostScene& s, uint32_t treeletPasses)
 void buildCompactNodes(const HostScene& s, std::vector<TbNodeC>& out, TbQuantFrame& q, uint32_t nodeUnits)
 {
     double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-    auto grow = [&](const float* cc, const float* hh, int k) { for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], (double)cc[a * 2 + k] - hh[a * 2 + k]); hi[a] = std::max(hi[a], (double)cc[a * 2 + k] + hh[a * 2 + k]); } };
+    auto grow = [&](const float* cc, const float* hh, int k) { for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], (double)cc[a * 2 + k] - hh[a * 2 + k]);
+        hi[a] = std::max(hi[a], (double)cc[a * 2 + k] + hh[a * 2 + k]); } };
     auto boxOf = [](const TbNodeB& n, float* cc, float* hh) { /* [axis * 2 + child] */
         cc[0] = n.cx[0]; cc[1] = n.cx[1]; cc[2] = n.cy[0]; cc[3] = n.cy[1]; cc[4] = n.cz[0]; cc[5] = n.cz[1];
         hh[0] = n.hx[0]; hh[1] = n.hx[1]; hh[2] = n.hy[0]; hh[3] = n.hy[1]; hh[4] = n.hz[0]; hh[5] = n.hz[1];
     };
-    auto isPad = [](const TbNodeB& n) { return n.left == TB_BVH_LEAF_FLAG && n.right == TB_BVH_LEAF_FLAG && n.hx[0] == 0.0f && n.hx[1] == 0.0f && n.cx[0] == 0.0f && n.cx[1] == 0.0f; };
+    auto isPad = [](const TbNodeB& n) { return n.left == TB_BVH_LEAF_FLAG && n.right == TB_BVH_LEAF_FLAG && n.hx[0] == 0.0f && n.hx[1] == 0.0f && n.cx[0] ==
+        0.0f && n.cx[1] == 0.0f; };
     for (const TbNodeB& n : s.nodesB) { if (isPad(n)) continue; float cc[6], hh[6]; boxOf(n, cc, hh); grow(cc, hh, 0); grow(cc, hh, 1); }
     double ext = 0; for (int a = 0; a < 3; a++) ext = std::max(ext, hi[a] - lo[a]);
     if (!(ext > 0)) ext = 1.0;
@@ -170,7 +177,8 @@ void buildCompactNodes(const HostScene& s, std::vector<TbNodeC>& out, TbQuantFra
         /* the origin is an fp32 number: step it DOWN until two cells of margin are really there (a scene far from the coordinate origin has
          * ulps larger than the margin; if they are larger than the grid can absorb, the box test below refuses the layout and the render
          * stays with layout B) */
-        for (int guard = 0; guard < 64 && !((double)q.origin[a] + 2.0 * (double)q.cell[a] <= lo[a]); guard++) q.origin[a] = std::nextafter(q.origin[a], -std::numeric_limits<float>::infinity());
+        for (int guard = 0; guard < 64 && !((double)q.origin[a] + 2.0 * (double)q.cell[a] <= lo[a]); guard++) q.origin[a] = std::nextafter(q.origin[a],
+            -std::numeric_limits<float>::infinity());
     }
     out.assign(s.nodesB.size(), TbNodeC{});
     auto ref = [nodeUnits](uint32_t r) { return (r & TB_BVH_LEAF_FLAG) ? (TB_BVH_LEAF_FLAG | ((r & ~TB_BVH_LEAF_FLAG) * 3u)) : r * nodeUnits; };
@@ -180,7 +188,8 @@ void buildCompactNodes(const HostScene& s, std::vector<TbNodeC>& out, TbQuantFra
         if (isPad(n)) continue;
         float cc[6], hh[6]; boxOf(n, cc, hh);
         for (int a = 0; a < 3; a++) for (int k = 0; k < 2; k++) {
-            const double bl = ((double)cc[a * 2 + k] - hh[a * 2 + k] - q.origin[a]) / q.cell[a], bh = ((double)cc[a * 2 + k] + hh[a * 2 + k] - q.origin[a]) / q.cell[a];
+            const double bl = ((double)cc[a * 2 + k] - hh[a * 2 + k] - q.origin[a]) / q.cell[a],
+                bh = ((double)cc[a * 2 + k] + hh[a * 2 + k] - q.origin[a]) / q.cell[a];
             long ql = (long)std::floor(bl - 0.125), qh = (long)std::ceil(bh + 0.125);
             if (ql < 0 || qh > 65535 || !(bl == bl) || !(bh == bh)) throw std::runtime_error("compact nodes: a box lies outside the quantisation grid");
             const long cq = (ql + qh) >> 1, hq = qh - cq; /* cq - hq <= ql and cq + hq == qh */
@@ -210,15 +219,18 @@ void BuildTlasGpu(tb_context* c, HostScene& s, const std::vector<float>& blasBox
 {
     const uint32_t M = (uint32_t)s.instances.size();
     std::vector<float> o2w(12ull * M), w2o(12ull * M); std::vector<uint32_t> blas(M), base(M);
-    for (uint32_t i = 0; i < M; i++) { memcpy(&o2w[12ull * i], s.instances[i].objectToWorld, 48); memcpy(&w2o[12ull * i], s.instances[i].worldToObject, 48); blas[i] = s.instances[i].blas; base[i] = s.instances[i].hitGroupBase; }
+    for (uint32_t i = 0; i < M; i++) { memcpy(&o2w[12ull * i], s.instances[i].objectToWorld, 48); memcpy(&w2o[12ull * i], s.instances[i].worldToObject, 48);
+        blas[i] = s.instances[i].blas; base[i] = s.instances[i].hitGroupBase; }
     const size_t total = 16 + 32 * (2ull * M - 1) + 116ull * M, scratchBytes = bvh_gpu_tlas_scratch_bytes(M);
     DevBuf dO, dW, dB, dH, dBox, dScratch, dA, dTop, dWords;
     auto up = [&](DevBuf& b, const void* p, size_t bytes) { ensure(b, bytes); HIP_TRY(hipMemcpyAsync(b.p, p, bytes, hipMemcpyHostToDevice, c->stream)); };
     try {
-        up(dO, o2w.data(), o2w.size() * 4); up(dW, w2o.data(), w2o.size() * 4); up(dB, blas.data(), 4ull * M); up(dH, base.data(), 4ull * M); up(dBox, blasBoxes.data(), blasBoxes.size() * 4);
+        up(dO, o2w.data(), o2w.size() * 4); up(dW, w2o.data(), w2o.size() * 4); up(dB, blas.data(), 4ull * M); up(dH, base.data(), 4ull * M);
+            up(dBox, blasBoxes.data(), blasBoxes.size() * 4);
         ensure(dScratch, scratchBytes); ensure(dA, total); ensure(dTop, std::max<size_t>(1, M - 1) * sizeof(TbNodeB)); ensure(dWords, 8);
         HIP_TRY(hipMemsetAsync(dA.p, 0, total, c->stream));
-        HIP_TRY(bvh_gpu_build_tlas(c->stream, M, (const float*)dO.p, (const float*)dW.p, (const uint32_t*)dB.p, (const uint32_t*)dH.p, (const float*)dBox.p, (uint8_t*)dScratch.p, scratchBytes,
+        HIP_TRY(bvh_gpu_build_tlas(c->stream, M, (const float*)dO.p, (const float*)dW.p, (const uint32_t*)dB.p, (const uint32_t*)dH.p, (const float*)dBox.p,
+            (uint8_t*)dScratch.p, scratchBytes,
                                    (uint8_t*)dA.p, (TbNodeB*)dTop.p, (uint32_t*)dWords.p, (uint32_t*)dWords.p + 1));
         s.tlasA.resize(total); top.assign(M > 1 ? M - 1 : 0, TbNodeB{});
         uint32_t words[2];
@@ -240,27 +252,32 @@ void finalizeScene(tb_context* c, bool build)
     {   /* share of the triangles whose material sends a path on an interior walk (the pre-pass policy in renderImpl) */
         uint64_t walks = 0;
         if (s.instances.empty())
-            for (uint32_t g : s.triGeometry) { if (g < s.hitGroups.size()) { const uint32_t m = s.hitGroups[g].MaterialIndex; if (m < s.materials.size() && (s.materials[m].Flags & TB_MAT_SUBSURFACE_SCATTER)) walks++; } }
+            for (uint32_t g : s.triGeometry) { if (g < s.hitGroups.size()) { const uint32_t m = s.hitGroups[g].MaterialIndex;
+                if (m < s.materials.size() && (s.materials[m].Flags & TB_MAT_SUBSURFACE_SCATTER)) walks++; } }
         c->interiorWalkTriangleShare = s.triGeometry.empty() ? 0.0f : (float)((double)walks / (double)s.triGeometry.size());
     }
     auto opt = [&](const char* k, int64_t d) { auto it = c->options.find(k); return it == c->options.end() ? d : it->second; };
     const int64_t builder = opt("bvh_builder", 0);
     const bool twoLevel = !s.instances.empty();
     if (build) {
-    if (twoLevel && (builder == 2 || builder == 4)) /* every bottom-level structure and the top level on the GPU (GpuBVH2Builder.cpp:498-501: the same passes, no treelets at the top) */
+    /* every bottom-level structure and the top level on the GPU (GpuBVH2Builder.cpp:498-501: the same passes, no treelets at the top) */
+    if (twoLevel && (builder == 2 || builder == 4))
         BuildBvhWith(s, [&](HostScene& one) { BuildBvhGpu(c, one, builder == 4 ? 3u : 0u); },
-                     [&](HostScene& all, const std::vector<float>& boxes, std::vector<TbNodeB>& top, uint32_t& rootRef, uint32_t& depth) { BuildTlasGpu(c, all, boxes, top, rootRef, depth); });
+                     [&](HostScene& all, const std::vector<float>& boxes, std::vector<TbNodeB>& top, uint32_t& rootRef, uint32_t& depth) { BuildTlasGpu(c, all,
+                         boxes, top, rootRef, depth); });
     else if (twoLevel) BuildBvh(s, (int)builder);
     else if (builder == 2 || builder == 4) BuildBvhGpu(c, s, builder == 4 ? 3u : 0u);
     else BuildBvh(s, (int)builder);
-    if (!twoLevel) reorderNodes(s, (int)opt("node_order", 2), (uint32_t)opt("node_order_top_levels", 10)); /* measured on the 870 k scene: 0 -> 2258, 1 -> 2283, 2 (10 levels) -> 2300 Msamples/s */
+    /* measured on the 870 k scene: 0 -> 2258, 1 -> 2283, 2 (10 levels) -> 2300 Msamples/s */
+    if (!twoLevel) reorderNodes(s, (int)opt("node_order", 2), (uint32_t)opt("node_order_top_levels", 10));
     }
     c->camera = s.camera;
     releaseScene(c);
     TbDeviceScene& d = c->ds;
     if (s.nodesB.size() > 0x7fffffffull / 5 || s.trisB.size() > 0x7fffffffull / 3) throw std::runtime_error("scene too large for 31-bit device child refs");
     /* device child refs: offsets in 16-B units (pt_scene.h) */
-    auto deviceRef = [](uint32_t ref, uint32_t nodeUnits) { return (ref & TB_BVH_LEAF_FLAG) ? (TB_BVH_LEAF_FLAG | ((ref & ~TB_BVH_LEAF_FLAG) * 3u)) : ref * nodeUnits; };
+    auto deviceRef = [](uint32_t ref,
+        uint32_t nodeUnits) { return (ref & TB_BVH_LEAF_FLAG) ? (TB_BVH_LEAF_FLAG | ((ref & ~TB_BVH_LEAF_FLAG) * 3u)) : ref * nodeUnits; };
     {
         std::vector<TbNodeB> dev(s.nodesB);
         /* two-level scenes: the first M - 1 nodes are the top level, whose leaf refs address 64-B instance records (4 units) */
@@ -268,14 +285,17 @@ void finalizeScene(tb_context* c, bool build)
         auto topRef = [](uint32_t ref) { return (ref & TB_BVH_LEAF_FLAG) ? (TB_BVH_LEAF_FLAG | ((ref & ~TB_BVH_LEAF_FLAG) * 4u)) : ref * 4u; };
         for (size_t i = 0; i < dev.size(); i++) {
             TbNodeB& nd = dev[i];
-            if (i < topNodes) { nd.left = topRef(nd.left); nd.right = topRef(nd.right); } else { nd.left = deviceRef(nd.left, 4); nd.right = deviceRef(nd.right, 4); }
+            if (i < topNodes) { nd.left = topRef(nd.left); nd.right = topRef(nd.right); } else { nd.left = deviceRef(nd.left, 4);
+                nd.right = deviceRef(nd.right, 4); }
         }
         d.nodes = upload(c, dev);
     }
     d.tris = upload(c, s.trisB);
     d.nodesC = nullptr; c->compactTried = false; /* layout C is built when a render or trace first asks for it (ensureCompactNodes) */
-    d.rootRef = twoLevel ? ((s.rootRefB & TB_BVH_LEAF_FLAG) ? (TB_BVH_LEAF_FLAG | ((s.rootRefB & ~TB_BVH_LEAF_FLAG) * 4u)) : s.rootRefB * 4u) : deviceRef(s.rootRefB, 4); /* 0 or LEAF|0: the same in both images */ d.numNodes = (uint32_t)s.nodesB.size(); d.numTris = (uint32_t)s.trisB.size();
-    { const TbAabbNode* root = (const TbAabbNode*)((twoLevel ? s.tlasA.data() : s.bvhA.data()) + 16); memcpy(d.rootCenter, root->center, 12); memcpy(d.rootHalf, root->halfDim, 12); }
+    d.rootRef = twoLevel ? ((s.rootRefB & TB_BVH_LEAF_FLAG) ? (TB_BVH_LEAF_FLAG | ((s.rootRefB & ~TB_BVH_LEAF_FLAG) * 4u)) : s.rootRefB * 4u) :
+        deviceRef(s.rootRefB, 4); /* 0 or LEAF|0: the same in both images */ d.numNodes = (uint32_t)s.nodesB.size(); d.numTris = (uint32_t)s.trisB.size();
+    { const TbAabbNode* root = (const TbAabbNode*)((twoLevel ? s.tlasA.data() : s.bvhA.data()) + 16); memcpy(d.rootCenter, root->center, 12);
+        memcpy(d.rootHalf, root->halfDim, 12); }
     {   /* instances in their device form: the bottom-level root as a device child ref */
         std::vector<TbInstanceB> devInst(s.instancesB);
         for (TbInstanceB& ib : devInst) ib.blasRootRef = deviceRef(ib.blasRootRef, 4);
@@ -284,7 +304,8 @@ void finalizeScene(tb_context* c, bool build)
     /* shading records in their 16-B aligned device form (pt_scene.h) */
     std::vector<TbDevHitGroup> devHit(s.hitGroups.size());
     for (size_t i = 0; i < devHit.size(); i++) {
-        if (s.hitGroups[i].VertexBufferOffset % 32 || s.hitGroups[i].IndexBufferOffset % 4) throw std::runtime_error("hit group buffer offsets must be vertex-/index-aligned");
+        if (s.hitGroups[i].VertexBufferOffset % 32 || s.hitGroups[i].IndexBufferOffset % 4)
+            throw std::runtime_error("hit group buffer offsets must be vertex-/index-aligned");
         devHit[i] = TbDevHitGroup{s.hitGroups[i].MaterialIndex, s.hitGroups[i].VertexBufferOffset / 4, s.hitGroups[i].IndexBufferOffset / 4, 0};
     }
     std::vector<TbDevMaterial> devMat(s.materials.size());
@@ -309,8 +330,10 @@ void finalizeScene(tb_context* c, bool build)
     /* whole-scene LDS image */
     {
         std::vector<uint8_t> blob;
-        auto put = [&](const void* p, size_t bytes) { while (blob.size() % 16) blob.push_back(0); uint32_t off = (uint32_t)blob.size(); const uint8_t* b = (const uint8_t*)p; blob.insert(blob.end(), b, b + bytes); return off; };
-        auto ldsRef = [](uint32_t ref) { return (ref & TB_BVH_LEAF_FLAG) ? (TB_BVH_LEAF_FLAG | ((ref & ~TB_BVH_LEAF_FLAG) * 3u * TB_LDS_TRI_COPIES)) : ref * (TB_LDS_NODE_STRIDE / 16); };
+        auto put = [&](const void* p, size_t bytes) { while (blob.size() % 16) blob.push_back(0); uint32_t off = (uint32_t)blob.size();
+            const uint8_t* b = (const uint8_t*)p; blob.insert(blob.end(), b, b + bytes); return off; };
+        auto ldsRef = [](uint32_t ref) { return (ref & TB_BVH_LEAF_FLAG) ? (TB_BVH_LEAF_FLAG | ((ref & ~TB_BVH_LEAF_FLAG) * 3u * TB_LDS_TRI_COPIES)) : ref *
+            (TB_LDS_NODE_STRIDE / 16); };
         {   /* nodes TB_LDS_NODE_STRIDE apart (pt_scene.h) */
             std::vector<uint8_t> padded(s.nodesB.size() * TB_LDS_NODE_STRIDE, 0);
             for (size_t i = 0; i < s.nodesB.size(); i++) {

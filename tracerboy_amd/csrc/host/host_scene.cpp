@@ -171,7 +171,8 @@ inline bool usable(const PbrtMesh& mesh)
 {
     if (mesh.index.empty() || mesh.vertex.empty()) return false;
     const size_t nv = mesh.vertex.size();
-    for (uint32_t i : mesh.index) if (i >= nv) throw std::runtime_error("mesh index " + std::to_string(i) + " is beyond its " + std::to_string(nv) + " vertices");
+    for (uint32_t i : mesh.index) if (i >= nv) throw std::runtime_error("mesh index " + std::to_string(i) + " is beyond its " + std::to_string(nv) +
+        " vertices");
     if (!mesh.normal.empty() && mesh.normal.size() < nv) throw std::runtime_error("mesh has fewer normals than vertices");
     if (!mesh.texcoord.empty() && mesh.texcoord.size() < nv) throw std::runtime_error("mesh has fewer texture coordinates than vertices");
     return true;
@@ -250,7 +251,8 @@ GeometrySlot AppendGeometry(HostScene& out, const PbrtMesh& mesh, const Affine& 
             Vec3 normal = cross(edge1, edge2);
             if (dot(normal, normal) <= 0.0000000001f) normal = Vec3(0, 1, 0);
             else normal = normalize(xfmNormal(xf, normal));
-            for (uint32_t vi : {ix, iy, iz}) { float* p = &out.vertexBuffer[(size_t)vertexBufferOffset / 4 + 8 * (size_t)vi]; p[0] = normal.x; p[1] = normal.y; p[2] = normal.z; }
+            for (uint32_t vi : {ix, iy, iz}) { float* p = &out.vertexBuffer[(size_t)vertexBufferOffset / 4 + 8 * (size_t)vi]; p[0] = normal.x; p[1] = normal.y;
+                p[2] = normal.z; }
         }
         out.triVertexIndex.push_back(firstVertex + ix); out.triVertexIndex.push_back(firstVertex + iy); out.triVertexIndex.push_back(firstVertex + iz);
         out.triGeometry.push_back(geometryIndexForTris); out.triPrimitive.push_back(i); out.triFlags.push_back(geometryFlag);
@@ -278,7 +280,8 @@ void Rows(const Affine& a, float r[12])
 float Determinant(const float t[12]) /* RayTracingHelper.hlsli:287-295 */
 {
 #define M(r, c) t[(r) * 4 + (c)]
-    return M(0, 0) * M(1, 1) * M(2, 2) - M(0, 0) * M(2, 1) * M(1, 2) - M(1, 0) * M(0, 1) * M(2, 2) + M(1, 0) * M(2, 1) * M(0, 2) + M(2, 0) * M(0, 1) * M(1, 2) - M(2, 0) * M(1, 1) * M(0, 2);
+    return M(0, 0) * M(1, 1) * M(2, 2) - M(0, 0) * M(2, 1) * M(1, 2) - M(1, 0) * M(0, 1) * M(2, 2) + M(1, 0) * M(2, 1) * M(0, 2) + M(2, 0) * M(0, 1) * M(1,
+        2) - M(2, 0) * M(1, 1) * M(0, 2);
 }
 
 /* InverseAffineTransform, RayTracingHelper.hlsli:297-316 -- the fallback layer inverts ObjectToWorld on the GPU in fp32
@@ -287,18 +290,30 @@ void InverseAffineTransform(const float t[12], float o[12])
 {
     const float invDet = 1.0f / Determinant(t);
 #define O(r, c) o[(r) * 4 + (c)]
-    O(0, 0) = invDet * (M(1, 1) * (M(2, 2) * 1.0f - 0.0f * M(2, 3)) + M(2, 1) * (0.0f * M(1, 3) - M(1, 2) * 1.0f) + 0.0f * (M(1, 2) * M(2, 3) - M(2, 2) * M(1, 3)));
-    O(1, 0) = invDet * (M(1, 2) * (M(2, 0) * 1.0f - 0.0f * M(2, 3)) + M(2, 2) * (0.0f * M(1, 3) - M(1, 0) * 1.0f) + 0.0f * (M(1, 0) * M(2, 3) - M(2, 0) * M(1, 3)));
-    O(2, 0) = invDet * (M(1, 3) * (M(2, 0) * 0.0f - 0.0f * M(2, 1)) + M(2, 3) * (0.0f * M(1, 1) - M(1, 0) * 0.0f) + 1.0f * (M(1, 0) * M(2, 1) - M(2, 0) * M(1, 1)));
-    O(0, 1) = invDet * (M(2, 1) * (M(0, 2) * 1.0f - 0.0f * M(0, 3)) + 0.0f * (M(2, 2) * M(0, 3) - M(0, 2) * M(2, 3)) + M(0, 1) * (0.0f * M(2, 3) - M(2, 2) * 1.0f));
-    O(1, 1) = invDet * (M(2, 2) * (M(0, 0) * 1.0f - 0.0f * M(0, 3)) + 0.0f * (M(2, 0) * M(0, 3) - M(0, 0) * M(2, 3)) + M(0, 2) * (0.0f * M(2, 3) - M(2, 0) * 1.0f));
-    O(2, 1) = invDet * (M(2, 3) * (M(0, 0) * 0.0f - 0.0f * M(0, 1)) + 1.0f * (M(2, 0) * M(0, 1) - M(0, 0) * M(2, 1)) + M(0, 3) * (0.0f * M(2, 1) - M(2, 0) * 0.0f));
-    O(0, 2) = invDet * (0.0f * (M(0, 2) * M(1, 3) - M(1, 2) * M(0, 3)) + M(0, 1) * (M(1, 2) * 1.0f - 0.0f * M(1, 3)) + M(1, 1) * (0.0f * M(0, 3) - M(0, 2) * 1.0f));
-    O(1, 2) = invDet * (0.0f * (M(0, 0) * M(1, 3) - M(1, 0) * M(0, 3)) + M(0, 2) * (M(1, 0) * 1.0f - 0.0f * M(1, 3)) + M(1, 2) * (0.0f * M(0, 3) - M(0, 0) * 1.0f));
-    O(2, 2) = invDet * (1.0f * (M(0, 0) * M(1, 1) - M(1, 0) * M(0, 1)) + M(0, 3) * (M(1, 0) * 0.0f - 0.0f * M(1, 1)) + M(1, 3) * (0.0f * M(0, 1) - M(0, 0) * 0.0f));
-    O(0, 3) = invDet * (M(0, 1) * (M(2, 2) * M(1, 3) - M(1, 2) * M(2, 3)) + M(1, 1) * (M(0, 2) * M(2, 3) - M(2, 2) * M(0, 3)) + M(2, 1) * (M(1, 2) * M(0, 3) - M(0, 2) * M(1, 3)));
-    O(1, 3) = invDet * (M(0, 2) * (M(2, 0) * M(1, 3) - M(1, 0) * M(2, 3)) + M(1, 2) * (M(0, 0) * M(2, 3) - M(2, 0) * M(0, 3)) + M(2, 2) * (M(1, 0) * M(0, 3) - M(0, 0) * M(1, 3)));
-    O(2, 3) = invDet * (M(0, 3) * (M(2, 0) * M(1, 1) - M(1, 0) * M(2, 1)) + M(1, 3) * (M(0, 0) * M(2, 1) - M(2, 0) * M(0, 1)) + M(2, 3) * (M(1, 0) * M(0, 1) - M(0, 0) * M(1, 1)));
+    O(0, 0) = invDet * (M(1, 1) * (M(2, 2) * 1.0f - 0.0f * M(2, 3)) + M(2, 1) * (0.0f * M(1, 3) - M(1, 2) * 1.0f) + 0.0f * (M(1, 2) * M(2, 3) - M(2, 2) * M(1,
+        3)));
+    O(1, 0) = invDet * (M(1, 2) * (M(2, 0) * 1.0f - 0.0f * M(2, 3)) + M(2, 2) * (0.0f * M(1, 3) - M(1, 0) * 1.0f) + 0.0f * (M(1, 0) * M(2, 3) - M(2, 0) * M(1,
+        3)));
+    O(2, 0) = invDet * (M(1, 3) * (M(2, 0) * 0.0f - 0.0f * M(2, 1)) + M(2, 3) * (0.0f * M(1, 1) - M(1, 0) * 0.0f) + 1.0f * (M(1, 0) * M(2, 1) - M(2, 0) * M(1,
+        1)));
+    O(0, 1) = invDet * (M(2, 1) * (M(0, 2) * 1.0f - 0.0f * M(0, 3)) + 0.0f * (M(2, 2) * M(0, 3) - M(0, 2) * M(2, 3)) + M(0, 1) * (0.0f * M(2, 3) - M(2,
+        2) * 1.0f));
+    O(1, 1) = invDet * (M(2, 2) * (M(0, 0) * 1.0f - 0.0f * M(0, 3)) + 0.0f * (M(2, 0) * M(0, 3) - M(0, 0) * M(2, 3)) + M(0, 2) * (0.0f * M(2, 3) - M(2,
+        0) * 1.0f));
+    O(2, 1) = invDet * (M(2, 3) * (M(0, 0) * 0.0f - 0.0f * M(0, 1)) + 1.0f * (M(2, 0) * M(0, 1) - M(0, 0) * M(2, 1)) + M(0, 3) * (0.0f * M(2, 1) - M(2,
+        0) * 0.0f));
+    O(0, 2) = invDet * (0.0f * (M(0, 2) * M(1, 3) - M(1, 2) * M(0, 3)) + M(0, 1) * (M(1, 2) * 1.0f - 0.0f * M(1, 3)) + M(1, 1) * (0.0f * M(0, 3) - M(0,
+        2) * 1.0f));
+    O(1, 2) = invDet * (0.0f * (M(0, 0) * M(1, 3) - M(1, 0) * M(0, 3)) + M(0, 2) * (M(1, 0) * 1.0f - 0.0f * M(1, 3)) + M(1, 2) * (0.0f * M(0, 3) - M(0,
+        0) * 1.0f));
+    O(2, 2) = invDet * (1.0f * (M(0, 0) * M(1, 1) - M(1, 0) * M(0, 1)) + M(0, 3) * (M(1, 0) * 0.0f - 0.0f * M(1, 1)) + M(1, 3) * (0.0f * M(0, 1) - M(0,
+        0) * 0.0f));
+    O(0, 3) = invDet * (M(0, 1) * (M(2, 2) * M(1, 3) - M(1, 2) * M(2, 3)) + M(1, 1) * (M(0, 2) * M(2, 3) - M(2, 2) * M(0, 3)) + M(2, 1) * (M(1, 2) * M(0,
+        3) - M(0, 2) * M(1, 3)));
+    O(1, 3) = invDet * (M(0, 2) * (M(2, 0) * M(1, 3) - M(1, 0) * M(2, 3)) + M(1, 2) * (M(0, 0) * M(2, 3) - M(2, 0) * M(0, 3)) + M(2, 2) * (M(1, 0) * M(0,
+        3) - M(0, 0) * M(1, 3)));
+    O(2, 3) = invDet * (M(0, 3) * (M(2, 0) * M(1, 1) - M(1, 0) * M(2, 1)) + M(1, 3) * (M(0, 0) * M(2, 1) - M(2, 0) * M(0, 1)) + M(2, 3) * (M(1, 0) * M(0,
+        1) - M(0, 0) * M(1, 1)));
 #undef O
 #undef M
 }
@@ -385,7 +400,8 @@ void ConvertScene(const PbrtScene& in, HostScene& out, const ConvertOptions& opt
                         it = blasOf.emplace(o, idx).first;
                     }
                     if (it->second != 0xffffffffu) insts.push_back(InstDef{it->second, X});
-                    if (insts.size() > 0x00ffffffu || ++visited > 0x04000000u) throw std::runtime_error("more than 2^24-1 instances (nested instancing multiplies)");
+                    if (insts.size() > 0x00ffffffu || ++visited > 0x04000000u)
+                        throw std::runtime_error("more than 2^24-1 instances (nested instancing multiplies)");
                     visit(*o, X, depth + 1);
                 }
             }
@@ -394,7 +410,8 @@ void ConvertScene(const PbrtScene& in, HostScene& out, const ConvertOptions& opt
         if (insts.size() > 0x00ffffffu) throw std::runtime_error("more than 2^24-1 instances");
         for (BlasDef& d : defs) {
             HostScene::Blas b; b.firstTri = (uint32_t)out.triGeometry.size();
-            for (const PbrtMeshSP& m : d.meshes) d.slots.push_back(AppendGeometry(out, *m, Affine(), (uint32_t)d.slots.size(), MaterialOf(*m, tracker, textures)));
+            for (const PbrtMeshSP& m : d.meshes) d.slots.push_back(AppendGeometry(out, *m, Affine(), (uint32_t)d.slots.size(), MaterialOf(*m, tracker,
+                textures)));
             b.numTris = (uint32_t)out.triGeometry.size() - b.firstTri;
             out.blas.push_back(b);
         }

@@ -65,7 +65,8 @@ void BuildBvh(HostScene& scene, int builder);
 /* the same with the construction of a single structure / of the top level supplied by the caller (the GPU builders, context.cpp);
  * tlas fills scene.tlasA, the M - 1 layout-B top-level nodes, the root reference and the top level's depth from the structures' root
  * boxes (min xyz, max xyz per structure) */
-typedef std::function<void(HostScene&, const std::vector<float>& blasRootBoxes, std::vector<TbNodeB>& topNodes, uint32_t& rootRef, uint32_t& depth)> TlasBuilder;
+typedef std::function<void(HostScene&, const std::vector<float>& blasRootBoxes, std::vector<TbNodeB>& topNodes, uint32_t& rootRef,
+    uint32_t& depth)> TlasBuilder;
 void BuildBvhWith(HostScene& scene, const std::function<void(HostScene&)>& single, const TlasBuilder& tlas);
 
 /* Procedural stand-ins (procedural.cpp) */
@@ -75,7 +76,8 @@ void MakeProceduralScene(HostScene& out, int kind, uint32_t targetTriangles, uin
 bool WritePngRGBA8(const std::string& file, uint32_t W, uint32_t H, const uint8_t* rgba, std::string& err);
 bool WritePfmRGB(const std::string& file, uint32_t W, uint32_t H, const float* rgba, std::string& err);
 bool WriteExrRGBA(const std::string& file, uint32_t W, uint32_t H, const float* rgba, std::string& err);
-bool LoadImageRGBA32F(const std::string& file, std::vector<TbFloat4>& texels, uint32_t& w, uint32_t& h, bool& normalizedFormat, std::string& err, bool* hasAlpha = nullptr);
+bool LoadImageRGBA32F(const std::string& file, std::vector<TbFloat4>& texels, uint32_t& w, uint32_t& h, bool& normalizedFormat, std::string& err,
+    bool* hasAlpha = nullptr);
 /* PNG / TGA (image_decode.cpp): texels as the DXGI typed load of what DirectXTex produces, top row first */
 /* D3D12_REQ_TEXTURE2D_U_OR_V_DIMENSION: what the reference could create a texture for; every reader refuses more before it allocates */
 inline bool ImageDimensionsOk(uint32_t w, uint32_t h) { return w >= 1 && h >= 1 && w <= 16384 && h <= 16384; }

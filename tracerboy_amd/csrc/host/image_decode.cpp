@@ -24,7 +24,8 @@ bool readFile(const std::string& file, std::vector<uint8_t>& out, std::string& e
     FILE* f = fopen(file.c_str(), "rb");
     if (!f) { err = "cannot open image '" + file + "'"; return false; }
     struct stat st;
-    if (fstat(fileno(f), &st) != 0 || !S_ISREG(st.st_mode)) { fclose(f); err = "'" + file + "' is not a regular file"; return false; }   /* fopen succeeds on a directory and ftell then reports LONG_MAX */
+    /* fopen succeeds on a directory and ftell then reports LONG_MAX */
+    if (fstat(fileno(f), &st) != 0 || !S_ISREG(st.st_mode)) { fclose(f); err = "'" + file + "' is not a regular file"; return false; }
     fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET);
     out.resize(n > 0 ? (size_t)n : 0);
     bool ok = out.empty() || fread(out.data(), 1, out.size(), f) == out.size();
@@ -73,7 +74,8 @@ void inflateRaw(BitReader& br, std::vector<uint8_t>& out)
 {
     static const uint16_t lenBase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
     static const uint8_t lenExtra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-    static const uint16_t distBase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+    static const uint16_t distBase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145,
+        8193, 12289, 16385, 24577};
     static const uint8_t distExtra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
     for (;;) {
         const uint32_t final = br.get(1), type = br.get(2);
@@ -106,7 +108,8 @@ void inflateRaw(BitReader& br, std::vector<uint8_t>& out)
                     if (sym < 16) lengths[i++] = (uint8_t)sym;
                     else {
                         uint8_t prev = 0; int rep;
-                        if (sym == 16) { if (i == 0) throw std::runtime_error("inflate: repeat without previous length"); prev = lengths[i - 1]; rep = 3 + (int)br.get(2); }
+                        if (sym == 16) { if (i == 0) throw std::runtime_error("inflate: repeat without previous length"); prev = lengths[i - 1];
+                            rep = 3 + (int)br.get(2); }
                         else if (sym == 17) rep = 3 + (int)br.get(3);
                         else rep = 11 + (int)br.get(7);
                         if (i + rep > nlen + ndist) throw std::runtime_error("inflate: repeat overruns the code lengths");
@@ -152,7 +155,8 @@ void zlibInflate(const std::vector<uint8_t>& z, std::vector<uint8_t>& out)
 
 /* ---- PNG ---------------------------------------------------------------------------------------------------------- */
 inline uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
-inline int paeth(int a, int b, int c) { int p = a + b - c, pa = abs(p - a), pb = abs(p - b), pc = abs(p - c); return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c); }
+inline int paeth(int a, int b, int c) { int p = a + b - c, pa = abs(p - a), pb = abs(p - b), pc = abs(p - c);
+    return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c); }
 
 /* unfilters `rows` scanlines of `rowBytes` bytes (each preceded by its filter byte) in place; returns the pixel bytes */
 void unfilter(const uint8_t* src, uint32_t rows, size_t rowBytes, size_t bpp, std::vector<uint8_t>& dst)
@@ -183,7 +187,8 @@ bool decodePng(const std::vector<uint8_t>& d, DecodedImage& img, std::string& er
         const uint32_t n = be32(&d[at]); const uint8_t* type = &d[at + 4];
         if (at + 12 + n > d.size()) throw std::runtime_error("png: truncated chunk");
         const uint8_t* body = &d[at + 8];
-        if (!memcmp(type, "IHDR", 4)) { if (n < 13) throw std::runtime_error("png: short IHDR"); W = be32(body); H = be32(body + 4); depth = body[8]; ctype = body[9]; interlace = body[12]; if (body[10] || body[11]) throw std::runtime_error("png: unknown compression / filter method"); }
+        if (!memcmp(type, "IHDR", 4)) { if (n < 13) throw std::runtime_error("png: short IHDR"); W = be32(body); H = be32(body + 4); depth = body[8];
+            ctype = body[9]; interlace = body[12]; if (body[10] || body[11]) throw std::runtime_error("png: unknown compression / filter method"); }
         else if (!memcmp(type, "PLTE", 4)) palette.assign(body, body + n);
         else if (!memcmp(type, "tRNS", 4)) trns.assign(body, body + n);
         else if (!memcmp(type, "IDAT", 4)) idat.insert(idat.end(), body, body + n);
@@ -191,7 +196,8 @@ bool decodePng(const std::vector<uint8_t>& d, DecodedImage& img, std::string& er
         at += 12 + n;
     }
     const int channels = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
-    if (!W || !H || !channels || !(depth == 1 || depth == 2 || depth == 4 || depth == 8 || depth == 16) || interlace > 1) throw std::runtime_error("png: unsupported header");
+    if (!W || !H || !channels || !(depth == 1 || depth == 2 || depth == 4 || depth == 8 || depth == 16) || interlace > 1)
+        throw std::runtime_error("png: unsupported header");
     if (ctype == 3 && palette.empty()) throw std::runtime_error("png: palette image without PLTE");
     if (!ImageDimensionsOk(W, H)) throw std::runtime_error("png: dimensions beyond the 16384 a 2-D texture can have");
     if ((ctype == 2 || ctype == 4 || ctype == 6) && depth < 8) throw std::runtime_error("png: bit depth not allowed for this colour type");
@@ -202,7 +208,8 @@ bool decodePng(const std::vector<uint8_t>& d, DecodedImage& img, std::string& er
         static const uint32_t xs0[7] = {0, 4, 0, 2, 0, 1, 0}, ys0[7] = {0, 0, 4, 0, 2, 0, 1}, dxs0[7] = {8, 8, 4, 4, 2, 2, 1}, dys0[7] = {8, 8, 8, 4, 4, 2, 2};
         size_t want = 0;
         if (!interlace) want = (size_t)H * (((size_t)W * bitsPerPixel + 7) / 8 + 1);
-        else for (int p = 0; p < 7; p++) { const size_t pw = (W + dxs0[p] - 1 - xs0[p]) / dxs0[p], ph = (H + dys0[p] - 1 - ys0[p]) / dys0[p]; if (pw && ph) want += ph * ((pw * bitsPerPixel + 7) / 8 + 1); }
+        else for (int p = 0; p < 7; p++) { const size_t pw = (W + dxs0[p] - 1 - xs0[p]) / dxs0[p], ph = (H + dys0[p] - 1 - ys0[p]) / dys0[p];
+            if (pw && ph) want += ph * ((pw * bitsPerPixel + 7) / 8 + 1); }
         if (raw.size() < want) throw std::runtime_error("png: image data too short");
     }
     /* samples[y][x][c] as 16-bit values at the file's bit depth */
@@ -245,7 +252,8 @@ bool decodePng(const std::vector<uint8_t>& d, DecodedImage& img, std::string& er
             else t = TbFloat4{g, 0.0f, 0.0f, 1.0f};
             break; }
         case 2: {
-            bool key = trns.size() >= 6 && s[0] == (uint16_t)((trns[0] << 8) | trns[1]) && s[1] == (uint16_t)((trns[2] << 8) | trns[3]) && s[2] == (uint16_t)((trns[4] << 8) | trns[5]);
+            bool key = trns.size() >= 6 && s[0] == (uint16_t)((trns[0] << 8) | trns[1]) && s[1] == (uint16_t)((trns[2] << 8) | trns[3]) && s[2] ==
+                (uint16_t)((trns[4] << 8) | trns[5]);
             t = TbFloat4{(float)s[0] / maxv, (float)s[1] / maxv, (float)s[2] / maxv, key ? 0.0f : 1.0f};
             break; }
         case 3: {
@@ -271,7 +279,8 @@ bool decodeTga(const std::vector<uint8_t>& d, DecodedImage& img, std::string& er
     const uint32_t W = d[12] | (d[13] << 8), H = d[14] | (d[15] << 8); const int bits = d[16], desc = d[17];
     const bool rle = type >= 9; const int base = rle ? type - 8 : type;
     if (!W || !H || !(base == 1 || base == 2 || base == 3)) { err = "TGA: unsupported image type"; return false; }
-    if ((base == 2 && !(bits == 16 || bits == 24 || bits == 32)) || (base == 3 && bits != 8) || (base == 1 && (bits != 8 || cmapType != 1))) { err = "TGA: unsupported pixel depth"; return false; }
+    if ((base == 2 && !(bits == 16 || bits == 24 || bits == 32)) || (base == 3 && bits != 8) || (base == 1 && (bits != 8 || cmapType != 1))) { err =
+        "TGA: unsupported pixel depth"; return false; }
     size_t at = 18 + (size_t)idLen;
     const size_t cmapEntry = (size_t)(cmapBits + 7) / 8;
     if (base == 1 && !(cmapBits == 15 || cmapBits == 16 || cmapBits == 24 || cmapBits == 32)) { err = "TGA: unsupported colour-map entry size"; return false; }
@@ -288,12 +297,16 @@ bool decodeTga(const std::vector<uint8_t>& d, DecodedImage& img, std::string& er
         while (o < pix.size()) {
             if (at >= d.size()) throw std::runtime_error("TGA: truncated RLE stream");
             const int hdr = d[at++], count = (hdr & 0x7f) + 1;
-            if (hdr & 0x80) { if (at + px > d.size()) throw std::runtime_error("TGA: truncated"); for (int k = 0; k < count && o < pix.size(); k++) { memcpy(&pix[o], &d[at], px); o += px; } at += px; }
-            else { const size_t n = (size_t)count * px; if (at + n > d.size() || o + n > pix.size()) throw std::runtime_error("TGA: truncated"); memcpy(&pix[o], &d[at], n); o += n; at += n; }
+            if (hdr & 0x80) { if (at + px > d.size()) throw std::runtime_error("TGA: truncated");
+                for (int k = 0; k < count && o < pix.size(); k++) { memcpy(&pix[o], &d[at], px); o += px; } at += px; }
+            else { const size_t n = (size_t)count * px; if (at + n > d.size() || o + n > pix.size()) throw std::runtime_error("TGA: truncated");
+                memcpy(&pix[o], &d[at], n); o += n; at += n; }
         }
     }
     auto colour = [&](const uint8_t* p, size_t nbytes) -> TbFloat4 { /* little-endian BGR(A) / A1R5G5B5 */
-        if (nbytes == 2) { const uint16_t v = (uint16_t)(p[0] | (p[1] << 8)); return TbFloat4{(float)((v >> 10) & 31) / 31.0f, (float)((v >> 5) & 31) / 31.0f, (float)(v & 31) / 31.0f, (desc & 0x0f) ? (float)(v >> 15) : 1.0f}; }
+        if (nbytes == 2) { const uint16_t v = (uint16_t)(p[0] | (p[1] << 8));
+            return TbFloat4{(float)((v >> 10) & 31) / 31.0f, (float)((v >> 5) & 31) / 31.0f, (float)(v & 31) / 31.0f, (desc & 0x0f) ? (float)(v >> 15) : 1.0f};
+            }
         return TbFloat4{(float)p[2] / 255.0f, (float)p[1] / 255.0f, (float)p[0] / 255.0f, nbytes == 4 ? (float)p[3] / 255.0f : 1.0f};
     };
     img.width = W; img.height = H; img.normalized = true; img.hasAlpha = false;
@@ -304,7 +317,8 @@ bool decodeTga(const std::vector<uint8_t>& d, DecodedImage& img, std::string& er
         const uint8_t* p = &pix[((size_t)y * W + x) * px];
         TbFloat4 t;
         if (base == 3) t = TbFloat4{(float)p[0] / 255.0f, 0.0f, 0.0f, 1.0f};
-        else if (base == 1) { const int idx = p[0] - cmapFirst; if (idx < 0 || idx >= cmapLen) throw std::runtime_error("TGA: colour-map index out of range"); t = colour(cmap + (size_t)idx * cmapEntry, cmapEntry); }
+        else if (base == 1) { const int idx = p[0] - cmapFirst; if (idx < 0 || idx >= cmapLen) throw std::runtime_error("TGA: colour-map index out of range");
+            t = colour(cmap + (size_t)idx * cmapEntry, cmapEntry); }
         else t = colour(p, px);
         if (t.w != 0.0f) allZeroAlpha = false;
         if (t.w != 1.0f) anyAlpha = true;
@@ -323,7 +337,8 @@ bool DecodeImageFile(const std::string& file, DecodedImage& img, std::string& er
 {
     std::vector<uint8_t> d;
     if (!readFile(file, d, err)) return false;
-    auto ends = [&](const char* s) { size_t n = strlen(s); if (file.size() < n) return false; for (size_t i = 0; i < n; i++) if (tolower(file[file.size() - n + i]) != s[i]) return false; return true; };
+    auto ends = [&](const char* s) { size_t n = strlen(s); if (file.size() < n) return false;
+        for (size_t i = 0; i < n; i++) if (tolower(file[file.size() - n + i]) != s[i]) return false; return true; };
     try {
         if (ends(".png")) return decodePng(d, img, err);
         if (ends(".tga")) return decodeTga(d, img, err);

@@ -56,14 +56,16 @@ struct JpegBits {
     int decode(const JpegHuff& h)
     {
         int code = 0;
-        for (int l = 1; l <= 16; l++) { code = (code << 1) | get(1); if (h.maxcode[l] >= 0 && code <= h.maxcode[l] && code >= h.mincode[l]) return h.vals[h.valptr[l] + code - h.mincode[l]]; }
+        for (int l = 1; l <= 16; l++) { code = (code << 1) | get(1);
+            if (h.maxcode[l] >= 0 && code <= h.maxcode[l] && code >= h.mincode[l]) return h.vals[h.valptr[l] + code - h.mincode[l]]; }
         throw std::runtime_error("jpeg: bad Huffman code");
     }
     static int extend(int v, int t) { return v < (1 << (t - 1)) ? v - (1 << t) + 1 : v; }
     void restart() /* at an RSTn: drop the bit buffer, step over the marker */
     {
         acc = 0; cnt = 0;
-        if (hitMarker) { hitMarker = false; if (at + 1 < n && p[at] == 0xff && p[at + 1] >= 0xd0 && p[at + 1] <= 0xd7) at += 2; else throw std::runtime_error("jpeg: restart marker expected"); }
+        if (hitMarker) { hitMarker = false; if (at + 1 < n && p[at] == 0xff && p[at + 1] >= 0xd0 && p[at + 1] <= 0xd7) at += 2;
+            else throw std::runtime_error("jpeg: restart marker expected"); }
         else { /* the marker may not have been reached by the bit reader yet */
             while (at + 1 < n && !(p[at] == 0xff && p[at + 1] >= 0xd0 && p[at + 1] <= 0xd7)) at++;
             if (at + 1 >= n) throw std::runtime_error("jpeg: restart marker expected");
@@ -81,12 +83,14 @@ inline uint8_t clamp255(int v) { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v
 void idctIslow(const int* coef /* dequantised, natural order */, uint8_t* out, size_t stride)
 {
     const int CONST_BITS = 13, PASS1_BITS = 2;
-    const int F_0_298 = 2446, F_0_390 = 3196, F_0_541 = 4433, F_0_765 = 6270, F_0_899 = 7373, F_1_175 = 9633, F_1_501 = 12299, F_1_847 = 15137, F_1_961 = 16069, F_2_053 = 16819, F_2_562 = 20995, F_3_072 = 25172;
+    const int F_0_298 = 2446, F_0_390 = 3196, F_0_541 = 4433, F_0_765 = 6270, F_0_899 = 7373, F_1_175 = 9633, F_1_501 = 12299, F_1_847 = 15137,
+        F_1_961 = 16069, F_2_053 = 16819, F_2_562 = 20995, F_3_072 = 25172;
     auto descale = [](long x, int n) { return (int)((x + (1L << (n - 1))) >> n); };
     int ws[64];
     for (int c = 0; c < 8; c++) {
         const int* in = coef + c; int* w = ws + c;
-        if (!in[8] && !in[16] && !in[24] && !in[32] && !in[40] && !in[48] && !in[56]) { const int dc = in[0] * (1 << PASS1_BITS); for (int r = 0; r < 8; r++) w[8 * r] = dc; continue; }
+        if (!in[8] && !in[16] && !in[24] && !in[32] && !in[40] && !in[48] && !in[56]) { const int dc = in[0] * (1 << PASS1_BITS);
+            for (int r = 0; r < 8; r++) w[8 * r] = dc; continue; }
         long z2 = in[16], z3 = in[48];
         long z1 = (z2 + z3) * F_0_541, tmp2 = z1 + z3 * (-F_1_847), tmp3 = z1 + z2 * F_0_765;
         z2 = in[0]; z3 = in[32];
@@ -123,7 +127,9 @@ void idctIslow(const int* coef /* dequantised, natural order */, uint8_t* out, s
     }
 }
 
-struct JpegComp { int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0, pred = 0; uint32_t bw = 0, bh = 0 /* blocks of the padded (MCU) grid */, cw = 0, ch = 0 /* blocks the component itself needs */, dw = 0, dh = 0 /* downsampled size */;
+struct JpegComp { int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0, pred = 0;
+    uint32_t bw = 0, bh = 0 /* blocks of the padded (MCU) grid */, cw = 0, ch = 0 /* blocks the component itself needs */, dw = 0,
+    dh = 0 /* downsampled size */;
                   std::vector<int16_t> coef; /* bw * bh * 64, natural order, before dequantisation */ std::vector<uint8_t> plane; size_t stride = 0; };
 
 /* One scan of a sequential or progressive frame into the components' coefficient arrays (ITU T.81 F.2 / G.1).  Sequential scans carry
@@ -151,7 +157,8 @@ void decodeJpegScan(JpegBits& br, std::vector<JpegComp*>& sc, const JpegHuff* dc
             return;
         }
         if (Ss == 0) { /* DC band */
-            if (Ah == 0) { const int t = br.decode(dc[c.td]); if (t > 11) throw std::runtime_error("jpeg: bad DC size"); c.pred += t ? JpegBits::extend(br.get(t), t) : 0; co[0] = (int16_t)(c.pred * (1 << Al)); }
+            if (Ah == 0) { const int t = br.decode(dc[c.td]); if (t > 11) throw std::runtime_error("jpeg: bad DC size");
+                c.pred += t ? JpegBits::extend(br.get(t), t) : 0; co[0] = (int16_t)(c.pred * (1 << Al)); }
             else if (br.get(1)) co[0] = (int16_t)(co[0] | p1);
             return;
         }
@@ -187,7 +194,8 @@ void decodeJpegScan(JpegBits& br, std::vector<JpegComp*>& sc, const JpegHuff* dc
     };
     for (uint32_t uy = 0; uy < unitsY; uy++) for (uint32_t ux = 0; ux < unitsX; ux++) {
         if (restartInterval && toRestart == 0) { br.restart(); for (JpegComp* c : sc) c->pred = 0; eobrun = 0; toRestart = restartInterval; }
-        if (interleaved) { for (JpegComp* c : sc) for (int by = 0; by < c->v; by++) for (int bx = 0; bx < c->h; bx++) block(*c, ux * (uint32_t)c->h + (uint32_t)bx, uy * (uint32_t)c->v + (uint32_t)by); }
+        if (interleaved) { for (JpegComp* c : sc) for (int by = 0; by < c->v; by++) for (int bx = 0; bx < c->h; bx++) block(*c,
+            ux * (uint32_t)c->h + (uint32_t)bx, uy * (uint32_t)c->v + (uint32_t)by); }
         else block(*sc[0], ux, uy);
         if (restartInterval) toRestart--;
     }
@@ -198,14 +206,16 @@ bool decodeJpeg(const std::vector<uint8_t>& d, DecodedImage& img, std::string& e
     if (d.size() < 4 || d[0] != 0xff || d[1] != 0xd8) { err = "not a JPEG file"; return false; }
     uint16_t qt[4][64]; bool qtSet[4] = {false, false, false, false};
     JpegHuff dc[4], ac[4];
-    std::vector<JpegComp> comps; uint32_t W = 0, H = 0; int hmax = 1, vmax = 1, restartInterval = 0; int adobeTransform = -1; bool sawSof = false, progressive = false, sawScan = false;
+    std::vector<JpegComp> comps; uint32_t W = 0, H = 0; int hmax = 1, vmax = 1, restartInterval = 0; int adobeTransform = -1;
+        bool sawSof = false, progressive = false, sawScan = false;
     uint32_t mcusX = 0, mcusY = 0;
     size_t at = 2;
     auto u16 = [&](size_t o) -> uint32_t { if (o + 1 >= d.size()) throw std::runtime_error("jpeg: truncated"); return ((uint32_t)d[o] << 8) | d[o + 1]; };
     for (bool done = false; !done;) {
         while (at < d.size() && d[at] != 0xff) at++;
         while (at < d.size() && d[at] == 0xff) at++;
-        if (at >= d.size()) { if (sawScan) break; throw std::runtime_error("jpeg: no scan found"); } /* a missing EOI after complete scans is tolerated, like libjpeg */
+        /* a missing EOI after complete scans is tolerated, like libjpeg */
+        if (at >= d.size()) { if (sawScan) break; throw std::runtime_error("jpeg: no scan found"); }
         const uint8_t m = d[at++];
         if (m == 0xd8 || (m >= 0xd0 && m <= 0xd7) || m == 0x01 || m == 0x00) continue;
         if (m == 0xd9) { if (!sawScan) throw std::runtime_error("jpeg: end of image before any scan"); break; }
@@ -214,7 +224,8 @@ bool decodeJpeg(const std::vector<uint8_t>& d, DecodedImage& img, std::string& e
         if (m == 0xdb) { /* DQT */
             size_t p = seg;
             while (p < end) { const int pq = d[p] >> 4, tq = d[p] & 15; p++; if (tq > 3) throw std::runtime_error("jpeg: bad quantisation table id");
-                for (int i = 0; i < 64; i++) { if (p + (pq ? 2 : 1) > end) throw std::runtime_error("jpeg: truncated DQT"); qt[tq][kZigzag[i]] = pq ? (uint16_t)u16(p) : d[p]; p += pq ? 2 : 1; }
+                for (int i = 0; i < 64; i++) { if (p + (pq ? 2 : 1) > end) throw std::runtime_error("jpeg: truncated DQT");
+                    qt[tq][kZigzag[i]] = pq ? (uint16_t)u16(p) : d[p]; p += pq ? 2 : 1; }
                 qtSet[tq] = true; }
         } else if (m == 0xc4) { /* DHT */
             size_t p = seg;
@@ -234,15 +245,19 @@ bool decodeJpeg(const std::vector<uint8_t>& d, DecodedImage& img, std::string& e
             if (seg + 6 + 3 * (size_t)nc > end) throw std::runtime_error("jpeg: short frame header");
             if (!ImageDimensionsOk(W, H)) throw std::runtime_error("jpeg: dimensions beyond the 16384 a 2-D texture can have");
             comps.resize((size_t)nc);
-            for (int i = 0; i < nc; i++) { JpegComp& c = comps[(size_t)i]; c.id = d[seg + 6 + 3 * i]; c.h = d[seg + 7 + 3 * i] >> 4; c.v = d[seg + 7 + 3 * i] & 15; c.tq = d[seg + 8 + 3 * i];
-                if (c.h < 1 || c.h > 4 || c.v < 1 || c.v > 4 || c.tq > 3) throw std::runtime_error("jpeg: bad sampling factors"); hmax = std::max(hmax, c.h); vmax = std::max(vmax, c.v); }
-            if (nc == 1) { comps[0].h = comps[0].v = 1; hmax = vmax = 1; } /* a single component is never interleaved: its factors only scale the (absent) others */
+            for (int i = 0; i < nc; i++) { JpegComp& c = comps[(size_t)i]; c.id = d[seg + 6 + 3 * i]; c.h = d[seg + 7 + 3 * i] >> 4;
+                c.v = d[seg + 7 + 3 * i] & 15; c.tq = d[seg + 8 + 3 * i];
+                if (c.h < 1 || c.h > 4 || c.v < 1 || c.v > 4 || c.tq > 3) throw std::runtime_error("jpeg: bad sampling factors"); hmax = std::max(hmax, c.h);
+                    vmax = std::max(vmax, c.v); }
+            /* a single component is never interleaved: its factors only scale the (absent) others */
+            if (nc == 1) { comps[0].h = comps[0].v = 1; hmax = vmax = 1; }
             mcusX = (W + 8u * (uint32_t)hmax - 1) / (8u * (uint32_t)hmax); mcusY = (H + 8u * (uint32_t)vmax - 1) / (8u * (uint32_t)vmax);
             for (JpegComp& c : comps) {
                 c.dw = (W * (uint32_t)c.h + (uint32_t)hmax - 1) / (uint32_t)hmax; c.dh = (H * (uint32_t)c.v + (uint32_t)vmax - 1) / (uint32_t)vmax;
                 c.cw = (c.dw + 7) / 8; c.ch = (c.dh + 7) / 8; c.bw = mcusX * (uint32_t)c.h; c.bh = mcusY * (uint32_t)c.v;
                 if ((uint64_t)c.bw * c.bh > (1u << 24)) throw std::runtime_error("jpeg: image too large");
-                if ((uint64_t)c.bw * c.bh > 64ull * d.size() + 4096) throw std::runtime_error("jpeg: the file is too short for the frame its header describes");   /* a block costs at least a bit of DC */
+                /* a block costs at least a bit of DC */
+                if ((uint64_t)c.bw * c.bh > 64ull * d.size() + 4096) throw std::runtime_error("jpeg: the file is too short for the frame its header describes");
                 c.coef.assign((size_t)c.bw * c.bh * 64, 0);
             }
             sawSof = true;
@@ -252,17 +267,22 @@ bool decodeJpeg(const std::vector<uint8_t>& d, DecodedImage& img, std::string& e
         else if (m == 0xee && len >= 14 && !memcmp(&d[seg], "Adobe", 5)) adobeTransform = d[seg + 11];
         else if (m == 0xda) { /* SOS */
             if (!sawSof) throw std::runtime_error("jpeg: scan before frame header");
-            const int ns = d[seg]; if (ns < 1 || ns > (int)comps.size() || seg + 1 + 2 * (size_t)ns + 3 > end) throw std::runtime_error("jpeg: bad scan header");
+            const int ns = d[seg];
+                if (ns < 1 || ns > (int)comps.size() || seg + 1 + 2 * (size_t)ns + 3 > end) throw std::runtime_error("jpeg: bad scan header");
             std::vector<JpegComp*> sc;
             for (int i = 0; i < ns; i++) { const int cid = d[seg + 1 + 2 * i]; JpegComp* found = nullptr;
                 for (JpegComp& c : comps) if (c.id == cid) found = &c;
                 if (!found) throw std::runtime_error("jpeg: scan names an unknown component");
-                found->td = d[seg + 2 + 2 * i] >> 4; found->ta = d[seg + 2 + 2 * i] & 15; if (found->td > 3 || found->ta > 3) throw std::runtime_error("jpeg: bad table selector"); sc.push_back(found); }
+                found->td = d[seg + 2 + 2 * i] >> 4; found->ta = d[seg + 2 + 2 * i] & 15;
+                    if (found->td > 3 || found->ta > 3) throw std::runtime_error("jpeg: bad table selector"); sc.push_back(found); }
             const int Ss = d[seg + 1 + 2 * ns], Se = d[seg + 2 + 2 * ns], Ah = d[seg + 3 + 2 * ns] >> 4, Al = d[seg + 3 + 2 * ns] & 15;
-            if (progressive) { if (Ss > Se || Se > 63 || (Ss == 0 && Se != 0) || (Ss > 0 && ns != 1) || Al > 13) throw std::runtime_error("jpeg: bad progressive scan parameters"); }
+            if (progressive) { if (Ss > Se || Se > 63 || (Ss == 0 && Se != 0) || (Ss > 0 && ns != 1) || Al > 13)
+                throw std::runtime_error("jpeg: bad progressive scan parameters"); }
             else if (Ss != 0 || Se != 63 || Ah != 0 || Al != 0) throw std::runtime_error("jpeg: bad sequential scan parameters");
-            for (JpegComp* c : sc) { if ((!progressive || (Ss == 0 && Ah == 0)) && !dc[c->td].present) throw std::runtime_error("jpeg: scan refers to a DC table that was not defined");
-                                     if ((!progressive || Ss > 0) && !ac[c->ta].present) throw std::runtime_error("jpeg: scan refers to an AC table that was not defined"); }
+            for (JpegComp* c : sc) { if ((!progressive || (Ss == 0 && Ah == 0)) && !dc[c->td].present)
+                throw std::runtime_error("jpeg: scan refers to a DC table that was not defined");
+                                     if ((!progressive || Ss > 0) && !ac[c->ta].present)
+                                         throw std::runtime_error("jpeg: scan refers to an AC table that was not defined"); }
             JpegBits br(d.data(), d.size(), end);
             decodeJpegScan(br, sc, dc, ac, progressive, Ss, Se, Ah, Al, mcusX, mcusY, restartInterval);
             sawScan = true;
@@ -298,7 +318,8 @@ bool decodeJpeg(const std::vector<uint8_t>& d, DecodedImage& img, std::string& e
             }
         } else if (exact && hx == 2 && vx == 2 && c.dw > 2) { /* h2v2_fancy_upsample: 9/16, 3/16, 3/16, 1/16, rounding 8 / 7 alternately */
             for (uint32_t y = 0; y < H; y++) {
-                const uint32_t j = y >> 1; const uint32_t far = (y & 1) ? (j + 1 < c.dh ? j + 1 : j) : (j > 0 ? j - 1 : j); /* the context row beyond an edge repeats the edge row */
+                /* the context row beyond an edge repeats the edge row */
+                const uint32_t j = y >> 1; const uint32_t far = (y & 1) ? (j + 1 < c.dh ? j + 1 : j) : (j > 0 ? j - 1 : j);
                 auto colsum = [&](uint32_t i) { return 3 * in(i, j) + in(i, far); };
                 for (uint32_t x = 0; x < W; x++) {
                     const uint32_t i = x >> 1; const int cur = colsum(i); int v;
@@ -309,7 +330,8 @@ bool decodeJpeg(const std::vector<uint8_t>& d, DecodedImage& img, std::string& e
             }
         } else { /* replication (int_upsample) for every other ratio; ratios that are not whole numbers take the nearest sample below */
             for (uint32_t y = 0; y < H; y++) for (uint32_t x = 0; x < W; x++) {
-                const uint32_t sx = std::min<uint32_t>((uint32_t)((uint64_t)x * (uint32_t)c.h / (uint32_t)hmax), c.bw * 8 - 1), sy = std::min<uint32_t>((uint32_t)((uint64_t)y * (uint32_t)c.v / (uint32_t)vmax), c.bh * 8 - 1);
+                const uint32_t sx = std::min<uint32_t>((uint32_t)((uint64_t)x * (uint32_t)c.h / (uint32_t)hmax), c.bw * 8 - 1),
+                    sy = std::min<uint32_t>((uint32_t)((uint64_t)y * (uint32_t)c.v / (uint32_t)vmax), c.bh * 8 - 1);
                 o[(size_t)y * W + x] = (uint8_t)in(sx, sy);
             }
         }
@@ -331,8 +353,10 @@ bool decodeJpeg(const std::vector<uint8_t>& d, DecodedImage& img, std::string& e
 }
 
 /* ---- BMP ------------------------------------------------------------------------------------------------------------------- */
-uint32_t rd32(const std::vector<uint8_t>& d, size_t o) { if (o + 4 > d.size()) throw std::runtime_error("image: truncated"); return (uint32_t)d[o] | ((uint32_t)d[o + 1] << 8) | ((uint32_t)d[o + 2] << 16) | ((uint32_t)d[o + 3] << 24); }
-uint32_t rd16(const std::vector<uint8_t>& d, size_t o) { if (o + 2 > d.size()) throw std::runtime_error("image: truncated"); return (uint32_t)d[o] | ((uint32_t)d[o + 1] << 8); }
+uint32_t rd32(const std::vector<uint8_t>& d, size_t o) { if (o + 4 > d.size()) throw std::runtime_error("image: truncated");
+    return (uint32_t)d[o] | ((uint32_t)d[o + 1] << 8) | ((uint32_t)d[o + 2] << 16) | ((uint32_t)d[o + 3] << 24); }
+uint32_t rd16(const std::vector<uint8_t>& d, size_t o) { if (o + 2 > d.size()) throw std::runtime_error("image: truncated");
+    return (uint32_t)d[o] | ((uint32_t)d[o + 1] << 8); }
 
 /* value of a bit field scaled to [0, 1]: UNORM of the field's own width */
 float maskUnorm(uint32_t v, uint32_t mask)
@@ -350,11 +374,13 @@ bool decodeBmp(const std::vector<uint8_t>& d, DecodedImage& img, std::string& er
     if (hdr < 40) { err = "BMP: OS/2 core headers are not supported"; return false; }
     const int32_t w = (int32_t)rd32(d, 18), hs = (int32_t)rd32(d, 22);
     const uint32_t bpp = rd16(d, 28), comp = rd32(d, 30); uint32_t colours = rd32(d, 46);
-    if (w <= 0 || hs == 0 || w > 16384 || hs > 16384 || hs < -16384) { err = "BMP: bad dimensions (a 2-D texture has at most 16384 texels a side)"; return false; }
+    if (w <= 0 || hs == 0 || w > 16384 || hs > 16384 || hs < -16384) { err = "BMP: bad dimensions (a 2-D texture has at most 16384 texels a side)";
+        return false; }
     const uint32_t W = (uint32_t)w, H = (uint32_t)(hs < 0 ? -hs : hs); const bool topDown = hs < 0;
     if (comp != 0 && comp != 3) { err = "BMP: RLE / embedded JPEG / PNG compression is not supported"; return false; }
     uint32_t rm = 0, gm = 0, bm = 0, am = 0;
-    if (comp == 3) { const size_t mo = hdr >= 52 ? 54 : 14 + 40; rm = rd32(d, mo); gm = rd32(d, mo + 4); bm = rd32(d, mo + 8); if (hdr >= 56) am = rd32(d, mo + 12); }
+    if (comp == 3) { const size_t mo = hdr >= 52 ? 54 : 14 + 40; rm = rd32(d, mo); gm = rd32(d, mo + 4); bm = rd32(d, mo + 8);
+        if (hdr >= 56) am = rd32(d, mo + 12); }
     else if (bpp == 16) { rm = 0x7c00; gm = 0x03e0; bm = 0x001f; }
     else if (bpp == 32) { rm = 0x00ff0000; gm = 0x0000ff00; bm = 0x000000ff; if (hdr >= 56) am = rd32(d, 14 + 40 + 12); if (hdr < 108) am = 0; }
     std::vector<TbFloat4> pal;
@@ -362,7 +388,8 @@ bool decodeBmp(const std::vector<uint8_t>& d, DecodedImage& img, std::string& er
         if (!colours) colours = 1u << bpp;
         if (colours > 256) throw std::runtime_error("BMP: bad palette size");
         const size_t po = 14 + (size_t)hdr + (comp == 3 && hdr == 40 ? 12 : 0);
-        for (uint32_t i = 0; i < colours; i++) { if (po + 4 * i + 3 >= d.size()) throw std::runtime_error("BMP: truncated palette"); pal.push_back(px(d[po + 4 * i + 2] / 255.0f, d[po + 4 * i + 1] / 255.0f, d[po + 4 * i] / 255.0f, 1.0f)); }
+        for (uint32_t i = 0; i < colours; i++) { if (po + 4 * i + 3 >= d.size()) throw std::runtime_error("BMP: truncated palette");
+            pal.push_back(px(d[po + 4 * i + 2] / 255.0f, d[po + 4 * i + 1] / 255.0f, d[po + 4 * i] / 255.0f, 1.0f)); }
     }
     if (bpp != 1 && bpp != 4 && bpp != 8 && bpp != 16 && bpp != 24 && bpp != 32) { err = "BMP: unsupported bit depth"; return false; }
     const size_t rowBytes = ((size_t)W * bpp + 31) / 32 * 4;
@@ -373,9 +400,11 @@ bool decodeBmp(const std::vector<uint8_t>& d, DecodedImage& img, std::string& er
         const uint8_t* row = &d[dataOff + rowBytes * (topDown ? y : H - 1 - y)];
         for (uint32_t x = 0; x < W; x++) {
             TbFloat4 t;
-            if (bpp <= 8) { const uint32_t per = 8 / bpp, idx = (row[x / per] >> ((per - 1 - x % per) * bpp)) & ((1u << bpp) - 1); t = idx < pal.size() ? pal[idx] : px(0, 0, 0, 1); }
+            if (bpp <= 8) { const uint32_t per = 8 / bpp, idx = (row[x / per] >> ((per - 1 - x % per) * bpp)) & ((1u << bpp) - 1);
+                t = idx < pal.size() ? pal[idx] : px(0, 0, 0, 1); }
             else if (bpp == 24) t = px(row[3 * x + 2] / 255.0f, row[3 * x + 1] / 255.0f, row[3 * x] / 255.0f, 1.0f);
-            else { const uint32_t v = bpp == 16 ? ((uint32_t)row[2 * x] | ((uint32_t)row[2 * x + 1] << 8)) : ((uint32_t)row[4 * x] | ((uint32_t)row[4 * x + 1] << 8) | ((uint32_t)row[4 * x + 2] << 16) | ((uint32_t)row[4 * x + 3] << 24));
+            else { const uint32_t v = bpp == 16 ? ((uint32_t)row[2 * x] | ((uint32_t)row[2 * x + 1] << 8)) : ((uint32_t)row[4 * x] | ((uint32_t)row[4 * x +
+                1] << 8) | ((uint32_t)row[4 * x + 2] << 16) | ((uint32_t)row[4 * x + 3] << 24));
                    t = px(maskUnorm(v, rm), maskUnorm(v, gm), maskUnorm(v, bm), am ? maskUnorm(v, am) : 1.0f); }
             if (t.w != 1.0f) anyAlpha = true;
             img.texels[(size_t)y * W + x] = t;
@@ -389,7 +418,8 @@ bool decodeBmp(const std::vector<uint8_t>& d, DecodedImage& img, std::string& er
 float halfToFloat(uint16_t h)
 {
     const uint32_t s = (uint32_t)(h >> 15) << 31, e = (h >> 10) & 31u, m = h & 1023u; uint32_t u;
-    if (e == 0) { if (!m) u = s; else { int k = 0; uint32_t mm = m; while (!(mm & 1024u)) { mm <<= 1; k++; } u = s | ((uint32_t)(113 - k) << 23) | ((mm & 1023u) << 13); } }
+    if (e == 0) { if (!m) u = s; else { int k = 0; uint32_t mm = m; while (!(mm & 1024u)) { mm <<= 1; k++;
+        } u = s | ((uint32_t)(113 - k) << 23) | ((mm & 1023u) << 13); } }
     else if (e == 31) u = s | 0x7f800000u | (m << 13);
     else u = s | ((e + 112u) << 23) | (m << 13);
     float f; memcpy(&f, &u, 4); return f;
@@ -414,7 +444,8 @@ void bcAlpha8(const uint8_t* b, float a[8], bool snorm) /* the interpolated-alph
     if (eight) for (int i = 1; i < 7; i++) a[1 + i] = ((float)(7 - i) * a0 + (float)i * a1) / 7.0f;
     else { for (int i = 1; i < 5; i++) a[1 + i] = ((float)(5 - i) * a0 + (float)i * a1) / 5.0f; a[6] = snorm ? -1.0f : 0.0f; a[7] = 1.0f; }
 }
-uint32_t bcAlphaIndex(const uint8_t* b, int texel) { uint64_t bits = 0; for (int i = 0; i < 6; i++) bits |= (uint64_t)b[2 + i] << (8 * i); return (uint32_t)(bits >> (3 * texel)) & 7u; }
+uint32_t bcAlphaIndex(const uint8_t* b, int texel) { uint64_t bits = 0; for (int i = 0; i < 6; i++) bits |= (uint64_t)b[2 + i] << (8 * i);
+    return (uint32_t)(bits >> (3 * texel)) & 7u; }
 
 /* BC7 (DXGI 97-99): eight block modes, up to three endpoint subsets chosen by a fixed partition shape, 2-4 bit indices of which the
  * "anchor" pixel of every subset stores one bit less (D3D11 functional spec 19.5.9; the tables are the format's constants, regenerated by
@@ -471,7 +502,8 @@ const uint8_t bc7Anchor3b[64] = {
 struct Bc7Mode { uint8_t subsets, partBits, rotBits, idxSelBit, colourBits, alphaBits, endpointP, sharedP, idxBits, idx2Bits; };
 const Bc7Mode bc7Modes[8] = {{3, 4, 0, 0, 4, 0, 1, 0, 3, 0}, {2, 6, 0, 0, 6, 0, 0, 1, 3, 0}, {3, 6, 0, 0, 5, 0, 0, 0, 2, 0}, {2, 6, 0, 0, 7, 0, 1, 0, 2, 0},
                              {1, 0, 2, 1, 5, 6, 0, 0, 2, 3}, {1, 0, 2, 0, 7, 8, 0, 0, 2, 2}, {1, 0, 0, 0, 7, 7, 1, 0, 4, 0}, {2, 6, 0, 0, 5, 5, 1, 0, 2, 0}};
-const uint8_t bc7Weights2[4] = {0, 21, 43, 64}, bc7Weights3[8] = {0, 9, 18, 27, 37, 46, 55, 64}, bc7Weights4[16] = {0, 4, 9, 13, 17, 21, 26, 30, 34, 38, 43, 47, 51, 55, 60, 64};
+const uint8_t bc7Weights2[4] = {0, 21, 43, 64}, bc7Weights3[8] = {0, 9, 18, 27, 37, 46, 55, 64}, bc7Weights4[16] = {0, 4, 9, 13, 17, 21, 26, 30, 34, 38, 43,
+    47, 51, 55, 60, 64};
 
 void bc7Block(const uint8_t* b, TbFloat4 texel[16])
 {
@@ -486,7 +518,8 @@ void bc7Block(const uint8_t* b, TbFloat4 texel[16])
     for (uint32_t e = 0; e < numEp; e++) ep[e][3] = m.alphaBits ? get(m.alphaBits) : 255u;
     uint32_t cb = m.colourBits, ab = m.alphaBits;
     if (m.endpointP || m.sharedP) {
-        uint32_t pb[6]; if (m.endpointP) for (uint32_t e = 0; e < numEp; e++) pb[e] = get(1); else for (uint32_t k = 0; k < m.subsets; k++) pb[2 * k] = pb[2 * k + 1] = get(1);
+        uint32_t pb[6]; if (m.endpointP) for (uint32_t e = 0; e < numEp; e++) pb[e] = get(1);
+            else for (uint32_t k = 0; k < m.subsets; k++) pb[2 * k] = pb[2 * k + 1] = get(1);
         for (uint32_t e = 0; e < numEp; e++) { for (int c = 0; c < 3; c++) ep[e][c] = (ep[e][c] << 1) | pb[e]; if (ab) ep[e][3] = (ep[e][3] << 1) | pb[e]; }
         cb++; if (ab) ab++;
     }
@@ -522,20 +555,26 @@ bool decodeDds(const std::vector<uint8_t>& d, DecodedImage& img, std::string& er
     const uint32_t rm = rd32(d, 92), gm = rd32(d, 96), bm = rd32(d, 100), am = rd32(d, 104);
     if (!ImageDimensionsOk(W, H)) { err = "DDS: bad dimensions (a 2-D texture has at most 16384 texels a side)"; return false; }
     size_t off = 128; uint32_t dxgi = 0;
-    auto cc = [](const char* s) { return (uint32_t)(uint8_t)s[0] | ((uint32_t)(uint8_t)s[1] << 8) | ((uint32_t)(uint8_t)s[2] << 16) | ((uint32_t)(uint8_t)s[3] << 24); };
+    auto cc = [](const char* s) { return (uint32_t)(uint8_t)s[0] | ((uint32_t)(uint8_t)s[1] << 8) | ((uint32_t)(uint8_t)s[2] << 16) |
+        ((uint32_t)(uint8_t)s[3] << 24); };
     enum { RAW, BC1, BC2, BC3, BC4, BC5, BC4S, BC5S, BC7, F16, F32, F32R, U16 } kind = RAW;
     if (pfFlags & 4u) {
         if (fourcc == cc("DX10")) { if (d.size() < 148) { err = "DDS: truncated DX10 header"; return false; } dxgi = rd32(d, 128); off = 148; }
-        else if (fourcc == cc("DXT1")) kind = BC1; else if (fourcc == cc("DXT2") || fourcc == cc("DXT3")) kind = BC2; else if (fourcc == cc("DXT4") || fourcc == cc("DXT5")) kind = BC3;
-        else if (fourcc == cc("ATI1") || fourcc == cc("BC4U")) kind = BC4; else if (fourcc == cc("BC4S")) kind = BC4S; else if (fourcc == cc("ATI2") || fourcc == cc("BC5U")) kind = BC5; else if (fourcc == cc("BC5S")) kind = BC5S;
+        else if (fourcc == cc("DXT1")) kind = BC1; else if (fourcc == cc("DXT2") || fourcc == cc("DXT3")) kind = BC2;
+            else if (fourcc == cc("DXT4") || fourcc == cc("DXT5")) kind = BC3;
+        else if (fourcc == cc("ATI1") || fourcc == cc("BC4U")) kind = BC4; else if (fourcc == cc("BC4S")) kind = BC4S;
+            else if (fourcc == cc("ATI2") || fourcc == cc("BC5U")) kind = BC5; else if (fourcc == cc("BC5S")) kind = BC5S;
         else if (fourcc == 113) kind = F16; else if (fourcc == 116) kind = F32; else if (fourcc == 114) kind = F32R; else if (fourcc == 36) kind = U16;
         else { err = "DDS: unsupported FourCC"; return false; }
     }
-    uint32_t m[4] = {rm, gm, bm, (pfFlags & 1u) ? am : 0u}; uint32_t rawBits = bits; bool lum = (pfFlags & 0x20000u) != 0, alphaOnly = (pfFlags & 2u) != 0 && !(pfFlags & 0x40u) && !lum;
+    uint32_t m[4] = {rm, gm, bm, (pfFlags & 1u) ? am : 0u}; uint32_t rawBits = bits;
+        bool lum = (pfFlags & 0x20000u) != 0, alphaOnly = (pfFlags & 2u) != 0 && !(pfFlags & 0x40u) && !lum;
     if (dxgi) {
         switch (dxgi) {
-        case 71: case 72: kind = BC1; break; case 74: case 75: kind = BC2; break; case 77: case 78: kind = BC3; break; case 80: kind = BC4; break; case 81: kind = BC4S; break;
-        case 83: kind = BC5; break; case 84: kind = BC5S; break; case 97: case 98: case 99: kind = BC7; break; case 10: kind = F16; break; case 2: kind = F32; break; case 41: kind = F32R; break; case 11: kind = U16; break;
+        case 71: case 72: kind = BC1; break; case 74: case 75: kind = BC2; break; case 77: case 78: kind = BC3; break; case 80: kind = BC4; break;
+            case 81: kind = BC4S; break;
+        case 83: kind = BC5; break; case 84: kind = BC5S; break; case 97: case 98: case 99: kind = BC7; break; case 10: kind = F16; break; case 2: kind = F32;
+            break; case 41: kind = F32R; break; case 11: kind = U16; break;
         case 28: case 29: kind = RAW; rawBits = 32; m[0] = 0xff; m[1] = 0xff00; m[2] = 0xff0000; m[3] = 0xff000000u; break;          /* R8G8B8A8_UNORM(_SRGB) */
         case 87: case 91: kind = RAW; rawBits = 32; m[0] = 0xff0000; m[1] = 0xff00; m[2] = 0xff; m[3] = 0xff000000u; break;          /* B8G8R8A8 */
         case 88: case 93: kind = RAW; rawBits = 32; m[0] = 0xff0000; m[1] = 0xff00; m[2] = 0xff; m[3] = 0; break;                    /* B8G8R8X8 */
@@ -547,7 +586,8 @@ bool decodeDds(const std::vector<uint8_t>& d, DecodedImage& img, std::string& er
     }
     bool sized = false;
     auto need = [&](size_t bytes) { if (off + bytes > d.size()) throw std::runtime_error("DDS: truncated surface");
-                                    if (!sized) { img.texels.assign((size_t)W * H, px(0, 0, 0, 1)); sized = true; } };   /* nothing of the header's size is allocated before the surface is known to be there */
+                                    /* nothing of the header's size is allocated before the surface is known to be there */
+                                    if (!sized) { img.texels.assign((size_t)W * H, px(0, 0, 0, 1)); sized = true; } };
     img.width = W; img.height = H; img.normalized = !(kind == F16 || kind == F32 || kind == F32R);
     if (kind == RAW) {
         if (rawBits != 8 && rawBits != 16 && rawBits != 24 && rawBits != 32) { err = "DDS: unsupported bit count"; return false; }
@@ -556,7 +596,8 @@ bool decodeDds(const std::vector<uint8_t>& d, DecodedImage& img, std::string& er
             uint32_t v = 0; for (size_t k = 0; k < bpp; k++) v |= (uint32_t)d[off + i * bpp + k] << (8 * k);
             TbFloat4 t;
             if (alphaOnly) t = px(0, 0, 0, maskUnorm(v, am ? am : 0xffu));
-            else if (lum) { const float l = maskUnorm(v, m[0]); t = px(l, l, l, m[3] ? maskUnorm(v, m[3]) : 1.0f); }       /* L8 / A8L8: DirectXTex expands luminance to grey RGB */
+            /* L8 / A8L8: DirectXTex expands luminance to grey RGB */
+            else if (lum) { const float l = maskUnorm(v, m[0]); t = px(l, l, l, m[3] ? maskUnorm(v, m[3]) : 1.0f); }
             else if (!m[1] && !m[2] && dxgi == 61) t = px(maskUnorm(v, m[0]), 0.0f, 0.0f, 1.0f);
             else t = px(maskUnorm(v, m[0]), maskUnorm(v, m[1]), maskUnorm(v, m[2]), m[3] ? maskUnorm(v, m[3]) : 1.0f);
             img.texels[i] = t;
@@ -566,7 +607,8 @@ bool decodeDds(const std::vector<uint8_t>& d, DecodedImage& img, std::string& er
         for (size_t i = 0; i < (size_t)W * H; i++) {
             const size_t o = off + i * bpp; float f[4] = {0, 0, 0, 1};
             if (kind == F32) memcpy(f, &d[o], 16); else if (kind == F32R) memcpy(f, &d[o], 4);
-            else for (int k = 0; k < 4; k++) { const uint16_t h = (uint16_t)rd16(d, o + 2 * (size_t)k); f[k] = kind == F16 ? halfToFloat(h) : (float)h / 65535.0f; }
+            else for (int k = 0; k < 4; k++) { const uint16_t h = (uint16_t)rd16(d, o + 2 * (size_t)k);
+                f[k] = kind == F16 ? halfToFloat(h) : (float)h / 65535.0f; }
             img.texels[i] = px(f[0], f[1], f[2], f[3]);
         }
     } else {
@@ -580,13 +622,16 @@ bool decodeDds(const std::vector<uint8_t>& d, DecodedImage& img, std::string& er
                 const uint32_t idx = (uint32_t)cb[4] | ((uint32_t)cb[5] << 8) | ((uint32_t)cb[6] << 16) | ((uint32_t)cb[7] << 24);
                 float a8[8]; if (kind == BC3) bcAlpha8(b, a8, false);
                 for (int t = 0; t < 16; t++) { texel[t] = c[(idx >> (2 * t)) & 3u];
-                    if (kind == BC2) texel[t].w = (float)((b[t / 2] >> (4 * (t & 1))) & 15) / 15.0f; else if (kind == BC3) texel[t].w = a8[bcAlphaIndex(b, t)]; }
+                    if (kind == BC2) texel[t].w = (float)((b[t / 2] >> (4 * (t & 1))) & 15) / 15.0f; else if (kind == BC3) texel[t].w = a8[bcAlphaIndex(b, t)];
+                        }
             } else if (kind == BC7) bc7Block(b, texel);
             else {
                 const bool sn = kind == BC4S || kind == BC5S; float r8[8], g8[8]; bcAlpha8(b, r8, sn); if (kind == BC5 || kind == BC5S) bcAlpha8(b + 8, g8, sn);
-                for (int t = 0; t < 16; t++) texel[t] = px(r8[bcAlphaIndex(b, t)], (kind == BC5 || kind == BC5S) ? g8[bcAlphaIndex(b + 8, t)] : 0.0f, 0.0f, 1.0f);
+                for (int t = 0; t < 16; t++) texel[t] = px(r8[bcAlphaIndex(b, t)], (kind == BC5 || kind == BC5S) ? g8[bcAlphaIndex(b + 8, t)] : 0.0f, 0.0f,
+                    1.0f);
             }
-            for (int t = 0; t < 16; t++) { const uint32_t x = bx * 4 + (uint32_t)(t & 3), y = by * 4 + (uint32_t)(t >> 2); if (x < W && y < H) img.texels[(size_t)y * W + x] = texel[t]; }
+            for (int t = 0; t < 16; t++) { const uint32_t x = bx * 4 + (uint32_t)(t & 3), y = by * 4 + (uint32_t)(t >> 2);
+                if (x < W && y < H) img.texels[(size_t)y * W + x] = texel[t]; }
         }
     }
     bool anyAlpha = false; for (const TbFloat4& t : img.texels) if (t.w != 1.0f) { anyAlpha = true; break; }

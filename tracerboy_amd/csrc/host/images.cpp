@@ -41,7 +41,8 @@ bool loadHdr(const std::string& file, std::vector<TbFloat4>& texels, uint32_t& W
     (void)rgbe;
     std::getline(in, line);
     int h = 0, w = 0; char sy = 0, sx = 0, ay = 0, ax = 0;
-    if (sscanf(line.c_str(), "%c%c %d %c%c %d", &sy, &ay, &h, &sx, &ax, &w) != 6 || ay != 'Y' || ax != 'X' || w <= 0 || h <= 0) { err = file + ": unsupported HDR resolution line '" + line + "'"; return false; }
+    if (sscanf(line.c_str(), "%c%c %d %c%c %d", &sy, &ay, &h, &sx, &ax,
+        &w) != 6 || ay != 'Y' || ax != 'X' || w <= 0 || h <= 0) { err = file + ": unsupported HDR resolution line '" + line + "'"; return false; }
     W = (uint32_t)w; H = (uint32_t)h;
     if (!ImageDimensionsOk(W, H)) { err = file + ": HDR dimensions beyond the 16384 a 2-D texture can have"; return false; }
     {   /* a run-length packet holds at most 127 values of one channel in 2 bytes: refuse a header the rest of the file cannot fill */
@@ -60,8 +61,10 @@ bool loadHdr(const std::string& file, std::vector<TbFloat4>& texels, uint32_t& W
                 while (x < W) {
                     unsigned char cnt; in.read((char*)&cnt, 1);
                     if (!in) { err = file + ": truncated HDR data"; return false; }
-                    if (cnt > 128) { unsigned char v; in.read((char*)&v, 1); uint32_t n = cnt - 128u; if (x + n > W) { err = file + ": bad HDR run"; return false; } for (uint32_t k = 0; k < n; k++) scan[(size_t)(x++) * 4 + c] = v; }
-                    else { uint32_t n = cnt; if (n == 0 || x + n > W) { err = file + ": bad HDR run"; return false; } for (uint32_t k = 0; k < n; k++) { unsigned char v; in.read((char*)&v, 1); scan[(size_t)(x++) * 4 + c] = v; } }
+                    if (cnt > 128) { unsigned char v; in.read((char*)&v, 1); uint32_t n = cnt - 128u; if (x + n > W) { err = file + ": bad HDR run";
+                        return false; } for (uint32_t k = 0; k < n; k++) scan[(size_t)(x++) * 4 + c] = v; }
+                    else { uint32_t n = cnt; if (n == 0 || x + n > W) { err = file + ": bad HDR run"; return false;
+                        } for (uint32_t k = 0; k < n; k++) { unsigned char v; in.read((char*)&v, 1); scan[(size_t)(x++) * 4 + c] = v; } }
                 }
             }
         } else {
@@ -111,7 +114,8 @@ bool loadPfm(const std::string& file, std::vector<TbFloat4>& texels, uint32_t& W
 
 } // namespace
 
-bool LoadImageRGBA32F(const std::string& file, std::vector<TbFloat4>& texels, uint32_t& w, uint32_t& h, bool& normalizedFormat, std::string& err, bool* hasAlpha)
+bool LoadImageRGBA32F(const std::string& file, std::vector<TbFloat4>& texels, uint32_t& w, uint32_t& h, bool& normalizedFormat, std::string& err,
+    bool* hasAlpha)
 {
     normalizedFormat = false;
     if (hasAlpha) *hasAlpha = false;
@@ -154,7 +158,8 @@ bool LoadBlueNoiseTiles(HostScene& scene)
         std::vector<unsigned char> raw(256 * 256 * 4);
         if (!in || !in.read((char*)raw.data(), (std::streamsize)raw.size())) { scene.blueNoise0.clear(); scene.blueNoise1.clear(); return false; }
         dst[i]->resize(256 * 256);
-        for (size_t p = 0; p < 256 * 256; p++) (*dst[i])[p] = TbFloat4{raw[4 * p] / 255.0f, raw[4 * p + 1] / 255.0f, raw[4 * p + 2] / 255.0f, raw[4 * p + 3] / 255.0f};
+        for (size_t p = 0; p < 256 * 256; p++) (*dst[i])[p] = TbFloat4{raw[4 * p] / 255.0f, raw[4 * p + 1] / 255.0f, raw[4 * p + 2] / 255.0f,
+            raw[4 * p + 3] / 255.0f};
     }
     return true;
 }
@@ -165,11 +170,13 @@ namespace {
 uint32_t crc32_update(uint32_t crc, const uint8_t* p, size_t n)
 {
     static uint32_t table[256]; static bool init = false;
-    if (!init) { for (uint32_t i = 0; i < 256; i++) { uint32_t c = i; for (int k = 0; k < 8; k++) c = (c & 1) ? 0xedb88320u ^ (c >> 1) : c >> 1; table[i] = c; } init = true; }
+    if (!init) { for (uint32_t i = 0; i < 256; i++) { uint32_t c = i; for (int k = 0; k < 8; k++) c = (c & 1) ? 0xedb88320u ^ (c >> 1) : c >> 1; table[i] = c;
+        } init = true; }
     for (size_t i = 0; i < n; i++) crc = table[(crc ^ p[i]) & 0xff] ^ (crc >> 8);
     return crc;
 }
-void put32be(std::vector<uint8_t>& v, uint32_t x) { v.push_back((uint8_t)(x >> 24)); v.push_back((uint8_t)(x >> 16)); v.push_back((uint8_t)(x >> 8)); v.push_back((uint8_t)x); }
+void put32be(std::vector<uint8_t>& v, uint32_t x) { v.push_back((uint8_t)(x >> 24)); v.push_back((uint8_t)(x >> 16)); v.push_back((uint8_t)(x >> 8));
+    v.push_back((uint8_t)x); }
 void pngChunk(std::vector<uint8_t>& out, const char type[4], const std::vector<uint8_t>& data)
 {
     put32be(out, (uint32_t)data.size());
@@ -196,7 +203,8 @@ bool WritePngRGBA8(const std::string& file, uint32_t W, uint32_t H, const uint8_
     }
     put32be(z, (b << 16) | a);
     std::vector<uint8_t> out = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
-    std::vector<uint8_t> ihdr; put32be(ihdr, W); put32be(ihdr, H); ihdr.push_back(8); ihdr.push_back(6); ihdr.push_back(0); ihdr.push_back(0); ihdr.push_back(0);
+    std::vector<uint8_t> ihdr; put32be(ihdr, W); put32be(ihdr, H); ihdr.push_back(8); ihdr.push_back(6); ihdr.push_back(0); ihdr.push_back(0);
+        ihdr.push_back(0);
     pngChunk(out, "IHDR", ihdr); pngChunk(out, "IDAT", z); pngChunk(out, "IEND", {});
     FILE* f = fopen(file.c_str(), "wb");
     if (!f) { err = "cannot open " + file + " for writing"; return false; }
@@ -257,7 +265,8 @@ bool WriteExrRGBA(const std::string& file, uint32_t W, uint32_t H, const float* 
     std::vector<float> line((size_t)W * 4);
     for (uint32_t y = 0; y < H && ok; y++) {
         const float* src = rgba + (size_t)y * W * 4;
-        for (uint32_t x = 0; x < W; x++) { line[x] = src[x * 4 + 3]; line[W + x] = src[x * 4 + 2]; line[2 * (size_t)W + x] = src[x * 4 + 1]; line[3 * (size_t)W + x] = src[x * 4]; }
+        for (uint32_t x = 0; x < W; x++) { line[x] = src[x * 4 + 3]; line[W + x] = src[x * 4 + 2]; line[2 * (size_t)W + x] = src[x * 4 + 1];
+            line[3 * (size_t)W + x] = src[x * 4]; }
         const int32_t head[2] = {(int32_t)y, (int32_t)(16u * W)};
         ok = fwrite(head, 4, 2, f) == 2 && fwrite(line.data(), 4, line.size(), f) == line.size();
     }

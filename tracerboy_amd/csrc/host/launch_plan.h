@@ -20,10 +20,13 @@ inline void PlanLaunch(const tb_plan_input& in, tb_launch_plan& p)
          * deep, or option split_stack_cap of them with the rest in global memory), the scene image, 48-B ray slots, the queue -- beyond
          * 160 KB, or more 8x8 tiles than a claimed item has bits for (frames above ~8192 x 8192).  Such a call runs the lock-step kernel,
          * with a rule of its own (it used to throw a generic HIP error out of renderSplit). */
-        const uint64_t trav = (uint64_t)std::max<int64_t>(1, in.split_trav), shade = in.split_shade > 0 ? (uint64_t)in.split_shade : (in.scene_in_lds ? 4u : 6u);
+        const uint64_t trav = (uint64_t)std::max<int64_t>(1, in.split_trav),
+            shade = in.split_shade > 0 ? (uint64_t)in.split_shade : (in.scene_in_lds ? 4u : 6u);
         uint64_t ring = 256; while (ring < 256u * shade) ring *= 2;
-        const uint64_t entries = (in.split_stack_cap > 0 && (uint64_t)in.split_stack_cap < in.stack_depth && !in.scene_in_lds) ? (uint64_t)in.split_stack_cap : in.stack_depth;
-        const uint64_t lds = entries * trav * 256u + (in.scene_in_lds ? ((uint64_t)in.lds_blob_bytes + 15u) / 16u * 16u : 0u) + shade * 128u * 48u + ring * 4u + 16u;
+        const uint64_t entries = (in.split_stack_cap > 0 && (uint64_t)in.split_stack_cap < in.stack_depth && !in.scene_in_lds) ? (uint64_t)in.split_stack_cap :
+            in.stack_depth;
+        const uint64_t lds = entries * trav * 256u + (in.scene_in_lds ? ((uint64_t)in.lds_blob_bytes + 15u) / 16u * 16u : 0u) + shade * 128u * 48u + ring *
+            4u + 16u;
         const bool fits = lds <= 160u * 1024u && 4ull * std::max<uint64_t>(1, in.owned_regions) <= 0xfffffull && (trav + shade) * 64u <= 1024u;
         if (fits) { p.pipeline = 4; p.rule_pipeline = TB_PLAN_RULE_SPLIT; return; }
         p.rule_pipeline = TB_PLAN_RULE_SPLIT_NO_ROOM; /* and on with the lock-step kernel's plan; the rule stays */
@@ -45,18 +48,21 @@ inline void PlanLaunch(const tb_plan_input& in, tb_launch_plan& p)
         const uint64_t share = (160u * 1024u / in.variant_waves_hi) / 512u * 512u, fixed = (in.scene_in_lds ? in.lds_blob_bytes : 0u) + 128u;
         const uint64_t ldsPerGroup = ((uint64_t)in.stack_depth * 1024u + fixed + 511u) / 512u * 512u; /* + static LDS, 512-B granules */
         const int64_t forcedCap = in.stack_lds_cap; /* tests: split the stack although it would fit */
-        if (ldsPerGroup <= share && !(forcedCap > 0 && p.groups && (uint64_t)forcedCap < in.stack_depth)) { p.high_occupancy_copy = 1; p.rule_copy = TB_PLAN_RULE_COPY_FITS; }
+        if (ldsPerGroup <= share && !(forcedCap > 0 && p.groups && (uint64_t)forcedCap < in.stack_depth)) { p.high_occupancy_copy = 1;
+            p.rule_copy = TB_PLAN_RULE_COPY_FITS; }
         else if (p.groups && share > fixed + 4u * 1024u) {
             uint32_t cap = (uint32_t)((share - fixed) / 1024u);
             if (forcedCap > 0) cap = std::min<uint32_t>(cap, (uint32_t)forcedCap);
             const uint32_t over = in.stack_depth > cap ? in.stack_depth - cap : 0u;
-            if (over > 0 && over <= (uint32_t)in.stack_overflow_max) { p.high_occupancy_copy = 1; p.stack_lds_entries = cap; p.stack_overflow_entries = over; p.rule_copy = TB_PLAN_RULE_COPY_SPLIT_STACK; }
+            if (over > 0 && over <= (uint32_t)in.stack_overflow_max) { p.high_occupancy_copy = 1; p.stack_lds_entries = cap; p.stack_overflow_entries = over;
+                p.rule_copy = TB_PLAN_RULE_COPY_SPLIT_STACK; }
             else p.rule_copy = TB_PLAN_RULE_COPY_TOO_DEEP;
         } else p.rule_copy = TB_PLAN_RULE_COPY_NO_ROOM;
     } else p.rule_copy = TB_PLAN_RULE_COPY_NONE;
     /* Two-level scenes: the tuned walk lives in the frame-group kernels of the higher-occupancy copies; every other launch of an
      * instanced scene goes to the full feature set, whose kernels carry the walk in all their forms */
-    if (in.two_level && !(p.high_occupancy_copy && p.groups)) { p.full_variant = 1; p.high_occupancy_copy = 0; p.stack_lds_entries = in.stack_depth; p.stack_overflow_entries = 0; p.rule_copy = TB_PLAN_RULE_COPY_FULL_FOR_INSTANCES; }
+    if (in.two_level && !(p.high_occupancy_copy && p.groups)) { p.full_variant = 1; p.high_occupancy_copy = 0; p.stack_lds_entries = in.stack_depth;
+        p.stack_overflow_entries = 0; p.rule_copy = TB_PLAN_RULE_COPY_FULL_FOR_INSTANCES; }
     const bool ext = p.full_variant || (in.variant_features & TB_PLAN_FEAT_EXT) != 0, sss = !p.full_variant && (in.variant_features & TB_PLAN_FEAT_SSS) != 0;
     /* Compact nodes (option node_layout = 1): frame-group kernels of the higher-occupancy copies, scenes fetched from memory */
     p.compact_nodes = in.node_layout == 1 && in.has_compact_nodes && p.high_occupancy_copy && p.groups && !in.scene_in_lds && !in.two_level;
@@ -68,7 +74,8 @@ inline void PlanLaunch(const tb_plan_input& in, tb_launch_plan& p)
      * scene in which glass is one material among others (fewer than half of the triangles: van- / bistro-class 20 % / 10 %, +9 % / +8 %);
      * BY TRIAL elsewhere (516 k triangles of glass blobs lose 5.6 % with it, the same scene in matte 1.2 %): renderImpl times the first
      * calls of a kind both ways and keeps the faster (the pictures are the same bits either way). */
-    const bool prepassKernels = ((in.variant_waves_hi && p.high_occupancy_copy) || (!in.variant_waves_hi && in.variant_prepass_in_base && !p.full_variant && !p.stack_overflow_entries))
+    const bool prepassKernels = ((in.variant_waves_hi && p.high_occupancy_copy) || (!in.variant_waves_hi && in.variant_prepass_in_base && !p.full_variant &&
+        !p.stack_overflow_entries))
                                 && p.groups && !in.scene_in_lds && !in.two_level && !ext && in.max_bounces > 0;
     p.prepass = TB_PLAN_PREPASS_OFF; p.rule_prepass = TB_PLAN_RULE_PREPASS_NO_KERNEL;
     if (prepassKernels) {
@@ -77,10 +84,12 @@ inline void PlanLaunch(const tb_plan_input& in, tb_launch_plan& p)
         else if (in.primary_prepass == 1) {
             /* the call's OWN samples: a rank of a tile split renders its tiles only (round 5: rank 0 of 8 on a 4K frame x 8 is an
              * 8.3 M-sample call, where the pre-pass between two launches of a stream costs what it saves: 6.53 / 6.45 ms with / without) */
-            const uint64_t callSamples = std::min<uint64_t>((uint64_t)in.width * in.height, (uint64_t)std::max<uint64_t>(1, in.owned_regions) * 256u) * in.frames;
+            const uint64_t callSamples = std::min<uint64_t>((uint64_t)in.width * in.height, (uint64_t)std::max<uint64_t>(1,
+                in.owned_regions) * 256u) * in.frames;
             if (callSamples < (1ull << 24)) p.rule_prepass = TB_PLAN_RULE_PREPASS_SMALL_CALL;
             else if (!sss && !in.has_lights) { p.prepass = TB_PLAN_PREPASS_ON; p.rule_prepass = TB_PLAN_RULE_PREPASS_ENV_LIT; }
-            else if (sss && in.interior_walk_triangle_share < 0.5f) { p.prepass = TB_PLAN_PREPASS_ON; p.rule_prepass = TB_PLAN_RULE_PREPASS_GLASS_AMONG_OTHERS; }
+            else if (sss && in.interior_walk_triangle_share < 0.5f) { p.prepass = TB_PLAN_PREPASS_ON; p.rule_prepass = TB_PLAN_RULE_PREPASS_GLASS_AMONG_OTHERS;
+                }
             else { p.prepass = TB_PLAN_PREPASS_TRIAL; p.rule_prepass = TB_PLAN_RULE_PREPASS_TRIAL; }
         }
     }
@@ -102,7 +111,8 @@ inline void PlanLaunch(const tb_plan_input& in, tb_launch_plan& p)
     const uint64_t regions = std::max<uint64_t>(1, in.owned_regions);
     const uint32_t frames = std::min(batch, in.frames);
     const uint64_t capG = in.scene_in_lds ? 64 : (sss ? 16 : 4), itemsWanted = in.scene_in_lds ? 12288 : 24576;
-    const uint32_t autoG = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(frames, capG), std::max<uint64_t>(1, ((uint64_t)frames * regions + itemsWanted - 1) / itemsWanted));
+    const uint32_t autoG = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(frames, capG), std::max<uint64_t>(1,
+        ((uint64_t)frames * regions + itemsWanted - 1) / itemsWanted));
     uint32_t G = in.frame_group > 0 ? (uint32_t)in.frame_group : autoG;
     while (G & (G - 1)) G &= G - 1;
     while ((frames + G - 1) / G > 4095u) G *= 2;

@@ -27,7 +27,8 @@ namespace {
 enum { /* BinaryFileFormat.cpp:48-109 */
     T_SCENE = 1, T_OBJECT, T_SHAPE, T_INSTANCE, T_CAMERA, T_FILM, T_SPECTRUM, T_SAMPLER, T_INTEGRATOR,
     T_MATERIAL = 10, T_DISNEY, T_UBER, T_MIX, T_GLASS, T_MIRROR, T_MATTE, T_SUBSTRATE, T_SUBSURFACE, T_FOURIER, T_METAL, T_PLASTIC, T_TRANSLUCENT, T_HAIR,
-    T_TEXTURE = 30, T_IMAGE_TEXTURE, T_SCALE_TEXTURE, T_PTEX_TEXTURE, T_CONSTANT_TEXTURE, T_CHECKER_TEXTURE, T_WINDY, T_FBM, T_MARBLE, T_MIX_TEXTURE, T_WRINKLED,
+    T_TEXTURE = 30, T_IMAGE_TEXTURE, T_SCALE_TEXTURE, T_PTEX_TEXTURE, T_CONSTANT_TEXTURE, T_CHECKER_TEXTURE, T_WINDY, T_FBM, T_MARBLE, T_MIX_TEXTURE,
+        T_WRINKLED,
     T_TRIANGLE_MESH = 50, T_QUAD_MESH, T_SPHERE, T_DISK, T_CURVE,
     T_AREALIGHT_BB = 60, T_AREALIGHT_RGB,
     T_INFINITE_LIGHT = 70, T_DISTANT_LIGHT, T_SPOT_LIGHT, T_POINT_LIGHT,
@@ -55,8 +56,10 @@ struct Cursor {
     bool b() { return get<uint8_t>() != 0; }
     Vec3 v3() { Vec3 v; v.x = f(); v.y = f(); v.z = f(); return v; }
     Affine affine() { Affine a; a.l.vx = v3(); a.l.vy = v3(); a.l.vz = v3(); a.p = v3(); return a; }
-    std::string str() { int32_t k = i32(); if (k < 0) throw std::runtime_error("pbf: negative string length"); std::string s((size_t)k, ' '); bytes(&s[0], (size_t)k); return s; }
-    uint64_t count(size_t elemBytes) { uint64_t c = get<uint64_t>(); if (elemBytes && c > (n - at) / elemBytes) throw std::runtime_error("pbf: vector longer than its entity"); return c; }
+    std::string str() { int32_t k = i32(); if (k < 0) throw std::runtime_error("pbf: negative string length"); std::string s((size_t)k, ' ');
+        bytes(&s[0], (size_t)k); return s; }
+    uint64_t count(size_t elemBytes) { uint64_t c = get<uint64_t>();
+        if (elemBytes && c > (n - at) / elemBytes) throw std::runtime_error("pbf: vector longer than its entity"); return c; }
     void skipSpectrum() { uint64_t c = count(8); at += (size_t)c * 8; } /* Spectrum::spd, vector<pair<float,float>> */
 };
 
@@ -125,7 +128,8 @@ struct Reader {
             m.roughness = c.f(); m.uRoughness = c.f(); m.vRoughness = c.f(); c.b(); c.skipSpectrum(); c.skipSpectrum(); m.eta3 = c.v3();
             break; }
         case T_MIRROR: { material(e, c, "mirror"); tex(c); e.mat->kr = c.v3(); break; }
-        case T_PLASTIC: { material(e, c, "plastic"); PbrtMaterial& m = *e.mat; m.map_kd = tex(c); tex(c); m.kd = c.v3(); m.ks = c.v3(); m.roughness = c.f(); break; }
+        case T_PLASTIC: { material(e, c, "plastic"); PbrtMaterial& m = *e.mat; m.map_kd = tex(c); tex(c); m.kd = c.v3(); m.ks = c.v3(); m.roughness = c.f();
+            break; }
 
         case T_AREALIGHT_RGB: e.area = std::make_shared<AreaLight>(); e.area->rgb = true; e.area->L = c.v3(); break;
         case T_AREALIGHT_BB: e.area = std::make_shared<AreaLight>(); e.area->rgb = false; break;
@@ -164,11 +168,14 @@ struct Reader {
         case T_OBJECT: {
             e.obj = std::make_shared<PbrtObject>(); e.obj->name = c.str();
             int32_t n = c.i32();
-            for (int32_t i = 0; i < n; i++) { int id = c.i32(); if (id >= 0 && id < (int)ents.size()) { if (ents[(size_t)id].mesh) e.obj->shapes.push_back(ents[(size_t)id].mesh); else if (ents[(size_t)id].unsupportedShape) skipped++; } }
+            for (int32_t i = 0; i < n; i++) { int id = c.i32();
+                if (id >= 0 && id < (int)ents.size()) { if (ents[(size_t)id].mesh) e.obj->shapes.push_back(ents[(size_t)id].mesh);
+                else if (ents[(size_t)id].unsupportedShape) skipped++; } }
             n = c.i32();
             for (int32_t i = 0; i < n; i++) { std::shared_ptr<PbrtLight> l = ref(c.i32(), &Entity::light); if (l) objectLights[e.obj.get()].push_back(*l); }
             n = c.i32();
-            for (int32_t i = 0; i < n; i++) { std::shared_ptr<PbrtInstance> in = ref(c.i32(), &Entity::inst); if (in && in->object) e.obj->instances.push_back(*in); }
+            for (int32_t i = 0; i < n; i++) { std::shared_ptr<PbrtInstance> in = ref(c.i32(), &Entity::inst);
+                if (in && in->object) e.obj->instances.push_back(*in); }
             break; }
         case T_CAMERA: { e.cam = std::make_shared<Camera>(); e.cam->fov = c.f(); c.f(); c.f(); e.cam->frame = c.affine(); break; }
         case T_FILM: { e.film = std::make_shared<Film>(); e.film->w = c.i32(); e.film->h = c.i32(); break; }
@@ -193,8 +200,11 @@ std::shared_ptr<PbrtScene> importPBF(const std::string& fileName)
     FILE* f = fopen(fileName.c_str(), "rb");
     if (!f) throw std::runtime_error("could not open '" + fileName + "'");
     std::vector<uint8_t> data;
-    { struct stat st; if (fstat(fileno(f), &st) != 0 || !S_ISREG(st.st_mode)) { fclose(f); throw std::runtime_error("'" + fileName + "' is not a regular file"); } }
-    { fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET); data.resize(n > 0 ? (size_t)n : 0); if (!data.empty() && fread(data.data(), 1, data.size(), f) != data.size()) { fclose(f); throw std::runtime_error("short read from '" + fileName + "'"); } }
+    { struct stat st; if (fstat(fileno(f), &st) != 0 || !S_ISREG(st.st_mode)) { fclose(f);
+        throw std::runtime_error("'" + fileName + "' is not a regular file"); } }
+    { fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET); data.resize(n > 0 ? (size_t)n : 0);
+        if (!data.empty() && fread(data.data(), 1, data.size(), f) != data.size()) { fclose(f); throw std::runtime_error("short read from '" + fileName + "'");
+        } }
     fclose(f);
     if (data.size() < 4) throw std::runtime_error("pbf: file too short");
     int32_t tag; memcpy(&tag, data.data(), 4);
@@ -215,7 +225,8 @@ std::shared_ptr<PbrtScene> importPBF(const std::string& fileName)
     const SceneRec& sr = *r.ents.back().scene;
     auto scene = std::make_shared<PbrtScene>();
     scene->basePath = r.dir;
-    if (sr.film >= 0 && sr.film < (int)r.ents.size() && r.ents[(size_t)sr.film].film) { scene->filmWidth = r.ents[(size_t)sr.film].film->w; scene->filmHeight = r.ents[(size_t)sr.film].film->h; }
+    if (sr.film >= 0 && sr.film < (int)r.ents.size() && r.ents[(size_t)sr.film].film) { scene->filmWidth = r.ents[(size_t)sr.film].film->w;
+        scene->filmHeight = r.ents[(size_t)sr.film].film->h; }
     if (!sr.cameras.empty() && sr.cameras[0] >= 0 && sr.cameras[0] < (int)r.ents.size() && r.ents[(size_t)sr.cameras[0]].cam) {
         scene->hasCamera = true; scene->cameraFrame = r.ents[(size_t)sr.cameras[0]].cam->frame; scene->fov = r.ents[(size_t)sr.cameras[0]].cam->fov;
     }

@@ -26,9 +26,11 @@ void dumpMaterial(FILE* f, const PbrtMaterialSP& m)
     fprintf(f, "material_type 1 %s\n", ok ? t.c_str() : "other");
     if (!m) return;
     if (t == "matte") { putf(f, "kd", &m->kd.x, 3); putf(f, "sigma", &m->sigma, 1); fprintf(f, "map_kd 1 %d\n", m->map_kd ? 1 : 0); }
-    if (t == "substrate") { putf(f, "kd", &m->kd.x, 3); putf(f, "ks", &m->ks.x, 3); putf(f, "uroughness", &m->uRoughness, 1); putf(f, "vroughness", &m->vRoughness, 1); }
+    if (t == "substrate") { putf(f, "kd", &m->kd.x, 3); putf(f, "ks", &m->ks.x, 3); putf(f, "uroughness", &m->uRoughness, 1);
+        putf(f, "vroughness", &m->vRoughness, 1); }
     if (t == "plastic") { putf(f, "kd", &m->kd.x, 3); putf(f, "ks", &m->ks.x, 3); putf(f, "roughness", &m->roughness, 1); }
-    if (t == "uber") { putf(f, "kd", &m->kd.x, 3); putf(f, "ks", &m->ks.x, 3); putf(f, "kt", &m->kt.x, 3); putf(f, "opacity", &m->opacity.x, 3); putf(f, "index", &m->index, 1); putf(f, "roughness", &m->roughness, 1); putf(f, "uroughness", &m->uRoughness, 1); }
+    if (t == "uber") { putf(f, "kd", &m->kd.x, 3); putf(f, "ks", &m->ks.x, 3); putf(f, "kt", &m->kt.x, 3); putf(f, "opacity", &m->opacity.x, 3);
+        putf(f, "index", &m->index, 1); putf(f, "roughness", &m->roughness, 1); putf(f, "uroughness", &m->uRoughness, 1); }
     if (t == "mirror") putf(f, "kr", &m->kr.x, 3);
     if (t == "metal") { putf(f, "eta", &m->eta3.x, 3); putf(f, "roughness", &m->roughness, 1); putf(f, "uroughness", &m->uRoughness, 1); }
     if (t == "glass") putf(f, "index", &m->index, 1);

@@ -134,7 +134,8 @@ private:
             };
             Token v = next();
             if (v.text == "[" && !v.quoted) {
-                for (;;) { Token e = next(); if (e.eof) throw std::runtime_error("unterminated parameter list"); if (e.text == "]" && !e.quoted) break; addValue(e); }
+                for (;;) { Token e = next(); if (e.eof) throw std::runtime_error("unterminated parameter list"); if (e.text == "]" && !e.quoted) break;
+                    addValue(e); }
             } else addValue(v);
             ps[name] = p;
         }
@@ -143,10 +144,14 @@ private:
 
     static bool has(const ParamSet& ps, const std::string& n) { return ps.find(n) != ps.end(); }
     static bool isTexture(const ParamSet& ps, const std::string& n) { auto it = ps.find(n); return it != ps.end() && it->second.type == "texture"; }
-    static float get1f(const ParamSet& ps, const std::string& n, float def) { auto it = ps.find(n); if (it == ps.end() || it->second.num.empty()) return def; return (float)it->second.num[0]; }
-    static bool has3f(const ParamSet& ps, const std::string& n) { auto it = ps.find(n); return it != ps.end() && it->second.num.size() == 3 && it->second.type != "spectrum"; }
-    static void get3f(const ParamSet& ps, const std::string& n, Vec3& v) { auto it = ps.find(n); if (it == ps.end() || it->second.num.size() < 3) return; v = Vec3((float)it->second.num[0], (float)it->second.num[1], (float)it->second.num[2]); }
-    static std::string getStr(const ParamSet& ps, const std::string& n) { auto it = ps.find(n); if (it == ps.end() || it->second.str.empty()) return ""; return it->second.str[0]; }
+    static float get1f(const ParamSet& ps, const std::string& n, float def) { auto it = ps.find(n); if (it == ps.end() || it->second.num.empty()) return def;
+        return (float)it->second.num[0]; }
+    static bool has3f(const ParamSet& ps, const std::string& n) { auto it = ps.find(n);
+        return it != ps.end() && it->second.num.size() == 3 && it->second.type != "spectrum"; }
+    static void get3f(const ParamSet& ps, const std::string& n, Vec3& v) { auto it = ps.find(n); if (it == ps.end() || it->second.num.size() < 3) return;
+        v = Vec3((float)it->second.num[0], (float)it->second.num[1], (float)it->second.num[2]); }
+    static std::string getStr(const ParamSet& ps, const std::string& n) { auto it = ps.find(n); if (it == ps.end() || it->second.str.empty()) return "";
+        return it->second.str[0]; }
 
     PbrtTextureSP findTexture(const std::string& name) const
     {
@@ -194,8 +199,10 @@ private:
             if (has(ps, "uroughness") && !isTexture(ps, "uroughness")) m->uRoughness = get1f(ps, "uroughness", 0.f);
             if (has(ps, "vroughness") && !isTexture(ps, "vroughness")) m->vRoughness = get1f(ps, "vroughness", 0.f);
             if (has3f(ps, "eta")) get3f(ps, "eta", m->eta3);
-        } else if (type == "glass") { /* :671-688; createMaterial_glass (impl/semantic/Materials.cpp:411-420) ASSIGNS getParam1f("index"), whose fall-back is 0: a glass
-                                       * without an "index" parameter has index 0 in the reference, not the struct's 1.5 (found by the reference's own vw-van scene, whose
+        } else if (type == "glass")
+            { /* :671-688; createMaterial_glass (impl/semantic/Materials.cpp:411-420) ASSIGNS getParam1f("index"), whose fall-back is 0: a glass
+                                       * without an "index" parameter has index 0 in the reference, not the struct's 1.5 (found by the reference's own vw-van
+                                        * scene, whose
                                        * three glass materials name no index; tests/golden/vw-van.parser.digest.json) */
             m->kr = Vec3(1.f); m->kt = Vec3(1.f); m->index = get1f(ps, "index", 0.f);
             get3f(ps, "Kr", m->kr); get3f(ps, "Kt", m->kt);
@@ -205,7 +212,8 @@ private:
             m->roughness = get1f(ps, "roughness", 0.9f); m->specTrans = get1f(ps, "spectrans", 0.f);
         } else if (type == "mix") { /* :454-471 */
             m->amount = Vec3(.5f);
-            if (!isTexture(ps, "amount")) { if (has3f(ps, "amount")) get3f(ps, "amount", m->amount); else if (has(ps, "amount")) m->amount = Vec3(get1f(ps, "amount", .5f)); }
+            if (!isTexture(ps, "amount")) { if (has3f(ps, "amount")) get3f(ps, "amount", m->amount);
+                else if (has(ps, "amount")) m->amount = Vec3(get1f(ps, "amount", .5f)); }
             std::string n0 = getStr(ps, "namedmaterial1"), n1 = getStr(ps, "namedmaterial2");
             if (n0.empty() || n1.empty()) throw std::runtime_error("mix material w/o 'namedmaterial1/2' parameter");
             auto i0 = gs.namedMaterials.find(n0), i1 = gs.namedMaterials.find(n1);
@@ -259,9 +267,11 @@ private:
             };
             v3("P", mesh->vertex); v3("N", mesh->normal);
             auto uvIt = ps.find("uv"); if (uvIt == ps.end()) uvIt = ps.find("st");
-            if (uvIt != ps.end()) for (size_t i = 0; i + 1 < uvIt->second.num.size(); i += 2) { Vec2 t; t.x = (float)uvIt->second.num[i]; t.y = (float)uvIt->second.num[i + 1]; mesh->texcoord.push_back(t); }
+            if (uvIt != ps.end()) for (size_t i = 0; i + 1 < uvIt->second.num.size(); i += 2) { Vec2 t; t.x = (float)uvIt->second.num[i];
+                t.y = (float)uvIt->second.num[i + 1]; mesh->texcoord.push_back(t); }
             auto ix = ps.find("indices");
-            if (ix != ps.end()) { size_t n = ix->second.num.size() / 3 * 3; for (size_t i = 0; i < n; i++) mesh->index.push_back((uint32_t)(int64_t)ix->second.num[i]); }
+            if (ix != ps.end()) { size_t n = ix->second.num.size() / 3 * 3;
+                for (size_t i = 0; i < n; i++) mesh->index.push_back((uint32_t)(int64_t)ix->second.num[i]); }
         }
         for (Vec3& v : mesh->vertex) v = xfmPoint(ctm, v);
         for (Vec3& v : mesh->normal) v = xfmNormal(ctm, v);
@@ -285,9 +295,11 @@ private:
                 gs = attributeStack.back(); attributeStack.pop_back(); ctm = transformStack.back(); transformStack.pop_back();
             }
             else if (d == "TransformBegin") transformStack.push_back(ctm);
-            else if (d == "TransformEnd") { if (transformStack.empty()) throw std::runtime_error("unmatched TransformEnd"); ctm = transformStack.back(); transformStack.pop_back(); }
+            else if (d == "TransformEnd") { if (transformStack.empty()) throw std::runtime_error("unmatched TransformEnd"); ctm = transformStack.back();
+                transformStack.pop_back(); }
             else if (d == "Identity") ctm = Affine();
-            else if (d == "Scale") { Vec3 s = parseVec3(); Affine a; a.l.vx = Vec3(s.x, 0, 0); a.l.vy = Vec3(0, s.y, 0); a.l.vz = Vec3(0, 0, s.z); ctm = ctm * a; }
+            else if (d == "Scale") { Vec3 s = parseVec3(); Affine a; a.l.vx = Vec3(s.x, 0, 0); a.l.vy = Vec3(0, s.y, 0); a.l.vz = Vec3(0, 0, s.z);
+                ctm = ctm * a; }
             else if (d == "Translate") { Vec3 s = parseVec3(); Affine a; a.p = s; ctm = ctm * a; }
             else if (d == "Rotate") { /* math.h:183-191 */
                 float angle = parseFloat(); Vec3 axis = parseVec3();
@@ -321,9 +333,12 @@ private:
                 scene->cameraFrame = inverse(ctm);
                 namedCoordSys["camera"] = scene->cameraFrame;
             }
-            else if (d == "Film") { next(); ParamSet ps = parseParams(); scene->filmWidth = (int)get1f(ps, "xresolution", 0); scene->filmHeight = (int)get1f(ps, "yresolution", 0); }
-            else if (d == "Integrator" || d == "Sampler" || d == "PixelFilter" || d == "Accelerator" || d == "SurfaceIntegrator" || d == "VolumeIntegrator" || d == "Renderer") { next(); parseParams(); }
-            else if (d == "MakeNamedMedium" || d == "MediumInterface") { next(); if (d == "MediumInterface") { Token p2 = peek(); if (p2.quoted) next(); } else parseParams(); }
+            else if (d == "Film") { next(); ParamSet ps = parseParams(); scene->filmWidth = (int)get1f(ps, "xresolution", 0);
+                scene->filmHeight = (int)get1f(ps, "yresolution", 0); }
+            else if (d == "Integrator" || d == "Sampler" || d == "PixelFilter" || d == "Accelerator" || d == "SurfaceIntegrator" || d == "VolumeIntegrator" ||
+                d == "Renderer") { next(); parseParams(); }
+            else if (d == "MakeNamedMedium" || d == "MediumInterface") { next(); if (d == "MediumInterface") { Token p2 = peek(); if (p2.quoted) next();
+                } else parseParams(); }
             else if (d == "MakeNamedMaterial") {
                 Token n = next(); ParamSet ps = parseParams();
                 gs.namedMaterials[n.text] = makeMaterial(getStr(ps, "type"), n.text, ps);
@@ -338,12 +353,15 @@ private:
                 Token n = next(); next(); /* "spectrum" | "float" */ Token kind = next(); ParamSet ps = parseParams();
                 gs.namedTextures[n.text] = makeTexture(n.text, kind.text, ps);
             }
-            else if (d == "AreaLightSource") { Token ty = next(); ParamSet ps = parseParams(); gs.hasAreaLight = true; gs.areaL = Vec3(1.f); get3f(ps, "L", gs.areaL); }
+            else if (d == "AreaLightSource") { Token ty = next(); ParamSet ps = parseParams(); gs.hasAreaLight = true; gs.areaL = Vec3(1.f);
+                get3f(ps, "L", gs.areaL); }
             else if (d == "LightSource") {
                 Token ty = next(); ParamSet ps = parseParams();
                 PbrtLight l; l.transform = ctm;
-                if (ty.text == "infinite") { l.kind = PbrtLight::Infinite; std::string mn = getStr(ps, "mapname"); l.mapName = mn; l.mapFile = mn.empty() ? mn : global(mn); get3f(ps, "L", l.L); get3f(ps, "scale", l.scale); scene->lights.push_back(l); }
-                else if (ty.text == "distant") { l.kind = PbrtLight::Distant; get3f(ps, "L", l.L); get3f(ps, "scale", l.scale); get3f(ps, "from", l.from); get3f(ps, "to", l.to); scene->lights.push_back(l); }
+                if (ty.text == "infinite") { l.kind = PbrtLight::Infinite; std::string mn = getStr(ps, "mapname"); l.mapName = mn;
+                    l.mapFile = mn.empty() ? mn : global(mn); get3f(ps, "L", l.L); get3f(ps, "scale", l.scale); scene->lights.push_back(l); }
+                else if (ty.text == "distant") { l.kind = PbrtLight::Distant; get3f(ps, "L", l.L); get3f(ps, "scale", l.scale); get3f(ps, "from", l.from);
+                    get3f(ps, "to", l.to); scene->lights.push_back(l); }
                 /* point / spot / others: TracerBoy.cpp:1896-1917 ignores them */
             }
             else if (d == "Shape") { Token ty = next(); ParamSet ps = parseParams(); emitShape(ty.text, ps); }
@@ -359,7 +377,9 @@ private:
             else if (d == "ObjectInstance") {
                 Token n = next(); auto it = objects.find(n.text);
                 if (it == objects.end()) throw std::runtime_error("ObjectInstance of unknown object '" + n.text + "'");
-                for (const std::shared_ptr<PbrtObject>& open : objectStack) if (open == it->second) throw std::runtime_error("object '" + n.text + "' is instanced inside its own definition");   /* the only way to a cycle: objects exist from their ObjectBegin on */
+                /* the only way to a cycle: objects exist from their ObjectBegin on */
+                for (const std::shared_ptr<PbrtObject>& open : objectStack) if (open == it->second) throw std::runtime_error("object '" + n.text +
+                    "' is instanced inside its own definition");
                 PbrtInstance inst; inst.xfm = ctm; inst.object = it->second; currentObject().instances.push_back(inst);
             }
             else if (d == "ActiveTransform" || d == "TransformTimes") { next(); if (d == "TransformTimes") next(); }
@@ -404,10 +424,12 @@ void readPly(const std::string& fileName, std::vector<Vec3>& pos, std::vector<Ve
     if (fmt == BE) throw std::runtime_error(fileName + ": big-endian PLY not supported");
     {   /* an element costs at least a byte: a count the rest of the file cannot hold is a damaged header, not something to allocate */
         const std::streampos here = in.tellg(); in.seekg(0, std::ios::end); const uint64_t left = here < 0 ? 0 : (uint64_t)(in.tellg() - here); in.seekg(here);
-        for (const Elem& e : elems) if (!e.props.empty() && e.count > left) throw std::runtime_error(fileName + ": PLY element count beyond the size of the file");
+        for (const Elem& e : elems) if (!e.props.empty() && e.count > left) throw std::runtime_error(fileName +
+            ": PLY element count beyond the size of the file");
     }
     auto listLength = [&](double v) -> size_t { if (!(v >= 0.0 && v <= 1e6)) throw std::runtime_error(fileName + ": bad PLY list length"); return (size_t)v; };
-    auto vertexIndex = [&](double v) -> uint32_t { if (!(v >= 0.0 && v <= 4294967295.0)) throw std::runtime_error(fileName + ": bad PLY vertex index"); return (uint32_t)v; };
+    auto vertexIndex = [&](double v) -> uint32_t { if (!(v >= 0.0 && v <= 4294967295.0)) throw std::runtime_error(fileName + ": bad PLY vertex index");
+        return (uint32_t)v; };
     auto sizeOf = [](const std::string& t) -> int {
         if (t == "char" || t == "uchar" || t == "int8" || t == "uint8") return 1;
         if (t == "short" || t == "ushort" || t == "int16" || t == "uint16") return 2;
@@ -431,7 +453,8 @@ void readPly(const std::string& fileName, std::vector<Vec3>& pos, std::vector<Ve
     for (const Elem& e : elems) {
         if (e.name == "vertex") {
             bool hasN = false, hasUV = false;
-            for (const Prop& p : e.props) { if (p.name == "nx" || p.name == "ny" || p.name == "nz") hasN = true; if (p.name == "u" || p.name == "s" || p.name == "v" || p.name == "t") hasUV = true; }
+            for (const Prop& p : e.props) { if (p.name == "nx" || p.name == "ny" || p.name == "nz") hasN = true;
+                if (p.name == "u" || p.name == "s" || p.name == "v" || p.name == "t") hasUV = true; }
             pos.resize(e.count); if (hasN) nor.resize(e.count); if (hasUV) uv.resize(e.count);
             for (size_t i = 0; i < e.count; i++)
                 for (const Prop& p : e.props) {
@@ -448,7 +471,8 @@ void readPly(const std::string& fileName, std::vector<Vec3>& pos, std::vector<Ve
                     if (!p.isList) { readNum(p.type); continue; }
                     size_t n = listLength(readNum(p.listCount));
                     bool isIdx = p.name == "vertex_indices" || p.name == "vertex_index";
-                    if (isIdx && n != 3) throw std::runtime_error(fileName + ": PLY face with " + std::to_string(n) + " vertices (only triangles are supported)");
+                    if (isIdx && n != 3) throw std::runtime_error(fileName + ": PLY face with " + std::to_string(n) +
+                        " vertices (only triangles are supported)");
                     for (size_t k = 0; k < n; k++) { double v = readNum(p.listItem); if (isIdx) idx.push_back(vertexIndex(v)); }
                 }
         } else {

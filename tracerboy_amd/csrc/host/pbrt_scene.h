@@ -39,7 +39,8 @@ inline Affine operator*(const Affine& a, const Affine& b) { Affine r; r.l = a.l 
 inline float dot(const Vec3& a, const Vec3& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 inline Vec3 cross(const Vec3& a, const Vec3& b) { return Vec3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
 inline Vec3 normalize(const Vec3& a) { return a * (1 / sqrtf(dot(a, a))); }
-inline Mat3 transpose(const Mat3& a) { Mat3 m; m.vx = Vec3(a.vx.x, a.vy.x, a.vz.x); m.vy = Vec3(a.vx.y, a.vy.y, a.vz.y); m.vz = Vec3(a.vx.z, a.vy.z, a.vz.z); return m; }
+inline Mat3 transpose(const Mat3& a) { Mat3 m; m.vx = Vec3(a.vx.x, a.vy.x, a.vz.x); m.vy = Vec3(a.vx.y, a.vy.y, a.vz.y); m.vz = Vec3(a.vx.z, a.vy.z, a.vz.z);
+    return m; }
 inline float determinant(const Mat3& a) { return dot(a.vx, cross(a.vy, a.vz)); }
 inline Mat3 adjoint_transpose(const Mat3& a) { Mat3 m; m.vx = cross(a.vy, a.vz); m.vy = cross(a.vz, a.vx); m.vz = cross(a.vx, a.vy); return m; }
 inline Mat3 inverse_transpose(const Mat3& a) { return adjoint_transpose(a) * (1 / determinant(a)); }

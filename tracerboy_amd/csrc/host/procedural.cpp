@@ -31,7 +31,8 @@ void makeBlob(MeshOut& m, tb3 c, float radius, uint32_t rings, uint32_t segs, ui
     float ph[6], fr[6];
     for (int i = 0; i < 6; i++) { ph[i] = urand(st) * 6.2831853f; fr[i] = 2.0f + tb_floor(urand(st) * 7.0f); }
     auto radial = [&](float theta, float phi) {
-        float d = tb_sin(fr[0] * theta + ph[0]) * tb_sin(fr[1] * phi + ph[1]) + 0.5f * tb_sin(fr[2] * theta + fr[3] * phi + ph[2]) + 0.25f * tb_sin(3.0f * fr[4] * phi + ph[3]) * tb_cos(2.0f * fr[5] * theta + ph[4]);
+        float d = tb_sin(fr[0] * theta + ph[0]) * tb_sin(fr[1] * phi + ph[1]) + 0.5f * tb_sin(fr[2] * theta + fr[3] * phi + ph[2]) + 0.25f * tb_sin(3.0f *
+            fr[4] * phi + ph[3]) * tb_cos(2.0f * fr[5] * theta + ph[4]);
         return radius * (1.0f + bump * d);
     };
     for (uint32_t r = 0; r <= rings; r++) for (uint32_t s = 0; s <= segs; s++) {
@@ -75,7 +76,8 @@ void makeBlob(MeshOut& m, tb3 c, float radius, uint32_t rings, uint32_t segs, ui
 void makeQuad(MeshOut& m, tb3 p0, tb3 p1, tb3 p2, tb3 p3, tb3 n)
 {
     tb3 p[4] = {p0, p1, p2, p3}; const float uv[8] = {0, 0, 1, 0, 1, 1, 0, 1};
-    for (int i = 0; i < 4; i++) { m.pos.push_back(p[i].x); m.pos.push_back(p[i].y); m.pos.push_back(p[i].z); m.nrm.push_back(n.x); m.nrm.push_back(n.y); m.nrm.push_back(n.z); m.uv.push_back(uv[2 * i]); m.uv.push_back(uv[2 * i + 1]); }
+    for (int i = 0; i < 4; i++) { m.pos.push_back(p[i].x); m.pos.push_back(p[i].y); m.pos.push_back(p[i].z); m.nrm.push_back(n.x); m.nrm.push_back(n.y);
+        m.nrm.push_back(n.z); m.uv.push_back(uv[2 * i]); m.uv.push_back(uv[2 * i + 1]); }
     const uint32_t ix[6] = {0, 1, 2, 0, 2, 3}; m.idx.insert(m.idx.end(), ix, ix + 6);
 }
 
@@ -88,9 +90,11 @@ TbMaterial baseMaterial()
 }
 TbMaterial matte(float r, float g, float b) { TbMaterial m = baseMaterial(); m.albedo = {r, g, b}; m.Flags |= TB_MAT_NO_SPECULAR; return m; }
 TbMaterial mirror() { TbMaterial m = baseMaterial(); m.albedo = {0.9f, 0.9f, 0.9f}; m.SpecularCoef = 1.0f; m.Flags |= TB_MAT_METALLIC; return m; }
-TbMaterial metal(float rough) { TbMaterial m = baseMaterial(); m.albedo = {1, 1, 1}; m.IOR = 0.7434f; m.roughness = rough; m.Flags |= TB_MAT_METALLIC; return m; }
+TbMaterial metal(float rough) { TbMaterial m = baseMaterial(); m.albedo = {1, 1, 1}; m.IOR = 0.7434f; m.roughness = rough; m.Flags |= TB_MAT_METALLIC;
+    return m; }
 TbMaterial glass() { TbMaterial m = baseMaterial(); m.IOR = 1.5f; m.Flags |= TB_MAT_SUBSURFACE_SCATTER; return m; }
-TbMaterial plastic(float r, float g, float b, float rough) { TbMaterial m = baseMaterial(); m.albedo = {r, g, b}; m.roughness = rough; m.SpecularCoef = 0.25f; m.IOR = 3.0f; return m; }
+TbMaterial plastic(float r, float g, float b, float rough) { TbMaterial m = baseMaterial(); m.albedo = {r, g, b}; m.roughness = rough; m.SpecularCoef = 0.25f;
+    m.IOR = 3.0f; return m; }
 TbMaterial emitter(float r, float g, float b) { TbMaterial m = matte(0, 0, 0); m.emissive = {r, g, b}; m.Flags |= TB_MAT_LIGHT; return m; }
 
 void addMesh(HostScene& s, const MeshOut& m, uint32_t materialIndex, bool isLight, tb3 L)
@@ -159,15 +163,18 @@ void MakeProceduralScene(HostScene& s, int kind, uint32_t targetTriangles, uint3
         uint32_t st = seed ^ 0x9e3779b9u;
         for (int i = 0; i < 39; i++) {
             float r = 0.1f + 0.8f * urand(st), g = 0.1f + 0.8f * urand(st), b = 0.1f + 0.8f * urand(st);
-            switch (i % 5) { case 0: case 1: s.materials.push_back(matte(r, g, b)); break; case 2: s.materials.push_back(plastic(r, g, b, 0.05f + 0.3f * urand(st))); break;
-                case 3: s.materials.push_back(metal(0.02f + 0.3f * urand(st))); break; default: s.materials.push_back(i % 10 == 4 ? glass() : mirror()); break; }
+            switch (i % 5) { case 0: case 1: s.materials.push_back(matte(r, g, b)); break;
+                case 2: s.materials.push_back(plastic(r, g, b, 0.05f + 0.3f * urand(st))); break;
+                case 3: s.materials.push_back(metal(0.02f + 0.3f * urand(st))); break; default: s.materials.push_back(i % 10 == 4 ? glass() : mirror()); break;
+                    }
         }
     }
     const uint32_t numSurfaceMaterials = (uint32_t)s.materials.size();
 
     float spacing = 2.4f, width = spacing * gx, depth = spacing * gz;
     { MeshOut g; float hx = width * 0.5f + 4.0f, hz = depth * 0.5f + 4.0f;
-      makeQuad(g, tb3_make(-hx, 0, -hz), tb3_make(-hx, 0, hz), tb3_make(hx, 0, hz), tb3_make(hx, 0, -hz), tb3_make(0, 1, 0)); addMesh(s, g, 0, false, tb3_splat(0)); }
+      makeQuad(g, tb3_make(-hx, 0, -hz), tb3_make(-hx, 0, hz), tb3_make(hx, 0, hz), tb3_make(hx, 0, -hz), tb3_make(0, 1, 0));
+          addMesh(s, g, 0, false, tb3_splat(0)); }
     uint32_t st = seed * 2654435761u + 12345u;
     for (uint32_t iz = 0; iz < gz; iz++) for (uint32_t ix = 0; ix < gx; ix++) {
         uint32_t b = iz * gx + ix;
@@ -180,8 +187,11 @@ void MakeProceduralScene(HostScene& s, int kind, uint32_t targetTriangles, uint3
     if (kind != 0) {
         uint32_t nl = kind == 1 ? 1 : 4;
         for (uint32_t i = 0; i < nl; i++) {
-            float cx = nl == 1 ? 0.0f : (((float)(i % 2) - 0.5f) * width * 0.5f), cz = nl == 1 ? 0.0f : (((float)(i / 2) - 0.5f) * depth * 0.5f), y = 5.0f, h = 1.0f;
-            MeshOut q; makeQuad(q, tb3_make(cx - h, y, cz - h), tb3_make(cx + h, y, cz - h), tb3_make(cx + h, y, cz + h), tb3_make(cx - h, y, cz + h), tb3_make(0, -1, 0));
+            float cx = nl == 1 ? 0.0f : (((float)(i % 2) - 0.5f) * width * 0.5f), cz = nl == 1 ? 0.0f : (((float)(i / 2) - 0.5f) * depth * 0.5f), y = 5.0f,
+                h = 1.0f;
+            MeshOut q;
+                makeQuad(q, tb3_make(cx - h, y, cz - h), tb3_make(cx + h, y, cz - h), tb3_make(cx + h, y, cz + h), tb3_make(cx - h, y, cz + h), tb3_make(0, -1,
+                0));
             s.materials.push_back(emitter(17.0f, 12.0f, 4.0f));
             addMesh(s, q, (uint32_t)s.materials.size() - 1, true, tb3_make(17.0f, 12.0f, 4.0f));
         }
@@ -196,7 +206,8 @@ void MakeProceduralScene(HostScene& s, int kind, uint32_t targetTriangles, uint3
     setCamera(s, tb3_make(0.0f, dist * 0.35f, dist), tb3_make(0.0f, kind == 0 ? 1.0f : 0.8f, 0.0f), kind == 0 ? 20.1143f : 35.0f);
     s.config.CameraLensHeight = s.camera.LensHeight;
     tb3 mn = tb3_splat(3.4e38f), mx = tb3_splat(-3.4e38f);
-    for (size_t i = 0; i + 2 < s.positions.size(); i += 3) { tb3 p = tb3_make(s.positions[i], s.positions[i + 1], s.positions[i + 2]); mn = tb3_min(mn, p); mx = tb3_max(mx, p); }
+    for (size_t i = 0; i + 2 < s.positions.size(); i += 3) { tb3 p = tb3_make(s.positions[i], s.positions[i + 1], s.positions[i + 2]); mn = tb3_min(mn, p);
+        mx = tb3_max(mx, p); }
     s.sceneMin[0] = mn.x; s.sceneMin[1] = mn.y; s.sceneMin[2] = mn.z; s.sceneMax[0] = mx.x; s.sceneMax[1] = mx.y; s.sceneMax[2] = mx.z;
 }
 

@@ -58,7 +58,8 @@ __device__ __forceinline__ uint32_t expand10(uint32_t v)
     return v;
 }
 
-__global__ __launch_bounds__(BLOCK) void bvh_morton(const float* positions, const uint32_t* triVertexIndex, uint32_t N, const uint32_t* ordMin, const uint32_t* ordMax,
+__global__ __launch_bounds__(BLOCK) void bvh_morton(const float* positions, const uint32_t* triVertexIndex, uint32_t N, const uint32_t* ordMin,
+    const uint32_t* ordMax,
                                                     unsigned long long* keys)
 {
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
@@ -67,7 +68,8 @@ __global__ __launch_bounds__(BLOCK) void bvh_morton(const float* positions, cons
     const tb3 dim = tb3_max(smax - smin, tb3_splat(0.00001f));
     const tb3 c = (vertex(positions, triVertexIndex, i, 0) + vertex(positions, triVertexIndex, i, 1) + vertex(positions, triVertexIndex, i, 2)) / 3.0f;
     const tb3 u = (c - smin) / dim;
-    const float ax = tb_min(tb_max(u.x * 1024.0f, 0.0f), 1023.0f), ay = tb_min(tb_max(u.y * 1024.0f, 0.0f), 1023.0f), az = tb_min(tb_max(u.z * 1024.0f, 0.0f), 1023.0f);
+    const float ax = tb_min(tb_max(u.x * 1024.0f, 0.0f), 1023.0f), ay = tb_min(tb_max(u.y * 1024.0f, 0.0f), 1023.0f), az = tb_min(tb_max(u.z * 1024.0f, 0.0f),
+        1023.0f);
     const uint32_t code = expand10((uint32_t)ay) | (expand10((uint32_t)ax) << 1) | (expand10((uint32_t)az) << 2); /* axis 0 <- y, 1 <- x, 2 <- z */
     keys[i] = ((unsigned long long)code << 32) | (unsigned long long)i;
 }
@@ -152,7 +154,8 @@ struct TreeletBufs {
     uint32_t* stamp;                                    /* per inner node: bvh_treelet_up */
 };
 
-__global__ __launch_bounds__(BLOCK) void bvh_treelet_leaves(const float* positions, const uint32_t* triVertexIndex, const unsigned long long* keys, uint32_t N, TreeletBufs b)
+__global__ __launch_bounds__(BLOCK) void bvh_treelet_leaves(const float* positions, const uint32_t* triVertexIndex, const unsigned long long* keys, uint32_t N,
+    TreeletBufs b)
 {
     const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
     if (k >= N) return;
@@ -288,7 +291,8 @@ struct FitOut {
     TbAabbNode* nodesA; uint8_t* primsA; TbPrimitiveMeta* metaA; /* layout A */
     TbNodeB* nodesB; TbTriB* trisB;                               /* layout B */
     uint32_t* count; uint32_t* height; uint32_t* stamp;           /* per node scratch */
-    const uint32_t* leafMap;                                      /* top level: sorted leaf k -> instance index (a layout-B leaf ref names the instance); null for triangles */
+    /* top level: sorted leaf k -> instance index (a layout-B leaf ref names the instance); null for triangles */
+    const uint32_t* leafMap;
 };
 
 __device__ __forceinline__ void put_node(TbAabbNode* nodes, uint32_t i, tb3 mn, tb3 mx, uint32_t fx, uint32_t fy)
@@ -300,7 +304,8 @@ __device__ __forceinline__ void put_node(TbAabbNode* nodes, uint32_t i, tb3 mn, 
     nodes[i] = n;
 }
 
-__global__ __launch_bounds__(BLOCK) void bvh_fit_leaves(const float* positions, const uint32_t* triVertexIndex, const uint32_t* triGeometry, const uint32_t* triPrimitive,
+__global__ __launch_bounds__(BLOCK) void bvh_fit_leaves(const float* positions, const uint32_t* triVertexIndex, const uint32_t* triGeometry,
+    const uint32_t* triPrimitive,
                                                         const uint32_t* triFlags, const unsigned long long* keys, uint32_t N, FitOut o)
 {
     const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
@@ -391,7 +396,8 @@ __global__ __launch_bounds__(BLOCK) void tlas_morton(uint32_t M, const float* le
     const tb3 smin = tb3_make(ord2f(ordMin[0]), ord2f(ordMin[1]), ord2f(ordMin[2])), smax = tb3_make(ord2f(ordMax[0]), ord2f(ordMax[1]), ord2f(ordMax[2]));
     const tb3 dim = tb3_max(smax - smin, tb3_splat(0.00001f));
     const tb3 u = (tb3_make(leafC[3 * i], leafC[3 * i + 1], leafC[3 * i + 2]) - smin) / dim;
-    const float ax = tb_min(tb_max(u.x * 1024.0f, 0.0f), 1023.0f), ay = tb_min(tb_max(u.y * 1024.0f, 0.0f), 1023.0f), az = tb_min(tb_max(u.z * 1024.0f, 0.0f), 1023.0f);
+    const float ax = tb_min(tb_max(u.x * 1024.0f, 0.0f), 1023.0f), ay = tb_min(tb_max(u.y * 1024.0f, 0.0f), 1023.0f), az = tb_min(tb_max(u.z * 1024.0f, 0.0f),
+        1023.0f);
     const uint32_t code = expand10((uint32_t)ay) | (expand10((uint32_t)ax) << 1) | (expand10((uint32_t)az) << 2);
     keys[i] = ((unsigned long long)code << 32) | (unsigned long long)i;
 }
@@ -473,8 +479,10 @@ static hipError_t run_levels(hipStream_t stream, uint32_t* progress, uint32_t to
     return hipSuccess;
 }
 
-extern "C" hipError_t bvh_gpu_build(hipStream_t stream, const float* positions, const uint32_t* triVertexIndex, const uint32_t* triGeometry, const uint32_t* triPrimitive,
-                                    const uint32_t* triFlags, uint32_t N, uint32_t treeletPasses, uint8_t* scratch, size_t scratchBytes, uint8_t* bvhA, TbNodeB* nodesB,
+extern "C" hipError_t bvh_gpu_build(hipStream_t stream, const float* positions, const uint32_t* triVertexIndex, const uint32_t* triGeometry,
+    const uint32_t* triPrimitive,
+                                    const uint32_t* triFlags, uint32_t N, uint32_t treeletPasses, uint8_t* scratch, size_t scratchBytes, uint8_t* bvhA,
+                                        TbNodeB* nodesB,
                                     TbTriB* trisB, uint32_t* rootHeight)
 {
     if (N == 0) return hipErrorInvalidValue;
@@ -505,7 +513,8 @@ extern "C" hipError_t bvh_gpu_build(hipStream_t stream, const float* positions, 
     BVH_TRY(hipMemsetAsync(bounds + 4, 0x00, 12, stream));  /* ordMax = 0 */
     const uint32_t blocksN = (N + BLOCK - 1) / BLOCK, blocksInner = N > 1 ? (N - 1 + BLOCK - 1) / BLOCK : 1;
     hipLaunchKernelGGL(bvh_bounds, dim3(blocksN < 2048u ? blocksN : 2048u), dim3(BLOCK), 0, stream, positions, triVertexIndex, N, bounds, bounds + 4);
-    hipLaunchKernelGGL(bvh_morton, dim3(blocksN), dim3(BLOCK), 0, stream, positions, triVertexIndex, N, (const uint32_t*)bounds, (const uint32_t*)(bounds + 4), keysIn);
+    hipLaunchKernelGGL(bvh_morton, dim3(blocksN), dim3(BLOCK), 0, stream, positions, triVertexIndex, N, (const uint32_t*)bounds, (const uint32_t*)(bounds + 4),
+        keysIn);
     BVH_TRY(rocprim::radix_sort_keys(sortScratch, sortTmp, keysIn, keysOut, (size_t)N, 0, 62, stream));
     if (N > 1) hipLaunchKernelGGL(bvh_hierarchy, dim3(blocksInner), dim3(BLOCK), 0, stream, (const unsigned long long*)keysOut, N, left, right, parent);
     /* TreeletReorder::Optimize (TreeletReorder.cpp:38-109): MinTrianglesPerTreelet 7, 14, 28 for the three PREFER_FAST_TRACE passes */
@@ -513,7 +522,8 @@ extern "C" hipError_t bvh_gpu_build(hipStream_t stream, const float* positions, 
         if (pass == 0) { /* boxes and triangle counts of the LBVH; the rebuilds keep both exact from here on */
             hipLaunchKernelGGL(bvh_treelet_leaves, dim3(blocksN), dim3(BLOCK), 0, stream, positions, triVertexIndex, (const unsigned long long*)keysOut, N, tb);
             BVH_TRY(hipMemsetAsync(stamp, 0, 4ull * N, stream));
-            BVH_TRY(run_levels(stream, counters, N - 1, [&](uint32_t t) { hipLaunchKernelGGL(bvh_treelet_up, dim3(blocksInner), dim3(BLOCK), 0, stream, N, tb, t, counters); }));
+            BVH_TRY(run_levels(stream, counters, N - 1, [&](uint32_t t) { hipLaunchKernelGGL(bvh_treelet_up, dim3(blocksInner), dim3(BLOCK), 0, stream, N, tb,
+                t, counters); }));
         }
         uint32_t cur = 0, n = 0;
         BVH_TRY(hipMemsetAsync(counters + 1, 0, 8, stream));
@@ -521,9 +531,11 @@ extern "C" hipError_t bvh_gpu_build(hipStream_t stream, const float* positions, 
         BVH_TRY(read_word(stream, counters + 1, n));
         while (n) { /* one round per link of the longest chain of dependent treelets */
             if (n > N / 7 + 1) return hipErrorLaunchFailure;
-            hipLaunchKernelGGL(bvh_treelet_rebuild, dim3(n), dim3(64), 0, stream, N, minTris, tb, (const uint32_t*)(counters + 1 + cur), (const uint32_t*)lists[cur]);
+            hipLaunchKernelGGL(bvh_treelet_rebuild, dim3(n), dim3(64), 0, stream, N, minTris, tb, (const uint32_t*)(counters + 1 + cur),
+                (const uint32_t*)lists[cur]);
             BVH_TRY(hipMemsetAsync(counters + 1 + (cur ^ 1u), 0, 4, stream));
-            hipLaunchKernelGGL(bvh_treelet_advance, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, stream, N, minTris, tb, (const uint32_t*)(counters + 1 + cur), (const uint32_t*)lists[cur],
+            hipLaunchKernelGGL(bvh_treelet_advance, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, stream, N, minTris, tb,
+                (const uint32_t*)(counters + 1 + cur), (const uint32_t*)lists[cur],
                                counters + 1 + (cur ^ 1u), lists[cur ^ 1u]);
             cur ^= 1u;
             BVH_TRY(read_word(stream, counters + 1 + cur, n));
@@ -535,10 +547,12 @@ extern "C" hipError_t bvh_gpu_build(hipStream_t stream, const float* positions, 
     FitOut o;
     o.nodesA = (TbAabbNode*)(bvhA + offBoxes); o.primsA = bvhA + offPrims; o.metaA = (TbPrimitiveMeta*)(bvhA + offMeta);
     o.nodesB = nodesB; o.trisB = trisB; o.count = count; o.height = height; o.stamp = stamp; o.leafMap = nullptr;
-    hipLaunchKernelGGL(bvh_fit_leaves, dim3(blocksN), dim3(BLOCK), 0, stream, positions, triVertexIndex, triGeometry, triPrimitive, triFlags, (const unsigned long long*)keysOut, N, o);
+    hipLaunchKernelGGL(bvh_fit_leaves, dim3(blocksN), dim3(BLOCK), 0, stream, positions, triVertexIndex, triGeometry, triPrimitive, triFlags,
+        (const unsigned long long*)keysOut, N, o);
     if (N > 1) {
         BVH_TRY(hipMemsetAsync(stamp, 0, 4ull * N, stream));
-        BVH_TRY(run_levels(stream, counters, N - 1, [&](uint32_t t) { hipLaunchKernelGGL(bvh_fit_up, dim3(blocksInner), dim3(BLOCK), 0, stream, N, (const uint32_t*)left, (const uint32_t*)right, o, t, counters); }));
+        BVH_TRY(run_levels(stream, counters, N - 1, [&](uint32_t t) { hipLaunchKernelGGL(bvh_fit_up, dim3(blocksInner), dim3(BLOCK), 0, stream, N,
+            (const uint32_t*)left, (const uint32_t*)right, o, t, counters); }));
     }
     BVH_TRY(hipMemcpyAsync(rootHeight, height, 4, hipMemcpyDeviceToDevice, stream)); /* node 0 is the root (the only leaf when N == 1) */
     BVH_TRY(hipStreamSynchronize(stream)); /* hdr lives on this stack frame */
@@ -554,11 +568,14 @@ extern "C" size_t bvh_gpu_tlas_scratch_bytes(uint32_t M)
     unsigned long long* nullKeys = nullptr;
     (void)rocprim::radix_sort_keys(nullptr, sortTmp, nullKeys, nullKeys, (size_t)M, 0, 62, (hipStream_t)0);
     const size_t nodes = 2ull * M - 1;
-    return 2 * round256(8ull * M) + 3 * round256(4 * nodes) + 4 * round256(4ull * M) + 2 * round256(12ull * M) + round256(64) + round256(256) + round256(sortTmp);
+    return 2 * round256(8ull * M) + 3 * round256(4 * nodes) + 4 * round256(4ull * M) + 2 * round256(12ull * M) + round256(64) + round256(256) +
+        round256(sortTmp);
 }
 
-extern "C" hipError_t bvh_gpu_build_tlas(hipStream_t stream, uint32_t M, const float* objectToWorld, const float* worldToObject, const uint32_t* blasIndex, const uint32_t* hitGroupBase,
-                                         const float* blasBoxes, uint8_t* scratch, size_t scratchBytes, uint8_t* tlasA, TbNodeB* topNodes, uint32_t* rootRefOut, uint32_t* rootHeight)
+extern "C" hipError_t bvh_gpu_build_tlas(hipStream_t stream, uint32_t M, const float* objectToWorld, const float* worldToObject, const uint32_t* blasIndex,
+    const uint32_t* hitGroupBase,
+                                         const float* blasBoxes, uint8_t* scratch, size_t scratchBytes, uint8_t* tlasA, TbNodeB* topNodes,
+                                             uint32_t* rootRefOut, uint32_t* rootHeight)
 {
     if (M == 0) return hipErrorInvalidValue;
     const size_t nodes = 2ull * M - 1;
@@ -586,19 +603,22 @@ extern "C" hipError_t bvh_gpu_build_tlas(hipStream_t stream, uint32_t M, const f
     BVH_TRY(hipMemsetAsync(bounds + 4, 0x00, 12, stream));
     const uint32_t blocksM = (M + BLOCK - 1) / BLOCK, blocksInner = M > 1 ? (M - 1 + BLOCK - 1) / BLOCK : 1;
     hipLaunchKernelGGL(tlas_leaf_boxes, dim3(blocksM), dim3(BLOCK), 0, stream, M, in, leafC, leafH, bounds, bounds + 4);
-    hipLaunchKernelGGL(tlas_morton, dim3(blocksM), dim3(BLOCK), 0, stream, M, (const float*)leafC, (const uint32_t*)bounds, (const uint32_t*)(bounds + 4), keysIn);
+    hipLaunchKernelGGL(tlas_morton, dim3(blocksM), dim3(BLOCK), 0, stream, M, (const float*)leafC, (const uint32_t*)bounds, (const uint32_t*)(bounds + 4),
+        keysIn);
     BVH_TRY(rocprim::radix_sort_keys(sortScratch, sortTmp, keysIn, keysOut, (size_t)M, 0, 62, stream));
     if (M > 1) hipLaunchKernelGGL(bvh_hierarchy, dim3(blocksInner), dim3(BLOCK), 0, stream, (const unsigned long long*)keysOut, M, left, right, parent);
     const uint64_t offBoxes = 16, offMeta = offBoxes + 32 * nodes, total = offMeta + 116ull * M;
     const TbBvhHeader hdr = {(uint32_t)offBoxes, (uint32_t)offMeta, (uint32_t)offMeta, (uint32_t)total};
     BVH_TRY(hipMemcpyAsync(tlasA, &hdr, 16, hipMemcpyHostToDevice, stream));
-    hipLaunchKernelGGL(tlas_fit_leaves, dim3(blocksM), dim3(BLOCK), 0, stream, M, (const unsigned long long*)keysOut, (const float*)leafC, (const float*)leafH, in,
+    hipLaunchKernelGGL(tlas_fit_leaves, dim3(blocksM), dim3(BLOCK), 0, stream, M, (const unsigned long long*)keysOut, (const float*)leafC, (const float*)leafH,
+        in,
                        (TbAabbNode*)(tlasA + offBoxes), tlasA + offMeta, count, height, order);
     if (M > 1) {
         FitOut o; memset(&o, 0, sizeof o);
         o.nodesA = (TbAabbNode*)(tlasA + offBoxes); o.nodesB = topNodes; o.count = count; o.height = height; o.stamp = stamp; o.leafMap = order;
         BVH_TRY(hipMemsetAsync(stamp, 0, 4ull * M, stream));
-        BVH_TRY(run_levels(stream, counters, M - 1, [&](uint32_t t) { hipLaunchKernelGGL(bvh_fit_up, dim3(blocksInner), dim3(BLOCK), 0, stream, M, (const uint32_t*)left, (const uint32_t*)right, o, t, counters); }));
+        BVH_TRY(run_levels(stream, counters, M - 1, [&](uint32_t t) { hipLaunchKernelGGL(bvh_fit_up, dim3(blocksInner), dim3(BLOCK), 0, stream, M,
+            (const uint32_t*)left, (const uint32_t*)right, o, t, counters); }));
         const uint32_t zero = 0;
         BVH_TRY(hipMemcpyAsync(rootRefOut, &zero, 4, hipMemcpyHostToDevice, stream));
     } else {

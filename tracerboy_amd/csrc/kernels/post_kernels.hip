@@ -192,7 +192,8 @@ __global__ __launch_bounds__(256) void post_average_kernel(const uint32_t* histo
     }
 }
 
-__global__ __launch_bounds__(256) void post_process_kernel(TbPostConstants pc, const TbFloat4* in, const float* inR32, const TbFloat4* aux, const float* averaged,
+__global__ __launch_bounds__(256) void post_process_kernel(TbPostConstants pc, const TbFloat4* in, const float* inR32, const TbFloat4* aux,
+    const float* averaged,
                                                            TbFloat4* out, uint32_t* outRgba8)
 {
     const uint32_t groupsX = (pc.W + 15u) / 16u;
@@ -238,7 +239,8 @@ __global__ __launch_bounds__(256) void post_process_kernel(TbPostConstants pc, c
     (void)aux;
     if (out) out[i] = TbFloat4{o.x, o.y, o.z, 1.0f};
     if (outRgba8) { /* R8G8B8A8_UNORM store: clamp, scale, + 0.5, truncate */
-        uint32_t r = (uint32_t)(tb_saturate(o.x) * 255.0f + 0.5f), g = (uint32_t)(tb_saturate(o.y) * 255.0f + 0.5f), b = (uint32_t)(tb_saturate(o.z) * 255.0f + 0.5f);
+        uint32_t r = (uint32_t)(tb_saturate(o.x) * 255.0f + 0.5f), g = (uint32_t)(tb_saturate(o.y) * 255.0f + 0.5f),
+            b = (uint32_t)(tb_saturate(o.z) * 255.0f + 0.5f);
         outRgba8[i] = r | (g << 8) | (b << 16) | 0xff000000u;
     }
 }

@@ -17,7 +17,8 @@ __device__ __forceinline__ void make_refs(SceneRefs& sc, const TbDeviceScene& ds
         sc.vertices = (const float*)(blob + ds.offVertices); sc.materials = (const TbDevMaterial*)(blob + ds.offMaterials);
         sc.lights = (const TbDevLight*)(blob + ds.offLights);
     } else {
-        sc.nodes = (const uint8_t*)ds.nodes; sc.tris = ds.tris; sc.trisPermuted = 0; sc.hitGroups = ds.hitGroups; sc.indices = ds.indexBuffer; sc.vertices = ds.vertexBuffer;
+        sc.nodes = (const uint8_t*)ds.nodes; sc.tris = ds.tris; sc.trisPermuted = 0; sc.hitGroups = ds.hitGroups; sc.indices = ds.indexBuffer;
+            sc.vertices = ds.vertexBuffer;
         sc.materials = ds.materials; sc.lights = ds.lights;
     }
     sc.numHitGroups = ds.numHitGroups; sc.numIndices = ds.numIndices; sc.numVertexFloats = ds.numVertexFloats;
@@ -67,7 +68,8 @@ __device__ __noinline__ uint32_t claim_work_item(uint32_t* counters, uint32_t re
  * LDS reads become flat loads through the texture addresser and the 870 k scene lost 2.7 %.)
  * groupConst: regions, log2(frames per group), frame groups per region, "a claim has found nothing", tag base ((launch epoch & 0xff) << 16);
  * bindState: binders under way, slots bound so far; both and the 8-entry ring live in the workgroup's LDS. */
-__device__ __noinline__ void fg_bind_next(uint32_t* groupConst, uint32_t* bindState, unsigned long long* slotTable, uint32_t* workCounter, unsigned long long* logRow,
+__device__ __noinline__ void fg_bind_next(uint32_t* groupConst, uint32_t* bindState, unsigned long long* slotTable, uint32_t* workCounter,
+    unsigned long long* logRow,
                                           uint32_t logCap, uint32_t banded, TbTileMap tiles, uint32_t W, uint32_t H)
 {
     atomicAdd(&bindState[0], 1u);
@@ -81,7 +83,8 @@ __device__ __noinline__ void fg_bind_next(uint32_t* groupConst, uint32_t* bindSt
             const uint32_t slot = atomicAdd(&bindState[1], 1u), group = item >> 20, region = item & 0xfffffu;
             uint32_t rx, ry;
             block_region(tiles, W, H, region, rx, ry);
-            const unsigned long long e = (unsigned long long)(((volatile uint32_t*)groupConst)[4] | ((slot + 1u) & 0xffffu)) << 40 | ((unsigned long long)(group << lg) << 24) | (unsigned long long)(ry << 12) | rx;
+            const unsigned long long e = (unsigned long long)(((volatile uint32_t*)groupConst)[4] | ((slot + 1u) & 0xffffu)) << 40 |
+                ((unsigned long long)(group << lg) << 24) | (unsigned long long)(ry << 12) | rx;
             ((volatile unsigned long long*)slotTable)[slot & 7u] = e;
             __hip_atomic_store(logRow + slot, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
@@ -92,7 +95,8 @@ __device__ __noinline__ void fg_bind_next(uint32_t* groupConst, uint32_t* bindSt
 
 /* a slot whose ring entry is not (or no longer) its own: the slot's entry, or 0 = ask again later, 1 = nothing left for this workgroup
  * (an entry has its tag in the top bits: never 0 or 1; by value -- an out-parameter would put the caller's copy on the stack) */
-__device__ __noinline__ unsigned long long fg_resolve_slow(uint32_t s, uint32_t tag, const uint32_t* groupConst, const uint32_t* bindState, const unsigned long long* logRow)
+__device__ __noinline__ unsigned long long fg_resolve_slow(uint32_t s, uint32_t tag, const uint32_t* groupConst, const uint32_t* bindState,
+    const unsigned long long* logRow)
 {
     if (s < ((volatile const uint32_t*)bindState)[1]) {
         /* bound, but the ring has gone round since (or the binder is between taking the number and writing the entry): the log knows.

@@ -147,7 +147,8 @@ TBD RayPre ray_prepare(tb3 o, tb3 d) /* GetRayData, TraverseFunction.hlsli:473-4
  * has hit nothing -- 1.39 million steps for one ray in 12 000 of the reference's vw-van scene, 86 % of the render's steps and, in a lock-step
  * wave, three orders of magnitude of its time (1.5 Msamples/s).  Such a ray is a miss at once, in the kernels and in the checker alike
  * (oracle/tb_oracle.cpp RayCannotHit; TB_LITERAL_BOX_TEST=1 walks it literally: tests/test_vw_van.py shows the same bits either way). */
-TBD bool ray_cannot_hit(tb3 o, tb3 d) { return __builtin_isunordered(o.x, o.y) || __builtin_isunordered(o.z, d.x) || __builtin_isunordered(d.y, d.z); } /* three v_cmp_u_f32: unordered = either operand is a NaN */
+/* three v_cmp_u_f32: unordered = either operand is a NaN */
+TBD bool ray_cannot_hit(tb3 o, tb3 d) { return __builtin_isunordered(o.x, o.y) || __builtin_isunordered(o.z, d.x) || __builtin_isunordered(d.y, d.z); }
 
 TBD bool box_test(float& tEntry, float closest, const RayPre& r, tb3 c, tb3 h) /* RayBoxTest :204-221 */
 {
@@ -236,7 +237,8 @@ struct Hit { float t, u, v; uint32_t prim, geom; };
 TBD bool is_valid_hit(const SceneRefs& sc, const TbDeviceScene& ds, uint32_t geom, uint32_t prim, float u, float v);
 
 template <bool ALPHA>
-TBD void tri_test(Hit& best, float tMin, tb3 o, const RayPre& r, const TbTriB& tri, bool permuted, const SceneRefs& sc, const TbDeviceScene& ds, uint32_t geomBase = 0u)
+TBD void tri_test(Hit& best, float tMin, tb3 o, const RayPre& r, const TbTriB& tri, bool permuted, const SceneRefs& sc, const TbDeviceScene& ds,
+    uint32_t geomBase = 0u)
 {
     float Az, Bz, Cz, U, V, W;
     if (permuted) {
@@ -316,7 +318,7 @@ TBD bool traverse(const SceneRefs& sc, const TbDeviceScene& ds, tb3 o, tb3 d, Hi
 {
     best.t = MAX_T; best.u = best.v = 0.0f; best.prim = best.geom = 0u;
     if (ray_cannot_hit(o, d)) return false;
-    walk_owns(o);
+    walk_owns(o); walk_owns(d); /* d: read by ray_prepare only, but as the path's own rd it lives across the walk and was reloaded at each use there */
     RayPre r = ray_prepare(o, d);
     float unusedT;
     if (!box_test(unusedT, best.t, r, ld3(ds.rootCenter), ld3(ds.rootHalf))) return false; /* :566-580 */
@@ -385,11 +387,13 @@ TBD tb3 xfm_point34(const float* m, tb3 v) /* pinned order of the dp4: one fma c
 }
 TBD tb3 xfm_vector34(const float* m, tb3 v)
 {
-    return tb3_make(tb_fma(m[2], v.z, tb_fma(m[1], v.y, m[0] * v.x)), tb_fma(m[6], v.z, tb_fma(m[5], v.y, m[4] * v.x)), tb_fma(m[10], v.z, tb_fma(m[9], v.y, m[8] * v.x)));
+    return tb3_make(tb_fma(m[2], v.z, tb_fma(m[1], v.y, m[0] * v.x)), tb_fma(m[6], v.z, tb_fma(m[5], v.y, m[4] * v.x)), tb_fma(m[10], v.z, tb_fma(m[9], v.y,
+        m[8] * v.x)));
 }
 
 template <bool RAY_COUNTERS, bool ALPHA, bool HYBRID = false>
-TBD bool traverse_instanced(const SceneRefs& sc, const TbDeviceScene& ds, tb3 o, tb3 d, Hit& best, uint32_t* stack, uint32_t stride, uint32_t& boxes, uint32_t& tris,
+TBD bool traverse_instanced(const SceneRefs& sc, const TbDeviceScene& ds, tb3 o, tb3 d, Hit& best, uint32_t* stack, uint32_t stride, uint32_t& boxes,
+    uint32_t& tris,
                             uint32_t* overflow = nullptr)
 {
     best.t = MAX_T; best.u = best.v = 0.0f; best.prim = best.geom = 0u;
@@ -678,12 +682,16 @@ TBD TbMaterial get_material(const SceneRefs& sc, const TbDeviceScene& ds, float&
     TbMaterial mat = fetch_material(sc, (uint32_t)id);
     if (back) { mat.emissive.x = mat.emissive.y = mat.emissive.z = 0.0f; }
     if ((F & FEAT_MIX) && (mat.Flags & TB_MAT_MIX) != 0) { /* 1 R */
-        if (rnd(seed, time) < mat.albedo.z) mat = fetch_material(sc, (uint32_t)mat.albedo.x);
-        else mat = fetch_material(sc, (uint32_t)mat.albedo.y);
+        /* one record fetch on the index the coin selects (the two sides' fetches were issued one after the other for a divergent wave) */
+        const uint32_t pick = rnd(seed, time) < mat.albedo.z ? (uint32_t)mat.albedo.x : (uint32_t)mat.albedo.y;
+        mat = fetch_material(sc, pick);
     } else if (F & FEAT_TEXTURES) {
-        if (mat.albedoIndex != TB_INVALID_TEXTURE) { F4 t = texture_fetch(ds, mat.albedoIndex, u, v); mat.albedo.x = t.x; mat.albedo.y = t.y; mat.albedo.z = t.z; }
-        if (mat.emissiveIndex != TB_INVALID_TEXTURE && !back) { F4 t = texture_fetch(ds, mat.emissiveIndex, u, v); mat.emissive.x = t.x; mat.emissive.y = t.y; mat.emissive.z = t.z; }
-        if (mat.specularMapIndex != TB_INVALID_TEXTURE) { F4 t = texture_fetch(ds, mat.specularMapIndex, u, v); mat.roughness = t.y; if (t.z > 0.5f) mat.Flags |= TB_MAT_METALLIC; }
+        if (mat.albedoIndex != TB_INVALID_TEXTURE) { F4 t = texture_fetch(ds, mat.albedoIndex, u, v); mat.albedo.x = t.x; mat.albedo.y = t.y;
+            mat.albedo.z = t.z; }
+        if (mat.emissiveIndex != TB_INVALID_TEXTURE && !back) { F4 t = texture_fetch(ds, mat.emissiveIndex, u, v); mat.emissive.x = t.x; mat.emissive.y = t.y;
+            mat.emissive.z = t.z; }
+        if (mat.specularMapIndex != TB_INVALID_TEXTURE) { F4 t = texture_fetch(ds, mat.specularMapIndex, u, v); mat.roughness = t.y;
+            if (t.z > 0.5f) mat.Flags |= TB_MAT_METALLIC; }
     }
     bool anyAlbedo = mat.albedo.x != 0.0f || mat.albedo.y != 0.0f || mat.albedo.z != 0.0f;
     if ((F & FEAT_SSS) && (mat.Flags & TB_MAT_SUBSURFACE_SCATTER) != 0 && anyAlbedo) { /* ArtistFriendlyAlbdeoToAbsorption :1224-1233 */
@@ -714,21 +722,13 @@ TBD float diffuse_brdf(tb3 L, tb3 N) { return tb_max(tb3_dot(L, N), 0.0f) / PI; 
 
 TBD tb3 reorient(tb3 v, tb3 n) /* ReorientVectorAroundNormal :1001-1015 */
 {
+    /* (a select form -- one square root and three divisions on operands chosen per lane -- was measured in round 5, twice, on one box against
+     * this form: within +-0.5 % on all six workloads) */
     tb3 t;
     if (tb_abs(n.x) > tb_abs(n.y)) t = tb3_make(-n.z, 0, n.x) / tb_sqrt(n.x * n.x + n.z * n.z);
     else t = tb3_make(0, n.z, -n.y) / tb_sqrt(n.y * n.y + n.z * n.z);
     tb3 b = tb3_cross(n, t);
     return tb3_normalize(v.x * t + v.y * n + v.z * b);
-}
-
-TBD tb3 cosine_direction(tb3 n, float r0, float r1) /* :1025-1041 */
-{
-    float r = tb_sqrt(r0);
-    float theta = (2.0f * PI) * r1;
-    float x = r * tb_cos(theta);
-    float y = tb_sqrt(tb_max(EPSILON, 1.0f - r0));
-    float z = r * tb_sin(theta);
-    return reorient(tb3_make(x, y, z), n);
 }
 
 TBD tb3 lobe_direction(tb3 n, float roughness, float r0, float r1, float& pdf) /* GenerateImportanceSampledDirection :1048-1064 */
@@ -739,17 +739,6 @@ TBD tb3 lobe_direction(tb3 n, float roughness, float r0, float r1, float& pdf) /
     tb3 d = tb3_make(tb_sin(phi) * tb_cos(theta), tb_cos(phi), tb_sin(phi) * tb_sin(theta));
     pdf = (lobe + 1.0f) * tb_pow(tb_cos(phi), lobe) / (2.0f * PI);
     return reorient(d, n);
-}
-
-TBD tb3 ggx_reflect(float& seed, float time, tb3 incoming, tb3 n, float roughness) /* ImportanceSampleGGX :1066-1082, 2 R */
-{
-    roughness = tb_max(MIN_ROUGHNESS, roughness);
-    float a = roughness * roughness, a2 = a * a;
-    float u1 = rnd(seed, time); float u2 = rnd(seed, time);
-    float theta = (2.0f * PI) * u2;
-    float phi = tb_acos(tb_sqrt((1.0f - u1) / ((a2 - 1.0f) * u1 + 1.0f)));
-    tb3 d = tb3_make(tb_sin(phi) * tb_cos(theta), tb_cos(phi), tb_sin(phi) * tb_sin(theta));
-    return tb3_reflect(incoming, reorient(d, n));
 }
 
 TBD float ggx_pdf(tb3 n, tb3 outgoing, tb3 h, float roughness) /* ImportanceSampleGGXPDF :1084-1094 */
@@ -763,7 +752,6 @@ TBD float ggx_pdf(tb3 n, tb3 outgoing, tb3 h, float roughness) /* ImportanceSamp
     return d * tb_abs(tb3_dot(h, n)) / (4.0f * tb_abs(tb3_dot(outgoing, h)));
 }
 
-TBD tb3 half_vector_safe(tb3 a, tb3 b, tb3 n) { return tb3_dot(a, b) > (-1.0f + EPSILON) ? tb3_normalize(a + b) : n; }
 
 /* ---- per-path state ------------------------------------------------------------------------------ */
 enum : uint32_t {
@@ -1016,6 +1004,7 @@ TBD void path_on_closest(Path& p, const SceneRefs& sc, const TbDeviceScene& ds, 
     const bool back = nDotD > 0.0f;
     TbMaterial m = get_material<F>(sc, ds, p.seed, pf.Time, s.material, s.u, s.v, back);
     p.nMat++;
+    /* detail_normal's own condition */
     tb3 Nd = (F & FEAT_TEXTURES) ? detail_normal(ds, pf, m, s.normal, s.tangent, s.u, s.v) : s.normal;
     if ((F & FEAT_EXT) && first) { /* :1365-1376 */
         tb3 camPos = ld3(pf.CameraPosition);
@@ -1065,15 +1054,23 @@ TBD void path_on_closest(Path& p, const SceneRefs& sc, const TbDeviceScene& ds, 
 template <uint32_t F>
 TBD void path_on_shadow(Path& p, const SceneRefs& sc, const TbDeviceScene& ds, const TbPerFrameConstants& pf, bool isHit, const Hit& h)
 {
+    /* GetMaterial of the blocker, of which only two things reach the result: the mix coin it may flip (one R, iff the record has
+     * MIX_MATERIAL_FLAG; a mix material takes no texture overrides, RayGenCommon.h:298-341) and the LIGHT flag of the record it ends with.
+     * Hit attributes, back-face test, overrides and SSS coefficients of the full function are not computed: two or three small loads
+     * instead of the index triple, three vertices and one or two 84-B records. */
     bool lit = true;
     if (isHit) {
-        Surface s;
-        fetch_surface(sc, h, s, false);
-        bool back = tb3_dot(s.normal, p.rd) > 0.0f;
-        TbMaterial m = get_material<F>(sc, ds, p.seed, pf.Time, s.material, s.u, s.v, back);
         p.nMat++;
-        if ((m.Flags & TB_MAT_LIGHT) == 0) lit = false;
+        const uint32_t mi = h.geom < sc.numHitGroups ? sc.hitGroups[h.geom].MaterialIndex : 0u;
+        int flags = mi < sc.numMaterials ? sc.materials[mi].m.Flags : 0;
+        if ((F & FEAT_MIX) && (flags & TB_MAT_MIX) != 0) { /* 1 R */
+            const TbFloat3 mix = sc.materials[mi].m.albedo; /* (index A, index B, weight): mi is in range, its flags were just read */
+            const uint32_t pick = rnd(p.seed, pf.Time) < mix.z ? (uint32_t)mix.x : (uint32_t)mix.y;
+            flags = pick < sc.numMaterials ? sc.materials[pick].m.Flags : 0;
+        }
+        lit = (flags & TB_MAT_LIGHT) != 0;
     }
+    (void)ds;
     /* shadowed: (pend*0)*lightColor == +-0 for finite operands and NaN otherwise; contrib*0 has the same
      * value except when pend*lightColor overflows fp32, which needs radiance ~1e38 (parity notes) */
     p.L = p.L + (lit ? p.contrib : p.contrib * 0.0f);
@@ -1083,18 +1080,20 @@ TBD void path_on_shadow(Path& p, const SceneRefs& sc, const TbDeviceScene& ds, c
 /* The same visibility test for kernels that scatter BEFORE they trace the feeler (pt_persistent.inc, feature sets without mix
  * materials): lightDir is the feeler's direction, the path's own ray already is the next bounce.  Touches nothing but L. */
 template <uint32_t F>
-TBD void path_apply_shadow(Path& p, const SceneRefs& sc, const TbDeviceScene& ds, const TbPerFrameConstants& pf, bool isHit, const Hit& h, tb3 lightDir, tb3 contrib)
+TBD void path_apply_shadow(Path& p, const SceneRefs& sc, const TbDeviceScene& ds, const TbPerFrameConstants& pf, bool isHit, const Hit& h, tb3 lightDir,
+    tb3 contrib)
 {
     static_assert(!(F & FEAT_MIX), "GetMaterial of the blocker draws a random number for mix materials: the feeler must be judged before the scatter");
+    /* Without mix materials GetMaterial of the blocker draws no random number, and of everything it computes -- hit attributes, the back-face
+     * test, texture overrides, the SSS coefficients -- only the LIGHT flag of the record is read here (an override can add METALLIC, nothing
+     * else): two dword loads (hit group -> material index -> flags) instead of the index triple, three vertices and the 84-B record.
+     * nMat still counts the reference's GetMaterial call (byte model). */
     bool lit = true;
     if (isHit) {
-        Surface s;
-        fetch_surface(sc, h, s, false);
-        const bool back = tb3_dot(s.normal, lightDir) > 0.0f;
-        const TbMaterial m = get_material<F>(sc, ds, p.seed, pf.Time, s.material, s.u, s.v, back);
         p.nMat++;
-        if ((m.Flags & TB_MAT_LIGHT) == 0) lit = false;
+        lit = shadow_hit_is_light(sc, h.geom);
     }
+    (void)ds; (void)pf; (void)lightDir;
     p.L = p.L + (lit ? contrib : contrib * 0.0f);
 }
 
@@ -1136,12 +1135,30 @@ TBD void path_scatter(Path& p, const TbPerFrameConstants& pf)
 {
     const bool first = p.bounce == 0;
     const bool spec = (F & FEAT_SPECULAR) && (p.flags & F_SPECULAR) != 0, perfect = (F & FEAT_SPECULAR) && (p.flags & F_PERFECT) != 0;
-    const bool allowsSpec = (F & FEAT_SPECULAR) && (p.matFlags & TB_MAT_NO_SPECULAR) == 0, metallic = (F & FEAT_SPECULAR) && (p.matFlags & TB_MAT_METALLIC) != 0;
+    const bool allowsSpec = (F & FEAT_SPECULAR) && (p.matFlags & TB_MAT_NO_SPECULAR) == 0,
+        metallic = (F & FEAT_SPECULAR) && (p.matFlags & TB_MAT_METALLIC) != 0;
     p.rd = p.prevDir; p.ro = p.nextOrigin;
     p.flags = (p.flags & ~F_PREV_PERFECT) | (perfect ? F_PREV_PERFECT : 0u); /* :1520 */
-    if (spec) {
-        p.rd = ggx_reflect(p.seed, pf.Time, p.prevDir, p.N, p.roughness); /* :1521-1526 */
-    } else if ((F & FEAT_SSS) && (p.matFlags & TB_MAT_SUBSURFACE_SCATTER) != 0) { /* :1529-1600 */
+    const bool interior = !spec && (F & FEAT_SSS) && (p.matFlags & TB_MAT_SUBSURFACE_SCATTER) != 0;
+    if (!interior) {
+        /* GGX reflection (:1521-1526, ImportanceSampleGGX :1066-1082) and the cosine-weighted hemisphere (:1695, :1025-1041) draw the same two
+         * random numbers in the same order, turn the second into the same azimuth and end in the same ReorientVectorAroundNormal about N:
+         * a plastic surface flips a coin between them, so a wave always holds both.  The lane's polar part (A = sin, B = cos of the polar
+         * angle) is computed on its own side; the azimuth's sine and cosine, the three products and the reorientation once for the wave. */
+        const float r0 = rnd(p.seed, pf.Time); const float r1 = rnd(p.seed, pf.Time);
+        const float theta = (2.0f * PI) * r1;
+        float A, B;
+        if (spec) {
+            const float roughness = tb_max(MIN_ROUGHNESS, p.roughness);
+            const float a = roughness * roughness, a2 = a * a;
+            const float phi = tb_acos(tb_sqrt((1.0f - r0) / ((a2 - 1.0f) * r0 + 1.0f)));
+            A = tb_sin(phi); B = tb_cos(phi);
+        } else {
+            A = tb_sqrt(r0); B = tb_sqrt(tb_max(EPSILON, 1.0f - r0));
+        }
+        const tb3 w = reorient(tb3_make(A * tb_cos(theta), B, A * tb_sin(theta)), p.N);
+        p.rd = spec ? tb3_reflect(p.prevDir, w) : w;
+    } else { /* :1529-1600 */
         bool reflected;
         if (!refract_or_reflect(p, pf, p.N, p.nDotD, p.curIOR / p.newIOR, perfect, reflected)) { p.state = ST_DONE; return; } /* :1552 */
         bool noScatter = p.scattering.x < EPSILON;
@@ -1153,37 +1170,43 @@ TBD void path_scatter(Path& p, const TbPerFrameConstants& pf)
         if (exiting) { finish_bounce(p, pf); return; } /* loop body never runs, then `continue` :1690 */
         p.state = ST_SSS; /* first walk step's ray is (p.ro, p.rd) */
         return;
-    } else {
-        float r0 = rnd(p.seed, pf.Time); float r1 = rnd(p.seed, pf.Time);
-        p.rd = cosine_direction(p.N, r0, r1); /* :1695 */
     }
+    /* The lanes of a wave fall on all three sides of the reference's branches here (matte, plastic and metal share a scene), and a branching
+     * form issues every side's divisions and pow()s for the whole wave.  What the sides have in common is therefore computed once, on operands
+     * selected per lane: the half vector's normalisation, the three divisions of T by the pdf, the GGX term.  Each lane's operations and their
+     * order are those of its own branch (kernel.glsl:1699-1769). */
     float diffusePdf = tb3_dot(p.rd, p.N) / PI; /* :1699 */
-    if (allowsSpec) {
-        tb3 hv = half_vector_safe(-p.prevDir, p.rd, p.N);
-        float specPdf = ggx_pdf(p.N, p.rd, hv, p.roughness);
-        float pdf = metallic ? specPdf : tb_lerp(specPdf, diffusePdf, 0.5f);
-        p.T = p.T / pdf;
-    } else {
-        p.T = p.T / diffusePdf;
+    const bool anySpec = allowsSpec || metallic;
+    tb3 hvN = tb3_splat(0.0f), hvSafe = tb3_splat(0.0f);
+    if (anySpec) {
+        const tb3 toEye = -p.prevDir;
+        hvN = tb3_normalize(toEye + p.rd);                                            /* the metallic branch's half vector, :1735 */
+        hvSafe = tb3_dot(toEye, p.rd) > (-1.0f + EPSILON) ? hvN : p.N;               /* GetHalfVectorSafe :1258-1269 */
     }
+    float pdf = diffusePdf;
+    if (allowsSpec) {
+        float specPdf = ggx_pdf(p.N, p.rd, hvSafe, p.roughness);
+        pdf = metallic ? specPdf : tb_lerp(specPdf, diffusePdf, 0.5f);
+    }
+    p.T = p.T / pdf;
     if ((F & FEAT_EXT) && first) p.flags |= F_AOV_EMISSIVE; /* :1720-1723 (value stored in path_on_closest) */
     tb3 albedo = ((F & FEAT_EXT) && pf.IsRealTime && first) ? tb3_splat(1.0f) : p.albedo;
-    if (metallic) { /* :1734-1741 */
-        tb3 hv = tb3_normalize(-p.prevDir + p.rd);
+    if (anySpec) {
+        const tb3 hv = metallic ? hvN : hvSafe;
         float r2 = tb_max(p.roughness * p.roughness, MIN_ROUGHNESS_SQUARED);
-        float specular = ggx_ndf(p.Nd, hv, r2) / (4.0f * tb_abs(tb3_dot(-p.prevDir, hv)) * tb_max(tb_abs(tb3_dot(-p.prevDir, p.N)), tb_abs(tb3_dot(p.rd, p.N))));
-        p.T = p.T * (specular * albedo * tb_saturate(tb3_dot(p.rd, p.N)));
-    } else if (allowsSpec) { /* :1744-1765 */
-        tb3 hv = half_vector_safe(-p.prevDir, p.rd, p.N);
-        float fresnel = p.specCoef + (1.0f - p.specCoef) * tb_pow(tb_abs(1.0f - tb3_dot(-p.prevDir, hv)), 5.0f);
-        float dm = (float)(28.0 / (23.0 * 3.1415926535)) * (1.0f - p.specCoef)
-            * (1.0f - tb_pow(1.0f - 0.5f * tb3_dot(-p.prevDir, p.N), 5.0f))
-            * (1.0f - tb_pow(1.0f - 0.5f * tb3_dot(p.rd, p.N), 5.0f));
-        tb3 diffuse = albedo * dm;
-        float r2 = tb_max(p.roughness * p.roughness, MIN_ROUGHNESS_SQUARED);
-        float specular = ggx_ndf(p.Nd, hv, r2) / (4.0f * tb_abs(tb3_dot(-p.prevDir, hv)) * tb_max(tb_abs(tb3_dot(-p.prevDir, p.N)), tb_abs(tb3_dot(p.rd, p.N))));
-        tb3 mult = (diffuse + tb3_splat(fresnel * specular)) * tb_saturate(tb3_dot(p.rd, p.N));
-        p.T = p.T * mult;
+        float specular = ggx_ndf(p.Nd, hv, r2) / (4.0f * tb_abs(tb3_dot(-p.prevDir, hv)) * tb_max(tb_abs(tb3_dot(-p.prevDir, p.N)), tb_abs(tb3_dot(p.rd,
+            p.N))));
+        if (metallic) { /* :1734-1741 */
+            p.T = p.T * (specular * albedo * tb_saturate(tb3_dot(p.rd, p.N)));
+        } else { /* :1744-1765 */
+            float fresnel = p.specCoef + (1.0f - p.specCoef) * tb_pow(tb_abs(1.0f - tb3_dot(-p.prevDir, hv)), 5.0f);
+            float dm = (float)(28.0 / (23.0 * 3.1415926535)) * (1.0f - p.specCoef)
+                * (1.0f - tb_pow(1.0f - 0.5f * tb3_dot(-p.prevDir, p.N), 5.0f))
+                * (1.0f - tb_pow(1.0f - 0.5f * tb3_dot(p.rd, p.N), 5.0f));
+            tb3 diffuse = albedo * dm;
+            tb3 mult = (diffuse + tb3_splat(fresnel * specular)) * tb_saturate(tb3_dot(p.rd, p.N));
+            p.T = p.T * mult;
+        }
     } else { /* :1766-1769 */
         p.T = p.T * (albedo * diffuse_brdf(p.rd, p.Nd));
     }

@@ -38,7 +38,8 @@ __global__ __launch_bounds__(BLOCK) void trace_closest_kernel(TbDeviceScene ds, 
     Hit h; uint32_t nb = 0, nt = 0;
     bool hit;
     if (NODEC) hit = traverse<true, true, false, true>(sc, ds, o, d, h, stack, BLOCK, nb, nt);
-    else hit = ds.numInstances ? traverse_instanced<true, true>(sc, ds, o, d, h, stack, BLOCK, nb, nt) : traverse<true, true>(sc, ds, o, d, h, stack, BLOCK, nb, nt);
+    else hit = ds.numInstances ? traverse_instanced<true, true>(sc, ds, o, d, h, stack, BLOCK, nb, nt) : traverse<true, true>(sc, ds, o, d, h, stack, BLOCK,
+        nb, nt);
     outT[i] = hit ? h.t : -1.0f;
     if (outBary) { outBary[2 * i] = hit ? h.u : 0.0f; outBary[2 * i + 1] = hit ? h.v : 0.0f; }
     if (outPrim) outPrim[i] = hit ? h.prim : 0xffffffffu;
@@ -62,7 +63,8 @@ __global__ void device_math_kernel(int fn, uint32_t n, const float* a, const flo
     case 4: r = tb_exp(x); break; case 5: r = tb_log(x); break; case 6: r = tb_pow(x, y); break; case 7: r = tb_sqrt(x); break;
     case 8: r = tb_exp2(x); break; case 9: r = tb_log2(x); break; case 10: r = tb_asin(x); break;
     case 11: r = x / y; break; case 12: r = tb_frac(tb_sin(x + y) * 43758.5453123f); break; case 13: r = hash13(x, y, 0.0f); break;
-    case 14: r = tb_min(x, y); break; case 15: r = tb_max(x, y); break; case 16: r = tb_frac(x); break; case 17: r = tb_floor(x); break; case 18: r = tb_rcp(x); break;
+    case 14: r = tb_min(x, y); break; case 15: r = tb_max(x, y); break; case 16: r = tb_frac(x); break; case 17: r = tb_floor(x); break;
+        case 18: r = tb_rcp(x); break;
     default: break;
     }
     out[i] = r;
@@ -87,7 +89,8 @@ __global__ void pack_owned_kernel(const TbFloat4* full, TbFloat4* packed, uint32
 
 /* rank 0 of a tile split: the inverse of pack_owned_kernel over the gathered buffers of all ranks (tb_unpack_gathered_device).
  * gathered = world x capacity pixels, rank r's packed tiles at r * capacity; one workgroup per tile of the frame. */
-__global__ void unpack_gathered_kernel(const TbFloat4* gathered, size_t capacity, TbFloat4* full, uint32_t W, uint32_t H, uint32_t world, uint32_t tileW, uint32_t tileH)
+__global__ void unpack_gathered_kernel(const TbFloat4* gathered, size_t capacity, TbFloat4* full, uint32_t W, uint32_t H, uint32_t world, uint32_t tileW,
+    uint32_t tileH)
 {
     const uint32_t tilesX = (W + tileW - 1) / tileW, t = blockIdx.x;
     const uint32_t rank = t % world, local = t / world;
@@ -102,7 +105,8 @@ __global__ void unpack_gathered_kernel(const TbFloat4* gathered, size_t capacity
 
 /* Ordered sum of the frame-group mode's sample buffer (TbDeviceTargets::samples): RayGenCommon.h:721-727 per pixel,
  * frames in order.  One lane per owned pixel; reads numFrames x 16 B, HBM-bound. */
-__global__ __launch_bounds__(256) void accumulate_samples_kernel(const TbFloat4* samples, uint32_t W, uint32_t H, uint32_t firstFrame, uint32_t numFrames, TbTileMap tiles,
+__global__ __launch_bounds__(256) void accumulate_samples_kernel(const TbFloat4* samples, uint32_t W, uint32_t H, uint32_t firstFrame, uint32_t numFrames,
+    TbTileMap tiles,
                                                                  TbFloat4* output, TbFloat4* jittered)
 {
     const uint32_t n = W * H;
@@ -133,7 +137,8 @@ __global__ __launch_bounds__(256) void accumulate_samples_kernel(const TbFloat4*
 
 extern "C" {
 
-hipError_t pt_launch_accumulate_samples(hipStream_t stream, const TbFloat4* samples, uint32_t W, uint32_t H, uint32_t firstFrame, uint32_t numFrames, const TbTileMap* tiles,
+hipError_t pt_launch_accumulate_samples(hipStream_t stream, const TbFloat4* samples, uint32_t W, uint32_t H, uint32_t firstFrame, uint32_t numFrames,
+    const TbTileMap* tiles,
                                         TbFloat4* output, TbFloat4* jittered)
 {
     hipLaunchKernelGGL(accumulate_samples_kernel, dim3(2048), dim3(256), 0, stream, samples, W, H, firstFrame, numFrames, *tiles, output, jittered);
@@ -149,8 +154,10 @@ hipError_t pt_launch_trace_closest(hipStream_t stream, const TbDeviceScene* ds, 
     const void* fn = ds->nodesC ? (const void*)trace_closest_kernel<true> : (const void*)trace_closest_kernel<false>;
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    if (ds->nodesC) hipLaunchKernelGGL(trace_closest_kernel<true>, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), lds, stream, *ds, n, origins, dirs, outT, outMat, outBary, outPrim, outGeom, outNormal, outUV, outBoxes, outTris);
-    else hipLaunchKernelGGL(trace_closest_kernel<false>, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), lds, stream, *ds, n, origins, dirs, outT, outMat, outBary, outPrim, outGeom, outNormal, outUV, outBoxes, outTris);
+    if (ds->nodesC) hipLaunchKernelGGL(trace_closest_kernel<true>, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), lds, stream, *ds, n, origins, dirs, outT,
+        outMat, outBary, outPrim, outGeom, outNormal, outUV, outBoxes, outTris);
+    else hipLaunchKernelGGL(trace_closest_kernel<false>, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), lds, stream, *ds, n, origins, dirs, outT, outMat, outBary,
+        outPrim, outGeom, outNormal, outUV, outBoxes, outTris);
     return hipGetLastError();
 }
 
@@ -160,7 +167,8 @@ hipError_t pt_launch_device_math(hipStream_t stream, int fn, uint32_t n, const f
     return hipGetLastError();
 }
 
-hipError_t pt_launch_unpack_gathered(hipStream_t stream, const TbFloat4* gathered, size_t capacity, TbFloat4* full, uint32_t W, uint32_t H, uint32_t world, uint32_t tileW, uint32_t tileH)
+hipError_t pt_launch_unpack_gathered(hipStream_t stream, const TbFloat4* gathered, size_t capacity, TbFloat4* full, uint32_t W, uint32_t H, uint32_t world,
+    uint32_t tileW, uint32_t tileH)
 {
     const uint32_t tilesTotal = ((W + tileW - 1) / tileW) * ((H + tileH - 1) / tileH);
     if (tilesTotal == 0) return hipSuccess;
@@ -168,7 +176,8 @@ hipError_t pt_launch_unpack_gathered(hipStream_t stream, const TbFloat4* gathere
     return hipGetLastError();
 }
 
-hipError_t pt_launch_pack_owned(hipStream_t stream, const TbFloat4* full, TbFloat4* packed, uint32_t W, uint32_t H, const TbTileMap* tiles, uint32_t numOwnedTiles)
+hipError_t pt_launch_pack_owned(hipStream_t stream, const TbFloat4* full, TbFloat4* packed, uint32_t W, uint32_t H, const TbTileMap* tiles,
+    uint32_t numOwnedTiles)
 {
     if (numOwnedTiles == 0) return hipSuccess;
     hipLaunchKernelGGL(pack_owned_kernel, dim3(numOwnedTiles), dim3(256), 0, stream, full, packed, W, H, *tiles, numOwnedTiles);

@@ -19,7 +19,8 @@
 /* Device copies of the shading records, padded / trimmed to 16-B multiples so that each is fetched with 16-B loads
  * (a scattered 4-B load costs the vector memory pipe as much as a 16-B one).  The byte model of DESIGN.md keeps the
  * reference's record sizes. */
-struct __attribute__((aligned(16))) TbDevHitGroup { uint32_t MaterialIndex, vFirst, iFirst, pad; }; /* the fields of HitGroupShaderRecord the path reads; offsets in elements */
+/* the fields of HitGroupShaderRecord the path reads; offsets in elements */
+struct __attribute__((aligned(16))) TbDevHitGroup { uint32_t MaterialIndex, vFirst, iFirst, pad; };
 struct __attribute__((aligned(16))) TbDevMaterial { TbMaterial m; uint32_t pad[3]; };               /* 84 -> 96 B */
 struct __attribute__((aligned(16))) TbDevLight { TbLight l; uint32_t pad[2]; };                     /* 104 -> 112 B */
 
@@ -74,7 +75,9 @@ struct TbDeviceTargets {
      * accumulate_samples_kernel then sums them in frame order, which keeps the fp32 accumulation of RayGenCommon.h:704-727
      * bit for bit while no lane waits for its neighbours' longer paths. */
     TbFloat4* samples; uint32_t frameGroup; uint32_t* workCounter;
-    unsigned long long* slotLog; uint32_t slotLogCap; /* frame-group mode: slotLogCap entries per workgroup of the launch (at most 16 per CU), zeroed by the launcher; every slot a workgroup binds is recorded here (pt_persistent.inc) */
+    /* frame-group mode: slotLogCap entries per workgroup of the launch (at most 16 per CU), zeroed by the launcher; every slot a workgroup binds is recorded
+     * here (pt_persistent.inc) */
+    unsigned long long* slotLog; uint32_t slotLogCap;
     uint32_t bandedItems;  /* claim_work_item (pt_common.hpp): every XCD's list covers a contiguous eighth of the regions instead of every eighth region */
     /* Primary-visibility pre-pass (frame-group mode, nullable).  The camera ray of a sample depends on (x, y, frame) alone, and the
      * rays of an 8x8 pixel tile at one frame walk almost the same nodes, whereas inside the lock-step kernel a lane's primary ray is
@@ -84,7 +87,8 @@ struct TbDeviceTargets {
      * up instead of walking.  Same camera ray, same walk, same hit, same bits; one lock-step trip less per path. */
     unsigned long long* primaryHits;
     uint32_t* debugCounters; /* nullable; [0] = hit records of the pre-pass that failed their epoch / check word and were walked again (pt_persistent.inc) */
-    uint32_t launchEpoch; /* frame-group mode: a number no other launch on these buffers has had (host counter); stamps the slot-log entries (low byte) and the hit records */
+    /* frame-group mode: a number no other launch on these buffers has had (host counter); stamps the slot-log entries (low byte) and the hit records */
+    uint32_t launchEpoch;
 };
 
 /* Split-role kernel (pipeline 4, pt_split.inc): a workgroup is `travWaves` traversal waves followed by `shadeWaves` shading waves.
@@ -96,7 +100,8 @@ struct TbSplitParams {
     uint32_t readyMin;      /* a shading wave goes on when this many of its lanes have all their rays back (or every lane that waits) */
     uint32_t refillMin;     /* a traversal wave asks the queue for rays when this many of its lanes are idle */
     uint32_t innerWeight, leafWeight; /* a step runs the inner-node body when lanesAtInnerNodes * leafWeight >= lanesAtLeaves * innerWeight */
-    uint32_t travLast, shadePrio; /* the traversal waves are the LAST waves of the workgroup (younger: they yield issue slots to the shading waves); s_setprio 3 for the shading waves */
+    /* the traversal waves are the LAST waves of the workgroup (younger: they yield issue slots to the shading waves); s_setprio 3 for the shading waves */
+    uint32_t travLast, shadePrio;
     uint32_t ringCap;       /* entries of the ray queue: a power of two >= 2 x 128 x shadeWaves */
     uint32_t spinLimit;     /* every wait is bounded: a wave that has slept this often raises *abortFlag and the launch winds down */
     uint32_t* abortFlag;    /* host-visible word, 0 while all is well */

@@ -7,7 +7,11 @@
 #define PT_COUNT 0
 #define PT_ONLY_PERSISTENT 1
 #ifndef TB_SSS_WAVES
-#define TB_SSS_WAVES 6 /* waves per SIMD (80 VGPRs + scratch).  Round 3, when the walk loop still reloaded spilled values at every step: 3 / 4 / 5 / 6 waves = 1 102 / 1 211 / 1 316 / 1 263 (bistro-class), - / 1 495 / 1 564 / 1 501 (van-class) Msamples/s.  Round 4, walk loops free of scratch (walk_owns, pt_device.hpp): 4 / 5 / 6 / 7 / 8 waves = 1 332 / 1 374 / 1 410 / 819 / 1 255 (bistro-class), 1 688 / 1 657 / 1 706 / 969 / 1 517 (van-class; 7 workgroups per CU do not divide the work lists). Experiments: -DTB_SSS_WAVES=n (scripts/build_sss_sweep.py, scripts/sss_waves_timing.sh); context_internal.h reads the same macro */
+/* waves per SIMD (80 VGPRs + scratch).  Round 3, when the walk loop still reloaded spilled values at every step: 3 / 4 / 5 / 6 waves = 1 102 / 1 211 / 1 316 /
+ * 1 263 (bistro-class), - / 1 495 / 1 564 / 1 501 (van-class) Msamples/s.  Round 4, walk loops free of scratch (walk_owns, pt_device.hpp): 4 / 5 / 6 / 7 / 8
+ * waves = 1 332 / 1 374 / 1 410 / 819 / 1 255 (bistro-class), 1 688 / 1 657 / 1 706 / 969 / 1 517 (van-class; 7 workgroups per CU do not divide the work
+ * lists). Experiments: -DTB_SSS_WAVES=n (scripts/build_sss_sweep.py, scripts/sss_waves_timing.sh); context_internal.h reads the same macro */
+#define TB_SSS_WAVES 6
 #endif
 #ifdef TB_NO_OCCUPANCY_BOUND /* measurement only (scripts/spill_share.sh): the same kernels with all the registers they want, i.e. without spills */
 #define PT_PERSISTENT_ATTR

@@ -15,5 +15,7 @@
 #else
 #define PT_PERSISTENT_ATTR __attribute__((amdgpu_waves_per_eu(TB_SURF_WAVES)))
 #endif
-#define PT_PRIMARY_IN_BASE 1 /* this feature set has no higher-occupancy copy: the primary-visibility pre-pass is compiled here (Teapot: env-lit, a large part of its rays are camera rays) */
+/* this feature set has no higher-occupancy copy: the primary-visibility pre-pass is compiled here (Teapot: env-lit, a large part of its rays are camera rays)
+ * */
+#define PT_PRIMARY_IN_BASE 1
 #include "pt_variant.inc"

@@ -6,7 +6,10 @@
 #define PT_COUNT 0
 #define PT_ONLY_PERSISTENT 1
 #ifndef TB_VOL_WAVES
-#define TB_VOL_WAVES 4 /* waves per SIMD (128 VGPRs + scratch).  Round 4, walk loops free of scratch (walk_owns, pt_device.hpp), the reference's vw-van at 4K x 8: 4 / 5 / 6 waves = 1 824 / 1 617 / 1 582 Msamples/s flattened, 1 608 / 1 601 / 1 028 as a two-level scene (at 6 its 53-level tree leaves the tuned copy); 1080p 1 379 / 1 266 / 1 243.  Experiments: -DTB_VOL_WAVES=n (scripts/ab_device_flags.sh); context_internal.h reads the same macro */
+/* waves per SIMD (128 VGPRs + scratch).  Round 4, walk loops free of scratch (walk_owns, pt_device.hpp), the reference's vw-van at 4K x 8: 4 / 5 / 6 waves = 1
+ * 824 / 1 617 / 1 582 Msamples/s flattened, 1 608 / 1 601 / 1 028 as a two-level scene (at 6 its 53-level tree leaves the tuned copy); 1080p 1 379 / 1 266 / 1
+ * 243.  Experiments: -DTB_VOL_WAVES=n (scripts/ab_device_flags.sh); context_internal.h reads the same macro */
+#define TB_VOL_WAVES 4
 #endif
 #ifdef TB_NO_OCCUPANCY_BOUND /* measurement only (scripts/spill_share.sh): the same kernels with all the registers they want, i.e. without spills */
 #define PT_PERSISTENT_ATTR

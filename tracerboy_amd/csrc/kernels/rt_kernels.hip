@@ -50,7 +50,8 @@ __device__ __forceinline__ TbFloat4 sample_bilinear_clamp(const TbFloat4* t, uin
 }
 
 __global__ __launch_bounds__(64) void rt_temporal_kernel(TbTemporalConstants k, const TbFloat4* history, const TbFloat4* current, const TbFloat4* worldPos,
-                                                         const TbFloat4* prevWorldPos, const TbFloat4* momentHistory, const TbFloat4* normals, TbFloat4* out, TbFloat4* outMoment)
+                                                         const TbFloat4* prevWorldPos, const TbFloat4* momentHistory, const TbFloat4* normals, TbFloat4* out,
+                                                             TbFloat4* outMoment)
 {
     uint32_t px, py;
     const uint32_t W = k.ResolutionX, H = k.ResolutionY;
@@ -78,7 +79,8 @@ __global__ __launch_bounds__(64) void rt_temporal_kernel(TbTemporalConstants k, 
 
     tb3 PrevFrameColor = tb3_splat(0.0f), PrevMomentData = tb3_splat(0.0f);
     float t = -1.0f; /* PlaneIntersection :78-88 */
-    { const float denom = dot3(PrevFrameCameraDir, PrevFrameRayDirection); if (tb_abs(denom) > 0.0f) t = dot3(prevPos - PrevFrameFocalPoint, PrevFrameCameraDir) / denom; }
+    { const float denom = dot3(PrevFrameCameraDir, PrevFrameRayDirection);
+        if (tb_abs(denom) > 0.0f) t = dot3(prevPos - PrevFrameFocalPoint, PrevFrameCameraDir) / denom; }
     bool bValidHistory = false;
     if (!k.IgnoreHistory && t >= 0.0f && bHitValid) {
         const tb3 LensPosition = PrevFrameFocalPoint + PrevFrameRayDirection * t;
@@ -117,7 +119,8 @@ __global__ __launch_bounds__(64) void rt_temporal_kernel(TbTemporalConstants k, 
         outputAlpha = tb_max(m2 - m1 * m1, 0.0f);
     }
     const float hw = bValidHistory ? k.HistoryWeight : 0.0f;
-    out[i] = TbFloat4{tb_lerp(RawOutputColor.x, PrevFrameColor.x, hw), tb_lerp(RawOutputColor.y, PrevFrameColor.y, hw), tb_lerp(RawOutputColor.z, PrevFrameColor.z, hw), outputAlpha};
+    out[i] = TbFloat4{tb_lerp(RawOutputColor.x, PrevFrameColor.x, hw), tb_lerp(RawOutputColor.y, PrevFrameColor.y, hw), tb_lerp(RawOutputColor.z,
+        PrevFrameColor.z, hw), outputAlpha};
 }
 
 __global__ __launch_bounds__(64) void rt_denoise_kernel(TbDenoiserConstants k, const TbFloat4* input, const TbFloat4* normals, const TbFloat4* positions,
@@ -150,7 +153,8 @@ __global__ __launch_bounds__(64) void rt_denoise_kernel(TbDenoiserConstants k, c
                 const float lumaWeight = tb_exp(-tb_abs(l - luma) / tb_max(k.LumaWeightingMultiplier * centerVarianceSqrt, EPS));
                 const float normalWeight = tb_pow(tb_max(0.0f, dot3(normal, xyz(normals[c]))), k.NormalWeightingExponential);
                 const float distance = len3(xyz(positions[c]) - position);
-                const float positionWeight = tb_exp(-distance / (k.IntersectionPositionWeightingMultiplier * tb_abs((float)ox * distanceToNeighborPixel + (float)oy * distanceToNeighborPixel) + EPS));
+                const float positionWeight = tb_exp(-distance / (k.IntersectionPositionWeightingMultiplier * tb_abs((float)ox * distanceToNeighborPixel +
+                    (float)oy * distanceToNeighborPixel) + EPS));
                 const float kw[3] = {3.0f / 8.0f, 1.0f / 4.0f, 1.0f / 16.0f};
                 const int ax = xo < 0 ? -xo : xo, ay = yo < 0 ? -yo : yo; /* |offset / OffsetMultiplier| of DenoiserCS: the tap's index in the 5x5 kernel */
                 const float weight = (((lumaWeight * positionWeight) * normalWeight) * kw[ax]) * kw[ay];
@@ -163,36 +167,44 @@ __global__ __launch_bounds__(64) void rt_denoise_kernel(TbDenoiserConstants k, c
         const TbFloat4 n = input[i];
         accumulatedVariance = n.w; accumulatedColor = xyz(n); weightedSum = 1.0f;
     }
-    out[i] = TbFloat4{accumulatedColor.x / weightedSum, accumulatedColor.y / weightedSum, accumulatedColor.z / weightedSum, accumulatedVariance / (weightedSum * weightedSum)};
+    out[i] = TbFloat4{accumulatedColor.x / weightedSum, accumulatedColor.y / weightedSum, accumulatedColor.z / weightedSum,
+        accumulatedVariance / (weightedSum * weightedSum)};
 }
 
-__global__ __launch_bounds__(64) void rt_composite_kernel(uint32_t W, uint32_t H, const TbFloat4* albedoTex, const TbFloat4* lighting, const TbFloat4* emissiveTex, TbFloat4* out)
+__global__ __launch_bounds__(64) void rt_composite_kernel(uint32_t W, uint32_t H, const TbFloat4* albedoTex, const TbFloat4* lighting,
+    const TbFloat4* emissiveTex, TbFloat4* out)
 {
     uint32_t px, py;
     if (!pixel_of(W, H, px, py)) return;
     const size_t i = (size_t)py * W + px;
     const TbFloat4 a = albedoTex[i]; const tb3 albedo = xyz(a), l = xyz(lighting[i]), e = xyz(emissiveTex[i]);
     const float diffuse = a.w, specular = 1.0f - diffuse;
-    out[i] = TbFloat4{((albedo.x * l.x) * diffuse + l.x * specular) + e.x, ((albedo.y * l.y) * diffuse + l.y * specular) + e.y, ((albedo.z * l.z) * diffuse + l.z * specular) + e.z, 1.0f};
+    out[i] = TbFloat4{((albedo.x * l.x) * diffuse + l.x * specular) + e.x, ((albedo.y * l.y) * diffuse + l.y * specular) + e.y,
+        ((albedo.z * l.z) * diffuse + l.z * specular) + e.z, 1.0f};
 }
 
 } // namespace
 
-extern "C" hipError_t rt_launch_temporal(hipStream_t stream, const TbTemporalConstants* k, const TbFloat4* history, const TbFloat4* current, const TbFloat4* worldPos,
-                                         const TbFloat4* prevWorldPos, const TbFloat4* momentHistory, const TbFloat4* normals, TbFloat4* out, TbFloat4* outMoment)
+extern "C" hipError_t rt_launch_temporal(hipStream_t stream, const TbTemporalConstants* k, const TbFloat4* history, const TbFloat4* current,
+    const TbFloat4* worldPos,
+                                         const TbFloat4* prevWorldPos, const TbFloat4* momentHistory, const TbFloat4* normals, TbFloat4* out,
+                                             TbFloat4* outMoment)
 {
     const uint32_t groups = ((k->ResolutionX + 7u) / 8u) * ((k->ResolutionY + 7u) / 8u);
-    hipLaunchKernelGGL(rt_temporal_kernel, dim3(groups), dim3(64), 0, stream, *k, history, current, worldPos, prevWorldPos, momentHistory, normals, out, outMoment);
+    hipLaunchKernelGGL(rt_temporal_kernel, dim3(groups), dim3(64), 0, stream, *k, history, current, worldPos, prevWorldPos, momentHistory, normals, out,
+        outMoment);
     return hipGetLastError();
 }
-extern "C" hipError_t rt_launch_denoise(hipStream_t stream, const TbDenoiserConstants* k, const TbFloat4* input, const TbFloat4* normals, const TbFloat4* positions,
+extern "C" hipError_t rt_launch_denoise(hipStream_t stream, const TbDenoiserConstants* k, const TbFloat4* input, const TbFloat4* normals,
+    const TbFloat4* positions,
                                         const TbFloat4* undenoised, TbFloat4* out)
 {
     const uint32_t groups = ((k->ResolutionX + 7u) / 8u) * ((k->ResolutionY + 7u) / 8u);
     hipLaunchKernelGGL(rt_denoise_kernel, dim3(groups), dim3(64), 0, stream, *k, input, normals, positions, undenoised, out);
     return hipGetLastError();
 }
-extern "C" hipError_t rt_launch_composite(hipStream_t stream, uint32_t W, uint32_t H, const TbFloat4* albedo, const TbFloat4* lighting, const TbFloat4* emissive, TbFloat4* out)
+extern "C" hipError_t rt_launch_composite(hipStream_t stream, uint32_t W, uint32_t H, const TbFloat4* albedo, const TbFloat4* lighting,
+    const TbFloat4* emissive, TbFloat4* out)
 {
     const uint32_t groups = ((W + 7u) / 8u) * ((H + 7u) / 8u);
     hipLaunchKernelGGL(rt_composite_kernel, dim3(groups), dim3(64), 0, stream, W, H, albedo, lighting, emissive, out);
