@@ -312,13 +312,18 @@ TBD void walk_owns(tb3& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z));
  * compiled in (it still needs ds.alphaTest at run time); HYBRID: split stack; NODEC: fetch layout-C nodes (ds.nodesC) instead of layout B;
  * PROFILE: the wave-occupancy profile (counting launches only).  One flag per thing a kernel pays for: the first parameter used to stand
  * for "counters or the full feature set", one refactor away from changing who pays for what. */
-template <bool RAY_COUNTERS, bool ALPHA, bool HYBRID = false, bool NODEC = false, bool PROFILE = false>
+template <bool RAY_COUNTERS, bool ALPHA, bool HYBRID = false, bool NODEC = false, bool PROFILE = false, bool OWN_DIR = false>
 TBD bool traverse(const SceneRefs& sc, const TbDeviceScene& ds, tb3 o, tb3 d, Hit& best, uint32_t* stack, uint32_t stride,
                   uint32_t& boxes, uint32_t& tris, WaveProf* prof = nullptr, uint32_t* overflow = nullptr)
 {
     best.t = MAX_T; best.u = best.v = 0.0f; best.prim = best.geom = 0u;
     if (ray_cannot_hit(o, d)) return false;
-    walk_owns(o); walk_owns(d); /* d: read by ray_prepare only, but as the path's own rd it lives across the walk and was reloaded at each use there */
+    walk_owns(o);
+    /* OWN_DIR (the feature sets with interior walks, whose kernels are held to 6 / 4 waves per SIMD): the direction too -- ray_prepare alone reads
+     * it, but as the path's own rd it lives across the walk, was spilled whole and reloaded at each of its uses, and in one kernel a component of
+     * the ORIGIN went to scratch inside the walk instead.  Not for the other sets: the copy is three v_mov per ray, 0.6 % of the VALU-bound
+     * cornell-box kernel's instructions (round 5: 7 001 against 7 065 Msamples/s with it there). */
+    if (OWN_DIR) walk_owns(d);
     RayPre r = ray_prepare(o, d);
     float unusedT;
     if (!box_test(unusedT, best.t, r, ld3(ds.rootCenter), ld3(ds.rootHalf))) return false; /* :566-580 */
