@@ -216,3 +216,47 @@ def test_no_work_item_is_bound_and_left_unrendered(gpu_tb, settings, copies):
     finally:
         gpu_tb.SetOption("high_occupancy", 1); gpu_tb.SetOption("primary_prepass", 1)
         gpu_tb.SetOption("pooled_samples", 256 << 20); gpu_tb.SetOption("stack_lds_cap", 0); gpu_tb.SetOption("stack_overflow_max", 24)
+
+
+@pytest.mark.parametrize("scene", ["proc0_env", "proc1_sss", "proc2_sss_depth16", "cornell_from_memory", "teapot_surf", "mix_glass_vol"])
+def test_first_bounce_pass_is_bit_identical(gpu_tb, settings, scene):
+    """Option first_bounce (round 5, pt_first): where the pre-pass runs, a sample's whole first bounce -- camera ray, shading of the first hit,
+    that hit's feeler, the scatter -- runs there with one pixel tile per wave, and the lock-step kernel takes the path's state from a 96-B
+    record.  Same step functions in the same order: the picture is the pre-pass's and the oracle's, bit for bit -- also over progressive
+    calls, a split stack, blue noise and a rank's share of a tile split.  (Off by default: it loses on the scenes with interior walks,
+    docs/experiments/r5.md section 7.)"""
+    s = copy.copy(settings)
+    try:
+        if scene == "proc0_env": gpu_tb.LoadProcedural(0, 30000, 5); s.MaxBounces = 6
+        elif scene == "proc1_sss": gpu_tb.LoadProcedural(1, 30000, 7); s.MaxBounces = 6
+        elif scene == "proc2_sss_depth16": gpu_tb.LoadProcedural(2, 40000, 9); s.MaxBounces = 16
+        elif scene == "mix_glass_vol": gpu_tb.SetOption("scene_in_lds", 0); gpu_tb.LoadScene(os.path.join(GOLDEN, "scenes", "mix-glass", "scene.pbrt")); s.MaxBounces = 6
+        elif scene == "teapot_surf": gpu_tb.LoadScene(os.path.join(GOLDEN, "scenes", "Teapot", "scene.pbrt")); s.MaxBounces = 6
+        else: gpu_tb.SetOption("scene_in_lds", 0); gpu_tb.LoadScene(CORNELL); s.MaxBounces = 8
+        W, H, F = 200, 120, 9
+        a, aj, _ = _render(gpu_tb, 2, W, H, F, s)
+        gpu_tb.SetOption("first_bounce", 1)
+        b, bj, used = _render(gpu_tb, 2, W, H, F, s)
+        assert used == 1 and gpu_tb.GetOption("last_first_bounce") == 1
+        assert np.array_equal(bits(a), bits(b)) and np.array_equal(bits(aj), bits(bj))
+        ref = ol.render(gpu_tb.HostSceneView(), gpu_tb.FrameConstants(W, H, 0, s, 0.0), W, H, F, threads=8, jittered=True)
+        assert np.array_equal(bits(b), bits(ref["output"])) and np.array_equal(bits(bj), bits(ref["jittered"]))
+        c, cj, _ = _render(gpu_tb, 2, W, H, F, s, calls=3)             # progressive: three calls of three frames
+        assert np.array_equal(bits(c), bits(b)) and np.array_equal(bits(cj), bits(bj))
+        sb = copy.copy(s); sb.EnableBlueNoise = 1; sb.MaxBounces = 1   # the path ends in the first-bounce pass; blue-noise film jitter
+        gpu_tb.SetOption("first_bounce", 0); a1, _, _ = _render(gpu_tb, 2, W, H, F, sb)
+        gpu_tb.SetOption("first_bounce", 1); b1, _, _ = _render(gpu_tb, 2, W, H, F, sb)
+        assert np.array_equal(bits(a1), bits(b1))
+        gpu_tb.SetOption("stack_lds_cap", 4); gpu_tb.SetOption("stack_overflow_max", 64)   # split stack: pt_first<F, HYBRID>
+        b2, _, _ = _render(gpu_tb, 2, W, H, F, s)
+        if scene != "teapot_surf": assert gpu_tb.GetOption("last_plan_stack_overflow") > 0    # surf has no split-stack copy
+        assert np.array_equal(bits(b2), bits(b))
+        gpu_tb.SetOption("stack_lds_cap", 0); gpu_tb.SetOption("stack_overflow_max", 24)
+        gpu_tb.SetTileAssignment(3, 8, 64, 64)                          # rank 3 of 8: its own tiles equal the whole frame's
+        t, _, _ = _render(gpu_tb, 2, W, H, F, s)
+        own = (t[..., 3] != 0)
+        assert own.any() and np.array_equal(bits(t[own]), bits(b[own]))
+    finally:
+        gpu_tb.SetTileAssignment(0, 1)
+        gpu_tb.SetOption("first_bounce", 0); gpu_tb.SetOption("primary_prepass", 1); gpu_tb.SetOption("scene_in_lds", 1)
+        gpu_tb.SetOption("stack_lds_cap", 0); gpu_tb.SetOption("stack_overflow_max", 24)

@@ -175,6 +175,7 @@ struct tb_context {
     DevBuf splitProf; uint32_t* splitAbort = nullptr; int lastSplitWaves = 0;
     int lastFgPar = 0;          /* which of the two sample buffers the last frame-group launch wrote (debug query) */
     int lastPrimaryPrepass = 0; /* 1: the last render took its first hits from the primary-visibility pre-pass */
+    int lastFirstBounce = 0;    /* 1: ... its paths' state after the first bounce from the first-bounce pass */
     /* Multi-device group (tb_create_multi): this context is device 0 of the group and owns the assembled frame; `peers` are the
      * contexts of the other devices.  A render splits the frame into 64x64 tiles dealt round-robin over the devices (DESIGN.md
      * section 7), every device renders its own, the peers' packed tiles come over with hipMemcpyPeerAsync (xGMI) and are un-permuted

@@ -391,7 +391,11 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
         else if (t.calls == 1) { prepass = true; t.pending = 1; t.stamp = c->kernelEventStamp + 1; t.calls = 2; }
         else { prepass = false; t.pending = 2; t.stamp = c->kernelEventStamp + 1; t.calls = 1; }
     }
-    c->lastPrimaryPrepass = prepass ? 1 : 0; c->lastPlan = plan;
+    /* first-bounce pass (option first_bounce; pt_first, pt_persistent.inc): where the pre-pass runs, run a sample's whole first bounce there --
+     * camera ray, shading, the first hit's feeler, scatter -- and hand the lock-step kernel the path's state (96-B records instead of 32-B hits) */
+    const bool firstBounce = prepass && opt("first_bounce", 0) != 0 && !compactNodes;
+    const size_t hitRecordBytes = firstBounce ? 96 : 32;
+    c->lastPrimaryPrepass = prepass ? 1 : 0; c->lastFirstBounce = firstBounce ? 1 : 0; c->lastPlan = plan;
     /* launches of the kernels without the EXT features (no selected pixel, no AOVs: nothing but the sample buffer is written)
      * may overlap the drain of the launch before them */
     bool overlap = plan.overlap_launches != 0;
@@ -484,7 +488,7 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
                 const int numCUs = deviceCUs(c);
                 if (c->fgSlotLog[par].bytes < 16ull * numCUs * 16 * 8) ensure(c->fgSlotLog[par], 16ull * numCUs * 16 * 8);
                 warm.slotLog = (unsigned long long*)c->fgSlotLog[par].p; warm.slotLogCap = 16; warm.launchEpoch = ++c->launchEpoch;
-                warm.primaryHits = withHits ? (unsigned long long*)c->fgHits[par].p : nullptr;
+                warm.primaryHits = withHits ? (unsigned long long*)c->fgHits[par].p : nullptr; warm.firstBounce = withHits && firstBounce ? 1u : 0u;
                 TbDeviceScene dsPar = dsLaunch; if (dsPar.stackOverflow) dsPar.stackOverflow += par * overflowHalf;
                 hipStream_t st = overlap ? c->side[par] : c->stream;
                 HIP_TRY(launch(st, &dsPar, &pf, &warm, W, H, c->samplesRendered, 0, &c->tiles, withHits ? 0 : (c->sceneInLds ? 1 : 0), 0, 0));
@@ -513,13 +517,13 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
                  * run once themselves, with no frames, down both side streams -- a queue whose scratch has to grow under a dispatch
                  * that follows another kernel closely gave one wrong 16x16 region in the first render of 1 process in ~3 000 */
                 for (uint32_t par = 0; par < 2u; par++)
-                    if (c->fgHits[par].bytes < pixels * batch * 32) {
+                    if (c->fgHits[par].bytes < pixels * batch * hitRecordBytes) {
                         HIP_TRY(hipStreamSynchronize(c->side[par])); HIP_TRY(hipStreamSynchronize(c->stream));
-                        ensure(c->fgHits[par], pixels * batch * 32);
-                        HIP_TRY(hipMemsetAsync(c->fgHits[par].p, 0, pixels * batch * 32, overlap ? c->side[par] : c->stream));
+                        ensure(c->fgHits[par], pixels * batch * hitRecordBytes);
+                        HIP_TRY(hipMemsetAsync(c->fgHits[par].p, 0, pixels * batch * hitRecordBytes, overlap ? c->side[par] : c->stream));
                     }
                 /* one kernel per (split stack, node layout) */
-                const void* key = (const void*)((uintptr_t)launch ^ (1u | (dsLaunch.stackOverflow ? 2u : 0u) | (dsLaunch.nodesC ? 4u : 0u)));
+                const void* key = (const void*)((uintptr_t)launch ^ (1u | (dsLaunch.stackOverflow ? 2u : 0u) | (dsLaunch.nodesC ? 4u : 0u) | (firstBounce ? 8u : 0u)));
                 if (std::find(c->warmedLaunchers.begin(), c->warmedLaunchers.end(), key) == c->warmedLaunchers.end()) {
                     for (uint32_t par = 0; par < 2u; par++) warmFrameGroupForm(par, true);
                     c->warmedLaunchers.push_back(key);
@@ -542,7 +546,7 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
                         HIP_TRY(hipStreamSynchronize(c->stream)); ensure(c->fgSlotLog[par], wgs * tg.slotLogCap * 8); }
                     tg.slotLog = (unsigned long long*)c->fgSlotLog[par].p;
                 }
-                if (prepass) tg.primaryHits = (unsigned long long*)c->fgHits[par].p;
+                if (prepass) { tg.primaryHits = (unsigned long long*)c->fgHits[par].p; tg.firstBounce = firstBounce ? 1u : 0u; }
                 if (overlap) HIP_TRY(hipStreamWaitEvent(ptStream, c->evFold[par], 0)); /* the fold that last read this sample buffer */
                 if (f0 == 0) { if (clearStats && overlap) HIP_TRY(hipMemsetAsync(c->stats.p, 0, 16, ptStream));
                     HIP_TRY(hipEventRecord(c->evKernelStart, ptStream)); }

@@ -89,6 +89,11 @@ struct TbDeviceTargets {
     uint32_t* debugCounters; /* nullable; [0] = hit records of the pre-pass that failed their epoch / check word and were walked again (pt_persistent.inc) */
     /* frame-group mode: a number no other launch on these buffers has had (host counter); stamps the slot-log entries (low byte) and the hit records */
     uint32_t launchEpoch;
+    /* 1: primaryHits holds FIRST-BOUNCE STATE records -- 96 B per sample, written by pt_first (pt_persistent.inc), which runs a sample's whole
+     * first bounce with one 8x8 pixel tile per wave: camera ray, shading of the first hit, the feeler of that hit (a quarter of all rays and,
+     * being shadow feelers, 29 % of all walk steps of the van-class scene: they start next to each other and converge on the same lights)
+     * and the scatter.  The lock-step kernel takes the state where pt_first left it.  Same functions in the same order: same bits. */
+    uint32_t firstBounce;
 };
 
 /* Split-role kernel (pipeline 4, pt_split.inc): a workgroup is `travWaves` traversal waves followed by `shadeWaves` shading waves.
