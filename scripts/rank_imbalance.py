@@ -31,6 +31,7 @@ ap.add_argument("--legs", default="vwvan,c4,c5")
 ap.add_argument("--worlds", default="1,2,4,8")
 ap.add_argument("--spp", type=int, default=None)   # samples per pixel of a step (default: the workload's own, 8 for the 4K legs)
 ap.add_argument("--imbalance-threshold", type=float, default=1.05)
+ap.add_argument("--tiles", default="")   # e.g. "32,16": sweep these tile sizes too, whatever the imbalance (the largest world only)
 args = ap.parse_args()
 worlds = [int(x) for x in args.worlds.split(",")]
 
@@ -104,7 +105,13 @@ for key in args.legs.split(","):
              "deal": "round-robin (tile t -> rank t % N)", "kernel_variant": bench.VARIANTS[tb.GetOption("last_variant")]}
     entry.update(rows)
     top = rows.get("world%d" % max(worlds))
-    if top and top["max_over_mean"] > args.imbalance_threshold:
+    if args.tiles:
+        keep = worlds
+        worlds = [1, max(keep)] if 1 in keep else [max(keep)]
+        for t in [int(x) for x in args.tiles.split(",")]:
+            entry["tile%d" % t] = sweep(W, H, SPP, s, t)
+        worlds = keep
+    elif top and top["max_over_mean"] > args.imbalance_threshold:
         print("   max/mean %.3f > %.2f: trying 32x32 tiles" % (top["max_over_mean"], args.imbalance_threshold), flush=True)
         entry["tile32"] = sweep(W, H, SPP, s, 32)
     result[key] = entry
