@@ -86,7 +86,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-readback", action="store_true")   # skip the PCIe-inclusive side measurement
     ap.add_argument("--no-legs", "--no-c3", dest="no_legs", action="store_true")   # skip roofline_<leg> / scale_<leg>
     ap.add_argument("--legs", default=None)                 # comma list; default: every leg of this N
-    ap.add_argument("--leg-steps", type=int, default=3)
+    # steps of a leg: 5, so that a burst is mostly steady state (the first and last launch of a burst have no partner in
+    # flight; at 3 steps vw-van's leg read 1 817 Msamples/s where twenty steps give 1 950)
+    ap.add_argument("--leg-steps", type=int, default=5)
     ap.add_argument("--async-steps", action="store_true")   # N = 1: run the N > 1 step pipeline (async render + pack + consumer)
     ap.add_argument("--sync-steps", action="store_true")    # N = 1: wait for every render before enqueuing the next
     ap.add_argument("--cpu-baseline-seconds", type=float, default=10.0)
