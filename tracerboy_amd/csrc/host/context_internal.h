@@ -123,7 +123,7 @@ struct tb_context {
     int numCUs = 0;           /* of `device` (deviceCUs) */
     uint32_t launchEpoch = 0; /* TbDeviceTargets::launchEpoch of the last frame-group launch */
     DevBuf fgSlotLog[2]; /* frame-group mode: the workgroups' logs of bound slots (TbDeviceTargets::slotLog) */
-    DevBuf fgHits[2];   /* primary-visibility pre-pass: 32-B record of every sample's first hit (TbDeviceTargets::primaryHits) */
+    DevBuf fgHits[2];   /* primary-visibility pre-pass: 16-B or 32-B record of every sample's first hit (TbDeviceTargets::primaryHits) */
     DevBuf stackOverflow; /* split traversal stack of the higher-occupancy kernel copies on deep trees (pt_scene.h) */
     std::vector<const void*> warmedLaunchers; /* frame-group kernels that have run once on both side streams (renderImpl) */
     uint32_t fgLaunch = 0; bool sideOrdered = false; /* sideOrdered: the side streams have been ordered after everything else on `stream` */
@@ -170,6 +170,8 @@ struct tb_context {
     uint64_t kernelEventStamp = 0; /* counts the renders that have recorded evKernelStart / evKernel: a trial's sample belongs to the render it was asked of */
     uint32_t sceneGeneration = 0; /* counts finalizeScene calls */
     float interiorWalkTriangleShare = 0; /* finalizeScene */
+    uint32_t hitPrimBits = 32, hitGeomBits = 32; /* finalizeScene: bits that hold every primitive index / hit-group index of the scene (compact hit records) */
+    int lastCompactHits = 0;
     DevBuf debugCounters; /* TbDeviceTargets::debugCounters (16 words, zeroed once) */
     /* pipeline 4: host-mapped abort word of the split-role kernel (renderSplit); travWaves * 100 + shadeWaves of the last launch */
     DevBuf splitProf; uint32_t* splitAbort = nullptr; int lastSplitWaves = 0;

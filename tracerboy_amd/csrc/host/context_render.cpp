@@ -394,7 +394,12 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
     /* first-bounce pass (option first_bounce; pt_first, pt_persistent.inc): where the pre-pass runs, run a sample's whole first bounce there --
      * camera ray, shading, the first hit's feeler, scatter -- and hand the lock-step kernel the path's state (96-B records instead of 32-B hits) */
     const bool firstBounce = prepass && opt("first_bounce", 0) != 0 && !compactNodes;
-    const size_t hitRecordBytes = firstBounce ? 96 : 32;
+    /* compact hit records (pt_scene.h): 16 B where the scene's hit-group and primitive indices leave at least 4 bits of the fourth word for the stamp */
+    const uint32_t hitIndexBits = c->hitPrimBits + c->hitGeomBits;
+    const bool compactHits = prepass && !firstBounce && opt("compact_hits", 1) != 0 && hitIndexBits >= 1 && hitIndexBits <= 28;
+    auto hitStampOf = [&](uint32_t epoch) { return compactHits ? 1u + epoch % ((1u << (32u - hitIndexBits)) - 1u) : 0u; };
+    const size_t hitRecordBytes = firstBounce ? 96 : compactHits ? 16 : 32;
+    c->lastCompactHits = compactHits ? 1 : 0;
     c->lastPrimaryPrepass = prepass ? 1 : 0; c->lastFirstBounce = firstBounce ? 1 : 0; c->lastPlan = plan;
     /* launches of the kernels without the EXT features (no selected pixel, no AOVs: nothing but the sample buffer is written)
      * may overlap the drain of the launch before them */
@@ -489,6 +494,7 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
                 if (c->fgSlotLog[par].bytes < 16ull * numCUs * 16 * 8) ensure(c->fgSlotLog[par], 16ull * numCUs * 16 * 8);
                 warm.slotLog = (unsigned long long*)c->fgSlotLog[par].p; warm.slotLogCap = 16; warm.launchEpoch = ++c->launchEpoch;
                 warm.primaryHits = withHits ? (unsigned long long*)c->fgHits[par].p : nullptr; warm.firstBounce = withHits && firstBounce ? 1u : 0u;
+                warm.hitStamp = withHits ? hitStampOf(warm.launchEpoch) : 0u; warm.hitPrimBits = c->hitPrimBits; warm.hitGeomBits = c->hitGeomBits;
                 TbDeviceScene dsPar = dsLaunch; if (dsPar.stackOverflow) dsPar.stackOverflow += par * overflowHalf;
                 hipStream_t st = overlap ? c->side[par] : c->stream;
                 HIP_TRY(launch(st, &dsPar, &pf, &warm, W, H, c->samplesRendered, 0, &c->tiles, withHits ? 0 : (c->sceneInLds ? 1 : 0), 0, 0));
@@ -546,7 +552,8 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
                         HIP_TRY(hipStreamSynchronize(c->stream)); ensure(c->fgSlotLog[par], wgs * tg.slotLogCap * 8); }
                     tg.slotLog = (unsigned long long*)c->fgSlotLog[par].p;
                 }
-                if (prepass) { tg.primaryHits = (unsigned long long*)c->fgHits[par].p; tg.firstBounce = firstBounce ? 1u : 0u; }
+                if (prepass) { tg.primaryHits = (unsigned long long*)c->fgHits[par].p; tg.firstBounce = firstBounce ? 1u : 0u;
+                    tg.hitStamp = hitStampOf(tg.launchEpoch); tg.hitPrimBits = c->hitPrimBits; tg.hitGeomBits = c->hitGeomBits; }
                 if (overlap) HIP_TRY(hipStreamWaitEvent(ptStream, c->evFold[par], 0)); /* the fold that last read this sample buffer */
                 if (f0 == 0) { if (clearStats && overlap) HIP_TRY(hipMemsetAsync(c->stats.p, 0, 16, ptStream));
                     HIP_TRY(hipEventRecord(c->evKernelStart, ptStream)); }

@@ -256,6 +256,12 @@ void finalizeScene(tb_context* c, bool build)
                 if (m < s.materials.size() && (s.materials[m].Flags & TB_MAT_SUBSURFACE_SCATTER)) walks++; } }
         c->interiorWalkTriangleShare = s.triGeometry.empty() ? 0.0f : (float)((double)walks / (double)s.triGeometry.size());
     }
+    {   /* compact hit records (pt_scene.h): the widths of the two index fields */
+        uint32_t maxPrim = 0;
+        for (uint32_t q : s.triPrimitive) maxPrim = std::max(maxPrim, q);
+        auto bitsFor = [](uint64_t maxValue) { uint32_t b = 1; while (b < 32 && (maxValue >> b)) b++; return b; };
+        c->hitPrimBits = bitsFor(maxPrim); c->hitGeomBits = bitsFor(s.hitGroups.empty() ? 0 : s.hitGroups.size() - 1);
+    }
     auto opt = [&](const char* k, int64_t d) { auto it = c->options.find(k); return it == c->options.end() ? d : it->second; };
     const int64_t builder = opt("bvh_builder", 0);
     const bool twoLevel = !s.instances.empty();

@@ -94,6 +94,11 @@ struct TbDeviceTargets {
      * being shadow feelers, 29 % of all walk steps of the van-class scene: they start next to each other and converge on the same lights)
      * and the scatter.  The lock-step kernel takes the state where pt_first left it.  Same functions in the same order: same bits. */
     uint32_t firstBounce;
+    /* Compact hit records (nonzero hitStamp): 16 B per sample -- (t or -1, u, v, stamp << (hitPrimBits + hitGeomBits) | hit group << hitPrimBits |
+     * primitive) -- one load for the lane that draws the sample instead of two (the lock-step kernels are bound by the vector-memory issue rate).
+     * hitStamp is never 0 (a cleared buffer is nobody's record) and changes with every launch; the 16-B piece is written and read whole, so it
+     * needs no check word.  A hit whose indices do not fit their fields is stored with stamp 0: its lane walks the camera ray itself. */
+    uint32_t hitStamp, hitPrimBits, hitGeomBits;
 };
 
 /* Split-role kernel (pipeline 4, pt_split.inc): a workgroup is `travWaves` traversal waves followed by `shadeWaves` shading waves.
