@@ -36,8 +36,11 @@ def spill_map(text, want=""):
                 br = re.match(r"s_c?branch\S*\s+(\.LBB\d+_\d+)", ins)
                 if br and br.group(1) in index and index[br.group(1)] <= k: loops.add((index[br.group(1)], k))
         count = lambda prefix, a=0, b=None: sum(sum(1 for i in blocks[k]["ins"] if i.startswith(prefix)) for k in range(a, len(blocks) if b is None else b + 1))
+        # node and triangle fetches: 16-B loads, or 12-B ones where a kernel reads nothing of a triangle record's fourth words (it shades from the
+        # triangles' shading records and never sees the indices kept there)
+        wide = lambda a, b: count("global_load_dwordx4", a, b) + count("global_load_dwordx3", a, b)
         size = lambda a, b: sum(len(blocks[k]["ins"]) for k in range(a, b + 1))
-        walk = [(a, b) for a, b in loops if count("global_load_dwordx4", a, b) >= 4 and size(a, b) < 600]
+        walk = [(a, b) for a, b in loops if wide(a, b) >= 4 and size(a, b) < 600]
         outer = [l for l in walk if not any(o != l and o[0] <= l[0] and l[1] <= o[1] for o in walk)]   # a walk = the inner-node loop nested in the while-while loop
         # Scratch accesses INSIDE A WALK, by LLVM's own loop annotation of the listing: the kernel's outermost loop is the path loop (depth 1); a
         # depth-2 loop whose extent (its own blocks and everything nested between them) fetches nodes -- four or more global_load_dwordx4 -- is a
@@ -46,7 +49,7 @@ def spill_map(text, want=""):
         extents = {}
         for k, b in enumerate(blocks):
             if b["header"] and b["header"][1] == 2: lo, hi = extents.get(b["header"][0], (k, k)); extents[b["header"][0]] = (min(lo, k), max(hi, k))
-        walks = [(lo, hi) for lo, hi in extents.values() if count("global_load_dwordx4", lo, hi) >= 4]
+        walks = [(lo, hi) for lo, hi in extents.values() if wide(lo, hi) >= 4]
         deep = lambda prefix: sum(count(prefix, lo, hi) for lo, hi in walks)
         out.append({"name": name, "instr": size(0, len(blocks) - 1), "scratch_ld": count("scratch_load"), "scratch_st": count("scratch_store"),
                     "deep_ld": deep("scratch_load"), "deep_st": deep("scratch_store"), "walks": len(walks),

@@ -260,3 +260,39 @@ def test_first_bounce_pass_is_bit_identical(gpu_tb, settings, scene):
         gpu_tb.SetTileAssignment(0, 1)
         gpu_tb.SetOption("first_bounce", 0); gpu_tb.SetOption("primary_prepass", 1); gpu_tb.SetOption("scene_in_lds", 1)
         gpu_tb.SetOption("stack_lds_cap", 0); gpu_tb.SetOption("stack_overflow_max", 24)
+
+
+@pytest.mark.parametrize("scene", ["proc0_env", "proc1_sss", "teapot_surf", "vw_van_vol"])
+def test_compact_hit_records_are_bit_identical(gpu_tb, settings, scene):
+    """The pre-pass leaves a sample's first hit in 16 B -- (t, u, v, stamp | hit group | primitive) -- where the scene's indices leave the stamp
+    at least 4 bits of the fourth word (option compact_hits, default on; pt_scene.h), in the stamped 32-B record otherwise.  Same hit either way:
+    the pictures are equal bit for bit, to each other and to the render without a pre-pass; with the primitive field made too narrow for the scene
+    (compact_hits = 1 + k) the hits that do not fit are stored as nobody's, their lanes walk the camera ray themselves -- counted by
+    debug_prepass_rejects -- and the picture is still the same."""
+    s = copy.copy(settings)
+    try:
+        if scene == "proc0_env": gpu_tb.LoadProcedural(0, 30000, 5); s.MaxBounces = 6
+        elif scene == "proc1_sss": gpu_tb.LoadProcedural(1, 30000, 7); s.MaxBounces = 6
+        elif scene == "teapot_surf": gpu_tb.LoadScene(os.path.join(GOLDEN, "scenes", "Teapot", "scene.pbrt")); s.MaxBounces = 6
+        else: gpu_tb.LoadScene(os.path.join(GOLDEN, "scenes", "vw-van", "vw-van.pbrt")); s.MaxBounces = 4
+        W, H, F = 200, 120, 9
+        gpu_tb.SetOption("compact_hits", 0)
+        wide, widej, used = _render(gpu_tb, 2, W, H, F, s)
+        assert used == 1 and gpu_tb.GetOption("last_compact_hits") == 0
+        gpu_tb.SetOption("compact_hits", 1)
+        a, aj, used = _render(gpu_tb, 2, W, H, F, s)
+        assert used == 1 and gpu_tb.GetOption("last_compact_hits") == 1
+        assert np.array_equal(bits(a), bits(wide)) and np.array_equal(bits(aj), bits(widej))
+        none, nonej, used = _render(gpu_tb, 0, W, H, F, s)
+        assert used == 0 and np.array_equal(bits(a), bits(none)) and np.array_equal(bits(aj), bits(nonej))
+        c, cj, _ = _render(gpu_tb, 2, W, H, F, s, calls=3)                 # progressive: three calls, three stamps
+        assert np.array_equal(bits(c), bits(a)) and np.array_equal(bits(cj), bits(aj))
+        before = gpu_tb.GetOption("debug_prepass_rejects")
+        gpu_tb.SetOption("compact_hits", 1 + 6)                            # the primitive field 6 bits too narrow
+        n, nj, used = _render(gpu_tb, 2, W, H, F, s)
+        assert used == 1 and gpu_tb.GetOption("last_compact_hits") == 1
+        if scene != "vw_van_vol":   # (1 425 small geometries: most of the van's primitive indices fit even the narrow field)
+            assert gpu_tb.GetOption("debug_prepass_rejects") > before
+        assert np.array_equal(bits(n), bits(a)) and np.array_equal(bits(nj), bits(aj))
+    finally:
+        gpu_tb.SetOption("compact_hits", 1); gpu_tb.SetOption("primary_prepass", 1)

@@ -395,8 +395,12 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
      * camera ray, shading, the first hit's feeler, scatter -- and hand the lock-step kernel the path's state (96-B records instead of 32-B hits) */
     const bool firstBounce = prepass && opt("first_bounce", 0) != 0 && !compactNodes;
     /* compact hit records (pt_scene.h): 16 B where the scene's hit-group and primitive indices leave at least 4 bits of the fourth word for the stamp */
-    const uint32_t hitIndexBits = c->hitPrimBits + c->hitGeomBits;
-    const bool compactHits = prepass && !firstBounce && opt("compact_hits", 1) != 0 && hitIndexBits >= 1 && hitIndexBits <= 28;
+    /* (option compact_hits = 1 + k, a test hook: the primitive field k bits narrower than the scene needs -- hits that do not fit are stored as
+     * nobody's and walked again by their lanes) */
+    const int64_t compactOpt = opt("compact_hits", 1);
+    const uint32_t hitPrimBits = compactOpt >= 2 ? (uint32_t)std::max<int64_t>(1, (int64_t)c->hitPrimBits - (compactOpt - 1)) : c->hitPrimBits;
+    const uint32_t hitIndexBits = hitPrimBits + c->hitGeomBits;
+    const bool compactHits = prepass && !firstBounce && compactOpt != 0 && hitIndexBits >= 1 && hitIndexBits <= 28;
     auto hitStampOf = [&](uint32_t epoch) { return compactHits ? 1u + epoch % ((1u << (32u - hitIndexBits)) - 1u) : 0u; };
     const size_t hitRecordBytes = firstBounce ? 96 : compactHits ? 16 : 32;
     c->lastCompactHits = compactHits ? 1 : 0;
@@ -494,7 +498,7 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
                 if (c->fgSlotLog[par].bytes < 16ull * numCUs * 16 * 8) ensure(c->fgSlotLog[par], 16ull * numCUs * 16 * 8);
                 warm.slotLog = (unsigned long long*)c->fgSlotLog[par].p; warm.slotLogCap = 16; warm.launchEpoch = ++c->launchEpoch;
                 warm.primaryHits = withHits ? (unsigned long long*)c->fgHits[par].p : nullptr; warm.firstBounce = withHits && firstBounce ? 1u : 0u;
-                warm.hitStamp = withHits ? hitStampOf(warm.launchEpoch) : 0u; warm.hitPrimBits = c->hitPrimBits; warm.hitGeomBits = c->hitGeomBits;
+                warm.hitStamp = withHits ? hitStampOf(warm.launchEpoch) : 0u; warm.hitPrimBits = hitPrimBits; warm.hitGeomBits = c->hitGeomBits;
                 TbDeviceScene dsPar = dsLaunch; if (dsPar.stackOverflow) dsPar.stackOverflow += par * overflowHalf;
                 hipStream_t st = overlap ? c->side[par] : c->stream;
                 HIP_TRY(launch(st, &dsPar, &pf, &warm, W, H, c->samplesRendered, 0, &c->tiles, withHits ? 0 : (c->sceneInLds ? 1 : 0), 0, 0));
@@ -553,7 +557,7 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
                     tg.slotLog = (unsigned long long*)c->fgSlotLog[par].p;
                 }
                 if (prepass) { tg.primaryHits = (unsigned long long*)c->fgHits[par].p; tg.firstBounce = firstBounce ? 1u : 0u;
-                    tg.hitStamp = hitStampOf(tg.launchEpoch); tg.hitPrimBits = c->hitPrimBits; tg.hitGeomBits = c->hitGeomBits; }
+                    tg.hitStamp = hitStampOf(tg.launchEpoch); tg.hitPrimBits = hitPrimBits; tg.hitGeomBits = c->hitGeomBits; }
                 if (overlap) HIP_TRY(hipStreamWaitEvent(ptStream, c->evFold[par], 0)); /* the fold that last read this sample buffer */
                 if (f0 == 0) { if (clearStats && overlap) HIP_TRY(hipMemsetAsync(c->stats.p, 0, 16, ptStream));
                     HIP_TRY(hipEventRecord(c->evKernelStart, ptStream)); }
