@@ -296,3 +296,25 @@ def test_compact_hit_records_are_bit_identical(gpu_tb, settings, scene):
         assert np.array_equal(bits(n), bits(a)) and np.array_equal(bits(nj), bits(aj))
     finally:
         gpu_tb.SetOption("compact_hits", 1); gpu_tb.SetOption("primary_prepass", 1)
+
+
+@pytest.mark.parametrize("scene", ["proc1_sss", "teapot_surf"])
+def test_texture_use_hint_changes_no_bit(gpu_tb, settings, scene):
+    """TbDeviceScene::textureUse (round 5): a feature set with textures compiled in serves scenes whose materials read none (a glass scene needs
+    the sss set); path_on_closest then fetches the first 16 B of a vertex only and interpolates no uv / tangent.  Option texture_use_hint = 0
+    (set before the scene is loaded) fetches whole vertices whatever the materials say: the same picture."""
+    s = copy.copy(settings); s.MaxBounces = 6
+    W, H, F = 200, 120, 9
+    def load():
+        if scene == "proc1_sss": gpu_tb.LoadProcedural(1, 30000, 7)
+        else: gpu_tb.LoadScene(os.path.join(GOLDEN, "scenes", "Teapot", "scene.pbrt"))
+    try:
+        gpu_tb.SetOption("texture_use_hint", 0); load()
+        a, aj, _ = _render(gpu_tb, 1, W, H, F, s)
+        gpu_tb.SetOption("texture_use_hint", 1); load()
+        b, bj, _ = _render(gpu_tb, 1, W, H, F, s)
+        assert np.array_equal(bits(a), bits(b)) and np.array_equal(bits(aj), bits(bj))
+        ref = ol.render(gpu_tb.HostSceneView(), gpu_tb.FrameConstants(W, H, 0, s, 0.0), W, H, F, threads=8, jittered=True)
+        assert np.array_equal(bits(b), bits(ref["output"])) and np.array_equal(bits(bj), bits(ref["jittered"]))
+    finally:
+        gpu_tb.SetOption("texture_use_hint", 1); gpu_tb.SetOption("primary_prepass", 1)

@@ -333,6 +333,13 @@ void finalizeScene(tb_context* c, bool build)
      * walk never holds more than bvhMaxDepth - 1 entries (one spare) */
     d.stackDepth = s.bvhMaxDepth < 2 ? 2 : s.bvhMaxDepth;
     d.alphaTest = opt("alpha_test", 0) ? 1u : 0u;
+    d.textureUse = 0;
+    for (const TbMaterial& m : s.materials) {
+        if (m.albedoIndex != TB_INVALID_TEXTURE || m.emissiveIndex != TB_INVALID_TEXTURE || m.specularMapIndex != TB_INVALID_TEXTURE ||
+            m.alphaIndex != TB_INVALID_TEXTURE) d.textureUse |= 1u;
+        if (m.normalMapIndex != TB_INVALID_TEXTURE) d.textureUse |= 2u;
+    }
+    if (opt("texture_use_hint", 1) == 0) d.textureUse = 3u; /* 0: fetch whole vertices whatever the materials say */
     /* whole-scene LDS image */
     {
         std::vector<uint8_t> blob;

@@ -518,15 +518,23 @@ struct __attribute__((aligned(16))) Vertex8 { float f[8]; };   /* N.xyz, UV.xy, 
 struct Index3 { uint32_t a, b, c; };
 
 /* out-of-range reads return 0 like the reference's raw buffer loads; a record is either wholly inside or treated as absent */
-TBD Vertex8 load_vertex(const SceneRefs& sc, uint32_t firstFloat)
+struct __attribute__((aligned(16))) Vertex4 { float f[4]; };
+TBD Vertex8 load_vertex(const SceneRefs& sc, uint32_t firstFloat, bool second = true)
 {
+    /* two 16-B pieces: normal and u; v and the tangent (second false: not fetched, zeros).  A vertex is wholly inside the buffer or absent. */
+    const bool inside = firstFloat + 8u <= sc.numVertexFloats;
+    Vertex4 a, b;
+    for (int k = 0; k < 4; k++) a.f[k] = b.f[k] = 0.0f;
+    if (inside) a = *(const Vertex4*)(sc.vertices + firstFloat);
+    if (inside && second) b = *(const Vertex4*)(sc.vertices + firstFloat + 4);
     Vertex8 v;
-    if (firstFloat + 8u <= sc.numVertexFloats) v = *(const Vertex8*)(sc.vertices + firstFloat);
-    else for (int k = 0; k < 8; k++) v.f[k] = 0.0f;
+    for (int k = 0; k < 4; k++) { v.f[k] = a.f[k]; v.f[4 + k] = b.f[k]; }
     return v;
 }
 
-TBD void fetch_surface(const SceneRefs& sc, const Hit& h, Surface& s, bool needTangent)
+/* needUV false: the second 16-B piece of the vertices (v, tangent) is not fetched and u = v = 0 -- for callers that know no material of the scene
+ * reads a texture (TbDeviceScene::textureUse) */
+TBD void fetch_surface(const SceneRefs& sc, const Hit& h, Surface& s, bool needTangent, bool needUV = true)
 {
     TbDevHitGroup rec;
     if (h.geom < sc.numHitGroups) rec = sc.hitGroups[h.geom];
@@ -535,7 +543,8 @@ TBD void fetch_surface(const SceneRefs& sc, const Hit& h, Surface& s, bool needT
     Index3 ix; ix.a = ix.b = ix.c = 0u;
     if (iAt + 3u <= sc.numIndices) ix = *(const Index3*)(sc.indices + iAt);
     const float bx = 1 - h.u - h.v, by = h.u, bz = h.v; /* GetBarycentrics3 :135-138 */
-    const Vertex8 v0 = load_vertex(sc, 8 * ix.a + rec.vFirst), v1 = load_vertex(sc, 8 * ix.b + rec.vFirst), v2 = load_vertex(sc, 8 * ix.c + rec.vFirst);
+    const Vertex8 v0 = load_vertex(sc, 8 * ix.a + rec.vFirst, needUV), v1 = load_vertex(sc, 8 * ix.b + rec.vFirst, needUV),
+                  v2 = load_vertex(sc, 8 * ix.c + rec.vFirst, needUV);
     s.u = tb_fma(bz, v2.f[3], tb_fma(by, v1.f[3], bx * v0.f[3]));
     s.v = tb_fma(bz, v2.f[4], tb_fma(by, v1.f[4], bx * v0.f[4]));
     tb3 n0 = tb3_make(v0.f[0], v0.f[1], v0.f[2]), n1 = tb3_make(v1.f[0], v1.f[1], v1.f[2]), n2 = tb3_make(v2.f[0], v2.f[1], v2.f[2]);
@@ -1002,7 +1011,10 @@ TBD void path_on_closest(Path& p, const SceneRefs& sc, const TbDeviceScene& ds, 
         p.state = ST_DONE; return;
     }
     Surface s;
-    fetch_surface(sc, h, s, (F & FEAT_TEXTURES) && pf.EnableNormalMaps != 0);
+    /* (scenes without textures served by a feature set that has them: TbDeviceScene::textureUse) */
+    const bool needUV = (F & FEAT_TEXTURES) && (ds.textureUse & 3u) != 0u;
+    fetch_surface(sc, h, s, (F & FEAT_TEXTURES) && pf.EnableNormalMaps != 0 && (ds.textureUse & 2u) != 0u, needUV);
+    if (!needUV) s.u = 0.0f;
     tb3 RayPoint = tb3_madd(p.rd, h.t, p.ro);
     p.nextOrigin = RayPoint + s.normal * EPSILON; /* :1353, unflipped normal */
     float nDotD = tb3_dot(s.normal, p.rd);

@@ -46,6 +46,10 @@ struct TbDeviceScene {
     const TbFloat4* blueNoise1;
     TbConfigConstants config;
     uint32_t alphaTest;          /* option "alpha_test": IsValidHit filter on candidate hits of non-opaque geometry (full variant only) */
+    /* what the scene's materials can ask of a hit's vertices beyond their normals: bit 0 = some material has an albedo / emissive / specular /
+     * alpha texture (the interpolated uv is read), bit 1 = some material has a normal map (the tangent is).  A feature set with textures compiled in
+     * serves scenes without any (a glass scene needs the `sss` set): path_on_closest then fetches 16 B per vertex instead of 32. */
+    uint32_t textureUse;
     uint32_t parkMin;            /* while-while scheduling of traverse(): leave the inner-node loop when fewer lanes than this still descend */
     uint32_t stackDepth;         /* entries per lane of the traversal stack held in LDS (= bvh max depth, unless the stack is split) */
     /* split stack (HYBRID kernels, frame-group launches of the higher-occupancy copies on trees too deep for their LDS share):
