@@ -224,6 +224,7 @@ int tb_set_material(tb_context* c, int id, const TbMaterial* in)
         if (c->sceneInLds) HIP_TRY(hipMemcpy((void*)(c->ds.ldsBlob + c->ds.offMaterials + sizeof(TbDevMaterial) * (size_t)id), in, sizeof *in,
             hipMemcpyHostToDevice));
         c->sceneFeatures = sceneFeatureMask(c->scene);
+        c->ds.textureUse = sceneTextureUse(c); /* the edit may be the scene's first texture or normal map */
         c->samplesRendered = 0;
         for (tb_context* p : c->peers) { const int rc = tb_set_material(p, id, in); if (rc != TB_OK) return rc; }
         return TB_OK;

@@ -235,6 +235,7 @@ void ensure(DevBuf& b, size_t bytes);
 /* context_scene.cpp */
 void releaseScene(tb_context* c);
 uint32_t sceneFeatureMask(const HostScene& s);
+uint32_t sceneTextureUse(const tb_context* c);
 uint32_t settingsFeatureMask(const tb_context* c, const tb_output_settings& s, bool aov);
 void ensureCompactNodes(tb_context* c);
 void finalizeScene(tb_context* c, bool build = true); /* build = false: c->scene already holds a built, reordered tree (a peer of a multi-device group) */

@@ -245,6 +245,20 @@ void BuildTlasGpu(tb_context* c, HostScene& s, const std::vector<float>& blasBox
     for (DevBuf* b : {&dO, &dW, &dB, &dH, &dBox, &dScratch, &dA, &dTop, &dWords}) b->release();
 }
 
+/* TbDeviceScene::textureUse of the scene as it stands (finalizeScene, tb_set_material) */
+uint32_t sceneTextureUse(const tb_context* c)
+{
+    auto it = c->options.find("texture_use_hint");
+    if (it != c->options.end() && it->second == 0) return 3u; /* 0: fetch whole vertices whatever the materials say */
+    uint32_t use = 0;
+    for (const TbMaterial& m : c->scene.materials) {
+        if (m.albedoIndex != TB_INVALID_TEXTURE || m.emissiveIndex != TB_INVALID_TEXTURE || m.specularMapIndex != TB_INVALID_TEXTURE ||
+            m.alphaIndex != TB_INVALID_TEXTURE) use |= 1u;
+        if (m.normalMapIndex != TB_INVALID_TEXTURE) use |= 2u;
+    }
+    return use;
+}
+
 void finalizeScene(tb_context* c, bool build)
 {
     HostScene& s = c->scene;
@@ -333,13 +347,7 @@ void finalizeScene(tb_context* c, bool build)
      * walk never holds more than bvhMaxDepth - 1 entries (one spare) */
     d.stackDepth = s.bvhMaxDepth < 2 ? 2 : s.bvhMaxDepth;
     d.alphaTest = opt("alpha_test", 0) ? 1u : 0u;
-    d.textureUse = 0;
-    for (const TbMaterial& m : s.materials) {
-        if (m.albedoIndex != TB_INVALID_TEXTURE || m.emissiveIndex != TB_INVALID_TEXTURE || m.specularMapIndex != TB_INVALID_TEXTURE ||
-            m.alphaIndex != TB_INVALID_TEXTURE) d.textureUse |= 1u;
-        if (m.normalMapIndex != TB_INVALID_TEXTURE) d.textureUse |= 2u;
-    }
-    if (opt("texture_use_hint", 1) == 0) d.textureUse = 3u; /* 0: fetch whole vertices whatever the materials say */
+    d.textureUse = sceneTextureUse(c);
     /* whole-scene LDS image */
     {
         std::vector<uint8_t> blob;
