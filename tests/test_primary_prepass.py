@@ -318,3 +318,28 @@ def test_texture_use_hint_changes_no_bit(gpu_tb, settings, scene):
         assert np.array_equal(bits(b), bits(ref["output"])) and np.array_equal(bits(bj), bits(ref["jittered"]))
     finally:
         gpu_tb.SetOption("texture_use_hint", 1); gpu_tb.SetOption("primary_prepass", 1)
+
+
+@pytest.mark.parametrize("scene", ["proc0_env", "proc1_sss", "cornell_lds"])
+def test_host_camera_constants_change_no_bit(gpu_tb, settings, scene):
+    """TbDeviceTargets::camPre (round 5): what path_begin derives from the launch's camera and frame size alone -- the pinhole, 1 / W, 1 / H, W / H --
+    is computed once on the host with the same tb_vec.h functions and handed to the kernels that fetch their scene from memory.  Option
+    camera_constants = 0 makes every path_begin compute them itself: the same picture, and the oracle's.  (The LDS-resident kernels always compute
+    their own.)"""
+    s = copy.copy(settings); s.MaxBounces = 6
+    W, H, F = 200, 120, 9
+    try:
+        if scene == "proc0_env": gpu_tb.LoadProcedural(0, 30000, 5)
+        elif scene == "proc1_sss": gpu_tb.LoadProcedural(1, 30000, 7)
+        else: gpu_tb.LoadScene(CORNELL)
+        gpu_tb.SetOption("camera_constants", 0)
+        a, aj, _ = _render(gpu_tb, 1, W, H, F, s)
+        a0, a0j, _ = _render(gpu_tb, 0, W, H, F, s)
+        gpu_tb.SetOption("camera_constants", 1)
+        b, bj, _ = _render(gpu_tb, 1, W, H, F, s)
+        b0, b0j, _ = _render(gpu_tb, 0, W, H, F, s)
+        for x, y in ((a, b), (aj, bj), (a0, b0), (a0j, b0j), (a, a0)): assert np.array_equal(bits(x), bits(y))
+        ref = ol.render(gpu_tb.HostSceneView(), gpu_tb.FrameConstants(W, H, 0, s, 0.0), W, H, F, threads=8, jittered=True)
+        assert np.array_equal(bits(b), bits(ref["output"])) and np.array_equal(bits(bj), bits(ref["jittered"]))
+    finally:
+        gpu_tb.SetOption("camera_constants", 1); gpu_tb.SetOption("primary_prepass", 1)

@@ -2,6 +2,7 @@
  * kernels: renderImpl executes the plan launch_plan.h makes (pipeline, copy of the feature set, split stack, pre-pass, batches and frame
  * groups), keeps the two trials no rule could replace (pre-pass, overlapping launches) and dispatches to the other pipelines. */
 #include "context_internal.h"
+#include "tb_vec.h"
 
 namespace tbctx {
 
@@ -324,6 +325,14 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
         tg.rayStats = (unsigned long long*)c->rayStats.p; }
     TbPerFrameConstants pf;
     MakeFrameConstants(c->scene, c->camera, s, c->samplesRendered, timeSeed, c->selX, c->selY, pf);
+    if (opt("camera_constants", 1) != 0) { /* TbDeviceTargets::camPre: path_begin's own expressions (pt_device.hpp), evaluated once */
+        const float resX = (float)W, resY = (float)H;
+        const tb3 camPos = tb3_make(pf.CameraPosition.x, pf.CameraPosition.y, pf.CameraPosition.z);
+        const tb3 lookAt = tb3_make(pf.CameraLookAt.x, pf.CameraLookAt.y, pf.CameraLookAt.z);
+        const tb3 focal = camPos - pf.FocalDistance * tb3_normalize(lookAt - camPos);
+        tg.camFocal[0] = focal.x; tg.camFocal[1] = focal.y; tg.camFocal[2] = focal.z;
+        tg.camInvResX = 1.0f / resX; tg.camInvResY = 1.0f / resY; tg.camAspect = resX / resY; tg.camPre = 1u;
+    }
     uint32_t need = c->sceneFeatures | settingsFeatureMask(c, s, aov);
     if (count || opt("force_full_variant", 0)) need = PT_FEAT_ALL;
     const Variant* v = nullptr;

@@ -848,7 +848,8 @@ TBD void blue_noise(const TbDeviceScene& ds, const TbPerFrameConstants& pf, uint
  * `frame` is PerFrameConstants.GlobalFrameCount of this sample (a lane may be on a different frame
  * than its neighbours in the persistent kernel, so it is not read from pf). */
 template <uint32_t F>
-TBD void path_begin(Path& p, const TbDeviceScene& ds, const TbPerFrameConstants& pf, uint32_t frame, uint32_t W, uint32_t H, uint32_t x, uint32_t y)
+TBD void path_begin(Path& p, const TbDeviceScene& ds, const TbPerFrameConstants& pf, uint32_t frame, uint32_t W, uint32_t H, uint32_t x, uint32_t y,
+                    const TbDeviceTargets* cam = nullptr /* TbDeviceTargets::camPre: the launch's camera constants, from the host */)
 {
     p.flags = 0; p.bounce = 0; p.lastBoxes = p.lastTris = 0; p.nMat = p.nLight = 0;
     p.aovNormal = p.aovAlbedo = p.aovEmissive = p.aovWorldPos = tb3_splat(0.0f); p.aovNeighbor = 0.0f; p.aovDepth = 0.0f;
@@ -859,7 +860,8 @@ TBD void path_begin(Path& p, const TbDeviceScene& ds, const TbPerFrameConstants&
     float pcx = uvx * resX, pcy = uvy * resY;
     float bn[8];
     blue_noise<F>(ds, pf, frame, p.seed, x, y, bn, (F & FEAT_EXT) ? 0xc3u : 0x03u); /* kernel.glsl:1830: the pixel jitter, with FEAT_EXT also the DOF jitter */
-    float psx = 1.0f / resX, psy = 1.0f / resY;
+    const bool pre = cam && cam->camPre;
+    float psx = pre ? cam->camInvResX : 1.0f / resX, psy = pre ? cam->camInvResY : 1.0f / resY;
     float u = pcx * psx, v = pcy * psy;
     float jx = bn[0], jy = bn[1];
     if ((F & FEAT_EXT) && pf.FixedPixelOffset.x >= 0.0f) { jx = pf.FixedPixelOffset.x; jy = pf.FixedPixelOffset.y; }
@@ -877,9 +879,9 @@ TBD void path_begin(Path& p, const TbDeviceScene& ds, const TbPerFrameConstants&
     p.weight = w;
     u += offX * psx * (pixelRadius * 2.0f);
     v += offY * psy * (pixelRadius * 2.0f);
-    float aspect = resX / resY;
+    float aspect = pre ? cam->camAspect : resX / resY;
     tb3 camPos = ld3(pf.CameraPosition);
-    tb3 focal = camPos - pf.FocalDistance * tb3_normalize(ld3(pf.CameraLookAt) - camPos);
+    tb3 focal = pre ? ld3(cam->camFocal) : camPos - pf.FocalDistance * tb3_normalize(ld3(pf.CameraLookAt) - camPos);
     float lensHeight = ds.config.CameraLensHeight;
     tb3 lens = lens_position(pf, lensHeight, u, v, aspect);
     p.ro = focal; p.rd = tb3_normalize(lens - focal);

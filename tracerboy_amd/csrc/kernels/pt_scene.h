@@ -103,6 +103,10 @@ struct TbDeviceTargets {
      * hitStamp is never 0 (a cleared buffer is nobody's record) and changes with every launch; the 16-B piece is written and read whole, so it
      * needs no check word.  A hit whose indices do not fit their fields is stored with stamp 0: its lane walks the camera ray itself. */
     uint32_t hitStamp, hitPrimBits, hitGeomBits;
+    /* What path_begin computes from the launch's camera and frame size alone, computed once on the host with the same functions (tb_vec.h: IEEE
+     * division and square root on both sides, same bits): the pinhole, 1 / W, 1 / H, W / H -- four divisions and a square root of ~250 instructions
+     * that the lock-step kernel ran for the few lanes of a wave that had just finished a path.  camPre = 0: not filled, path_begin computes them. */
+    float camFocal[3], camInvResX, camInvResY, camAspect; uint32_t camPre;
 };
 
 /* Split-role kernel (pipeline 4, pt_split.inc): a workgroup is `travWaves` traversal waves followed by `shadeWaves` shading waves.
