@@ -52,16 +52,33 @@ PIPELINES = ("lockstep", "stream", "wavefront", "pooled", "split")
 
 # key -> the workload.  ONE bvh builder per workload at every N (the driver divides its per-N values, so the
 # tree must not change with N).  "opts" are tb_set_option()s applied before the scene is loaded.
+# Round 5 (scripts/vwvan_builders.py, profiles/r5/builders.json): the host's SAH build with ONE reinsertion pass (option
+# reinsertion_passes; none for the 2.98 M-triangle scene and for Teapot, whose tree is better without) loads in < 5 s and beats the
+# GPU-built LBVH + treelets the legs used before by 4-18 %.
 WORKLOADS = {
     "c2": dict(scene="cornell-box", builder=1, W=1920, H=1080, spp=64, depth=8),       # BASELINE configs[1], the headline
-    "c3": dict(scene="proc0:870000", builder=1, W=1920, H=1080, spp=128, depth=6),     # configs[2] class: 870 k triangles
-    "c4": dict(scene="proc1:700000", builder=4, W=3840, H=2160, spp=8, depth=6),       # configs[3] class: glass, 4K, 8 of 256 spp
-    "c5": dict(scene="proc2:2980000", builder=4, W=3840, H=2160, spp=8, depth=16),     # configs[4] class: 2.98 M tris, 40 materials
-    "teapot": dict(scene=TEAPOT, builder=1, W=1920, H=1080, spp=16, depth=8),          # the reference's Teapot: textures + env + GGX
+    # configs[2] class: 870 k triangles
+    "c3": dict(scene="proc0:870000", builder=1, W=1920, H=1080, spp=128, depth=6, opts={"reinsertion_passes": 1}),
+    # configs[3] class: glass, 4K, 8 of 256 spp
+    "c4": dict(scene="proc1:700000", builder=1, W=3840, H=2160, spp=8, depth=6, opts={"reinsertion_passes": 1}),
+    # configs[4] class: 2.98 M tris, 40 materials
+    "c5": dict(scene="proc2:2980000", builder=1, W=3840, H=2160, spp=8, depth=16, opts={"reinsertion_passes": 0}),
+    # the reference's Teapot: textures + env + GGX
+    "teapot": dict(scene=TEAPOT, builder=1, W=1920, H=1080, spp=16, depth=8, opts={"reinsertion_passes": 0}),
     # the reference's own configs[3] scene (Scenes/vw-van minus the absent body shell, tests/golden/make_vw_van_fixture.py)
-    "vwvan": dict(scene=VWVAN, builder=4, W=3840, H=2160, spp=8, depth=6, opts={"flatten_instances": 1}),
-    "vwvan_2level": dict(scene=VWVAN, builder=4, W=3840, H=2160, spp=8, depth=6, opts={"flatten_instances": 0}),
+    "vwvan": dict(scene=VWVAN, builder=1, W=3840, H=2160, spp=8, depth=6, opts={"flatten_instances": 1, "reinsertion_passes": 1}),
+    "vwvan_2level": dict(scene=VWVAN, builder=1, W=3840, H=2160, spp=8, depth=6, opts={"flatten_instances": 0, "reinsertion_passes": 1}),
 }
+
+
+def builder_label(w):
+    """config.bvh_builder of a workload: the builder and, for the SAH build, its reinsertion passes when the workload sets them"""
+    passes = (w.get("opts") or {}).get("reinsertion_passes")
+    if passes is None or w["builder"] != 1:
+        return BUILDERS[w["builder"]]
+    return "%s+%d reinsertion pass%s" % (BUILDERS[w["builder"]], passes, "" if passes == 1 else "es")
+
+
 EXTRA_LEGS = ("c3", "c4", "c5", "teapot", "vwvan", "vwvan_2level")    # N = 1: roofline_<leg>
 SCALE_LEGS = ("c4", "c5", "vwvan")                                    # N > 1: scale_<leg>
 
@@ -423,6 +440,7 @@ class Bench:
         """Returns the seconds the load took (host parse / generation + BVH build + upload)."""
         tb = self.tb
         tb.SetOption("bvh_builder", builder)
+        tb.SetOption("reinsertion_passes", -1)     # the library's own choice unless the workload says otherwise (options outlive a load)
         for k, v in (opts or {}).items():
             tb.SetOption(k, v)
         t0 = time.time()
@@ -658,7 +676,7 @@ def extra_leg(b, np, torch, key, steps):
               "data": data_label(w["scene"]), "triangles": int(info.numTriangles),
               "value": round(W * H * SPP * steps / dt / 1e6, 1), "unit_value": "Msamples/s",
               "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps, "scene_load_s": round(load_s, 2),
-              "bvh_builder": BUILDERS[w["builder"]], "kernel_variant": variant, "primary_prepass": prepass,
+              "bvh_builder": builder_label(w), "kernel_variant": variant, "primary_prepass": prepass,
               "launches_overlap": overlapped, "kernel": "pt_primary + pt_persistent" if prepass else "pt_persistent",
               "frac_note": "SURVEY 8d byte model x samples / launch time / 8 TB/s: traversal throughput in the reference's "
                            "units; the bytes are served mostly by L2 / Infinity Cache (traffic_GBs is what the fabric carries)"})
@@ -827,7 +845,7 @@ def scale_leg(b, np, torch, dist, tiles, key, rank, world, backend, steps, barri
     r = {"workload": "%s %dx%d %dspp depth%d" % (scene_label(w["scene"]), W, H, SPP, D), "data": data_label(w["scene"]),
          "triangles": int(info.numTriangles), "value": round(W * H * SPP * steps / elapsed / 1e6, 1), "unit": "Msamples/s",
          "ms_per_step": round(elapsed / steps * 1e3, 3), "steps": steps, "n_gpus": world, "scaling": "strong",
-         "parallelism": "tiles%d" % world, "tile": TILE, "bvh_builder": BUILDERS[w["builder"]],
+         "parallelism": "tiles%d" % world, "tile": TILE, "bvh_builder": builder_label(w),
          "kernel_variant": VARIANTS[tb.GetOption("last_variant")], "primary_prepass": bool(tb.GetOption("last_primary_prepass")),
          "launches_overlap": bool(tb.GetOption("last_overlap")), "scene_load_s": round(load_max, 2),
          "scene_load_s_note": "max over ranks (every rank loads and builds the scene itself)"}

@@ -813,6 +813,8 @@ def test_bench_multi_rank_step_on_one_gpu(tmp_path):
     frame rank 0 assembled equals a single-GPU render of the whole frame, bit for bit."""
     import json, subprocess, sys
     from conftest import ROOT
+    sys.path.insert(0, ROOT)
+    import bench as bench_mod
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(TB_BENCH_SHARE_DEVICE="1", TB_BENCH_BACKEND="gloo")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--width", "712", "--height", "400", "--spp", "6",
@@ -843,7 +845,7 @@ def test_bench_multi_rank_step_on_one_gpu(tmp_path):
         assert sl["assembled_frame_equals_single_gpu"] is True, leg
         sbl = sl["scale_breakdown"]
         assert all(sbl[k] > 0 for k in ("render_ms", "pack_ms", "gather_ms", "unpack_ms")) and sbl["render_max_over_mean"] >= 1.0
-        assert sl["bvh_builder"] == "lbvh+treelets-gpu"          # the same tree as the N = 1 line's roofline_<leg>
+        assert sl["bvh_builder"] == bench_mod.builder_label(bench_mod.WORKLOADS[leg])   # the same tree as the N = 1 line's roofline_<leg>
     assert out["scale_vwvan"]["kernel_variant"] == "vol" and out["scale_c4"]["kernel_variant"] == "sss"
 
 

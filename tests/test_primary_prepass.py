@@ -343,3 +343,27 @@ def test_host_camera_constants_change_no_bit(gpu_tb, settings, scene):
         assert np.array_equal(bits(b), bits(ref["output"])) and np.array_equal(bits(bj), bits(ref["jittered"]))
     finally:
         gpu_tb.SetOption("camera_constants", 1); gpu_tb.SetOption("primary_prepass", 1)
+
+
+def test_reinsertion_passes_option_changes_the_tree_not_the_picture(gpu_tb, settings):
+    """Option reinsertion_passes (round 5): how many insertion-based optimisation passes follow builder 1's top-down SAH build (-1: by size).  bench.py's
+    legs use 0 or 1 (load time under 5 s).  A different tree tests different boxes; the picture is the oracle's on each tree, and -- the closest hit of a
+    ray not depending on the tree -- the same on both."""
+    s = copy.copy(settings); s.MaxBounces = 5
+    W, H, F = 160, 96, 5
+    pics, boxes = [], []
+    try:
+        gpu_tb.SetOption("bvh_builder", 1)
+        for passes in (0, 2):
+            gpu_tb.SetOption("reinsertion_passes", passes)
+            gpu_tb.LoadProcedural(0, 20000, 11)
+            out, jit, _ = _render(gpu_tb, 1, W, H, F, s)
+            ref = ol.render(gpu_tb.HostSceneView(), gpu_tb.FrameConstants(W, H, 0, s, 0.0), W, H, F, threads=8, jittered=True)
+            assert np.array_equal(bits(out), bits(ref["output"])) and np.array_equal(bits(jit), bits(ref["jittered"]))
+            gpu_tb.SetOption("count_rays", 1); gpu_tb.InvalidateHistory(); gpu_tb.Render(W, H, 1, s, 0.0)
+            boxes.append(int(gpu_tb.ReadbackStats().rays.boxesTested)); gpu_tb.SetOption("count_rays", 0)
+            pics.append(out)
+        assert boxes[0] != boxes[1]
+        assert np.array_equal(bits(pics[0]), bits(pics[1]))
+    finally:
+        gpu_tb.SetOption("reinsertion_passes", -1); gpu_tb.SetOption("count_rays", 0); gpu_tb.SetOption("bvh_builder", 0); gpu_tb.SetOption("primary_prepass", 1)

@@ -368,7 +368,7 @@ void BuildBvhSingle(HostScene& s, int builder)
     if (builder == 1) {
         buildSah(s, t);
         const char* cap = getenv("TB_REINSERT_PASSES"); /* experiments: 0 turns the passes off */
-        const int passes = cap ? atoi(cap) : (N <= 4096 ? 16 : 3);
+        const int passes = cap ? atoi(cap) : s.reinsertionPasses >= 0 ? s.reinsertionPasses : (N <= 4096 ? 16 : 3);
         if (passes > 0) optimizeByReinsertion(s, t, passes, N <= 4096 ? 1e-6 : 5e-3);
     } else {
         buildLbvh(s, t);
@@ -571,6 +571,7 @@ void BuildBvhWith(HostScene& s, const std::function<void(HostScene&)>& single, c
     for (size_t b = 0; b < s.blas.size(); b++) {
         HostScene::Blas& bl = s.blas[b];
         HostScene tmp;
+        tmp.reinsertionPasses = s.reinsertionPasses;
         tmp.positions.swap(s.positions);
         tmp.triVertexIndex.assign(s.triVertexIndex.begin() + 3ull * bl.firstTri, s.triVertexIndex.begin() + 3ull * (bl.firstTri + bl.numTris));
         tmp.triGeometry.assign(s.triGeometry.begin() + bl.firstTri, s.triGeometry.begin() + bl.firstTri + bl.numTris);

@@ -44,6 +44,10 @@ struct HostScene {
     std::vector<TbTriB> trisB;
     uint32_t rootRefB = 0;   /* child-ref encoding of the root (leaf bit set when N == 1) */
     uint32_t bvhMaxDepth = 0;
+    /* builder 1 (SAH): reinsertion passes after the top-down build; -1 = by size (16 up to 4 096 triangles, 3 above).  Option "reinsertion_passes":
+     * on a 700 k-triangle scene the top-down build is ~1 s and every pass ~2.5 s of load time; one pass brings most of what three do
+     * (the reference's vw-van at 4K: 62.6 box tests per sample with the GPU-built LBVH + treelets, 58.5 / 54.6 / 54.0 with 0 / 1 / 3 passes) */
+    int reinsertionPasses = -1;
 };
 
 struct ConvertOptions {
