@@ -7,9 +7,10 @@ import bench  # noqa: E402
 from tracerboy_amd import api  # noqa: E402
 b = bench.Bench(api, 0); tb = b.tb
 for key in sys.argv[1:]:
-    w = bench.WORKLOADS[key]; b.load_workload(key)
-    for kv in os.environ.get("TB_OPTS", "").split(","):   # e.g. TB_OPTS=chain_main_kernels=1,overlap_launches=2
+    w = bench.WORKLOADS[key]
+    for kv in os.environ.get("TB_OPTS", "").split(","):   # e.g. TB_OPTS=node_order=1,overlap_launches=2 (set before the load: some act there)
         if kv: tb.SetOption(kv.split("=")[0], int(kv.split("=")[1]))
+    b.load_workload(key)
     s = b.settings(w["depth"]); W, H, F = w["W"], w["H"], w["spp"]
     for _ in range(2): tb.InvalidateHistory(); tb.Render(W, H, F, s, 0.0)
     t = time.perf_counter()
