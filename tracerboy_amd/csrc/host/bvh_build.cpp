@@ -25,6 +25,7 @@
 #include <cstdlib>
 #include <stdexcept>
 #include <thread>
+#include <mutex>
 
 namespace tbhost {
 
@@ -117,73 +118,103 @@ inline void grow(Bounds& b, tb3 p) { b.mn = tb3_min(b.mn, p); b.mx = tb3_max(b.m
 inline void grow(Bounds& b, const Bounds& o) { b.mn = tb3_min(b.mn, o.mn); b.mx = tb3_max(b.mx, o.mx); }
 inline float area(const Bounds& b) { tb3 d = b.mx - b.mn; if (d.x < 0 || d.y < 0 || d.z < 0) return 0.0f; return 2.0f * (d.x * d.y + d.y * d.z + d.z * d.x); }
 
+/* Top-down binned SAH (32 bins per axis, one triangle per leaf; median split along the widest axis where no bin boundary separates the
+ * centroids).  Numbering: inner nodes in preorder (a subtree over c triangles holds c - 1 of them, so the left child of inner node i is i + 1 and
+ * the right child i + [triangles on the left]), leaf k = the k-th triangle of the final left-to-right order -- both follow from a range's place
+ * alone, so subtrees are built by several threads (the large nodes at the top bin their triangles in parallel first) and the tree is the one a
+ * single depth-first thread numbers (scripts/tree_digest.py).  min / max are exact and order-free (tb_math.h), the counts are integers. */
 void buildSah(const HostScene& s, Tree& t)
 {
     const uint32_t N = t.N;
     std::vector<Bounds> tb(N); std::vector<tb3> cen(N);
-    for (uint32_t i = 0; i < N; i++) { Bounds b = emptyB(); for (int k = 0; k < 3; k++) grow(b, P(s, i, k)); tb[i] = b; cen[i] = (b.mn + b.mx) * 0.5f; }
+    parallelFor(N, [&](size_t a, size_t z) { for (size_t i = a; i < z; i++) { Bounds b = emptyB(); for (int k = 0; k < 3; k++) grow(b, P(s, (uint32_t)i, k));
+        tb[i] = b; cen[i] = (b.mn + b.mx) * 0.5f; } });
     std::vector<uint32_t> ids(N); for (uint32_t i = 0; i < N; i++) ids[i] = i;
-    t.order.clear(); t.order.reserve(N);
     if (N >= 2) { t.left.assign(N - 1, 0); t.right.assign(N - 1, 0); }
-    struct Job { uint32_t begin, end, node; };
-    std::vector<Job> stack;
-    /* inner nodes are numbered in the order they are created; leaves take their number from the
-     * position of their triangle in the final left-to-right order, which a depth-first emission gives */
-    uint32_t nextInner = 0;
-    struct Pending { uint32_t begin, end; uint32_t parent; int side; };
-    std::vector<Pending> todo; todo.push_back({0, N, 0xffffffffu, 0});
-    std::vector<uint32_t> leafOfRange; /* unused */
-    /* depth-first, left before right, so that leaf numbers increase left to right */
-    while (!todo.empty()) {
-        Pending p = todo.back(); todo.pop_back();
-        uint32_t count = p.end - p.begin, me;
-        if (count == 1) {
-            me = (N - 1) + (uint32_t)t.order.size();
-            t.order.push_back(ids[p.begin]);
-        } else {
-            me = nextInner++;
-            Bounds cb = emptyB(); for (uint32_t i = p.begin; i < p.end; i++) grow(cb, cen[ids[i]]);
-            tb3 ext = cb.mx - cb.mn;
-            int axis = (ext.x >= ext.y && ext.x >= ext.z) ? 0 : (ext.y >= ext.z ? 1 : 2);
-            uint32_t mid = p.begin + count / 2;
-            float e = tb3_get(ext, axis);
-            bool split = false;
-            if (e > 0.0f && count > 2) {
-                const int B = 32; Bounds bb[B]; uint32_t bc[B];
-                float bestCost = 3.402823466e+38f; int bestAxis = -1, bestBin = -1;
-                for (int ax = 0; ax < 3; ax++) {
-                    float ea = tb3_get(ext, ax); if (!(ea > 0.0f)) continue;
-                    for (int i = 0; i < B; i++) { bb[i] = emptyB(); bc[i] = 0; }
-                    float k0 = tb3_get(cb.mn, ax), k1 = (float)B * (1.0f - 1e-6f) / ea;
-                    for (uint32_t i = p.begin; i < p.end; i++) { int b = (int)((tb3_get(cen[ids[i]], ax) - k0) * k1); b = b < 0 ? 0 : (b >= B ? B - 1 : b);
-                        grow(bb[b], tb[ids[i]]); bc[b]++; }
-                    float ra[B]; Bounds acc = emptyB(); uint32_t rc[B]; uint32_t c = 0;
-                    for (int i = B - 1; i > 0; i--) { grow(acc, bb[i]); c += bc[i]; ra[i] = area(acc); rc[i] = c; }
-                    acc = emptyB(); c = 0;
-                    for (int i = 0; i < B - 1; i++) { grow(acc, bb[i]); c += bc[i]; if (c == 0 || rc[i + 1] == 0) continue;
-                        float cost = area(acc) * (float)c + ra[i + 1] * (float)rc[i + 1]; if (cost < bestCost) { bestCost = cost; bestAxis = ax; bestBin = i;
-                        } }
-                }
-                if (bestAxis >= 0) {
-                    float ea = tb3_get(ext, bestAxis), k0 = tb3_get(cb.mn, bestAxis), k1 = (float)B * (1.0f - 1e-6f) / ea;
-                    auto it = std::stable_partition(ids.begin() + p.begin, ids.begin() + p.end, [&](uint32_t id) { int b = (int)((tb3_get(cen[id],
-                        bestAxis) - k0) * k1); b = b < 0 ? 0 : (b >= B ? B - 1 : b); return b <= bestBin; });
-                    mid = (uint32_t)(it - ids.begin());
-                    split = mid > p.begin && mid < p.end;
-                }
+    constexpr int B = 32;
+    struct Bins { Bounds bb[3][B]; uint32_t bc[3][B]; Bounds cb; };
+    constexpr uint32_t WIDE = 1u << 17; /* ranges from here up are scanned by several threads */
+    /* where [begin, end) is cut; reorders ids inside the range */
+    auto split = [&](uint32_t begin, uint32_t end) -> uint32_t {
+        const uint32_t count = end - begin;
+        Bounds cb = emptyB();
+        if (count >= WIDE) {
+            std::mutex m;
+            parallelFor(count, [&](size_t a, size_t z) { Bounds l = emptyB(); for (size_t i = a; i < z; i++) grow(l, cen[ids[begin + i]]);
+                std::lock_guard<std::mutex> g(m); grow(cb, l); });
+        } else for (uint32_t i = begin; i < end; i++) grow(cb, cen[ids[i]]);
+        const tb3 ext = cb.mx - cb.mn;
+        const int axis = (ext.x >= ext.y && ext.x >= ext.z) ? 0 : (ext.y >= ext.z ? 1 : 2);
+        uint32_t mid = begin + count / 2;
+        const float e = tb3_get(ext, axis);
+        bool cut = false;
+        if (e > 0.0f && count > 2) {
+            float k0[3], k1[3]; bool use[3];
+            for (int ax = 0; ax < 3; ax++) { const float ea = tb3_get(ext, ax); use[ax] = ea > 0.0f; k0[ax] = tb3_get(cb.mn, ax);
+                k1[ax] = use[ax] ? (float)B * (1.0f - 1e-6f) / ea : 0.0f; }
+            auto binOf = [&](uint32_t id, int ax) { int b = (int)((tb3_get(cen[id], ax) - k0[ax]) * k1[ax]); return b < 0 ? 0 : (b >= B ? B - 1 : b); };
+            Bounds bb[3][B]; uint32_t bc[3][B];
+            for (int ax = 0; ax < 3; ax++) for (int i = 0; i < B; i++) { bb[ax][i] = emptyB(); bc[ax][i] = 0; }
+            auto scan = [&](size_t a, size_t z, Bounds (*lb)[B], uint32_t (*lc)[B]) {
+                for (size_t i = a; i < z; i++) { const uint32_t id = ids[begin + i];
+                    for (int ax = 0; ax < 3; ax++) if (use[ax]) { const int b = binOf(id, ax); grow(lb[ax][b], tb[id]); lc[ax][b]++; } } };
+            if (count >= WIDE) {
+                std::mutex m;
+                parallelFor(count, [&](size_t a, size_t z) {
+                    std::vector<Bounds> lbv(3 * B, emptyB()); std::vector<uint32_t> lcv(3 * B, 0);
+                    scan(a, z, (Bounds(*)[B])lbv.data(), (uint32_t(*)[B])lcv.data());
+                    std::lock_guard<std::mutex> g(m);
+                    for (int ax = 0; ax < 3; ax++) for (int i = 0; i < B; i++) { grow(bb[ax][i], lbv[ax * B + i]); bc[ax][i] += lcv[ax * B + i]; } });
+            } else scan(0, count, bb, bc);
+            float bestCost = 3.402823466e+38f; int bestAxis = -1, bestBin = -1;
+            for (int ax = 0; ax < 3; ax++) {
+                if (!use[ax]) continue;
+                float ra[B]; Bounds acc = emptyB(); uint32_t rc[B]; uint32_t c = 0;
+                for (int i = B - 1; i > 0; i--) { grow(acc, bb[ax][i]); c += bc[ax][i]; ra[i] = area(acc); rc[i] = c; }
+                acc = emptyB(); c = 0;
+                for (int i = 0; i < B - 1; i++) { grow(acc, bb[ax][i]); c += bc[ax][i]; if (c == 0 || rc[i + 1] == 0) continue;
+                    const float cost = area(acc) * (float)c + ra[i + 1] * (float)rc[i + 1]; if (cost < bestCost) { bestCost = cost; bestAxis = ax; bestBin = i; } }
             }
-            if (!split) { /* median along the widest axis (also the fallback for coincident centroids) */
-                mid = p.begin + count / 2;
-                std::stable_sort(ids.begin() + p.begin, ids.begin() + p.end, [&](uint32_t a, uint32_t b) { return tb3_get(cen[a], axis) < tb3_get(cen[b],
-                    axis); });
+            if (bestAxis >= 0) {
+                auto it = std::stable_partition(ids.begin() + begin, ids.begin() + end, [&](uint32_t id) { return binOf(id, bestAxis) <= bestBin; });
+                mid = (uint32_t)(it - ids.begin());
+                cut = mid > begin && mid < end;
             }
-            /* push right first so the left subtree is emitted first */
-            todo.push_back({mid, p.end, me, 1});
-            todo.push_back({p.begin, mid, me, 0});
         }
-        if (p.parent != 0xffffffffu) { if (p.side == 0) t.left[p.parent] = me; else t.right[p.parent] = me; }
+        if (!cut) { /* median along the widest axis (also the fallback for coincident centroids) */
+            mid = begin + count / 2;
+            std::stable_sort(ids.begin() + begin, ids.begin() + end, [&](uint32_t a, uint32_t b) { return tb3_get(cen[a], axis) < tb3_get(cen[b], axis); });
+        }
+        return mid;
+    };
+    struct Job { uint32_t begin, end, id; }; /* an inner node: its triangles and its number */
+    auto expand = [&](const Job& j, std::vector<Job>& out) {
+        const uint32_t mid = split(j.begin, j.end), nl = mid - j.begin, nr = j.end - mid;
+        const uint32_t l = nl == 1 ? (N - 1) + j.begin : j.id + 1, r = nr == 1 ? (N - 1) + mid : j.id + nl;
+        t.left[j.id] = l; t.right[j.id] = r;
+        if (nr > 1) out.push_back(Job{mid, j.end, r});
+        if (nl > 1) out.push_back(Job{j.begin, mid, l});
+    };
+    if (N >= 2) {
+        /* the top of the tree, largest range first, until there is work for every thread; then one depth-first walk per remaining subtree */
+        std::vector<Job> open; open.push_back(Job{0, N, 0});
+        unsigned hw = std::thread::hardware_concurrency(); if (hw == 0) hw = 1;
+        const size_t threads = N < 65536 ? 1 : std::min<size_t>(hw, 16);
+        while (threads > 1 && open.size() < 8 * threads) {
+            size_t big = 0; for (size_t i = 1; i < open.size(); i++) if (open[i].end - open[i].begin > open[big].end - open[big].begin) big = i;
+            if (open[big].end - open[big].begin < 4096) break;
+            const Job j = open[big]; open.erase(open.begin() + big);
+            expand(j, open);
+        }
+        std::sort(open.begin(), open.end(), [](const Job& a, const Job& b) { return a.end - a.begin > b.end - b.begin; });
+        std::atomic<size_t> next{0};
+        auto worker = [&]() { std::vector<Job> stack;
+            for (size_t k = next++; k < open.size(); k = next++) { stack.clear(); stack.push_back(open[k]);
+                while (!stack.empty()) { const Job j = stack.back(); stack.pop_back(); expand(j, stack); } } };
+        if (threads == 1) worker();
+        else { std::vector<std::thread> th; for (size_t i = 0; i < threads; i++) th.emplace_back(worker); for (auto& x : th) x.join(); }
     }
-    (void)stack; (void)leafOfRange;
+    t.order = ids; /* leaf k is the k-th triangle from the left */
 }
 
 /* ---- reinsertion passes (after Bittner, Hapala & Havran, "Fast insertion-based optimization of bounding volume
