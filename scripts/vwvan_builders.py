@@ -29,6 +29,7 @@ for builder in [int(x) for x in a.builders.split(",")]:
                                    "boxes_per_sample": round(st.boxesTested / n, 2), "tris_per_sample": round(st.trianglesTested / n, 2),
                                    "rays_per_sample": round(st.rays / n, 3), "stack_overflow_entries": int(tb.GetOption("last_plan_stack_overflow")),
                                    "kernel_variant": variant, "prepass": prepass,
-                                   "reinsertion_passes": os.environ.get("TB_REINSERT_PASSES", "3 (default)") if builder == 1 else None}
+                                   "reinsertion_passes": os.environ.get("TB_REINSERT_PASSES", "3 (default)") if builder == 1 else None,
+                                   "reinsertion_share": os.environ.get("TB_REINSERT_SHARE", "100") if builder == 1 else None}
     print("builder", builder, rows["builder%d" % builder], flush=True)
     if a.out: json.dump({"workload": a.workload, "rows": rows}, open(a.out, "w"), indent=1)

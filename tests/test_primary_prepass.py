@@ -355,7 +355,7 @@ def test_reinsertion_passes_option_changes_the_tree_not_the_picture(gpu_tb, sett
     try:
         gpu_tb.SetOption("bvh_builder", 1)
         for passes in (0, 2):
-            gpu_tb.SetOption("reinsertion_passes", passes)
+            gpu_tb.SetOption("reinsertion_passes", passes); gpu_tb.SetOption("reinsertion_share", 100 if passes == 0 else 10)   # (the largest 10 % of the subtrees)
             gpu_tb.LoadProcedural(0, 20000, 11)
             out, jit, _ = _render(gpu_tb, 1, W, H, F, s)
             ref = ol.render(gpu_tb.HostSceneView(), gpu_tb.FrameConstants(W, H, 0, s, 0.0), W, H, F, threads=8, jittered=True)
@@ -366,4 +366,5 @@ def test_reinsertion_passes_option_changes_the_tree_not_the_picture(gpu_tb, sett
         assert boxes[0] != boxes[1]
         assert np.array_equal(bits(pics[0]), bits(pics[1]))
     finally:
-        gpu_tb.SetOption("reinsertion_passes", -1); gpu_tb.SetOption("count_rays", 0); gpu_tb.SetOption("bvh_builder", 0); gpu_tb.SetOption("primary_prepass", 1)
+        gpu_tb.SetOption("reinsertion_passes", -1); gpu_tb.SetOption("reinsertion_share", 100); gpu_tb.SetOption("count_rays", 0); gpu_tb.SetOption("bvh_builder", 0)
+        gpu_tb.SetOption("primary_prepass", 1)

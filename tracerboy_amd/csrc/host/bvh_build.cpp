@@ -259,7 +259,12 @@ void optimizeByReinsertion(const HostScene& s, Tree& t, int maxPasses, double mi
     for (int pass = 0; pass < maxPasses; pass++) {
         for (uint32_t x = 1; x < M; x++) cand[x - 1] = x;
         std::stable_sort(cand.begin(), cand.end(), [&](uint32_t a, uint32_t b) { return sa[a] > sa[b]; });
+        /* only the largest <share> percent of the subtrees (HostScene::reinsertionShare; TB_REINSERT_SHARE overrides it for experiments) */
+        size_t tried = 0; const char* shareEnv = getenv("TB_REINSERT_SHARE");
+        const double share = shareEnv ? atof(shareEnv) : (double)s.reinsertionShare;
+        const size_t limit = share >= 100.0 ? cand.size() : (size_t)((double)cand.size() * std::max(share, 0.0) / 100.0);
         for (uint32_t x : cand) {
+            if (tried++ >= limit) break;
             const uint32_t p = parent[x]; if (p == NONE || p == 0) continue; /* children of the root stay: node 0 remains the root */
             const uint32_t g = parent[p], sib = t.left[p] == x ? t.right[p] : t.left[p];
             /* cut: the sibling takes the parent's place, the parent node p is kept to become the new junction */
@@ -293,6 +298,7 @@ void optimizeByReinsertion(const HostScene& s, Tree& t, int maxPasses, double mi
             refit(p);
         }
         const double now = totalCost();
+        if (getenv("TB_REINSERT_VERBOSE")) fprintf(stderr, "reinsertion pass %d: SAH cost %.6g -> %.6g\n", pass, cost, now);
         const bool goOn = now < cost * (1.0 - minGain);
         cost = now;
         if (!goOn) break;
@@ -602,7 +608,7 @@ void BuildBvhWith(HostScene& s, const std::function<void(HostScene&)>& single, c
     for (size_t b = 0; b < s.blas.size(); b++) {
         HostScene::Blas& bl = s.blas[b];
         HostScene tmp;
-        tmp.reinsertionPasses = s.reinsertionPasses;
+        tmp.reinsertionPasses = s.reinsertionPasses; tmp.reinsertionShare = s.reinsertionShare;
         tmp.positions.swap(s.positions);
         tmp.triVertexIndex.assign(s.triVertexIndex.begin() + 3ull * bl.firstTri, s.triVertexIndex.begin() + 3ull * (bl.firstTri + bl.numTris));
         tmp.triGeometry.assign(s.triGeometry.begin() + bl.firstTri, s.triGeometry.begin() + bl.firstTri + bl.numTris);

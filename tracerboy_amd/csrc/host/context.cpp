@@ -635,7 +635,7 @@ int tb_unpack_gathered_host(uint32_t W, uint32_t H, uint32_t world, uint32_t tw,
 int tb_set_option(tb_context* c, const char* name, int64_t v)
 {
     if (!c || !name) return TB_E_INVALID;
-    static const char* known[] = {"reinsertion_passes", "camera_constants", "texture_use_hint", "compact_hits", "first_bounce", "primary_prepass", "pipeline", "count_rays", "bvh_builder", "flatten_instances", "aov", "scene_in_lds", "lds_scene_budget",
+    static const char* known[] = {"reinsertion_share", "reinsertion_passes", "camera_constants", "texture_use_hint", "compact_hits", "first_bounce", "primary_prepass", "pipeline", "count_rays", "bvh_builder", "flatten_instances", "aov", "scene_in_lds", "lds_scene_budget",
         "force_full_variant", "wavefront_paths", "wavefront_grid", "wavefront_segment", "pooled_paths", "pooled_samples", "pooled_profile", "park_min",
         "alpha_test", "node_order", "node_order_top_levels", "frame_group", "overlap_launches", "high_occupancy", "stack_lds_cap", "stack_overflow_max",
         "flip_texture_uvs", "wavefront_sort", "banded_items", "node_layout", "wavefront_refill",

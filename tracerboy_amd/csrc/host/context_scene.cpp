@@ -279,7 +279,7 @@ void finalizeScene(tb_context* c, bool build)
     auto opt = [&](const char* k, int64_t d) { auto it = c->options.find(k); return it == c->options.end() ? d : it->second; };
     const int64_t builder = opt("bvh_builder", 0);
     const bool twoLevel = !s.instances.empty();
-    s.reinsertionPasses = (int)opt("reinsertion_passes", -1);
+    s.reinsertionPasses = (int)opt("reinsertion_passes", -1); s.reinsertionShare = (int)opt("reinsertion_share", 100);
     if (build) {
     /* every bottom-level structure and the top level on the GPU (GpuBVH2Builder.cpp:498-501: the same passes, no treelets at the top) */
     if (twoLevel && (builder == 2 || builder == 4))

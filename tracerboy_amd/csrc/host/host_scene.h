@@ -48,6 +48,11 @@ struct HostScene {
      * on a 700 k-triangle scene the top-down build is ~1 s and every pass ~2.5 s of load time; one pass brings most of what three do
      * (the reference's vw-van at 4K: 62.6 box tests per sample with the GPU-built LBVH + treelets, 58.5 / 54.6 / 54.0 with 0 / 1 / 3 passes) */
     int reinsertionPasses = -1;
+    /* ... and how much of the tree a pass takes up again: the largest <share> percent of the subtrees (by surface area), 100 = all.  Option
+     * "reinsertion_share".  Measured on the 700 k-triangle van-class scene (SAH cost = sum of the inner nodes' areas, 18 533 after the top-down build):
+     * one pass over everything 14 521 in 7.8 s, three 14 330 in 16 s; three passes over the largest 2 % 13 939 in under a second -- moving the small
+     * subtrees first costs the large ones their better places. */
+    int reinsertionShare = 100;
 };
 
 struct ConvertOptions {
