@@ -52,22 +52,23 @@ PIPELINES = ("lockstep", "stream", "wavefront", "pooled", "split")
 
 # key -> the workload.  ONE bvh builder per workload at every N (the driver divides its per-N values, so the
 # tree must not change with N).  "opts" are tb_set_option()s applied before the scene is loaded.
-# Round 5 (scripts/vwvan_builders.py, profiles/r5/builders.json): the host's SAH build with ONE reinsertion pass (option
-# reinsertion_passes; none for the 2.98 M-triangle scene and for Teapot, whose tree is better without) loads in < 5 s and beats the
-# GPU-built LBVH + treelets the legs used before by 4-18 %.
+# Round 5 (scripts/vwvan_builders.py, profiles/r5/builders.json): the host's SAH build with three reinsertion passes over the largest 3 %
+# of the subtrees (options reinsertion_passes / reinsertion_share; one such pass for the 2.98 M-triangle scene, none for Teapot, whose
+# tree is better without) loads in 1-3.5 s and beats the GPU-built LBVH + treelets the legs used before by 4-19 %.
+SAH3 = {"reinsertion_passes": 3, "reinsertion_share": 3}   # three reinsertion passes over the largest 3 % of the subtrees
 WORKLOADS = {
     "c2": dict(scene="cornell-box", builder=1, W=1920, H=1080, spp=64, depth=8),       # BASELINE configs[1], the headline
     # configs[2] class: 870 k triangles
-    "c3": dict(scene="proc0:870000", builder=1, W=1920, H=1080, spp=128, depth=6, opts={"reinsertion_passes": 1}),
+    "c3": dict(scene="proc0:870000", builder=1, W=1920, H=1080, spp=128, depth=6, opts=dict(SAH3)),
     # configs[3] class: glass, 4K, 8 of 256 spp
-    "c4": dict(scene="proc1:700000", builder=1, W=3840, H=2160, spp=8, depth=6, opts={"reinsertion_passes": 1}),
+    "c4": dict(scene="proc1:700000", builder=1, W=3840, H=2160, spp=8, depth=6, opts=dict(SAH3)),
     # configs[4] class: 2.98 M tris, 40 materials
-    "c5": dict(scene="proc2:2980000", builder=1, W=3840, H=2160, spp=8, depth=16, opts={"reinsertion_passes": 0}),
+    "c5": dict(scene="proc2:2980000", builder=1, W=3840, H=2160, spp=8, depth=16, opts={"reinsertion_passes": 1, "reinsertion_share": 3}),
     # the reference's Teapot: textures + env + GGX
     "teapot": dict(scene=TEAPOT, builder=1, W=1920, H=1080, spp=16, depth=8, opts={"reinsertion_passes": 0}),
     # the reference's own configs[3] scene (Scenes/vw-van minus the absent body shell, tests/golden/make_vw_van_fixture.py)
-    "vwvan": dict(scene=VWVAN, builder=1, W=3840, H=2160, spp=8, depth=6, opts={"flatten_instances": 1, "reinsertion_passes": 1}),
-    "vwvan_2level": dict(scene=VWVAN, builder=1, W=3840, H=2160, spp=8, depth=6, opts={"flatten_instances": 0, "reinsertion_passes": 1}),
+    "vwvan": dict(scene=VWVAN, builder=1, W=3840, H=2160, spp=8, depth=6, opts=dict(SAH3, flatten_instances=1)),
+    "vwvan_2level": dict(scene=VWVAN, builder=1, W=3840, H=2160, spp=8, depth=6, opts=dict(SAH3, flatten_instances=0)),
 }
 
 
@@ -76,7 +77,8 @@ def builder_label(w):
     passes = (w.get("opts") or {}).get("reinsertion_passes")
     if passes is None or w["builder"] != 1:
         return BUILDERS[w["builder"]]
-    return "%s+%d reinsertion pass%s" % (BUILDERS[w["builder"]], passes, "" if passes == 1 else "es")
+    share = (w.get("opts") or {}).get("reinsertion_share", 100)
+    return "%s+%d reinsertion pass%s%s" % (BUILDERS[w["builder"]], passes, "" if passes == 1 else "es", "" if share >= 100 else " over %d%%" % share)
 
 
 EXTRA_LEGS = ("c3", "c4", "c5", "teapot", "vwvan", "vwvan_2level")    # N = 1: roofline_<leg>
@@ -441,6 +443,7 @@ class Bench:
         tb = self.tb
         tb.SetOption("bvh_builder", builder)
         tb.SetOption("reinsertion_passes", -1)     # the library's own choice unless the workload says otherwise (options outlive a load)
+        tb.SetOption("reinsertion_share", 100)
         for k, v in (opts or {}).items():
             tb.SetOption(k, v)
         t0 = time.time()
