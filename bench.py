@@ -102,6 +102,7 @@ def parse_args(argv=None):
     ap.add_argument("--pipeline", type=int, default=0)  # 0 lock-step bounce (fastest measured), 1 stream, 2 wavefront, 3 pooled, 4 split
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=INT")  # extra tb_set_option()s, before the scene is loaded
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true")     # profiling runs only: skip the oracle comparison of the timed frames (the line then carries no parity block)
     ap.add_argument("--no-readback", action="store_true")   # skip the PCIe-inclusive side measurement
     ap.add_argument("--no-legs", "--no-c3", dest="no_legs", action="store_true")   # skip roofline_<leg> / scale_<leg>
     ap.add_argument("--legs", default=None)                 # comma list; default: every leg of this N
@@ -266,9 +267,11 @@ def spill_share(key):
     commits profiles/rN/<key>_spill_share.json."""
     f = _newest(key + "_spill_share.json")
     if not f:
-        return None, None
+        return None, None, False
     d = json.load(open(f))
-    return d.get("vmem_spill_share"), os.path.relpath(f, ROOT)
+    from tracerboy_amd import build as tb_build
+    stale = d.get("_kernel_digest") != tb_build.kernel_digest()     # measured of other device code (ADVICE r5): marked, like pmc_stale
+    return d.get("vmem_spill_share"), os.path.relpath(f, ROOT), stale
 
 
 def traffic_bytes(passes):
@@ -311,10 +314,21 @@ def add_pipe_fields(r, key, passes):
                              "definition": "TA_TA_BUSY / 256 TAs, or 4 x SQ_ACTIVE_INST_VALU / 1024 SIMDs, per launch cycle"}
     if pipes.get("valu_busy") is not None and pipes.get("valu_lane_utilisation") is not None:
         r["useful_issue_frac"] = round(pipes["valu_busy"] * pipes["valu_lane_utilisation"], 3)
-    share, src = spill_share(key) if key else (None, None)
+    share, src, spill_stale = spill_share(key) if key else (None, None, False)
     r["vmem_spill_share"] = share
     if src:
         r["vmem_spill_source"] = src
+        r["vmem_spill_stale"] = bool(spill_stale)
+    # Which resource the committed counters say limits the kernel.  `frac` stays the contract's number (SURVEY 8d algorithmic bytes /
+    # launch time / 8 TB/s -- "contract_bound": "hbm"); `bound` names the pipe that is actually saturated: the texture addresser's
+    # issue of vector-memory instructions wherever it is busier than the fabric is full (the caches serve the bytes).
+    if r.get("bound") == "hbm":
+        r["contract_bound"] = "hbm"
+        ta, fabric = pipes.get("ta_busy"), r.get("traffic_frac_of_peak")
+        if ta is not None and fabric is not None and ta > fabric:
+            r["bound"] = "vmem_issue"
+            r["bound_note"] = ("texture addresser %.2f busy against %.2f of HBM peak on the fabric (committed PMC): the kernel is bound by "
+                               "the issue of vector-memory instructions, not by DRAM bandwidth; frac is still the contract's byte rate / 8 TB/s" % (ta, fabric))
     return r
 
 
@@ -648,6 +662,73 @@ def timed_steps(step, barrier, warmup, steps):
     return time.perf_counter() - t0
 
 
+
+# ------------------------------------------------------------------------------------------------- parity gate
+NO_PARITY = False          # --no-parity (profiling runs)
+PARITY_TOL = 1e-4          # BASELINE.md section 2 / north_star: relative L2 per pixel <= 1e-4 before any timing is accepted
+ORACLE_NAME = "oracle/tb_oracle.cpp"
+
+
+def parity_compare(np, gpu, cpu):
+    """Radiance sums of the HIP path against the oracle's over the same pixels (RGBA32F, .w = the weight): bit equality, the
+    relative L2 of the whole block and the largest per-pixel relative L2 (north_star words the gate per pixel)."""
+    g, c = np.ascontiguousarray(gpu, np.float32), np.ascontiguousarray(cpu, np.float32)
+    equal = bool(np.array_equal(g.view(np.uint32), c.view(np.uint32)))
+    if equal:
+        return {"bit_equal": True, "rel_l2": 0.0, "max_pixel_rel_l2": 0.0, "pixels": int(g.shape[0] * g.shape[1]), "differing_pixels": 0}
+    d = g.astype(np.float64) - c.astype(np.float64)
+    whole = float(np.sqrt((d ** 2).sum()) / max(np.sqrt((c.astype(np.float64) ** 2).sum()), 1e-30))
+    px = np.sqrt((d ** 2).sum(axis=-1)) / np.maximum(np.sqrt((c.astype(np.float64) ** 2).sum(axis=-1)), 1e-30)
+    px = np.where(np.isfinite(px), px, np.inf)       # a NaN on either side is a failure, not a zero
+    if np.isnan(d).any():
+        whole = float("inf")
+    return {"bit_equal": False, "rel_l2": whole, "max_pixel_rel_l2": float(px.max()), "pixels": int(g.shape[0] * g.shape[1]),
+            "differing_pixels": int((g.view(np.uint32) != c.view(np.uint32)).any(axis=-1).sum())}
+
+
+def parity_ok(block):
+    return bool(block and (block.get("bit_equal") or (block.get("rel_l2", 1.0) <= PARITY_TOL and block.get("max_pixel_rel_l2", 1.0) <= PARITY_TOL)))
+
+
+def strip_rows(H, k=2):
+    """k 8-row strips inside the frame: at 1/3 and 2/3 of its height (rows of whole 8x8 tiles)."""
+    return [min(max(0, (H * (i + 1) // (k + 1)) // 8 * 8), max(0, H - 8)) for i in range(k)]
+
+
+def parity_strips(tb, np, frame, W, H, frames, s, threads, rows=None):
+    """8-row strips of `frame` (the GPU's accumulation of `frames` frames) against the oracle fed the same host scene and frame
+    constants: the gate of one leg, a second or two on the box's CPUs."""
+    import oracle_lib as ol
+    rows = strip_rows(H) if rows is None else rows
+    view, pf = tb.HostSceneView(), tb.FrameConstants(W, H, 0, s, 0.0)
+    t0 = time.perf_counter()
+    g, c = [], []
+    for y0 in rows:
+        y1 = min(H, y0 + 8)
+        ref = ol.render(view, pf, W, H, frames, y0=y0, y1=y1, threads=threads)["output"]
+        g.append(frame[y0:y1]); c.append(ref[y0:y1])
+    blk = parity_compare(np, np.concatenate(g), np.concatenate(c))
+    blk.update({"frames": int(frames), "against": ORACLE_NAME, "compared": "8-row strips at y = %s of the %dx%d frame" % (rows, W, H),
+                "tolerance": PARITY_TOL, "oracle_s": round(time.perf_counter() - t0, 2)})
+    blk["ok"] = parity_ok(blk)
+    return blk
+
+
+def oracle_threads():
+    cores = len(os.sched_getaffinity(0))
+    q = cpu_allowance().get("cgroup_quota_cpus")
+    return max(1, min(cores, int(q + 0.999))) if q else cores
+
+
+def gate(block, r, key="value"):
+    """A figure whose frame failed the gate is not a figure: value -> null, the measured number kept under value_unverified."""
+    r["parity"] = block
+    if not (block or {}).get("ok", parity_ok(block)):
+        r[key + "_unverified"] = r.get(key)
+        r[key] = None
+    return r
+
+
 # ------------------------------------------------------------------------------------------------- N = 1 legs
 def extra_leg(b, np, torch, key, steps):
     """One more workload under the driver's clock: loaded, warmed, `steps` renders enqueued back to back and waited for
@@ -672,6 +753,9 @@ def extra_leg(b, np, torch, key, steps):
     variant = VARIANTS[tb.GetOption("last_variant")]
     prepass, overlapped = bool(tb.GetOption("last_primary_prepass")), bool(tb.GetOption("last_overlap"))
     two_level = bool(w.get("opts", {}).get("flatten_instances", 1) == 0)
+    # the gate: the frame the last timed step left in HBM, two 8-row strips of it against the oracle at the
+    # leg's own sample count
+    parity = None if NO_PARITY else parity_strips(tb, np, tb.ReadAccumulation(), W, H, SPP, s, oracle_threads())
     avg, frames, st = measure_kernel(tb, W, H, SPP, s, steps)
     passes, src = pmc_summary(key)
     r = hbm_roofline(avg, frames, W * H, st, passes, src)
@@ -690,6 +774,8 @@ def extra_leg(b, np, torch, key, steps):
             "a launch is the pair primary-visibility pre-pass (pt_primary: every camera ray of the batch, one 8x8 pixel tile "
             "per wave) + lock-step kernel: avg_launch_ms spans both, the committed counters are their sums")
     add_pipe_fields(r, key, passes)
+    if parity is not None:
+        gate(parity, r)
     if key == "c3":
         r["what_limits_it"] = ("instruction issue at ~19 of 64 lanes: a CU's texture addresser takes ~17 cycles per wave-level "
                                "load whatever the number of active lanes (scripts/microbench/gather64.hip) and every VALU "
@@ -736,10 +822,14 @@ def pcie_leg(tb, np, W, H, SPP, s, steps):
             "note": "render + tb_read_accum into pageable host memory, synchronous, %d steps" % n}
 
 
-def cpu_baseline_leg(tb, args, W, H, SPP, s):
+def cpu_baseline_leg(tb, args, W, H, SPP, s, np=None, timed_frame=None):
     """The scalar oracle (oracle/tb_oracle.cpp) on a bounded sample of the timed workload -- whole frames, sized to about
     --cpu-baseline-seconds -- on the threads the box lets run at once, and on one thread.  N = 1 only (the contract; at
-    N > 1 the other ranks' host threads would share the quota with it: ADVICE r4)."""
+    N > 1 the other ranks' host threads would share the quota with it: ADVICE r4).
+    The image it renders is the gate of the headline (CPU image vs HIP image before any timing is accepted):
+    returns (cpu_baseline block, parity block).  `timed_frame` = the accumulation the last timed step left in HBM (SPP frames); when
+    the CPU sample covers fewer frames than SPP the GPU renders that many frames again for the comparison and the timed frame itself
+    is gated on strips at the full sample count."""
     import oracle_lib as ol
     allowance = cpu_allowance()
     cores = len(os.sched_getaffinity(0))      # the CPUs this process may run on, not the machine's ...
@@ -754,9 +844,24 @@ def cpu_baseline_leg(tb, args, W, H, SPP, s):
     frames = int(max(1, min(SPP, budget / max(dt, 1e-3))))
     c0 = os.times()
     t1 = time.perf_counter()
-    ol.render(view, pf, W, H, frames, threads=cores)
+    cpu_image = ol.render(view, pf, W, H, frames, threads=cores)["output"]
     dt = time.perf_counter() - t1
     c1 = os.times()
+    parity = None
+    if np is not None:
+        if timed_frame is not None and frames == SPP:
+            gpu_image, what = timed_frame, "the frame the last timed step left in HBM"
+        else:
+            tb.InvalidateHistory()
+            tb.Render(W, H, frames, s, 0.0)
+            gpu_image, what = tb.ReadAccumulation(), "a render of the CPU sample's %d frames after the timed region" % frames
+        parity = parity_compare(np, gpu_image, cpu_image)
+        parity.update({"frames": int(frames), "of_frames": int(SPP), "against": ORACLE_NAME, "tolerance": PARITY_TOL,
+                       "compared": "the whole %dx%d frame x %d spp: %s" % (W, H, frames, what), "timed_frame": bool(frames == SPP and timed_frame is not None)})
+        if timed_frame is not None and frames != SPP:    # a slow box: the timed frame itself, on strips at its full sample count
+            parity["timed_frame_strips"] = parity_strips(tb, np, timed_frame, W, H, SPP, s, cores)
+        parity["ok"] = parity_ok(parity) and parity_ok(parity.get("timed_frame_strips", parity))
+    del cpu_image
     cpu_seconds = (c1.user - c0.user) + (c1.system - c0.system)   # cpu_seconds / dt = CPUs' worth of service
     if cores == 1:
         dt1, n1, rows1 = dt, W * H * frames, "the same run"
@@ -807,7 +912,7 @@ def cpu_baseline_leg(tb, args, W, H, SPP, s):
         cb["configs0"] = {"workload": "cornell-box 512x512 4spp depth4", "all_threads_s": round(dt3, 4),
                           "single_thread_s": round(dt4, 3), "all_threads": round(n0 / dt3 / 1e6, 3),
                           "single_thread": round(n0 / dt4 / 1e6, 4)}
-    return cb
+    return cb, parity
 
 
 def cpu_baseline_copied():
@@ -858,7 +963,11 @@ def scale_leg(b, np, torch, dist, tiles, key, rank, world, backend, steps, barri
     if exp:
         r["expected_speedup"] = exp
     if rank == 0:
+        torch.cuda.synchronize()
+        assembled = ts.frame.cpu().numpy()
         r["assembled_frame_equals_single_gpu"] = ts.assembled_equals_single_gpu(np, SPP, s)
+        if not NO_PARITY:
+            gate(parity_strips(tb, np, assembled, W, H, SPP, s, oracle_threads()), r)   # the assembled frame of the last timed step against the oracle
     tb.SetOption("overlap_launches", 1)
     dist.barrier()
     return r
@@ -866,7 +975,9 @@ def scale_leg(b, np, torch, dist, tiles, key, rank, world, backend, steps, barri
 
 # ------------------------------------------------------------------------------------------------- main
 def main():
+    global NO_PARITY
     args = parse_args()
+    NO_PARITY = args.no_parity
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_spawn(args))          # nothing above this line imports torch or touches the GPU
     rank = int(os.environ.get("RANK", "0"))
@@ -950,6 +1061,12 @@ def main():
     if pipelined or not args.sync_steps:
         tb.Sync()
         kernel_ms.append(tb.GetOption("last_kernel_us") / 1e3)   # HIP events of the last render of the timed region
+    # the frame the last timed step left in HBM, for the parity gate below (N = 1: the accumulation surface; N > 1: what rank 0
+    # assembled from the gathered tiles)
+    timed_frame = None
+    if rank == 0:
+        torch.cuda.synchronize()
+        timed_frame = ts.frame.cpu().numpy() if world > 1 else tb.ReadAccumulation()
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -1069,8 +1186,17 @@ def main():
     if rank == 0:
         if world == 1 and not args.no_readback:
             result["pcie_inclusive"] = pcie_leg(tb, np, W, H, SPP, s, args.steps)
+        parity = None
         if not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline_leg(tb, args, W, H, SPP, s) if world == 1 else cpu_baseline_copied()
+            if world == 1:
+                result["cpu_baseline"], parity = cpu_baseline_leg(tb, args, W, H, SPP, s, np, timed_frame)
+            else:
+                result["cpu_baseline"] = cpu_baseline_copied()
+        if parity is None and not args.no_parity:
+            # no CPU-baseline leg in this run (N > 1, or --no-cpu-baseline): the timed frame is gated on strips
+            parity = parity_strips(tb, np, timed_frame, W, H, SPP, s, oracle_threads())
+        if parity is not None:
+            gate(parity, result)
         print(json.dumps(result))
     tb.close()
     if world > 1:

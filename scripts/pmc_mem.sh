@@ -5,7 +5,7 @@ set -u
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
 TAG=$1; shift
 OUT=gpurun_out/pmcmem_$TAG; rm -rf $OUT; mkdir -p $OUT
-ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-c3 --sync-steps $*"
+ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-parity --no-c3 --sync-steps $*"
 # one small group per pass (a pass that asks one block for more counters than it has aborts rocprofv3 and then hangs in its
 # signal handler: every pass runs under `timeout`)
 pass() { timeout 150 rocprofv3 --pmc "${@:2}" --output-format csv -d $OUT/$1 -o $1 -- python3 bench.py $ARGS > /dev/null 2> $OUT/$1.err || echo "pass $1 failed / timed out"; }

@@ -5,7 +5,7 @@ set -u
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
 TAG=$1; shift
 OUT=gpurun_out/pmcq_$TAG; rm -rf $OUT; mkdir -p $OUT
-ARGS="--steps 2 --warmup 1 --no-cpu-baseline $*"
+ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-parity $*"
 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES --output-format csv -d $OUT/a -o a -- python3 bench.py $ARGS > /dev/null 2> $OUT/a.err
 rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM GRBM_GUI_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_SMEM --output-format csv -d $OUT/b -o b -- python3 bench.py $ARGS > /dev/null 2> $OUT/b.err
 python3 - "$OUT" "$TAG" <<'PY'

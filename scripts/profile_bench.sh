@@ -12,7 +12,7 @@ OUT=gpurun_out/$TAG
 rm -rf $OUT; mkdir -p $OUT
 # --sync-steps: one launch at a time, so that a kernel's duration in the trace is its own (bench.py's default overlaps the launches of
 # consecutive steps; its roofline block times non-overlapped launches the same way)
-ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-c3 --sync-steps ${BENCH_ARGS:-}"
+ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-parity --no-c3 --sync-steps ${BENCH_ARGS:-}"
 python3 bench.py $ARGS > $OUT/bench.json 2> $OUT/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python3 bench.py $ARGS > /dev/null 2> $OUT/trace.err
 pass() { rocprofv3 --pmc "${@:2}" --output-format csv -d $OUT/pmc_$1 -o $1 -- python3 bench.py $ARGS > /dev/null 2> $OUT/$1.err; }
@@ -22,7 +22,9 @@ pass sq SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INS
 pass lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM GRBM_GUI_ACTIVE
 pass tcc TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum
 pass util SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_SCA
-for f in $(find $OUT/trace -name "*kernel_stats.csv"); do cp "$f" $OUT/kernel_stats.csv; head -6 "$f"; done
+for f in $(find $OUT/trace -name "*kernel_stats.csv"); do cp "$f" $OUT/kernel_stats_all_dispatches.csv; done
+# what is committed as <TAG>_kernel_stats.csv: time per REAL launch (the zero-frame dispatches that warm the side streams dropped)
+python3 scripts/kernel_stats_real.py $OUT/trace $OUT/kernel_stats.csv
 python3 - "$OUT" <<'PY'
 import sys, json
 sys.path.insert(0, "scripts"); sys.path.insert(0, ".")

@@ -10,9 +10,8 @@ cases = [("cornell", dict(path=os.path.join(G, "cornell-box", "scene.pbrt"))), (
          ("proc0:300000", dict(procedural=(0, 300000, 1234))), ("proc1:150000", dict(procedural=(1, 150000, 7))), ("proc2:400000", dict(procedural=(2, 400000, 9))),
          ("vwvan", dict(path=os.path.join(G, "vw-van", "vw-van.pbrt"))), ("vwvan 2-level", dict(path=os.path.join(G, "vw-van", "vw-van.pbrt"), flatten_instances=False))]
 for passes in ("0", "1"):
-    os.environ["TB_REINSERT_PASSES"] = passes
     for name, kw in cases:
-        t = time.time(); hs = api.HostScene(bvh_builder=1, **kw); dt = time.time() - t; v = hs.view()
+        t = time.time(); hs = api.HostScene(bvh_builder=1, reinsertion_passes=int(passes), **kw); dt = time.time() - t; v = hs.view()
         h = hashlib.sha1(C.string_at(v.bvh, v.bvhBytes))
         if v.tlas: h.update(C.string_at(v.tlas, v.tlasBytes))
         print("%-14s passes %s  %s  %9d B  %.2f s" % (name, passes, h.hexdigest()[:16], v.bvhBytes, dt), flush=True)

@@ -9,12 +9,16 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 from tracerboy_amd import api  # noqa: E402
 ap = argparse.ArgumentParser(); ap.add_argument("out", nargs="?"); ap.add_argument("--builders", default="4,3,2,1"); ap.add_argument("--workload", default="vwvan")
+ap.add_argument("--passes", type=int, default=None); ap.add_argument("--share", type=int, default=None)   # options reinsertion_passes / reinsertion_share over the workload's own
 a = ap.parse_args()
 b = bench.Bench(api, 0); tb = b.tb
 w = bench.WORKLOADS[a.workload]; W, H, F = w["W"], w["H"], w["spp"]; s = b.settings(w["depth"])
 rows = {}
 for builder in [int(x) for x in a.builders.split(",")]:
-    t0 = time.time(); b.load(w["scene"], builder, w.get("opts")); load_s = time.time() - t0
+    opts = dict(w.get("opts") or {})
+    if a.passes is not None: opts["reinsertion_passes"] = a.passes
+    if a.share is not None: opts["reinsertion_share"] = a.share
+    t0 = time.time(); b.load(w["scene"], builder, opts); load_s = time.time() - t0
     for _ in range(2): tb.InvalidateHistory(); tb.Render(W, H, F, s, 0.0)
     for _ in range(3):
         for _ in range(5): tb.InvalidateHistory(); tb.Render(W, H, F, s, 0.0, sync=False)
@@ -29,7 +33,7 @@ for builder in [int(x) for x in a.builders.split(",")]:
                                    "boxes_per_sample": round(st.boxesTested / n, 2), "tris_per_sample": round(st.trianglesTested / n, 2),
                                    "rays_per_sample": round(st.rays / n, 3), "stack_overflow_entries": int(tb.GetOption("last_plan_stack_overflow")),
                                    "kernel_variant": variant, "prepass": prepass,
-                                   "reinsertion_passes": os.environ.get("TB_REINSERT_PASSES", "3 (default)") if builder == 1 else None,
-                                   "reinsertion_share": os.environ.get("TB_REINSERT_SHARE", "100") if builder == 1 else None}
+                                   "reinsertion_passes": opts.get("reinsertion_passes", "library default") if builder == 1 else None,
+                                   "reinsertion_share": opts.get("reinsertion_share", 100) if builder == 1 else None}
     print("builder", builder, rows["builder%d" % builder], flush=True)
     if a.out: json.dump({"workload": a.workload, "rows": rows}, open(a.out, "w"), indent=1)

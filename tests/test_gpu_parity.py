@@ -110,6 +110,30 @@ def test_trace_closest_matches_oracle_exactly(gpu_tb, settings, scene):
         assert np.array_equal(g[k], c[k]), k
 
 
+def load_bench_workload(tb, key):
+    """Load workload `key` of bench.WORKLOADS the way bench.py does -- the dict is imported, not restated: its builder and its
+    tb_set_option()s (reinsertion passes / share, flatten_instances) -- so that the full-size parity tests walk the very trees the
+    bench times (the tests' trees were not the bench's).  Options outlive a load: back to the defaults afterwards."""
+    import bench
+    w = bench.WORKLOADS[key]
+    tb.SetOption("bvh_builder", w["builder"]); tb.SetOption("reinsertion_passes", -1); tb.SetOption("reinsertion_share", 100)
+    try:
+        for k, v in (w.get("opts") or {}).items():
+            tb.SetOption(k, v)
+        scene = w["scene"]
+        if scene == "cornell-box":
+            tb.LoadScene(bench.CORNELL)
+        elif scene.startswith("proc"):
+            kind, tris = scene[4:].split(":")
+            tb.LoadProcedural(int(kind), int(tris), 1234)
+        else:
+            tb.LoadScene(scene)
+    finally:
+        tb.SetOption("bvh_builder", 0); tb.SetOption("reinsertion_passes", -1); tb.SetOption("reinsertion_share", 100)
+        tb.SetOption("flatten_instances", 1)
+    return w
+
+
 def _oracle(tb, W, H, frames, s, **kw):
     return ol.render(tb.HostSceneView(), tb.FrameConstants(W, H, 0, s, 0.0), W, H, frames, threads=8, **kw)
 
@@ -674,7 +698,7 @@ def test_full_size_properties_c2(gpu_tb, settings):
     assert 0.05 < mean[0] < 1.0 and mean[0] > mean[1] > mean[2]  # warm light: R > G > B
 
 
-@pytest.mark.parametrize("scene", ["cornell", "proc"])
+@pytest.mark.parametrize("scene", ["cornell", "proc", "cornell-bench-tree"])
 def test_full_size_frame_groups_equal_one_pixel_per_lane(gpu_tb, settings, scene):
     """The bench workloads in full (1920x1080; cornell 64 spp depth 8 from LDS, 200 k triangles 16 spp depth 6 from global
     memory): the frame-group launch (resident grid, work items claimed through the device counters, sample buffer + ordered
@@ -683,6 +707,9 @@ def test_full_size_frame_groups_equal_one_pixel_per_lane(gpu_tb, settings, scene
     s = copy.copy(settings)
     if scene == "cornell":
         gpu_tb.LoadScene(CORNELL); s.MaxBounces = 8; F = 64
+    elif scene == "cornell-bench-tree":           # the headline exactly: bench.WORKLOADS["c2"]'s tree, size, sample count and depth
+        w = load_bench_workload(gpu_tb, "c2"); s.MaxBounces = w["depth"]; F = w["spp"]
+        assert (W, H) == (w["W"], w["H"])
     else:
         gpu_tb.LoadProcedural(0, 200000, 1234); s.MaxBounces = 6; F = 16
     gpu_tb.InvalidateHistory(); gpu_tb.Render(W, H, F, s, 0.0)
@@ -713,18 +740,24 @@ def _strip_and_properties(gpu_tb, s, W, H, F, rows):
     return out
 
 
-def test_config_c3_dragon_class_870k(gpu_tb, settings):
-    """BASELINE.json configs[2] shape: the 870 k-triangle procedural stand-in for Scenes/dragon, 1920x1080, depth 6,
+@pytest.mark.parametrize("tree", ["sah-default-passes", "bench"])
+def test_config_c3_dragon_class_870k(gpu_tb, settings, tree):
+    """tree = "bench": the tree bench.py's roofline_c3 leg times (bench.WORKLOADS["c3"]: builder and reinsertion options imported).
+    BASELINE.json configs[2] shape: the 870 k-triangle procedural stand-in for Scenes/dragon, 1920x1080, depth 6,
     constant white environment.  (a) 2 spp: weights / NaN properties and two 8-row strips against the oracle;
     (b) the configuration's full 128 spp: the frame-group launch (what bench.py times) is bit-identical to the one-pixel-per-lane
     launch over the whole frame, and a strip of the 128-spp image is the oracle's."""
     W, H = 1920, 1080
     s = copy.copy(settings); s.MaxBounces = 6
-    gpu_tb.SetOption("bvh_builder", 1)                                   # binned SAH + reinsertion, bench.py's default tree
-    try:
-        gpu_tb.LoadProcedural(0, 870000, 1234)
-    finally:
-        gpu_tb.SetOption("bvh_builder", 0)
+    if tree == "bench":
+        w = load_bench_workload(gpu_tb, "c3")
+        assert (w["W"], w["H"], w["spp"], w["depth"]) == (W, H, 128, 6)
+    else:
+        gpu_tb.SetOption("bvh_builder", 1)                               # binned SAH + the library's own reinsertion passes
+        try:
+            gpu_tb.LoadProcedural(0, 870000, 1234)
+        finally:
+            gpu_tb.SetOption("bvh_builder", 0)
     info = gpu_tb.SceneInfo()
     assert abs(info.numTriangles - 870000) <= 8700
     gpu_tb.InvalidateHistory(); gpu_tb.Render(W, H, 2, s, 0.0)
@@ -743,21 +776,28 @@ def test_config_c3_dragon_class_870k(gpu_tb, settings):
     assert np.array_equal(bits(groups[540:542]), bits(ref[540:542]))
 
 
+@pytest.mark.parametrize("tree", ["lbvh+treelets-gpu", "bench"])
 @pytest.mark.parametrize("cfg", ["c4_van_class", "c5_bistro_class"])
-def test_config_c4_c5_4k_scenes(gpu_tb, settings, cfg):
-    """BASELINE.json configs[3] / [4] shapes on ONE GPU (the 8-GPU run splits exactly this frame into tiles): 3840x2160,
+def test_config_c4_c5_4k_scenes(gpu_tb, settings, cfg, tree):
+    """tree = "bench": the trees bench.py's roofline_c4 / _c5 and scale_c4 / _c5 legs time (bench.WORKLOADS imported).
+    BASELINE.json configs[3] / [4] shapes on ONE GPU (the 8-GPU run splits exactly this frame into tiles): 3840x2160,
     C4-class = 0.7 M triangles with matte / plastic / metal / mirror / glass (SSS walk), default depth 6;
     C5-class = 2.98 M triangles, 40 materials, 4 area lights, depth 16, tree built on the GPU (LBVH + treelet passes).
     2 spp: properties over the whole frame + 8-row strips against the oracle; then the tile split of the 8-rank run
     (this rank = 3 of 8) gives the same bits for its own pixels."""
     W, H, F = 3840, 2160, 2
     s = copy.copy(settings)
-    gpu_tb.SetOption("bvh_builder", 4)
-    try:
-        if cfg == "c4_van_class": gpu_tb.LoadProcedural(1, 700000, 1234); s.MaxBounces = 6
-        else: gpu_tb.LoadProcedural(2, 2980000, 1234); s.MaxBounces = 16
-    finally:
-        gpu_tb.SetOption("bvh_builder", 0)
+    if tree == "bench":
+        w = load_bench_workload(gpu_tb, "c4" if cfg == "c4_van_class" else "c5")
+        assert (w["W"], w["H"]) == (W, H)
+        s.MaxBounces = w["depth"]
+    else:
+        gpu_tb.SetOption("bvh_builder", 4)
+        try:
+            if cfg == "c4_van_class": gpu_tb.LoadProcedural(1, 700000, 1234); s.MaxBounces = 6
+            else: gpu_tb.LoadProcedural(2, 2980000, 1234); s.MaxBounces = 16
+        finally:
+            gpu_tb.SetOption("bvh_builder", 0)
     gpu_tb.InvalidateHistory(); gpu_tb.Render(W, H, F, s, 0.0)
     assert gpu_tb.GetOption("last_variant") == 5                           # "sss": SSS walk, no mix materials
     full = _strip_and_properties(gpu_tb, s, W, H, F, (1000, 1400))

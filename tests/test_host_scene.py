@@ -213,10 +213,9 @@ def test_reinsertion_passes_keep_the_tree_valid_and_cut_box_tests(built, monkeyp
     and a path-traced frame tests fewer boxes than with the passes turned off."""
     from tracerboy_amd import api
     s = api.GetDefaultOutputSettings(); s.EnableBlueNoise = 0; s.MaxBounces = 3
-    for make in (lambda: api.HostScene(CORNELL, bvh_builder=1), lambda: api.HostScene(procedural=(0, 6000, 1234), bvh_builder=1)):
-        monkeypatch.setenv("TB_REINSERT_PASSES", "0")
-        plain = make()
-        monkeypatch.delenv("TB_REINSERT_PASSES")
+    for make in (lambda **kw: api.HostScene(CORNELL, bvh_builder=1, **kw), lambda **kw: api.HostScene(procedural=(0, 6000, 1234), bvh_builder=1, **kw)):
+        plain = make(reinsertion_passes=0)
+        monkeypatch.setenv("TB_REINSERT_PASSES", "0")    # an environment variable no longer reaches the builder (ADVICE r5)
         opt = make()
         tri = opt.triangles()
         assert np.array_equal(tri["positions"], plain.triangles()["positions"])

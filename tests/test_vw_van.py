@@ -52,20 +52,29 @@ def test_vw_van_conversion(built):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("tree", ["lbvh+treelets-gpu", "bench"])
 @pytest.mark.parametrize("flatten", [1, 0])
-def test_vw_van_4k_strips_bit_exact(gpu_tb, settings, flatten):
-    """configs[3]'s frame on one GPU, flattened and as the two-level structure the reference hands its hardware path (240 instances):
+def test_vw_van_4k_strips_bit_exact(gpu_tb, settings, flatten, tree):
+    """tree = "bench": the trees bench.py's roofline_vwvan / _vwvan_2level / scale_vwvan legs time (bench.WORKLOADS imported).
+    configs[3]'s frame on one GPU, flattened and as the two-level structure the reference hands its hardware path (240 instances):
     whole-frame properties + 8-row strips against the oracle (which walks the same structure)."""
     W, H, F = 3840, 2160, 2
     s = copy.copy(settings); s.MaxBounces = 6
-    gpu_tb.SetOption("flatten_instances", flatten); gpu_tb.SetOption("bvh_builder", 4)
-    try:
-        gpu_tb.LoadScene(VW)
-    finally:
-        gpu_tb.SetOption("flatten_instances", 1); gpu_tb.SetOption("bvh_builder", 0)
+    if tree == "bench":
+        from test_gpu_parity import load_bench_workload
+        w = load_bench_workload(gpu_tb, "vwvan" if flatten else "vwvan_2level")
+        assert (w["W"], w["H"], w["depth"]) == (W, H, s.MaxBounces) and w["opts"]["flatten_instances"] == flatten
+    else:
+        gpu_tb.SetOption("flatten_instances", flatten); gpu_tb.SetOption("bvh_builder", 4)
+        try:
+            gpu_tb.LoadScene(VW)
+        finally:
+            gpu_tb.SetOption("flatten_instances", 1); gpu_tb.SetOption("bvh_builder", 0)
     gpu_tb.InvalidateHistory(); gpu_tb.Render(W, H, F, s, 0.0)
     # "vol": interior walks AND a mix material; the two-level tree is 53 levels deep: 39 entries of the tuned copy's stack in LDS (four workgroups per CU), 14 in global memory
-    assert gpu_tb.GetOption("last_variant") == 3 and gpu_tb.GetOption("last_plan_stack_overflow") == (3 if flatten else 14)
+    assert gpu_tb.GetOption("last_variant") == 3
+    if tree != "bench":
+        assert gpu_tb.GetOption("last_plan_stack_overflow") == (3 if flatten else 14)
     out, jit = gpu_tb.ReadAccumulation(jittered=True)
     # a sample that comes back NaN is dropped WITH its weight (RayGenCommon.h:704-727; this scene's index-0 glass makes some): weights count at most the frames
     assert not np.isnan(out).any() and (out[..., 3] <= float(F)).all() and (out[..., 3] == float(F)).mean() > 0.98 and (out[..., :3] >= 0).all() and out[..., :3].max() > 0

@@ -23,6 +23,7 @@
 #include <atomic>
 #include <cstring>
 #include <cstdlib>
+#include <exception>
 #include <stdexcept>
 #include <thread>
 #include <mutex>
@@ -45,9 +46,13 @@ template <class F> void parallelFor(size_t n, F f)
     unsigned hw = std::thread::hardware_concurrency(); if (hw == 0) hw = 1;
     size_t nt = n < 65536 ? 1 : std::min<size_t>(hw, 16);
     if (nt == 1) { f((size_t)0, n); return; }
+    /* an exception in a worker (bad_alloc) is carried to the caller instead of ending the process */
     std::vector<std::thread> th; size_t chunk = (n + nt - 1) / nt;
-    for (size_t t = 0; t < nt; t++) { size_t a = t * chunk, b = std::min(n, a + chunk); if (a < b) th.emplace_back([=]() { f(a, b); }); }
+    std::exception_ptr failed; std::mutex fm;
+    for (size_t t = 0; t < nt; t++) { size_t a = t * chunk, b = std::min(n, a + chunk);
+        if (a < b) th.emplace_back([=, &failed, &fm]() { try { f(a, b); } catch (...) { std::lock_guard<std::mutex> g(fm); if (!failed) failed = std::current_exception(); } }); }
     for (auto& t : th) t.join();
+    if (failed) std::rethrow_exception(failed);
 }
 
 inline uint32_t expand10(uint32_t v) { v &= 0x3ff; v = (v | (v << 16)) & 0x030000FF; v = (v | (v << 8)) & 0x0300F00F; v = (v | (v << 4)) & 0x030C30C3;
@@ -135,10 +140,13 @@ void buildSah(const HostScene& s, Tree& t)
     struct Bins { Bounds bb[3][B]; uint32_t bc[3][B]; Bounds cb; };
     constexpr uint32_t WIDE = 1u << 17; /* ranges from here up are scanned by several threads */
     /* where [begin, end) is cut; reorders ids inside the range */
+    bool topPhase = true; /* wide ranges are scanned by several threads only while ONE thread splits the top of the tree: a worker thread of the
+                           * second phase that met a wide range used to start 16 more threads of its own */
     auto split = [&](uint32_t begin, uint32_t end) -> uint32_t {
         const uint32_t count = end - begin;
+        const bool wide = topPhase && count >= WIDE;
         Bounds cb = emptyB();
-        if (count >= WIDE) {
+        if (wide) {
             std::mutex m;
             parallelFor(count, [&](size_t a, size_t z) { Bounds l = emptyB(); for (size_t i = a; i < z; i++) grow(l, cen[ids[begin + i]]);
                 std::lock_guard<std::mutex> g(m); grow(cb, l); });
@@ -158,7 +166,7 @@ void buildSah(const HostScene& s, Tree& t)
             auto scan = [&](size_t a, size_t z, Bounds (*lb)[B], uint32_t (*lc)[B]) {
                 for (size_t i = a; i < z; i++) { const uint32_t id = ids[begin + i];
                     for (int ax = 0; ax < 3; ax++) if (use[ax]) { const int b = binOf(id, ax); grow(lb[ax][b], tb[id]); lc[ax][b]++; } } };
-            if (count >= WIDE) {
+            if (wide) {
                 std::mutex m;
                 parallelFor(count, [&](size_t a, size_t z) {
                     std::vector<Bounds> lbv(3 * B, emptyB()); std::vector<uint32_t> lcv(3 * B, 0);
@@ -200,19 +208,27 @@ void buildSah(const HostScene& s, Tree& t)
         std::vector<Job> open; open.push_back(Job{0, N, 0});
         unsigned hw = std::thread::hardware_concurrency(); if (hw == 0) hw = 1;
         const size_t threads = N < 65536 ? 1 : std::min<size_t>(hw, 16);
-        while (threads > 1 && open.size() < 8 * threads) {
+        /* ... and until no open range is wide any more (the workers below scan their ranges alone) */
+        for (;;) {
             size_t big = 0; for (size_t i = 1; i < open.size(); i++) if (open[i].end - open[i].begin > open[big].end - open[big].begin) big = i;
-            if (open[big].end - open[big].begin < 4096) break;
+            if (open.empty()) break;
+            const uint32_t bigCount = open[big].end - open[big].begin;
+            if (!(threads > 1 && ((open.size() < 8 * threads && bigCount >= 4096) || bigCount >= WIDE))) break;
             const Job j = open[big]; open.erase(open.begin() + big);
             expand(j, open);
         }
+        topPhase = false;
         std::sort(open.begin(), open.end(), [](const Job& a, const Job& b) { return a.end - a.begin > b.end - b.begin; });
         std::atomic<size_t> next{0};
+        std::exception_ptr failed; std::mutex fm;
         auto worker = [&]() { std::vector<Job> stack;
-            for (size_t k = next++; k < open.size(); k = next++) { stack.clear(); stack.push_back(open[k]);
-                while (!stack.empty()) { const Job j = stack.back(); stack.pop_back(); expand(j, stack); } } };
+            try {
+                for (size_t k = next++; k < open.size(); k = next++) { stack.clear(); stack.push_back(open[k]);
+                    while (!stack.empty()) { const Job j = stack.back(); stack.pop_back(); expand(j, stack); } }
+            } catch (...) { std::lock_guard<std::mutex> g(fm); if (!failed) failed = std::current_exception(); next = open.size(); } };
         if (threads == 1) worker();
         else { std::vector<std::thread> th; for (size_t i = 0; i < threads; i++) th.emplace_back(worker); for (auto& x : th) x.join(); }
+        if (failed) std::rethrow_exception(failed); /* surfaces through tb_load_scene as an error code */
     }
     t.order = ids; /* leaf k is the k-th triangle from the left */
 }
@@ -259,9 +275,10 @@ void optimizeByReinsertion(const HostScene& s, Tree& t, int maxPasses, double mi
     for (int pass = 0; pass < maxPasses; pass++) {
         for (uint32_t x = 1; x < M; x++) cand[x - 1] = x;
         std::stable_sort(cand.begin(), cand.end(), [&](uint32_t a, uint32_t b) { return sa[a] > sa[b]; });
-        /* only the largest <share> percent of the subtrees (HostScene::reinsertionShare; TB_REINSERT_SHARE overrides it for experiments) */
-        size_t tried = 0; const char* shareEnv = getenv("TB_REINSERT_SHARE");
-        const double share = shareEnv ? atof(shareEnv) : (double)s.reinsertionShare;
+        /* only the largest <share> percent of the subtrees (HostScene::reinsertionShare: option "reinsertion_share", the builder word of
+         * tb_host_scene_load -- no environment override: a left-over variable used to change the tree without a trace) */
+        size_t tried = 0;
+        const double share = (double)s.reinsertionShare;
         const size_t limit = share >= 100.0 ? cand.size() : (size_t)((double)cand.size() * std::max(share, 0.0) / 100.0);
         for (uint32_t x : cand) {
             if (tried++ >= limit) break;
@@ -298,7 +315,8 @@ void optimizeByReinsertion(const HostScene& s, Tree& t, int maxPasses, double mi
             refit(p);
         }
         const double now = totalCost();
-        if (getenv("TB_REINSERT_VERBOSE")) fprintf(stderr, "reinsertion pass %d: SAH cost %.6g -> %.6g\n", pass, cost, now);
+        static const bool verbose = getenv("TB_REINSERT_VERBOSE") != nullptr; /* diagnostics only: changes no tree */
+        if (verbose) fprintf(stderr, "reinsertion pass %d: SAH cost %.6g -> %.6g\n", pass, cost, now);
         const bool goOn = now < cost * (1.0 - minGain);
         cost = now;
         if (!goOn) break;
@@ -404,8 +422,7 @@ void BuildBvhSingle(HostScene& s, int builder)
     const uint32_t N = t.N;
     if (builder == 1) {
         buildSah(s, t);
-        const char* cap = getenv("TB_REINSERT_PASSES"); /* experiments: 0 turns the passes off */
-        const int passes = cap ? atoi(cap) : s.reinsertionPasses >= 0 ? s.reinsertionPasses : (N <= 4096 ? 16 : 3);
+        const int passes = s.reinsertionPasses >= 0 ? s.reinsertionPasses : (N <= 4096 ? 16 : 3); /* option "reinsertion_passes" */
         if (passes > 0) optimizeByReinsertion(s, t, passes, N <= 4096 ? 1e-6 : 5e-3);
     } else {
         buildLbvh(s, t);

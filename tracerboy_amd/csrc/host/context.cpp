@@ -333,10 +333,12 @@ int tb_read_aov(tb_context* c, int which, void* dst)
 int tb_accum_device_ptr(tb_context* c, void** o, void** j)
 {
     if (!c) return TB_E_INVALID;
+    /* the abort word of the split-role kernel is host-mapped: a launch that has already given up is reported without waiting for anything --
+     * and WITHOUT consuming the report (tb_sync / tb_read_accum on the same incomplete frame must still fail), with no pointer
+     * handed out */
+    if (c->splitAbort && *c->splitAbort) return fail(c, TB_E_DEVICE, splitAbortMessage(c, false));
     if (o) *o = c->output.p;
     if (j) *j = c->jittered.p;
-    /* the abort word of the split-role kernel is host-mapped: a launch that has already given up is reported without waiting for anything */
-    if (c->splitAbort && *c->splitAbort) return fail(c, TB_E_DEVICE, splitAbortMessage(c));
     return c->output.p ? TB_OK : TB_E_INVALID;
 }
 
@@ -635,7 +637,7 @@ int tb_unpack_gathered_host(uint32_t W, uint32_t H, uint32_t world, uint32_t tw,
 int tb_set_option(tb_context* c, const char* name, int64_t v)
 {
     if (!c || !name) return TB_E_INVALID;
-    static const char* known[] = {"reinsertion_share", "reinsertion_passes", "camera_constants", "texture_use_hint", "compact_hits", "first_bounce", "primary_prepass", "pipeline", "count_rays", "bvh_builder", "flatten_instances", "aov", "scene_in_lds", "lds_scene_budget",
+    static const char* known[] = {"reinsertion_share", "reinsertion_passes", "compact_stamp_bits", "camera_constants", "texture_use_hint", "compact_hits", "first_bounce", "primary_prepass", "pipeline", "count_rays", "bvh_builder", "flatten_instances", "aov", "scene_in_lds", "lds_scene_budget",
         "force_full_variant", "wavefront_paths", "wavefront_grid", "wavefront_segment", "pooled_paths", "pooled_samples", "pooled_profile", "park_min",
         "alpha_test", "node_order", "node_order_top_levels", "frame_group", "overlap_launches", "high_occupancy", "stack_lds_cap", "stack_overflow_max",
         "flip_texture_uvs", "wavefront_sort", "banded_items", "node_layout", "wavefront_refill",
@@ -754,6 +756,15 @@ struct tb_host_scene { HostScene scene; };
 
 static int hostFail(char* err, uint32_t n, int code, const std::string& m) { if (err && n) { strncpy(err, m.c_str(), n - 1); err[n - 1] = 0; } return code; }
 
+/* bvh_builder of the host-scene entry points: builder | (reinsertion passes + 1) << 8 | reinsertion share (percent) << 16; a zero field =
+ * the library's own choice (options "reinsertion_passes" / "reinsertion_share" of a context) */
+static void applyBuilderWord(HostScene& s, int word)
+{
+    const int passes = (word >> 8) & 0xff, share = (word >> 16) & 0xff;
+    if (passes) s.reinsertionPasses = passes - 1;
+    if (share) s.reinsertionShare = share;
+}
+
 int tb_host_scene_load(const char* path, int builder, int loadFlags, tb_host_scene** out, char* err, uint32_t errLen)
 {
     if (!path || !out) return TB_E_INVALID;
@@ -762,7 +773,7 @@ int tb_host_scene_load(const char* path, int builder, int loadFlags, tb_host_sce
         std::shared_ptr<PbrtScene> ps = importScene(path);
         tb_host_scene* h = new tb_host_scene();
         ConvertOptions co; co.flattenInstances = (loadFlags & 1) != 0; co.flipTextureUVs = (loadFlags & 2) == 0;
-        try { ConvertScene(*ps, h->scene, co); BuildBvh(h->scene, builder); } catch (...) { delete h; throw; }
+        try { ConvertScene(*ps, h->scene, co); applyBuilderWord(h->scene, builder); BuildBvh(h->scene, builder & 0xff); } catch (...) { delete h; throw; }
         *out = h; return TB_OK;
     } catch (const std::exception& e) {
         std::string m = e.what();
@@ -778,7 +789,7 @@ int tb_host_scene_procedural(int kind, uint32_t tris, uint32_t seed, int builder
     *out = nullptr;
     try {
         tb_host_scene* h = new tb_host_scene();
-        try { MakeProceduralScene(h->scene, kind, tris, seed); BuildBvh(h->scene, builder); } catch (...) { delete h; throw; }
+        try { MakeProceduralScene(h->scene, kind, tris, seed); applyBuilderWord(h->scene, builder); BuildBvh(h->scene, builder & 0xff); } catch (...) { delete h; throw; }
         *out = h; return TB_OK;
     } catch (const std::exception& e) { return hostFail(err, errLen, TB_E_INVALID, e.what()); }
 }

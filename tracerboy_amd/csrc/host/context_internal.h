@@ -241,7 +241,7 @@ void ensureCompactNodes(tb_context* c);
 void finalizeScene(tb_context* c, bool build = true); /* build = false: c->scene already holds a built, reordered tree (a peer of a multi-device group) */
 /* context_render.cpp */
 int deviceCUs(tb_context* c);
-std::string splitAbortMessage(tb_context* c);
+std::string splitAbortMessage(tb_context* c, bool clear = true);
 int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_output_settings* settings, float timeSeed, bool sync);
 
 } // namespace tbctx

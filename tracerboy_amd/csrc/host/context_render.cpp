@@ -146,7 +146,7 @@ int deviceCUs(tb_context* c)
  * split_wl (TbSplitParams), split_frame_group (frames of a wave's work item), split_stack_cap (stack entries kept in LDS; the rest
  * of a deeper tree's stack lives in global memory, pt_scene.h). */
 /* the split-role kernel's abort word and the state the wave that raised it left behind (pt_split.inc give_up); clears the word */
-std::string splitAbortMessage(tb_context* c)
+std::string splitAbortMessage(tb_context* c, bool clear)
 {
     volatile uint32_t* w = c->splitAbort;
     char buf[512];
@@ -154,7 +154,7 @@ std::string splitAbortMessage(tb_context* c)
     snprintf(buf, sizeof buf,
         "the split-role kernel gave up (%s for spin_limit sleeps; workgroup %u wave %u; state %u %u 0x%x 0x%x; tickets %u, positions %u, shading waves done %u); the frame is incomplete",
              why[w[0] < 4 ? w[0] : 0], w[1] >> 8, w[1] & 255u, w[2], w[3], w[4], w[5], w[6], w[7], w[8]);
-    for (int i = 0; i < 9; i++) w[i] = 0;
+    if (clear) for (int i = 0; i < 9; i++) w[i] = 0; /* a query that is not the end of a render (tb_accum_device_ptr) reports and leaves the report for tb_sync */
     return buf;
 }
 
@@ -410,7 +410,13 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
     const uint32_t hitPrimBits = compactOpt >= 2 ? (uint32_t)std::max<int64_t>(1, (int64_t)c->hitPrimBits - (compactOpt - 1)) : c->hitPrimBits;
     const uint32_t hitIndexBits = hitPrimBits + c->hitGeomBits;
     const bool compactHits = prepass && !firstBounce && compactOpt != 0 && hitIndexBits >= 1 && hitIndexBits <= 28;
-    auto hitStampOf = [&](uint32_t epoch) { return compactHits ? 1u + epoch % ((1u << (32u - hitIndexBits)) - 1u) : 0u; };
+    /* The stamp is cyclic: with s = 32 - hitIndexBits bits it repeats every 2^s - 1 launches (15 at the 4-bit minimum; a buffer sees every second
+     * launch, so a record as a launch 30 launches ago left it on the same buffer would pass -- every launch in between has rewritten every record
+     * of the buffer, and what was actually observed, a line of the launch before last, differs in its stamp at any width).  There is no check
+     * word: a 16-B piece is written and read whole.  Option compact_stamp_bits (a test hook) narrows the stamp to that many bits so that a small
+     * scene can be stressed at the minimum width (tests/test_buffer_reuse_stress.py). */
+    const uint32_t stampBits = (uint32_t)std::min<int64_t>(32 - (int64_t)hitIndexBits, std::max<int64_t>(2, opt("compact_stamp_bits", 32)));
+    auto hitStampOf = [&](uint32_t epoch) { return compactHits ? 1u + epoch % ((1u << stampBits) - 1u) : 0u; };
     const size_t hitRecordBytes = firstBounce ? 96 : compactHits ? 16 : 32;
     c->lastCompactHits = compactHits ? 1 : 0;
     c->lastPrimaryPrepass = prepass ? 1 : 0; c->lastFirstBounce = firstBounce ? 1 : 0; c->lastPlan = plan;
