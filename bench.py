@@ -67,7 +67,8 @@ WORKLOADS = {
     # the reference's Teapot: textures + env + GGX
     "teapot": dict(scene=TEAPOT, builder=1, W=1920, H=1080, spp=16, depth=8, opts={"reinsertion_passes": 0}),
     # the reference's own configs[3] scene (Scenes/vw-van minus the absent body shell, tests/golden/make_vw_van_fixture.py)
-    "vwvan": dict(scene=VWVAN, builder=1, W=3840, H=2160, spp=8, depth=6, opts=dict(SAH3, flatten_instances=1)),
+    # (tile: the N > 1 deal of this workload -- a car in the middle of a sky balances better on 32x32 tiles: 6.14x against 5.93x at N = 8, profiles/r5/rank_tiles_32spp.json)
+    "vwvan": dict(scene=VWVAN, builder=1, W=3840, H=2160, spp=8, depth=6, opts=dict(SAH3, flatten_instances=1), tile=32),
     "vwvan_2level": dict(scene=VWVAN, builder=1, W=3840, H=2160, spp=8, depth=6, opts=dict(SAH3, flatten_instances=0)),
 }
 
@@ -83,6 +84,10 @@ def builder_label(w):
 
 EXTRA_LEGS = ("c3", "c4", "c5", "teapot", "vwvan", "vwvan_2level")    # N = 1: roofline_<leg>
 SCALE_LEGS = ("c4", "c5", "vwvan")                                    # N > 1: scale_<leg>
+# N > 1: samples per pixel of a scale leg's timed step.  The configurations are 256 / 1024 spp; a step of 32 measures them (a launch costs a
+# fixed 0.8-2.7 ms more than its samples on a rank's eighth of a 4K frame -- scripts/async_rate.py, docs/experiments/r6.md -- which is a third
+# of an 8-spp step and a twentieth of a 32-spp one); the 8-spp step of the N = 1 legs is timed beside it as `at_short_steps`.
+SCALE_SPP, SCALE_SHORT_SPP = 32, 8
 
 
 def parse_args(argv=None):
@@ -411,30 +416,29 @@ def expected_speedup(scene, W, H, spp, depth, world):
 
 
 def expected_speedup_leg(key, world):
-    """The 4K configurations: one GPU emulated EVERY rank r of N in turn on the leg's scene (scripts/rank_imbalance.py ->
-    profiles/rN/rank_imbalance.json); a step of the N-GPU job takes what its slowest rank takes, so the expected speed-up
-    is t(1 GPU) / max_r t(rank r of N) and max / mean over the ranks is the tile imbalance SURVEY 8e names as the limiter."""
-    f = _newest("rank_imbalance.json")
-    if not f:
+    """The 4K configurations: one GPU emulated EVERY rank r of N in turn on the leg's scene with the leg's tile size
+    (scripts/rank_imbalance.py --spp 32 -> profiles/rN/rank_imbalance_32spp.json: the step the leg is quoted on; without --spp ->
+    rank_imbalance.json: the 8-spp short step); a step of the N-GPU job takes what its slowest rank takes, so the expected speed-up is
+    t(1 GPU) / max_r t(rank r of N) and max / mean over the ranks is the tile imbalance SURVEY 8e names as the limiter."""
+    def row(pattern, spp):
+        f = _newest(pattern)
+        if not f:
+            return None
+        d = json.load(open(f)).get(key)
+        if not d or "world1" not in d or ("world%d" % world) not in d or d.get("tile", TILE) != WORKLOADS[key].get("tile", TILE):
+            return None
+        one, w = d["world1"], d["world%d" % world]
+        return {"spp": spp, "vs_1gpu": round(one["max_ms"] / w["max_ms"], 2), "max_over_mean_rank_ms": w["max_over_mean"],
+                "slowest_rank": w.get("slowest_rank"), "ms_per_step_slowest_rank": w["max_ms"], "tile": d.get("tile", TILE),
+                "deal": d.get("deal", "round-robin"), "source": os.path.relpath(f, ROOT)}
+    main, short = row("rank_imbalance_32spp.json", SCALE_SPP), row("rank_imbalance.json", SCALE_SHORT_SPP)
+    if not main:
         return None
-    d = json.load(open(f)).get(key)
-    if not d or "world1" not in d or ("world%d" % world) not in d:
-        return None
-    one, w = d["world1"], d["world%d" % world]
-    longer = None
-    f32 = _newest("rank_imbalance_32spp.json")
-    if f32:
-        d32 = json.load(open(f32)).get(key) or {}
-        if "world1" in d32 and ("world%d" % world) in d32:
-            longer = {"spp": 32, "vs_1gpu": round(d32["world1"]["max_ms"] / d32["world%d" % world]["max_ms"], 2),
-                      "max_over_mean_rank_ms": d32["world%d" % world]["max_over_mean"], "source": os.path.relpath(f32, ROOT),
-                      "note": "the same sweep at 32 spp per step: a launch costs ~1.5 ms more than its samples whatever its size "
-                              "(its tail), which weighs a quarter of a rank's 8-spp step and little of a longer one"}
-    return {"vs_1gpu": round(one["max_ms"] / w["max_ms"], 2), "max_over_mean_rank_ms": w["max_over_mean"], "at_longer_steps": longer,
-            "slowest_rank": w.get("slowest_rank"), "ms_per_step_slowest_rank": w["max_ms"], "tile": d.get("tile", TILE),
-            "deal": d.get("deal", "round-robin"), "source": os.path.relpath(f, ROOT),
-            "note": "one GPU emulating each rank of N in turn (async step: render + pack + stream-ordered consumer); "
-                    "the xGMI gather (16.6 MB per peer at N = 8) overlaps the next render"}
+    main["at_short_steps"] = short
+    main["note"] = ("one GPU emulating each rank of N in turn (async step: render + pack + stream-ordered consumer); the xGMI gather "
+                    "(16.6 MB per peer at N = 8) overlaps the next render.  A launch costs a fixed 0.8-2.7 ms more than its samples on a rank's "
+                    "share of a 4K frame (scripts/async_rate.py): a third of an 8-spp step, a twentieth of the 32-spp step quoted")
+    return main
 
 
 # ------------------------------------------------------------------------------------------------- the renderer
@@ -531,12 +535,12 @@ class TileSplit:
     the gather.  Nothing in a step blocks the host: render and pack are enqueued on the library's stream, the gather on
     RCCL's, the un-permute on torch's stream behind the gather, ordered by stream waits."""
 
-    def __init__(self, tb, torch, dist, tiles, rank, world, backend, W, H, standin_consumer=False):
+    def __init__(self, tb, torch, dist, tiles, rank, world, backend, W, H, standin_consumer=False, tile=TILE):
         self.tb, self.torch, self.dist, self.rank, self.world, self.backend = tb, torch, dist, rank, world, backend
-        self.W, self.H = W, H
-        tb.SetTileAssignment(rank, world, TILE, TILE)
+        self.W, self.H, self.tile = W, H, tile
+        tb.SetTileAssignment(rank, world, tile, tile)
         self.owned = tb.OwnedPixels(W, H)
-        self.capacity = max(tiles.packed_capacity(W, H, world, TILE, TILE), 1)
+        self.capacity = max(tiles.packed_capacity(W, H, world, tile, tile), 1)
         z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device="cuda")   # noqa: E731
         self.packed = [z(self.capacity, 4) for _ in range(2)]
         root = world > 1 and rank == 0
@@ -551,7 +555,7 @@ class TileSplit:
 
     def _unpack(self):
         torch = self.torch
-        self.tb.UnpackGatheredTo(self.gathered.data_ptr(), self.capacity, self.W, self.H, self.world, TILE, TILE,
+        self.tb.UnpackGatheredTo(self.gathered.data_ptr(), self.capacity, self.W, self.H, self.world, self.tile, self.tile,
                                  self.frame.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
 
     def _host_gather(self, buf):
@@ -647,7 +651,7 @@ class TileSplit:
         tb.InvalidateHistory()
         tb.Render(self.W, self.H, spp, s, 0.0)
         whole = tb.ReadAccumulation()
-        tb.SetTileAssignment(self.rank, self.world, TILE, TILE)
+        tb.SetTileAssignment(self.rank, self.world, self.tile, self.tile)
         return bool(np.array_equal(assembled.view(np.uint32), whole.view(np.uint32)))
 
 
@@ -944,17 +948,25 @@ def scale_leg(b, np, torch, dist, tiles, key, rank, world, backend, steps, barri
     # +4-5 %, vw-van +18-39 %, profiles/r4/overlap_ab*.json) and a rank's share of a frame is a smaller call still; a trial
     # would not settle within the leg's few steps.  scripts/rank_imbalance.py (expected_speedup) runs the same way.
     tb.SetOption("overlap_launches", 2)
-    ts = TileSplit(tb, torch, dist, tiles, rank, world, backend, W, H)
-    elapsed = timed_steps(lambda: ts.step(SPP, s), barrier, 2, steps)
+    tile = w.get("tile", TILE)
+    ts = TileSplit(tb, torch, dist, tiles, rank, world, backend, W, H, tile=tile)
     dev = "cuda" if backend == "nccl" else "cpu"
-    t = torch.tensor([elapsed, load_s], device=dev, dtype=torch.float64)
+    # the short step first (8 spp, the N = 1 legs' step), then the step the leg is quoted on: the frame that stays assembled is the long step's
+    short = timed_steps(lambda: ts.step(SCALE_SHORT_SPP, s), barrier, 2, steps)
+    SPP = SCALE_SPP
+    elapsed = timed_steps(lambda: ts.step(SPP, s), barrier, 1, steps)
+    t = torch.tensor([elapsed, load_s, short], device=dev, dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed, load_max = float(t[0]), float(t[1])
+    elapsed, load_max, short = float(t[0]), float(t[1]), float(t[2])
     tb.Sync()
     r = {"workload": "%s %dx%d %dspp depth%d" % (scene_label(w["scene"]), W, H, SPP, D), "data": data_label(w["scene"]),
          "triangles": int(info.numTriangles), "value": round(W * H * SPP * steps / elapsed / 1e6, 1), "unit": "Msamples/s",
          "ms_per_step": round(elapsed / steps * 1e3, 3), "steps": steps, "n_gpus": world, "scaling": "strong",
-         "parallelism": "tiles%d" % world, "tile": TILE, "bvh_builder": builder_label(w),
+         "at_short_steps": {"spp": SCALE_SHORT_SPP, "value": round(W * H * SCALE_SHORT_SPP * steps / short / 1e6, 1), "unit": "Msamples/s",
+                            "ms_per_step": round(short / steps * 1e3, 3),
+                            "note": "the same step at the N = 1 legs' 8 spp: a rank's launch then carries its fixed cost (its drain: the longest paths of "
+                                    "its last samples) over an eighth of the work"},
+         "parallelism": "tiles%d" % world, "tile": tile, "bvh_builder": builder_label(w),
          "kernel_variant": VARIANTS[tb.GetOption("last_variant")], "primary_prepass": bool(tb.GetOption("last_primary_prepass")),
          "launches_overlap": bool(tb.GetOption("last_overlap")), "scene_load_s": round(load_max, 2),
          "scene_load_s_note": "max over ranks (every rank loads and builds the scene itself)"}

@@ -298,7 +298,8 @@ typedef struct tb_host_scene tb_host_scene;
 /* load_flags: bit 0 = flatten instanced shapes (option "flatten_instances"), bit 1 = do NOT flip texture v (the Assimp
  * convention; .pbrt / .pbf loads flip: m_flipTextureUVs, TracerBoy.cpp:1208,1222; option "flip_texture_uvs" = 0).
  * bvh_builder: option "bvh_builder" in bits 0-7; for builder 1 optionally (reinsertion passes + 1) << 8 and (share of the subtrees a
- * pass tries, percent) << 16 -- options "reinsertion_passes" / "reinsertion_share"; a zero field leaves the library's own choice. */
+ * pass tries, percent) << 16 -- options "reinsertion_passes" / "reinsertion_share" -- and (percent of extra references from pre-splitting the
+ * triangles with the emptiest boxes, <= 127) << 24 -- option "presplit"; a zero field leaves the library's own choice. */
 int tb_host_scene_load(const char* pbrt_path, int bvh_builder, int load_flags, tb_host_scene** out, char* err, uint32_t err_len);
 int tb_host_scene_procedural(int kind, uint32_t target_triangles, uint32_t seed, int bvh_builder, tb_host_scene** out, char* err, uint32_t err_len);
 void tb_host_scene_free(tb_host_scene* s);

@@ -496,6 +496,87 @@ extern "C" int tbo_validate_bvh(const uint8_t* bvh, uint32_t bvhBytes, const flo
     const float EPS = 0.001f;
     if (bvhBytes < 16) return -1;
     TbBvhHeader h; memcpy(&h, bvh, 16);
+    /* A tree over PRE-SPLIT references (the build's option "presplit"; not a thing the reference's builders make) has more leaves than the scene
+     * has triangles: every leaf still holds a whole input triangle, several leaves may hold the same one, and a leaf's box bounds the PART of
+     * its triangle it stands for.  The invariants become: child boxes inside parent boxes, every node reached once, every leaf's triangle
+     * is an input triangle and its box lies inside that triangle's bounds, every input triangle is held by at least one leaf, and the boxes of
+     * a triangle's leaves together cover it (checked on 13 points of the triangle: vertices, edge midpoints, centroid, six more inside). */
+    if (h.offsetToPrimitiveMetaData > h.offsetToVertices && (h.offsetToPrimitiveMetaData - h.offsetToVertices) % 40u == 0 &&
+        (h.offsetToPrimitiveMetaData - h.offsetToVertices) / 40u > N) {
+        const uint32_t L = (h.offsetToPrimitiveMetaData - h.offsetToVertices) / 40u;
+        const uint64_t nn = 2ull * L - 1;
+        if (h.offsetToBoxes != 16 || h.offsetToVertices != 16 + 32 * nn || h.totalSize != h.offsetToPrimitiveMetaData + 12ull * L || h.totalSize > bvhBytes) return -2;
+        const TbAabbNode* nodes = (const TbAabbNode*)(bvh + 16);
+        const uint8_t* prims = bvh + h.offsetToVertices;
+        auto hash9 = [](const float* f) { uint64_t hsh = 1469598103934665603ull; for (int i = 0; i < 9; i++) { uint32_t u; memcpy(&u, f + i, 4);
+            hsh = (hsh ^ u) * 1099511628211ull; } return hsh; };
+        std::unordered_map<uint64_t, uint32_t> first; /* 9 floats -> first input triangle with them */
+        std::vector<uint32_t> same(N);                 /* triangle -> the first triangle with the same vertices */
+        for (uint32_t t = 0; t < N; t++) {
+            float f[9]; for (int k = 0; k < 3; k++) memcpy(f + 3 * k, positions + 3ull * triVertexIndex[3ull * t + k], 12);
+            auto it = first.emplace(hash9(f), t); same[t] = it.first->second;
+        }
+        std::vector<std::vector<uint32_t>> leavesOf(N); /* (first) triangle -> its leaf nodes */
+        std::vector<uint8_t> seen((size_t)nn, 0), leafSeen(L, 0);
+        struct Item { uint32_t node, depth; };
+        std::vector<Item> st; st.push_back({0, 1});
+        uint32_t maxDepth = 0; uint64_t visited = 0;
+        while (!st.empty()) {
+            Item it = st.back(); st.pop_back();
+            if (it.node >= nn) return -3;
+            if (seen[it.node]) return -4;
+            seen[it.node] = 1; visited++;
+            if (it.depth > maxDepth) maxDepth = it.depth;
+            const TbAabbNode& nd = nodes[it.node];
+            float pmin[3], pmax[3];
+            for (int a = 0; a < 3; a++) { pmin[a] = nd.center[a] - nd.halfDim[a]; pmax[a] = nd.center[a] + nd.halfDim[a]; }
+            if (nd.flags & TB_BVH_LEAF_FLAG) {
+                const uint32_t k = nd.flags & TB_BVH_INDEX_MASK;
+                if (k >= L || leafSeen[k]) return -5;
+                leafSeen[k] = 1;
+                float f[9]; memcpy(f, prims + 40ull * k + 4, 36);
+                auto q = first.find(hash9(f));
+                if (q == first.end()) return -7;
+                for (int a = 0; a < 3; a++) { /* the part's box lies inside its triangle's bounds */
+                    const float tmin = std::min(f[a], std::min(f[3 + a], f[6 + a])), tmax = std::max(f[a], std::max(f[3 + a], f[6 + a]));
+                    if (!(pmin[a] + EPS >= tmin - EPS && pmax[a] - EPS <= tmax + EPS)) return -6;
+                }
+                leavesOf[q->second].push_back(it.node);
+            } else {
+                uint32_t ch[2] = {nd.flags & TB_BVH_INDEX_MASK, nd.rightNodeIndex};
+                for (int c = 0; c < 2; c++) {
+                    if (ch[c] == 0 || ch[c] >= nn) return -8;
+                    const TbAabbNode& cn = nodes[ch[c]];
+                    for (int a = 0; a < 3; a++) {
+                        float cmin = cn.center[a] - cn.halfDim[a], cmax = cn.center[a] + cn.halfDim[a];
+                        if (!(pmin[a] - EPS <= cmin && pmax[a] + EPS >= cmax)) return -9;
+                    }
+                    st.push_back({ch[c], it.depth + 1});
+                }
+            }
+        }
+        if (visited != nn) return -10;
+        static const float W[13][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {.5f, .5f, 0}, {0, .5f, .5f}, {.5f, 0, .5f}, {1 / 3.f, 1 / 3.f, 1 / 3.f}, {.6f, .2f, .2f},
+            {.2f, .6f, .2f}, {.2f, .2f, .6f}, {.8f, .1f, .1f}, {.1f, .8f, .1f}, {.1f, .1f, .8f}};
+        for (uint32_t t = 0; t < N; t++) {
+            const std::vector<uint32_t>& lv = leavesOf[same[t]];
+            if (lv.empty()) return -11;
+            if (same[t] != t) continue;
+            float f[9]; for (int k = 0; k < 3; k++) memcpy(f + 3 * k, positions + 3ull * triVertexIndex[3ull * t + k], 12);
+            for (int w = 0; w < 13; w++) {
+                float pt[3]; for (int a = 0; a < 3; a++) pt[a] = W[w][0] * f[a] + W[w][1] * f[3 + a] + W[w][2] * f[6 + a];
+                bool in = false;
+                for (uint32_t nodeIdx : lv) {
+                    const TbAabbNode& nd = nodes[nodeIdx]; bool ok = true;
+                    for (int a = 0; a < 3; a++) if (!(pt[a] + EPS >= nd.center[a] - nd.halfDim[a] && pt[a] - EPS <= nd.center[a] + nd.halfDim[a])) ok = false;
+                    if (ok) { in = true; break; }
+                }
+                if (!in) return -12; /* a point of the triangle that none of its parts' boxes holds */
+            }
+        }
+        if (maxDepthOut) *maxDepthOut = maxDepth;
+        return 0;
+    }
     const uint64_t numNodes = 2ull * N - 1;
     if (h.offsetToBoxes != 16 || h.offsetToVertices != 16 + 32 * numNodes || h.offsetToPrimitiveMetaData != h.offsetToVertices + 40ull * N ||
         h.totalSize != h.offsetToPrimitiveMetaData + 12ull * N || h.totalSize > bvhBytes) return -2;

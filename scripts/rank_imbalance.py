@@ -100,8 +100,9 @@ for key in args.legs.split(","):
     b.load_workload(key)
     tb.SetOption("overlap_launches", 2)
     print("%s: loaded in %.1f s" % (key, time.time() - t0), flush=True)
-    rows = sweep(W, H, SPP, s, bench.TILE)
-    entry = {"workload": "%s %dx%d %dspp depth%d" % (bench.scene_label(w["scene"]), W, H, SPP, w["depth"]), "tile": bench.TILE,
+    tile = w.get("tile", bench.TILE)          # the deal bench.py's scale_<leg> uses for this workload
+    rows = sweep(W, H, SPP, s, tile)
+    entry = {"workload": "%s %dx%d %dspp depth%d" % (bench.scene_label(w["scene"]), W, H, SPP, w["depth"]), "tile": tile,
              "deal": "round-robin (tile t -> rank t % N)", "kernel_variant": bench.VARIANTS[tb.GetOption("last_variant")]}
     entry.update(rows)
     top = rows.get("world%d" % max(worlds))
@@ -111,7 +112,7 @@ for key in args.legs.split(","):
         for t in [int(x) for x in args.tiles.split(",")]:
             entry["tile%d" % t] = sweep(W, H, SPP, s, t)
         worlds = keep
-    elif top and top["max_over_mean"] > args.imbalance_threshold:
+    elif top and top["max_over_mean"] > args.imbalance_threshold and tile != 32:
         print("   max/mean %.3f > %.2f: trying 32x32 tiles" % (top["max_over_mean"], args.imbalance_threshold), flush=True)
         entry["tile32"] = sweep(W, H, SPP, s, 32)
     result[key] = entry

@@ -59,8 +59,9 @@ for rep in range(3):
     assert rc == 0, rc
     start, dry, drawn = log[:, cap - 1].astype(np.float64), log[:, cap - 2].astype(np.float64), log[:, cap - 7]
     wave_end = log[:, cap - 6:cap - 2].astype(np.float64)
+    stat = log[:, cap - 11:cap - 7][:, ::-1].astype(np.float64)      # [-8] bind ticks, [-9] parked lane-trips, [-10] out-of-line resolves, [-11] binds
     live = (start > 0) & (wave_end.max(axis=1) > 0)
-    start, dry, wave_end, drawn = start[live], dry[live], wave_end[live], drawn[live]
+    start, dry, wave_end, drawn, stat = start[live], dry[live], wave_end[live], drawn[live], stat[live]
     end = wave_end.max(axis=1)
     t0, t1 = start.min(), end.max()
     tick = 1e-5  # ms per 100-MHz tick
@@ -72,14 +73,23 @@ for rep in range(3):
     # lane-time lost at the end: dead workgroups' slots until the launch ends (only workgroups that ended after the first dry lane count: the
     # ones before were replaced by the grid's second half) + half of each workgroup's own drain
     lost = np.where(end >= (t0 + (first_dry or 0) / tick), (t1 - end), 0.0).sum() * tick + 0.5 * d2e.sum()
-    resident = int(((start - t0) * tick < 0.05).sum())
+    early = (start - t0) * tick < 0.05          # the resident half of the 2x grid; the rest start in slots the first leavers free and find the lists empty
+    resident = int(early.sum())
+    res_end = (t1 - end[early]) * tick
+    res_drawn = drawn[early].astype(np.float64)
+    body_rate = res_drawn.sum() / max(first_dry or launch, 1e-9)      # samples per ms while every lane had work (an upper bound: some were drawn later)
     pct = lambda v: [round(float(np.percentile(v, q)), 3) for q in (10, 50, 90, 99, 100)] if len(v) else None  # noqa: E731
     r = {"launch_ms": round(launch, 3), "kernel_ms_hip_events": round(tb.GetOption("last_kernel_us") / 1e3, 3), "frames_per_launch": int(frames),
          "workgroups": int(live.sum()), "resident_at_start": resident, "first_dry_ms": None if first_dry is None else round(first_dry, 3),
          "first_exit_ms": round(float((end.min() - t0) * tick), 3), "tail_ms": None if first_dry is None else round(launch - first_dry, 3),
          "idle_lane_ms_share": round(float(lost / max(resident, 1) / launch), 4),
          "wg_dry_to_exit_ms_p10_50_90_99_max": pct(d2e), "wg_exit_before_launch_end_ms_p10_50_90_99_max": pct(spread),
-         "samples_per_workgroup_p10_50_90_99_max": pct(drawn.astype(np.float64)), "workgroups_started_late": int(((start - t0) * tick >= 0.05).sum())}
+         "resident_exit_before_launch_end_ms_p10_50_90_99_max": pct(res_end), "resident_samples_min_p10_50_90_max": [float(res_drawn.min())] + pct(res_drawn)[:3] + [float(res_drawn.max())],
+         "launch_if_no_tail_ms": round(float(res_drawn.sum() / body_rate), 3) if first_dry else None,
+         "workgroups_started_late": int((~early).sum()),
+         "binds_per_resident_wg": round(float(stat[early, 3].mean()), 1), "bind_us_mean": round(float(stat[early, 0].sum() / max(stat[early, 3].sum(), 1) * 0.01), 2),
+         "bind_ms_per_resident_wg": round(float(stat[early, 0].mean() * tick), 3), "parked_lane_trips_per_resident_wg": round(float(stat[early, 1].mean()), 1),
+         "slow_resolves_per_resident_wg": round(float(stat[early, 2].mean()), 1)}
     rows.append(r)
     print(json.dumps(r), flush=True)
 doc = {"leg": a.leg, "world": a.world, "rank": a.rank, "spp": SPP, "opts": a.opt, "variant": bench.VARIANTS[tb.GetOption("last_variant")],

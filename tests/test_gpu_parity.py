@@ -273,6 +273,27 @@ def test_procedural_glass_mirror_plastic_bit_exact(gpu_tb, settings, kind):
     assert np.array_equal(bits(gpu_tb.ReadAccumulation()), bits(ref))
 
 
+def test_presplit_tree_bit_exact(gpu_tb, settings):
+    """Option presplit (round 6): a tree whose leaves outnumber the triangles (the largest, emptiest triangle boxes cut into parts; a part's leaf
+    holds the whole triangle) -- the kernels walk it like any other, the picture is the oracle's on the same image, and the same bits as the tree
+    without."""
+    W, H, F = 96, 64, 3
+    s = copy.copy(settings); s.MaxBounces = 6
+    pics = []
+    for pre in (0, 30):
+        gpu_tb.SetOption("bvh_builder", 1); gpu_tb.SetOption("presplit", pre)
+        try:
+            gpu_tb.LoadProcedural(1, 40000, 99)
+        finally:
+            gpu_tb.SetOption("bvh_builder", 0); gpu_tb.SetOption("presplit", 0)
+        gpu_tb.InvalidateHistory(); gpu_tb.Render(W, H, F, s, 0.0)
+        pics.append(gpu_tb.ReadAccumulation())
+        assert np.array_equal(bits(pics[-1]), bits(_oracle(gpu_tb, W, H, F, s)["output"]))
+        leaves = (gpu_tb.HostSceneView().bvhBytes - 16 + 32) // 116
+        assert (leaves > gpu_tb.SceneInfo().numTriangles) == (pre > 0)
+    assert np.array_equal(bits(pics[0]), bits(pics[1]))
+
+
 def test_all_kernel_variants_agree(gpu_tb, settings):
     """Feature-stripped kernel variants only remove branches the scene can never take."""
     gpu_tb.LoadScene(CORNELL)
@@ -866,6 +887,7 @@ def test_bench_multi_rank_step_on_one_gpu(tmp_path):
     assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "tiles2" and out["config"]["tile"] == 64
     assert out["config"]["assembled_frame_equals_single_gpu"] is True
     assert out["value"] > 0 and out["scaling"] == "strong"
+    assert out["parity"]["ok"] is True and out["parity"]["bit_equal"] is True      # the assembled frame of the last timed step against the oracle (strips)
     # the per-stage breakdown the driver's SCALE record needs to say where a step's time goes, and how many ranks the collective saw
     sb = out["scale_breakdown"]
     assert out["rccl_ranks"] == 2 and out["collective_backend"] == "gloo"
@@ -883,6 +905,12 @@ def test_bench_multi_rank_step_on_one_gpu(tmp_path):
         sl = out["scale_" + leg]
         assert sl["n_gpus"] == 2 and sl["value"] > 0 and sl["ms_per_step"] > 0 and sl["steps"] >= 1 and "3840x2160" in sl["workload"]
         assert sl["assembled_frame_equals_single_gpu"] is True, leg
+        # the leg is quoted on a 32-spp step (the configurations are 256 / 1024 spp), with the 8-spp short step beside it; the frame rank 0
+        # assembled in the last timed step passed the parity gate against the oracle; the deal is the workload's own tile size
+        assert "%dspp" % bench_mod.SCALE_SPP in sl["workload"] and sl["at_short_steps"]["spp"] == bench_mod.SCALE_SHORT_SPP
+        assert sl["at_short_steps"]["value"] > 0 and sl["at_short_steps"]["ms_per_step"] < sl["ms_per_step"]
+        assert sl["parity"]["ok"] is True and sl["parity"]["bit_equal"] is True and sl["parity"]["frames"] == bench_mod.SCALE_SPP
+        assert sl["tile"] == bench_mod.WORKLOADS[leg].get("tile", bench_mod.TILE)
         sbl = sl["scale_breakdown"]
         assert all(sbl[k] > 0 for k in ("render_ms", "pack_ms", "gather_ms", "unpack_ms")) and sbl["render_max_over_mean"] >= 1.0
         assert sl["bvh_builder"] == bench_mod.builder_label(bench_mod.WORKLOADS[leg])   # the same tree as the N = 1 line's roofline_<leg>

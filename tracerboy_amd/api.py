@@ -187,7 +187,7 @@ class HostScene:
     """Host-only LoadScene (parse + convert + BVH build): no GPU needed, renders nothing."""
 
     def __init__(self, path=None, procedural=None, bvh_builder=0, flatten_instances=True, flip_texture_uvs=True, reinsertion_passes=None,
-                 reinsertion_share=None):
+                 reinsertion_share=None, presplit=None):
         self._h = C.c_void_p()
         err = C.create_string_buffer(512)
         # the builder word of include/tracerboy_hip.h: builder | (passes + 1) << 8 | share << 16
@@ -195,6 +195,8 @@ class HostScene:
             bvh_builder |= (int(reinsertion_passes) + 1) << 8
         if reinsertion_share is not None:
             bvh_builder |= int(reinsertion_share) << 16
+        if presplit is not None:
+            bvh_builder |= min(int(presplit), 127) << 24
         if path is not None:
             rc = lib().tb_host_scene_load(os.fsencode(path), bvh_builder, (1 if flatten_instances else 0) | (0 if flip_texture_uvs else 2), C.byref(self._h), err, 512)
         else:

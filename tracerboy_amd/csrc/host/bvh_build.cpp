@@ -21,6 +21,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cmath>
 #include <cstring>
 #include <cstdlib>
 #include <exception>
@@ -32,14 +33,27 @@ namespace tbhost {
 
 namespace {
 
+struct Bounds { tb3 mn, mx; };
+
 struct Tree {
-    uint32_t N = 0;
-    std::vector<uint32_t> order;       /* sorted position k -> input triangle */
+    uint32_t N = 0;                    /* leaves = references (one per triangle unless the SAH builder pre-split some, presplitReferences) */
+    std::vector<uint32_t> order;       /* sorted position k -> reference (= input triangle where nothing was pre-split) */
     std::vector<uint32_t> left, right; /* children of inner node i (node ids; leaf k = N-1+k) */
+    /* pre-split references (option "presplit", builder 1): reference r is the part of triangle refTri[r] inside refBox[r]; both empty = reference r is
+     * triangle r with its own bounds */
+    std::vector<uint32_t> refTri; std::vector<Bounds> refBox;
 };
 
 inline tb3 P(const HostScene& s, uint32_t tri, int k) { const float* p = &s.positions[3ull * s.triVertexIndex[3ull * tri + k]];
     return tb3_make(p[0], p[1], p[2]); }
+inline uint32_t triOfRef(const Tree& t, uint32_t r) { return t.refTri.empty() ? r : t.refTri[r]; }
+inline Bounds boundsOfRef(const HostScene& s, const Tree& t, uint32_t r)
+{
+    if (!t.refBox.empty()) return t.refBox[r];
+    Bounds b; b.mn = tb3_splat(3.402823466e+38f); b.mx = tb3_splat(-3.402823466e+38f);
+    for (int k = 0; k < 3; k++) { const tb3 v = P(s, r, k); b.mn = tb3_min(b.mn, v); b.mx = tb3_max(b.mx, v); }
+    return b;
+}
 
 template <class F> void parallelFor(size_t n, F f)
 {
@@ -117,7 +131,6 @@ void buildLbvh(const HostScene& s, Tree& t)
 }
 
 /* ---- binned SAH ---------------------------------------------------------------------------- */
-struct Bounds { tb3 mn, mx; };
 inline Bounds emptyB() { Bounds b; b.mn = tb3_splat(3.402823466e+38f); b.mx = tb3_splat(-3.402823466e+38f); return b; }
 inline void grow(Bounds& b, tb3 p) { b.mn = tb3_min(b.mn, p); b.mx = tb3_max(b.mx, p); }
 inline void grow(Bounds& b, const Bounds& o) { b.mn = tb3_min(b.mn, o.mn); b.mx = tb3_max(b.mx, o.mx); }
@@ -132,7 +145,7 @@ void buildSah(const HostScene& s, Tree& t)
 {
     const uint32_t N = t.N;
     std::vector<Bounds> tb(N); std::vector<tb3> cen(N);
-    parallelFor(N, [&](size_t a, size_t z) { for (size_t i = a; i < z; i++) { Bounds b = emptyB(); for (int k = 0; k < 3; k++) grow(b, P(s, (uint32_t)i, k));
+    parallelFor(N, [&](size_t a, size_t z) { for (size_t i = a; i < z; i++) { const Bounds b = boundsOfRef(s, t, (uint32_t)i);
         tb[i] = b; cen[i] = (b.mn + b.mx) * 0.5f; } });
     std::vector<uint32_t> ids(N); for (uint32_t i = 0; i < N; i++) ids[i] = i;
     if (N >= 2) { t.left.assign(N - 1, 0); t.right.assign(N - 1, 0); }
@@ -233,6 +246,124 @@ void buildSah(const HostScene& s, Tree& t)
     t.order = ids; /* leaf k is the k-th triangle from the left */
 }
 
+/* ---- pre-split references (option "presplit" = percent of extra references allowed; builder 1) ---------------------------------------
+ * A BVH with one triangle per leaf pays for every large or diagonal triangle with a box that is mostly empty, and so do all its
+ * ancestors.  Before the top-down build the references whose boxes hold the most EMPTY surface are cut in two -- the triangle is clipped to
+ * both halves and each half becomes a reference of its own with the clipped part's box (Ernst & Greiner 2007, "Early split clipping"; the
+ * choice of what to cut and where after Karras & Aila 2013: largest box surface beyond what the clipped polygon needs first, the plane the
+ * coarsest one of a power-of-two grid over the scene that crosses the box, so that neighbouring triangles are cut by the same planes) --
+ * until `percent` % more references exist than triangles.  The builder then sees N' references; the leaves hold the WHOLE triangle
+ * (vertices and indices copied per reference), only their boxes are the parts': a ray meets the triangle in whichever part's box it enters,
+ * tests it like any other, and a second part's test of the same triangle finds t0 == best.t and commits nothing (`t0 < best`,
+ * TraverseFunction.hlsli:297).  Closest hits are those of any other tree over the same triangles; the oracle walks the same image.
+ * MEASURED AND NOT USED BY ANY WORKLOAD (round 6, docs/experiments/r6.md): pictures stay the same bits and triangle tests fall (vw-van 6.69 ->
+ * 4.99 per sample) but box tests RISE (55.5 -> 61.2; Teapot 49.9 -> 64.1 from 18 extra references): the large triangles such a cut removes from
+ * the top of the tree are what gives a near-first closest-hit walk its early, tight `closest`.  Off by default (option presplit = 0). */
+struct Poly { int n; double v[10][3]; };
+inline void clipPoly(Poly& p, int axis, double pos, bool keepBelow)
+{
+    Poly o; o.n = 0;
+    for (int i = 0; i < p.n; i++) {
+        const double* a = p.v[i]; const double* b = p.v[(i + 1) % p.n];
+        const bool ia = keepBelow ? a[axis] <= pos : a[axis] >= pos, ib = keepBelow ? b[axis] <= pos : b[axis] >= pos;
+        if (ia && o.n < 10) { memcpy(o.v[o.n++], a, 24); }
+        if (ia != ib && o.n < 10) {
+            const double t = (pos - a[axis]) / (b[axis] - a[axis]);
+            for (int k = 0; k < 3; k++) o.v[o.n][k] = a[k] + t * (b[k] - a[k]);
+            o.v[o.n][axis] = pos; o.n++;
+        }
+    }
+    p = o;
+}
+inline Poly polyOfRef(const HostScene& s, uint32_t tri, const Bounds& b)
+{
+    Poly p; p.n = 3;
+    for (int k = 0; k < 3; k++) { const tb3 v = P(s, tri, k); p.v[k][0] = v.x; p.v[k][1] = v.y; p.v[k][2] = v.z; }
+    for (int a = 0; a < 3 && p.n >= 3; a++) { clipPoly(p, a, tb3_get(b.mn, a), false); if (p.n >= 3) clipPoly(p, a, tb3_get(b.mx, a), true); }
+    return p;
+}
+/* bounds of a clipped polygon, rounded outwards and widened by a few ulps of the coordinates (the clip points are computed, not given),
+ * inside `within` */
+inline Bounds boundsOfPoly(const Poly& p, const Bounds& within)
+{
+    double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
+    for (int i = 0; i < p.n; i++) for (int k = 0; k < 3; k++) { mn[k] = std::min(mn[k], p.v[i][k]); mx[k] = std::max(mx[k], p.v[i][k]); }
+    Bounds b;
+    float lo[3], hi[3];
+    for (int k = 0; k < 3; k++) {
+        const double pad = 4.0 * 1.1920929e-7 * std::max(std::fabs(mn[k]), std::fabs(mx[k]));
+        lo[k] = std::nextafterf((float)(mn[k] - pad), -3.402823466e+38f); hi[k] = std::nextafterf((float)(mx[k] + pad), 3.402823466e+38f);
+    }
+    b.mn = tb3_max(tb3_make(lo[0], lo[1], lo[2]), within.mn); b.mx = tb3_min(tb3_make(hi[0], hi[1], hi[2]), within.mx);
+    return b;
+}
+inline double idealArea(const Poly& p) /* surface of the flattest box a polygon of this area vector could have: twice the sum of its projections */
+{
+    double ax = 0, ay = 0, az = 0;
+    for (int i = 1; i + 1 < p.n; i++) {
+        const double e1[3] = {p.v[i][0] - p.v[0][0], p.v[i][1] - p.v[0][1], p.v[i][2] - p.v[0][2]}, e2[3] = {p.v[i + 1][0] - p.v[0][0], p.v[i + 1][1] - p.v[0][1],
+            p.v[i + 1][2] - p.v[0][2]};
+        ax += e1[1] * e2[2] - e1[2] * e2[1]; ay += e1[2] * e2[0] - e1[0] * e2[2]; az += e1[0] * e2[1] - e1[1] * e2[0];
+    }
+    return std::fabs(ax) + std::fabs(ay) + std::fabs(az);
+}
+
+void presplitReferences(const HostScene& s, Tree& t, int percent)
+{
+    const uint32_t N = t.N;
+    const uint64_t budget = (uint64_t)N * (uint64_t)std::max(percent, 0) / 100u;
+    if (!budget || N < 2) return;
+    t.refTri.resize(N); t.refBox.resize(N);
+    Bounds scene = emptyB();
+    for (uint32_t i = 0; i < N; i++) { t.refTri[i] = i; Bounds b = emptyB(); for (int k = 0; k < 3; k++) grow(b, P(s, i, k)); t.refBox[i] = b; grow(scene, b); }
+    const tb3 sext = tb3_max(scene.mx - scene.mn, tb3_splat(1e-30f));
+    auto areaD = [](const Bounds& b) { const double x = (double)b.mx.x - b.mn.x, y = (double)b.mx.y - b.mn.y, z = (double)b.mx.z - b.mn.z; return 2.0 * (x * y + y * z + z * x); };
+    /* what a cut can remove: the box's surface beyond the clipped polygon's own */
+    auto priority = [&](uint32_t r) { const Poly p = polyOfRef(s, t.refTri[r], t.refBox[r]); return p.n < 3 ? 0.0 : areaD(t.refBox[r]) - idealArea(p); };
+    struct Item { double pri; uint32_t ref; bool operator<(const Item& o) const { return pri < o.pri || (pri == o.pri && ref > o.ref); } };
+    std::vector<Item> heap; heap.reserve(N + (size_t)budget * 2);
+    double totalArea = 0;
+    for (uint32_t i = 0; i < N; i++) { totalArea += areaD(t.refBox[i]); heap.push_back(Item{priority(i), i}); }
+    std::make_heap(heap.begin(), heap.end());
+    /* Worth a reference of its own (and an inner node above it, whose box every ray through the neighbourhood then tests): a box many times
+     * the scene's mean triangle box of which a good part is empty.  Cutting ordinary triangles only makes the tree deeper: with a plain budget
+     * of +10 % the Teapot went from 49.9 to 68.7 box tests per sample. */
+    constexpr double kBig = 16.0, kEmpty = 0.3;
+    const double bigArea = kBig * totalArea / (double)N;
+    uint64_t made = 0;
+    while (made < budget && !heap.empty()) {
+        std::pop_heap(heap.begin(), heap.end()); const Item it = heap.back(); heap.pop_back();
+        if (!(it.pri > 0.0)) break;
+        if (!(areaD(t.refBox[it.ref]) > bigArea && it.pri > kEmpty * areaD(t.refBox[it.ref]))) continue;
+        const Bounds b = t.refBox[it.ref];
+        const tb3 ext = b.mx - b.mn;
+        int axis = (ext.x >= ext.y && ext.x >= ext.z) ? 0 : (ext.y >= ext.z ? 1 : 2);
+        /* the coarsest plane of the scene's power-of-two grid strictly inside the box on that axis (the midpoint if none down to 2^-30) */
+        const double lo = tb3_get(b.mn, axis), hi = tb3_get(b.mx, axis), s0 = tb3_get(scene.mn, axis), se = tb3_get(sext, axis);
+        double plane = 0.5 * (lo + hi);
+        for (int level = 1; level <= 30; level++) {
+            const double cell = se / (double)(1u << level);
+            const double k = std::floor((lo - s0) / cell) + 1.0, cand = s0 + k * cell;
+            if (cand > lo && cand < hi) { plane = cand; break; }
+        }
+        const float pf = (float)plane;
+        if (!(pf > tb3_get(b.mn, axis) && pf < tb3_get(b.mx, axis))) continue; /* too thin to cut in float */
+        Poly whole = polyOfRef(s, t.refTri[it.ref], b);
+        if (whole.n < 3) continue;
+        Poly L = whole, R = whole; clipPoly(L, axis, (double)pf, true); clipPoly(R, axis, (double)pf, false);
+        if (L.n < 3 || R.n < 3) continue;
+        Bounds wl = b, wr = b;
+        if (axis == 0) { wl.mx.x = pf; wr.mn.x = pf; } else if (axis == 1) { wl.mx.y = pf; wr.mn.y = pf; } else { wl.mx.z = pf; wr.mn.z = pf; }
+        const Bounds bl = boundsOfPoly(L, wl), br = boundsOfPoly(R, wr);
+        const uint32_t nr = (uint32_t)t.refTri.size();
+        t.refBox[it.ref] = bl; t.refTri.push_back(t.refTri[it.ref]); t.refBox.push_back(br); made++;
+        heap.push_back(Item{areaD(bl) - idealArea(L), it.ref}); std::push_heap(heap.begin(), heap.end());
+        heap.push_back(Item{areaD(br) - idealArea(R), nr}); std::push_heap(heap.begin(), heap.end());
+    }
+    if (!made) { t.refTri.clear(); t.refBox.clear(); return; }
+    t.N = (uint32_t)t.refTri.size();
+}
+
 /* ---- reinsertion passes (after Bittner, Hapala & Havran, "Fast insertion-based optimization of bounding volume
  * hierarchies", 2013): every subtree in turn is cut out and put back where the sum of the inner nodes' surface areas -- what
  * a random ray pays in box tests -- grows least, until a pass gains little.  The place is found by a branch-and-bound descent
@@ -250,7 +381,7 @@ void optimizeByReinsertion(const HostScene& s, Tree& t, int maxPasses, double mi
     std::vector<Bounds> box(M); std::vector<float> sa(M); std::vector<uint32_t> parent(M, NONE); std::vector<uint16_t> height(M, 0);
     auto isLeaf = [&](uint32_t x) { return x >= N - 1; };
     auto unite = [&](const Bounds& a, const Bounds& b) { Bounds u = a; grow(u, b); return u; };
-    for (uint32_t k = 0; k < N; k++) { Bounds b = emptyB(); for (int v = 0; v < 3; v++) grow(b, P(s, t.order[k], v));
+    for (uint32_t k = 0; k < N; k++) { Bounds b = boundsOfRef(s, t, t.order[k]);
         b.mn = tb3_min(b.mn, b.mx - tb3_splat(0.001f)); box[N - 1 + k] = b; sa[N - 1 + k] = area(b); }
     for (uint32_t i = 0; i + 1 < N; i++) { parent[t.left[i]] = i; parent[t.right[i]] = i; }
     auto pull = [&](uint32_t x) { const uint32_t l = t.left[x], r = t.right[x]; box[x] = unite(box[l], box[r]); sa[x] = area(box[x]);
@@ -419,7 +550,9 @@ void BuildBvhSingle(HostScene& s, int builder)
     if (N64 == 0) throw std::runtime_error("BuildBvh: no triangles");
     if (N64 > 0x00ffffffull) throw std::runtime_error("BuildBvh: more than 2^24-1 triangles does not fit the 24-bit node indices of the reference layout");
     Tree t; t.N = (uint32_t)N64;
-    const uint32_t N = t.N;
+    if (builder == 1 && s.presplitPercent > 0) presplitReferences(s, t, s.presplitPercent);
+    if (t.N > 0x00ffffffu) throw std::runtime_error("BuildBvh: more than 2^24-1 references after pre-splitting (lower option presplit)");
+    const uint32_t N = t.N; /* leaves: references (= triangles unless pre-split) */
     if (builder == 1) {
         buildSah(s, t);
         const int passes = s.reinsertionPasses >= 0 ? s.reinsertionPasses : (N <= 4096 ? 16 : 3); /* option "reinsertion_passes" */
@@ -440,7 +573,7 @@ void BuildBvhSingle(HostScene& s, int builder)
     TbPrimitiveMeta* meta = (TbPrimitiveMeta*)(s.bvhA.data() + offMeta);
     s.trisB.resize(N);
     for (uint32_t k = 0; k < N; k++) {
-        uint32_t tri = t.order[k];
+        uint32_t tri = triOfRef(t, t.order[k]);
         TbPrimitive p; p.PrimitiveType = 1;
         TbTriB tbv;
         for (int v = 0; v < 3; v++) {
@@ -475,9 +608,8 @@ void BuildBvhSingle(HostScene& s, int builder)
         uint32_t x = walk[w];
         if (x >= N - 1) {
             uint32_t k = x - (N - 1);
-            const TbTriB& q = s.trisB[k];
-            tb3 v0 = tb3_make(q.v0[0], q.v0[1], q.v0[2]), v1 = tb3_make(q.v1[0], q.v1[1], q.v1[2]), v2 = tb3_make(q.v2[0], q.v2[1], q.v2[2]);
-            tb3 mn = tb3_min(tb3_min(v0, v1), v2), mx = tb3_max(tb3_max(v0, v1), v2);
+            const Bounds rb = boundsOfRef(s, t, t.order[k]); /* the triangle's own bounds, or the pre-split part's */
+            tb3 mn = rb.mn, mx = rb.mx;
             mn = tb3_min(mn, mx - tb3_splat(0.001f));
             put(x, mn, mx, k | TB_BVH_LEAF_FLAG, 1);
             count[x] = 1;
@@ -625,7 +757,7 @@ void BuildBvhWith(HostScene& s, const std::function<void(HostScene&)>& single, c
     for (size_t b = 0; b < s.blas.size(); b++) {
         HostScene::Blas& bl = s.blas[b];
         HostScene tmp;
-        tmp.reinsertionPasses = s.reinsertionPasses; tmp.reinsertionShare = s.reinsertionShare;
+        tmp.reinsertionPasses = s.reinsertionPasses; tmp.reinsertionShare = s.reinsertionShare; tmp.presplitPercent = s.presplitPercent;
         tmp.positions.swap(s.positions);
         tmp.triVertexIndex.assign(s.triVertexIndex.begin() + 3ull * bl.firstTri, s.triVertexIndex.begin() + 3ull * (bl.firstTri + bl.numTris));
         tmp.triGeometry.assign(s.triGeometry.begin() + bl.firstTri, s.triGeometry.begin() + bl.firstTri + bl.numTris);
@@ -638,7 +770,7 @@ void BuildBvhWith(HostScene& s, const std::function<void(HostScene&)>& single, c
         allA.insert(allA.end(), tmp.bvhA.begin(), tmp.bvhA.end());
         const uint32_t nodeBase = (uint32_t)allNodes.size(), triBase = (uint32_t)allTris.size();
         auto rebase = [&](uint32_t ref) { return (ref & TB_BVH_LEAF_FLAG) ? (TB_BVH_LEAF_FLAG | ((ref & ~TB_BVH_LEAF_FLAG) + triBase)) : ref + nodeBase; };
-        if (bl.numTris > 1) for (TbNodeB nd : tmp.nodesB) { nd.left = rebase(nd.left); nd.right = rebase(nd.right); allNodes.push_back(nd); }
+        if (tmp.trisB.size() > 1) for (TbNodeB nd : tmp.nodesB) { nd.left = rebase(nd.left); nd.right = rebase(nd.right); allNodes.push_back(nd); }
         allTris.insert(allTris.end(), tmp.trisB.begin(), tmp.trisB.end());
         bl.rootRefB = rebase(tmp.rootRefB); bl.depth = tmp.bvhMaxDepth;
         maxBlasDepth = std::max(maxBlasDepth, bl.depth);

@@ -637,7 +637,7 @@ int tb_unpack_gathered_host(uint32_t W, uint32_t H, uint32_t world, uint32_t tw,
 int tb_set_option(tb_context* c, const char* name, int64_t v)
 {
     if (!c || !name) return TB_E_INVALID;
-    static const char* known[] = {"reinsertion_share", "reinsertion_passes", "compact_stamp_bits", "camera_constants", "texture_use_hint", "compact_hits", "first_bounce", "primary_prepass", "pipeline", "count_rays", "bvh_builder", "flatten_instances", "aov", "scene_in_lds", "lds_scene_budget",
+    static const char* known[] = {"reinsertion_share", "reinsertion_passes", "presplit", "compact_stamp_bits", "debug_profile_groups", "camera_constants", "texture_use_hint", "compact_hits", "first_bounce", "primary_prepass", "pipeline", "count_rays", "bvh_builder", "flatten_instances", "aov", "scene_in_lds", "lds_scene_budget",
         "force_full_variant", "wavefront_paths", "wavefront_grid", "wavefront_segment", "pooled_paths", "pooled_samples", "pooled_profile", "park_min",
         "alpha_test", "node_order", "node_order_top_levels", "frame_group", "overlap_launches", "high_occupancy", "stack_lds_cap", "stack_overflow_max",
         "flip_texture_uvs", "wavefront_sort", "banded_items", "node_layout", "wavefront_refill",
@@ -756,13 +756,14 @@ struct tb_host_scene { HostScene scene; };
 
 static int hostFail(char* err, uint32_t n, int code, const std::string& m) { if (err && n) { strncpy(err, m.c_str(), n - 1); err[n - 1] = 0; } return code; }
 
-/* bvh_builder of the host-scene entry points: builder | (reinsertion passes + 1) << 8 | reinsertion share (percent) << 16; a zero field =
+/* bvh_builder of the host-scene entry points: builder | (reinsertion passes + 1) << 8 | reinsertion share (percent) << 16 | presplit (percent, <= 127) << 24; a zero field =
  * the library's own choice (options "reinsertion_passes" / "reinsertion_share" of a context) */
 static void applyBuilderWord(HostScene& s, int word)
 {
-    const int passes = (word >> 8) & 0xff, share = (word >> 16) & 0xff;
+    const int passes = (word >> 8) & 0xff, share = (word >> 16) & 0xff, presplit = (word >> 24) & 0x7f;
     if (passes) s.reinsertionPasses = passes - 1;
     if (share) s.reinsertionShare = share;
+    if (presplit) s.presplitPercent = presplit;
 }
 
 int tb_host_scene_load(const char* path, int builder, int loadFlags, tb_host_scene** out, char* err, uint32_t errLen)

@@ -321,7 +321,9 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
         tg.aovNormals = (TbFloat4*)c->aov[2].p; tg.aovWorldPos0 = (TbFloat4*)c->aov[3].p; tg.aovWorldPos1 = (TbFloat4*)c->aov[4].p;
         tg.aovCustom = (TbFloat4*)c->aov[5].p; tg.aovDepth = (float*)c->aov[6].p; tg.aovEmissive = (TbFloat4*)c->aov[7].p;
     }
-    if (count) { ensure(c->rayStats, 21 * 8); if (c->samplesRendered == 0) HIP_TRY(hipMemsetAsync(c->rayStats.p, 0, 21 * 8, c->stream));
+    /* (debug_profile_groups: the counters' buffer handed to a frame-group launch -- only a library built with -DTB_EXP_PROFILE_GROUPS has a kernel
+     * that writes them, scripts/c2_instruction_mix.py; the shipped frame-group kernels carry no counters and ignore the pointer) */
+    if (count || opt("debug_profile_groups", 0)) { ensure(c->rayStats, 21 * 8); if (c->samplesRendered == 0) HIP_TRY(hipMemsetAsync(c->rayStats.p, 0, 21 * 8, c->stream));
         tg.rayStats = (unsigned long long*)c->rayStats.p; }
     TbPerFrameConstants pf;
     MakeFrameConstants(c->scene, c->camera, s, c->samplesRendered, timeSeed, c->selX, c->selY, pf);

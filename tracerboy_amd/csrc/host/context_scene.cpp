@@ -280,6 +280,7 @@ void finalizeScene(tb_context* c, bool build)
     const int64_t builder = opt("bvh_builder", 0);
     const bool twoLevel = !s.instances.empty();
     s.reinsertionPasses = (int)opt("reinsertion_passes", -1); s.reinsertionShare = (int)opt("reinsertion_share", 100);
+    s.presplitPercent = (int)std::max<int64_t>(0, std::min<int64_t>(400, opt("presplit", 0)));
     if (build) {
     /* every bottom-level structure and the top level on the GPU (GpuBVH2Builder.cpp:498-501: the same passes, no treelets at the top) */
     if (twoLevel && (builder == 2 || builder == 4))

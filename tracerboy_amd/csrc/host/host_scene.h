@@ -53,6 +53,9 @@ struct HostScene {
      * one pass over everything 14 521 in 7.8 s, three 14 330 in 16 s; three passes over the largest 2 % 13 939 in under a second -- moving the small
      * subtrees first costs the large ones their better places. */
     int reinsertionShare = 100;
+    /* builder 1: percent of extra references the builder may make by cutting the triangles with the emptiest boxes in two before it builds
+     * (bvh_build.cpp presplitReferences; option "presplit"); 0 = one reference per triangle */
+    int presplitPercent = 0;
 };
 
 struct ConvertOptions {

@@ -23,6 +23,7 @@ __device__ __forceinline__ void make_refs(SceneRefs& sc, const TbDeviceScene& ds
     }
     sc.numHitGroups = ds.numHitGroups; sc.numIndices = ds.numIndices; sc.numVertexFloats = ds.numVertexFloats;
     sc.numMaterials = ds.numMaterials; sc.numLights = ds.numLights;
+    sc.topNodes = nullptr; sc.topUnits = 0u;
 }
 
 /* the 16x16 region of this workgroup (tb_persistent_grid, pt_scene.h); false when it lies outside the frame */
@@ -49,7 +50,11 @@ __device__ __noinline__ uint32_t claim_work_item(uint32_t* counters, uint32_t re
          * others'.  (Agent-scope counters were suspected when work items went missing and were not the cause -- the ray counters of
          * the counting launches are agent-scope adds from every XCD and equal the oracle's; the cause was the order in which slots
          * were bound, pt_persistent.inc bind_next.  The wider scope stays: a claim is made once per thousand samples.) */
+#ifdef TB_CLAIM_AGENT /* experiment: is the claim's cost the system scope? */
+        const uint32_t q = (blockIdx.x + t) & 7u, c = __hip_atomic_fetch_add(counters + q * 16u, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
         const uint32_t q = (blockIdx.x + t) & 7u, c = __hip_atomic_fetch_add(counters + q * 16u, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#endif
         if (banded) {
             const uint32_t b0 = (uint32_t)(((unsigned long long)regions * q) >> 3), n = (uint32_t)(((unsigned long long)regions * (q + 1u)) >> 3) - b0;
             if (n && c < n * numGroups) { const uint32_t group = c / n; return group << 20 | (b0 + (c - group * n)); }

@@ -33,6 +33,17 @@
 
 namespace pt {
 
+/* Pricing builds (scripts/c2_instruction_mix.sh; never shipped): -DTB_EXP_DOUBLE=k evaluates ONE phase of the path loop a second time on
+ * operands the compiler cannot tell from new ones (they pass through an empty asm) and folds the copy's results into a compare that never
+ * holds, so that nothing of it is shared with the real evaluation or removed.  The difference of SQ_INSTS_VALU between such a build and
+ * the shipped one is the phase's dynamic VALU instruction count.  1 path_begin, 2 both walks whole, 3 the inner-node step, 4 the leaf step,
+ * 5 path_on_closest, 6 path_scatter, 7 the ray set-up (GetRayData + root box), 8 every rnd(), 9 every IEEE division of ray set-up. */
+#ifndef TB_EXP_DOUBLE
+#define TB_EXP_DOUBLE 0
+#endif
+__device__ __forceinline__ float exp_opaque(float x) { asm volatile("" : "+v"(x)); return x; }
+__device__ __forceinline__ bool exp_never(float a, float b, float c, float d) { return __float_as_uint(a) + 3u * __float_as_uint(b) + 5u * __float_as_uint(c) + 7u * __float_as_uint(d) == 0x7fc12345u && a == 1.2345e-33f; }
+
 constexpr float EPSILON = 0.000001f;      /* kernel.glsl:1 */
 constexpr float PI = 3.1415926535f;       /* kernel.glsl:2 */
 constexpr float LARGE_NUMBER = 1e20f;
@@ -58,6 +69,8 @@ struct SceneRefs {
     const TbDevHitGroup* hitGroups; const uint32_t* indices; const float* vertices;
     const TbDevMaterial* materials; const TbDevLight* lights;
     uint32_t numHitGroups, numIndices, numVertexFloats, numMaterials, numLights;
+    /* the top of the tree in LDS (scenes fetched from memory): refs below topUnits (16-B units) are read from topNodes instead of `nodes` */
+    const uint8_t* topNodes; uint32_t topUnits;
 };
 
 TBD tb3 ld3(const float* p) { return tb3_make(p[0], p[1], p[2]); }
@@ -68,6 +81,9 @@ TBD float rnd(float& seed, float time)
 {
     float s = seed;
     seed = seed + 1.0f;
+#if TB_EXP_DOUBLE == 8
+    { const float r2 = tb_frac(tb_sin(exp_opaque(s) + time) * 43758.5453123f); if (exp_never(r2, s, time, r2)) seed = seed + 1.0f; }
+#endif
     return tb_frac(tb_sin(s + time) * 43758.5453123f);
 }
 
@@ -176,6 +192,9 @@ struct __attribute__((aligned(16))) TriB16 { TbTriB t; };
 
 TBD TbNodeB load_node(const SceneRefs& sc, uint32_t ref)
 {
+#ifdef TB_TOPCACHE
+    if (ref < sc.topUnits) return ((const NodeB16*)(sc.topNodes + (ref << 4)))->n;
+#endif
     return ((const NodeB16*)(sc.nodes + ((size_t)ref << 4)))->n; /* device child refs are offsets in 16-B units (pt_scene.h) */
 }
 
@@ -326,6 +345,12 @@ TBD bool traverse(const SceneRefs& sc, const TbDeviceScene& ds, tb3 o, tb3 d, Hi
     if (OWN_DIR) walk_owns(d);
     RayPre r = ray_prepare(o, d);
     float unusedT;
+#if TB_EXP_DOUBLE == 7
+    { const tb3 o2 = tb3_make(exp_opaque(o.x), exp_opaque(o.y), exp_opaque(o.z)), d2 = tb3_make(exp_opaque(d.x), exp_opaque(d.y), exp_opaque(d.z));
+      const RayPre r2 = ray_prepare(o2, d2); float t2; const bool in2 = box_test(t2, best.t, r2, ld3(ds.rootCenter), ld3(ds.rootHalf));
+      if (exp_never(r2.inv.x + r2.inv.y + r2.inv.z, r2.oinv.x + r2.oinv.y + r2.oinv.z + r2.ainv.x + r2.ainv.y + r2.ainv.z, r2.shear.x + r2.shear.y + r2.shear.z + r2.operm.x + r2.operm.y +
+          r2.operm.z, t2 + (float)(r2.kx + 3 * r2.ky + 9 * r2.kz + (int)r2.permUnits)) && in2) best.prim ^= 1u; }
+#endif
     if (!box_test(unusedT, best.t, r, ld3(ds.rootCenter), ld3(ds.rootHalf))) return false; /* :566-580 */
     if (NODEC) ray_to_grid(r, ds, o);
     /* "while-while" scheduling: a lane that reaches a leaf parks on it until the other lanes of the
@@ -347,7 +372,12 @@ TBD bool traverse(const SceneRefs& sc, const TbDeviceScene& ds, tb3 o, tb3 d, Hi
             if (PROFILE) prof_hit(prof, PROF_INNER);
             float lt, rt; bool lh, rh; uint32_t nl, nr;
             if (NODEC) { const NodeC16 n = load_node_c(ds, ref); box_test2_c(lh, rh, lt, rt, best.t, r, n); nl = n.left; nr = n.right; }
-            else { const TbNodeB n = load_node(sc, ref); box_test2(lh, rh, lt, rt, best.t, r, n); nl = n.left; nr = n.right; }
+            else { const TbNodeB n = load_node(sc, ref); box_test2(lh, rh, lt, rt, best.t, r, n); nl = n.left; nr = n.right;
+#if TB_EXP_DOUBLE == 3
+                { RayPre r2 = r; r2.inv = tb3_make(exp_opaque(r.inv.x), exp_opaque(r.inv.y), exp_opaque(r.inv.z)); float lt2, rt2; bool lh2, rh2;
+                  box_test2(lh2, rh2, lt2, rt2, exp_opaque(best.t), r2, n); if (exp_never(lt2, rt2, lh2 ? 1.0f : 2.0f, rh2 ? 3.0f : 5.0f)) best.prim ^= 1u; }
+#endif
+            }
             if (RAY_COUNTERS) boxes += 2;
             if (lh && rh) {
                 bool rightFirst = rt < lt;
@@ -368,6 +398,12 @@ TBD bool traverse(const SceneRefs& sc, const TbDeviceScene& ds, tb3 o, tb3 d, Hi
             if (PROFILE) prof_hit(prof, PROF_LEAF);
             const TbTriB tri = load_tri(sc, sc.trisPermuted ? ref + r.permUnits : ref);
             if (RAY_COUNTERS) tris++;
+#if TB_EXP_DOUBLE == 4
+            { Hit b2 = best; b2.t = exp_opaque(best.t); RayPre r2 = r; r2.operm = tb3_make(exp_opaque(r.operm.x), exp_opaque(r.operm.y), exp_opaque(r.operm.z));
+              r2.shear = tb3_make(exp_opaque(r.shear.x), exp_opaque(r.shear.y), exp_opaque(r.shear.z));
+              const tb3 o2 = tb3_make(exp_opaque(o.x), exp_opaque(o.y), exp_opaque(o.z));
+              tri_test<ALPHA>(b2, MIN_T, o2, r2, tri, sc.trisPermuted != 0, sc, ds); if (exp_never(b2.t, b2.u, b2.v, b2.t) && b2.prim == 77u) best.geom ^= 1u; }
+#endif
             tri_test<ALPHA>(best, MIN_T, o, r, tri, sc.trisPermuted != 0, sc, ds);
             ref = pop();
         }
