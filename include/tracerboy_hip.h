@@ -216,7 +216,13 @@ int tb_unpack_gathered_host(uint32_t width, uint32_t height, uint32_t world, uin
 /* Tunables / instrumentation: "pipeline" (0 = lock-step-bounce persistent kernel [default, fastest measured],
  * 1 = streaming persistent kernel with a resumable BVH walk),
  * "count_rays" (0/1), "bvh_builder" (0 = LBVH, 1 = binned SAH + reinsertion passes, 2 = LBVH built on the GPU, 3 = LBVH + the fallback layer's
- * three treelet passes = the tree the reference's PREFER_FAST_TRACE build traverses, 4 = the same built on the GPU), "flatten_instances". */
+ * three treelet passes = the tree the reference's PREFER_FAST_TRACE build traverses, 4 = the same built on the GPU), "flatten_instances".
+ * Builder 1: "reinsertion_passes" (-1 = the library's choice), "reinsertion_share" (percent of the subtrees a pass tries, largest first),
+ * "presplit" (percent of extra references from cutting the triangles with the largest, emptiest boxes before the build; 0 = off, the default:
+ * measured to raise box tests).  Launch policy: "frame_group", "guided_groups" (0 never, 1 = calls that wait [default], 2 always: the frame
+ * groups of a region shrink over the last groups of a launch), "primary_prepass", "overlap_launches", "high_occupancy", "stack_lds_cap",
+ * "compact_hits", "camera_constants", "texture_use_hint", "node_layout", "node_order" -- each described where launch_plan.h / context_render.cpp use it.
+ * An unknown name is an error. */
 int tb_set_option(tb_context* ctx, const char* name, int64_t value);
 int64_t tb_get_option(tb_context* ctx, const char* name);
 
@@ -256,6 +262,9 @@ typedef struct tb_plan_input {
     /* pipeline 4 (split-role kernel): its workgroup shape, so that the plan knows whether a workgroup's LDS and the frame's work items fit
      * and says "the lock-step kernel" itself where they do not (rule TB_PLAN_RULE_SPLIT_NO_ROOM) instead of leaving the launcher to refuse */
     int64_t split_trav /* 4 */, split_shade /* 0 = 4 with the scene in LDS, 6 otherwise */, split_stack_cap /* 0 = the whole stack in LDS */;
+    /* frame groups that shrink towards the end of a launch (option guided_groups: 0 never, 1 = calls that wait for their result, 2 always) and
+     * whether this call waits (tb_render, not tb_render_async) */
+    int64_t guided_groups /* 1 */; uint32_t sync_call;
 } tb_plan_input;
 typedef struct tb_launch_plan {
     int32_t pipeline;                 /* 0 lock-step, 1 streaming, 2 wavefront, 3 pooled, 4 split-role: what will run */
@@ -267,12 +276,17 @@ typedef struct tb_launch_plan {
     uint32_t overlap_launches;
     uint32_t batch_frames, frame_group; /* frame-group mode only */
     uint32_t rule_pipeline, rule_copy, rule_prepass; /* TB_PLAN_RULE_*: which branch decided */
+    uint32_t guided_groups;           /* frame-group mode: the groups of a region halve in size towards the end of a launch (frame_group = the largest) */
 } tb_launch_plan;
 void tb_plan_defaults(tb_plan_input* in);  /* zeroes, then the option defaults */
 /* waves per SIMD the higher-occupancy copy of a feature set ("matte", "env", "surf", "vol", "full", "sss") is compiled for -- what
  * renderImpl puts into tb_plan_input::variant_waves_hi; 0 = the set has no such copy, -1 = no such set.  Needs no context. */
 int tb_variant_waves_hi(const char* variant_name);
 int tb_plan_launch(const tb_plan_input* in, tb_launch_plan* out);
+/* The frame groups of a region in a frame-group launch of `frames` frames whose (largest) group holds frame_group frames (a power of two): returns
+ * their number; with group < that number also the group's first frame and its frame count.  guided = 0: equal groups; 1: the sizes halve towards
+ * the end of the launch (tb_launch_plan::guided_groups; pt_scene.h tb_fg_groups -- the same function the kernels run).  Needs no context. */
+uint32_t tb_frame_groups(uint32_t frames, uint32_t frame_group, uint32_t guided, uint32_t group, uint32_t* first_frame, uint32_t* num_frames);
 
 /* The kernel seam, exported so the checker can run on exactly the arrays the kernels read:
  * fills `view` with HOST pointers owned by the context (valid until the next load/destroy). */

@@ -589,20 +589,22 @@ WorldEnd
         gpu_tb.SetOption("pipeline", 0); gpu_tb.SetOption("bvh_builder", 0)
 
 
+@pytest.mark.parametrize("guided", [0, 2])
 @pytest.mark.parametrize("group", [1, 3, 8])
-def test_frame_group_mode_bit_exact(gpu_tb, settings, group):
+def test_frame_group_mode_bit_exact(gpu_tb, settings, group, guided):
     """Frame-group mode of the persistent kernel (TbDeviceTargets::samples): workgroups render `group` frames each into a
     (frame, pixel) sample buffer that is summed in frame order afterwards -- the image and the jittered image must be the
-    oracle's bits, also across two progressive calls and several sample-buffer batches."""
+    oracle's bits, also across two progressive calls and several sample-buffer batches.  guided = 2: the groups of a region shrink
+    towards the end of every launch (option guided_groups; by default only calls that wait get them)."""
     gpu_tb.LoadScene(CORNELL)
     W, H, F = 200, 120, 7
-    gpu_tb.SetOption("frame_group", group); gpu_tb.SetOption("pooled_samples", W * H * 3)
+    gpu_tb.SetOption("frame_group", group); gpu_tb.SetOption("pooled_samples", W * H * 3); gpu_tb.SetOption("guided_groups", guided)
     try:
         gpu_tb.Render(W, H, F - 2, settings, 0.0)
         gpu_tb.Render(W, H, 2, settings, 0.0)
         out, jit = gpu_tb.ReadAccumulation(jittered=True)
     finally:
-        gpu_tb.SetOption("frame_group", 0); gpu_tb.SetOption("pooled_samples", 256 << 20)
+        gpu_tb.SetOption("frame_group", 0); gpu_tb.SetOption("pooled_samples", 256 << 20); gpu_tb.SetOption("guided_groups", 1)
     ref = _oracle(gpu_tb, W, H, F, settings, jittered=True)
     assert np.array_equal(bits(out), bits(ref["output"]))
     assert np.array_equal(bits(jit), bits(ref["jittered"]))
@@ -629,6 +631,36 @@ def test_frame_group_many_frames_small_image(gpu_tb, settings):
         gpu_tb.SetOption("frame_group", 0)
     assert np.all(groups[..., 3] == float(F))
     assert np.array_equal(bits(groups), bits(classic)) and np.array_equal(bits(groups_jit), bits(classic_jit))
+
+
+@pytest.mark.parametrize("frames,group", [(64, 32), (37, 4), (9, 2), (130, 16), (5, 1)])
+def test_guided_frame_groups_bit_exact(gpu_tb, settings, frames, group):
+    """Groups that shrink towards the end of a launch (pt_scene.h tb_fg_groups; what a synchronous call of 2+ groups gets by default): slots of
+    different sizes in one launch, ragged frame counts, the asynchronous path forced (option 2), a frame whose last region row is half outside --
+    every picture the bits of the one-pixel-per-lane kernel, which other tests hold to the oracle."""
+    gpu_tb.LoadProcedural(0, 20000, 5)
+    W, H = 328, 200
+    s = copy.copy(settings); s.MaxBounces = 5
+    gpu_tb.SetOption("frame_group", -1)
+    try:
+        gpu_tb.InvalidateHistory(); gpu_tb.Render(W, H, frames, s, 0.0); ref = gpu_tb.ReadAccumulation(jittered=True)
+    finally:
+        gpu_tb.SetOption("frame_group", 0)
+    gpu_tb.SetOption("frame_group", group)
+    try:
+        for mode in (1, 2, 0):
+            gpu_tb.SetOption("guided_groups", mode)
+            gpu_tb.InvalidateHistory(); gpu_tb.Render(W, H, frames, s, 0.0)
+            assert gpu_tb.GetOption("last_plan_guided_groups") == (1 if (mode and frames >= 2 * group) else 0)
+            got = gpu_tb.ReadAccumulation(jittered=True)
+            assert np.array_equal(bits(got[0]), bits(ref[0])) and np.array_equal(bits(got[1]), bits(ref[1])), mode
+            if mode == 2:                                       # ... and back-to-back asynchronous calls on the two side streams
+                for _ in range(3):
+                    gpu_tb.InvalidateHistory(); gpu_tb.Render(W, H, frames, s, 0.0, sync=False)
+                gpu_tb.Sync()
+                assert np.array_equal(bits(gpu_tb.ReadAccumulation()), bits(ref[0]))
+    finally:
+        gpu_tb.SetOption("frame_group", 0); gpu_tb.SetOption("guided_groups", 1)
 
 
 def test_frame_group_default_and_classic_agree(gpu_tb, settings):

@@ -161,3 +161,41 @@ def test_prepass_small_call_rule_counts_the_calls_own_samples():
     eighth = plan(SSSV, dict(UHD, owned_regions=240 * 135 // 8), frames=8, stack_depth=30, has_lights=1, interior_walk_triangle_share=0.2)
     assert (whole.prepass, whole.rule_prepass) == (ON, PRE_GLASS_AMONG_OTHERS) and (eighth.prepass, eighth.rule_prepass) == (OFF, PRE_SMALL_CALL)
     assert plan(SSSV, dict(UHD, owned_regions=240 * 135 // 8), frames=32, stack_depth=30, has_lights=1, interior_walk_triangle_share=0.2).prepass == ON
+
+
+def test_guided_frame_groups_tile_the_launch_exactly():
+    """tb_frame_groups (pt_scene.h tb_fg_groups, the function the kernels bind their work with): equal groups, or groups whose sizes halve towards the
+    end of a launch -- either way the groups of a region are consecutive, disjoint, cover frames [0, F) exactly, never grow, and a guided launch
+    ends in single frames while half of its frames sit in groups of the full size."""
+    import ctypes as C
+    from tracerboy_amd import api
+    L = api.lib()
+    for F in list(range(1, 70)) + [127, 128, 129, 255, 1000, 4095, 5000]:
+        for G in (1, 2, 4, 8, 16, 32, 64):
+            for guided in (0, 1):
+                f0, nf = C.c_uint32(), C.c_uint32()
+                total = L.tb_frame_groups(F, G, guided, 0xffffffff, None, None)
+                assert total >= 1
+                at, sizes = 0, []
+                for g in range(total):
+                    assert L.tb_frame_groups(F, G, guided, g, C.byref(f0), C.byref(nf)) == total
+                    assert f0.value == at and 1 <= nf.value <= G, (F, G, guided, g, f0.value, nf.value)
+                    at += nf.value; sizes.append(nf.value)
+                assert at == F, (F, G, guided, sizes)
+                if guided and F >= 2 * G:
+                    assert sizes == sorted(sizes, reverse=True) and sizes[0] == G and sizes[-1] == 1
+                    assert sum(x for x in sizes if x < G) < 2 * G          # only the end of the launch is cut small: less than two groups' worth of frames
+                else:
+                    assert all(x == G for x in sizes[:-1])
+
+
+def test_guided_groups_are_for_calls_that_wait():
+    """Option guided_groups: 1 (default) = synchronous calls of 2+ frames only, 2 = every frame-group call, 0 = never; a launch whose groups would not fit
+    the claim word (4095 groups a region, 2^21 items) keeps equal groups."""
+    c2 = dict(scene_in_lds=1, lds_blob_bytes=17 * 1024, stack_depth=11, has_lights=1)
+    assert plan(MATTE, HD, c2, frames=64).guided_groups == 0                                   # tb_render_async
+    p = plan(MATTE, HD, c2, frames=64, sync_call=1); assert p.guided_groups == 1 and p.frame_group == 32
+    assert plan(MATTE, HD, c2, frames=64, sync_call=1, guided_groups=0).guided_groups == 0
+    assert plan(MATTE, HD, c2, frames=64, guided_groups=2).guided_groups == 1
+    assert plan(MATTE, HD, c2, frames=1, sync_call=1).guided_groups == 0                         # one frame: nothing to shrink
+    assert plan(ENVV, HD, frames=1, stack_depth=31, sync_call=1).guided_groups == 0              # not a frame-group launch at all

@@ -266,7 +266,7 @@ void renderSplit(tb_context* c, const Variant* v, uint32_t W, uint32_t H, uint32
 }
 
 /* what PlanLaunch (launch_plan.h) is told about this context's scene, the call and the options */
-void fillPlanInput(tb_context* c, const Variant* v, uint32_t W, uint32_t H, uint32_t n, const tb_output_settings& s, bool aov, bool count, tb_plan_input& in)
+void fillPlanInput(tb_context* c, const Variant* v, uint32_t W, uint32_t H, uint32_t n, const tb_output_settings& s, bool aov, bool count, bool sync, tb_plan_input& in)
 {
     auto opt = [&](const char* k, int64_t d) { auto it = c->options.find(k); return it == c->options.end() ? d : it->second; };
     memset(&in, 0, sizeof in);
@@ -284,6 +284,7 @@ void fillPlanInput(tb_context* c, const Variant* v, uint32_t W, uint32_t H, uint
     in.stack_overflow_max = opt("stack_overflow_max", 24); in.node_layout = opt("node_layout", 0); in.primary_prepass = opt("primary_prepass", 1);
     in.overlap_launches = opt("overlap_launches", 1); in.pooled_samples = opt("pooled_samples", 256ll << 20);
     in.split_trav = opt("split_trav", 4); in.split_shade = opt("split_shade", 0); in.split_stack_cap = opt("split_stack_cap", 0);
+    in.guided_groups = opt("guided_groups", 1); in.sync_call = sync ? 1u : 0u;
 }
 
 int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_output_settings* settings, float timeSeed, bool sync)
@@ -347,7 +348,7 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
         "tb_render: two-level (instanced) scenes are not supported by pipelines 1-3; use pipeline 0 or flatten_instances = 1");
     /* WHAT to launch is decided by a pure function of scene statistics, call size and options (launch_plan.h; tests/test_launch_plan.py
      * walks its branches on the CPU); what follows executes the plan. */
-    tb_plan_input pin; fillPlanInput(c, v, W, H, n, s, aov, count, pin);
+    tb_plan_input pin; fillPlanInput(c, v, W, H, n, s, aov, count, sync, pin);
     tb_launch_plan plan; PlanLaunch(pin, plan);
     if (plan.pipeline == 4 && !splitLaunchable(c, v, W, H, pf)) { /* the launcher's own refusal: the lock-step kernel, by the plan's rules for it */
         pin.pipeline = 0; PlanLaunch(pin, plan); plan.rule_pipeline = TB_PLAN_RULE_SPLIT_NO_ROOM;
@@ -493,7 +494,8 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
             if (regions > 0xfffffu) throw std::runtime_error("frame too large for the frame-group launch (more than 2^20 16x16 regions)");
             ensure(c->workCounter, 1024);
             tg.bandedItems = (uint32_t)opt("banded_items", 0);
-            tg.frameGroup = plan.frame_group;
+            tg.frameGroup = plan.frame_group; tg.fgGuided = plan.guided_groups;
+            uint32_t lgGroup = 0; while ((2u << lgGroup) <= tg.frameGroup) lgGroup++;
             if (overlap && !c->sideOrdered) { /* first overlapped launch after other work on the main stream: order the side streams behind it once */
                 HIP_TRY(hipEventRecord(c->evMain, c->stream));
                 for (int i = 0; i < 2; i++) HIP_TRY(hipStreamWaitEvent(c->side[i], c->evMain, 0));
@@ -565,7 +567,7 @@ int renderImpl(tb_context* c, uint32_t W, uint32_t H, uint32_t n, const tb_outpu
                      * items at the SMALLEST resident grid the launcher may choose (2 per CU), so that the rows of any grid hold the whole list
                      * several times over and a workgroup whose row is full (it retires) never strands work */
                     const int numCUs = deviceCUs(c);
-                    const uint64_t items = regions * (((uint64_t)nf + tg.frameGroup - 1) / tg.frameGroup), wgs = 16ull * (uint64_t)numCUs,
+                    const uint64_t items = regions * (uint64_t)tb_fg_groups(nf, lgGroup, tg.fgGuided, 0xffffffffu, nullptr, nullptr), wgs = 16ull * (uint64_t)numCUs,
                         fewest = 2ull * (uint64_t)numCUs;
                     tg.slotLogCap = (uint32_t)std::min<uint64_t>(65534, 8 * ((items + fewest - 1) / fewest) + 16); /* 16 bits of an entry's tag */
                     tg.launchEpoch = ++c->launchEpoch; c->lastSlotLogCap = (int)tg.slotLogCap;

@@ -6,6 +6,7 @@
 #include <stdint.h>
 #include <algorithm>
 #include "../../../include/tracerboy_hip.h"
+#include "../kernels/pt_scene.h"
 
 namespace tbhost {
 
@@ -118,6 +119,23 @@ inline void PlanLaunch(const tb_plan_input& in, tb_launch_plan& p)
     while ((frames + G - 1) / G > 4095u) G *= 2;
     while (G < frames && regions * ((frames + G - 1) / G) > (1ull << 21)) G *= 2;
     p.frame_group = G;
+    /* Groups that shrink towards the end of the launch (pt_scene.h tb_fg_groups).  A workgroup binds its work one or two groups ahead and the SIMDs
+     * issue oldest wave first, so the workgroups that started last progress at a tenth of the rate of the first (scripts/wg_timeline.py: 16 k to
+     * 237 k samples per workgroup of one cornell-box launch) and still hold two whole groups when the lists run dry: 3.0 ms of a 20.1-ms launch
+     * that has the chip to itself.  With the last two to three groups' worth of frames cut into one more group of G, then G / 2, G / 4 ... and
+     * single frames last, what is left then is a few hundred samples (cornell-box 1080p x 64: 20.1 -> 19.1 ms; vw-van 4K x 8: 33.2 -> 30.6 ms).
+     * Small groups cost lane utilisation (a workgroup's lanes straddle image regions more of the time: G = 2 needs 12 % more wave
+     * instructions than G = 32 for the same picture) and cache locality, which is why only the END of a launch gets them -- a launch shorter
+     * than two groups has none to spare and stays as it is (van-class 4K x 8 in one group of 8 per region: 35.0 -> 36.5 ms when cut) -- and only
+     * where the end is exposed: calls that wait for their result (option guided_groups = 1, the default; 2 = every call, 0 = never).
+     * Back-to-back asynchronous calls fill one launch's end with the next launch's beginning and lose 0.3 ms per launch (1.6 %) as they are;
+     * cut small they lose 5 % (cornell-box 18.75 -> 19.69 ms per step). */
+    p.guided_groups = 0;
+    if (in.guided_groups == 2 || (in.guided_groups == 1 && in.sync_call)) {
+        uint32_t lg = 0; while ((2u << lg) <= G) lg++;
+        const uint64_t groups = tb_fg_groups(frames, lg, 1u, 0xffffffffu, nullptr, nullptr);
+        if (groups <= 4095u && regions * groups <= (1ull << 21) && frames >= 2u * G) p.guided_groups = 1;
+    }
 }
 
 } // namespace tbhost

@@ -23,7 +23,6 @@ __device__ __forceinline__ void make_refs(SceneRefs& sc, const TbDeviceScene& ds
     }
     sc.numHitGroups = ds.numHitGroups; sc.numIndices = ds.numIndices; sc.numVertexFloats = ds.numVertexFloats;
     sc.numMaterials = ds.numMaterials; sc.numLights = ds.numLights;
-    sc.topNodes = nullptr; sc.topUnits = 0u;
 }
 
 /* the 16x16 region of this workgroup (tb_persistent_grid, pt_scene.h); false when it lies outside the frame */
@@ -50,11 +49,7 @@ __device__ __noinline__ uint32_t claim_work_item(uint32_t* counters, uint32_t re
          * others'.  (Agent-scope counters were suspected when work items went missing and were not the cause -- the ray counters of
          * the counting launches are agent-scope adds from every XCD and equal the oracle's; the cause was the order in which slots
          * were bound, pt_persistent.inc bind_next.  The wider scope stays: a claim is made once per thousand samples.) */
-#ifdef TB_CLAIM_AGENT /* experiment: is the claim's cost the system scope? */
-        const uint32_t q = (blockIdx.x + t) & 7u, c = __hip_atomic_fetch_add(counters + q * 16u, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#else
         const uint32_t q = (blockIdx.x + t) & 7u, c = __hip_atomic_fetch_add(counters + q * 16u, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-#endif
         if (banded) {
             const uint32_t b0 = (uint32_t)(((unsigned long long)regions * q) >> 3), n = (uint32_t)(((unsigned long long)regions * (q + 1u)) >> 3) - b0;
             if (n && c < n * numGroups) { const uint32_t group = c / n; return group << 20 | (b0 + (c - group * n)); }
@@ -71,8 +66,10 @@ __device__ __noinline__ uint32_t claim_work_item(uint32_t* counters, uint32_t re
  * pointers, the log's capacity and the epoch alive through the path loop and cost every frame-group kernel 16-48 B of scratch per lane
  * and 3 % of its speed.  (Moving the per-path part out of line as well -- the ring lookup of every drawn sample -- was measured too: its
  * LDS reads become flat loads through the texture addresser and the 870 k scene lost 2.7 %.)
- * groupConst: regions, log2(frames per group), frame groups per region, "a claim has found nothing", tag base ((launch epoch & 0xff) << 16);
- * bindState: binders under way, slots bound so far; both and the 8-entry ring live in the workgroup's LDS. */
+ * groupConst: regions, log2(frames per group: of the LARGEST group when the groups shrink, tb_fg_groups), frame groups per region, "a claim has found
+ * nothing", tag base ((launch epoch & 0xff) << 16), frames of the launch | guided << 31;
+ * bindState: binders under way, slots bound so far; both and the 8-entry ring live in the workgroup's LDS.
+ * A slot's entry: tag << 40 | first frame of the group (relative, 15 bits) << 24 | log2(frames of the group) << 20 | region y << 10 | region x. */
 __device__ __noinline__ void fg_bind_next(uint32_t* groupConst, uint32_t* bindState, unsigned long long* slotTable, uint32_t* workCounter,
     unsigned long long* logRow,
                                           uint32_t logCap, uint32_t banded, TbTileMap tiles, uint32_t W, uint32_t H)
@@ -88,8 +85,11 @@ __device__ __noinline__ void fg_bind_next(uint32_t* groupConst, uint32_t* bindSt
             const uint32_t slot = atomicAdd(&bindState[1], 1u), group = item >> 20, region = item & 0xfffffu;
             uint32_t rx, ry;
             block_region(tiles, W, H, region, rx, ry);
+            const uint32_t fg = ((volatile uint32_t*)groupConst)[5];
+            uint32_t frame0 = group << lg, lgS = lg;
+            if (fg >> 31) (void)tb_fg_groups(fg & 0x7fffffffu, lg, 1u, group, &frame0, &lgS); /* groups that shrink towards the end of the launch */
             const unsigned long long e = (unsigned long long)(((volatile uint32_t*)groupConst)[4] | ((slot + 1u) & 0xffffu)) << 40 |
-                ((unsigned long long)(group << lg) << 24) | (unsigned long long)(ry << 12) | rx;
+                ((unsigned long long)frame0 << 24) | (unsigned long long)(lgS << 20) | (unsigned long long)(ry << 10) | rx;
             ((volatile unsigned long long*)slotTable)[slot & 7u] = e;
             __hip_atomic_store(logRow + slot, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }

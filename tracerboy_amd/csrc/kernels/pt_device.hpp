@@ -69,8 +69,6 @@ struct SceneRefs {
     const TbDevHitGroup* hitGroups; const uint32_t* indices; const float* vertices;
     const TbDevMaterial* materials; const TbDevLight* lights;
     uint32_t numHitGroups, numIndices, numVertexFloats, numMaterials, numLights;
-    /* the top of the tree in LDS (scenes fetched from memory): refs below topUnits (16-B units) are read from topNodes instead of `nodes` */
-    const uint8_t* topNodes; uint32_t topUnits;
 };
 
 TBD tb3 ld3(const float* p) { return tb3_make(p[0], p[1], p[2]); }
@@ -192,9 +190,6 @@ struct __attribute__((aligned(16))) TriB16 { TbTriB t; };
 
 TBD TbNodeB load_node(const SceneRefs& sc, uint32_t ref)
 {
-#ifdef TB_TOPCACHE
-    if (ref < sc.topUnits) return ((const NodeB16*)(sc.topNodes + (ref << 4)))->n;
-#endif
     return ((const NodeB16*)(sc.nodes + ((size_t)ref << 4)))->n; /* device child refs are offsets in 16-B units (pt_scene.h) */
 }
 

@@ -79,6 +79,10 @@ struct TbDeviceTargets {
      * accumulate_samples_kernel then sums them in frame order, which keeps the fp32 accumulation of RayGenCommon.h:704-727
      * bit for bit while no lane waits for its neighbours' longer paths. */
     TbFloat4* samples; uint32_t frameGroup; uint32_t* workCounter;
+    /* 1: the work items of a region shrink towards the end of the launch (tb_fg_groups below): half of the frames in groups of frameGroup, half of
+     * the rest in groups half that size, ... single frames last -- what is left bound to slow workgroups when the lists run dry is then a few
+     * hundred samples instead of two whole groups (docs/experiments/r6.md: the end of a launch that has the chip to itself) */
+    uint32_t fgGuided;
     /* frame-group mode: slotLogCap entries per workgroup of the launch (at most 16 per CU), zeroed by the launcher; every slot a workgroup binds is recorded
      * here (pt_persistent.inc) */
     unsigned long long* slotLog; uint32_t slotLogCap;
@@ -136,6 +140,34 @@ struct TbTileMap { /* multi-GPU tile ownership: tile t is rendered iff t % world
  * XCDs, so every XCD gets real work; launching the whole frame and letting foreign workgroups exit left half of the
  * XCDs idle for every even world size (a rank's tiles then all sit in columns of one parity: measured 51 / 42 / 32 %
  * efficiency at 2 / 4 / 8 ranks, scripts/tile_split_timing.py). */
+/* Frame groups of a region in a frame-group launch of F frames.  Uniform (guided = 0, or a launch shorter than two groups): ceil(F / 2^lg0)
+ * groups of 2^lg0 frames.  Guided: equal groups up to the last two to three groups' worth of frames, over which the sizes halve -- one more
+ * whole group, then groups half that size over half of what is left, and so on; the last stretch is single frames.  With group == ~0u
+ * returns the number of groups; otherwise writes the group's first frame (relative to the launch) and log2 of its frame count.  Host (plan,
+ * slot logs, grid) and device (fg_bind_next) share it. */
+#if defined(__HIPCC__) || defined(__cplusplus)
+static inline
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+uint32_t tb_fg_groups(uint32_t F, uint32_t lg0, uint32_t guided, uint32_t group, uint32_t* frame0, uint32_t* lg)
+{
+    if (!guided || F < (2u << lg0)) { if (group != 0xffffffffu) { *frame0 = group << lg0; *lg = lg0; } return (F + (1u << lg0) - 1u) >> lg0; }
+    const uint32_t uniform = (F - (2u << lg0)) >> lg0; /* whole groups before the stretch that shrinks (2 to 3 groups' worth of frames) */
+    if (group != 0xffffffffu && group < uniform) { *frame0 = group << lg0; *lg = lg0; return 0u; }
+    uint32_t f = uniform << lg0, total = uniform, l = lg0;
+    while (f < F) {
+        const uint32_t left = F - f;
+        const uint32_t n = l == 0u ? left : ((left / 2u) >> l); /* single frames run to the end; larger groups fill half of what is left */
+        if (n == 0u) { l--; continue; }
+        if (group != 0xffffffffu && group < total + n) { *frame0 = f + ((group - total) << l); *lg = l; return 0u; }
+        total += n; f += n << l;
+        if (l > 0u) l--;
+    }
+    return total;
+}
+#endif
+
 #if defined(__HIPCC__) || defined(__cplusplus)
 static inline
 #if defined(__HIPCC__)
