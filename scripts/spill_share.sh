@@ -5,10 +5,10 @@
 # unchanged, so the control flow and every real load and store are the same) and the two builds' SQ_INSTS_VMEM_RD / _WR per launch
 # are subtracted.  Here (CPU):  python scripts/build_variant.py nobound --flags=-DTB_NO_OCCUPANCY_BOUND=1 --tus kernels/pt_variant_sss4.hip \
 #                                 kernels/pt_variant_vol4.hip kernels/pt_variant_surf.hip
-# GPU box:     bash scripts/spill_share.sh   ->  gpurun_out/r5/<leg>_spill_share.json (copy to profiles/rN/)
+# GPU box:     bash scripts/spill_share.sh   ->  gpurun_out/r6/<leg>_spill_share.json (copy to profiles/rN/)
 set -u
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
-OUT=gpurun_out/r5/spill_share; rm -rf $OUT; mkdir -p $OUT
+OUT=gpurun_out/r6/spill_share; rm -rf $OUT; mkdir -p $OUT
 LEGS=${LEGS:-"c4 c5 vwvan vwvan_2level teapot"}
 for tag in base nobound; do
   if [ "$tag" = base ]; then unset TB_LIB; else export TB_LIB=$PWD/tracerboy_amd/_sweep/libtracerboy_hip_$tag.so; fi
@@ -41,6 +41,6 @@ for leg in legs:
            "spill_loads_per_launch": b["SQ_INSTS_VMEM_RD"] - n["SQ_INSTS_VMEM_RD"], "spill_stores_per_launch": b["SQ_INSTS_VMEM_WR"] - n["SQ_INSTS_VMEM_WR"],
            "vmem_spill_share": round(1.0 - vm_n / vm_b, 4) if vm_b else None, "_kernel_digest": tb_build.kernel_digest(),
            "method": "SQ_INSTS_VMEM_RD + _WR per launch (pre-pass + lock-step kernel) of the shipped build minus the same kernels built without their occupancy bound (no spills; same plan, same control flow)"}
-    json.dump(doc, open("gpurun_out/r5/%s_spill_share.json" % leg, "w"), indent=1)
+    json.dump(doc, open("gpurun_out/r6/%s_spill_share.json" % leg, "w"), indent=1)
     print(leg, doc["vmem_spill_share"], doc["spill_loads_per_launch"], doc["spill_stores_per_launch"], b["ms_per_step"], n["ms_per_step"])
 PY

@@ -638,7 +638,7 @@ def test_guided_frame_groups_bit_exact(gpu_tb, settings, frames, group):
     """Groups that shrink towards the end of a launch (pt_scene.h tb_fg_groups; what a synchronous call of 2+ groups gets by default): slots of
     different sizes in one launch, ragged frame counts, the asynchronous path forced (option 2), a frame whose last region row is half outside --
     every picture the bits of the one-pixel-per-lane kernel, which other tests hold to the oracle."""
-    gpu_tb.LoadProcedural(0, 20000, 5)
+    gpu_tb.LoadScene(CORNELL)                      # a scene in LDS: the feature sets' frame-group kernels for such scenes carry the copy that reads a slot's size
     W, H = 328, 200
     s = copy.copy(settings); s.MaxBounces = 5
     gpu_tb.SetOption("frame_group", -1)
@@ -659,6 +659,11 @@ def test_guided_frame_groups_bit_exact(gpu_tb, settings, frames, group):
                     gpu_tb.InvalidateHistory(); gpu_tb.Render(W, H, frames, s, 0.0, sync=False)
                 gpu_tb.Sync()
                 assert np.array_equal(bits(gpu_tb.ReadAccumulation()), bits(ref[0]))
+        # a scene fetched from memory keeps equal groups whatever the option says (its kernels have no such copy), same bits
+        gpu_tb.LoadProcedural(0, 20000, 5)
+        gpu_tb.SetOption("frame_group", -1); gpu_tb.InvalidateHistory(); gpu_tb.Render(W, H, frames, s, 0.0); ref = gpu_tb.ReadAccumulation()
+        gpu_tb.SetOption("frame_group", group); gpu_tb.SetOption("guided_groups", 2); gpu_tb.InvalidateHistory(); gpu_tb.Render(W, H, frames, s, 0.0)
+        assert gpu_tb.GetOption("last_plan_guided_groups") == 0 and np.array_equal(bits(gpu_tb.ReadAccumulation()), bits(ref))
     finally:
         gpu_tb.SetOption("frame_group", 0); gpu_tb.SetOption("guided_groups", 1)
 

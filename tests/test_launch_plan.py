@@ -199,3 +199,4 @@ def test_guided_groups_are_for_calls_that_wait():
     assert plan(MATTE, HD, c2, frames=64, guided_groups=2).guided_groups == 1
     assert plan(MATTE, HD, c2, frames=1, sync_call=1).guided_groups == 0                         # one frame: nothing to shrink
     assert plan(ENVV, HD, frames=1, stack_depth=31, sync_call=1).guided_groups == 0              # not a frame-group launch at all
+    assert plan(ENVV, HD, frames=64, stack_depth=31, sync_call=1, guided_groups=2).guided_groups == 0   # fetched from memory: those kernels have no such copy

@@ -131,7 +131,9 @@ inline void PlanLaunch(const tb_plan_input& in, tb_launch_plan& p)
      * Back-to-back asynchronous calls fill one launch's end with the next launch's beginning and lose 0.3 ms per launch (1.6 %) as they are;
      * cut small they lose 5 % (cornell-box 18.75 -> 19.69 ms per step). */
     p.guided_groups = 0;
-    if (in.guided_groups == 2 || (in.guided_groups == 1 && in.sync_call)) {
+    /* (compiled into the frame-group kernels of LDS-resident scenes, whole stack in LDS: the other feature sets' kernels gained 0-2 % from it when measured
+     * -- 870 k scene +1.3 %, Teapot +1.8 %, the 4K scenes nothing -- and do not carry the copy) */
+    if ((in.guided_groups == 2 || (in.guided_groups == 1 && in.sync_call)) && in.scene_in_lds && !p.stack_overflow_entries) {
         uint32_t lg = 0; while ((2u << lg) <= G) lg++;
         const uint64_t groups = tb_fg_groups(frames, lg, 1u, 0xffffffffu, nullptr, nullptr);
         if (groups <= 4095u && regions * groups <= (1ull << 21) && frames >= 2u * G) p.guided_groups = 1;
