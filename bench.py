@@ -20,8 +20,14 @@ What one JSON line carries:
                       full 128 spp, the 4K scenes the 8 GPUs divide (stand-ins and the reference's own vw-van, flattened
                       and two-level) and the reference's Teapot.  `frac` is the SURVEY 8d algorithmic byte rate / 8 TB/s.
   "scale_<leg>"       N > 1 only: the 8-GPU configurations (van-class, bistro-class, vw-van at 3840x2160) through the
-                      same tile-split step, each with its own scale_breakdown and expected_speedup.
+                      same tile-split step, quoted on a 32-spp step (the configurations are 256 / 1024 spp) with the 8-spp step
+                      beside it (at_short_steps), each with its own scale_breakdown and expected_speedup.
   "cpu_baseline"      N = 1 only: the scalar oracle on the host cores, bounded sample of the timed workload.
+  "parity"            the gate of BASELINE.md section 2 (CPU image vs HIP image before any timing is accepted): the frame the LAST TIMED
+                      STEP left in HBM against the oracle's -- the whole frame for the headline at N = 1 (the image cpu_baseline renders
+                      anyway), two 8-row strips at the workload's own sample count for every roofline_<leg> / scale_<leg> and for the
+                      assembled frame at N > 1.  bit_equal, rel_l2 (block) and max_pixel_rel_l2; a figure whose frame is beyond 1e-4
+                      prints value: null (the number stays as value_unverified).
 """
 import argparse
 import glob
