@@ -249,6 +249,7 @@ typedef struct tb_plan_input {
     uint32_t variant_waves_hi;        /* waves per SIMD of its higher-occupancy copy, 0 = it has none */
     uint32_t variant_prepass_in_base; /* its only copy carries the pre-pass (surf) */
     uint32_t variant_has_wavefront, variant_has_pooled, variant_has_split; /* pipelines 2 / 3 / 4 exist for it */
+    uint32_t variant_stash_entries;   /* LDS entries per lane the higher-occupancy copy's frame-group kernels keep behind the stacks (scenes fetched from memory) */
     /* the loaded scene */
     uint32_t scene_in_lds, lds_blob_bytes, stack_depth, two_level, has_lights, has_compact_nodes;
     float interior_walk_triangle_share; /* share of the triangles whose material starts an interior walk */
@@ -282,6 +283,9 @@ void tb_plan_defaults(tb_plan_input* in);  /* zeroes, then the option defaults *
 /* waves per SIMD the higher-occupancy copy of a feature set ("matte", "env", "surf", "vol", "full", "sss") is compiled for -- what
  * renderImpl puts into tb_plan_input::variant_waves_hi; 0 = the set has no such copy, -1 = no such set.  Needs no context. */
 int tb_variant_waves_hi(const char* variant_name);
+/* LDS entries per lane (1 KB per workgroup each) the frame-group kernels of that copy keep behind the traversal stacks for a path's cold state --
+ * tb_plan_input::variant_stash_entries; 0 = none, -1 = no such set */
+int tb_variant_stash_entries(const char* variant_name);
 int tb_plan_launch(const tb_plan_input* in, tb_launch_plan* out);
 /* The frame groups of a region in a frame-group launch of `frames` frames whose (largest) group holds frame_group frames (a power of two): returns
  * their number; with group < that number also the group's first frame and its frame count.  guided = 0: equal groups; 1: the sizes halve towards

@@ -200,3 +200,17 @@ def test_guided_groups_are_for_calls_that_wait():
     assert plan(MATTE, HD, c2, frames=1, sync_call=1).guided_groups == 0                         # one frame: nothing to shrink
     assert plan(ENVV, HD, frames=1, stack_depth=31, sync_call=1).guided_groups == 0              # not a frame-group launch at all
     assert plan(ENVV, HD, frames=64, stack_depth=31, sync_call=1, guided_groups=2).guided_groups == 0   # fetched from memory: those kernels have no such copy
+
+
+def test_a_copys_stash_comes_off_the_stacks_share_of_lds():
+    """A higher-occupancy copy whose frame-group kernels park a path's cold state in LDS (tb_variant_stash_entries: env keeps 7 entries per lane = 7 KB
+    per workgroup) leaves the stack that much less: at 6 waves per SIMD 26 entries become 19, deeper trees split earlier; launches that have no stash
+    (one pixel per lane, scenes in LDS, two-level scenes) keep the full share."""
+    assert api.VariantStashEntries("env") == 7 and api.VariantStashEntries("sss") == 0 and api.VariantStashEntries("surf") == 0 and api.VariantStashEntries("nope") == -1
+    env = dict(ENVV, variant_stash_entries=api.VariantStashEntries("env"))
+    full = lds_entries(W_ENV)
+    p = plan(env, HD, frames=128, stack_depth=19, max_bounces=6); assert (p.rule_copy, p.stack_lds_entries, p.stack_overflow_entries) == (COPY_FITS, 19, 0)
+    p = plan(env, HD, frames=128, stack_depth=30, max_bounces=6); assert (p.rule_copy, p.stack_lds_entries, p.stack_overflow_entries) == (COPY_SPLIT_STACK, full - 7, 30 - (full - 7))
+    p = plan(ENVV, HD, frames=128, stack_depth=26, max_bounces=6); assert (p.rule_copy, p.stack_lds_entries) == (COPY_FITS, 26)        # a copy without a stash
+    p = plan(env, HD, frames=1, stack_depth=26); assert p.groups == 0 and p.rule_copy == COPY_FITS                                     # one pixel per lane: no stash in that kernel
+    p = plan(env, HD, frames=16, stack_depth=40, two_level=1); assert p.stack_lds_entries == full                                      # two-level walk: no stash either

@@ -163,7 +163,7 @@ class tb_scene_info(C.Structure):
 class tb_plan_input(C.Structure):
     """include/tracerboy_hip.h tb_plan_input: what the launch policy is told (scene statistics, the call, the options)."""
     _fields_ = [("variant_features", C.c_uint32), ("variant_waves_hi", C.c_uint32), ("variant_prepass_in_base", C.c_uint32),
-                ("variant_has_wavefront", C.c_uint32), ("variant_has_pooled", C.c_uint32), ("variant_has_split", C.c_uint32),
+                ("variant_has_wavefront", C.c_uint32), ("variant_has_pooled", C.c_uint32), ("variant_has_split", C.c_uint32), ("variant_stash_entries", C.c_uint32),
                 ("scene_in_lds", C.c_uint32), ("lds_blob_bytes", C.c_uint32), ("stack_depth", C.c_uint32), ("two_level", C.c_uint32), ("has_lights", C.c_uint32),
                 ("has_compact_nodes", C.c_uint32), ("interior_walk_triangle_share", C.c_float),
                 ("width", C.c_uint32), ("height", C.c_uint32), ("frames", C.c_uint32), ("max_bounces", C.c_int32), ("owned_regions", C.c_uint64),

@@ -94,6 +94,7 @@ def lib():
         "tb_last_render_ms": (C.c_float, [vp]),
         "tb_trace_closest": (C.c_int, [vp, C.c_uint32] + [vp] * 11),
         "tb_device_math": (C.c_int, [vp, C.c_int, C.c_uint32, vp, vp, vp]),
+        "tb_variant_stash_entries": (C.c_int, [C.c_char_p]),
         "tb_frame_groups": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, P(C.c_uint32), P(C.c_uint32)]),
         "tb_host_scene_load": (C.c_int, [C.c_char_p, C.c_int, C.c_int, P(vp), C.c_char_p, C.c_uint32]),
         "tb_host_scene_procedural": (C.c_int, [C.c_int, C.c_uint32, C.c_uint32, C.c_int, P(vp), C.c_char_p, C.c_uint32]),
@@ -139,6 +140,11 @@ def GetDefaultPostProcessSettings():
 def VariantWavesHi(name):
     """Waves per SIMD the higher-occupancy copy of feature set `name` is compiled for (0: no such copy; tb_variant_waves_hi)."""
     return int(lib().tb_variant_waves_hi(name.encode()))
+
+
+def VariantStashEntries(name):
+    """LDS entries per lane the higher-occupancy copy's frame-group kernels keep behind the stacks (tb_variant_stash_entries)."""
+    return int(lib().tb_variant_stash_entries(name.encode()))
 
 
 def PlanLaunch(**kw):

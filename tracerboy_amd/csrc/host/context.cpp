@@ -15,14 +15,14 @@ namespace tbctx {
 std::string g_createError;
 #ifndef __HIP_DEVICE_COMPILE__ /* host data: the file goes through hipcc's device pass too, which has no use for a table of host functions */
 const Variant kVariants[] = {
-    {0u, pt_launch_persistent_matte, "matte", pt_launch_persistent_matte5, TB_MATTE_WAVES, 0, wf_launch_matte, true, pt_launch_split_matte},
-        {PT_FEAT_ENV, pt_launch_persistent_env, "env", pt_launch_persistent_env5, TB_ENV_WAVES, 1, wf_launch_env, true, pt_launch_split_env},
-    {PT_FEAT_ENV | PT_FEAT_SPECULAR | PT_FEAT_TEXTURES, pt_launch_persistent_surf, "surf", nullptr, 0, 2, wf_launch_surf, true, pt_launch_split_surf},
+    {0u, pt_launch_persistent_matte, "matte", pt_launch_persistent_matte5, TB_MATTE_WAVES, 0, wf_launch_matte, true, pt_launch_split_matte, 0u},
+        {PT_FEAT_ENV, pt_launch_persistent_env, "env", pt_launch_persistent_env5, TB_ENV_WAVES, 1, wf_launch_env, true, pt_launch_split_env, TB_ENV_STASH},
+    {PT_FEAT_ENV | PT_FEAT_SPECULAR | PT_FEAT_TEXTURES, pt_launch_persistent_surf, "surf", nullptr, 0, 2, wf_launch_surf, true, pt_launch_split_surf, 0u},
         {PT_FEAT_ENV | PT_FEAT_SPECULAR | PT_FEAT_TEXTURES | PT_FEAT_SSS, pt_launch_persistent_sss, "sss", pt_launch_persistent_sss4, TB_SSS_WAVES, 5,
-            wf_launch_sss, false, pt_launch_split_sss},
+            wf_launch_sss, false, pt_launch_split_sss, 0u},
     {PT_FEAT_ENV | PT_FEAT_SPECULAR | PT_FEAT_TEXTURES | PT_FEAT_SSS | PT_FEAT_MIX, pt_launch_persistent_vol, "vol", pt_launch_persistent_vol4, TB_VOL_WAVES,
-        3, wf_launch_vol, false, nullptr},
-        {PT_FEAT_ALL, pt_launch_persistent_full, "full", nullptr, 0, 4, nullptr, false, nullptr},
+        3, wf_launch_vol, false, nullptr, 0u},
+        {PT_FEAT_ALL, pt_launch_persistent_full, "full", nullptr, 0, 4, nullptr, false, nullptr, 0u},
 };
 const int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));
 #endif
@@ -539,6 +539,12 @@ void tb_plan_defaults(tb_plan_input* in)
     memset(in, 0, sizeof *in);
     in->high_occupancy = 1; in->stack_overflow_max = 24; in->primary_prepass = 1; in->overlap_launches = 1; in->pooled_samples = 256ll << 20;
     in->split_trav = 4; in->guided_groups = 1;
+}
+int tb_variant_stash_entries(const char* name)
+{
+    if (!name) return -1;
+    for (int i = 0; i < tbctx::kNumVariants; i++) if (!strcmp(tbctx::kVariants[i].name, name)) return tbctx::kVariants[i].fnHi ? (int)tbctx::kVariants[i].stashHi : 0;
+    return -1;
 }
 int tb_variant_waves_hi(const char* name)
 {

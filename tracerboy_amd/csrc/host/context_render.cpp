@@ -272,6 +272,7 @@ void fillPlanInput(tb_context* c, const Variant* v, uint32_t W, uint32_t H, uint
     memset(&in, 0, sizeof in);
     /* surf: compiled into its only copy */
     in.variant_features = v->features; in.variant_waves_hi = v->fnHi ? v->wavesHi : 0u; in.variant_prepass_in_base = (!v->fnHi && v->id == 2) ? 1u : 0u;
+    in.variant_stash_entries = v->fnHi ? v->stashHi : 0u;
     in.variant_has_wavefront = v->wf ? 1u : 0u; in.variant_has_pooled = v->pooled ? 1u : 0u; in.variant_has_split = v->split ? 1u : 0u;
     in.scene_in_lds = c->sceneInLds ? 1u : 0u; in.lds_blob_bytes = c->ds.ldsBlobBytes; in.stack_depth = c->ds.stackDepth;
         in.two_level = c->ds.numInstances ? 1u : 0u;

@@ -46,7 +46,9 @@ inline void PlanLaunch(const tb_plan_input& in, tb_launch_plan& p)
      * Msamples/s at 4K), with 24 it runs in the tuned two-level walk (1 266; 1 544 with launches overlapping, more than the flattened scene's 1 395). */
     p.stack_lds_entries = in.stack_depth;
     if (in.variant_waves_hi && pipe == 0 && !in.count_rays && in.high_occupancy != 0) {
-        const uint64_t share = (160u * 1024u / in.variant_waves_hi) / 512u * 512u, fixed = (in.scene_in_lds ? in.lds_blob_bytes : 0u) + 128u;
+        /* (+ the copy's stash of a path's cold state behind the stacks: frame-group kernels, scenes fetched from memory, one level) */
+        const uint64_t stash = (p.groups && !in.scene_in_lds && !in.two_level) ? (uint64_t)in.variant_stash_entries * 1024u : 0u;
+        const uint64_t share = (160u * 1024u / in.variant_waves_hi) / 512u * 512u, fixed = (in.scene_in_lds ? in.lds_blob_bytes : 0u) + 128u + stash;
         const uint64_t ldsPerGroup = ((uint64_t)in.stack_depth * 1024u + fixed + 511u) / 512u * 512u; /* + static LDS, 512-B granules */
         const int64_t forcedCap = in.stack_lds_cap; /* tests: split the stack although it would fit */
         if (ldsPerGroup <= share && !(forcedCap > 0 && p.groups && (uint64_t)forcedCap < in.stack_depth)) { p.high_occupancy_copy = 1;

@@ -10,5 +10,15 @@
 #ifndef TB_ENV_WAVES
 #define TB_ENV_WAVES 6 /* experiments: -DTB_ENV_WAVES=n (scripts/ab_flags.sh); context.cpp reads the same macro */
 #endif
+/* A stash of TB_ENV_STASH LDS entries per lane behind the stacks (pt_persistent.inc PT_LDS_STASH): throughput, radiance and seed wait there across
+ * every walk instead of in scratch.  870 k scene 1080p x 128, same box, asynchronous steps: 4 830 -> 4 990 Msamples/s (+3.3 %) with 7 entries and 19
+ * of the stack's in LDS; 13 entries (the next ray across the feeler too) 4 978.  Only this feature set gains (round 5: sss -2 %, surf -3 %).
+ * context_internal.h carries the same macro: the plan takes the bytes off the stack's share of LDS. */
+#ifndef TB_ENV_STASH
+#define TB_ENV_STASH 7
+#endif
+#if TB_ENV_STASH > 0
+#define PT_LDS_STASH TB_ENV_STASH
+#endif
 #define PT_PERSISTENT_ATTR __attribute__((amdgpu_waves_per_eu(TB_ENV_WAVES))) /* keep in step with kVariants[].wavesHi, context.cpp */
 #include "pt_variant.inc"
