@@ -19,9 +19,9 @@ const Variant kVariants[] = {
         {PT_FEAT_ENV, pt_launch_persistent_env, "env", pt_launch_persistent_env5, TB_ENV_WAVES, 1, wf_launch_env, true, pt_launch_split_env, TB_ENV_STASH},
     {PT_FEAT_ENV | PT_FEAT_SPECULAR | PT_FEAT_TEXTURES, pt_launch_persistent_surf, "surf", nullptr, 0, 2, wf_launch_surf, true, pt_launch_split_surf, 0u},
         {PT_FEAT_ENV | PT_FEAT_SPECULAR | PT_FEAT_TEXTURES | PT_FEAT_SSS, pt_launch_persistent_sss, "sss", pt_launch_persistent_sss4, TB_SSS_WAVES, 5,
-            wf_launch_sss, false, pt_launch_split_sss, 0u},
+            wf_launch_sss, false, pt_launch_split_sss, TB_SSS_STASH},
     {PT_FEAT_ENV | PT_FEAT_SPECULAR | PT_FEAT_TEXTURES | PT_FEAT_SSS | PT_FEAT_MIX, pt_launch_persistent_vol, "vol", pt_launch_persistent_vol4, TB_VOL_WAVES,
-        3, wf_launch_vol, false, nullptr, 0u},
+        3, wf_launch_vol, false, nullptr, TB_VOL_STASH},
         {PT_FEAT_ALL, pt_launch_persistent_full, "full", nullptr, 0, 4, nullptr, false, nullptr, 0u},
 };
 const int kNumVariants = (int)(sizeof(kVariants) / sizeof(kVariants[0]));

@@ -101,6 +101,12 @@ extern std::string g_createError;
 #ifndef TB_ENV_STASH
 #define TB_ENV_STASH 7 /* pt_variant_env5.hip: LDS entries per lane its frame-group kernels keep behind the stacks for a path's cold state */
 #endif
+#ifndef TB_VOL_STASH
+#define TB_VOL_STASH 0
+#endif
+#ifndef TB_SSS_STASH
+#define TB_SSS_STASH 0
+#endif
 /* stashHi: LDS entries per lane the frame-group kernels of the fnHi copy keep behind the stacks (scenes fetched from memory, one level) */
 struct Variant { uint32_t features; pt_variant_fn fn; const char* name; pt_variant_fn fnHi; uint32_t wavesHi; int id; wf_variant_fn wf; bool pooled;
     pt_split_fn split; uint32_t stashHi; };

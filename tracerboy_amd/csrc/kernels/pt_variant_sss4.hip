@@ -18,4 +18,7 @@
 #else
 #define PT_PERSISTENT_ATTR __attribute__((amdgpu_waves_per_eu(TB_SSS_WAVES))) /* keep in step with kVariants[].wavesHi, context.cpp */
 #endif
+#if defined(TB_SSS_STASH) && TB_SSS_STASH > 0 /* experiments: an LDS stash of a path's cold state like the env copy's (pt_variant_env5.hip); context_internal.h reads the same macro */
+#define PT_LDS_STASH TB_SSS_STASH
+#endif
 #include "pt_variant.inc"
