@@ -99,8 +99,10 @@ SCALE_SPP, SCALE_SHORT_SPP = 32, 8
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    # defaults: a burst long enough to be mostly steady state (the first and the last launch of a burst have no partner in flight: 5 steps read
+    # 6 990-7 020 Msamples/s where 20 give 7 130; 0.4 s of GPU time either way)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=64)
@@ -119,7 +121,7 @@ def parse_args(argv=None):
     ap.add_argument("--legs", default=None)                 # comma list; default: every leg of this N
     # steps of a leg: 5, so that a burst is mostly steady state (the first and last launch of a burst have no partner in
     # flight; at 3 steps vw-van's leg read 1 817 Msamples/s where twenty steps give 1 950)
-    ap.add_argument("--leg-steps", type=int, default=5)
+    ap.add_argument("--leg-steps", type=int, default=8)
     ap.add_argument("--async-steps", action="store_true")   # N = 1: run the N > 1 step pipeline (async render + pack + consumer)
     ap.add_argument("--sync-steps", action="store_true")    # N = 1: wait for every render before enqueuing the next
     ap.add_argument("--cpu-baseline-seconds", type=float, default=10.0)
