@@ -62,7 +62,8 @@ def _deps_digest():
                 if f.endswith((".h", ".hpp", ".inc", ".cpp", ".hip")):
                     with open(os.path.join(dp, f), "rb") as fh:
                         h.update(f.encode()); h.update(fh.read())
-    h.update(" ".join(COMMON + DEVICE + [k + " ".join(v) for k, v in sorted(TU_SCHEDULER.items())]).encode())
+    # (not the include path: the checkout sits elsewhere on the GPU box, and a stamp that names it made every process there rebuild the library)
+    h.update(" ".join([f for f in COMMON + DEVICE if not f.startswith("-I")] + [k + " ".join(v) for k, v in sorted(TU_SCHEDULER.items())]).encode())
     return h.hexdigest()
 
 
