@@ -60,7 +60,7 @@ def test_frame_groups_from_two_frames_or_one_in_lds():
 def test_dragon_class_c3_plan():
     """BASELINE configs[2]: 870 k triangles, environment-lit, no lights: 6-wave copy, the 128 frames in one batch (2^28 sample slots hold 129 frames of 1080p), groups of 4, pre-pass at once."""
     p = plan(ENVV, HD, frames=128, stack_depth=26, max_bounces=6)
-    assert (p.groups, p.high_occupancy_copy, p.rule_copy, p.batch_frames, p.frame_group) == (1, 1, COPY_FITS, 128, 4)
+    assert (p.groups, p.high_occupancy_copy, p.rule_copy, p.batch_frames, p.frame_group) == (1, 1, COPY_FITS, 128, 16)   # (4 until round 6: the cap of scenes fetched from memory)
     assert (p.prepass, p.rule_prepass, p.overlap_launches) == (ON, PRE_ENV_LIT, 1)
     # the same tree built by the GPU (36 levels): the 6-wave copy's share of LDS holds 26 entries, the other 10 go to global memory
     p = plan(ENVV, HD, frames=128, stack_depth=36, max_bounces=6)
@@ -108,7 +108,9 @@ def test_4k_glass_scenes_c4_c5_plans():
 
 
 def test_group_size_rules():
-    assert plan(ENVV, HD, frames=16, stack_depth=26).frame_group == 4                # memory scenes: at most 4
+    assert plan(ENVV, HD, frames=16, stack_depth=26).frame_group == 4                # 16 x 8 160 regions / 24 576 items wanted
+    assert plan(ENVV, HD, frames=512, stack_depth=26).frame_group == 16              # memory scenes: at most 16 ...
+    assert plan(ENVV, HD, frames=512, stack_depth=26, sync_call=1).frame_group == 4  # ... for back-to-back calls; a call that waits keeps its launch's end short
     assert plan(ENVV, HD, frames=2, stack_depth=26).frame_group == 1                 # 16 320 items already
     assert plan(MATTE, HD, frames=16, scene_in_lds=1, lds_blob_bytes=17000, stack_depth=11).frame_group == 8    # 12 288 items wanted
     assert plan(MATTE, HD, frames=512, scene_in_lds=1, lds_blob_bytes=17000, stack_depth=11).frame_group == 64  # cap for scenes in LDS

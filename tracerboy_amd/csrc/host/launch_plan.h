@@ -107,13 +107,17 @@ inline void PlanLaunch(const tb_plan_input& in, tb_launch_plan& p)
     batch = (in.frames + (in.frames + batch - 1) / batch - 1) / ((in.frames + batch - 1) / batch);
     p.batch_frames = batch;
     /* Group size: about 24 576 work items per launch (half as many for a scene in LDS: cornell-box x 64 frames, G = 8 / 16 / 32 / 64:
-     * 6 940 / 7 091 / 7 145 / 7 117 Msamples/s), at most 4 frames a group for scenes fetched from memory (870 k scene x 128, G = 2 / 4 / 8 /
-     * 16 / 32: 4 440 / 4 513 / 4 495 / 4 401 / 4 167 with the pre-pass), 16 for the feature sets with interior walks (van- / bistro-class
-     * 4K x 32, G = 2 / 4 / 8 / 16: 1 646 / 1 692 / 1 721 / 1 727 and 1 323 / 1 363 / 1 407 / 1 430), 64 for scenes in LDS; a power of two
-     * (samples find their frame with shifts); at most 4 095 groups a region and 2^21 items a launch (slot logs, claim_work_item) */
+     * 6 940 / 7 091 / 7 145 / 7 117 Msamples/s), at most 16 frames a group for scenes fetched from memory -- a workgroup's lanes that straddle
+     * two image regions walk rays of different length together (docs/experiments/r6.md section 4), so fewer, longer groups win until too few
+     * items are left to balance: 870 k scene x 128 with round 6's kernels, G = 2 / 4 / 8 / 16 / 32 / 64: 4 853 / 4 979 / 5 054 / 5 110 /
+     * 5 048 / 4 793 (round 4's kernels peaked at 4: 4 440 / 4 513 / 4 495 / 4 401 / 4 167, and the cap stood at 4 until round 6); van- /
+     * bistro-class 4K x 32, G = 4 / 8 / 16 / 32: 1 985 / 2 019 / 2 025 / 2 033 and 1 606 / 1 660 / 1 673 / 1 676 -- 64 for scenes in LDS; a power
+     * of two (samples find their frame with shifts); at most 4 095 groups a region and 2^21 items a launch (slot logs, claim_work_item) */
     const uint64_t regions = std::max<uint64_t>(1, in.owned_regions);
     const uint32_t frames = std::min(batch, in.frames);
-    const uint64_t capG = in.scene_in_lds ? 64 : (sss ? 16 : 4), itemsWanted = in.scene_in_lds ? 12288 : 24576;
+    /* (a call that waits has nobody to fill its launch's ragged end, which grows with the groups: the 870 k scene's launch alone takes 55.4 ms in
+     * groups of 4 and 57.0 ms in groups of 16 -- it keeps round 4's cap of 4 unless the feature set has interior walks, whose sweep asked for 16) */
+    const uint64_t capG = in.scene_in_lds ? 64 : ((sss || !in.sync_call) ? 16 : 4), itemsWanted = in.scene_in_lds ? 12288 : 24576;
     const uint32_t autoG = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(frames, capG), std::max<uint64_t>(1,
         ((uint64_t)frames * regions + itemsWanted - 1) / itemsWanted));
     uint32_t G = in.frame_group > 0 ? (uint32_t)in.frame_group : autoG;
