@@ -1131,6 +1131,10 @@ def main():
             avg_ms, launch_frames, st = measure_kernel(tb, W, H, SPP, s, runs)
             launch_timing = ("HIP events around %d path-tracing launches run one at a time after the timed region "
                              "(the timed steps overlap)" % runs)
+            if tb.GetOption("last_plan_guided_groups"):
+                launch_timing += ("; a launch the caller waits for gets frame groups that shrink over its end (the GUIDED copy of the kernel, option "
+                                  "guided_groups): these launches and the committed counters are of that copy, the timed asynchronous steps run "
+                                  "the copy with equal groups")
         else:
             avg_ms = float(np.mean(kernel_ms))
             launch_frames = tb.GetOption("last_kernel_frames")
