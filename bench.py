@@ -509,6 +509,7 @@ def measure_kernel(tb, W, H, spp, s, runs):
         tb.Render(W, H, spp, s, 0.0)
         ms.append(tb.GetOption("last_kernel_us") / 1e3)
     frames = tb.GetOption("last_kernel_frames")
+    measure_kernel.guided = bool(tb.GetOption("last_plan_guided_groups"))   # did these launches get the shrinking end (calls that wait, scenes in LDS)?
     tb.SetOption("count_rays", 1)
     tb.Render(W, H, 1, s, 0.0)           # counters-on launch of the same kernels, 1 spp, outside every timed region
     st = tb.ReadbackStats().rays
@@ -1131,7 +1132,7 @@ def main():
             avg_ms, launch_frames, st = measure_kernel(tb, W, H, SPP, s, runs)
             launch_timing = ("HIP events around %d path-tracing launches run one at a time after the timed region "
                              "(the timed steps overlap)" % runs)
-            if tb.GetOption("last_plan_guided_groups"):
+            if getattr(measure_kernel, "guided", False):
                 launch_timing += ("; a launch the caller waits for gets frame groups that shrink over its end (the GUIDED copy of the kernel, option "
                                   "guided_groups): these launches and the committed counters are of that copy, the timed asynchronous steps run "
                                   "the copy with equal groups")
