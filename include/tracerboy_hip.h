@@ -220,7 +220,7 @@ int tb_unpack_gathered_host(uint32_t width, uint32_t height, uint32_t world, uin
  * Builder 1: "reinsertion_passes" (-1 = the library's choice), "reinsertion_share" (percent of the subtrees a pass tries, largest first),
  * "presplit" (percent of extra references from cutting the triangles with the largest, emptiest boxes before the build; 0 = off, the default:
  * measured to raise box tests).  Launch policy: "frame_group", "guided_groups" (0 never, 1 = calls that wait [default], 2 always: the frame
- * groups of a region shrink over the last groups of a launch), "primary_prepass", "overlap_launches", "high_occupancy", "stack_lds_cap",
+ * groups of a region shrink over the last groups of a launch), "primary_prepass", "overlap_launches", "costly_first", "high_occupancy", "stack_lds_cap",
  * "compact_hits", "camera_constants", "texture_use_hint", "node_layout", "node_order" -- each described where launch_plan.h / context_render.cpp use it.
  * An unknown name is an error. */
 int tb_set_option(tb_context* ctx, const char* name, int64_t value);
@@ -266,6 +266,9 @@ typedef struct tb_plan_input {
     /* frame groups that shrink towards the end of a launch (option guided_groups: 0 never, 1 = calls that wait for their result, 2 always) and
      * whether this call waits (tb_render, not tb_render_async) */
     int64_t guided_groups /* 1 */; uint32_t sync_call;
+    /* the regions where paths were long in the launches before are handed out first (option costly_first: 0 never, 1 = feature sets with interior walks, calls
+     * below 3 x 2^24 samples [default], 2 = those feature sets at any size) */
+    uint32_t costly_first /* 1 */;
 } tb_plan_input;
 typedef struct tb_launch_plan {
     int32_t pipeline;                 /* 0 lock-step, 1 streaming, 2 wavefront, 3 pooled, 4 split-role: what will run */
@@ -278,6 +281,7 @@ typedef struct tb_launch_plan {
     uint32_t batch_frames, frame_group; /* frame-group mode only */
     uint32_t rule_pipeline, rule_copy, rule_prepass; /* TB_PLAN_RULE_*: which branch decided */
     uint32_t guided_groups;           /* frame-group mode: the groups of a region halve in size towards the end of a launch (frame_group = the largest) */
+    uint32_t costly_first;            /* frame-group mode: the launch hands its regions out in the order of TbDeviceTargets::regionOrder (pt_scene.h) */
 } tb_launch_plan;
 void tb_plan_defaults(tb_plan_input* in);  /* zeroes, then the option defaults */
 /* waves per SIMD the higher-occupancy copy of a feature set ("matte", "env", "surf", "vol", "full", "sss") is compiled for -- what

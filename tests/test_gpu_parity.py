@@ -668,6 +668,60 @@ def test_guided_frame_groups_bit_exact(gpu_tb, settings, frames, group):
         gpu_tb.SetOption("frame_group", 0); gpu_tb.SetOption("guided_groups", 1)
 
 
+def _read_device_u32(ptr, n):
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    buf = np.zeros(n, np.uint32)
+    assert hip.hipMemcpy(ctypes.c_void_p(buf.ctypes.data), ctypes.c_void_p(ptr), ctypes.c_size_t(buf.nbytes), 2) == 0
+    return buf
+
+
+@pytest.mark.parametrize("world,rank", [(1, 0), (3, 1)])
+def test_costly_regions_first_is_a_permutation_and_changes_no_bit(gpu_tb, settings, world, rank):
+    """Costly regions first (pt_scene.h TbDeviceTargets::regionOrder, option costly_first): the kernels with interior walks count long walks per region
+    and the next launch hands those regions out first.  The table every launch reads must be a permutation of its regions whatever the counts are
+    (a region handed out twice or never is a wrong picture), counted regions in front; and the picture is the one-pixel-per-lane kernel's bits with
+    the table empty, filled, and filled under back-to-back asynchronous launches that count while the next table is built."""
+    gpu_tb.LoadProcedural(1, 20000, 5)               # glass blobs: feature set with interior walks, fetched from memory
+    W, H, F = 328, 200, 6                            # last region row half outside the frame
+    s = copy.copy(settings); s.MaxBounces = 6
+    gpu_tb.SetTileAssignment(rank, world, 64, 64)
+    try:
+        gpu_tb.SetOption("frame_group", -1); gpu_tb.InvalidateHistory(); gpu_tb.Render(W, H, F, s, 0.0); ref = gpu_tb.ReadAccumulation(jittered=True)
+        gpu_tb.SetOption("frame_group", 2)
+        for rnd in range(3):
+            if rnd == 2: gpu_tb.SetOption("costly_late_samples", 256 * 2 * 300)   # only the last 300 items of the usual list count as late
+            gpu_tb.InvalidateHistory(); gpu_tb.Render(W, H, F, s, 0.0)
+            assert gpu_tb.GetOption("last_plan_costly_first") == 1
+            got = gpu_tb.ReadAccumulation(jittered=True)
+            assert np.array_equal(bits(got[0]), bits(ref[0])) and np.array_equal(bits(got[1]), bits(ref[1])), rnd
+            regions, groups = ((W + 15) // 16) * ((H + 15) // 16), F // 2
+            head = _read_device_u32(gpu_tb.GetOption("debug_region_order_ptr"), 1)
+            cost = _read_device_u32(gpu_tb.GetOption("debug_region_cost_ptr"), 1 << 20)
+            if world == 1:
+                order = _read_device_u32(gpu_tb.GetOption("debug_region_order_ptr"), 1 + regions * groups)
+                usual = [(g << 20) | r for g in range(groups) for r in range(regions)]
+                assert sorted(order[1:].tolist()) == usual                              # every item once
+                moved = int(order[0])
+                assert (rnd == 0) == (moved == 0)                                       # the first launch found no counts; it left some
+                pos = {v: i for i, v in enumerate(usual)}
+                for part in (order[1:1 + moved], order[1 + moved:]):                    # both parts in their usual order
+                    assert np.all(np.diff(np.array([pos[int(v)] for v in part], np.int64)) > 0)
+                bx = (W + 15) // 16
+                c_of = lambda r: int(cost[(r // bx) << 10 | (r % bx)])
+                assert all(pos[int(v)] >= (len(usual) - 300 if rnd == 2 else 0) for v in order[1:1 + moved])
+                assert all(c_of(int(v) & 0xfffff) > 0 for v in order[1:1 + moved])      # (a count may have arrived after the table was built: no claim about the rest)
+            assert world > 1 or int(cost.sum()) > 0
+        for _ in range(4):
+            gpu_tb.InvalidateHistory(); gpu_tb.Render(W, H, F, s, 0.0, sync=False)
+        gpu_tb.Sync()
+        assert np.array_equal(bits(gpu_tb.ReadAccumulation()), bits(ref[0]))
+        gpu_tb.SetOption("costly_first", 0); gpu_tb.InvalidateHistory(); gpu_tb.Render(W, H, F, s, 0.0)
+        assert gpu_tb.GetOption("last_plan_costly_first") == 0 and np.array_equal(bits(gpu_tb.ReadAccumulation()), bits(ref[0]))
+    finally:
+        gpu_tb.SetOption("frame_group", 0); gpu_tb.SetOption("costly_first", 1); gpu_tb.SetOption("costly_late_samples", 1 << 40); gpu_tb.SetTileAssignment(0, 1, 64, 64)
+
+
 def test_frame_group_default_and_classic_agree(gpu_tb, settings):
     """A call of 8 or more frames takes the frame-group mode by itself (lanes draw (pixel, frame) pairs of their region from an
     LDS counter); frame_group = -1 keeps the one-pixel-per-lane kernel.  Both are the oracle's bits, on a frame whose last

@@ -216,3 +216,20 @@ def test_a_copys_stash_comes_off_the_stacks_share_of_lds():
     p = plan(ENVV, HD, frames=128, stack_depth=26, max_bounces=6); assert (p.rule_copy, p.stack_lds_entries) == (COPY_FITS, 26)        # a copy without a stash
     p = plan(env, HD, frames=1, stack_depth=26); assert p.groups == 0 and p.rule_copy == COPY_FITS                                     # one pixel per lane: no stash in that kernel
     p = plan(env, HD, frames=16, stack_depth=40, two_level=1); assert p.stack_lds_entries == full                                      # two-level walk: no stash either
+
+
+def test_costly_regions_first_is_for_small_calls_of_the_interior_walk_sets():
+    """Option costly_first (pt_scene.h TbDeviceTargets::regionOrder): 1 (default) = frame-group launches of the feature sets with interior walks on
+    scenes fetched from memory, calls below 3 x 2^24 samples of the context's own (a rank of 8 of a 4K frame at 8 and at 32 spp; not the whole 4K
+    frame x 8, whose launch is four times as long as its longest path and measured -0.4 ... -1.8 %); 2 = at any size; 0 = never."""
+    eighth = dict(UHD, owned_regions=240 * 135 // 8)
+    kw = dict(stack_depth=30, has_lights=1, interior_walk_triangle_share=0.2)
+    assert plan(SSSV, eighth, frames=8, **kw).costly_first == 1 and plan(SSSV, eighth, frames=32, **kw).costly_first == 1
+    assert plan(SSSV, eighth, frames=64, pooled_samples=1 << 30, **kw).costly_first == 0  # one launch of 66 M samples of its own
+    assert plan(SSSV, eighth, frames=64, **kw).costly_first == 1                          # ... which the default sample-buffer budget cuts into two of 32 frames
+    assert plan(SSSV, UHD, frames=8, **kw).costly_first == 0 and plan(SSSV, UHD, frames=8, costly_first=2, **kw).costly_first == 1
+    assert plan(SSSV, UHD, frames=4, **kw).costly_first == 1
+    assert plan(SSSV, eighth, frames=8, costly_first=0, **kw).costly_first == 0
+    assert plan(SSSV, eighth, frames=1, **kw).costly_first == 0                           # one frame: not a frame-group launch
+    assert plan(ENVV, eighth, frames=8, stack_depth=30).costly_first == 0                  # no interior walks: nothing is counted
+    assert plan(MATTE, HD, frames=64, scene_in_lds=1, lds_blob_bytes=17 * 1024, stack_depth=11, has_lights=1).costly_first == 0

@@ -170,14 +170,14 @@ class tb_plan_input(C.Structure):
                 ("count_rays", C.c_uint32), ("aov", C.c_uint32), ("realtime", C.c_uint32), ("selected_pixel", C.c_uint32),
                 ("pipeline", C.c_int64), ("frame_group", C.c_int64), ("high_occupancy", C.c_int64), ("stack_lds_cap", C.c_int64), ("stack_overflow_max", C.c_int64),
                 ("node_layout", C.c_int64), ("primary_prepass", C.c_int64), ("overlap_launches", C.c_int64), ("pooled_samples", C.c_int64),
-                ("split_trav", C.c_int64), ("split_shade", C.c_int64), ("split_stack_cap", C.c_int64), ("guided_groups", C.c_int64), ("sync_call", C.c_uint32)]
+                ("split_trav", C.c_int64), ("split_shade", C.c_int64), ("split_stack_cap", C.c_int64), ("guided_groups", C.c_int64), ("sync_call", C.c_uint32), ("costly_first", C.c_uint32)]
 
 
 class tb_launch_plan(C.Structure):
     _fields_ = [("pipeline", C.c_int32), ("groups", C.c_uint32), ("high_occupancy_copy", C.c_uint32), ("full_variant", C.c_uint32),
                 ("stack_lds_entries", C.c_uint32), ("stack_overflow_entries", C.c_uint32), ("compact_nodes", C.c_uint32), ("prepass", C.c_uint32),
                 ("overlap_launches", C.c_uint32), ("batch_frames", C.c_uint32), ("frame_group", C.c_uint32),
-                ("rule_pipeline", C.c_uint32), ("rule_copy", C.c_uint32), ("rule_prepass", C.c_uint32), ("guided_groups", C.c_uint32)]
+                ("rule_pipeline", C.c_uint32), ("rule_copy", C.c_uint32), ("rule_prepass", C.c_uint32), ("guided_groups", C.c_uint32), ("costly_first", C.c_uint32)]
 
 
 assert C.sizeof(TbPostConstants) == 36

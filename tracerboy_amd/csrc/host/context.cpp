@@ -537,7 +537,7 @@ void tb_plan_defaults(tb_plan_input* in)
 {
     if (!in) return;
     memset(in, 0, sizeof *in);
-    in->high_occupancy = 1; in->stack_overflow_max = 24; in->primary_prepass = 1; in->overlap_launches = 1; in->pooled_samples = 256ll << 20;
+    in->high_occupancy = 1; in->stack_overflow_max = 24; in->primary_prepass = 1; in->overlap_launches = 1; in->pooled_samples = 256ll << 20; in->costly_first = 1;
     in->split_trav = 4; in->guided_groups = 1;
 }
 int tb_variant_stash_entries(const char* name)
@@ -652,7 +652,7 @@ int tb_unpack_gathered_host(uint32_t W, uint32_t H, uint32_t world, uint32_t tw,
 int tb_set_option(tb_context* c, const char* name, int64_t v)
 {
     if (!c || !name) return TB_E_INVALID;
-    static const char* known[] = {"reinsertion_share", "reinsertion_passes", "presplit", "guided_groups", "compact_stamp_bits", "debug_profile_groups", "camera_constants", "texture_use_hint", "compact_hits", "first_bounce", "primary_prepass", "pipeline", "count_rays", "bvh_builder", "flatten_instances", "aov", "scene_in_lds", "lds_scene_budget",
+    static const char* known[] = {"costly_first", "costly_late_samples", "reinsertion_share", "reinsertion_passes", "presplit", "guided_groups", "compact_stamp_bits", "debug_profile_groups", "camera_constants", "texture_use_hint", "compact_hits", "first_bounce", "primary_prepass", "pipeline", "count_rays", "bvh_builder", "flatten_instances", "aov", "scene_in_lds", "lds_scene_budget",
         "force_full_variant", "wavefront_paths", "wavefront_grid", "wavefront_segment", "pooled_paths", "pooled_samples", "pooled_profile", "park_min",
         "alpha_test", "node_order", "node_order_top_levels", "frame_group", "overlap_launches", "high_occupancy", "stack_lds_cap", "stack_overflow_max",
         "flip_texture_uvs", "wavefront_sort", "banded_items", "node_layout", "wavefront_refill",
@@ -690,6 +690,9 @@ int64_t tb_get_option(tb_context* c, const char* name)
     if (!strcmp(name, "last_plan_rule_prepass")) return c->lastPlan.rule_prepass;
     if (!strcmp(name, "last_plan_frame_group")) return c->lastPlan.frame_group;
     if (!strcmp(name, "last_plan_guided_groups")) return c->lastPlan.guided_groups;
+    if (!strcmp(name, "last_plan_costly_first")) return c->lastPlan.costly_first;
+    if (!strcmp(name, "debug_region_order_ptr")) return (int64_t)(uintptr_t)c->regionOrder[c->lastFgPar].p;
+    if (!strcmp(name, "debug_region_cost_ptr")) return (int64_t)(uintptr_t)c->regionCost.p;
     if (!strcmp(name, "last_plan_stack_overflow")) return c->lastPlan.stack_overflow_entries;
     if (!strcmp(name, "last_split_waves")) return c->lastSplitWaves; /* traversal waves * 100 + shading waves per workgroup of the last pipeline-4 launch */
     /* the pipeline the last render actually ran (2 / 3 fall back to 0 for feature sets they lack) */

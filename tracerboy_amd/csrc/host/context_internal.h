@@ -134,6 +134,7 @@ struct tb_context {
     uint32_t launchEpoch = 0; /* TbDeviceTargets::launchEpoch of the last frame-group launch */
     DevBuf fgSlotLog[2]; /* frame-group mode: the workgroups' logs of bound slots (TbDeviceTargets::slotLog) */
     DevBuf fgHits[2];   /* primary-visibility pre-pass: 16-B or 32-B record of every sample's first hit (TbDeviceTargets::primaryHits) */
+    DevBuf regionCost, regionOrder[2]; uint64_t regionCostKey = ~0ull; /* costly regions first (TbDeviceTargets::regionCost / regionOrder): 2^20 counts; per side stream 1 + 2 x regions words */
     DevBuf stackOverflow; /* split traversal stack of the higher-occupancy kernel copies on deep trees (pt_scene.h) */
     std::vector<const void*> warmedLaunchers; /* frame-group kernels that have run once on both side streams (renderImpl) */
     uint32_t fgLaunch = 0; bool sideOrdered = false; /* sideOrdered: the side streams have been ordered after everything else on `stream` */

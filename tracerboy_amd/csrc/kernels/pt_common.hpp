@@ -42,7 +42,7 @@ __device__ __forceinline__ bool block_region(const TbTileMap& tiles, uint32_t W,
  * banded = 1: list q owns the q-th contiguous eighth of the regions, all frame groups of it, so that an XCD's L2 keeps seeing the
  * same part of the scene until its band is done and only then helps the others.  Returns group << 20 | region, or ~0 when
  * nothing is left.  Out of line: it runs once per few thousand samples and must not cost the path loop any registers. */
-__device__ __noinline__ uint32_t claim_work_item(uint32_t* counters, uint32_t regions, uint32_t numGroups, uint32_t banded)
+__device__ __noinline__ uint32_t claim_work_item(uint32_t* counters, uint32_t regions, uint32_t numGroups, uint32_t banded, const uint32_t* order = nullptr)
 {
     for (uint32_t t = 0; t < 8; t++) {
         /* system scope: list q is counted mostly by the workgroups of XCD q, but a workgroup whose own list is empty takes from the
@@ -55,7 +55,10 @@ __device__ __noinline__ uint32_t claim_work_item(uint32_t* counters, uint32_t re
             if (n && c < n * numGroups) { const uint32_t group = c / n; return group << 20 | (b0 + (c - group * n)); }
         } else {
             const uint32_t item = c * 8u + q;
-            if (item < regions * numGroups) { const uint32_t group = item / regions; return group << 20 | (item - group * regions); }
+            if (item < regions * numGroups) {
+                if (order) return order[1u + item]; /* TbDeviceTargets::regionOrder: the launch's items in the order the host had made for it */
+                const uint32_t group = item / regions; return group << 20 | (item - group * regions);
+            }
         }
     }
     return 0xffffffffu;
@@ -72,14 +75,14 @@ __device__ __noinline__ uint32_t claim_work_item(uint32_t* counters, uint32_t re
  * A slot's entry: tag << 40 | first frame of the group (relative, 15 bits) << 24 | log2(frames of the group) << 20 | region y << 10 | region x. */
 __device__ __noinline__ void fg_bind_next(uint32_t* groupConst, uint32_t* bindState, unsigned long long* slotTable, uint32_t* workCounter,
     unsigned long long* logRow,
-                                          uint32_t logCap, uint32_t banded, TbTileMap tiles, uint32_t W, uint32_t H)
+                                          uint32_t logCap, uint32_t banded, TbTileMap tiles, uint32_t W, uint32_t H, const uint32_t* order = nullptr)
 {
     atomicAdd(&bindState[0], 1u);
     if (!((volatile uint32_t*)groupConst)[3]) {
         const uint32_t regions = ((volatile uint32_t*)groupConst)[0], lg = ((volatile uint32_t*)groupConst)[1], numGroups = ((volatile uint32_t*)groupConst)[2];
         uint32_t item = 0xffffffffu;
         /* room in the log for every binder under way (the host sizes a row for 8x the workgroup's fair share; a full row retires the workgroup) */
-        if (((volatile uint32_t*)bindState)[1] + ((volatile uint32_t*)bindState)[0] <= logCap) item = claim_work_item(workCounter, regions, numGroups, banded);
+        if (((volatile uint32_t*)bindState)[1] + ((volatile uint32_t*)bindState)[0] <= logCap) item = claim_work_item(workCounter, regions, numGroups, banded, order);
         if (item == 0xffffffffu) ((volatile uint32_t*)groupConst)[3] = 1u;
         else {
             const uint32_t slot = atomicAdd(&bindState[1], 1u), group = item >> 20, region = item & 0xfffffu;

@@ -135,6 +135,47 @@ __global__ __launch_bounds__(256) void accumulate_samples_kernel(const TbFloat4*
 
 } // namespace
 
+/* TbDeviceTargets::regionOrder from TbDeviceTargets::regionCost (pt_scene.h): one workgroup of 1024.  order[0] = items moved to the front, order[1 ...] =
+ * a permutation of the launch's items (group << 20 | region, claim_work_item's usual list: group by group, regions ascending): first the items of
+ * COUNTED regions that the usual list holds at position lateFrom or later, then everything else, both parts in their usual order -- neighbours stay
+ * neighbours in the list (a first version sorted counted regions by count with atomics: what ran side by side was then scattered over the frame,
+ * and the whole-frame van-class step lost 1.2 % to the caches), and a launch much longer than its longest path keeps its usual order except for
+ * its end.  keys (regions words of scratch) holds the ONE reading of every count that all passes use: other launches keep counting while this
+ * runs, and an item read as moved in one pass and as not moved in the next would be handed out twice or never. */
+__global__ __launch_bounds__(1024) void region_order_kernel(const uint32_t* __restrict__ cost, TbTileMap tiles, uint32_t W, uint32_t H,
+    uint32_t regions, uint32_t numGroups, uint32_t lateFrom, uint32_t* __restrict__ order, uint32_t* __restrict__ keys)
+{
+    __shared__ uint32_t waveSum[16], base[2], moved;
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6, items = regions * numGroups;
+    if (t == 0) moved = 0;
+    for (uint32_t i = t; i < regions; i += 1024u) {
+        uint32_t bx, by; block_region(tiles, W, H, i, bx, by);
+        keys[i] = __hip_atomic_load(cost + ((by & 1023u) << 10 | (bx & 1023u)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1u : 0u;
+    }
+    __syncthreads(); /* (a workgroup's own global writes are visible to it after the barrier) */
+    uint32_t mine = 0;
+    for (uint32_t i = lateFrom + t; i < items; i += 1024u) mine += keys[i % regions];
+    if (mine) atomicAdd(&moved, mine);
+    __syncthreads();
+    if (t == 0) { order[0] = moved; base[1] = 0; base[0] = moved; }
+    __syncthreads();
+    for (uint32_t i0 = 0; i0 < items; i0 += 1024u) {
+        const uint32_t i = i0 + t, group = i < items ? i / regions : 0u, region = i - group * regions;
+        const bool in = i < items, front = in && i >= lateFrom && keys[region] != 0u;
+        const unsigned long long m = __ballot(front);
+        const uint32_t before = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) waveSum[wave] = (uint32_t)__popcll(m);
+        __syncthreads();
+        uint32_t frontBefore = before, total = 0;
+        for (uint32_t w = 0; w < 16u; w++) { const uint32_t v = waveSum[w]; if (w < wave) frontBefore += v; total += v; }
+        if (front) order[1u + base[1] + frontBefore] = group << 20 | region;
+        else if (in) order[1u + base[0] + (t - frontBefore)] = group << 20 | region;
+        __syncthreads();
+        if (t == 0) { base[1] += total; base[0] += 1024u - total; }
+        __syncthreads();
+    }
+}
+
 extern "C" {
 
 hipError_t pt_launch_accumulate_samples(hipStream_t stream, const TbFloat4* samples, uint32_t W, uint32_t H, uint32_t firstFrame, uint32_t numFrames,
@@ -145,6 +186,13 @@ hipError_t pt_launch_accumulate_samples(hipStream_t stream, const TbFloat4* samp
     return hipGetLastError();
 }
 
+
+hipError_t pt_launch_region_order(hipStream_t stream, const uint32_t* cost, const TbTileMap* tiles, uint32_t W, uint32_t H, uint32_t regions,
+                                  uint32_t numGroups, uint32_t lateFrom, uint32_t* order, uint32_t* keys)
+{
+    hipLaunchKernelGGL(region_order_kernel, dim3(1), dim3(1024), 0, stream, cost, *tiles, W, H, regions, numGroups, lateFrom, order, keys);
+    return hipGetLastError();
+}
 
 hipError_t pt_launch_trace_closest(hipStream_t stream, const TbDeviceScene* ds, uint32_t n, const float* origins, const float* dirs, float* outT, int* outMat,
                                    float* outBary, uint32_t* outPrim, uint32_t* outGeom, float* outNormal, float* outUV, uint32_t* outBoxes, uint32_t* outTris)

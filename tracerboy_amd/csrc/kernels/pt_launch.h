@@ -10,6 +10,10 @@ hipError_t pt_launch_persistent(hipStream_t stream, const TbDeviceScene* ds, con
                                 uint32_t firstFrame, uint32_t numFrames, const TbTileMap* tiles, int sceneInLds, int countRays);
 hipError_t pt_launch_trace_closest(hipStream_t stream, const TbDeviceScene* ds, uint32_t n, const float* origins, const float* dirs, float* outT, int* outMat,
                                    float* outBary, uint32_t* outPrim, uint32_t* outGeom, float* outNormal, float* outUV, uint32_t* outBoxes, uint32_t* outTris);
+/* TbDeviceTargets::regionOrder (1 + regions x numGroups words) from TbDeviceTargets::regionCost; keys: regions words of scratch; lateFrom: the first
+ * position of the usual list from which a counted region's items move to the front (pt_kernels.hip region_order_kernel) */
+hipError_t pt_launch_region_order(hipStream_t stream, const uint32_t* cost, const TbTileMap* tiles, uint32_t W, uint32_t H, uint32_t regions,
+                                  uint32_t numGroups, uint32_t lateFrom, uint32_t* order, uint32_t* keys);
 hipError_t pt_launch_accumulate_samples(hipStream_t stream, const TbFloat4* samples, uint32_t W, uint32_t H, uint32_t firstFrame, uint32_t numFrames,
     const TbTileMap* tiles,
                                         TbFloat4* output, TbFloat4* jittered);

@@ -62,6 +62,9 @@ struct TbDeviceScene {
 };
 
 /* Output surfaces of one dispatch (u0..u7, u10 of SharedRaytracing.h:13-23) */
+#ifndef TB_COSTLY_STEP
+#define TB_COSTLY_STEP 8 /* an interior walk counts for its region (TbDeviceTargets::regionCost) when it reaches this step */
+#endif
 struct TbDeviceTargets {
     TbFloat4* output;      /* u0 */
     TbFloat4* jittered;    /* u1 */
@@ -111,6 +114,15 @@ struct TbDeviceTargets {
      * division and square root on both sides, same bits): the pinhole, 1 / W, 1 / H, W / H -- four divisions and a square root of ~250 instructions
      * that the lock-step kernel ran for the few lanes of a wave that had just finished a path.  camPre = 0: not filled, path_begin computes them. */
     float camFocal[3], camInvResX, camInvResY, camAspect; uint32_t camPre;
+    /* Costly regions first (frame-group mode of the feature sets with interior walks, nullable).  A launch ends when its longest path does, and a
+     * path that walks a hundred steps inside glass takes milliseconds alone on its wave: started with the last items of the list it is most of a
+     * small launch's time (docs/experiments/r6.md: a rank of 8's 8-spp launch of vw-van is dry after 3.2 ms and ends after 10.1).  Paths are long
+     * where they were long a frame ago, so the kernels count, per 16x16 region of the FRAME, the interior walks that reach step TB_COSTLY_STEP
+     * (regionCost[ry << 10 | rx]: 2^20 words, a region's coordinates have 10 bits each; cleared with the scene), and region_order_kernel
+     * (pt_kernels.hip) turns the counts into the order in which the NEXT launch hands its items out: regionOrder[1 + i] = group << 20 | region
+     * of the i-th claim, a permutation of the usual list in which the items of counted regions that would come late are first.  Any permutation
+     * gives the same picture (a sample depends on pixel and frame alone); only the end of the launch moves. */
+    uint32_t* regionCost; const uint32_t* regionOrder;
 };
 
 /* Split-role kernel (pipeline 4, pt_split.inc): a workgroup is `travWaves` traversal waves followed by `shadeWaves` shading waves.
