@@ -220,7 +220,7 @@ int tb_unpack_gathered_host(uint32_t width, uint32_t height, uint32_t world, uin
  * Builder 1: "reinsertion_passes" (-1 = the library's choice), "reinsertion_share" (percent of the subtrees a pass tries, largest first),
  * "presplit" (percent of extra references from cutting the triangles with the largest, emptiest boxes before the build; 0 = off, the default:
  * measured to raise box tests).  Launch policy: "frame_group", "guided_groups" (0 never, 1 = calls that wait [default], 2 always: the frame
- * groups of a region shrink over the last groups of a launch), "primary_prepass", "overlap_launches", "costly_first", "high_occupancy", "stack_lds_cap",
+ * groups of a region shrink over the last groups of a launch), "primary_prepass", "overlap_launches", "costly_first" (+ "costly_late_samples"), "high_occupancy", "stack_lds_cap",
  * "compact_hits", "camera_constants", "texture_use_hint", "node_layout", "node_order" -- each described where launch_plan.h / context_render.cpp use it.
  * An unknown name is an error. */
 int tb_set_option(tb_context* ctx, const char* name, int64_t value);

@@ -31,6 +31,7 @@ ap.add_argument("--legs", default="vwvan,c4,c5")
 ap.add_argument("--worlds", default="1,2,4,8")
 ap.add_argument("--spp", type=int, default=None)   # samples per pixel of a step (default: the workload's own, 8 for the 4K legs)
 ap.add_argument("--imbalance-threshold", type=float, default=1.05)
+ap.add_argument("--opt", action="append", default=[])   # library options for an A/B, e.g. --opt costly_first=0
 ap.add_argument("--tiles", default="")   # e.g. "32,16": sweep these tile sizes too, whatever the imbalance (the largest world only)
 args = ap.parse_args()
 worlds = [int(x) for x in args.worlds.split(",")]
@@ -99,6 +100,7 @@ for key in args.legs.split(","):
     t0 = time.time()
     b.load_workload(key)
     tb.SetOption("overlap_launches", 2)
+    for kv in args.opt: tb.SetOption(kv.split("=")[0], int(kv.split("=")[1]))
     print("%s: loaded in %.1f s" % (key, time.time() - t0), flush=True)
     tile = w.get("tile", bench.TILE)          # the deal bench.py's scale_<leg> uses for this workload
     rows = sweep(W, H, SPP, s, tile)

@@ -140,9 +140,9 @@ inline void PlanLaunch(const tb_plan_input& in, tb_launch_plan& p)
      * glass, each alone on its wave -- outlast a small launch's other work by milliseconds when they start with the last items of the list: a rank of
      * 8's 8-spp launch of vw-van is dry after 3.2 ms and ends after 10.1.  The kernels count the interior walks that reach their 8th step per region;
      * the next launch hands the counted regions out first.  Same box, option off -> on (scripts/costly_first_ab.sh, profiles/r6/costly_first*.jsonl),
-     * a rank of 8 on the 4K frames, 8 / 32 spp, asynchronous steps: vw-van 5.45 -> 4.92 / 14.02 -> 13.35 ms, van-class 5.49 -> 5.25 / 19.06 -> 18.13,
-     * bistro-class 6.94 -> 6.66 / 24.05 -> 21.96 (launches that wait: -5 ... -18 %); the whole 4K frame x 8 (66 M samples, a launch four times as
-     * long as its longest path) gains nothing from it and loses 0.4-1.8 % of its cache hits to the changed order: calls below 3 x 2^24 samples only. */
+     * a rank of 8 on the 4K frames, 8 / 32 spp, asynchronous steps: vw-van 5.46 -> 4.92 / 13.91 -> 13.37 ms, van-class 5.51 -> 5.32 / 19.38 -> 18.60,
+     * bistro-class 6.95 -> 6.68 / 24.41 -> 22.80 (launches that wait: -6 ... -17 %); the whole 4K frame x 8 (66 M samples, a launch four times as
+     * long as its longest path) gains nothing from it and loses 0.4-1.8 % to the changed order: calls below 3 x 2^24 samples only. */
     const uint64_t ownSamples = std::min<uint64_t>((uint64_t)in.width * in.height, regions * 256u) * frames;
     p.costly_first = in.costly_first != 0 && (in.variant_features & TB_PLAN_FEAT_SSS) != 0 && !in.scene_in_lds && (in.costly_first == 2 || ownSamples < (3ull << 24));
     p.guided_groups = 0;
