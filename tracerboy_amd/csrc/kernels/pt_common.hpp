@@ -56,7 +56,9 @@ __device__ __noinline__ uint32_t claim_work_item(uint32_t* counters, uint32_t re
         } else {
             const uint32_t item = c * 8u + q;
             if (item < regions * numGroups) {
-                if (order) return order[1u + item]; /* TbDeviceTargets::regionOrder: the launch's items in the order the host had made for it */
+                /* TbDeviceTargets::regionOrder: the launch's items in the order region_order_kernel made for it.  System scope like the slot log: the
+                 * table is rewritten before every launch, and an XCD's L2 may still hold a line of it as the launch before last read it */
+                if (order) return __hip_atomic_load(order + 1u + item, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 const uint32_t group = item / regions; return group << 20 | (item - group * regions);
             }
         }

@@ -168,8 +168,9 @@ __global__ __launch_bounds__(1024) void region_order_kernel(const uint32_t* __re
         __syncthreads();
         uint32_t frontBefore = before, total = 0;
         for (uint32_t w = 0; w < 16u; w++) { const uint32_t v = waveSum[w]; if (w < wave) frontBefore += v; total += v; }
-        if (front) order[1u + base[1] + frontBefore] = group << 20 | region;
-        else if (in) order[1u + base[0] + (t - frontBefore)] = group << 20 | region;
+        /* (system scope, as claim_work_item reads it) */
+        if (front) __hip_atomic_store(order + 1u + base[1] + frontBefore, group << 20 | region, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        else if (in) __hip_atomic_store(order + 1u + base[0] + (t - frontBefore), group << 20 | region, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __syncthreads();
         if (t == 0) { base[1] += total; base[0] += 1024u - total; }
         __syncthreads();
