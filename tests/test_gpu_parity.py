@@ -696,7 +696,6 @@ def test_costly_regions_first_is_a_permutation_and_changes_no_bit(gpu_tb, settin
             got = gpu_tb.ReadAccumulation(jittered=True)
             assert np.array_equal(bits(got[0]), bits(ref[0])) and np.array_equal(bits(got[1]), bits(ref[1])), rnd
             regions, groups = ((W + 15) // 16) * ((H + 15) // 16), F // 2
-            head = _read_device_u32(gpu_tb.GetOption("debug_region_order_ptr"), 1)
             cost = _read_device_u32(gpu_tb.GetOption("debug_region_cost_ptr"), 1 << 20)
             if world == 1:
                 order = _read_device_u32(gpu_tb.GetOption("debug_region_order_ptr"), 1 + regions * groups)
