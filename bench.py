@@ -978,6 +978,8 @@ def scale_leg(b, np, torch, dist, tiles, key, rank, world, backend, steps, barri
          "parallelism": "tiles%d" % world, "tile": tile, "bvh_builder": builder_label(w),
          "kernel_variant": VARIANTS[tb.GetOption("last_variant")], "primary_prepass": bool(tb.GetOption("last_primary_prepass")),
          "launches_overlap": bool(tb.GetOption("last_overlap")), "scene_load_s": round(load_max, 2),
+         # this rank's launches handed the regions with long interior walks out first (launch_plan.h costly_first: small calls of the glass feature sets)
+         "costly_regions_first": bool(tb.GetOption("last_plan_costly_first")),
          "scene_load_s_note": "max over ranks (every rank loads and builds the scene itself)"}
     r["scale_breakdown"] = ts.breakdown(SPP, s, barrier, reps=2)
     exp = expected_speedup_leg(key, world)
